@@ -1,0 +1,402 @@
+// amg_api.hip — C ABI plumbing of libamg.so: lifetime, inputs, read-back, timings.
+#include <cstdarg>
+
+#include "amg_device.h"
+
+thread_local std::string g_amg_err;
+
+int amg_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_amg_err = buf;
+  return code;
+}
+
+extern "C" const char* amg_last_error(void) { return g_amg_err.c_str(); }
+
+// ------------------------------------------------------------------ stage timing
+void stages_reset(amg_ctx* c) {
+  for (auto& s : c->stages) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  c->stages.clear();
+}
+
+void stage_begin(amg_ctx* c, const char* name) {
+  if (!c->timing) return;
+  StageTime s{name, nullptr, nullptr, 0.f};
+  (void)hipEventCreate(&s.a);
+  (void)hipEventCreate(&s.b);
+  (void)hipEventRecord(s.a, c->stream);
+  c->stages.push_back(s);
+}
+
+void stage_end(amg_ctx* c) {
+  if (!c->timing || c->stages.empty()) return;
+  (void)hipEventRecord(c->stages.back().b, c->stream);
+}
+
+extern "C" int amg_last_timings(amg_ctx* c, const char** names, float* ms, int cap) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  (void)hipStreamSynchronize(c->stream);
+  int n = 0;
+  for (auto& s : c->stages) {
+    if (n >= cap) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) t = -1.f;
+    s.ms = t;
+    names[n] = s.name;
+    ms[n] = t;
+    ++n;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------ lifetime
+extern "C" int amg_create(int device, amg_ctx** out) {
+  if (!out) return amg_fail(AMG_E_ARG, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return amg_fail(AMG_E_HIP, "no HIP device available (%s): libamg has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return amg_fail(AMG_E_ARG, "device %d out of range [0,%d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  amg_ctx* c = new amg_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return amg_fail(AMG_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  int r = c->status.ensure(ST_WORDS * sizeof(unsigned long long));
+  if (r != AMG_OK) {
+    delete c;
+    return r;
+  }
+  const char* t = getenv("AMG_TIMING");
+  c->timing = !(t && t[0] == '0');
+  *out = c;
+  return AMG_OK;
+}
+
+extern "C" int amg_destroy(amg_ctx* c) {
+  if (!c) return AMG_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  stages_reset(c);
+  DevBuf* all[] = {&c->tokens,    &c->read_off,  &c->gene_start, &c->gene_end,  &c->read_len,
+                   &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir,
+                   &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,
+                   &c->edge_src,  &c->edge_tgt,  &c->edge_sdir,  &c->edge_tdir, &c->edge_cov,
+                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix,  &c->c_tokens_buf,
+                   &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
+                   &c->c_read_len, &c->status,   &c->sort_tmp,   &c->s0, &c->s1, &c->s2, &c->s3,
+                   &c->s4, &c->s5};
+  for (DevBuf* b : all) b->release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return AMG_OK;
+}
+
+extern "C" int amg_sync(amg_ctx* c) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" void* amg_stream(amg_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ------------------------------------------------------------------ inputs
+static int copy_in(amg_ctx* c, DevBuf& dst, const void* src, size_t bytes, int on_device) {
+  AMGCHK(dst.ensure(bytes + 64));
+  if (bytes)
+    HIPCHK(hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* read_offsets,
+                             int64_t n_reads, int32_t two_v, int on_device) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (n_reads < 0 || !read_offsets) return amg_fail(AMG_E_ARG, "bad read_offsets / n_reads");
+  if (two_v <= 0 || (two_v & 1)) return amg_fail(AMG_E_ARG, "two_v must be a positive even number");
+  HIPCHK(hipSetDevice(c->device));
+  int64_t n_tokens = 0;
+  if (on_device) {
+    HIPCHK(hipMemcpy(&n_tokens, read_offsets + n_reads, sizeof(int64_t), hipMemcpyDeviceToHost));
+  } else {
+    if (read_offsets[0] != 0) return amg_fail(AMG_E_ARG, "read_offsets[0] must be 0");
+    for (int64_t r = 0; r < n_reads; ++r)
+      if (read_offsets[r + 1] < read_offsets[r])
+        return amg_fail(AMG_E_ARG, "read_offsets not monotone at read %lld", (long long)r);
+    n_tokens = read_offsets[n_reads];
+  }
+  if (n_tokens > 0 && !tokens) return amg_fail(AMG_E_ARG, "null tokens");
+  AMGCHK(copy_in(c, c->tokens, tokens, (size_t)n_tokens * sizeof(int32_t), on_device));
+  AMGCHK(copy_in(c, c->read_off, read_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), on_device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->n_reads = n_reads;
+  c->n_tokens = n_tokens;
+  c->two_v = two_v;
+  c->have_pos = c->have_read_len = false;
+  c->built = false;
+  c->have_corrected = false;
+  c->node_hint = 0;
+  return AMG_OK;
+}
+
+extern "C" int amg_set_positions(amg_ctx* c, const int64_t* gene_start, const int64_t* gene_end,
+                                 const int64_t* read_len, int on_device) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  if (!gene_start || !gene_end) return amg_fail(AMG_E_ARG, "null positions");
+  HIPCHK(hipSetDevice(c->device));
+  AMGCHK(copy_in(c, c->gene_start, gene_start, (size_t)c->n_tokens * sizeof(int64_t), on_device));
+  AMGCHK(copy_in(c, c->gene_end, gene_end, (size_t)c->n_tokens * sizeof(int64_t), on_device));
+  c->have_pos = true;
+  c->have_read_len = false;
+  if (read_len) {
+    AMGCHK(copy_in(c, c->read_len, read_len, (size_t)c->n_reads * sizeof(int64_t), on_device));
+    c->have_read_len = true;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+// ------------------------------------------------------------------ counts + read-back
+__global__ void k_count_flags(const unsigned char* __restrict__ f, long long n,
+                              unsigned long long* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = (i < n && f[i]) ? 1ull : 0ull;
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+static int count_flags(amg_ctx* c, const DevBuf& buf, long long n, int64_t* out) {
+  *out = 0;
+  if (n <= 0) return AMG_OK;
+  unsigned long long* ctr = c->status.as<unsigned long long>() + ST_MISC;
+  HIPCHK(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     buf.as<unsigned char>(), n, ctr);
+  unsigned long long h = 0;
+  HIPCHK(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = (int64_t)h;
+  return AMG_OK;
+}
+
+extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
+  if (!c || !o) return amg_fail(AMG_E_ARG, "null argument");
+  memset(o, 0, sizeof(*o));
+  o->n_reads = c->n_reads;
+  o->n_tokens = c->n_tokens;
+  o->two_v = c->two_v;
+  if (!c->built) return AMG_OK;
+  HIPCHK(hipSetDevice(c->device));
+  o->k = c->k;
+  o->n_windows = c->n_windows;
+  o->n_short_reads = c->n_short;
+  o->n_nodes = c->n_nodes;
+  o->n_edges = c->n_edges;
+  o->n_pairs = c->n_pairs;
+  o->n_components = c->n_components;
+  o->node_table_slots = c->node_slots;
+  o->edge_table_slots = c->edge_slots;
+  o->build_retries = c->retries;
+  AMGCHK(count_flags(c, c->node_alive, c->n_nodes, &o->n_live_nodes));
+  AMGCHK(count_flags(c, c->edge_alive, c->n_edges, &o->n_live_edges));
+  AMGCHK(count_flags(c, c->read_fix, c->n_reads, &o->n_reads_to_correct));
+  return AMG_OK;
+}
+
+#define NEED_BUILT(c)                                                     \
+  do {                                                                    \
+    if (!(c)) return amg_fail(AMG_E_ARG, "null ctx");                     \
+    if (!(c)->built) return amg_fail(AMG_E_STATE, "amg_build first");     \
+    HIPCHK(hipSetDevice((c)->device));                                    \
+  } while (0)
+
+static int d2h(amg_ctx* c, void* dst, const DevBuf& src, size_t bytes) {
+  if (!dst || bytes == 0) return AMG_OK;
+  HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  return AMG_OK;
+}
+
+__global__ void k_first_split(const long long* __restrict__ first, long long n,
+                              long long* __restrict__ tok, signed char* __restrict__ dir) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long long f = first[i];
+  tok[i] = f >> 1;
+  dir[i] = (f & 1) ? -1 : 1;
+}
+
+extern "C" int amg_get_nodes(amg_ctx* c, int32_t* canon_tokens, uint32_t* coverage,
+                             int64_t* first_token, int8_t* first_dir, int32_t* component,
+                             uint8_t* alive) {
+  NEED_BUILT(c);
+  const size_t D = (size_t)c->n_nodes;
+  AMGCHK(d2h(c, canon_tokens, c->node_tokens, D * c->k * sizeof(int32_t)));
+  AMGCHK(d2h(c, coverage, c->node_cov, D * sizeof(uint32_t)));
+  AMGCHK(d2h(c, component, c->node_comp, D * sizeof(int32_t)));
+  AMGCHK(d2h(c, alive, c->node_alive, D));
+  if ((first_token || first_dir) && D) {
+    AMGCHK(c->s1.ensure(D * sizeof(long long)));
+    AMGCHK(c->s2.ensure(D));
+    hipLaunchKernelGGL(k_first_split, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream,
+                       c->node_first.as<long long>(), (long long)D, c->s1.as<long long>(),
+                       c->s2.as<signed char>());
+    AMGCHK(d2h(c, first_token, c->s1, D * sizeof(int64_t)));
+    AMGCHK(d2h(c, first_dir, c->s2, D));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_get_edges(amg_ctx* c, int32_t* src, int32_t* tgt, int8_t* sdir, int8_t* tdir,
+                             uint32_t* coverage, uint8_t* alive) {
+  NEED_BUILT(c);
+  const size_t E = (size_t)c->n_edges;
+  AMGCHK(d2h(c, src, c->edge_src, E * sizeof(int32_t)));
+  AMGCHK(d2h(c, tgt, c->edge_tgt, E * sizeof(int32_t)));
+  AMGCHK(d2h(c, sdir, c->edge_sdir, E));
+  AMGCHK(d2h(c, tdir, c->edge_tdir, E));
+  AMGCHK(d2h(c, coverage, c->edge_cov, E * sizeof(uint32_t)));
+  AMGCHK(d2h(c, alive, c->edge_alive, E));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_get_read_nodes(amg_ctx* c, int32_t* tok_node, int8_t* tok_dir) {
+  NEED_BUILT(c);
+  AMGCHK(d2h(c, tok_node, c->tok_node, (size_t)c->n_tokens * sizeof(int32_t)));
+  AMGCHK(d2h(c, tok_dir, c->tok_dir, (size_t)c->n_tokens));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_get_node_adj(amg_ctx* c, int64_t* offsets, int32_t* edge_ids) {
+  NEED_BUILT(c);
+  AMGCHK(d2h(c, offsets, c->adj_off, (size_t)(2 * c->n_nodes + 1) * sizeof(int64_t)));
+  AMGCHK(d2h(c, edge_ids, c->adj_edge, (size_t)c->n_edges * sizeof(int32_t)));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_get_reads_to_correct(amg_ctx* c, uint8_t* flags) {
+  NEED_BUILT(c);
+  AMGCHK(d2h(c, flags, c->read_fix, (size_t)c->n_reads));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+// ------------------------------------------------------------------ Node.listOfReads
+// (node, read) for every live window; windows are visited in (read, position) order, so a
+// STABLE sort by node id leaves each node's reads in first-appearance order with repeats
+// adjacent (a read's windows are contiguous) — construct_node.py:64-67.
+__global__ void k_read_window_count(const int* __restrict__ tok_node,
+                                    const long long* __restrict__ read_off, long long n_reads,
+                                    unsigned int* __restrict__ cnt) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  unsigned int n = 0;
+  for (long long t = read_off[r]; t < read_off[r + 1]; ++t) n += tok_node[t] >= 0 ? 1u : 0u;
+  cnt[r] = n;
+}
+
+__global__ void k_read_window_emit(const int* __restrict__ tok_node,
+                                   const long long* __restrict__ read_off, long long n_reads,
+                                   const long long* __restrict__ base, unsigned int* __restrict__ keys,
+                                   unsigned int* __restrict__ vals) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  long long o = base[r];
+  for (long long t = read_off[r]; t < read_off[r + 1]; ++t) {
+    int n = tok_node[t];
+    if (n >= 0) {
+      keys[o] = (unsigned int)n;
+      vals[o] = (unsigned int)r;
+      ++o;
+    }
+  }
+}
+
+// after the stable sort: keep the first of each run of equal (node, read)
+__global__ void k_mark_first_of_run(const unsigned int* __restrict__ keys,
+                                    const unsigned int* __restrict__ vals, long long n,
+                                    unsigned int* __restrict__ keep,
+                                    unsigned int* __restrict__ per_node) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int kf = (i == 0 || keys[i] != keys[i - 1] || vals[i] != vals[i - 1]) ? 1u : 0u;
+  keep[i] = kf;
+  if (kf) atomicAdd(&per_node[keys[i]], 1u);
+}
+
+__global__ void k_scatter_kept(const unsigned int* __restrict__ vals, const unsigned int* __restrict__ keep,
+                               const long long* __restrict__ pos, long long n, int* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i]) out[pos[i]] = (int)vals[i];
+}
+
+extern "C" int amg_get_node_reads(amg_ctx* c, int64_t* offsets, int32_t* read_idx) {
+  NEED_BUILT(c);
+  if (!offsets) return amg_fail(AMG_E_ARG, "offsets must not be NULL");
+  hipStream_t st = c->stream;
+  const long long R = c->n_reads, D = c->n_nodes;
+  // live windows per read -> bases
+  AMGCHK(c->s0.ensure((size_t)(R + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(R + 2) * sizeof(long long)));
+  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)(R + 2) * sizeof(unsigned int), st));
+  if (R > 0)
+    hipLaunchKernelGGL(k_read_window_count, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                       c->tok_node.as<int>(), c->read_off.as<long long>(), R, c->s0.as<unsigned int>());
+  AMGCHK(prim_exscan_u32_to_i64(c, c->s0.as<unsigned int>(), c->s5.as<long long>(), (size_t)R + 1));
+  long long W = 0;
+  HIPCHK(hipMemcpyAsync(&W, c->s5.as<long long>() + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(c->s1.ensure((size_t)(W + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(W + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s3.ensure((size_t)(W + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(W + 2) * sizeof(unsigned int)));
+  if (R > 0)
+    hipLaunchKernelGGL(k_read_window_emit, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                       c->tok_node.as<int>(), c->read_off.as<long long>(), R, c->s5.as<long long>(),
+                       c->s1.as<unsigned int>(), c->s2.as<unsigned int>());
+  AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s3.as<unsigned int>(),
+                           c->s2.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)W,
+                           ilog2_ceil((uint64_t)D + 2) + 1));
+  // s3 = sorted node ids, s4 = reads; keep flags -> s1, per-node counts -> s0 (D + 1)
+  AMGCHK(c->s0.ensure((size_t)(D + 2) * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)(D + 2) * sizeof(unsigned int), st));
+  if (W > 0)
+    hipLaunchKernelGGL(k_mark_first_of_run, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st,
+                       c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), W,
+                       c->s1.as<unsigned int>(), c->s0.as<unsigned int>());
+  AMGCHK(c->s5.ensure((size_t)(D + 2) * sizeof(long long)));
+  AMGCHK(prim_exscan_u32_to_i64(c, c->s0.as<unsigned int>(), c->s5.as<long long>(), (size_t)D + 1));
+  AMGCHK(d2h(c, offsets, c->s5, (size_t)(D + 1) * sizeof(int64_t)));
+  HIPCHK(hipStreamSynchronize(st));
+  if (read_idx && W > 0) {
+    long long total = offsets[D];
+    // positions of kept entries = exclusive scan of keep flags
+    AMGCHK(c->s2.ensure((size_t)(W + 2) * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(c->s1.as<unsigned int>() + W, 0, sizeof(unsigned int), st));
+    AMGCHK(prim_exscan_u32_to_i64(c, c->s1.as<unsigned int>(), c->s2.as<long long>(), (size_t)W + 1));
+    AMGCHK(c->s0.ensure((size_t)(total + 2) * sizeof(int)));
+    hipLaunchKernelGGL(k_scatter_kept, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st,
+                       c->s4.as<unsigned int>(), c->s1.as<unsigned int>(), c->s2.as<long long>(), W,
+                       c->s0.as<int>());
+    AMGCHK(d2h(c, read_idx, c->s0, (size_t)total * sizeof(int32_t)));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return AMG_OK;
+}

@@ -1,0 +1,648 @@
+// amg_build.hip — GeneMerGraph.__init__ on the device (reference construct_graph.py:31-102).
+//
+// Launch sequence of amg_build (all on ctx->stream):
+//   k_read_stats      per-read window / short-read counts          (construct_graph.py:53-55)
+//   k_tile_reads      first read boundary of every token tile
+//   k_node_upsert     K1+K2: LDS-staged sliding windows, canonical orientation
+//                     (construct_gene_mer.py:4-56), fingerprint, open-address upsert:
+//                     count (+=1, construct_node.py:33-36) and first-seen (atomicMax of ~first)
+//   k_compact_slots   wave-ballot / prefix-sum compaction of occupied slots
+//   radix sort        by first-seen  -> node id = insertion order of _nodes (:188-190)
+//   k_assign_nodes    dense node arrays (canonical tokens, coverage, first direction)
+//   k_edges           K3/K4: slot -> node id per window (get_readNodes, :165-178), exact
+//                     verification of the fingerprint against the node's canonical tuple,
+//                     and upsert of one record per adjacency into the edge-class table
+//                     (create_edges / add_edge_to_edges, :246-277; Edge.__hash__ classes,
+//                     construct_edge.py:104-124)
+//   k_compact_slots + sort + k_pair_width + scan + k_emit_edges
+//                     directed edges in _edges insertion order, E1 then E2 (:279-285)
+//   k_adj_keys + stable radix sort + k_row_count + scan
+//                     forwardEdgeHashes / backwardEdgeHashes lists (:287-298)
+//   k_uf_*            connected components, ids in DFS discovery order (:911-927)
+#include "amg_device.h"
+
+#define TILE_ITEMS 4
+#define TILE_THREADS 256
+#define TILE (TILE_THREADS * TILE_ITEMS)
+
+// ------------------------------------------------------------------ small kernels
+__global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, int k,
+                             unsigned long long* status) {
+  __shared__ unsigned long long s_w[4], s_s[4];
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long w = 0, sh = 0;
+  if (r < n_reads) {
+    long long len = read_off[r + 1] - read_off[r];
+    if (len >= k)
+      w = (unsigned long long)(len - k + 1);
+    else
+      sh = 1;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    w += __shfl_down(w, d, 64);
+    sh += __shfl_down(sh, d, 64);
+  }
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_w[wave] = w;
+    s_s[wave] = sh;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tw = 0, ts = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+      tw += s_w[i];
+      ts += s_s[i];
+    }
+    if (tw) atomicAdd(&status[ST_N_WINDOWS], tw);
+    if (ts) atomicAdd(&status[ST_N_SHORT], ts);
+  }
+}
+
+// tile_lo[b] = first j in [1, n_reads] with read_off[j] > b * TILE  (n_reads + 1 if none)
+__global__ void k_tile_reads(const long long* __restrict__ read_off, long long n_reads,
+                             long long n_tiles_plus2, long long* __restrict__ tile_lo) {
+  long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_tiles_plus2) return;
+  long long target = b * (long long)TILE;
+  long long lo = 1, hi = n_reads + 1;  // search in [1, n_reads + 1)
+  while (lo < hi) {
+    long long mid = (lo + hi) >> 1;
+    if (read_off[mid] > target)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  tile_lo[b] = lo;
+}
+
+struct LdsView {
+  const int* p;
+  __device__ __forceinline__ int operator[](int j) const { return p[j]; }
+};
+
+// shared by k_node_upsert and k_edges: stage the tile's tokens and read-end flags in LDS
+__device__ __forceinline__ void stage_tile(const int* __restrict__ tokens,
+                                           const long long* __restrict__ read_off,
+                                           const long long* __restrict__ tile_lo,
+                                           long long n_reads, long long n_tokens, int k,
+                                           long long t0, int* s_tok, unsigned char* s_bnd) {
+  const int tid = threadIdx.x;
+  const int span = TILE + k;  // tokens t0 .. t0 + TILE + k - 1, flags 0 .. TILE + k
+  for (int i = tid; i < span; i += TILE_THREADS) {
+    long long t = t0 + i;
+    s_tok[i] = t < n_tokens ? tokens[t] : 0;
+    s_bnd[i] = 0;
+  }
+  if (tid == 0) s_bnd[span] = 0;
+  __syncthreads();
+  // read ends (exclusive) that fall in (t0, t0 + TILE + k]
+  long long b = blockIdx.x;
+  long long lo = tile_lo[b], hi = tile_lo[b + 2];
+  for (long long j = lo + tid; j < hi; j += TILE_THREADS) {
+    long long off = read_off[j] - t0;
+    if (off <= span) s_bnd[off] = 1;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ K1 + K2
+__global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
+    const int* __restrict__ tokens, const long long* __restrict__ read_off,
+    const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k,
+    int two_v, unsigned long long seed, Slot* __restrict__ tab, unsigned long long mask,
+    unsigned int probe_limit, int* __restrict__ tok_slot, signed char* __restrict__ tok_dir,
+    unsigned long long* status) {
+  __shared__ int s_tok[TILE + AMG_MAX_K];
+  __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
+  const long long t0 = (long long)blockIdx.x * TILE;
+  stage_tile(tokens, read_off, tile_lo, n_reads, n_tokens, k, t0, s_tok, s_bnd);
+  const int flip = two_v - 1;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    int i = threadIdx.x + it * TILE_THREADS;
+    long long t = t0 + i;
+    if (t >= n_tokens) continue;
+    bool valid = (t + k <= n_tokens);
+    for (int j = 1; j < k; ++j) valid = valid && (s_bnd[i + j] == 0);
+    int out_slot = -1;
+    signed char out_dir = 0;
+    if (valid) {
+      LdsView w{s_tok + i};
+      int dir = canon_dir(w, k, flip);
+      if (dir == 0) {
+        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+      } else {
+        unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed);
+        unsigned long long first = ((unsigned long long)t << 1) | (dir < 0 ? 1ull : 0ull);
+        long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit);
+        if (slot < 0) {
+          status[ST_OVERFLOW] = 1;
+        } else {
+          out_slot = (int)((unsigned int)slot | (s_bnd[i + k] ? AMG_LAST_FLAG : 0u));
+          out_dir = (signed char)dir;
+        }
+      }
+    }
+    tok_slot[t] = out_slot;
+    tok_dir[t] = out_dir;
+  }
+}
+
+// ------------------------------------------------------------------ compaction
+// (first_seen, slot) of every occupied slot, any order; one atomicAdd per block.
+__global__ __launch_bounds__(256) void k_compact_slots(const Slot* __restrict__ tab,
+                                                       unsigned long long n_slots,
+                                                       unsigned long long* __restrict__ out_first,
+                                                       unsigned int* __restrict__ out_slot,
+                                                       unsigned long long* counter) {
+  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned long long s_base;
+  const int ITEMS = 8;
+  unsigned long long base = (unsigned long long)blockIdx.x * (256 * ITEMS);
+  unsigned long long firsts[ITEMS];
+  unsigned int have = 0, cnt = 0;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    unsigned long long s = base + it * 256 + threadIdx.x;
+    if (s < n_slots && tab[s].key != 0ull) {
+      firsts[it] = ~tab[s].first_inv;
+      have |= 1u << it;
+      ++cnt;
+    }
+  }
+  unsigned int total;
+  unsigned int off = block_exscan_256(cnt, &total, s_wave);
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  unsigned long long o = s_base + off;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (have & (1u << it)) {
+      out_first[o] = firsts[it];
+      out_slot[o] = (unsigned int)(base + it * 256 + threadIdx.x);
+      ++o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ node arrays
+__global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sorted,
+                               const unsigned int* __restrict__ slot_sorted, long long n_nodes,
+                               Slot* __restrict__ tab, const int* __restrict__ tokens, int k,
+                               int two_v, int* __restrict__ node_tokens,
+                               unsigned int* __restrict__ node_cov,
+                               long long* __restrict__ node_first,
+                               unsigned char* __restrict__ node_alive) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  unsigned long long first = first_sorted[i];
+  unsigned int slot = slot_sorted[i];
+  tab[slot].id = (int)i;
+  node_cov[i] = tab[slot].count;
+  node_first[i] = (long long)first;
+  node_alive[i] = 1;
+  long long t = (long long)(first >> 1);
+  int dir = (first & 1ull) ? -1 : 1;
+  const int flip = two_v - 1;
+  for (int j = 0; j < k; ++j)
+    node_tokens[i * k + j] = dir > 0 ? tokens[t + j] : flip - tokens[t + k - 1 - j];
+}
+
+// ------------------------------------------------------------------ K3 + K4
+__global__ __launch_bounds__(TILE_THREADS) void k_edges(
+    const int* __restrict__ tokens, long long n_tokens, int k, int two_v,
+    const Slot* __restrict__ node_tab, const int* __restrict__ node_tokens,
+    const int* __restrict__ tok_slot, const signed char* __restrict__ tok_dir,
+    int* __restrict__ tok_node, Slot* __restrict__ edge_tab, unsigned long long edge_mask,
+    unsigned int probe_limit, int verify, unsigned long long* status) {
+  __shared__ int s_id[TILE + 1];
+  __shared__ int s_raw[TILE + 1];
+  __shared__ signed char s_dir[TILE + 1];
+  const long long t0 = (long long)blockIdx.x * TILE;
+  const int flip = two_v - 1;
+  for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
+    long long t = t0 + i;
+    int raw = -1;
+    signed char d = 0;
+    if (t < n_tokens) {
+      raw = tok_slot[t];
+      d = tok_dir[t];
+    }
+    int id = -1;
+    if (raw != -1) {
+      id = node_tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
+      if (verify && i < TILE) {
+        // exact check: the window's canonical tuple must equal the node's tuple
+        const int* w = tokens + t;
+        const int* nt = node_tokens + (long long)id * k;
+        bool same = true;
+        for (int j = 0; j < k; ++j) {
+          int c = d > 0 ? w[j] : flip - w[k - 1 - j];
+          same = same && (c == nt[j]);
+        }
+        if (!same) status[ST_COLLISION] = 1;
+      }
+    }
+    s_id[i] = id;
+    s_raw[i] = raw;
+    s_dir[i] = d;
+    if (i < TILE && t < n_tokens) tok_node[t] = id;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    int i = threadIdx.x + it * TILE_THREADS;
+    int raw = s_raw[i];
+    if (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) continue;
+    // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
+    unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
+    int dA = s_dir[i], dB = s_dir[i + 1];
+    unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+    unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
+    unsigned long long key = (sign << 63) | ((unsigned long long)lo << 32) |
+                             (unsigned long long)(hi + 1u);
+    unsigned long long orient = (a == lo ? 1ull : 0ull) | (dA > 0 ? 2ull : 0ull) |
+                                (dB > 0 ? 4ull : 0ull);
+    unsigned long long first = ((unsigned long long)(t0 + i) << 3) | orient;
+    long long slot = table_upsert(edge_tab, edge_mask, key, mix64(key), first, probe_limit);
+    if (slot < 0) status[ST_OVERFLOW] = 2;
+  }
+}
+
+// ------------------------------------------------------------------ edge emission
+// width of pair i in directed edges: self-loop 1, otherwise 2
+__global__ void k_pair_width(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
+                             const Slot* __restrict__ edge_tab, unsigned int* __restrict__ width) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  unsigned long long key = edge_tab[slot_sorted[i]].key;
+  unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
+  unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
+  width[i] = lo == hi ? 1u : 2u;
+}
+
+__global__ void k_emit_edges(const unsigned long long* __restrict__ first_sorted,
+                             const unsigned int* __restrict__ slot_sorted, long long n_pairs,
+                             Slot* __restrict__ edge_tab, const long long* __restrict__ base,
+                             int* __restrict__ e_src, int* __restrict__ e_tgt,
+                             signed char* __restrict__ e_sdir, signed char* __restrict__ e_tdir,
+                             unsigned int* __restrict__ e_cov,
+                             unsigned char* __restrict__ e_alive) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  Slot* s = edge_tab + slot_sorted[i];
+  unsigned long long key = s->key, first = first_sorted[i];
+  int lo = (int)((key >> 32) & 0x7fffffffull);
+  int hi = (int)((key & 0xffffffffull) - 1ull);
+  int X = (first & 1ull) ? lo : hi, Y = (first & 1ull) ? hi : lo;
+  signed char dX = (first & 2ull) ? 1 : -1, dY = (first & 4ull) ? 1 : -1;
+  long long e = base[i];
+  s->id = (int)e;
+  unsigned int cnt = s->count;
+  if (lo == hi) {
+    // E1 and E2 fall in the same class: one edge, +2 per traversal
+    e_src[e] = X; e_tgt[e] = Y; e_sdir[e] = dX; e_tdir[e] = dY;
+    e_cov[e] = cnt * 2u; e_alive[e] = 1;
+  } else {
+    e_src[e] = X; e_tgt[e] = Y; e_sdir[e] = dX; e_tdir[e] = dY;
+    e_cov[e] = cnt; e_alive[e] = 1;
+    e_src[e + 1] = Y; e_tgt[e + 1] = X; e_sdir[e + 1] = (signed char)-dY;
+    e_tdir[e + 1] = (signed char)-dX; e_cov[e + 1] = cnt; e_alive[e + 1] = 1;
+  }
+}
+
+// adjacency rows: row = 2 * src + (sdir == +1 ? 0 : 1); edge ids ascending inside a row
+__global__ void k_adj_keys(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir,
+                           long long n_edges, unsigned int* __restrict__ keys,
+                           unsigned int* __restrict__ vals, unsigned int* __restrict__ row_count) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  unsigned int row = 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
+  keys[e] = row;
+  vals[e] = (unsigned int)e;
+  atomicAdd(&row_count[row], 1u);
+}
+
+// ------------------------------------------------------------------ components
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+  int p = ld_i32(parent + x);
+  while (p != x) {
+    int g = ld_i32(parent + p);
+    if (g != p) atomicMin(parent + x, g);  // path halving (monotone: only ever lowers)
+    x = p;
+    p = g;
+  }
+  return x;
+}
+
+__global__ void k_uf_init(int* parent, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) parent[i] = (int)i;
+}
+
+__global__ void k_uf_union(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
+                           const Slot* __restrict__ edge_tab, int* parent) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  unsigned long long key = edge_tab[slot_sorted[i]].key;
+  int a = (int)((key >> 32) & 0x7fffffffull);
+  int b = (int)((key & 0xffffffffull) - 1ull);
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) break;
+    if (a > b) { int t = a; a = b; b = t; }
+    int old = atomicCAS(parent + b, b, a);  // hook the larger root under the smaller
+    if (old == b) break;
+    b = old;
+  }
+}
+
+__global__ void k_uf_roots(int* parent, long long n, unsigned int* __restrict__ is_root) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = uf_find(parent, (int)i);
+  parent[i] = r;  // only thread i writes entry i with its final root; roots keep parent==self
+  is_root[i] = (r == (int)i) ? 1u : 0u;
+}
+
+// component id = 1 + rank of the component's smallest node id == DFS discovery order
+__global__ void k_uf_label(const int* __restrict__ root, const long long* __restrict__ root_rank,
+                           long long n, int* __restrict__ comp) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = root[i];
+  // root[] entries of non-roots may still point at an intermediate ancestor written by
+  // another thread's k_uf_roots; chase to the fixed point (roots satisfy root[r] == r)
+  while (root[r] != r) r = root[r];
+  comp[i] = (int)(root_rank[r] + 1);
+}
+
+// ------------------------------------------------------------------ host orchestration
+static inline unsigned int blocks_for(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned int)(b < 1 ? 1 : b);
+}
+
+static int read_status(amg_ctx* c, unsigned long long* host) {
+  HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+static uint64_t pow2_at_least(uint64_t x) {
+  uint64_t p = 1024;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// one attempt; returns AMG_OK, or AMG_E_OVERFLOW (1 = node table, 2 = edge table in
+// *which) / collision (*which = 3) for the caller to retry with other parameters
+static int build_once(amg_ctx* c, int k, int* which) {
+  *which = 0;
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, R = c->n_reads;
+  unsigned long long hs[ST_WORDS];
+  HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+
+  stage_begin(c, "read_stats");
+  long long n_tiles = (T + TILE - 1) / TILE;
+  AMGCHK(c->s0.ensure((size_t)(n_tiles + 2) * sizeof(long long)));
+  long long* tile_lo = c->s0.as<long long>();
+  if (R > 0)
+    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
+                       c->read_off.as<long long>(), R, k, c->status.as<unsigned long long>());
+  hipLaunchKernelGGL(k_tile_reads, dim3(blocks_for(n_tiles + 2, 256)), dim3(256), 0, st,
+                     c->read_off.as<long long>(), R, n_tiles + 2, tile_lo);
+  stage_end(c);
+
+  AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
+  AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
+  AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
+  AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot)));
+
+  stage_begin(c, "node_table_clear");
+  HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot), st));
+  stage_end(c);
+
+  const unsigned int probe_limit = 4096;
+  stage_begin(c, "node_upsert");
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_node_upsert, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st,
+                       c->tokens.as<int>(), c->read_off.as<long long>(), tile_lo, R, T, k,
+                       c->two_v, c->seed, c->node_tab.as<Slot>(),
+                       (unsigned long long)(c->node_slots - 1), probe_limit, c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->status.as<unsigned long long>());
+  stage_end(c);
+
+  // ---- rank nodes by first occurrence
+  stage_begin(c, "node_rank");
+  // worst case every slot is occupied; size scratch by min(slots, windows upper bound)
+  size_t max_nodes = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
+  AMGCHK(c->s1.ensure(max_nodes * sizeof(unsigned long long)));
+  AMGCHK(c->s2.ensure(max_nodes * sizeof(unsigned long long)));
+  AMGCHK(c->s3.ensure(max_nodes * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure(max_nodes * sizeof(unsigned int)));
+  hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->node_slots, 2048)), dim3(256), 0, st,
+                     c->node_tab.as<Slot>(), (unsigned long long)c->node_slots,
+                     c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
+                     c->status.as<unsigned long long>() + ST_COMPACT_A);
+  AMGCHK(read_status(c, hs));
+  if (hs[ST_PALINDROME])
+    return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
+  if (hs[ST_OVERFLOW]) {
+    *which = 1;
+    stage_end(c);
+    return AMG_E_OVERFLOW;
+  }
+  c->n_windows = (int64_t)hs[ST_N_WINDOWS];
+  c->n_short = (int64_t)hs[ST_N_SHORT];
+  c->n_nodes = (int64_t)hs[ST_COMPACT_A];
+  const long long D = c->n_nodes;
+  int first_bits = ilog2_ceil((uint64_t)(T > 0 ? T : 1) * 2 + 2) + 1;
+  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)D,
+                           first_bits));
+  AMGCHK(c->node_tokens.ensure((size_t)(D * k + 1) * sizeof(int)));
+  AMGCHK(c->node_cov.ensure((size_t)(D + 1) * sizeof(unsigned int)));
+  AMGCHK(c->node_first.ensure((size_t)(D + 1) * sizeof(long long)));
+  AMGCHK(c->node_comp.ensure((size_t)(D + 1) * sizeof(int)));
+  AMGCHK(c->node_alive.ensure((size_t)(D + 1)));
+  if (D > 0)
+    hipLaunchKernelGGL(k_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st,
+                       c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), D,
+                       c->node_tab.as<Slot>(), c->tokens.as<int>(), k, c->two_v,
+                       c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+  stage_end(c);
+
+  // ---- edges
+  if (c->edge_slots < (int64_t)pow2_at_least((uint64_t)D * 4)) c->edge_slots = pow2_at_least((uint64_t)D * 4);
+  AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
+  stage_begin(c, "edge_table_clear");
+  HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot), st));
+  stage_end(c);
+  stage_begin(c, "edge_upsert");
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_edges, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st,
+                       c->tokens.as<int>(), T, k, c->two_v, c->node_tab.as<Slot>(),
+                       c->node_tokens.as<int>(), c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->tok_node.as<int>(),
+                       c->edge_tab.as<Slot>(), (unsigned long long)(c->edge_slots - 1),
+                       probe_limit, 1, c->status.as<unsigned long long>());
+  stage_end(c);
+
+  stage_begin(c, "edge_rank");
+  size_t max_pairs = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+  AMGCHK(c->s1.ensure(max_pairs * sizeof(unsigned long long)));
+  AMGCHK(c->s2.ensure(max_pairs * sizeof(unsigned long long)));
+  AMGCHK(c->s3.ensure(max_pairs * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure(max_pairs * sizeof(unsigned int)));
+  hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->edge_slots, 2048)), dim3(256), 0, st,
+                     c->edge_tab.as<Slot>(), (unsigned long long)c->edge_slots,
+                     c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
+                     c->status.as<unsigned long long>() + ST_COMPACT_B);
+  AMGCHK(read_status(c, hs));
+  if (hs[ST_COLLISION]) {
+    *which = 3;
+    stage_end(c);
+    return AMG_E_OVERFLOW;
+  }
+  if (hs[ST_OVERFLOW]) {
+    *which = 2;
+    stage_end(c);
+    return AMG_E_OVERFLOW;
+  }
+  c->n_pairs = (int64_t)hs[ST_COMPACT_B];
+  const long long P = c->n_pairs;
+  int efirst_bits = ilog2_ceil((uint64_t)(T > 0 ? T : 1) * 8 + 8) + 1;
+  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)P,
+                           efirst_bits));
+  // widths -> bases (s3 reused for widths, s1 for bases: both free after the sort)
+  AMGCHK(c->s5.ensure((size_t)(P + 2) * sizeof(long long)));
+  unsigned int* width = c->s3.as<unsigned int>();
+  long long* base = c->s5.as<long long>();
+  if (P > 0) {
+    // one extra zero-width element so that base[P] = total
+    HIPCHK(hipMemsetAsync(width + P, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(k_pair_width, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                       c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(), width);
+    AMGCHK(prim_exscan_u32_to_i64(c, width, base, (size_t)P + 1));
+    long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, base + P, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->n_edges = total;
+  } else {
+    c->n_edges = 0;
+  }
+  const long long E = c->n_edges;
+  AMGCHK(c->edge_src.ensure((size_t)(E + 2) * sizeof(int)));
+  AMGCHK(c->edge_tgt.ensure((size_t)(E + 2) * sizeof(int)));
+  AMGCHK(c->edge_sdir.ensure((size_t)(E + 2)));
+  AMGCHK(c->edge_tdir.ensure((size_t)(E + 2)));
+  AMGCHK(c->edge_cov.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  AMGCHK(c->edge_alive.ensure((size_t)(E + 2)));
+  if (P > 0)
+    hipLaunchKernelGGL(k_emit_edges, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                       c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), P,
+                       c->edge_tab.as<Slot>(), base, c->edge_src.as<int>(), c->edge_tgt.as<int>(),
+                       c->edge_sdir.as<signed char>(), c->edge_tdir.as<signed char>(),
+                       c->edge_cov.as<unsigned int>(), c->edge_alive.as<unsigned char>());
+  stage_end(c);
+
+  // ---- components (uses the sorted pair list in s4 before it is recycled)
+  stage_begin(c, "components");
+  int* parent = c->node_comp.as<int>();  // holds roots until k_uf_label rewrites it
+  AMGCHK(c->s1.ensure((size_t)(D + 2) * sizeof(long long)));  // root ranks
+  AMGCHK(c->s2.ensure((size_t)(D + 2) * sizeof(unsigned int) + (size_t)(D + 2) * sizeof(int)));
+  unsigned int* is_root = c->s2.as<unsigned int>();
+  int* root_copy = reinterpret_cast<int*>(is_root + (D + 2));
+  if (D > 0) {
+    hipLaunchKernelGGL(k_uf_init, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D);
+    if (P > 0)
+      hipLaunchKernelGGL(k_uf_union, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                         c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(), parent);
+    hipLaunchKernelGGL(k_uf_roots, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D, is_root);
+    HIPCHK(hipMemsetAsync(is_root + D, 0, sizeof(unsigned int), st));
+    AMGCHK(prim_exscan_u32_to_i64(c, is_root, c->s1.as<long long>(), (size_t)D + 1));
+    HIPCHK(hipMemcpyAsync(root_copy, parent, (size_t)D * sizeof(int), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
+                       c->s1.as<long long>(), D, parent);
+    long long ncomp = 0;
+    HIPCHK(hipMemcpyAsync(&ncomp, c->s1.as<long long>() + D, sizeof(long long),
+                          hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->n_components = ncomp;
+  } else {
+    c->n_components = 0;
+  }
+  stage_end(c);
+
+  // ---- adjacency lists
+  stage_begin(c, "adjacency");
+  AMGCHK(c->adj_off.ensure((size_t)(2 * D + 2) * sizeof(long long)));
+  AMGCHK(c->adj_edge.ensure((size_t)(E + 2) * sizeof(int)));
+  AMGCHK(c->s1.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s3.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(2 * D + 2) * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->s4.p, 0, (size_t)(2 * D + 2) * sizeof(unsigned int), st));
+  if (E > 0) {
+    hipLaunchKernelGGL(k_adj_keys, dim3(blocks_for(E, 256)), dim3(256), 0, st,
+                       c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), E,
+                       c->s1.as<unsigned int>(), c->s2.as<unsigned int>(),
+                       c->s4.as<unsigned int>());
+    AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s3.as<unsigned int>(),
+                             c->s2.as<unsigned int>(),
+                             reinterpret_cast<unsigned int*>(c->adj_edge.p), (size_t)E,
+                             ilog2_ceil((uint64_t)2 * D + 2) + 1));
+  }
+  AMGCHK(prim_exscan_u32_to_i64(c, c->s4.as<unsigned int>(), c->adj_off.as<long long>(),
+                                (size_t)(2 * D + 1)));
+  stage_end(c);
+
+  AMGCHK(c->read_fix.ensure((size_t)R + 1));
+  HIPCHK(hipMemsetAsync(c->read_fix.p, 0, (size_t)R + 1, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
+extern "C" int amg_build(amg_ctx* c, int32_t k) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  HIPCHK(hipSetDevice(c->device));
+  stages_reset(c);
+  c->built = false;
+  c->have_corrected = false;
+  c->k = k;
+  c->retries = 0;
+  // table sizing: previous distinct-node count when known, otherwise the window bound
+  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 4 : (uint64_t)c->n_tokens * 2;
+  c->node_slots = (int64_t)pow2_at_least(want);
+  if (c->node_slots > (1ll << 30)) c->node_slots = 1ll << 30;
+  c->edge_slots = 1024;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    int which = 0;
+    int r = build_once(c, k, &which);
+    if (r == AMG_OK) {
+      c->built = true;
+      c->node_hint = c->n_nodes > 256 ? c->n_nodes : 256;
+      return AMG_OK;
+    }
+    if (r != AMG_E_OVERFLOW || which == 0) return r;
+    ++c->retries;
+    if (which == 1) {
+      if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
+      c->node_slots *= 4;
+    } else if (which == 2) {
+      c->edge_slots *= 4;
+    } else {
+      c->seed = c->seed * 6364136223846793005ull + 1442695040888963407ull;  // new fingerprint
+    }
+  }
+  return amg_fail(AMG_E_OVERFLOW, "build did not converge after 12 attempts");
+}

@@ -1,0 +1,112 @@
+// amg_device.h — device-side helpers shared by the build and pass kernels (gfx950).
+#pragma once
+#include "amg_internal.h"
+
+#define AMG_WAVE 64
+#define AMG_LAST_FLAG 0x80000000u
+
+// relaxed, agent-scope accessors: L1-bypassing loads, coherent with the device-scope
+// atomics that mutate the tables (MI355X_MICROARCH.md, "Inter-workgroup visibility").
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_i32(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return x;
+}
+
+// Canonical orientation of the window whose tokens are w[0..k-1] (any indexable view):
+// rc[j] = two_v - 1 - w[k-1-j]; canonical = lexicographic min(w, rc); returns +1 when the
+// window is the canonical one, -1 when its reverse complement is, 0 when they are equal
+// (palindrome: the reference asserts, construct_gene_mer.py:23-25).
+template <class View>
+__device__ __forceinline__ int canon_dir(const View& w, int k, int flip) {
+  for (int j = 0; j < k; ++j) {
+    int a = w[j];
+    int b = flip - w[k - 1 - j];
+    if (a != b) return a < b ? 1 : -1;
+  }
+  return 0;
+}
+
+// j-th token of the canonical tuple given the window view and its direction
+template <class View>
+__device__ __forceinline__ int canon_tok(const View& w, int k, int flip, int dir, int j) {
+  return dir > 0 ? w[j] : flip - w[k - 1 - j];
+}
+
+template <class View>
+__device__ __forceinline__ unsigned long long canon_fingerprint(const View& w, int k, int flip,
+                                                                int dir, unsigned long long seed) {
+  unsigned long long h = seed;
+  for (int j = 0; j < k; ++j) {
+    unsigned long long c = (unsigned long long)(unsigned int)canon_tok(w, k, flip, dir, j);
+    h = (h ^ c) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  h = mix64(h);
+  return h ? h : 1ull;
+}
+
+// Insert-or-find `key` (non-zero) in an open-addressing table of 32-byte slots with
+// linear probing; bump the slot's count and keep the minimum `first` value.
+// Entirely lock-free: the key is claimed by one 64-bit CAS, the counter by atomicAdd,
+// first-seen by atomicMax on the complement.  A stale (cached) read can only make us
+// take the slow path (CAS / atomicMax), never a wrong decision, because a slot's key
+// never changes once set and first_inv only grows.
+// Returns the slot index, or -1 if `limit` probes did not find a home.
+__device__ __forceinline__ long long table_upsert(Slot* tab, unsigned long long mask,
+                                                  unsigned long long key,
+                                                  unsigned long long start,
+                                                  unsigned long long first, unsigned int limit) {
+  unsigned long long idx = start & mask;
+  for (unsigned int probes = 0;; ++probes) {
+    Slot* s = tab + idx;
+    unsigned long long cur = ld_u64(&s->key);
+    if (cur == 0ull) {
+      cur = atomicCAS(&s->key, 0ull, key);
+      if (cur == 0ull) cur = key;
+    }
+    if (cur == key) {
+      atomicAdd(&s->count, 1u);
+      unsigned long long fi = ~first;
+      if (ld_u64(&s->first_inv) < fi) atomicMax(&s->first_inv, fi);
+      return (long long)idx;
+    }
+    if (probes >= limit) return -1;
+    idx = (idx + 1) & mask;
+  }
+}
+
+// block-wide exclusive prefix of a per-thread count (256 threads = 4 waves); returns the
+// thread's offset inside the block and the block total in *total.
+__device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigned int* total,
+                                                         unsigned int* s_wave /*[4]*/) {
+  unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned int y = __shfl_up(x, d, 64);
+    if (lane >= (unsigned)d) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  unsigned int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned int c = s_wave[w];
+    if ((unsigned)w < wave) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}

@@ -1,0 +1,178 @@
+// amg_internal.h — shared declarations of libamg.so (MI355X / gfx950 only).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/amg.h"
+
+// ------------------------------------------------------------------ error plumbing
+extern thread_local std::string g_amg_err;
+int amg_fail(int code, const char* fmt, ...);
+
+#define HIPCHK(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return amg_fail(AMG_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+                      hipGetErrorString(e_));                                          \
+  } while (0)
+#define AMGCHK(call)                 \
+  do {                               \
+    int r_ = (call);                 \
+    if (r_ != AMG_OK) return r_;     \
+  } while (0)
+
+// ------------------------------------------------------------------ device buffers
+// grow-only device allocation reused across builds (hipMalloc is ~ms for GB sizes)
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return AMG_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return amg_fail(AMG_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return AMG_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// ------------------------------------------------------------------ hash-table slot
+// One 32-byte slot = one 32-B sector: a probe touches exactly one sector.
+//   key      : 64-bit fingerprint of the canonical k-tuple (nodes) or the exact packed
+//              (lo, hi, sign) key (edges); 0 = empty.  Claimed by atomicCAS.
+//   first_inv: ~first_seen, maximised by atomicMax  (zero-initialised == "never seen").
+//              nodes: first_seen = (token index << 1) | (direction == -1)
+//              edges: first_seen = (token index << 3) | orientation bits
+//   count    : occurrences (atomicAdd)
+//   id       : dense id, written by the ranking kernel
+struct __attribute__((aligned(32))) Slot {
+  unsigned long long key;
+  unsigned long long first_inv;
+  unsigned int count;
+  int id;
+  unsigned long long pad;
+};
+static_assert(sizeof(Slot) == 32, "slot must be one 32-byte sector");
+
+// device-side status words (index into ctx->d_status)
+enum {
+  ST_NODE_INSERTS = 0,   // number of node slots claimed
+  ST_PAIR_INSERTS = 1,   // number of edge-class slots claimed
+  ST_OVERFLOW = 2,       // a probe sequence exceeded its limit
+  ST_PALINDROME = 3,     // window equal to its reverse complement
+  ST_COLLISION = 4,      // fingerprint collision found by the exact verify
+  ST_N_WINDOWS = 5,
+  ST_N_SHORT = 6,
+  ST_COMPACT_A = 7,      // scratch counters for compaction kernels
+  ST_COMPACT_B = 8,
+  ST_MISC = 9,
+  ST_WORDS = 16
+};
+
+struct StageTime {
+  const char* name;
+  hipEvent_t a, b;
+  float ms;
+};
+
+struct amg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  // ---- current read set (device)
+  DevBuf tokens;      // int32[n_tokens + pad]
+  DevBuf read_off;    // int64[n_reads + 1]
+  DevBuf gene_start;  // int64[n_tokens]   (optional)
+  DevBuf gene_end;    // int64[n_tokens]
+  DevBuf read_len;    // int64[n_reads]
+  bool have_pos = false, have_read_len = false;
+  int64_t n_reads = 0, n_tokens = 0;
+  int32_t two_v = 0;
+
+  // ---- build products
+  bool built = false;
+  int32_t k = 0;
+  uint64_t seed = 0x9E3779B97F4A7C15ull;
+  int64_t n_windows = 0, n_short = 0;
+  int64_t n_nodes = 0, n_pairs = 0, n_edges = 0, n_components = 0;
+  int64_t node_slots = 0, edge_slots = 0, retries = 0;
+  int64_t node_hint = 0;  // distinct-node estimate carried between builds
+
+  DevBuf node_tab;   // Slot[node_slots]
+  DevBuf edge_tab;   // Slot[edge_slots]
+  DevBuf tok_slot;   // int32[n_tokens]  slot index | LAST flag, -1 = no window
+  DevBuf tok_node;   // int32[n_tokens]  node id, -1 no window, -2 removed
+  DevBuf tok_dir;    // int8 [n_tokens]
+  // nodes (id order)
+  DevBuf node_tokens;  // int32[n_nodes * k]
+  DevBuf node_cov;     // uint32[n_nodes]
+  DevBuf node_first;   // int64[n_nodes]  first_seen value ((tok << 1) | dirbit)
+  DevBuf node_comp;    // int32[n_nodes]
+  DevBuf node_alive;   // uint8[n_nodes]
+  // edges (id order)
+  DevBuf edge_src, edge_tgt;    // int32[n_edges]
+  DevBuf edge_sdir, edge_tdir;  // int8[n_edges]
+  DevBuf edge_cov;              // uint32[n_edges]
+  DevBuf edge_alive;            // uint8[n_edges]
+  // adjacency CSR, row 2n = forward list of node n, 2n+1 = backward list
+  DevBuf adj_off;   // int64[2 n_nodes + 1]
+  DevBuf adj_edge;  // int32[n_edges]
+  // reads
+  DevBuf read_fix;  // uint8[n_reads]  read is in _readsToCorrect
+
+  // ---- corrected read set (output of amg_correct_reads)
+  bool have_corrected = false;
+  int64_t c_reads = 0, c_tokens = 0;
+  DevBuf c_tokens_buf, c_read_off, c_orig, c_changed, c_gstart, c_gend, c_read_len;
+
+  // ---- scratch
+  DevBuf status;       // unsigned long long[ST_WORDS]
+  DevBuf sort_tmp;     // rocPRIM temp storage
+  DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
+
+  std::vector<StageTime> stages;
+  bool timing = true;
+};
+
+// ------------------------------------------------------------------ primitives (amg_prims.hip)
+int prim_sort_u64_u32(amg_ctx* c, const unsigned long long* kin, unsigned long long* kout,
+                      const unsigned int* vin, unsigned int* vout, size_t n, int end_bit);
+int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
+                      const unsigned int* vin, unsigned int* vout, size_t n, int end_bit);
+int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n);
+int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n);
+
+// ------------------------------------------------------------------ stage timing
+void stage_begin(amg_ctx* c, const char* name);
+void stage_end(amg_ctx* c);
+void stages_reset(amg_ctx* c);
+
+// passes (amg_passes.hip)
+int amg_reset_passes(amg_ctx* c);
+
+static inline int ilog2_ceil(uint64_t x) {
+  int b = 0;
+  while ((1ull << b) < x && b < 63) ++b;
+  return b;
+}

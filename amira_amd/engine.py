@@ -1,0 +1,153 @@
+"""Thin array-level wrapper over the C ABI (include/amg.h): numpy in, numpy out.
+This is the layer bench.py times; amira_amd.construct_graph builds the reference's
+object API on top of it."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(_ffi.lib.amg_create(int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _ffi.lib.amg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_reads(self, tokens, read_offsets, two_v):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        read_offsets = np.ascontiguousarray(read_offsets, dtype=np.int64)
+        check(_ffi.lib.amg_set_reads(self._h, ptr(tokens), ptr(read_offsets),
+                                     len(read_offsets) - 1, int(two_v), 0))
+
+    def set_reads_device(self, tokens_ptr, read_offsets_ptr, n_reads, two_v):
+        check(_ffi.lib.amg_set_reads(self._h, C.c_void_p(tokens_ptr), C.c_void_p(read_offsets_ptr),
+                                     int(n_reads), int(two_v), 1))
+
+    def set_positions(self, gene_start, gene_end, read_len=None):
+        gs = np.ascontiguousarray(gene_start, dtype=np.int64)
+        ge = np.ascontiguousarray(gene_end, dtype=np.int64)
+        rl = None if read_len is None else np.ascontiguousarray(read_len, dtype=np.int64)
+        check(_ffi.lib.amg_set_positions(self._h, ptr(gs), ptr(ge), ptr(rl), 0))
+
+    # ---- build + counts
+    def build(self, k):
+        check(_ffi.lib.amg_build(self._h, int(k)))
+
+    def counts(self):
+        c = _ffi.Counts()
+        check(_ffi.lib.amg_counts(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def sync(self):
+        check(_ffi.lib.amg_sync(self._h))
+
+    def stream(self):
+        return _ffi.lib.amg_stream(self._h)
+
+    def timings(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = _ffi.lib.amg_last_timings(self._h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    # ---- read-back
+    def nodes(self):
+        c = self.counts()
+        D, k = c["n_nodes"], c["k"]
+        out = {
+            "tokens": np.empty((D, k), np.int32), "coverage": np.empty(D, np.uint32),
+            "first_token": np.empty(D, np.int64), "first_dir": np.empty(D, np.int8),
+            "component": np.empty(D, np.int32), "alive": np.empty(D, np.uint8),
+        }
+        check(_ffi.lib.amg_get_nodes(self._h, ptr(out["tokens"]), ptr(out["coverage"]),
+                                     ptr(out["first_token"]), ptr(out["first_dir"]),
+                                     ptr(out["component"]), ptr(out["alive"])))
+        return out
+
+    def edges(self):
+        E = self.counts()["n_edges"]
+        out = {"src": np.empty(E, np.int32), "tgt": np.empty(E, np.int32),
+               "sdir": np.empty(E, np.int8), "tdir": np.empty(E, np.int8),
+               "coverage": np.empty(E, np.uint32), "alive": np.empty(E, np.uint8)}
+        check(_ffi.lib.amg_get_edges(self._h, ptr(out["src"]), ptr(out["tgt"]), ptr(out["sdir"]),
+                                     ptr(out["tdir"]), ptr(out["coverage"]), ptr(out["alive"])))
+        return out
+
+    def read_nodes(self):
+        T = self.counts()["n_tokens"]
+        node, d = np.empty(T, np.int32), np.empty(T, np.int8)
+        check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), ptr(d)))
+        return node, d
+
+    def node_adj(self):
+        c = self.counts()
+        off, ids = np.empty(2 * c["n_nodes"] + 1, np.int64), np.empty(c["n_edges"], np.int32)
+        check(_ffi.lib.amg_get_node_adj(self._h, ptr(off), ptr(ids)))
+        return off, ids
+
+    def node_reads(self):
+        D = self.counts()["n_nodes"]
+        off = np.empty(D + 1, np.int64)
+        check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), None))
+        idx = np.empty(int(off[-1]) if D else 0, np.int32)
+        if len(idx):
+            check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), ptr(idx)))
+        return off, idx
+
+    def reads_to_correct(self):
+        f = np.empty(self.counts()["n_reads"], np.uint8)
+        check(_ffi.lib.amg_get_reads_to_correct(self._h, ptr(f)))
+        return f
+
+    # ---- passes
+    def filter(self, min_node_cov, min_edge_cov):
+        check(_ffi.lib.amg_filter(self._h, int(min_node_cov), int(min_edge_cov)))
+
+    def remove_nodes(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(_ffi.lib.amg_remove_nodes(self._h, ptr(ids), len(ids)))
+
+    def remove_short_linear_paths(self, min_length, protect=None):
+        D = self.counts()["n_nodes"]
+        n = C.c_int64(0)
+        ids = np.empty(D, np.int32)
+        pr = None if protect is None else np.ascontiguousarray(protect, dtype=np.uint8)
+        check(_ffi.lib.amg_remove_short_linear_paths(self._h, int(min_length), ptr(pr),
+                                                     C.byref(n), ptr(ids)))
+        return ids[: n.value].copy()
+
+    def remove_low_coverage_components(self, min_cov):
+        check(_ffi.lib.amg_remove_low_coverage_components(self._h, int(min_cov)))
+
+    def correct_reads(self):
+        nr, nt = C.c_int64(0), C.c_int64(0)
+        check(_ffi.lib.amg_correct_reads(self._h, C.byref(nr), C.byref(nt)))
+        return nr.value, nt.value
+
+    def corrected(self, n_reads, n_tokens, with_positions):
+        out = {"tokens": np.empty(n_tokens, np.int32), "read_offsets": np.empty(n_reads + 1, np.int64),
+               "orig_read": np.empty(n_reads, np.int32), "changed": np.empty(n_reads, np.uint8)}
+        gs = ge = None
+        if with_positions:
+            gs, ge = np.empty(n_tokens, np.int64), np.empty(n_tokens, np.int64)
+        check(_ffi.lib.amg_get_corrected(self._h, ptr(out["tokens"]), ptr(out["read_offsets"]),
+                                         ptr(out["orig_read"]), ptr(out["changed"]), ptr(gs), ptr(ge)))
+        out["gene_start"], out["gene_end"] = gs, ge
+        return out
+
+    def adopt_corrected(self):
+        check(_ffi.lib.amg_adopt_corrected(self._h))

@@ -1,0 +1,186 @@
+/*
+ * amg.h — C ABI of libamg.so, the MI355X (gfx950) gene-mer de Bruijn graph engine.
+ *
+ * This is the drop-in boundary for the read -> gene-mer-graph hot path of
+ * Danderson123/Amira v0.11.0.  The reference has no FFI of its own (it is pure
+ * Python); every entry point below replaces the Python call named beside it
+ * (file:line under the reference tree).  The binding a maintainer would add is the
+ * ctypes stub shown in INTEGRATION.md (amira_amd/_ffi.py is that stub).
+ *
+ * Conventions
+ *   - handle based: one amg_ctx per device; a ctx is not thread-safe;
+ *   - every function returns 0 on success, <0 on error (AMG_E_*); the message of the
+ *     last error on the calling thread is amg_last_error();
+ *   - the caller owns every buffer it passes; the library owns device memory behind
+ *     the handle; output sizes come from amg_counts() (two-call pattern);
+ *   - calls are synchronous with respect to the ctx's HIP stream when they return
+ *     data to the host; amg_sync() drains the stream otherwise;
+ *   - plain pointers and sizes only — no torch / C++ types cross this boundary.
+ *
+ * Data model (DESIGN.md "Data layout"):
+ *   token  = V + rank(gene) for '+', V - 1 - rank(gene) for '-', rank = ascending order
+ *            of sha256(pickle(name)) over the vocabulary (construct_gene.py:5-10,91-93).
+ *            Integer order of tokens == order of the reference's signed 256-bit gene
+ *            hashes, strand flip == two_v - 1 - token.
+ *   reads  = CSR: tokens[int32, n_tokens], read_offsets[int64, n_reads + 1].
+ *   window = k consecutive tokens of one read, identified by the index t of its first
+ *            token.  All per-window outputs are token-indexed arrays of length n_tokens
+ *            (entry t describes the window starting at token t, -1/0 where no window
+ *            starts), so a read's node list is the slice
+ *            [read_offsets[r], read_offsets[r+1] - k + 1).
+ *   node id = rank of the node's first occurrence (== insertion order of the
+ *            reference's GeneMerGraph._nodes dict, construct_graph.py:188-190).
+ *   edge id = insertion order of the reference's GeneMerGraph._edges dict
+ *            (construct_graph.py:268-277).
+ */
+#ifndef AMG_H
+#define AMG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amg_ctx amg_ctx;
+
+enum {
+  AMG_OK = 0,
+  AMG_E_HIP = -1,        /* a HIP runtime call failed                                  */
+  AMG_E_ARG = -2,        /* bad argument                                               */
+  AMG_E_STATE = -3,      /* call order (e.g. getters before amg_build)                 */
+  AMG_E_PALINDROME = -4, /* gene-mer == its reverse complement; the reference asserts  */
+                         /* (construct_gene_mer.py:23-25) -> AssertionError in Python  */
+  AMG_E_OVERFLOW = -5,   /* internal table overflow that retries could not resolve     */
+  AMG_E_NOMEM = -6,
+  AMG_E_DIST = -7        /* RCCL / multi-GPU exchange failure                          */
+};
+
+#define AMG_MAX_K 16
+
+typedef struct amg_counts_t {
+  int64_t n_reads;        /* reads in the current read set                             */
+  int64_t n_tokens;       /* genes over all reads                                      */
+  int64_t n_windows;      /* gene-mers = sum max(0, len - k + 1)                       */
+  int64_t n_short_reads;  /* reads with < k genes  (construct_graph.py:53-55)          */
+  int64_t n_nodes;        /* distinct canonical gene-mers ever inserted                */
+  int64_t n_edges;        /* directed edges ever inserted (reference _edges entries)   */
+  int64_t n_pairs;        /* undirected edge classes (each gives 2 edges, 1 if loop)   */
+  int64_t n_components;
+  int64_t n_live_nodes;   /* after filter / removals                                   */
+  int64_t n_live_edges;
+  int64_t n_reads_to_correct;
+  int64_t node_table_slots;
+  int64_t edge_table_slots;
+  int64_t build_retries;  /* table growth / fingerprint-collision rebuilds             */
+  int32_t k;
+  int32_t two_v;
+} amg_counts_t;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int amg_create(int device, amg_ctx** out);
+int amg_destroy(amg_ctx* ctx);
+const char* amg_last_error(void);
+int amg_sync(amg_ctx* ctx);
+/* the HIP stream every kernel of this ctx is launched on (for hipEvent timing) */
+void* amg_stream(amg_ctx* ctx);
+
+/* ---- input: replaces the readDict / gene_positions arguments of
+ *      GeneMerGraph.__init__ (construct_graph.py:31) ------------------------------- */
+/* on_device != 0: pointers are device pointers on ctx's device (copied D2D). */
+int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offsets,
+                  int64_t n_reads, int32_t two_v, int on_device);
+/* optional: per-gene [start,end] and per-read sequence length, used only by
+ * amg_correct_reads to carry gene positions (construct_graph.py:1311-1328,1669-1691).
+ * read_len may be NULL when no read will need position inference. */
+int amg_set_positions(amg_ctx* ctx, const int64_t* gene_start, const int64_t* gene_end,
+                      const int64_t* read_len, int on_device);
+
+/* ---- build: GeneMerGraph.__init__ (construct_graph.py:31-102), i.e.
+ *      Read.get_geneMers (construct_read.py:37-59), define_geneMer
+ *      (construct_gene_mer.py:42-56), add_node (:196-212), add_node_to_read (:165-178),
+ *      add_edge (:300-324), assign_component_ids (:920-927) --------------------------- */
+int amg_build(amg_ctx* ctx, int32_t k);
+int amg_counts(amg_ctx* ctx, amg_counts_t* out);
+
+/* ---- graph read-back (any pointer may be NULL to skip that column) ---------------- */
+/* nodes in id order; canon_tokens is [n_nodes * k]; first_token = token index of the
+ * node's first occurrence; first_dir = direction of that occurrence (+1/-1), i.e.
+ * node.get_geneMer().get_geneMerDirection() (construct_node.py:16-18). */
+int amg_get_nodes(amg_ctx* ctx, int32_t* canon_tokens, uint32_t* coverage,
+                  int64_t* first_token, int8_t* first_dir, int32_t* component,
+                  uint8_t* alive);
+/* directed edges in id order: Edge(sourceNode, targetNode, sourceNodeDirection,
+ * targetNodeDirection).edgeCoverage (construct_edge.py:31-37) */
+int amg_get_edges(amg_ctx* ctx, int32_t* src, int32_t* tgt, int8_t* sdir, int8_t* tdir,
+                  uint32_t* coverage, uint8_t* alive);
+/* per-token node id (-1: no window starts here, -2: node removed => None in the
+ * reference's _readNodes) and direction (+1/-1, 0 where no node)
+ * — get_readNodes / get_readNodeDirections (construct_graph.py:117-123) */
+int amg_get_read_nodes(amg_ctx* ctx, int32_t* tok_node, int8_t* tok_dir);
+/* adjacency, 2 rows per node: row 2*n = forwardEdgeHashes, row 2*n+1 =
+ * backwardEdgeHashes of node n, edge ids in list order (construct_node.py:79-101);
+ * offsets[2*n_nodes + 1], edge_ids[n_edges].  Dead edges stay listed; test `alive`. */
+int amg_get_node_adj(amg_ctx* ctx, int64_t* offsets, int32_t* edge_ids);
+/* Node.listOfReads (construct_node.py:64-67): ordered, de-duplicated read indices.
+ * Call with read_idx == NULL to get offsets (and thereby the total) first. */
+int amg_get_node_reads(amg_ctx* ctx, int64_t* offsets, int32_t* read_idx);
+
+/* ---- coverage filter and removals -------------------------------------------------- */
+/* filter_graph(minNodeCoverage, minEdgeCoverage) (construct_graph.py:523-540) */
+int amg_filter(amg_ctx* ctx, uint32_t min_node_cov, uint32_t min_edge_cov);
+/* remove_node for each listed node (construct_graph.py:463-484) */
+int amg_remove_nodes(amg_ctx* ctx, const int32_t* node_ids, int64_t n);
+/* remove_short_linear_paths(min_length) (construct_graph.py:679-720); protect[n] != 0
+ * keeps node n (the AMR_nodes exemption); removed_ids may be NULL. */
+int amg_remove_short_linear_paths(amg_ctx* ctx, int32_t min_length, const uint8_t* protect,
+                                  int64_t* n_removed, int32_t* removed_ids);
+/* remove_low_coverage_components(min) (construct_graph.py:950-958) */
+int amg_remove_low_coverage_components(amg_ctx* ctx, uint32_t min_component_coverage);
+/* get_reads_to_correct() as a 0/1 flag per read (construct_graph.py:148-150) */
+int amg_get_reads_to_correct(amg_ctx* ctx, uint8_t* flags);
+
+/* ---- per-read correction: correct_reads (construct_graph.py:1123-1396,1433-1480) --- */
+/* Re-threads every marked read through the filtered graph on the device and leaves
+ * the corrected read set in ctx.  Outputs: reads kept (marked reads whose nodes were
+ * all removed, and reads without any window, are dropped) and their total genes. */
+int amg_correct_reads(amg_ctx* ctx, int64_t* n_out_reads, int64_t* n_out_tokens);
+/* corrected CSR + origin: orig_read[i] = index (in the current read set) of corrected
+ * read i; changed[i] != 0 if read i was re-threaded (its gene list is a new list);
+ * gene_start/gene_end NULL unless positions were set. */
+int amg_get_corrected(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets,
+                      int32_t* orig_read, uint8_t* changed, int64_t* gene_start,
+                      int64_t* gene_end);
+/* the corrected read set becomes the current read set (device resident; the next
+ * amg_build runs on it) — the rebuild of graph_utils.py:147-150,165 */
+int amg_adopt_corrected(amg_ctx* ctx);
+
+/* ---- read-path clustering support: batched exact sub-list search
+ *      (is_sublist / find_sublist_indices, construct_graph.py:1957-1966,2117-2123;
+ *      Tree.find_all call sites path_finding_utils.py:244,290) ------------------------ */
+/* patterns are CSR token lists; each is searched forward in every read's TOKENS
+ * (which = 0) or NODE ids (which = 1).  Two-call: hit_read == NULL returns counts in
+ * hit_offsets[n_pat + 1]; then (hit_read, hit_pos) get one entry per occurrence,
+ * ordered by (pattern, read, position). */
+int amg_match_patterns(amg_ctx* ctx, int which, const int32_t* pat, const int64_t* pat_offsets,
+                       int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read,
+                       int32_t* hit_pos);
+
+/* ---- multi-GPU (read-sharded build with an RCCL all-to-all table merge;
+ *      the single-graph result of graph_utils.py:105-124 at cores = 1) --------------- */
+int amg_dist_unique_id(void* id128);                        /* ncclGetUniqueId, 128 bytes */
+int amg_dist_init(amg_ctx* ctx, const void* id128, int rank, int world);
+/* like amg_build, but ctx holds only this rank's contiguous read shard;
+ * read_index_base / token_index_base = global index of the shard's first read / token.
+ * After it returns every rank holds the GLOBAL node/edge tables and its own reads'
+ * node ids. */
+int amg_dist_build(amg_ctx* ctx, int32_t k, int64_t read_index_base, int64_t token_index_base);
+
+/* ---- per-stage device time of the last call, for bench.py ------------------------- */
+/* names[i] points at static strings; returns the number of stages (<= cap). */
+int amg_last_timings(amg_ctx* ctx, const char** names, float* ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMG_H */

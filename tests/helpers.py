@@ -1,0 +1,111 @@
+"""Test helpers: bring oracle graphs and engine arrays to one comparable form."""
+import numpy as np
+
+
+def oracle_arrays(g, vocab, read_ids, read_off, k):
+    """Array view of an oracle (or reference-API) graph in the engine's conventions."""
+    node_id = {}
+    tokens, cov, first_dir, comp = [], [], [], []
+    for h, n in g.get_nodes().items():
+        node_id[h] = len(node_id)
+        tokens.append([vocab.token(("+" if x.get_strand() == 1 else "-") + x.get_name())
+                       for x in n.get_canonical_geneMer()])
+        cov.append(n.get_node_coverage())
+        first_dir.append(n.get_geneMer().get_geneMerDirection())
+        comp.append(n.get_component())
+    edge_id = {}
+    src, tgt, sdir, tdir, ecov = [], [], [], [], []
+    for h, e in g.get_edges().items():
+        edge_id[h] = len(edge_id)
+        src.append(node_id[e.get_sourceNode().__hash__()])
+        tgt.append(node_id[e.get_targetNode().__hash__()])
+        sdir.append(e.get_sourceNodeDirection())
+        tdir.append(e.get_targetNodeDirection())
+        ecov.append(e.get_edge_coverage())
+    T = int(read_off[-1])
+    tok_node = np.full(T, -1, np.int32)
+    tok_dir = np.zeros(T, np.int8)
+    rn, rd = g.get_readNodes(), g.get_readNodeDirections()
+    for r, rid in enumerate(read_ids):
+        if rid not in rn:
+            continue
+        a = int(read_off[r])
+        for i, h in enumerate(rn[rid]):
+            if h is None:
+                tok_node[a + i] = -2
+            else:
+                tok_node[a + i] = node_id[h]
+                tok_dir[a + i] = rd[rid][i]
+    adj = []
+    for h, n in g.get_nodes().items():
+        adj.append([edge_id[x] for x in n.get_forward_edge_hashes()])
+        adj.append([edge_id[x] for x in n.get_backward_edge_hashes()])
+    ridx = {rid: i for i, rid in enumerate(read_ids)}
+    node_reads = [[ridx[r] for r in n.get_list_of_reads()] for n in g.get_nodes().values()]
+    return {
+        "tokens": np.asarray(tokens, np.int32).reshape(len(tokens), k),
+        "coverage": np.asarray(cov, np.uint32), "first_dir": np.asarray(first_dir, np.int8),
+        "component": np.asarray(comp, np.int32),
+        "src": np.asarray(src, np.int32), "tgt": np.asarray(tgt, np.int32),
+        "sdir": np.asarray(sdir, np.int8), "tdir": np.asarray(tdir, np.int8),
+        "ecov": np.asarray(ecov, np.uint32),
+        "tok_node": tok_node, "tok_dir": tok_dir, "adj": adj, "node_reads": node_reads,
+        "short": [r for r in read_ids if r in g.get_short_read_annotations()],
+        "to_correct": sorted(g.get_reads_to_correct()),
+    }
+
+
+def csr_lists(off, vals, alive=None):
+    out = []
+    for i in range(len(off) - 1):
+        row = vals[off[i]:off[i + 1]]
+        if alive is not None:
+            row = row[alive[row] != 0]
+        out.append(row.tolist())
+    return out
+
+
+def compare_engine_to_oracle(eng, want, live_only=False):
+    """Assert that the engine's current graph equals the oracle arrays `want`.
+    With live_only, dead nodes / edges of the engine are dropped and ids renumbered
+    (the oracle deletes them from its dicts)."""
+    c = eng.counts()
+    nodes, edges = eng.nodes(), eng.edges()
+    tok_node, tok_dir = eng.read_nodes()
+    off, adj = eng.node_adj()
+    if not live_only:
+        assert c["n_nodes"] == len(want["coverage"]) and c["n_edges"] == len(want["src"])
+        nmap = np.arange(c["n_nodes"])
+        emap = np.arange(c["n_edges"])
+        nkeep = np.ones(c["n_nodes"], bool)
+        ekeep = np.ones(c["n_edges"], bool)
+    else:
+        nkeep, ekeep = nodes["alive"] != 0, edges["alive"] != 0
+        nmap = np.cumsum(nkeep) - 1
+        emap = np.cumsum(ekeep) - 1
+        assert int(nkeep.sum()) == len(want["coverage"]), (int(nkeep.sum()), len(want["coverage"]))
+        assert int(ekeep.sum()) == len(want["src"]), (int(ekeep.sum()), len(want["src"]))
+    assert np.array_equal(nodes["tokens"][nkeep], want["tokens"])
+    assert np.array_equal(nodes["coverage"][nkeep], want["coverage"])
+    assert np.array_equal(nodes["first_dir"][nkeep], want["first_dir"])
+    assert np.array_equal(nodes["component"][nkeep], want["component"])
+    assert np.array_equal(nmap[edges["src"][ekeep]], want["src"])
+    assert np.array_equal(nmap[edges["tgt"][ekeep]], want["tgt"])
+    assert np.array_equal(edges["sdir"][ekeep], want["sdir"])
+    assert np.array_equal(edges["tdir"][ekeep], want["tdir"])
+    assert np.array_equal(edges["coverage"][ekeep], want["ecov"])
+    got_node = tok_node.copy()
+    m = tok_node >= 0
+    got_node[m] = nmap[tok_node[m]]
+    assert np.array_equal(got_node, want["tok_node"])
+    assert np.array_equal(np.where(tok_node >= 0, tok_dir, 0), want["tok_dir"])
+    rows = csr_lists(off, adj, edges["alive"] if live_only else None)
+    got_adj = []
+    for n in range(c["n_nodes"]):
+        if nkeep[n]:
+            got_adj.append([int(emap[e]) for e in rows[2 * n]])
+            got_adj.append([int(emap[e]) for e in rows[2 * n + 1]])
+    assert got_adj == want["adj"]
+    roff, ridx = eng.node_reads()
+    got_reads = [r for n, r in enumerate(csr_lists(roff, ridx)) if nkeep[n]]
+    assert got_reads == want["node_reads"]

@@ -1,0 +1,97 @@
+"""GPU parity of the HIP build (K1-K4, K7) against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import dump as D
+import procedures as P
+from helpers import compare_engine_to_oracle, oracle_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from amira_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _run(eng, reads, k, filt=None):
+    from amira_amd import tokenize
+    from amira_oracle import GeneMerGraph
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    eng.build(k)
+    g = GeneMerGraph(reads, k)
+    want = oracle_arrays(g, vocab, read_ids, offs, k)
+    c = eng.counts()
+    assert c["n_short_reads"] == len(want["short"])
+    assert c["n_windows"] == int((want["tok_node"] != -1).sum())
+    assert c["n_components"] == len(set(want["component"].tolist()))
+    compare_engine_to_oracle(eng, want)
+    if filt:
+        eng.filter(*filt)
+        g.filter_graph(*filt)
+        want = oracle_arrays(g, vocab, read_ids, offs, k)
+        compare_engine_to_oracle(eng, want, live_only=True)
+        flags = eng.reads_to_correct()
+        assert sorted(r for r, f in zip(read_ids, flags) if f) == want["to_correct"]
+    return c
+
+
+def test_tiny_known_answers(eng):
+    # tests/test_gene_mer_graph.py:38-68 shape: two reads sharing a gene-mer
+    c = _run(eng, {"read1": ["+gene1", "-gene2", "+gene3", "-gene4"],
+                   "read2": ["+gene1", "-gene2", "+gene3"]}, 3)
+    assert (c["n_nodes"], c["n_edges"]) == (2, 2)
+    # tandem self-loop and hairpin
+    c = _run(eng, {"r": ["-gene4"] * 5}, 3)
+    assert (c["n_nodes"], c["n_edges"]) == (1, 1)
+    _run(eng, {"r": ["+a", "+b", "-b", "-a"], "s": ["+a", "+b", "-b", "-a", "+c"]}, 3)
+    # k = 1: every gene is a node, canonical strand is '-'
+    _run(eng, {"r1": ["+a", "-b", "+c", "+a"], "r2": ["-c", "+b"], "r3": ["+d"]}, 1)
+
+
+def test_ragged_and_empty_reads(eng):
+    reads = {"e0": [], "s1": ["+a"], "s2": ["+a", "-b"], "x": ["+a", "-b", "+c"], "e1": [],
+             "y": ["-c", "+b", "-a", "+d", "+e", "-f", "+a", "-b", "+c"], "e2": []}
+    c = _run(eng, reads, 3)
+    assert c["n_short_reads"] == 5
+    _run(eng, reads, 5)
+    _run(eng, {"only_short": ["+a", "+b"]}, 3)
+    _run(eng, {}, 3)
+
+
+def test_palindrome_asserts_like_reference(eng):
+    from amira_amd import _ffi, tokenize
+    reads = {"p": ["+a", "-a", "+b"]}  # k = 2 window (+a, -a) equals its reverse complement
+    vocab, toks, offs, _ = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    with pytest.raises(_ffi.AmgError) as ei:
+        eng.build(2)
+    assert ei.value.code == _ffi.E_PALINDROME
+
+
+@pytest.mark.parametrize("name,k", [("five", 3), ("five", 5), ("seven", 3), ("eight", 5),
+                                     ("four", 3), ("nine", 5), ("three", 3)])
+def test_fixture_build_and_filter(eng, name, k):
+    calls, _ = P.fixture(name)
+    _run(eng, calls, k, filt=(3, 1))
+
+
+@pytest.mark.parametrize("seed,N,L,V,k,err", [(7, 400, 30, 300, 5, 0.03), (11, 400, 24, 200, 3, 0.03),
+                                              (13, 300, 40, 250, 7, 0.02), (17, 800, 40, 150, 5, 0.05),
+                                              (19, 500, 33, 400, 9, 0.02), (23, 300, 50, 300, 15, 0.01)])
+def test_synthetic_build_and_filter(eng, seed, N, L, V, k, err):
+    reads, _, _ = P.synth_inputs(seed, N, L, V, err)
+    _run(eng, reads, k, filt=(3, 1))
+    _run(eng, reads, k, filt=(2, 2))
+
+
+def test_rebuild_on_same_context(eng):
+    reads, _, _ = P.synth_inputs(3, 200, 30, 100, 0.02)
+    a = _run(eng, reads, 5)
+    b = _run(eng, reads, 3)
+    c = _run(eng, reads, 5)
+    assert a["n_nodes"] == c["n_nodes"] and b["n_nodes"] != 0
