@@ -106,29 +106,1077 @@ extern "C" int amg_remove_nodes(amg_ctx* c, const int32_t* node_ids, int64_t n) 
   return AMG_OK;
 }
 
-// ------------------------------------------------------------------ not yet implemented
+
+// ------------------------------------------------------------------ graph view for walkers
+struct GView {
+  const long long* adj_off;
+  const int* adj_edge;
+  const int* e_tgt;
+  const signed char* e_tdir;
+  const unsigned char* e_alive;
+  const unsigned char* n_alive;
+  const unsigned int* n_cov;
+  const int* n_tok;
+  const long long* n_first;
+  const int* n_comp;
+  int k, flip;
+};
+
+static GView make_view(amg_ctx* c) {
+  GView g;
+  g.adj_off = c->adj_off.as<long long>();
+  g.adj_edge = c->adj_edge.as<int>();
+  g.e_tgt = c->edge_tgt.as<int>();
+  g.e_tdir = c->edge_tdir.as<signed char>();
+  g.e_alive = c->edge_alive.as<unsigned char>();
+  g.n_alive = c->node_alive.as<unsigned char>();
+  g.n_cov = c->node_cov.as<unsigned int>();
+  g.n_tok = c->node_tokens.as<int>();
+  g.n_first = c->node_first.as<long long>();
+  g.n_comp = c->node_comp.as<int>();
+  g.k = c->k;
+  g.flip = c->two_v - 1;
+  return g;
+}
+
+__device__ __forceinline__ int row_live(const GView& g, long long row) {
+  int n = 0;
+  for (long long p = g.adj_off[row]; p < g.adj_off[row + 1]; ++p) n += g.e_alive[g.adj_edge[p]] ? 1 : 0;
+  return n;
+}
+// get_degree (:326-329): live edge classes on both sides
+__device__ __forceinline__ int node_degree(const GView& g, int n) {
+  return row_live(g, 2ll * n) + row_live(g, 2ll * n + 1);
+}
+
+// get_forward_node_from_node (:722-741) / get_backward_node_from_node (:781-802):
+// forward needs EXACTLY one live forward edge, backward takes the FIRST live backward edge.
+// returns 0 = no edge, 1 = edge but cannot extend, 2 = extend
+__device__ __forceinline__ int lin_step(const GView& g, int n, bool use_forward, int* tgt, int* tdir) {
+  long long row = 2ll * n + (use_forward ? 0 : 1);
+  int found = -1, cnt = 0;
+  for (long long p = g.adj_off[row]; p < g.adj_off[row + 1]; ++p) {
+    int e = g.adj_edge[p];
+    if (!g.e_alive[e]) continue;
+    if (found < 0) found = e;
+    ++cnt;
+    if (!use_forward) break;
+  }
+  if (found < 0 || (use_forward && cnt != 1)) return 0;
+  *tgt = g.e_tgt[found];
+  *tdir = g.e_tdir[found];
+  int deg = node_degree(g, *tgt);
+  return ((deg == 1 || deg == 2) && *tgt != n) ? 2 : 1;
+}
+
+// ------------------------------------------------------------------ remove_short_linear_paths (:679-720)
+#define CLIP_MAX 64
+__global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double thr,
+                            const unsigned int* __restrict__ comp_live,
+                            const unsigned char* __restrict__ protect,
+                            unsigned char* __restrict__ kill) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || !g.n_alive[i]) return;
+  int n = (int)i;
+  if (node_degree(g, n) != 1) return;
+  int d0 = (g.n_first[n] & 1ll) ? -1 : 1;  // direction of the node's first occurrence (:852-858)
+  int path[CLIP_MAX];
+  int len = 0;
+  path[len++] = n;
+  // backward walk, started with -d0 (get_backward_path_from_node, :804-847)
+  int tgt = -1, td = 0;
+  int r = lin_step(g, n, d0 == -1, &tgt, &td);
+  while (r == 2 && tgt != n) {
+    if (len >= min_length) return;  // already too long to be clipped
+    path[len++] = tgt;
+    r = lin_step(g, tgt, td == 1, &tgt, &td);
+  }
+  // forward walk, started with d0 (get_forward_path_from_node, :743-779)
+  r = lin_step(g, n, d0 == 1, &tgt, &td);
+  while (r == 2 && tgt != n) {
+    if (len >= min_length) return;
+    path[len++] = tgt;
+    r = lin_step(g, tgt, td == 1, &tgt, &td);
+  }
+  if (!(len > 0 && len < min_length)) return;
+  bool all_high = true;
+  for (int j = 0; j < len; ++j) all_high = all_high && ((double)g.n_cov[path[j]] > thr);
+  if (all_high) return;
+  // a tip that IS its whole component is kept (:710-713)
+  int distinct = 0;
+  for (int j = 0; j < len; ++j) {
+    bool dup = false;
+    for (int q = 0; q < j; ++q) dup = dup || (path[q] == path[j]);
+    distinct += dup ? 0 : 1;
+  }
+  if ((unsigned int)distinct == comp_live[g.n_comp[n]]) return;
+  for (int j = 0; j < len; ++j)
+    if (!protect || !protect[path[j]]) kill[path[j]] = 1;
+}
+
+__global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* __restrict__ alive,
+                            const unsigned int* __restrict__ cov, long long n, unsigned int min_cov,
+                            unsigned int* __restrict__ live_cnt, unsigned int* __restrict__ high_cnt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !alive[i]) return;
+  atomicAdd(&live_cnt[comp[i]], 1u);
+  if (high_cnt && cov[i] >= min_cov) atomicAdd(&high_cnt[comp[i]], 1u);
+}
+
+__global__ void k_cov_sum(const unsigned int* __restrict__ cov, const unsigned char* __restrict__ alive,
+                          long long n, unsigned long long* out /*[2]: sum, count*/) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long s = 0, c = 0;
+  if (i < n && alive[i]) {
+    s = cov[i];
+    c = 1;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    s += __shfl_down(s, d, 64);
+    c += __shfl_down(c, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && c) {
+    atomicAdd(&out[0], s);
+    atomicAdd(&out[1], c);
+  }
+}
+
+__global__ void k_apply_kill(const unsigned char* __restrict__ kill, unsigned char* __restrict__ alive,
+                             long long n, unsigned int* __restrict__ flag32) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int f = (kill[i] && alive[i]) ? 1u : 0u;
+  if (f) alive[i] = 0;
+  flag32[i] = f;
+}
+
+__global__ void k_scatter_ids(const unsigned int* __restrict__ flag32, const long long* __restrict__ pos,
+                              long long n, int* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag32[i]) out[pos[i]] = (int)i;
+}
+
+// kill[] (s0) -> node_alive, removal side effects, ascending list of removed ids
+static int finish_kill(amg_ctx* c, int64_t* n_removed, int32_t* removed_ids) {
+  hipStream_t st = c->stream;
+  const long long D = c->n_nodes;
+  AMGCHK(c->s1.ensure((size_t)(D + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(D + 2) * sizeof(long long)));
+  hipLaunchKernelGGL(k_apply_kill, dim3(nblk(D, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
+                     c->node_alive.as<unsigned char>(), D, c->s1.as<unsigned int>());
+  HIPCHK(hipMemsetAsync(c->s1.as<unsigned int>() + D, 0, sizeof(unsigned int), st));
+  AMGCHK(prim_exscan_u32_to_i64(c, c->s1.as<unsigned int>(), c->s2.as<long long>(), (size_t)D + 1));
+  long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->s2.as<long long>() + D, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_removed) *n_removed = total;
+  if (removed_ids && total > 0) {
+    AMGCHK(c->s3.ensure((size_t)total * sizeof(int)));
+    hipLaunchKernelGGL(k_scatter_ids, dim3(nblk(D, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
+                       c->s2.as<long long>(), D, c->s3.as<int>());
+    HIPCHK(hipMemcpyAsync(removed_ids, c->s3.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  if (total > 0) AMGCHK(apply_removals(c, 0));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
 extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, const uint8_t* protect,
                                              int64_t* n_removed, int32_t* removed_ids) {
-  (void)c; (void)min_length; (void)protect; (void)n_removed; (void)removed_ids;
-  return amg_fail(AMG_E_STATE, "amg_remove_short_linear_paths: not implemented yet");
+  NEED_BUILT(c);
+  if (min_length < 1 || min_length > CLIP_MAX)
+    return amg_fail(AMG_E_ARG, "min_length must be in [1, %d]", CLIP_MAX);
+  hipStream_t st = c->stream;
+  const long long D = c->n_nodes;
+  if (n_removed) *n_removed = 0;
+  if (D == 0) return AMG_OK;
+  stages_reset(c);
+  stage_begin(c, "clip");
+  // mean node coverage (:868-871): statistics.mean over live nodes, * 1.5 in double
+  unsigned long long* acc = c->status.as<unsigned long long>() + ST_COMPACT_A;
+  HIPCHK(hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_cov_sum, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_cov.as<unsigned int>(),
+                     c->node_alive.as<unsigned char>(), D, acc);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (h[1] == 0) { stage_end(c); return AMG_OK; }
+  double mean = (double)h[0] / (double)h[1];  // correctly rounded, == float(Fraction(sum, n))
+  double thr = mean * 1.5;
+  AMGCHK(c->s0.ensure((size_t)D + 8));
+  AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)D + 8, st));
+  HIPCHK(hipMemsetAsync(c->s4.p, 0, (size_t)(c->n_components + 2) * sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
+                     c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
+                     c->s4.as<unsigned int>(), (unsigned int*)nullptr);
+  unsigned char* d_protect = nullptr;
+  if (protect) {
+    AMGCHK(c->s5.ensure((size_t)D + 8));
+    HIPCHK(hipMemcpyAsync(c->s5.p, protect, (size_t)D, hipMemcpyHostToDevice, st));
+    d_protect = c->s5.as<unsigned char>();
+  }
+  hipLaunchKernelGGL(k_clip_mark, dim3(nblk(D, 128)), dim3(128), 0, st, make_view(c), D, (int)min_length,
+                     thr, c->s4.as<unsigned int>(), d_protect, c->s0.as<unsigned char>());
+  int r = finish_kill(c, n_removed, removed_ids);
+  stage_end(c);
+  c->have_corrected = false;
+  return r;
 }
-extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t m) {
-  (void)c; (void)m;
-  return amg_fail(AMG_E_STATE, "amg_remove_low_coverage_components: not implemented yet");
+
+// ------------------------------------------------------------------ remove_low_coverage_components (:950-958)
+__global__ void k_kill_low_components(const int* __restrict__ comp, const unsigned char* __restrict__ alive,
+                                      const unsigned int* __restrict__ high_cnt, long long n,
+                                      unsigned char* __restrict__ kill) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && alive[i] && high_cnt[comp[i]] == 0) kill[i] = 1;
 }
-extern "C" int amg_correct_reads(amg_ctx* c, int64_t* a, int64_t* b) {
-  (void)c; (void)a; (void)b;
-  return amg_fail(AMG_E_STATE, "amg_correct_reads: not implemented yet");
+
+extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t min_cov) {
+  NEED_BUILT(c);
+  hipStream_t st = c->stream;
+  const long long D = c->n_nodes;
+  if (D == 0) return AMG_OK;
+  size_t nc = (size_t)(c->n_components + 2);
+  AMGCHK(c->s0.ensure((size_t)D + 8));
+  AMGCHK(c->s4.ensure(2 * nc * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)D + 8, st));
+  HIPCHK(hipMemsetAsync(c->s4.p, 0, 2 * nc * sizeof(unsigned int), st));
+  unsigned int* live = c->s4.as<unsigned int>();
+  unsigned int* high = live + nc;
+  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
+                     c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, min_cov, live, high);
+  hipLaunchKernelGGL(k_kill_low_components, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
+                     c->node_alive.as<unsigned char>(), high, D, c->s0.as<unsigned char>());
+  c->have_corrected = false;
+  return finish_kill(c, nullptr, nullptr);
 }
+
+// ------------------------------------------------------------------ correct_reads (:1123-1396)
+// Pipeline (all device):
+//   k_corr_classify   one wave per read: class, [start,end] (find_read_boundaries :1153-1164),
+//                     number of None runs inside (identify_path_terminals :1375-1386), output bound
+//   scan(bound)       temp offsets
+//   k_corr_simple     one wave per read: unmarked reads are copied, reads that only lost their
+//                     ends are sliced ([start : end + k], :1277-1285)
+//   k_corr_gapped     one thread per gapped read: bounded DFS per None run
+//                     (new_find_paths_between_nodes :2292-2342), cartesian product of the
+//                     replacements (insert_elements :1166-1203), best candidate by shared genes,
+//                     then mean coverage (:1297-1310), genes via get_annotation_for_read (:1331-1373)
+//   k_corr_nw         one wave per gapped read (positions only): needleman_wunsch (:1433-1480) by
+//                     anti-diagonals, traceback, position carry-over (:1314-1325) and
+//                     replace_invalid_gene_positions (:1669-1691)
+//   scan + k_corr_pack  compaction into the corrected CSR
+enum { RC_SKIP = 0, RC_COPY = 1, RC_DROP = 2, RC_TRIM = 3, RC_GAPPED = 4, RC_KEEP_ORIG = 5 };
+
+struct CorrArgs {
+  const int* tokens;
+  const long long* read_off;
+  const int* tok_node;
+  const signed char* tok_dir;
+  const unsigned char* read_fix;
+  const long long* gstart;
+  const long long* gend;
+  const long long* read_len;
+  long long n_reads;
+  int k, flip, have_pos;
+  // per read
+  unsigned char* cls;
+  int* r_start;
+  int* r_end;
+  unsigned int* bound;
+  const long long* tmp_off;
+  unsigned int* new_len;
+  // temp output
+  int* tmp_tok;
+  long long* tmp_gs;
+  long long* tmp_ge;
+};
+
+__global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.n_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long t0 = a.read_off[r], t1 = a.read_off[r + 1];
+  const long long L = t1 - t0, n = L - a.k + 1;
+  unsigned char cls;
+  int start = 0, end = -1;
+  unsigned int bound = 0;
+  if (n <= 0) {
+    cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
+  } else if (!a.read_fix[r]) {
+    cls = RC_COPY;
+    bound = (unsigned int)L;
+  } else {
+    long long first = n, last = -1;
+    for (long long i = lane; i < n; i += 64)
+      if (a.tok_node[t0 + i] >= 0) {
+        first = first < i ? first : i;
+        last = last > i ? last : i;
+      }
+    for (int d = 32; d > 0; d >>= 1) {
+      long long f2 = __shfl_xor(first, d, 64), l2 = __shfl_xor(last, d, 64);
+      first = first < f2 ? first : f2;
+      last = last > l2 ? last : l2;
+    }
+    if (last < 0) {
+      cls = RC_DROP;  // every node filtered: the read is dropped (:1141,:1150)
+    } else {
+      start = (int)first;
+      end = (int)last;
+      unsigned int runs = 0, live = 0;
+      for (long long i = first + lane; i <= last; i += 64) {
+        bool none = a.tok_node[t0 + i] < 0;
+        live += none ? 0u : 1u;
+        // a None run ends where the next window is live
+        if (none && a.tok_node[t0 + i + 1] >= 0) ++runs;
+      }
+      for (int d = 32; d > 0; d >>= 1) {
+        runs += __shfl_xor(runs, d, 64);
+        live += __shfl_xor(live, d, 64);
+      }
+      if (runs == 0) {
+        cls = RC_TRIM;
+        bound = (unsigned int)(end - start + a.k);
+      } else {
+        cls = RC_GAPPED;
+        unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
+        bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
+      }
+    }
+  }
+  if (lane == 0) {
+    a.cls[r] = cls;
+    a.r_start[r] = start;
+    a.r_end[r] = end;
+    a.bound[r] = bound;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_corr_simple(CorrArgs a) {
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.n_reads) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned char cls = a.cls[r];
+  if (cls == RC_GAPPED) return;
+  unsigned int len = 0;
+  if (cls == RC_COPY || cls == RC_TRIM) {
+    const long long t0 = a.read_off[r];
+    long long src = t0, cnt = a.read_off[r + 1] - t0;
+    if (cls == RC_TRIM) {
+      src = t0 + a.r_start[r];
+      cnt = a.r_end[r] - a.r_start[r] + a.k;
+    }
+    const long long dst = a.tmp_off[r];
+    for (long long i = lane; i < cnt; i += 64) {
+      a.tmp_tok[dst + i] = a.tokens[src + i];
+      if (a.have_pos) {
+        a.tmp_gs[dst + i] = a.gstart[src + i];
+        a.tmp_ge[dst + i] = a.gend[src + i];
+      }
+    }
+    len = (unsigned int)cnt;
+  }
+  if (lane == 0) a.new_len[r] = len;
+}
+
+// ---- gapped reads
+#define DFS_MAX (2 * AMG_MAX_K + 4)
+
+struct PathSink {
+  int* buf;        // nullptr => count only
+  long long used;  // ints
+  int n_paths;
+};
+
+// new_find_paths_between_nodes(start, end, distance, direction): simple paths following the
+// forward list when the current direction is +1, the backward list when -1, in list order;
+// a path is accepted when it reaches `end` with <= distance nodes.  Emits [len, node*len, dir*len].
+__device__ void dfs_paths(const GView& g, int s, int sdir, int e, int distance, PathSink* sink) {
+  int node[DFS_MAX], dir[DFS_MAX];
+  long long cur[DFS_MAX], lim[DFS_MAX];
+  int depth = 0;
+  node[0] = s;
+  dir[0] = sdir;
+  bool entering = true;
+  while (depth >= 0) {
+    if (entering) {
+      int L = depth + 1;
+      if (node[depth] == e && L <= distance) {
+        if (sink->buf) {
+          int* o = sink->buf + sink->used;
+          o[0] = L;
+          for (int j = 0; j < L; ++j) {
+            o[1 + j] = node[j];
+            o[1 + L + j] = dir[j];
+          }
+        }
+        sink->used += 1 + 2 * L;
+        sink->n_paths += 1;
+        --depth;
+        entering = false;
+        continue;
+      }
+      if (L - 1 > distance) {
+        --depth;
+        entering = false;
+        continue;
+      }
+      long long row = 2ll * node[depth] + (dir[depth] == 1 ? 0 : 1);
+      cur[depth] = g.adj_off[row];
+      lim[depth] = g.adj_off[row + 1];
+      entering = false;
+    }
+    bool pushed = false;
+    while (cur[depth] < lim[depth]) {
+      int ed = g.adj_edge[cur[depth]++];
+      if (!g.e_alive[ed]) continue;
+      int t = g.e_tgt[ed];
+      bool seen = false;
+      for (int j = 0; j <= depth; ++j) seen = seen || (node[j] == t);
+      if (seen) continue;
+      node[depth + 1] = t;
+      dir[depth + 1] = g.e_tdir[ed];
+      ++depth;
+      entering = true;
+      pushed = true;
+      break;
+    }
+    if (!pushed) --depth;
+  }
+}
+
+// last gene of node n taken in direction d (get_gene_mer_genes / get_reverse_gene_mer_genes)
+__device__ __forceinline__ int oriented_tok(const GView& g, int n, int d, int j) {
+  const int* nt = g.n_tok + (long long)n * g.k;
+  return d == 1 ? nt[j] : g.flip - nt[g.k - 1 - j];
+}
+
+struct GapIter {
+  long long t0;
+  const int* tok_node;
+  int start, end, i;
+  int ps, pe;
+  __device__ bool next() {
+    // identify_path_terminals: for i in [start, end] with a None at i: path_start = i-1 if live,
+    // pair emitted when i+1 is live
+    while (i <= end) {
+      int idx = i++;
+      if (tok_node[t0 + idx] < 0) {
+        if (tok_node[t0 + idx - 1] >= 0) ps = idx - 1;
+        if (tok_node[t0 + idx + 1] >= 0) {
+          pe = idx + 1;
+          return true;
+        }
+      }
+    }
+    return false;
+  }
+};
+
+struct GapArgs {
+  CorrArgs a;
+  GView g;
+  const int* gapped_reads;
+  long long n_gapped;
+  int* pool;               // path pool (ints)
+  unsigned long long pool_cap;
+  unsigned long long* pool_used;  // bump pointer
+  unsigned long long* status;
+  int* cand;               // candidate scratch, [grid threads * cand_stride]
+  unsigned int cand_stride;
+  unsigned char* final_cls;
+};
+
+// build candidate `combo` (mixed radix over the gaps' path choices) into (out_node, out_dir);
+// returns its node count.  paths of gap q start at pool[gap_off[q]] as [len, nodes, dirs] records.
+__device__ int build_candidate(const GapArgs& A, long long t0, int start, int end, const int* rec,
+                               int n_gaps, unsigned long long combo, int* out_node, signed char* out_dir) {
+  // rec layout: for each gap q: [ps, pe, n_paths, first_record_offset] (4 ints)
+  // product(*lists): the LAST gap varies fastest
+  int n = 0;
+  int q = 0;
+  int i = start;
+  int prev_pe = -1;
+  // choice for gap q = (combo / prod_{j>q} n_j) % n_q
+  while (i <= end) {
+    if (q < n_gaps && rec[4 * q] == i) {
+      int ps = rec[4 * q], pe = rec[4 * q + 1], np = rec[4 * q + 2];
+      unsigned long long div = 1;
+      for (int j = q + 1; j < n_gaps; ++j) div *= (unsigned long long)rec[4 * j + 2];
+      int pick = (int)((combo / div) % (unsigned long long)np);
+      const int* p = A.pool + rec[4 * q + 3];
+      for (int s = 0; s < pick; ++s) p += 1 + 2 * p[0];
+      int L = p[0];
+      if (prev_pe == ps && n > 0) --n;  // shared endpoint: the later replacement overwrites it
+      for (int j = 0; j < L; ++j) {
+        out_node[n] = p[1 + j];
+        out_dir[n] = (signed char)p[1 + L + j];
+        ++n;
+      }
+      prev_pe = pe;
+      i = pe;
+      ++q;
+      if (!(q < n_gaps && rec[4 * q] == pe)) i = pe + 1;
+    } else {
+      out_node[n] = A.a.tok_node[t0 + i];
+      out_dir[n] = A.a.tok_dir[t0 + i];
+      ++n;
+      ++i;
+    }
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(64) void k_corr_gapped(GapArgs A) {
+  const CorrArgs& a = A.a;
+  const GView& g = A.g;
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  int* my = A.cand + gtid * (long long)A.cand_stride;
+  for (long long gi = gtid; gi < A.n_gapped; gi += gstride) {
+    const long long r = A.gapped_reads[gi];
+    const long long t0 = a.read_off[r];
+    const int L0 = (int)(a.read_off[r + 1] - t0);
+    const int start = a.r_start[r], end = a.r_end[r];
+    const long long dst = a.tmp_off[r];
+    // ---- pass 1: count paths per None run
+    int n_gaps = 0;
+    long long need = 0;
+    bool dead_end = false;
+    {
+      GapIter it{t0, a.tok_node, start, end, start, -1, -1};
+      while (it.next()) {
+        PathSink sink{nullptr, 0, 0};
+        dfs_paths(g, a.tok_node[t0 + it.ps], a.tok_dir[t0 + it.ps], a.tok_node[t0 + it.pe], 2 * g.k, &sink);
+        if (sink.n_paths == 0) dead_end = true;
+        need += sink.used;
+        ++n_gaps;
+      }
+    }
+    bool keep_orig = dead_end;  // product over an empty list: possible_paths == [] (:1292-1293)
+    int* rec = nullptr;
+    if (!keep_orig) {
+      // ---- reserve pool space: 4 ints per gap + the path records
+      unsigned long long want = (unsigned long long)need + 4ull * n_gaps;
+      unsigned long long base = atomicAdd(A.pool_used, want);
+      if (base + want > A.pool_cap) {
+        A.status[ST_OVERFLOW] = 3;  // host grows the pool and re-runs
+        a.new_len[r] = 0;
+        continue;
+      }
+      rec = A.pool + base;
+      int* wr = rec + 4 * n_gaps;
+      GapIter it{t0, a.tok_node, start, end, start, -1, -1};
+      int q = 0;
+      while (it.next()) {
+        PathSink sink{wr, 0, 0};
+        dfs_paths(g, a.tok_node[t0 + it.ps], a.tok_dir[t0 + it.ps], a.tok_node[t0 + it.pe], 2 * g.k, &sink);
+        rec[4 * q] = it.ps;
+        rec[4 * q + 1] = it.pe;
+        rec[4 * q + 2] = sink.n_paths;
+        rec[4 * q + 3] = (int)(wr - A.pool);
+        wr += sink.used;
+        ++q;
+      }
+    }
+    if (keep_orig) {
+      for (int i = 0; i < L0; ++i) {
+        a.tmp_tok[dst + i] = a.tokens[t0 + i];
+        if (a.have_pos) {
+          a.tmp_gs[dst + i] = a.gstart[t0 + i];
+          a.tmp_ge[dst + i] = a.gend[t0 + i];
+        }
+      }
+      a.new_len[r] = (unsigned int)L0;
+      A.final_cls[r] = RC_KEEP_ORIG;
+      continue;
+    }
+    // ---- enumerate the cartesian product in itertools.product order
+    unsigned long long n_combo = 1;
+    for (int q = 0; q < n_gaps; ++q) {
+      n_combo *= (unsigned long long)rec[4 * q + 2];
+      if (n_combo > (1ull << 40)) n_combo = 1ull << 40;  // unreachable in practice; bounds the loop
+    }
+    const int cap_nodes = (int)a.bound[r];
+    int* c_node = my;                                         // [cap_nodes]
+    signed char* c_dir = reinterpret_cast<signed char*>(my + cap_nodes);  // [cap_nodes]
+    int* c_gene = my + cap_nodes + (cap_nodes + 3) / 4;       // [cap_nodes + k]
+    int best_shared = 0;
+    unsigned long long best_sum = 0, best_len = 1;  // mean coverage 0
+    int best_n = -1;
+    for (unsigned long long combo = 0; combo < n_combo; ++combo) {
+      int n = build_candidate(A, t0, start, end, rec, n_gaps, combo, c_node, c_dir);
+      // genes (get_annotation_for_read): k-1 genes of the first node + last gene of every node
+      int ng = 0;
+      for (int j = 0; j < g.k - 1; ++j) c_gene[ng++] = oriented_tok(g, c_node[0], c_dir[0], j);
+      unsigned long long csum = 0;
+      for (int j = 0; j < n; ++j) {
+        c_gene[ng++] = oriented_tok(g, c_node[j], c_dir[j], g.k - 1);
+        csum += g.n_cov[c_node[j]];
+      }
+      // len(set(genes) & set(original genes))
+      int shared = 0;
+      for (int j = 0; j < ng; ++j) {
+        int tk = c_gene[j];
+        bool dup = false;
+        for (int q = 0; q < j && !dup; ++q) dup = (c_gene[q] == tk);
+        if (dup) continue;
+        bool hit = false;
+        for (int q = 0; q < L0 && !hit; ++q) hit = (a.tokens[t0 + q] == tk);
+        shared += hit ? 1 : 0;
+      }
+      // strictly more shared genes, or equal and strictly higher mean coverage (:1301-1308)
+      bool better = shared > best_shared ||
+                    (shared == best_shared && csum * best_len > best_sum * (unsigned long long)n);
+      if (better) {
+        best_shared = shared;
+        best_sum = csum;
+        best_len = (unsigned long long)n;
+        best_n = ng;
+        for (int j = 0; j < ng; ++j) a.tmp_tok[dst + j] = c_gene[j];
+      }
+    }
+    a.new_len[r] = (unsigned int)best_n;
+  }
+}
+
+// ---- positions for gapped reads: one wave per read
+#define NW_LDS_N 1024       // rows kept in LDS (rolling anti-diagonals, op list)
+#define NW_LDS_CELLS 16384  // pointer-matrix cells kept in LDS (one byte each)
+
+struct NwArgs {
+  CorrArgs a;
+  const int* gapped_reads;
+  long long n_gapped;
+  const unsigned char* final_cls;
+  const long long* big_off;  // per gapped read: byte offset of its global scratch (big reads only)
+  unsigned char* big_buf;
+};
+
+__global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
+  __shared__ unsigned char s_ptr[NW_LDS_CELLS];
+  __shared__ int s_diag[3 * (NW_LDS_N + 1)];
+  __shared__ unsigned char s_ops[2 * NW_LDS_N];
+  const CorrArgs& a = A.a;
+  const long long gi = blockIdx.x;
+  if (gi >= A.n_gapped) return;
+  const long long r = A.gapped_reads[gi];
+  if (A.final_cls[r] == RC_KEEP_ORIG) return;  // original genes kept: positions untouched
+  const int lane = threadIdx.x;
+  const long long t0 = a.read_off[r];
+  const int M = (int)(a.read_off[r + 1] - t0);  // y = original genes
+  const int N = (int)a.new_len[r];              // x = corrected genes
+  const long long dst = a.tmp_off[r];
+  const int* x = a.tmp_tok + dst;
+  const int* y = a.tokens + t0;
+  unsigned char* P = s_ptr;
+  int* dg = s_diag;
+  unsigned char* ops = s_ops;
+  const bool small = (N <= NW_LDS_N && M <= NW_LDS_N && (long long)N * M <= NW_LDS_CELLS);
+  if (!small) {
+    unsigned char* base = A.big_buf + A.big_off[gi];
+    P = base;
+    ops = base + (long long)N * M;
+    dg = reinterpret_cast<int*>(base + (((long long)N * M + N + M + 15) & ~15ll));
+  }
+  int* d0 = dg;            // anti-diagonal d-2, entry i+1 holds F[i, d-2-i]
+  int* d1 = d0 + (N + 1);  // anti-diagonal d-1
+  int* d2 = d1 + (N + 1);  // anti-diagonal d
+  // borders (:1439-1445): F[-1,-1] = 0, F[i,-1] = -i, F[-1,j] = -j
+  for (int d = 0; d <= N + M - 2; ++d) {
+    int ilo = d - (M - 1) > 0 ? d - (M - 1) : 0;
+    int ihi = d < N - 1 ? d : N - 1;
+    for (int i = ilo + lane; i <= ihi; i += 64) {
+      int j = d - i;
+      int f_dd = (i == 0 && j == 0) ? 0 : (i == 0 ? -(j - 1) : (j == 0 ? -(i - 1) : d0[i]));
+      int f_im1 = (i == 0) ? -j : d1[i];      // F[i-1, j]
+      int f_jm1 = (j == 0) ? -i : d1[i + 1];  // F[i, j-1]
+      int s_diag_ = f_dd + (x[i] == y[j] ? 1 : 0);
+      int s_left = f_im1 - 1;  // pointer LEFT = (-1, 0)
+      int s_up = f_jm1 - 1;    // pointer UP   = (0, -1)
+      // max over (score, pointer) tuples: on ties UP (0,-1) > LEFT (-1,0) > DIAG (-1,-1)
+      int best = s_diag_;
+      unsigned char ptr = 0;
+      if (s_left >= best) { best = s_left; ptr = 1; }
+      if (s_up >= best) { best = s_up; ptr = 2; }
+      d2[i + 1] = best;
+      P[(long long)i * M + j] = ptr;
+    }
+    __syncthreads();
+    int* t = d0; d0 = d1; d1 = d2; d2 = t;
+  }
+  if (lane != 0) return;
+  // traceback (:1458-1480); ops are collected back to front
+  int n_ops = 0;
+  int i = N - 1, j = M - 1;
+  while (i >= 0 && j >= 0) {
+    unsigned char p = P[(long long)i * M + j];
+    ops[n_ops++] = p;
+    if (p == 0) { --i; --j; }
+    else if (p == 1) --i;
+    else --j;
+  }
+  while (i >= 0) { ops[n_ops++] = 1; --i; }
+  while (j >= 0) { ops[n_ops++] = 2; --j; }
+  // carry positions over (:1314-1325), alignment walked front to back.  A mismatching
+  // diagonal column yields (None, None) WITHOUT consuming an original position.
+  const long long NONE = (long long)0x8000000000000000ull;
+  int xi = 0, yj = 0, cur = 0, out = 0;
+  for (int o = n_ops - 1; o >= 0; --o) {
+    unsigned char p = ops[o];
+    if (p == 0) {
+      if (x[xi] == y[yj]) {
+        a.tmp_gs[dst + out] = a.gstart[t0 + cur];
+        a.tmp_ge[dst + out] = a.gend[t0 + cur];
+        ++cur;
+      } else {
+        a.tmp_gs[dst + out] = NONE;
+        a.tmp_ge[dst + out] = NONE;
+      }
+      ++out; ++xi; ++yj;
+    } else if (p == 1) {
+      a.tmp_gs[dst + out] = NONE;
+      a.tmp_ge[dst + out] = NONE;
+      ++out; ++xi;
+    } else {
+      ++cur; ++yj;
+    }
+  }
+  // replace_invalid_gene_positions (:1669-1691): prev_end is the end of the last entry that
+  // was valid BEFORE repair; the look-ahead only sees entries that are still unrepaired.
+  long long prev_end = 0;
+  const long long rl = a.read_len ? a.read_len[r] : 0;
+  for (int q = 0; q < N; ++q) {
+    long long sv = a.tmp_gs[dst + q], ev = a.tmp_ge[dst + q];
+    if (ev != NONE) prev_end = ev;
+    if (sv == NONE && ev == NONE) {
+      long long nxt = NONE;
+      for (int w = q + 1; w < N; ++w)
+        if (a.tmp_gs[dst + w] != NONE) { nxt = a.tmp_gs[dst + w]; break; }
+      a.tmp_gs[dst + q] = prev_end;
+      a.tmp_ge[dst + q] = (nxt != NONE) ? nxt : rl - 1;
+    }
+  }
+}
+
+// ---- compaction into the corrected CSR
+__global__ void k_corr_keep(const unsigned int* __restrict__ new_len, long long n_reads,
+                            unsigned int* __restrict__ keep) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads) keep[r] = new_len[r] > 0 ? 1u : 0u;  // len(list_of_genes) > 0 (:1130)
+}
+
+struct PackArgs {
+  CorrArgs a;
+  const unsigned int* keep;
+  const long long* new_idx;    // exscan(keep)
+  const long long* new_off;    // exscan(new_len)
+  const unsigned char* final_cls;
+  int* o_tok;
+  long long* o_off;
+  int* o_orig;
+  unsigned char* o_changed;
+  long long* o_gs;
+  long long* o_ge;
+  long long* o_rl;
+};
+
+__global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
+  const CorrArgs& a = A.a;
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.n_reads || !A.keep[r]) return;
+  const int lane = threadIdx.x & 63;
+  const long long src = a.tmp_off[r], dst = A.new_off[r], n = a.new_len[r];
+  for (long long i = lane; i < n; i += 64) {
+    A.o_tok[dst + i] = a.tmp_tok[src + i];
+    if (a.have_pos) {
+      A.o_gs[dst + i] = a.tmp_gs[src + i];
+      A.o_ge[dst + i] = a.tmp_ge[src + i];
+    }
+  }
+  if (lane == 0) {
+    long long q = A.new_idx[r];
+    A.o_off[q] = dst;
+    A.o_orig[q] = (int)r;
+    unsigned char cls = A.final_cls[r];
+    A.o_changed[q] = (cls == RC_TRIM || cls == RC_GAPPED) ? 1 : 0;
+    if (a.read_len) A.o_rl[q] = a.read_len[r];
+  }
+}
+
+__global__ void k_list_gapped(const unsigned char* __restrict__ cls, long long n_reads,
+                              unsigned int* __restrict__ flag) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads) flag[r] = cls[r] == RC_GAPPED ? 1u : 0u;
+}
+
+__global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const long long* __restrict__ pos,
+                                 long long n_reads, int* __restrict__ out) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && flag[r]) out[pos[r]] = (int)r;
+}
+
+// global NW scratch size of gapped read gi (0 when it fits the LDS path)
+__global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
+                           const long long* __restrict__ read_off, const unsigned int* __restrict__ new_len,
+                           const unsigned char* __restrict__ final_cls, long long* __restrict__ size) {
+  long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= n_gapped) return;
+  long long r = gapped[gi];
+  long long N = new_len[r], M = read_off[r + 1] - read_off[r];
+  bool small = (N <= NW_LDS_N && M <= NW_LDS_N && N * M <= NW_LDS_CELLS);
+  long long bytes = 0;
+  if (!small && final_cls[r] != RC_KEEP_ORIG)
+    bytes = ((N * M + N + M + 15) & ~15ll) + ((3 * (N + 1) * 4 + 15) & ~15ll);
+  size[gi] = bytes;
+}
+
+__global__ void k_max_u32(const unsigned int* __restrict__ v, const unsigned char* __restrict__ cls,
+                          long long n, unsigned long long* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long x = (i < n && cls[i] == RC_GAPPED) ? v[i] : 0;
+  for (int d = 32; d > 0; d >>= 1) {
+    unsigned long long y = __shfl_down(x, d, 64);
+    x = x > y ? x : y;
+  }
+  if ((threadIdx.x & 63) == 0 && x) atomicMax(out, x);
+}
+
+extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_out_tokens) {
+  NEED_BUILT(c);
+  hipStream_t st = c->stream;
+  const long long R = c->n_reads;
+  stages_reset(c);
+  c->have_corrected = false;
+  // per-read scratch arrays (they must survive the scans, so each group has its own buffer)
+  size_t per_read = (size_t)(R + 2);
+  AMGCHK(c->s0.ensure(per_read * (1 + 1) + 64));                 // cls, final_cls
+  AMGCHK(c->s1.ensure(per_read * sizeof(int) * 2 + per_read * sizeof(long long) * 2 + 64));  // r_start, r_end, nw sizes/offsets
+  AMGCHK(c->s2.ensure(per_read * sizeof(unsigned int) * 3));     // bound, new_len, keep/flag
+  AMGCHK(c->s3.ensure(per_read * sizeof(long long) * 3));        // tmp_off, new_idx, new_off
+  unsigned char* cls = c->s0.as<unsigned char>();
+  unsigned char* final_cls = cls + per_read;
+  int* r_start = c->s1.as<int>();
+  int* r_end = r_start + per_read;
+  unsigned int* bound = c->s2.as<unsigned int>();
+  unsigned int* new_len = bound + per_read;
+  unsigned int* flag = new_len + per_read;
+  long long* tmp_off = c->s3.as<long long>();
+  long long* new_idx = tmp_off + per_read;
+  long long* new_off = new_idx + per_read;
+
+  CorrArgs a;
+  a.tokens = c->tokens.as<int>();
+  a.read_off = c->read_off.as<long long>();
+  a.tok_node = c->tok_node.as<int>();
+  a.tok_dir = c->tok_dir.as<signed char>();
+  a.read_fix = c->read_fix.as<unsigned char>();
+  a.gstart = c->have_pos ? c->gene_start.as<long long>() : nullptr;
+  a.gend = c->have_pos ? c->gene_end.as<long long>() : nullptr;
+  a.read_len = c->have_read_len ? c->read_len.as<long long>() : nullptr;
+  a.n_reads = R;
+  a.k = c->k;
+  a.flip = c->two_v - 1;
+  a.have_pos = c->have_pos ? 1 : 0;
+  a.cls = cls;
+  a.r_start = r_start;
+  a.r_end = r_end;
+  a.bound = bound;
+  a.tmp_off = tmp_off;
+  a.new_len = new_len;
+  a.tmp_tok = nullptr;
+  a.tmp_gs = a.tmp_ge = nullptr;
+
+  stage_begin(c, "correct_classify");
+  HIPCHK(hipMemsetAsync(bound, 0, per_read * sizeof(unsigned int) * 3, st));
+  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);
+  AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
+  long long tmp_total = 0;
+  unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
+  HIPCHK(hipMemsetAsync(mx, 0, sizeof(unsigned long long), st));
+  if (R > 0) hipLaunchKernelGGL(k_max_u32, dim3(nblk(R, 256)), dim3(256), 0, st, bound, cls, R, mx);
+  unsigned long long max_bound = 0;
+  HIPCHK(hipMemcpyAsync(&tmp_total, tmp_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&max_bound, mx, sizeof(max_bound), hipMemcpyDeviceToHost, st));
+  // list of gapped reads
+  if (R > 0) hipLaunchKernelGGL(k_list_gapped, dim3(nblk(R, 256)), dim3(256), 0, st, cls, R, flag);
+  AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
+  long long n_gapped = 0;
+  HIPCHK(hipMemcpyAsync(&n_gapped, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  stage_end(c);
+
+  AMGCHK(c->c_tokens_buf.ensure((size_t)(tmp_total + 4) * sizeof(int)));  // temp tokens live here first
+  DevBuf& tmpTok = c->s4;
+  AMGCHK(tmpTok.ensure((size_t)(tmp_total + 4) * sizeof(int)));
+  a.tmp_tok = tmpTok.as<int>();
+  DevBuf& tmpPos = c->s5;
+  if (c->have_pos) {
+    AMGCHK(tmpPos.ensure((size_t)(tmp_total + 4) * sizeof(long long) * 2));
+    a.tmp_gs = tmpPos.as<long long>();
+    a.tmp_ge = a.tmp_gs + (tmp_total + 4);
+  }
+  HIPCHK(hipMemcpyAsync(final_cls, cls, (size_t)R, hipMemcpyDeviceToDevice, st));
+
+  stage_begin(c, "correct_simple");
+  if (R > 0) hipLaunchKernelGGL(k_corr_simple, dim3(nblk(R, 4)), dim3(256), 0, st, a);
+  stage_end(c);
+
+  if (n_gapped > 0) {
+    stage_begin(c, "correct_gapped");
+    // gapped read list, path pool, candidate scratch: their own allocations
+    DevBuf& glist = c->c_orig;  // free until the pack step
+    AMGCHK(glist.ensure((size_t)(n_gapped + 1) * sizeof(int)));
+    hipLaunchKernelGGL(k_scatter_gapped, dim3(nblk(R, 256)), dim3(256), 0, st, flag, new_idx, R,
+                       glist.as<int>());
+    const unsigned int threads_total = 64u * 2048u;
+    unsigned int cand_stride = (unsigned int)(2 * max_bound + (max_bound + 3) / 4 + c->k + 16);
+    DevBuf& cand = c->c_gstart;  // free until the pack step
+    AMGCHK(cand.ensure((size_t)threads_total * cand_stride * sizeof(int)));
+    unsigned long long pool_cap = (unsigned long long)n_gapped * 64ull + (1ull << 20);
+    for (int attempt = 0;; ++attempt) {
+      DevBuf& pool = c->c_gend;  // free until the pack step
+      AMGCHK(pool.ensure((size_t)pool_cap * sizeof(int)));
+      unsigned long long* used = c->status.as<unsigned long long>() + ST_COMPACT_A;
+      HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+      GapArgs G;
+      G.a = a;
+      G.g = make_view(c);
+      G.gapped_reads = glist.as<int>();
+      G.n_gapped = n_gapped;
+      G.pool = pool.as<int>();
+      G.pool_cap = pool_cap;
+      G.pool_used = used;
+      G.status = c->status.as<unsigned long long>();
+      G.cand = cand.as<int>();
+      G.cand_stride = cand_stride;
+      G.final_cls = final_cls;
+      unsigned int blocks = (unsigned int)((n_gapped + 63) / 64);
+      if (blocks > 2048u) blocks = 2048u;
+      hipLaunchKernelGGL(k_corr_gapped, dim3(blocks), dim3(64), 0, st, G);
+      unsigned long long hs[ST_WORDS];
+      HIPCHK(hipMemcpyAsync(hs, c->status.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (!hs[ST_OVERFLOW]) break;
+      if (attempt >= 8) return amg_fail(AMG_E_OVERFLOW, "correct_reads: path pool overflow");
+      pool_cap = hs[ST_COMPACT_A] * 2 + (1ull << 20);
+    }
+    stage_end(c);
+
+    if (c->have_pos) {
+      stage_begin(c, "correct_positions");
+      // global scratch only for reads too large for the LDS path
+      long long* nw_size = reinterpret_cast<long long*>(
+          ((uintptr_t)(c->s1.as<int>() + 2 * per_read) + 15) & ~(uintptr_t)15);
+      long long* nw_off = nw_size + per_read;
+      HIPCHK(hipMemsetAsync(nw_size, 0, (size_t)(n_gapped + 1) * sizeof(long long), st));
+      hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
+                         n_gapped, a.read_off, new_len, final_cls, nw_size);
+      AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
+      long long big_total = 0;
+      HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      DevBuf& big = c->c_gend;  // the path pool is done
+      AMGCHK(big.ensure((size_t)big_total + 64));
+      NwArgs W;
+      W.a = a;
+      W.gapped_reads = c->c_orig.as<int>();
+      W.n_gapped = n_gapped;
+      W.final_cls = final_cls;
+      W.big_off = nw_off;
+      W.big_buf = big.as<unsigned char>();
+      hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
+      stage_end(c);
+    }
+  }
+
+  // ---- pack
+  stage_begin(c, "correct_pack");
+  if (R > 0) hipLaunchKernelGGL(k_corr_keep, dim3(nblk(R, 256)), dim3(256), 0, st, new_len, R, flag);
+  HIPCHK(hipMemsetAsync(flag + R, 0, sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(new_len + R, 0, sizeof(unsigned int), st));
+  AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
+  AMGCHK(prim_exscan_u32_to_i64(c, new_len, new_off, (size_t)R + 1));
+  long long out_reads = 0, out_tokens = 0;
+  HIPCHK(hipMemcpyAsync(&out_reads, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&out_tokens, new_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(c->c_tokens_buf.ensure((size_t)(out_tokens + 64) * sizeof(int)));
+  AMGCHK(c->c_read_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
+  AMGCHK(c->c_orig.ensure((size_t)(out_reads + 2) * sizeof(int)));
+  AMGCHK(c->c_changed.ensure((size_t)(out_reads + 2)));
+  if (c->have_pos) {
+    AMGCHK(c->c_gstart.ensure((size_t)(out_tokens + 64) * sizeof(long long)));
+    AMGCHK(c->c_gend.ensure((size_t)(out_tokens + 64) * sizeof(long long)));
+  }
+  if (c->have_read_len) AMGCHK(c->c_read_len.ensure((size_t)(out_reads + 2) * sizeof(long long)));
+  PackArgs Pk;
+  Pk.a = a;
+  Pk.keep = flag;
+  Pk.new_idx = new_idx;
+  Pk.new_off = new_off;
+  Pk.final_cls = final_cls;
+  Pk.o_tok = c->c_tokens_buf.as<int>();
+  Pk.o_off = c->c_read_off.as<long long>();
+  Pk.o_orig = c->c_orig.as<int>();
+  Pk.o_changed = c->c_changed.as<unsigned char>();
+  Pk.o_gs = c->have_pos ? c->c_gstart.as<long long>() : nullptr;
+  Pk.o_ge = c->have_pos ? c->c_gend.as<long long>() : nullptr;
+  Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
+  if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4)), dim3(256), 0, st, Pk);
+  HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
+                        hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  stage_end(c);
+  c->c_reads = out_reads;
+  c->c_tokens = out_tokens;
+  c->have_corrected = true;
+  if (n_out_reads) *n_out_reads = out_reads;
+  if (n_out_tokens) *n_out_tokens = out_tokens;
+  return AMG_OK;
+}
+
 extern "C" int amg_get_corrected(amg_ctx* c, int32_t* tokens, int64_t* read_offsets, int32_t* orig_read,
                                  uint8_t* changed, int64_t* gene_start, int64_t* gene_end) {
-  (void)c; (void)tokens; (void)read_offsets; (void)orig_read; (void)changed; (void)gene_start; (void)gene_end;
-  return amg_fail(AMG_E_STATE, "amg_get_corrected: not implemented yet");
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  auto get = [&](void* dst, const DevBuf& src, size_t bytes) -> int {
+    if (!dst || !bytes) return AMG_OK;
+    HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, st));
+    return AMG_OK;
+  };
+  AMGCHK(get(tokens, c->c_tokens_buf, (size_t)c->c_tokens * sizeof(int32_t)));
+  AMGCHK(get(read_offsets, c->c_read_off, (size_t)(c->c_reads + 1) * sizeof(int64_t)));
+  AMGCHK(get(orig_read, c->c_orig, (size_t)c->c_reads * sizeof(int32_t)));
+  AMGCHK(get(changed, c->c_changed, (size_t)c->c_reads));
+  if (c->have_pos) {
+    AMGCHK(get(gene_start, c->c_gstart, (size_t)c->c_tokens * sizeof(int64_t)));
+    AMGCHK(get(gene_end, c->c_gend, (size_t)c->c_tokens * sizeof(int64_t)));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
 }
+
 extern "C" int amg_adopt_corrected(amg_ctx* c) {
-  (void)c;
-  return amg_fail(AMG_E_STATE, "amg_adopt_corrected: not implemented yet");
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
+  std::swap(c->tokens, c->c_tokens_buf);
+  std::swap(c->read_off, c->c_read_off);
+  if (c->have_pos) {
+    std::swap(c->gene_start, c->c_gstart);
+    std::swap(c->gene_end, c->c_gend);
+  }
+  if (c->have_read_len) std::swap(c->read_len, c->c_read_len);
+  c->n_reads = c->c_reads;
+  c->n_tokens = c->c_tokens;
+  c->have_corrected = false;
+  c->built = false;
+  return AMG_OK;
 }
+
 extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, const int64_t* pat_offsets,
                                   int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read, int32_t* hit_pos) {
   (void)c; (void)which; (void)pat; (void)pat_offsets; (void)n_pat; (void)hit_offsets; (void)hit_read; (void)hit_pos;

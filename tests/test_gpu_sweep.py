@@ -1,0 +1,107 @@
+"""GPU parity of filter -> correct_reads -> rebuild -> clip -> correct_reads -> rebuild
+(the cleaning sweep of graph_utils.py:145-166) against the CPU oracle, at the array level
+of the C ABI."""
+import numpy as np
+import pytest
+
+import procedures as P
+from helpers import compare_engine_to_oracle, oracle_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from amira_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def flat_positions(read_ids, reads, pos):
+    gs = np.fromiter((p[0] for r in read_ids for p in pos[r]), dtype=np.int64)
+    ge = np.fromiter((p[1] for r in read_ids for p in pos[r]), dtype=np.int64)
+    assert len(gs) == sum(len(reads[r]) for r in read_ids)
+    return gs, ge
+
+
+def check_corrected(eng, vocab, read_ids, want_genes, want_pos):
+    n_reads, n_tokens = eng.correct_reads()
+    out = eng.corrected(n_reads, n_tokens, want_pos is not None)
+    got_ids = [read_ids[i] for i in out["orig_read"]]
+    assert got_ids == list(want_genes.keys())
+    offs = out["read_offsets"]
+    for i, rid in enumerate(got_ids):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert vocab.decode(out["tokens"][a:b]) == list(want_genes[rid]), rid
+        if want_pos is not None:
+            got = list(zip(out["gene_start"][a:b].tolist(), out["gene_end"][a:b].tolist()))
+            assert got == [tuple(p) for p in want_pos[rid]], rid
+    return got_ids, out
+
+
+def run_sweep(eng, reads, pos, fq, k, min_cov=3):
+    from amira_amd import tokenize
+    from amira_oracle import GeneMerGraph
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+    eng.set_positions(gs, ge, rl)
+    pos = {r: list(v) for r, v in pos.items()}
+
+    eng.build(k)
+    g1 = GeneMerGraph(reads, k, pos)
+    compare_engine_to_oracle(eng, oracle_arrays(g1, vocab, read_ids, offs, k))
+    eng.filter(min_cov, 1)
+    g1.filter_graph(min_cov, 1)
+    compare_engine_to_oracle(eng, oracle_arrays(g1, vocab, read_ids, offs, k), live_only=True)
+    r2, p2 = g1.correct_reads(fq)
+    ids2, out2 = check_corrected(eng, vocab, read_ids, r2, p2)
+
+    eng.adopt_corrected()
+    eng.build(k)
+    g2 = GeneMerGraph(r2, k, p2)
+    compare_engine_to_oracle(eng, oracle_arrays(g2, vocab, ids2, out2["read_offsets"], k))
+    removed = eng.remove_short_linear_paths(k)
+    order = {h: i for i, h in enumerate(g2.get_nodes())}
+    want_removed = sorted(order[h] for h in g2.remove_short_linear_paths(k))
+    assert sorted(removed.tolist()) == want_removed
+    compare_engine_to_oracle(eng, oracle_arrays(g2, vocab, ids2, out2["read_offsets"], k), live_only=True)
+    r3, p3 = g2.correct_reads(fq)
+    ids3, out3 = check_corrected(eng, vocab, ids2, r3, p3)
+
+    eng.adopt_corrected()
+    eng.build(k)
+    g3 = GeneMerGraph(r3, k, p3)
+    compare_engine_to_oracle(eng, oracle_arrays(g3, vocab, ids3, out3["read_offsets"], k))
+    return len(want_removed)
+
+
+@pytest.mark.parametrize("seed,N,L,V,k,err", [(7, 400, 30, 300, 5, 0.03), (11, 400, 24, 200, 3, 0.03),
+                                              (13, 300, 40, 250, 7, 0.02), (17, 800, 40, 150, 5, 0.05),
+                                              (29, 1500, 40, 1000, 5, 0.02), (31, 600, 60, 400, 5, 0.04)])
+def test_sweep_synthetic(eng, seed, N, L, V, k, err):
+    reads, pos, fq = P.synth_inputs(seed, N, L, V, err)
+    run_sweep(eng, reads, pos, fq, k)
+
+
+@pytest.mark.parametrize("name,k", [("nine", 3), ("nine", 5), ("three", 5), ("four", 5), ("six", 5)])
+def test_sweep_fixture(eng, name, k):
+    calls, pos = P.fixture(name)
+    lengths = {r: (pos[r][-1][1] + 200 if pos[r] else 100) for r in pos}
+    run_sweep(eng, calls, pos, P.FakeFastq(lengths), k)
+
+
+def test_low_coverage_components(eng):
+    from amira_amd import tokenize
+    from amira_oracle import GeneMerGraph
+    calls, _ = P.fixture("nine")
+    vocab, toks, offs, read_ids = tokenize(calls)
+    eng.set_reads(toks, offs, vocab.two_v)
+    eng.build(3)
+    g = GeneMerGraph(calls, 3)
+    for m in (5, 40):
+        eng.remove_low_coverage_components(m)
+        g.remove_low_coverage_components(m)
+        compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
