@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — gene-mer graph hot path on MI355X (driver contract: see the task brief).
+"""bench.py — read -> corrected gene-mer graph hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg3-sweep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3-sweep|cfg3|cfg2]
 
-A "step" is one pass of the hot path over the resident synthetic read set:
-  cfg2        100 k reads x 40 genes, k=5, 5 k-gene vocabulary: graph build + coverage
-  cfg3        1 M reads x 60 genes, k=5, 20 k-gene vocabulary: graph build
-  cfg3-sweep  cfg3 + error-correction sweep (build -> filter(3,1) -> correct -> build ->
-              clip(k) -> correct -> build)
-Inputs (CSR tokens) are resident in HBM before the timed region.  Prints ONE JSON line.
+A "step" is one pass of the hot path over one batch of synthetic gene calls whose CSR
+token arrays (and gene positions) are already resident in HBM:
+  cfg3-sweep (default) 1 M reads x 60 genes, k=5, 20 k-gene vocabulary, 2 % substitutions:
+             build -> filter_graph(3,1) -> correct_reads -> build ->
+             remove_short_linear_paths(5) -> correct_reads -> build
+             (the cleaning sweep of graph_utils.py:145-166; BASELINE.json configs[2])
+  cfg3       the first build of that sweep only
+  cfg2       100 k reads x 40 genes, k=5, 5 k-gene vocabulary: build + coverage (configs[1])
+Prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+Multi-GPU (torch.distributed.run): every rank processes its own N-read shard of the global
+stream (weak scaling, no data-path collective in this round).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -29,18 +33,28 @@ WORKLOADS = {
                  desc="synthetic 1M reads x 60 genes, k=5, 20k-gene vocab: graph build"),
     "cfg3-sweep": dict(N=1_000_000, L=60, V=20_000, k=5, err=0.02, seed=20250905 + 3, sweep=True,
                        desc="synthetic 1M reads x 60 genes, k=5, 20k-gene vocab: build + "
-                            "error-correction sweep"),
+                            "error-correction sweep (build, filter(3,1), correct, build, clip(5), "
+                            "correct, build)"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes_per_window(k, L):
-    """SURVEY.md section 8(d), split per kernel (tokens int32, slot/node id int32, dir int8,
-    counters uint32, first-seen uint64)."""
+def stage_bytes(stage, k, L, n_windows, n_reads, n_gapped):
+    """ALGORITHMIC bytes one launch of the named stage's dominant kernel moves (DESIGN.md
+    "Kernels"): tokens int32, slot/node id int32, dir int8, counters uint32, first-seen
+    uint64, positions 2 x int64."""
     tok = 4.0 * L / (L - k + 1)
-    node_kernel = tok + 5 + (4 * k + 8)            # token read + (slot, dir) write + key/ctr RMW
-    edge_kernel = (4 + 1) + 4 + (12 + 8) * (L - k) / (L - k + 1)  # slot,dir read + id write + edge RMW
-    return node_kernel, edge_kernel
+    per_window = {
+        "node_upsert": tok + 5 + (4 * k + 8),
+        "edge_upsert": 5 + 4 + (12 + 8) * (L - k) / (L - k + 1),
+    }
+    if stage in per_window:
+        return per_window[stage] * n_windows
+    if stage == "correct_positions":   # per gapped read: x, y tokens + positions in and out
+        return n_gapped * (L * 4 * 2 + L * 16 * 2)
+    if stage == "correct_gapped":      # per gapped read: window ids+dirs, tokens in, genes out
+        return n_gapped * ((L - k + 1) * 5 + L * 4 * 2)
+    return None
 
 
 def make_tokens(w, lo, hi):
@@ -56,34 +70,52 @@ def make_tokens(w, lo, hi):
 
 
 def cpu_baseline(w, budget_s=20.0):
-    """Pure-Python restatement of the reference (oracle/, same sha256+pickle work per
-    gene-mer as construct_gene.py:5-10) on a bounded sample of the same workload, 1 core."""
+    """Pure-Python restatement of the reference (oracle/: same sha256 + pickle work per
+    gene-mer as construct_gene.py:5-10) on a bounded sample of the same workload, 1 core —
+    the reference pipeline always builds with cores=1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from amira_amd import synth
-    from amira_oracle import GeneMerGraph, values
+    from amira_oracle import GeneMerGraph, driver, values
     values.CACHE_HASHES = False
-    n = 250
-    done_windows, spent, total_reads = 0, 0.0, 0
-    while spent < budget_s and total_reads < w["N"]:
-        ids, sts = synth.block_reads(w["seed"], total_reads, total_reads + n, w["L"], w["V"], w["err"])
-        reads = synth.to_read_dict(ids, sts, synth.gene_names(w["V"]), first=total_reads)
-        t = time.perf_counter()
-        GeneMerGraph(reads, w["k"])
-        spent += time.perf_counter() - t
-        done_windows += n * (w["L"] - w["k"] + 1)
-        total_reads += n
-    values.CACHE_HASHES = True
-    return {"value": done_windows / spent, "unit": "gene-mers/s", "cores": 1, "kind": "port",
-            "sample": f"{total_reads} reads of the same workload, build only, pure-Python oracle "
-                      f"with per-call sha256+pickle (reference cost model), {spent:.1f} s"}
+    L, k = w["L"], w["k"]
+    try:
+        if not w["sweep"]:
+            n, done, spent, first = 250, 0, 0.0, 0
+            while spent < budget_s and first < w["N"]:
+                ids, sts = synth.block_reads(w["seed"], first, first + n, L, w["V"], w["err"])
+                reads = synth.to_read_dict(ids, sts, synth.gene_names(w["V"]), first=first)
+                t = time.perf_counter()
+                GeneMerGraph(reads, k)
+                spent += time.perf_counter() - t
+                done += n * (L - k + 1)
+                first += n
+            sample = (f"{first} reads of the same stream, build only, pure-Python oracle with "
+                      f"per-call sha256+pickle (reference cost model), {spent:.1f} s")
+        else:
+            # a sweep needs depth to leave anything after filter_graph(3,1): same L, k, error
+            # rate, vocabulary scaled down so 1 200 reads give ~140x depth
+            n, V = 1200, 500
+            ids, sts = synth.block_reads(w["seed"], 0, n, L, V, w["err"])
+            reads = synth.to_read_dict(ids, sts, synth.gene_names(V))
+            pos = synth.positions_for(reads)
+            fq = driver.FakeFastq(synth.fake_fastq_lengths(reads))
+            t = time.perf_counter()
+            driver.correction_sweep(reads, pos, k, fq, 3)
+            spent = time.perf_counter() - t
+            done = n * (L - k + 1)
+            sample = (f"{n} reads x {L} genes, {V}-gene vocab (depth-preserving down-scale of the "
+                      f"workload), full sweep, pure-Python oracle with per-call sha256+pickle, {spent:.1f} s")
+    finally:
+        values.CACHE_HASHES = True
+    return {"value": done / spent, "unit": "gene-mers/s", "cores": 1, "kind": "port", "sample": sample}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
@@ -92,35 +124,79 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from amira_amd import Engine
 
-    # weak scaling: every rank holds N reads of the global stream (rank r: reads [rN, (r+1)N))
-    N = w["N"]
+    # weak scaling: rank r holds reads [r N, (r+1) N) of the global stream
+    N, L, k = w["N"], w["L"], w["k"]
     vocab, toks, offs = make_tokens(w, rank * N, (rank + 1) * N)
+    dev = torch.device("cuda", local_rank)
+    d_toks = torch.from_numpy(toks).to(dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    d_gs = d_ge = d_rl = None
+    if w["sweep"]:
+        d_gs = (torch.arange(L, dtype=torch.int64, device=dev) * 1000).repeat(N)
+        d_ge = d_gs + 899
+        d_rl = torch.full((N,), L * 1000 + 100, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     eng = Engine(local_rank)
-    eng.set_reads(toks, offs, vocab.two_v)  # H2D happens here, outside the timed region
-    n_windows = N * (w["L"] - w["k"] + 1)
+    n_windows = N * (L - k + 1)
+    stage_ms, info = {}, {}
 
-    def step():
-        eng.build(w["k"])
+    def tally():
+        for name, ms in eng.timings():  # HIP events recorded on the engine's own stream
+            stage_ms.setdefault(name, [0.0, 0])
+            stage_ms[name][0] += ms
+            stage_ms[name][1] += 1
+
+    def step(record):
+        # inputs are handed over as device pointers: D2D adoption, no PCIe in the step
+        eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v)
+        if w["sweep"]:
+            eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr())
+        eng.build(k)
+        if record:
+            tally()
+        if not w["sweep"]:
+            return
+        eng.filter(3, 1)
+        if record:
+            tally()
+            info["marked_reads"] = eng.counts()["n_reads_to_correct"] if "marked_reads" not in info else info["marked_reads"]
+        eng.correct_reads()
+        if record:
+            tally()
+        eng.adopt_corrected()
+        eng.build(k)
+        if record:
+            tally()
+        eng.remove_short_linear_paths(k)
+        if record:
+            tally()
+        eng.correct_reads()
+        if record:
+            tally()
+        eng.adopt_corrected()
+        eng.build(k)
+        if record:
+            tally()
 
     for _ in range(args.warmup):
-        step()
+        step(False)
+    # one instrumented step outside the timed region (per-stage HIP-event times, counts)
+    step(True)
+    counts = eng.counts()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     eng.sync()
-    stage_ms = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        for name, ms in eng.timings():   # HIP events recorded on the engine's own stream
-            stage_ms[name] = stage_ms.get(name, 0.0) + ms
+        step(False)
     eng.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -131,32 +207,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    counts = eng.counts()
     if rank == 0:
-        ms_per_step = dt * 1e3 / args.steps
-        value = world * n_windows * args.steps / dt
-        node_b, edge_b = algorithmic_bytes_per_window(w["k"], w["L"])
-        stage_avg = {k_: v / args.steps for k_, v in stage_ms.items()}
-        dom = max(("node_upsert", "edge_upsert"), key=lambda s: stage_avg.get(s, 0.0))
-        per_launch = (node_b if dom == "node_upsert" else edge_b) * n_windows
-        achieved = per_launch / (stage_avg[dom] * 1e-3) / 1e9
+        stage_avg = {n: v[0] / v[1] for n, v in stage_ms.items()}     # ms per launch
+        stage_tot = {n: v[0] for n, v in stage_ms.items()}            # ms per step
+        n_gapped = info.get("marked_reads", 0)
+        cands = {s: stage_bytes(s, k, L, n_windows, N, n_gapped) for s in stage_tot}
+        dom = max((s for s in cands if cands[s]), key=lambda s: stage_tot[s])
+        achieved = cands[dom] / (stage_avg[dom] * 1e-3) / 1e9
+        kernel_of = {"node_upsert": "k_node_upsert", "edge_upsert": "k_edges",
+                     "correct_positions": "k_corr_nw", "correct_gapped": "k_corr_gapped"}
         out = {
-            "metric": "gene-mers/s to GeneMerGraph (build + coverage)", "value": value,
-            "unit": "gene-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "metric": "gene-mers/s to corrected GeneMerGraph" if w["sweep"] else "gene-mers/s to GeneMerGraph (build + coverage)",
+            "value": world * n_windows * args.steps / dt, "unit": "gene-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": world * N * args.steps / dt,
-            "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": w["L"],
-                       "k": w["k"], "vocab": w["V"], "error_rate": w["err"],
-                       "gene_mers_per_gpu": n_windows, "nodes": counts["n_nodes"],
-                       "edges": counts["n_edges"],
+            "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": L, "k": k,
+                       "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
+                       "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
                        "multi_gpu": "independent read shards, no table merge (round 1)" if world > 1 else "n/a"},
-            "roofline": {"bound": "hbm", "kernel": "k_node_upsert" if dom == "node_upsert" else "k_edges",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": per_launch,
-                         "avg_launch_ms": stage_avg[dom]},
-            "stages_ms": stage_avg,
+            "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": cands[dom],
+                         "avg_launch_ms": stage_avg[dom], "launches_per_step": stage_ms[dom][1]},
+            "stages_ms_per_step": {n: round(v, 3) for n, v in stage_tot.items()},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
