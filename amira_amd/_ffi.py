@@ -45,6 +45,7 @@ def _load():
         "amg_stream": (P, [P]),
         "amg_set_reads": (C.c_int, [P, P, P, I64, I32, C.c_int]),
         "amg_set_positions": (C.c_int, [P, P, P, P, C.c_int]),
+        "amg_set_read_lengths": (C.c_int, [P, P, C.c_int]),
         "amg_build": (C.c_int, [P, I32]),
         "amg_counts": (C.c_int, [P, C.POINTER(Counts)]),
         "amg_get_nodes": (C.c_int, [P, P, P, P, P, P, P]),

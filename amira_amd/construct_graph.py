@@ -1,0 +1,959 @@
+"""GeneMerGraph — drop-in for amira/construct_graph.py (reference v0.11.0) on MI355X.
+
+Same constructor, accessors and passes as the reference class; the work is done by
+libamg.so (HIP, gfx950) through amira_amd.engine:
+
+    __init__                          amg_set_reads / amg_set_positions / amg_build
+    filter_graph                      amg_filter
+    remove_node & friends             amg_remove_nodes
+    remove_short_linear_paths         amg_remove_short_linear_paths
+    remove_low_coverage_components    amg_remove_low_coverage_components
+    correct_reads                     amg_correct_reads (+ amg_get_corrected)
+
+The device keeps the graph as integer arrays (DESIGN.md "Data layout").  The reference's
+object API (dicts keyed by 256-bit sha256 hashes, Node / Edge objects, per-read lists) is a
+VIEW that is materialised lazily from those arrays the first time an accessor needs it and
+dropped whenever a device pass changes the graph.  Hashes are computed on the host with the
+reference's own hashlib/pickle recipe, once per distinct node / edge.
+
+There is no CPU build path: constructing a graph without libamg.so or without a HIP device
+raises.  Host-side methods below only do what the reference also does in Python on top of a
+built graph (unitig gene strings, linear-path walks, anchor / block logic of the read-path
+clustering).
+"""
+import os
+import statistics
+import sys
+from itertools import product
+
+import numpy as np
+
+from . import _ffi
+from .construct_edge import Edge
+from .construct_gene import Gene, convert_int_strand_to_string, hashlib_hash
+from .construct_gene_mer import GeneMer
+from .construct_node import Node
+from .construct_read import Read  # noqa: F401  (re-exported like the reference)
+from .engine import Engine
+from .path_finding_utils import (
+    Tree,
+    construct_suffix_tree,
+    filter_blocks,
+    find_sublist_indices as _find_sublist_indices,
+    get_suffixes_from_initial_tree,
+    is_sublist as _is_sublist,
+    process_anchors,
+    process_combinations_for_i,
+)
+from .tokens import tokenize
+
+sys.setrecursionlimit(50000)  # construct_graph.py:27
+
+
+class _View:
+    """Reference-shaped object view of the device graph (see module docstring)."""
+
+    __slots__ = ("nodes", "edges", "readNodes", "readNodeDirections", "readNodePositions",
+                 "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
+
+
+class GeneMerGraph:
+    # ------------------------------------------------------------------ build
+    def __init__(self, readDict, kmerSize, gene_positions=None, device=None):
+        self._reads = readDict
+        self._kmerSize = kmerSize
+        self._minNodeCoverage = 1
+        self._minEdgeCoverage = 1
+        self._genePositions = gene_positions
+        self._view = None
+        self._extra_to_correct = set()
+        self._gene_cache = {}
+        dev = int(os.environ.get("AMG_DEVICE", "0")) if device is None else int(device)
+        self._engine = Engine(dev)
+        self._vocab, toks, offs, self._read_ids = tokenize(readDict)
+        self._read_off = offs
+        self._read_index = {r: i for i, r in enumerate(self._read_ids)}
+        self._engine.set_reads(toks, offs, self._vocab.two_v)
+        self._tokens = toks
+        self._gs = self._ge = None
+        if gene_positions:
+            n = int(offs[-1])
+            gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
+            for r, rid in enumerate(self._read_ids):
+                a, b = int(offs[r]), int(offs[r + 1])
+                if b > a:
+                    p = gene_positions[rid]
+                    # Read.get_geneMers indexes positions[i] / positions[i + k - 1] (construct_read.py:48-52)
+                    gs[a:b] = [x[0] for x in p[: b - a]]
+                    ge[a:b] = [x[1] for x in p[: b - a]]
+            self._gs, self._ge = gs, ge
+            self._engine.set_positions(gs, ge, None)
+        try:
+            self._engine.build(kmerSize)
+        except _ffi.AmgError as err:
+            if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
+                raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None
+            raise
+        counts = self._engine.counts()
+        self._shortReads = {rid: readDict[rid] for r, rid in enumerate(self._read_ids)
+                            if offs[r + 1] - offs[r] < kmerSize}
+        assert counts["n_short_reads"] == len(self._shortReads)
+
+    # ------------------------------------------------------------------ view plumbing
+    def _invalidate(self):
+        self._view = None
+
+    def _gene_obj(self, token):
+        g = self._gene_cache.get(token)
+        if g is None:
+            g = self._gene_cache[token] = Gene(self._vocab.gene(token))
+        return g
+
+    def _hash_of_tokens(self, toks):
+        return hashlib_hash(tuple([self._vocab.signed_hash(int(t)) for t in toks]))
+
+    def _v(self):
+        if self._view is not None:
+            return self._view
+        eng, vocab, k = self._engine, self._vocab, self._kmerSize
+        nodes, edges = eng.nodes(), eng.edges()
+        tok_node, tok_dir = eng.read_nodes()
+        adj_off, adj_edge = eng.node_adj()
+        nr_off, nr_idx = eng.node_reads()
+        v = _View()
+        v.arrays = {"nodes": nodes, "edges": edges, "tok_node": tok_node, "tok_dir": tok_dir}
+        D, E = len(nodes["coverage"]), len(edges["coverage"])
+        v.alive = nodes["alive"]
+        v.node_hash = [None] * D
+        v.nodes = {}
+        node_obj = [None] * D
+        read_ids = self._read_ids
+        for i in range(D):
+            if not nodes["alive"][i]:
+                continue
+            toks = nodes["tokens"][i].tolist()
+            canon = [self._gene_obj(t) for t in toks]
+            rc = [self._gene_obj(vocab.flip(t)) for t in reversed(toks)]
+            h = self._hash_of_tokens(toks)
+            node = Node(GeneMer._from_parts(canon, rc, int(nodes["first_dir"][i]), h))
+            node.nodeCoverage = int(nodes["coverage"][i])
+            node._component_ID = int(nodes["component"][i])
+            node.listOfReads = [read_ids[r] for r in nr_idx[nr_off[i]:nr_off[i + 1]].tolist()]
+            node._amg_id = i
+            v.node_hash[i] = h
+            v.nodes[h] = node
+            node_obj[i] = node
+        v.node_of_hash = {h: n._amg_id for h, n in v.nodes.items()}
+        v.edge_hash = [None] * E
+        v.edges = {}
+        for e in range(E):
+            if not edges["alive"][e]:
+                continue
+            edge = Edge(node_obj[edges["src"][e]], node_obj[edges["tgt"][e]],
+                        int(edges["sdir"][e]), int(edges["tdir"][e]))
+            edge.edgeCoverage = int(edges["coverage"][e])
+            edge._amg_id = e
+            h = edge.__hash__()
+            v.edge_hash[e] = h
+            v.edges[h] = edge
+        for i in range(D):
+            node = node_obj[i]
+            if node is None:
+                continue
+            node.forwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i]:adj_off[2 * i + 1]].tolist()
+                                      if edges["alive"][e]]
+            node.backwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i + 1]:adj_off[2 * i + 2]].tolist()
+                                       if edges["alive"][e]]
+        v.readNodes, v.readNodeDirections, v.readNodePositions = {}, {}, {}
+        offs, nh = self._read_off, v.node_hash
+        for r, rid in enumerate(read_ids):
+            a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
+            if n <= 0:
+                continue
+            ids = tok_node[a:a + n].tolist()
+            v.readNodes[rid] = [nh[x] if x >= 0 else None for x in ids]
+            dirs = tok_dir[a:a + n].tolist()
+            v.readNodeDirections[rid] = [d if x >= 0 else None for d, x in zip(dirs, ids)]
+            if self._gs is not None:
+                s, e = self._gs[a:a + n].tolist(), self._ge[a + k - 1:a + k - 1 + n].tolist()
+                v.readNodePositions[rid] = [(s[j], e[j]) if ids[j] >= 0 else None for j in range(n)]
+            else:
+                v.readNodePositions[rid] = [None] * n
+        self._view = v
+        return v
+
+    def _node_id(self, node_or_hash):
+        h = node_or_hash if isinstance(node_or_hash, int) else node_or_hash.__hash__()
+        return self._v().node_of_hash[h]
+
+    # ------------------------------------------------------------------ accessors (:104-163)
+    def get_reads(self):
+        return self._reads
+
+    def get_short_read_annotations(self):
+        return self._shortReads
+
+    def get_gene_positions(self):
+        return self._genePositions
+
+    def get_short_read_gene_positions(self):
+        return {r: self._genePositions[r] for r in self._shortReads}
+
+    def get_readNodes(self):
+        return self._v().readNodes
+
+    def get_readNodeDirections(self):
+        return self._v().readNodeDirections
+
+    def get_readNodePositions(self):
+        return self._v().readNodePositions
+
+    def get_kmerSize(self):
+        return self._kmerSize
+
+    def get_minEdgeCoverage(self):
+        return self._minEdgeCoverage
+
+    def get_minNodeCoverage(self):
+        return self._minNodeCoverage
+
+    def set_minNodeCoverage(self, minNodeCoverage):
+        self._minNodeCoverage = minNodeCoverage
+        return self._minNodeCoverage
+
+    def set_minEdgeCoverage(self, minEdgeCoverage):
+        self._minEdgeCoverage = minEdgeCoverage
+        return self._minEdgeCoverage
+
+    def get_nodes(self):
+        return self._v().nodes
+
+    def get_edges(self):
+        return self._v().edges
+
+    def get_reads_to_correct(self):
+        flags = self._engine.reads_to_correct()
+        out = {self._read_ids[r] for r in np.nonzero(flags)[0].tolist()}
+        out |= self._extra_to_correct
+        return out
+
+    def all_nodes(self):
+        for h in self.get_nodes():
+            yield self.get_nodes()[h]
+
+    def get_reads_for_nodes(self, list_of_nodes):
+        reads = set()
+        for h in list_of_nodes:
+            reads.update(self.get_node_by_hash(h).get_list_of_reads())
+        return reads
+
+    def get_nodes_containing_read(self, readId):
+        nodes = self.get_nodes()
+        return [nodes[h] for h in self.get_readNodes()[readId] if h in nodes]
+
+    def get_node_by_hash(self, nodeHash):
+        return self.get_nodes()[nodeHash]
+
+    def get_node(self, geneMer):
+        h = geneMer.__hash__()
+        assert h in self.get_nodes(), "This gene-mer is not in the graph"
+        return self.get_nodes()[h]
+
+    def get_edge_by_hash(self, edgeHash):
+        return self.get_edges()[edgeHash]
+
+    def get_total_number_of_nodes(self):
+        return self._engine.counts()["n_live_nodes"]
+
+    def get_total_number_of_edges(self):
+        return self._engine.counts()["n_live_edges"]
+
+    def get_total_number_of_reads(self):
+        return len(self._reads)
+
+    def get_nodes_containing(self, geneOfInterest):
+        """nodes whose canonical gene-mer holds the gene, in node order (:223-244)."""
+        assert not (geneOfInterest[0] == "+" or geneOfInterest[0] == "-"), (
+            "Strand information cannot be present for any specified genes")
+        assert isinstance(geneOfInterest, str), "Gene of interest is the wrong type"
+        v = self._v()
+        ids = self._node_ids_containing([geneOfInterest])
+        return [v.nodes[v.node_hash[i]] for i in ids]
+
+    def _node_ids_containing(self, genes):
+        v = self._v()
+        toks = []
+        for g in genes:
+            r = self._vocab.rank.get(g)
+            if r is not None:
+                V = max(self._vocab.V, 1)
+                toks += [V + r, V - 1 - r]
+        nt = v.arrays["nodes"]["tokens"]
+        if not toks or nt.size == 0:
+            return []
+        mask = np.isin(nt, np.asarray(toks, dtype=nt.dtype)).any(axis=1) & (v.alive != 0)
+        return np.nonzero(mask)[0].tolist()
+
+    # ------------------------------------------------------------------ topology (:326-400)
+    def get_degree(self, node):
+        return len(node.get_forward_edge_hashes()) + len(node.get_backward_edge_hashes())
+
+    def get_forward_edges(self, node):
+        return [self.get_edge_by_hash(h) for h in node.get_forward_edge_hashes()]
+
+    def get_backward_edges(self, node):
+        return [self.get_edge_by_hash(h) for h in node.get_backward_edge_hashes()]
+
+    def get_forward_neighbors(self, node):
+        return [e.get_targetNode() for e in self.get_forward_edges(node)]
+
+    def get_backward_neighbors(self, node):
+        return [e.get_targetNode() for e in self.get_backward_edges(node)]
+
+    def get_all_neighbors(self, node):
+        return self.get_forward_neighbors(node) + self.get_backward_neighbors(node)
+
+    def get_all_neighbor_hashes(self, node):
+        return set(n.__hash__() for n in self.get_all_neighbors(node))
+
+    def check_if_nodes_are_adjacent(self, sourceNode, targetNode):
+        return (targetNode.__hash__() in self.get_all_neighbor_hashes(sourceNode)
+                and sourceNode.__hash__() in self.get_all_neighbor_hashes(targetNode))
+
+    def get_edge_hashes_between_nodes(self, sourceNode, targetNode):
+        """(source->target hash, target->source hash); a pair of LISTS when either side has
+        several (the reference's multi-edge quirk, :364-386)."""
+        assert self.check_if_nodes_are_adjacent(sourceNode, targetNode)
+        s2t = [e.__hash__() for e in self.get_forward_edges(sourceNode) + self.get_backward_edges(sourceNode)
+               if e.get_targetNode() == targetNode]
+        t2s = [e.__hash__() for e in self.get_forward_edges(targetNode) + self.get_backward_edges(targetNode)
+               if e.get_targetNode() == sourceNode]
+        if not (len(s2t) > 1 or len(t2s) > 1):
+            return (s2t[0], t2s[0])
+        return (s2t, t2s)
+
+    def get_edges_between_nodes(self, sourceNode, targetNode):
+        a, b = self.get_edge_hashes_between_nodes(sourceNode, targetNode)
+        if not (isinstance(a, list) or isinstance(b, list)):
+            return self.get_edge_by_hash(a), self.get_edge_by_hash(b)
+        return [self.get_edge_by_hash(h) for h in a], [self.get_edge_by_hash(h) for h in b]
+
+    # ------------------------------------------------------------------ removals + filter
+    def remove_node(self, node):
+        """remove a node, its edges (both directions) and mask it on its reads (:463-484)."""
+        h = node.__hash__()
+        assert h in self.get_nodes(), "This node is not in the graph"
+        assert node == self.get_node_by_hash(h)
+        self._engine.remove_nodes([self._node_id(h)])
+        self._invalidate()
+
+    def _remove_node_ids(self, ids):
+        if len(ids):
+            self._engine.remove_nodes(np.asarray(ids, dtype=np.int32))
+            self._invalidate()
+
+    def list_nodes_to_remove(self, minNodeCoverage):
+        return {n for n in self.all_nodes() if not n.get_node_coverage() > minNodeCoverage - 1}
+
+    def list_edges_to_remove(self, minEdgeCoverage, nodesToRemove):
+        doomed = set()
+        for h, e in self.get_edges().items():
+            if not e.get_edge_coverage() > minEdgeCoverage - 1:
+                doomed.add(h)
+            if e.get_sourceNode() in nodesToRemove or e.get_targetNode() in nodesToRemove:
+                doomed.add(h)
+        return doomed
+
+    def filter_graph(self, minNodeCoverage, minEdgeCoverage):
+        """device coverage filter: nodes with coverage < minNodeCoverage, edges with coverage
+        < minEdgeCoverage or a removed endpoint; reads through removed nodes are masked and
+        queued for correction (:523-540)."""
+        self.set_minNodeCoverage(minNodeCoverage)
+        self.set_minEdgeCoverage(minEdgeCoverage)
+        self._engine.filter(max(int(minNodeCoverage), 0), max(int(minEdgeCoverage), 0))
+        self._invalidate()
+        return self
+
+    def remove_low_coverage_components(self, min_component_coverage):
+        self._engine.remove_low_coverage_components(max(int(min_component_coverage), 0))
+        self._invalidate()
+
+    def remove_short_linear_paths(self, min_length, sample_genesOfInterest={}):
+        """tip clipping on the device (:679-720); returns the hashes of the removed nodes."""
+        protect = None
+        if sample_genesOfInterest:
+            ids = self._node_ids_containing(list(sample_genesOfInterest))
+            if ids:
+                protect = np.zeros(self._engine.counts()["n_nodes"], np.uint8)
+                protect[ids] = 1
+        v = self._v()
+        removed = self._engine.remove_short_linear_paths(int(min_length), protect)
+        hashes = [v.node_hash[i] for i in removed.tolist()]
+        if len(hashes):
+            self._invalidate()
+        return hashes
+
+    def remove_non_AMR_associated_nodes(self, genesOfInterest):
+        """drop every node none of whose reads touches a node holding a gene of interest (:2941-2959)."""
+        v = self._v()
+        amr_ids = self._node_ids_containing(list(genesOfInterest))
+        tok_node = v.arrays["tok_node"]
+        D = len(v.alive)
+        is_amr = np.zeros(D + 1, bool)
+        is_amr[amr_ids] = True
+        live = tok_node >= 0
+        read_of_tok = np.repeat(np.arange(len(self._read_ids)), np.diff(self._read_off))
+        reads_hit = np.zeros(len(self._read_ids), bool)
+        reads_hit[read_of_tok[live & is_amr[np.where(live, tok_node, D)]]] = True
+        node_hit = np.zeros(D, bool)
+        node_hit[tok_node[live & reads_hit[read_of_tok]]] = True
+        self._remove_node_ids(np.nonzero((v.alive != 0) & ~node_hit)[0])
+
+    def remove_junk_reads(self, error_rate):
+        """split reads by their fraction of masked nodes; Python round() (:1398-1420)."""
+        new_reads, new_positions, rejected_reads, rejected_read_positions = {}, {}, {}, {}
+        for read_id, nodes in self.get_readNodes().items():
+            allowed = round(len(nodes) * (1 - error_rate))
+            masked = sum(1 for n in nodes if n is None)
+            if masked <= allowed:
+                new_reads[read_id] = self._reads[read_id]
+                new_positions[read_id] = self._genePositions[read_id]
+            else:
+                rejected_reads[read_id] = self._reads[read_id]
+                rejected_read_positions[read_id] = self._genePositions[read_id]
+        return new_reads, new_positions, rejected_reads, rejected_read_positions
+
+    def get_valid_reads_only(self):
+        fix = self.get_reads_to_correct()
+        return {r: g for r, g in self._reads.items() if r not in fix}
+
+    # ------------------------------------------------------------------ correction (:1123-1396)
+    def correct_reads(self, fastq_data):
+        """Re-thread every queued read through the filtered graph on the device and return
+        (corrected gene calls, corrected gene positions) like the reference: untouched reads
+        keep their original list objects, reads whose nodes were all removed disappear,
+        self._genePositions is updated in place for changed reads."""
+        eng, vocab = self._engine, self._vocab
+        have_pos = bool(self._genePositions)
+        if have_pos:
+            flags = eng.reads_to_correct()
+            lengths = np.zeros(len(self._read_ids), np.int64)
+            for r in np.nonzero(flags)[0].tolist():
+                try:  # only consulted when a trailing gene needs an inferred end (:1685)
+                    lengths[r] = len(fastq_data[self._read_ids[r]]["sequence"])
+                except (KeyError, TypeError, IndexError):
+                    lengths[r] = 0
+            eng.set_read_lengths(lengths)
+        n_reads, n_tokens = eng.correct_reads()
+        out = eng.corrected(n_reads, n_tokens, have_pos)
+        offs, toks = out["read_offsets"].tolist(), out["tokens"]
+        corrected_genes, corrected_gene_positions = {}, {}
+        for i, (orig, changed) in enumerate(zip(out["orig_read"].tolist(), out["changed"].tolist())):
+            read_id = self._read_ids[orig]
+            a, b = offs[i], offs[i + 1]
+            if changed:
+                corrected_genes[read_id] = vocab.decode(toks[a:b])
+                if have_pos:
+                    self._genePositions[read_id] = list(zip(out["gene_start"][a:b].tolist(),
+                                                            out["gene_end"][a:b].tolist()))
+            else:
+                corrected_genes[read_id] = self._reads[read_id]
+            if have_pos:
+                corrected_gene_positions[read_id] = self._genePositions[read_id]
+        return corrected_genes, corrected_gene_positions
+
+    def find_read_boundaries(self, readNode):
+        start, end = 0, len(readNode) - 1
+        for i, node in enumerate(readNode):
+            if node:
+                start = i
+                break
+        for i, node in enumerate(reversed(readNode)):
+            if node:
+                end = len(readNode) - 1 - i
+                break
+        return start, end
+
+    def identify_path_terminals(self, corrected, start, end):
+        terminals = []
+        for i in range(len(corrected)):
+            if start <= i <= end and not corrected[i]:
+                if corrected[i - 1]:
+                    path_start = i - 1
+                if corrected[i + 1]:
+                    terminals.append((path_start, i + 1))
+        return terminals
+
+    def insert_elements(self, base_list, insert_dict):
+        if len(insert_dict) == 0:
+            return [base_list]
+        choices = [[(key, p) for p in paths] for key, paths in insert_dict.items()]
+        results = []
+        for combination in product(*choices):
+            cur, shift = base_list[:], 0
+            for (start, end), path in combination:
+                cur[start + shift:end + shift + 1] = path
+                shift += len(path) - (end - start + 1)
+            results.append(cur)
+        return results
+
+    def new_find_paths_between_nodes(self, start_hash, end_hash, distance, current_direction,
+                                     path=None, seen_nodes=None):
+        """host twin of the device DFS in k_corr_gapped (:2292-2342)."""
+        path = [] if path is None else path
+        seen_nodes = set() if seen_nodes is None else seen_nodes
+        path.append((start_hash, current_direction))
+        seen_nodes.add(start_hash)
+        if (end_hash and start_hash == end_hash and len(path) <= distance) or (
+                end_hash is None and len(path) - 1 == distance):
+            return [list(path)]
+        if len(path) - 1 > distance:
+            return []
+        node = self.get_node_by_hash(start_hash)
+        hops = (node.get_forward_edge_hashes() if current_direction == 1
+                else node.get_backward_edge_hashes() if current_direction == -1 else [])
+        found = []
+        for edge_hash in hops:
+            edge = self.get_edge_by_hash(edge_hash)
+            nxt = edge.get_targetNode().__hash__()
+            if nxt not in seen_nodes:
+                found.extend(self.new_find_paths_between_nodes(
+                    nxt, end_hash, distance, edge.get_targetNodeDirection(), list(path), seen_nodes | {nxt}))
+        return found
+
+    def get_coverage_of_path(self, path):
+        return statistics.mean([self.get_node_by_hash(n).get_node_coverage() for n in path])
+
+    def get_annotation_for_read(self, listOfNodes, listOfNodeDirections, read_id):
+        assert len(listOfNodes) == len(listOfNodeDirections), (
+            f"The number of nodes and node directions for read {read_id} are not the same")
+        if not listOfNodeDirections:
+            listOfNodeDirections = self.get_readNodeDirections()[read_id]
+        oriented = lambda n, d: (self.get_gene_mer_genes(n) if d == 1 else self.get_reverse_gene_mer_genes(n))
+        if len(listOfNodes) == 1:
+            d = listOfNodeDirections[0]
+            if d != 1 and d != -1:
+                raise ValueError(f"Gene-mer direction for a node with 1 read cannot be {d}")
+            return oriented(self.get_node_by_hash(listOfNodes[0]), d)
+        genes = []
+        for i, h in enumerate(listOfNodes):
+            node, d = self.get_node_by_hash(h), listOfNodeDirections[i]
+            if i == 0:
+                genes += oriented(node, d)[:-1]
+            if d:
+                genes.append(oriented(node, d)[-1])
+        assert None not in genes
+        return genes
+
+    def needleman_wunsch(self, x, y):
+        """host twin of k_corr_nw: match 1 / mismatch 0 / gap -1, borders -index, ties broken
+        by max over (score, pointer) tuples => UP > LEFT > DIAG (:1433-1480)."""
+        N, M = len(x), len(y)
+        DIAG, LEFT, UP = (-1, -1), (-1, 0), (0, -1)
+        F, Ptr = {(-1, -1): 0}, {}
+        for i in range(N):
+            F[i, -1] = -i
+        for j in range(M):
+            F[-1, j] = -j
+        for i in range(N):
+            for j in range(M):
+                F[i, j], Ptr[i, j] = max((F[i - 1, j - 1] + int(x[i] == y[j]), DIAG),
+                                         (F[i - 1, j] - 1, LEFT), (F[i, j - 1] - 1, UP))
+        alignment = []
+        i, j = N - 1, M - 1
+        while i >= 0 and j >= 0:
+            step = Ptr[i, j]
+            alignment.append((x[i], y[j]) if step == DIAG else (x[i], "*") if step == LEFT else ("*", y[j]))
+            i, j = i + step[0], j + step[1]
+        while i >= 0:
+            alignment.append((x[i], "*"))
+            i -= 1
+        while j >= 0:
+            alignment.append(("*", y[j]))
+            j -= 1
+        return alignment[::-1]
+
+    def replace_invalid_gene_positions(self, new_positions, fastq_data, read_id):
+        prev_end = 0
+        for i, (start, end) in enumerate(new_positions):
+            if end is not None:
+                prev_end = end
+            if start is None and end is None:
+                next_start = next((p[0] for p in new_positions[i + 1:] if p[0] is not None), None)
+                if next_start is not None:
+                    new_positions[i] = (prev_end, next_start)
+                else:
+                    new_positions[i] = (prev_end, len(fastq_data[read_id]["sequence"]) - 1)
+        return new_positions
+
+    # ------------------------------------------------------------------ gene strings / unitigs
+    def get_gene_mer_genes(self, sourceNode):
+        return [convert_int_strand_to_string(g.get_strand()) + g.get_name()
+                for g in sourceNode.get_canonical_geneMer()]
+
+    def get_reverse_gene_mer_genes(self, sourceNode):
+        return [convert_int_strand_to_string(g.get_strand()) + g.get_name()
+                for g in sourceNode.get_reverse_geneMer()]
+
+    def get_gene_mer_label(self, sourceNode):
+        return "~~~".join(self.get_gene_mer_genes(sourceNode))
+
+    def get_nodes_with_degree(self, degree):
+        assert isinstance(degree, int), "The input degree must be an integer."
+        return [n for n in self.all_nodes() if self.get_degree(n) == degree]
+
+    def reverse_list_of_genes(self, list_of_genes):
+        return [("-" if g[0] == "+" else "+") + g[1:] for g in reversed(list_of_genes)]
+
+    def get_genes_in_unitig(self, listOfNodes):
+        """gene strings spelled by a node path (:617-677): extend to the right, and if that
+        fails at any step redo the whole path extending to the left."""
+        if len(listOfNodes) == 1:
+            return self.get_gene_mer_genes(self.get_node_by_hash(listOfNodes[0]))
+        k1 = self._kmerSize - 1
+
+        def first_orientation():
+            a, b = self.get_node_by_hash(listOfNodes[0]), self.get_node_by_hash(listOfNodes[1])
+            edge = self.get_edge_by_hash(self.get_edge_hashes_between_nodes(a, b)[0])
+            return (self.get_gene_mer_genes(a) if edge.get_sourceNodeDirection() == 1
+                    else self.get_reverse_gene_mer_genes(a))
+
+        def walk(prepend):
+            genes = []
+            for n in range(len(listOfNodes) - 1):
+                src = self.get_node_by_hash(listOfNodes[n])
+                tgt = self.get_node_by_hash(listOfNodes[n + 1])
+                self.get_edge_by_hash(self.get_edge_hashes_between_nodes(src, tgt)[0])
+                if n == 0:
+                    genes += first_orientation()
+                fw, bw = self.get_gene_mer_genes(tgt), self.get_reverse_gene_mer_genes(tgt)
+                if not prepend:
+                    tail = genes[-k1:] if k1 else genes[0:]
+                    if fw[:-1] == tail:
+                        genes.append(fw[-1])
+                    elif bw[:-1] == tail:
+                        genes.append(bw[-1])
+                    else:
+                        return None
+                else:
+                    head = genes[:k1]
+                    if fw[1:] == head:
+                        genes.insert(0, fw[0])
+                    elif bw[1:] == head:
+                        genes.insert(0, bw[0])
+                    else:
+                        raise ValueError("Gene sequences do not match in alternative path.")
+            return genes
+
+        genes = walk(False)
+        return genes if genes is not None else walk(True)
+
+    # ------------------------------------------------------------------ linear paths (:722-861)
+    def _linear_step(self, node, forward):
+        hashes = node.get_forward_edge_hashes() if forward else node.get_backward_edge_hashes()
+        if (forward and len(hashes) != 1) or (not forward and len(hashes) == 0):
+            return False, None, None
+        edge = self.get_edge_by_hash(hashes[0])
+        target = edge.get_targetNode()
+        extend = self.get_degree(target) in (1, 2) and target != node
+        return extend, target, edge.get_targetNodeDirection()
+
+    def get_forward_node_from_node(self, sourceNode):
+        return self._linear_step(sourceNode, True)
+
+    def get_backward_node_from_node(self, sourceNode):
+        return self._linear_step(sourceNode, False)
+
+    def get_forward_path_from_node(self, node, startDirection, wantBranchedNode=False):
+        path = [node.__hash__()]
+        extend, nxt, d = self._linear_step(node, startDirection == 1)
+        while extend and path[0] != nxt.__hash__():
+            path.append(nxt.__hash__())
+            extend, nxt, d = self._linear_step(nxt, d == 1)
+        if wantBranchedNode and nxt:
+            path.append(nxt.__hash__())
+        return path
+
+    def get_backward_path_from_node(self, node, startDirection, wantBranchedNode=False):
+        path = [node.__hash__()]
+        extend, nxt, d = self._linear_step(node, startDirection != -1)
+        while extend and path[-1] != nxt.__hash__():
+            path.insert(0, nxt.__hash__())
+            extend, nxt, d = self._linear_step(nxt, d != -1)
+        if wantBranchedNode and nxt:
+            path.insert(0, nxt.__hash__())
+        return path
+
+    def get_linear_path_for_node(self, node, wantBranchedNode=False):
+        d0 = node.get_geneMer().get_geneMerDirection()
+        backward = self.get_backward_path_from_node(node, -1 * d0, wantBranchedNode)
+        assert backward[-1] == node.__hash__()
+        forward = self.get_forward_path_from_node(node, d0, wantBranchedNode)
+        assert forward[0] == node.__hash__()
+        return backward[:-1] + [node.__hash__()] + forward[1:]
+
+    def get_all_node_coverages(self):
+        return [n.get_node_coverage() for n in self.all_nodes()]
+
+    def get_mean_node_coverage(self):
+        return statistics.mean(self.get_all_node_coverages())
+
+    # ------------------------------------------------------------------ components (:911-958)
+    def get_nodes_in_component(self, component):
+        return [n for n in self.all_nodes() if n.get_component() == int(component)]
+
+    def components(self):
+        return sorted({n.get_component() for n in self.all_nodes()})
+
+    def get_number_of_component(self):
+        return len(self.components())
+
+    def get_AMR_nodes(self, listOfGenes):
+        out = {}
+        for gene in listOfGenes:
+            for node in self.get_nodes_containing(gene):
+                out[node.__hash__()] = node
+        return out
+
+    def collect_reads_in_path(self, path):
+        nodes = self.get_nodes()
+        reads = set()
+        for h in list(path):
+            if h in nodes:
+                for r in nodes[h].get_reads():
+                    reads.add(r)
+        return reads
+
+    # ------------------------------------------------------------------ read-path clustering
+    def find_sublist_indices(self, main_list, sublist):
+        return _find_sublist_indices(main_list, sublist)
+
+    def is_sublist(self, long_list, sub_list):
+        return _is_sublist(long_list, sub_list)
+
+    def get_AMR_anchors(self, AMRNodes):
+        """anchor selection (:2629-2691), including the reference's use of FORWARD neighbours
+        for both sides of the first test."""
+        readNodes = self.get_readNodes()
+        anchors, terminals = set(), {}
+        for h in AMRNodes:
+            flags = terminals[h] = []
+            node = self.get_node_by_hash(h)
+            fw_other = [n for n in self.get_forward_neighbors(node) if n.__hash__() != h]
+            if len(fw_other) == 0:
+                anchors.add(h)
+            singletons, is_anchor = [], False
+            for r in node.get_reads():
+                on_read = readNodes[r]
+                if len(on_read) == 1 and on_read[0] == h:
+                    singletons.append(True)
+                    flags.append(True)
+                    break
+                singletons.append(False)
+                amr = [1 if n in AMRNodes else 0 for n in on_read]
+                for idx in [i for i, n in enumerate(on_read) if n == h]:
+                    if idx == 0 or idx == len(on_read) - 1:
+                        flags.append(True)
+                        continue
+                    if amr[idx - 1] == 0 or amr[idx + 1] == 0:
+                        is_anchor = True
+                        break
+                    flags.append(False)
+                if is_anchor:
+                    anchors.add(h)
+                    break
+            if all(singletons) or all(flags):
+                fw_amr = [n for n in self.get_forward_neighbors(node) if n.__hash__() in AMRNodes]
+                bw_amr = [n for n in self.get_backward_neighbors(node) if n.__hash__() in AMRNodes]
+                if len(bw_amr) == 0 or len(fw_amr) == 0:
+                    anchors.add(h)
+        for h, flags in terminals.items():
+            if flags and flags.count(True) / len(flags) > 0.3:
+                anchors.add(h)
+        return anchors
+
+    def get_singleton_paths(self, all_seen_nodes, nodeAnchors, final_paths, final_path_coverages):
+        for a in nodeAnchors:
+            if a not in all_seen_nodes:
+                key = tuple(self.get_genes_in_unitig([a]))
+                node = self.get_node_by_hash(a)
+                final_paths[key] = len(set(node.get_list_of_reads()))
+                final_path_coverages[key] = [node.get_node_coverage()]
+
+    def get_reads_supporting_path(self, path, suffix_tree):
+        return {rid.replace("_reverse", "") for rid, _ in suffix_tree.find_all(list(path))}
+
+    def get_all_sublists(self, lst, gene_call_subset, threshold, geneOfInterest, cores):
+        """windows of a block's gene path with enough read support (:2711-2723); the
+        reference maps the window length over a process pool, results are merged in order."""
+        sublists = {}
+        for i in range(1, len(lst) + 1):
+            found = process_combinations_for_i((i, threshold, geneOfInterest, lst, gene_call_subset))
+            for sub in found:
+                if sub:
+                    sublists[sub] = found[sub]
+        return sublists
+
+    def get_full_paths(self, node_tree, reads, nodeAnchors, threshold, gene_call_subset,
+                       geneOfInterest, cores):
+        full_blocks = {}
+        for a1 in nodeAnchors:
+            suffixes = get_suffixes_from_initial_tree(node_tree, a1)
+            sub_tree = Tree({r: list(reversed(s)) for r, s in suffixes.items()})
+            process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, node_tree, threshold)
+        gene_blocks = {}
+        for f in full_blocks:
+            options = self.get_all_sublists(self.get_genes_in_unitig(f), gene_call_subset, threshold,
+                                            geneOfInterest, cores)
+            if len(options) > 0:
+                gene_blocks[f] = options
+        filtered_blocks = filter_blocks({f: full_blocks[f] for f in gene_blocks})
+        final_paths, final_path_coverages, seen_nodes = {}, {}, set()
+        plus, minus = f"+{geneOfInterest}", f"-{geneOfInterest}"
+        for f1 in filtered_blocks:
+            seen_nodes.update(f1)
+            if f1 not in gene_blocks:
+                continue
+            differentiating = set()
+            for o1 in gene_blocks[f1]:
+                fwd, rev = list(o1), self.reverse_list_of_genes(list(o1))
+                shared = False
+                for f2 in filtered_blocks:
+                    if f1 == f2:
+                        continue
+                    other = self.get_genes_in_unitig(list(f2))
+                    if _is_sublist(other, fwd) or _is_sublist(other, rev):
+                        shared = True
+                        break
+                if not shared:
+                    differentiating.add(o1)
+            if differentiating:
+                chosen = sorted(list(differentiating),
+                                key=lambda x: (x.count(plus) + x.count(minus), gene_blocks[f1][x], len(x)),
+                                reverse=True)[0]
+                final_paths[chosen] = gene_blocks[f1][chosen]
+                final_path_coverages[chosen] = [self.get_node_by_hash(n).get_node_coverage() for n in list(f1)]
+        return final_paths, seen_nodes, final_path_coverages
+
+    def get_paths_for_gene(self, node_suffix_tree, gene_call_subset, nodeHashesOfInterest, threshold,
+                           geneOfInterest, cores):
+        anchors = self.get_AMR_anchors(nodeHashesOfInterest)
+        final_paths, seen, coverages = self.get_full_paths(
+            node_suffix_tree, self.get_readNodes(), anchors, threshold, gene_call_subset,
+            geneOfInterest, cores)
+        self.get_singleton_paths(seen, anchors, final_paths, coverages)
+        return final_paths, coverages
+
+    def split_into_subpaths(self, geneOfInterest, pathsOfinterest, path_coverages, path_reads,
+                            mean_node_coverage=None):
+        """allele clusters: reads holding a path exactly once, forward first (:2360-2455)."""
+        allele_count = 1
+        gene_clusters, read_tracking = {}, {}
+        if mean_node_coverage is None:
+            mean_node_coverage = self.get_mean_node_coverage()
+        for path in pathsOfinterest:
+            fwd = list(path)
+            rev = self.reverse_list_of_genes(fwd)
+            named = list(path)
+            fw_idx, rv_idx = {}, {}
+            for g, gene in enumerate(fwd):
+                if gene[1:] == geneOfInterest:
+                    allele = f"{geneOfInterest}_{allele_count}"
+                    fw_idx[g] = rv_idx[len(fwd) - g - 1] = allele
+                    gene_clusters[allele], read_tracking[allele] = [], set()
+                    named[g] = f"{gene[0]}{allele}"
+                    allele_count += 1
+            named = tuple(named)
+            for read_id, genes_on_read in self._reads.items():
+                hits, idx = _find_sublist_indices(genes_on_read, fwd), fw_idx
+                if not hits:
+                    hits, idx = _find_sublist_indices(genes_on_read, rev), rv_idx
+                    if not hits:
+                        continue
+                if len(hits) != 1:
+                    continue
+                path_reads.setdefault(named, set()).add(read_id)
+                path_start = hits[0][0]
+                for gene_index in idx:
+                    assert genes_on_read[path_start + gene_index][1:] == geneOfInterest
+                    s, e = self._genePositions[read_id][path_start + gene_index]
+                    entry = f"{read_id}_{s}_{e}"
+                    gene_clusters[idx[gene_index]].append(entry)
+                    read_tracking[idx[gene_index]].add(entry)
+        ranked = sorted([a for a in read_tracking], key=lambda x: len(read_tracking[x]), reverse=True)
+        doomed = set()
+        for i, a1 in enumerate(ranked):
+            if a1 in doomed:
+                continue
+            for a2 in ranked[i + 1:]:
+                if a1 != a2 and len(read_tracking[a1] & read_tracking[a2]) > 0:
+                    doomed.add(a2)
+        for d in doomed:
+            del gene_clusters[d]
+        return gene_clusters, path_reads
+
+    def assign_final_alleles_to_components(self, finalAllelesOfInterest, clustered_reads, allele_counts,
+                                           geneOfInterest):
+        readNodes = self.get_readNodes()
+        for allele in finalAllelesOfInterest:
+            for entry in finalAllelesOfInterest[allele]:
+                for node_hash in readNodes["_".join(entry.split("_")[:-2])]:
+                    component = self.get_node_by_hash(node_hash).get_component()
+                    break
+                break
+            gene_name = "_".join(allele.split("_")[:-1])
+            if gene_name not in allele_counts:
+                allele_counts[gene_name] = 1
+            clustered_reads.setdefault(component, {}).setdefault(geneOfInterest, {})[
+                f"{gene_name}_{allele_counts[gene_name]}"] = finalAllelesOfInterest[allele]
+            allele_counts[gene_name] += 1
+
+    def collect_component_missed_genes(self, component_nodeHashesOfInterest, clustered_reads,
+                                       allele_counts, geneOfInterest, path_reads):
+        for component, hashes in component_nodeHashesOfInterest.items():
+            clustered_reads.setdefault(component, {}).setdefault(geneOfInterest, {})
+            if len(clustered_reads[component][geneOfInterest]) != 0:
+                continue
+            if geneOfInterest not in allele_counts:
+                allele_counts[geneOfInterest] = 1
+            allele_name = f"{geneOfInterest}_{allele_counts[geneOfInterest]}"
+            key = tuple([f"+{allele_name}"])
+            bucket = clustered_reads[component][geneOfInterest][allele_name] = []
+            for read_id in self.collect_reads_in_path(hashes):
+                genes = self._reads[read_id]
+                for i in [i for i, g in enumerate(genes) if g[1:] == geneOfInterest]:
+                    s, e = self._genePositions[read_id][i]
+                    bucket.append(f"{read_id}_{s}_{e}")
+                path_reads.setdefault(key, set()).add(read_id)
+            allele_counts[geneOfInterest] += 1
+
+    def correct_low_coverage_paths(self, *args, **kwargs):
+        raise NotImplementedError(
+            "bubble popping (construct_graph.py:2196-2250) needs nucleotide reads and sourmash "
+            "MinHash; it is row f1 of SURVEY.md section 8 and outside this round's hot path")
+
+    def assign_reads_to_genes(self, listOfGenes, cores, allele_counts={}, mean_node_coverage=None,
+                              path_threshold=5):
+        """per gene of interest: anchors -> full blocks -> differentiating gene paths -> allele
+        clusters (:2880-2939)."""
+        clustered_reads, path_reads = {}, {}
+        if mean_node_coverage is None:
+            mean_node_coverage = self.get_mean_node_coverage()
+        for geneOfInterest in listOfGenes:
+            hashes = [n.__hash__() for n in self.get_nodes_containing(geneOfInterest)]
+            reads_with_gene = self.collect_reads_in_path(hashes)
+            node_tree = construct_suffix_tree({r: self.get_readNodes()[r] for r in reads_with_gene})
+            gene_call_subset = {r: self._reads[r] for r in reads_with_gene}
+            flipped = {r + "_reverse": self.reverse_list_of_genes(g) for r, g in gene_call_subset.items()}
+            gene_call_subset.update(flipped)
+            paths, coverages = self.get_paths_for_gene(node_tree, gene_call_subset, hashes,
+                                                       mean_node_coverage / 20, geneOfInterest, cores)
+            alleles, path_reads = self.split_into_subpaths(geneOfInterest, paths, coverages, path_reads,
+                                                           mean_node_coverage)
+            self.assign_final_alleles_to_components(alleles, clustered_reads, allele_counts, geneOfInterest)
+            by_component = {}
+            for h in hashes:
+                by_component.setdefault(self.get_node_by_hash(h).get_component(), set()).add(h)
+            self.collect_component_missed_genes(by_component, clustered_reads, allele_counts,
+                                                geneOfInterest, path_reads)
+        return clustered_reads, path_reads

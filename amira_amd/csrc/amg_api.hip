@@ -169,6 +169,16 @@ extern "C" int amg_set_positions(amg_ctx* c, const int64_t* gene_start, const in
   return AMG_OK;
 }
 
+extern "C" int amg_set_read_lengths(amg_ctx* c, const int64_t* read_len, int on_device) {
+  if (!c || !read_len) return amg_fail(AMG_E_ARG, "null argument");
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  HIPCHK(hipSetDevice(c->device));
+  AMGCHK(copy_in(c, c->read_len, read_len, (size_t)c->n_reads * sizeof(int64_t), on_device));
+  c->have_read_len = true;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
 // ------------------------------------------------------------------ counts + read-back
 __global__ void k_count_flags(const unsigned char* __restrict__ f, long long n,
                               unsigned long long* out) {

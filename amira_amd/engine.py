@@ -43,6 +43,10 @@ class Engine:
         rl = None if read_len is None else np.ascontiguousarray(read_len, dtype=np.int64)
         check(_ffi.lib.amg_set_positions(self._h, ptr(gs), ptr(ge), ptr(rl), 0))
 
+    def set_read_lengths(self, read_len):
+        rl = np.ascontiguousarray(read_len, dtype=np.int64)
+        check(_ffi.lib.amg_set_read_lengths(self._h, ptr(rl), 0))
+
     def set_positions_device(self, gs_ptr, ge_ptr, rl_ptr):
         check(_ffi.lib.amg_set_positions(self._h, C.c_void_p(gs_ptr), C.c_void_p(ge_ptr),
                                          C.c_void_p(rl_ptr) if rl_ptr else None, 1))

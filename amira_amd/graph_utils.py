@@ -1,0 +1,114 @@
+"""Graph drivers — drop-in for the hot-path part of amira/graph_utils.py (reference v0.11.0):
+build_graph (:12-14), build_multiprocessed_graph (:105-124), the cleaning loop of
+iterative_bubble_popping (:127-181), choose_kmer_size (:258-296) and
+get_overall_mean_node_coverages (:299-313).
+
+The reference's only parallelism is host processes over read shards whose merge is both slow
+(CHANGELOG "limit graph building to 1 CPU") and wrong for edge coverages
+(graph_utils.py:71-75); every pipeline call passes cores=1.  Here one graph is always built
+on the device and `cores` is accepted for signature compatibility only.
+"""
+import statistics
+import sys
+
+import numpy as np
+
+from .construct_graph import GeneMerGraph
+
+
+def build_graph(read_dict, kmer_size, gene_positions=None):
+    return GeneMerGraph(read_dict, kmer_size, gene_positions)
+
+
+def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positions=None):
+    """single-graph result (what cores=1 gives in the reference), built on the GPU."""
+    reads = {r: annotatedReads[r] for r in annotatedReads}
+    positions = None if gene_positions is None else {r: gene_positions[r] for r in gene_positions}
+    return build_graph(reads, geneMer_size, positions)
+
+
+def cleaning_sweep(reads, gene_positions, geneMer_size, fastq_content, node_min_coverage=3):
+    """one cleaning iteration without the bubble-popping tail (graph_utils.py:145-166):
+    build -> filter_graph(n, 1) -> correct_reads -> build -> remove_short_linear_paths(k)
+    -> correct_reads -> build.  Returns (graph, reads, positions)."""
+    graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
+    graph.filter_graph(node_min_coverage, 1)
+    reads, gene_positions = graph.correct_reads(fastq_content)
+    graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
+    graph.remove_short_linear_paths(geneMer_size)
+    reads, gene_positions = graph.correct_reads(fastq_content)
+    graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
+    return graph, reads, gene_positions
+
+
+def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleaning_iterations,
+                             geneMer_size, cores, short_reads, short_read_gene_positions,
+                             fastq_content, output_dir, node_min_coverage, sample_genesOfInterest,
+                             min_path_coverage):
+    """same loop as the reference; the final step of every iteration
+    (correct_low_coverage_paths) raises NotImplementedError."""
+    prev_nodes = 0
+    components_to_skip = set()
+    for this_iteration in range(cleaning_iterations):
+        sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
+        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        graph.filter_graph(node_min_coverage, 1)
+        new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
+        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        if graph.get_total_number_of_nodes() == prev_nodes:
+            sys.stderr.write(f"\n\tAmira: terminating cleaning at iteration {this_iteration+1}\n")
+            break
+        prev_nodes = graph.get_total_number_of_nodes()
+        sys.stderr.write("\n\tAmira: removing dead ends\n")
+        short_reads.update(graph.get_short_read_annotations())
+        short_read_gene_positions.update(graph.get_short_read_gene_positions())
+        graph.remove_short_linear_paths(geneMer_size)
+        new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
+        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        short_reads.update(graph.get_short_read_annotations())
+        short_read_gene_positions.update(graph.get_short_read_gene_positions())
+        new_annotatedReads, new_gene_position_dict, path_coverages, min_path_coverage = (
+            graph.correct_low_coverage_paths(fastq_content, sample_genesOfInterest, cores,
+                                             min_path_coverage, components_to_skip, True))
+    return new_annotatedReads, new_gene_position_dict
+
+
+def choose_kmer_size(overall_mean_node_coverage, new_annotatedReads, cores, new_gene_position_dict,
+                     sample_genesOfInterest):
+    """largest odd k in 3..15 such that, in every component, >= 80 % of the reads through
+    AMR nodes have >= 2k-1 genes (graph_utils.py:258-296)."""
+    geneMer_size = 3
+    if overall_mean_node_coverage >= 20:
+        for k in range(3, 16, 2):
+            graph = build_multiprocessed_graph(new_annotatedReads.copy(), k, cores,
+                                               new_gene_position_dict.copy())
+            amr = {n.__hash__() for g in sample_genesOfInterest for n in graph.get_nodes_containing(g)}
+
+            def is_component_valid(component):
+                members = [n.__hash__() for n in graph.get_nodes_in_component(component)]
+                reads = graph.collect_reads_in_path([h for h in members if h in amr])
+                lengths = [len(graph.get_reads()[r]) for r in reads]
+                if len(lengths) == 0:
+                    return True
+                return len([x for x in lengths if x >= (2 * k - 1)]) / len(lengths) >= 0.8
+
+            if all(is_component_valid(c) for c in graph.components()):
+                geneMer_size = k
+            else:
+                break
+    return geneMer_size
+
+
+def get_overall_mean_node_coverages(graph):
+    """mean over nodes of the number of the node's reads with >= k genes, k = 3,5,..,15
+    (graph_utils.py:299-313) — from the device's node->reads CSR."""
+    off, idx = graph._engine.node_reads()
+    alive = graph._engine.nodes()["alive"] != 0
+    read_len = np.diff(graph._read_off)
+    out = {}
+    for k in range(3, 16, 2):
+        ok = (read_len[idx] >= k).astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(ok)])
+        per_node = (csum[off[1:]] - csum[off[:-1]])[alive].tolist()
+        out[k] = statistics.mean(per_node) if per_node else 0
+    return out

@@ -1,0 +1,227 @@
+"""Read-path clustering helpers — drop-in for amira/path_finding_utils.py (reference v0.11.0).
+
+Same function names and argument meaning as the reference.  Sub-list search goes through
+``Tree`` below: the reference uses the PyPI package suffix-tree==0.1.2 only for
+``Tree(dict)`` / ``Tree.find_all(seq)``; when that package is importable it is used,
+otherwise an exact scan with the same results (ids + suffix from the match start).
+"""
+try:  # pragma: no cover - the package is not installed in the build image
+    from suffix_tree import Tree as _ExternalTree
+except Exception:  # noqa: BLE001
+    _ExternalTree = None
+
+
+class _Suffix:
+    """What Tree.find_all hands back per hit: str() is the space-joined suffix + ' $'."""
+
+    __slots__ = ("items",)
+
+    def __init__(self, items):
+        self.items = items
+
+    def __str__(self):
+        return " ".join([str(x) for x in self.items] + ["$"])
+
+
+class _ScanTree:
+    def __init__(self, data=None):
+        self._seqs = [(key, list(seq)) for key, seq in (data or {}).items()]
+
+    def find_all(self, query):
+        query = list(query)
+        m = len(query)
+        hits = []
+        if m == 0:
+            return hits
+        first = query[0]
+        for key, seq in self._seqs:
+            stop = len(seq) - m
+            i = 0
+            while i <= stop:
+                if seq[i] == first and seq[i:i + m] == query:
+                    hits.append((key, _Suffix(seq[i:])))
+                i += 1
+        return hits
+
+
+Tree = _ExternalTree or _ScanTree
+
+
+def _suffix_ints(path):
+    parts = str(path).split(" ")
+    if parts[0] == "None":
+        return None
+    return [int(n) for n in parts if n != "$"]
+
+
+def is_sublist(long_list, sub_list):
+    assert isinstance(long_list, list) and isinstance(sub_list, list)
+    m = len(sub_list)
+    for i in range(len(long_list) - m + 1):
+        if long_list[i:i + m] == sub_list:
+            return True
+    return False
+
+
+def find_sublist_indices(main_list, sublist):
+    m = len(sublist)
+    return [(i, i + m - 1) for i in range(len(main_list) - m + 1) if main_list[i:i + m] == sublist]
+
+
+def _greedy_clusters(adjacent_paths, fits):
+    ordered = sorted([p for p in adjacent_paths], key=len, reverse=True)
+    groups = {}
+    for p in ordered:
+        as_list = list(p)
+        matches = [rep for rep in groups if (not as_list) or fits(as_list, list(rep))]
+        if not matches:
+            groups[p] = {p}
+        if len(matches) == 1:
+            groups[matches[0]].add(p)
+    result = {}
+    for rep in groups:
+        members = list(groups[rep])
+        result[min(members, key=len)] = {"longest": max(members, key=len), "all": members}
+    return result
+
+
+def cluster_downstream_adjacent_paths(adjacent_paths):
+    """prefix-compatible clustering, longest first (path_finding_utils.py:11-36)."""
+    return _greedy_clusters(adjacent_paths, lambda p, c: p == c[:len(p)])
+
+
+def cluster_upstream_adjacent_paths(adjacent_paths):
+    """suffix-compatible clustering, longest first (:39-64)."""
+    return _greedy_clusters(adjacent_paths, lambda p, c: p == c[-len(p):])
+
+
+def construct_suffix_tree(read_nodes):
+    """adds '<read>_reverse' entries for reads with >1 distinct node — mutates its argument (:79-85)."""
+    flipped = {r + "_reverse": list(reversed(nodes)) for r, nodes in read_nodes.items()
+               if len(set(nodes)) != 1}
+    read_nodes.update(flipped)
+    return Tree(read_nodes)
+
+
+def get_suffixes_from_initial_tree(tree, a1):
+    best = {}
+    for read_id, path in tree.find_all([a1]):
+        nodes = _suffix_ints(path)
+        if nodes is None:
+            continue
+        if read_id not in best or len(nodes) > len(best[read_id]):
+            best[read_id] = nodes
+    return best
+
+
+def get_blocks_from_subtree(sub_tree, a2, nodeAnchors):
+    block_reads, block_duplicates = {}, {}
+    for read_id, path in sub_tree.find_all([a2]):
+        nodes = _suffix_ints(path)
+        if nodes is None:
+            continue
+        assert nodes[0] in nodeAnchors and nodes[-1] in nodeAnchors
+        block_duplicates[tuple(sorted([nodes, nodes[::-1]])[0])] = False
+        if "_reverse" not in read_id:
+            if read_id not in block_reads or len(nodes) > len(block_reads[read_id]):
+                block_reads[read_id] = nodes[::-1]
+    return block_reads, block_duplicates
+
+
+def get_all_context_options(nodes_on_reads, start, end):
+    up, down = nodes_on_reads[:start], nodes_on_reads[end + 1:]
+    up_options = {tuple(up[-i:]) for i in range(1, len(up) + 1)} | {()}
+    down_options = {tuple(down[:i]) for i in range(1, len(down) + 1)} | {()}
+    return up_options, down_options
+
+
+def get_canonical_representation(block_read):
+    return sorted([block_read, list(reversed(block_read))])[0]
+
+
+def update_duplicates(block_duplicates, canonical_tuple, positions_of_path):
+    if len(positions_of_path) > 1:
+        block_duplicates[canonical_tuple] = True
+    return block_duplicates
+
+
+def get_full_path_contexts(positions_of_path, contexts, reads, read_id, block_reads):
+    start, end = positions_of_path[0]
+    up_options, down_options = get_all_context_options(reads[read_id], start, end)
+    canonical = get_canonical_representation(block_reads[read_id])
+    key = tuple(canonical)
+    contexts.setdefault(key, {"upstream": set(), "downstream": set()})
+    if canonical == block_reads[read_id]:
+        contexts[key]["upstream"].update(up_options)
+        contexts[key]["downstream"].update(down_options)
+    else:  # the reference REPLACES the entry here
+        contexts[key] = {"upstream": {tuple(reversed(d)) for d in down_options},
+                         "downstream": {tuple(reversed(u)) for u in up_options}}
+
+
+def generate_contexts(block_reads, block_duplicates, reads):
+    contexts = {}
+    for read_id, block in block_reads.items():
+        where = find_sublist_indices(reads[read_id], block)
+        assert len(where) > 0
+        update_duplicates(block_duplicates, tuple(get_canonical_representation(block)), where)
+        if len(where) == 1:
+            get_full_path_contexts(where, contexts, reads, read_id, block_reads)
+    return contexts
+
+
+def build_full_paths(upstream_clusters, downstream_clusters, c):
+    return [u + c + d for u in upstream_clusters for d in downstream_clusters]
+
+
+def update_full_blocks(full_paths, tree, threshold, full_blocks, c):
+    for f in full_paths:
+        support = {read_id.replace("_reverse", "") for read_id, _ in tree.find_all(f)}
+        if support:
+            full_blocks[tuple(f)] = support
+
+
+def generate_full_paths(contexts, block_duplicates, full_blocks, tree, threshold):
+    for c in contexts:
+        if block_duplicates[c] is False:
+            ups = cluster_upstream_adjacent_paths(contexts[c]["upstream"])
+            downs = cluster_downstream_adjacent_paths(contexts[c]["downstream"])
+            update_full_blocks(build_full_paths(ups, downs, c), tree, threshold, full_blocks, c)
+
+
+def process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, tree, threshold):
+    for a2 in nodeAnchors:
+        if a1 != a2:
+            block_reads, block_duplicates = get_blocks_from_subtree(sub_tree, a2, nodeAnchors)
+            contexts = generate_contexts(block_reads, block_duplicates, reads)
+            generate_full_paths(contexts, block_duplicates, full_blocks, tree, threshold)
+
+
+def filter_blocks(full_blocks):
+    kept = {}
+    for p in sorted(list(full_blocks.keys()), key=len, reverse=True):
+        fwd = list(p)
+        rev = fwd[::-1]
+        if not any(is_sublist(list(f), fwd) or is_sublist(list(f), rev) for f in kept):
+            kept[p] = full_blocks[p]
+    return kept
+
+
+def get_reads_supporting_path(path, gene_tree):
+    return {read_id.replace("_reverse", "") for read_id, _ in gene_tree.find_all(list(path))}
+
+
+def process_combinations_for_i(args):
+    """every window of length i that holds all copies of the gene, with its read support (:296-310)."""
+    i, threshold, geneOfInterest, lst, gene_call_subset = args
+    gene_tree = Tree(gene_call_subset)
+    plus, minus = f"+{geneOfInterest}", f"-{geneOfInterest}"
+    wanted = lst.count(plus) + lst.count(minus)
+    found = {}
+    for start in range(len(lst) - i + 1):
+        comb = tuple(lst[start:start + i])
+        if comb.count(plus) + comb.count(minus) == wanted:
+            n = len(get_reads_supporting_path(comb, gene_tree))
+            if n >= threshold:
+                found[comb] = n
+    return found

@@ -96,6 +96,10 @@ int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offse
 int amg_set_positions(amg_ctx* ctx, const int64_t* gene_start, const int64_t* gene_end,
                       const int64_t* read_len, int on_device);
 
+/* per-read sequence length only (len(fastq[read]["sequence"]), construct_graph.py:1685);
+ * may be called any time before amg_correct_reads */
+int amg_set_read_lengths(amg_ctx* ctx, const int64_t* read_len, int on_device);
+
 /* ---- build: GeneMerGraph.__init__ (construct_graph.py:31-102), i.e.
  *      Read.get_geneMers (construct_read.py:37-59), define_geneMer
  *      (construct_gene_mer.py:42-56), add_node (:196-212), add_node_to_read (:165-178),
