@@ -604,6 +604,7 @@ static int build_once(amg_ctx* c, int k, int* which) {
                                 (size_t)(2 * D + 1)));
   stage_end(c);
 
+  c->ladj_valid = false;
   AMGCHK(c->read_fix.ensure((size_t)R + 1));
   HIPCHK(hipMemsetAsync(c->read_fix.p, 0, (size_t)R + 1, st));
   HIPCHK(hipStreamSynchronize(st));

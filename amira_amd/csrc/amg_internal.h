@@ -138,6 +138,11 @@ struct amg_ctx {
   // adjacency CSR, row 2n = forward list of node n, 2n+1 = backward list
   DevBuf adj_off;   // int64[2 n_nodes + 1]
   DevBuf adj_edge;  // int32[n_edges]
+  // live adjacency (only alive edges, targets inline) — rebuilt lazily after removals
+  DevBuf ladj_off;  // int64[2 n_nodes + 1]
+  DevBuf ladj;      // int2[n_live_edges]  {target node, target direction}
+  DevBuf ladj_cnt;  // uint32[2 n_nodes + 1] scratch of its own (callers hold s0..s5)
+  bool ladj_valid = false;
   // reads
   DevBuf read_fix;  // uint8[n_reads]  read is in _readsToCorrect
 

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void k_mask_reads(int* __restrict__ tok_node,
 
 static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
   hipStream_t st = c->stream;
+  c->ladj_valid = false;
   if (c->n_edges > 0)
     hipLaunchKernelGGL(k_filter_edges, dim3(nblk(c->n_edges, 256)), dim3(256), 0, st,
                        c->edge_src.as<int>(), c->edge_tgt.as<int>(), c->edge_cov.as<unsigned int>(),
@@ -109,11 +110,10 @@ extern "C" int amg_remove_nodes(amg_ctx* c, const int32_t* node_ids, int64_t n) 
 
 // ------------------------------------------------------------------ graph view for walkers
 struct GView {
-  const long long* adj_off;
-  const int* adj_edge;
-  const int* e_tgt;
-  const signed char* e_tdir;
-  const unsigned char* e_alive;
+  // live adjacency: row 2n = forward list of node n, row 2n+1 = backward list, only ALIVE
+  // edges, in list order, with the target inline (.x = target node, .y = target direction)
+  const long long* lrow;
+  const int2* lent;
   const unsigned char* n_alive;
   const unsigned int* n_cov;
   const int* n_tok;
@@ -122,13 +122,60 @@ struct GView {
   int k, flip;
 };
 
+__global__ void k_live_count(const long long* __restrict__ adj_off, const int* __restrict__ adj_edge,
+                             const unsigned char* __restrict__ e_alive, long long n_rows,
+                             unsigned int* __restrict__ cnt) {
+  long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  unsigned int n = 0;
+  for (long long p = adj_off[row]; p < adj_off[row + 1]; ++p) n += e_alive[adj_edge[p]] ? 1u : 0u;
+  cnt[row] = n;
+}
+
+__global__ void k_live_fill(const long long* __restrict__ adj_off, const int* __restrict__ adj_edge,
+                            const unsigned char* __restrict__ e_alive, const int* __restrict__ e_tgt,
+                            const signed char* __restrict__ e_tdir, long long n_rows,
+                            const long long* __restrict__ lrow, int2* __restrict__ lent) {
+  long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  long long o = lrow[row];
+  for (long long p = adj_off[row]; p < adj_off[row + 1]; ++p) {
+    int e = adj_edge[p];
+    if (e_alive[e]) lent[o++] = make_int2(e_tgt[e], (int)e_tdir[e]);
+  }
+}
+
+// forward/backward edge lists with the removed edges squeezed out: the walkers below then
+// never touch a dead edge (a hub node of an uncorrected graph lists hundreds of them)
+static int ensure_live_adj(amg_ctx* c) {
+  if (c->ladj_valid) return AMG_OK;
+  hipStream_t st = c->stream;
+  const long long rows = 2 * c->n_nodes;
+  AMGCHK(c->ladj_off.ensure((size_t)(rows + 2) * sizeof(long long)));
+  AMGCHK(c->ladj_cnt.ensure((size_t)(rows + 2) * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->ladj_cnt.p, 0, (size_t)(rows + 2) * sizeof(unsigned int), st));
+  if (rows > 0)
+    hipLaunchKernelGGL(k_live_count, dim3(nblk(rows, 256)), dim3(256), 0, st, c->adj_off.as<long long>(),
+                       c->adj_edge.as<int>(), c->edge_alive.as<unsigned char>(), rows,
+                       c->ladj_cnt.as<unsigned int>());
+  AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_off.as<long long>(), (size_t)rows + 1));
+  long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->ladj_off.as<long long>() + rows, sizeof(long long),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(c->ladj.ensure((size_t)(total + 1) * sizeof(int2)));
+  if (rows > 0)
+    hipLaunchKernelGGL(k_live_fill, dim3(nblk(rows, 256)), dim3(256), 0, st, c->adj_off.as<long long>(),
+                       c->adj_edge.as<int>(), c->edge_alive.as<unsigned char>(), c->edge_tgt.as<int>(),
+                       c->edge_tdir.as<signed char>(), rows, c->ladj_off.as<long long>(), c->ladj.as<int2>());
+  c->ladj_valid = true;
+  return AMG_OK;
+}
+
 static GView make_view(amg_ctx* c) {
   GView g;
-  g.adj_off = c->adj_off.as<long long>();
-  g.adj_edge = c->adj_edge.as<int>();
-  g.e_tgt = c->edge_tgt.as<int>();
-  g.e_tdir = c->edge_tdir.as<signed char>();
-  g.e_alive = c->edge_alive.as<unsigned char>();
+  g.lrow = c->ladj_off.as<long long>();
+  g.lent = c->ladj.as<int2>();
   g.n_alive = c->node_alive.as<unsigned char>();
   g.n_cov = c->node_cov.as<unsigned int>();
   g.n_tok = c->node_tokens.as<int>();
@@ -139,33 +186,22 @@ static GView make_view(amg_ctx* c) {
   return g;
 }
 
-__device__ __forceinline__ int row_live(const GView& g, long long row) {
-  int n = 0;
-  for (long long p = g.adj_off[row]; p < g.adj_off[row + 1]; ++p) n += g.e_alive[g.adj_edge[p]] ? 1 : 0;
-  return n;
-}
 // get_degree (:326-329): live edge classes on both sides
 __device__ __forceinline__ int node_degree(const GView& g, int n) {
-  return row_live(g, 2ll * n) + row_live(g, 2ll * n + 1);
+  return (int)(g.lrow[2ll * n + 2] - g.lrow[2ll * n]);
 }
 
 // get_forward_node_from_node (:722-741) / get_backward_node_from_node (:781-802):
 // forward needs EXACTLY one live forward edge, backward takes the FIRST live backward edge.
 // returns 0 = no edge, 1 = edge but cannot extend, 2 = extend
 __device__ __forceinline__ int lin_step(const GView& g, int n, bool use_forward, int* tgt, int* tdir) {
-  long long row = 2ll * n + (use_forward ? 0 : 1);
-  int found = -1, cnt = 0;
-  for (long long p = g.adj_off[row]; p < g.adj_off[row + 1]; ++p) {
-    int e = g.adj_edge[p];
-    if (!g.e_alive[e]) continue;
-    if (found < 0) found = e;
-    ++cnt;
-    if (!use_forward) break;
-  }
-  if (found < 0 || (use_forward && cnt != 1)) return 0;
-  *tgt = g.e_tgt[found];
-  *tdir = g.e_tdir[found];
-  int deg = node_degree(g, *tgt);
+  const long long row = 2ll * n + (use_forward ? 0 : 1);
+  const long long a = g.lrow[row], cnt = g.lrow[row + 1] - a;
+  if (cnt == 0 || (use_forward && cnt != 1)) return 0;
+  const int2 ent = g.lent[a];
+  *tgt = ent.x;
+  *tdir = ent.y;
+  const int deg = node_degree(g, *tgt);
   return ((deg == 1 || deg == 2) && *tgt != n) ? 2 : 1;
 }
 
@@ -218,9 +254,26 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
                             const unsigned int* __restrict__ cov, long long n, unsigned int min_cov,
                             unsigned int* __restrict__ live_cnt, unsigned int* __restrict__ high_cnt) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !alive[i]) return;
-  atomicAdd(&live_cnt[comp[i]], 1u);
-  if (high_cnt && cov[i] >= min_cov) atomicAdd(&high_cnt[comp[i]], 1u);
+  bool active = i < n && alive[i];
+  const int cid = active ? comp[i] : -1;
+  const bool high = active && high_cnt && cov[i] >= min_cov;
+  const int lane = threadIdx.x & 63;
+  // most nodes share one giant component: aggregate equal ids inside the wave so that a
+  // wave issues one atomic per distinct component instead of one per node
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lc = __shfl(cid, leader, 64);
+    const bool same = active && cid == lc;
+    const unsigned long long m = __ballot(same);
+    const unsigned long long mh = __ballot(same && high);
+    if (lane == leader) {
+      atomicAdd(&live_cnt[lc], (unsigned int)__popcll(m));
+      if (high_cnt && mh) atomicAdd(&high_cnt[lc], (unsigned int)__popcll(mh));
+    }
+    active = active && !same;
+    todo &= ~m;
+  }
 }
 
 __global__ void k_cov_sum(const unsigned int* __restrict__ cov, const unsigned char* __restrict__ alive,
@@ -316,6 +369,7 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
     HIPCHK(hipMemcpyAsync(c->s5.p, protect, (size_t)D, hipMemcpyHostToDevice, st));
     d_protect = c->s5.as<unsigned char>();
   }
+  AMGCHK(ensure_live_adj(c));
   hipLaunchKernelGGL(k_clip_mark, dim3(nblk(D, 128)), dim3(128), 0, st, make_view(c), D, (int)min_length,
                      thr, c->s4.as<unsigned int>(), d_protect, c->s0.as<unsigned char>());
   int r = finish_kill(c, n_removed, removed_ids);
@@ -523,20 +577,19 @@ __device__ void dfs_paths(const GView& g, int s, int sdir, int e, int distance, 
         continue;
       }
       long long row = 2ll * node[depth] + (dir[depth] == 1 ? 0 : 1);
-      cur[depth] = g.adj_off[row];
-      lim[depth] = g.adj_off[row + 1];
+      cur[depth] = g.lrow[row];
+      lim[depth] = g.lrow[row + 1];
       entering = false;
     }
     bool pushed = false;
     while (cur[depth] < lim[depth]) {
-      int ed = g.adj_edge[cur[depth]++];
-      if (!g.e_alive[ed]) continue;
-      int t = g.e_tgt[ed];
+      const int2 ent = g.lent[cur[depth]++];
+      int t = ent.x;
       bool seen = false;
       for (int j = 0; j <= depth; ++j) seen = seen || (node[j] == t);
       if (seen) continue;
       node[depth + 1] = t;
-      dir[depth + 1] = g.e_tdir[ed];
+      dir[depth + 1] = ent.y;
       ++depth;
       entering = true;
       pushed = true;
@@ -586,6 +639,7 @@ struct GapArgs {
   int* cand;               // candidate scratch, [grid threads * cand_stride]
   unsigned int cand_stride;
   unsigned char* final_cls;
+  unsigned char* need_slow;  // per gapped read: 1 = the wave-per-read fast kernel gave up
 };
 
 // build candidate `combo` (mixed radix over the gaps' path choices) into (out_node, out_dir);
@@ -635,6 +689,7 @@ __global__ __launch_bounds__(64) void k_corr_gapped(GapArgs A) {
   const long long gstride = (long long)gridDim.x * blockDim.x;
   int* my = A.cand + gtid * (long long)A.cand_stride;
   for (long long gi = gtid; gi < A.n_gapped; gi += gstride) {
+    if (!A.need_slow[gi]) continue;
     const long long r = A.gapped_reads[gi];
     const long long t0 = a.read_off[r];
     const int L0 = (int)(a.read_off[r + 1] - t0);
@@ -741,7 +796,300 @@ __global__ __launch_bounds__(64) void k_corr_gapped(GapArgs A) {
   }
 }
 
-// ---- positions for gapped reads: one wave per read
+#define NWF_MAX_M 64
+#define NWF_MAX_N 128
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ bool nw_fast_ok(long long N, long long M) {
+  return N <= NWF_MAX_N && M <= NWF_MAX_M && N > 0 && M > 0;
+}
+
+
+// ---- fast path of the gapped-read kernel: one wave per read, everything staged in LDS.
+// Reads that exceed any of its fixed capacities are flagged (need_slow) and left to the
+// general one-thread-per-read kernel above; results are identical by construction (same
+// DFS order, same product order, same comparisons).
+#define GF_MAXW 128     // windows per read
+#define GF_MAXGAP 16    // None runs per read
+#define GF_POOL 512     // ints of path records per read
+#define GF_CAND 192     // nodes of a candidate
+#define GF_MAXCOMBO 256
+
+// DFS of one None run with its stack in LDS (no private arrays: per-lane scratch would be
+// allocated for all 64 lanes and throttle occupancy).  Run by ONE lane of the wave.
+// Emits [run, len, nodes, dirs] records; returns the number of paths, -1 on pool overflow.
+struct DfsStack {
+  int* node;   // [DFS_MAX]
+  int* dir;    // [DFS_MAX]
+  int* cur;    // [DFS_MAX]  position in the adjacency row (edge ids are int32, so offsets fit)
+  int* lim;    // [DFS_MAX]
+};
+
+__device__ int dfs_paths_lds(const GView& g, const DfsStack& st, int s, int sdir, int e, int distance,
+                             int run, int* pool, int* used) {
+  int depth = 0, n_paths = 0;
+  bool overflow = false;
+  st.node[0] = s;
+  st.dir[0] = sdir;
+  bool entering = true;
+  while (depth >= 0) {
+    if (entering) {
+      const int L = depth + 1;
+      if (st.node[depth] == e && L <= distance) {
+        const int off = *used;
+        *used = off + 2 + 2 * L;
+        if (off + 2 + 2 * L <= GF_POOL) {
+          int* o = pool + off;
+          o[0] = run;
+          o[1] = L;
+          for (int j = 0; j < L; ++j) {
+            o[2 + j] = st.node[j];
+            o[2 + L + j] = st.dir[j];
+          }
+        } else {
+          overflow = true;
+        }
+        ++n_paths;
+        --depth;
+        entering = false;
+        continue;
+      }
+      if (L - 1 > distance) {
+        --depth;
+        entering = false;
+        continue;
+      }
+      const long long row = 2ll * st.node[depth] + (st.dir[depth] == 1 ? 0 : 1);
+      st.cur[depth] = (int)g.lrow[row];
+      st.lim[depth] = (int)g.lrow[row + 1];
+      entering = false;
+    }
+    bool pushed = false;
+    while (st.cur[depth] < st.lim[depth]) {
+      const int2 ent = g.lent[st.cur[depth]];
+      st.cur[depth] += 1;
+      const int t = ent.x;
+      bool seen = false;
+      for (int j = 0; j <= depth; ++j) seen = seen || (st.node[j] == t);
+      if (seen) continue;
+      st.node[depth + 1] = t;
+      st.dir[depth + 1] = ent.y;
+      ++depth;
+      entering = true;
+      pushed = true;
+      break;
+    }
+    if (!pushed) --depth;
+  }
+  return overflow ? -1 : n_paths;
+}
+
+__global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
+  __shared__ int s_node[4][GF_MAXW];
+  __shared__ signed char s_dir[4][GF_MAXW];
+  __shared__ int s_tok[4][GF_MAXW + AMG_MAX_K];
+  __shared__ int s_gap[4][GF_MAXGAP * 3];  // ps, pe, n_paths
+  __shared__ int s_pool[4][GF_POOL];
+  __shared__ int s_used[4];
+  __shared__ int s_cnode[4][GF_CAND];
+  __shared__ signed char s_cdir[4][GF_CAND];
+  __shared__ int s_gene[4][GF_CAND + AMG_MAX_K];
+  __shared__ int s_best[4][GF_CAND + AMG_MAX_K];
+  __shared__ int s_misc[4][4];
+  __shared__ int s_stack[4][4 * DFS_MAX];
+  const CorrArgs& a = A.a;
+  const GView& g = A.g;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long gi = (long long)blockIdx.x * 4 + wv;
+  if (gi >= A.n_gapped) return;
+  const long long r = A.gapped_reads[gi];
+  const long long t0 = a.read_off[r];
+  const int L0 = (int)(a.read_off[r + 1] - t0);
+  const int nwin = L0 - g.k + 1;
+  const int start = a.r_start[r], end = a.r_end[r];
+  const long long dst = a.tmp_off[r];
+  if (nwin > GF_MAXW) {
+    if (lane == 0) A.need_slow[gi] = 1;
+    return;
+  }
+  int* W = s_node[wv];
+  signed char* Dr = s_dir[wv];
+  int* TK = s_tok[wv];
+  int* GAP = s_gap[wv];
+  int* POOL = s_pool[wv];
+  for (int i = lane; i < nwin; i += 64) {
+    W[i] = a.tok_node[t0 + i];
+    Dr[i] = a.tok_dir[t0 + i];
+  }
+  for (int i = lane; i < L0; i += 64) TK[i] = a.tokens[t0 + i];
+  if (lane == 0) s_used[wv] = 0;
+  wave_sync();
+  // ---- None runs in [start, end] (identify_path_terminals), in read order
+  int n_gaps = 0;
+  for (int c0 = start; c0 <= end; c0 += 64) {
+    const int i = c0 + lane;
+    const bool is_end = i <= end && W[i] < 0 && W[i + 1] >= 0;  // i < end whenever W[i] < 0
+    const unsigned long long m = __ballot(is_end);
+    if (is_end) {
+      int q = n_gaps + __popcll(m & ((1ull << lane) - 1ull));
+      if (q < GF_MAXGAP) {
+        int ps = i - 1;
+        while (W[ps] < 0) --ps;
+        GAP[3 * q] = ps;
+        GAP[3 * q + 1] = i + 1;
+        GAP[3 * q + 2] = 0;
+      }
+    }
+    n_gaps += __popcll(m);
+  }
+  if (n_gaps > GF_MAXGAP) {
+    if (lane == 0) A.need_slow[gi] = 1;
+    return;
+  }
+  wave_sync();
+  // ---- one DFS per run (lane 0, runs in read order)
+  bool bad = false;
+  if (lane == 0) {
+    DfsStack stk{s_stack[wv], s_stack[wv] + DFS_MAX, s_stack[wv] + 2 * DFS_MAX, s_stack[wv] + 3 * DFS_MAX};
+    for (int q = 0; q < n_gaps && !bad; ++q) {
+      const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
+      const int np = dfs_paths_lds(g, stk, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv]);
+      GAP[3 * q + 2] = np < 0 ? 0 : np;
+      bad = np < 0;
+    }
+  }
+  if (__any(bad)) {
+    if (lane == 0) A.need_slow[gi] = 1;
+    return;
+  }
+  wave_sync();
+  unsigned long long n_combo = 1;
+  bool dead_end = false;
+  for (int q = 0; q < n_gaps; ++q) {
+    int np = GAP[3 * q + 2];
+    dead_end = dead_end || np == 0;
+    n_combo *= (unsigned long long)np;
+    if (n_combo > GF_MAXCOMBO) break;
+  }
+  if (dead_end) {
+    // possible_paths == []: the original genes (and positions) are kept (:1292-1293)
+    for (int i = lane; i < L0; i += 64) {
+      a.tmp_tok[dst + i] = TK[i];
+      if (a.have_pos) {
+        a.tmp_gs[dst + i] = a.gstart[t0 + i];
+        a.tmp_ge[dst + i] = a.gend[t0 + i];
+      }
+    }
+    if (lane == 0) {
+      a.new_len[r] = (unsigned int)L0;
+      A.final_cls[r] = RC_KEEP_ORIG;
+    }
+    return;
+  }
+  if (n_combo > GF_MAXCOMBO) {
+    if (lane == 0) A.need_slow[gi] = 1;
+    return;
+  }
+  int* CN = s_cnode[wv];
+  signed char* CD = s_cdir[wv];
+  int* GN = s_gene[wv];
+  int* BEST = s_best[wv];
+  const int used = s_used[wv];
+  int best_shared = 0, best_ng = -1;
+  unsigned long long best_sum = 0, best_len = 1;
+  for (unsigned long long combo = 0; combo < n_combo; ++combo) {
+    // ---- candidate node list (lane 0): live windows + the chosen path of every run
+    if (lane == 0) {
+      int n = 0, q = 0, i = start, prev_pe = -1;
+      bool over = false;
+      while (i <= end && !over) {
+        if (q < n_gaps && GAP[3 * q] == i) {
+          const int ps = GAP[3 * q], pe = GAP[3 * q + 1], np = GAP[3 * q + 2];
+          unsigned long long div = 1;
+          for (int j = q + 1; j < n_gaps; ++j) div *= (unsigned long long)GAP[3 * j + 2];
+          int pick = (int)((combo / div) % (unsigned long long)np);
+          int off = 0;
+          while (off < used) {  // records of run q appear in DFS order
+            if (POOL[off] == q) {
+              if (pick == 0) break;
+              --pick;
+            }
+            off += 2 + 2 * POOL[off + 1];
+          }
+          const int L = POOL[off + 1];
+          if (prev_pe == ps && n > 0) --n;
+          if (n + L > GF_CAND) { over = true; break; }
+          for (int j = 0; j < L; ++j) {
+            CN[n] = POOL[off + 2 + j];
+            CD[n] = (signed char)POOL[off + 2 + L + j];
+            ++n;
+          }
+          prev_pe = pe;
+          i = pe;
+          ++q;
+          if (!(q < n_gaps && GAP[3 * q] == pe)) i = pe + 1;
+        } else {
+          if (n + 1 > GF_CAND) { over = true; break; }
+          CN[n] = W[i];
+          CD[n] = Dr[i];
+          ++n;
+          ++i;
+        }
+      }
+      s_misc[wv][0] = over ? -1 : n;
+    }
+    wave_sync();
+    const int n = s_misc[wv][0];
+    if (n < 0) {
+      if (lane == 0) A.need_slow[gi] = 1;
+      return;
+    }
+    const int ng = n + g.k - 1;
+    // ---- genes (get_annotation_for_read) and coverage sum, lane-parallel
+    unsigned long long csum = 0;
+    for (int q = lane; q < ng; q += 64) {
+      const int idx = q < g.k - 1 ? 0 : q - (g.k - 1);
+      const int j = q < g.k - 1 ? q : g.k - 1;
+      GN[q] = oriented_tok(g, CN[idx], CD[idx], j);
+    }
+    for (int q = lane; q < n; q += 64) csum += g.n_cov[CN[q]];
+    for (int d = 32; d > 0; d >>= 1) csum += __shfl_xor(csum, d, 64);
+    wave_sync();
+    bool better = true;
+    if (n_combo > 1) {
+      // len(set(genes) & set(original genes))
+      int shared = 0;
+      for (int q = lane; q < ng; q += 64) {
+        const int tk = GN[q];
+        bool dup = false;
+        for (int w = 0; w < q && !dup; ++w) dup = (GN[w] == tk);
+        bool hit = false;
+        if (!dup)
+          for (int w = 0; w < L0 && !hit; ++w) hit = (TK[w] == tk);
+        shared += hit ? 1 : 0;
+      }
+      for (int d = 32; d > 0; d >>= 1) shared += __shfl_xor(shared, d, 64);
+      better = shared > best_shared ||
+               (shared == best_shared && csum * best_len > best_sum * (unsigned long long)n);
+      if (better) best_shared = shared;
+    }
+    if (better) {
+      best_sum = csum;
+      best_len = (unsigned long long)n;
+      best_ng = ng;
+      for (int q = lane; q < ng; q += 64) BEST[q] = GN[q];
+    }
+    wave_sync();
+  }
+  for (int q = lane; q < best_ng; q += 64) a.tmp_tok[dst + q] = BEST[q];
+  if (lane == 0) a.new_len[r] = (unsigned int)best_ng;
+}
+
+// ---- positions for gapped reads: one wave per read (general path: any N, M)
 #define NW_LDS_N 1024       // rows kept in LDS (rolling anti-diagonals, op list)
 #define NW_LDS_CELLS 16384  // pointer-matrix cells kept in LDS (one byte each)
 
@@ -752,6 +1100,7 @@ struct NwArgs {
   const unsigned char* final_cls;
   const long long* big_off;  // per gapped read: byte offset of its global scratch (big reads only)
   unsigned char* big_buf;
+  int allow_fast;            // 0: every read takes the general kernel (debugging / A-B switch)
 };
 
 __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
@@ -767,6 +1116,7 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
   const long long t0 = a.read_off[r];
   const int M = (int)(a.read_off[r + 1] - t0);  // y = original genes
   const int N = (int)a.new_len[r];              // x = corrected genes
+  if (A.allow_fast && nw_fast_ok(N, M)) return;  // k_corr_nw_fast handles it
   const long long dst = a.tmp_off[r];
   const int* x = a.tmp_tok + dst;
   const int* y = a.tokens + t0;
@@ -857,6 +1207,127 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
       a.tmp_gs[dst + q] = prev_end;
       a.tmp_ge[dst + q] = (nxt != NONE) ? nxt : rl - 1;
     }
+  }
+}
+
+
+// ---- fast path: M <= 64 original genes, N <= 128 corrected genes.  One wave per read, no
+// workgroup barriers: lane j owns column j of the DP matrix and the wave sweeps anti-diagonals
+// systolically — F[i-1,j] stays in the lane's own register, F[i,j-1] / F[i-1,j-1] arrive from
+// lane j-1 by shuffle.  Pointers are packed 2 bits per cell (16 rows per LDS word per lane).
+
+__global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
+  __shared__ unsigned int s_ptr[4][(NWF_MAX_N / 16) * 64];
+  __shared__ int s_x[4][NWF_MAX_N];
+  __shared__ unsigned char s_ops[4][NWF_MAX_N + NWF_MAX_M];
+  __shared__ long long s_gs[4][NWF_MAX_N];
+  __shared__ long long s_ge[4][NWF_MAX_N];
+  const CorrArgs& a = A.a;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long gi = (long long)blockIdx.x * 4 + wv;
+  if (gi >= A.n_gapped) return;
+  const long long r = A.gapped_reads[gi];
+  if (A.final_cls[r] == RC_KEEP_ORIG) return;
+  const long long t0 = a.read_off[r];
+  const int M = (int)(a.read_off[r + 1] - t0);
+  const int N = (int)a.new_len[r];
+  if (!nw_fast_ok(N, M)) return;  // k_corr_nw handles it
+  const long long dst = a.tmp_off[r];
+  unsigned int* P = s_ptr[wv];
+  int* X = s_x[wv];
+  unsigned char* ops = s_ops[wv];
+  long long* GS = s_gs[wv];
+  long long* GE = s_ge[wv];
+  for (int i = lane; i < N; i += 64) X[i] = a.tmp_tok[dst + i];
+  const int yj = lane < M ? a.tokens[t0 + lane] : -1;
+  wave_sync();
+  // ---- fill
+  int prev1 = 0, prev2 = 0;  // this lane's value one / two steps ago
+  unsigned int acc = 0;
+  for (int s = 0; s <= N + M - 2; ++s) {
+    const int i = s - lane;
+    const int l1 = __shfl_up(prev1, 1, 64);  // F[i, j-1]
+    const int l2 = __shfl_up(prev2, 1, 64);  // F[i-1, j-1]
+    const bool active = (lane < M) && i >= 0 && i < N;
+    int best = prev1;
+    if (active) {
+      const int f_up = (i == 0) ? -lane : prev1;  // F[i-1, j]
+      const int f_left = (lane == 0) ? -i : l1;   // F[i, j-1]
+      const int f_diag = (i == 0) ? (lane == 0 ? 0 : -(lane - 1)) : (lane == 0 ? -(i - 1) : l2);
+      const int s_d = f_diag + (X[i] == yj ? 1 : 0);
+      const int s_l = f_up - 1;    // pointer LEFT = (-1, 0)
+      const int s_u = f_left - 1;  // pointer UP   = (0, -1)
+      best = s_d;
+      unsigned int ptr = 0;
+      if (s_l >= best) { best = s_l; ptr = 1; }
+      if (s_u >= best) { best = s_u; ptr = 2; }
+      acc |= ptr << ((i & 15) * 2);
+      if ((i & 15) == 15 || i == N - 1) {
+        P[(i >> 4) * 64 + lane] = acc;
+        acc = 0;
+      }
+    }
+    prev2 = prev1;
+    prev1 = best;
+  }
+  wave_sync();
+  // ---- traceback (lane 0), ops back to front
+  int n_ops = 0;
+  if (lane == 0) {
+    int i = N - 1, j = M - 1;
+    while (i >= 0 && j >= 0) {
+      unsigned int p = (P[(i >> 4) * 64 + j] >> ((i & 15) * 2)) & 3u;
+      ops[n_ops++] = (unsigned char)p;
+      if (p == 0) { --i; --j; }
+      else if (p == 1) --i;
+      else --j;
+    }
+    while (i >= 0) { ops[n_ops++] = 1; --i; }
+    while (j >= 0) { ops[n_ops++] = 2; --j; }
+  }
+  n_ops = __shfl(n_ops, 0, 64);
+  wave_sync();
+  // ---- positions, in parallel over the alignment columns (front to back)
+  const long long NONE = (long long)0x8000000000000000ull;
+  int base_x = 0, base_y = 0, base_cur = 0;
+  for (int c0 = 0; c0 < n_ops; c0 += 64) {
+    const int f = c0 + lane;
+    const bool in = f < n_ops;
+    const unsigned char op = in ? ops[n_ops - 1 - f] : 3;
+    const bool isx = in && (op == 0 || op == 1), isy = in && (op == 0 || op == 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long bx = __ballot(isx), by = __ballot(isy);
+    const int xi = base_x + __popcll(bx & lt), yy = base_y + __popcll(by & lt);
+    const int ysel = __shfl(yj, yy < 64 ? yy : 0, 64);  // all lanes take part in the shuffle
+    const bool match = in && op == 0 && X[xi < NWF_MAX_N ? xi : 0] == ysel;
+    const bool inc = in && (op == 2 || match);
+    const unsigned long long bc = __ballot(inc);
+    const int cur = base_cur + __popcll(bc & lt);
+    if (isx) {
+      GS[xi] = match ? a.gstart[t0 + cur] : NONE;
+      GE[xi] = match ? a.gend[t0 + cur] : NONE;
+    }
+    base_x += __popcll(bx);
+    base_y += __popcll(by);
+    base_cur += __popcll(bc);
+  }
+  wave_sync();
+  // ---- replace_invalid_gene_positions, each lane repairs its own entries
+  const long long rl = a.read_len ? a.read_len[r] : 0;
+  for (int q = lane; q < N; q += 64) {
+    long long sv = GS[q], ev = GE[q];
+    if (sv == NONE && ev == NONE) {
+      long long prev_end = 0;
+      for (int w = q - 1; w >= 0; --w)
+        if (GE[w] != NONE) { prev_end = GE[w]; break; }
+      long long nxt = NONE;
+      for (int w = q + 1; w < N; ++w)
+        if (GS[w] != NONE) { nxt = GS[w]; break; }
+      sv = prev_end;
+      ev = (nxt != NONE) ? nxt : rl - 1;
+    }
+    a.tmp_gs[dst + q] = sv;
+    a.tmp_ge[dst + q] = ev;
   }
 }
 
@@ -1024,6 +1495,9 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   stage_end(c);
 
   if (n_gapped > 0) {
+    stage_begin(c, "live_adjacency");
+    AMGCHK(ensure_live_adj(c));
+    stage_end(c);
     stage_begin(c, "correct_gapped");
     // gapped read list, path pool, candidate scratch: their own allocations
     DevBuf& glist = c->c_orig;  // free until the pack step
@@ -1034,7 +1508,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     unsigned int cand_stride = (unsigned int)(2 * max_bound + (max_bound + 3) / 4 + c->k + 16);
     DevBuf& cand = c->c_gstart;  // free until the pack step
     AMGCHK(cand.ensure((size_t)threads_total * cand_stride * sizeof(int)));
-    unsigned long long pool_cap = (unsigned long long)n_gapped * 64ull + (1ull << 20);
+    // the general kernel only sees what the fast kernel hands over: start small, grow on demand
+    unsigned long long pool_cap = 1ull << 22;
+    AMGCHK(c->c_changed.ensure((size_t)n_gapped + 64));  // free until the pack step
+    unsigned char* need_slow = c->c_changed.as<unsigned char>();
     for (int attempt = 0;; ++attempt) {
       DevBuf& pool = c->c_gend;  // free until the pack step
       AMGCHK(pool.ensure((size_t)pool_cap * sizeof(int)));
@@ -1052,6 +1529,14 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       G.cand = cand.as<int>();
       G.cand_stride = cand_stride;
       G.final_cls = final_cls;
+      G.need_slow = need_slow;
+      if (attempt == 0) {
+        const char* nf = getenv("AMG_NO_FAST_GAPPED");  // debugging / A-B switch
+        const bool use_fast = !(nf && nf[0] == '1');
+        HIPCHK(hipMemsetAsync(need_slow, use_fast ? 0 : 1, (size_t)n_gapped + 1, st));
+        if (use_fast)
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, G);
+      }
       unsigned int blocks = (unsigned int)((n_gapped + 63) / 64);
       if (blocks > 2048u) blocks = 2048u;
       hipLaunchKernelGGL(k_corr_gapped, dim3(blocks), dim3(64), 0, st, G);
@@ -1086,6 +1571,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       W.final_cls = final_cls;
       W.big_off = nw_off;
       W.big_buf = big.as<unsigned char>();
+      const char* nfn = getenv("AMG_NO_FAST_NW");
+      W.allow_fast = !(nfn && nfn[0] == '1');
+      if (W.allow_fast)
+        hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, W);
       hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
       stage_end(c);
     }
