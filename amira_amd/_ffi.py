@@ -35,6 +35,13 @@ def _load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C amira_amd/csrc).  amira_amd has no CPU fallback."
         )
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not share
+    # the device.  Importing torch first makes the loader reuse the already-loaded runtime
+    # (same soname) for libamg.so, whichever order the application imports things in.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001 - torch is optional for the single-GPU path
+        pass
     lib = C.CDLL(LIB_PATH)
     P, I32, I64, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     sig = {
@@ -62,9 +69,17 @@ def _load():
         "amg_get_corrected": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_adopt_corrected": (C.c_int, [P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),
-        "amg_dist_unique_id": (C.c_int, [P]),
-        "amg_dist_init": (C.c_int, [P, P, C.c_int, C.c_int]),
-        "amg_dist_build": (C.c_int, [P, I32, I64, I64]),
+        "amg_dist_record_bytes": (C.c_int, [I32, C.POINTER(I64), C.POINTER(I64)]),
+        "amg_dist_nodes_local": (C.c_int, [P, I32, I64, I64, I32, P]),
+        "amg_dist_nodes_pack": (C.c_int, [P, P]),
+        "amg_dist_nodes_reduce": (C.c_int, [P, P, I64, C.POINTER(I64)]),
+        "amg_dist_nodes_owned": (C.c_int, [P, P]),
+        "amg_dist_nodes_global": (C.c_int, [P, P, I64]),
+        "amg_dist_edges_local": (C.c_int, [P, I32, P]),
+        "amg_dist_edges_pack": (C.c_int, [P, P]),
+        "amg_dist_edges_reduce": (C.c_int, [P, P, I64, C.POINTER(I64)]),
+        "amg_dist_edges_owned": (C.c_int, [P, P]),
+        "amg_dist_edges_global": (C.c_int, [P, P, I64]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     }
     for name, (res, args) in sig.items():

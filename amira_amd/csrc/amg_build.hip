@@ -111,8 +111,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
     const int* __restrict__ tokens, const long long* __restrict__ read_off,
     const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k,
     int two_v, unsigned long long seed, Slot* __restrict__ tab, unsigned long long mask,
-    unsigned int probe_limit, int* __restrict__ tok_slot, signed char* __restrict__ tok_dir,
-    unsigned long long* status) {
+    unsigned int probe_limit, long long tok_base, int* __restrict__ tok_slot,
+    signed char* __restrict__ tok_dir, unsigned long long* status) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
   const long long t0 = (long long)blockIdx.x * TILE;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
         status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
       } else {
         unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed);
-        unsigned long long first = ((unsigned long long)t << 1) | (dir < 0 ? 1ull : 0ull);
+        unsigned long long first = ((unsigned long long)(tok_base + t) << 1) | (dir < 0 ? 1ull : 0ull);
         long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit);
         if (slot < 0) {
           status[ST_OVERFLOW] = 1;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_compact_slots(const Slot* __restrict__ 
 __global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sorted,
                                const unsigned int* __restrict__ slot_sorted, long long n_nodes,
                                Slot* __restrict__ tab, const int* __restrict__ tokens, int k,
-                               int two_v, int* __restrict__ node_tokens,
+                               int two_v, long long tok_base, int* __restrict__ node_tokens,
                                unsigned int* __restrict__ node_cov,
                                long long* __restrict__ node_first,
                                unsigned char* __restrict__ node_alive) {
@@ -202,7 +202,7 @@ __global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sort
   node_cov[i] = tab[slot].count;
   node_first[i] = (long long)first;
   node_alive[i] = 1;
-  long long t = (long long)(first >> 1);
+  long long t = (long long)(first >> 1) - tok_base;
   int dir = (first & 1ull) ? -1 : 1;
   const int flip = two_v - 1;
   for (int j = 0; j < k; ++j)
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
     const Slot* __restrict__ node_tab, const int* __restrict__ node_tokens,
     const int* __restrict__ tok_slot, const signed char* __restrict__ tok_dir,
     int* __restrict__ tok_node, Slot* __restrict__ edge_tab, unsigned long long edge_mask,
-    unsigned int probe_limit, int verify, unsigned long long* status) {
+    unsigned int probe_limit, int verify, long long tok_base, unsigned long long* status) {
   __shared__ int s_id[TILE + 1];
   __shared__ int s_raw[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];
@@ -264,42 +264,51 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
                              (unsigned long long)(hi + 1u);
     unsigned long long orient = (a == lo ? 1ull : 0ull) | (dA > 0 ? 2ull : 0ull) |
                                 (dB > 0 ? 4ull : 0ull);
-    unsigned long long first = ((unsigned long long)(t0 + i) << 3) | orient;
+    unsigned long long first = ((unsigned long long)(tok_base + t0 + i) << 3) | orient;
     long long slot = table_upsert(edge_tab, edge_mask, key, mix64(key), first, probe_limit);
     if (slot < 0) status[ST_OVERFLOW] = 2;
   }
 }
 
 // ------------------------------------------------------------------ edge emission
-// width of pair i in directed edges: self-loop 1, otherwise 2 (SURVEY Appendix A.6)
-__global__ void k_pair_width(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
-                             const Slot* __restrict__ edge_tab, unsigned int* __restrict__ width) {
+// edge classes ("pairs") in first-seen order as plain arrays: key, count, first
+__global__ void k_gather_pairs(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
+                               const Slot* __restrict__ edge_tab, unsigned long long* __restrict__ pkey,
+                               unsigned int* __restrict__ pcnt) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
-  unsigned long long key = edge_tab[slot_sorted[i]].key;
+  const Slot* s = edge_tab + slot_sorted[i];
+  pkey[i] = s->key;
+  pcnt[i] = s->count;
+}
+
+// width of pair i in directed edges: self-loop 1, otherwise 2 (SURVEY Appendix A.6)
+__global__ void k_pair_width(const unsigned long long* __restrict__ pkey, long long n_pairs,
+                             unsigned int* __restrict__ width) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  unsigned long long key = pkey[i];
   unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
   unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
   width[i] = lo == hi ? 1u : 2u;
 }
 
-__global__ void k_emit_edges(const unsigned long long* __restrict__ first_sorted,
-                             const unsigned int* __restrict__ slot_sorted, long long n_pairs,
-                             Slot* __restrict__ edge_tab, const long long* __restrict__ base,
-                             int* __restrict__ e_src, int* __restrict__ e_tgt,
-                             signed char* __restrict__ e_sdir, signed char* __restrict__ e_tdir,
-                             unsigned int* __restrict__ e_cov,
+__global__ void k_emit_edges(const unsigned long long* __restrict__ pkey,
+                             const unsigned int* __restrict__ pcnt,
+                             const unsigned long long* __restrict__ pfirst, long long n_pairs,
+                             const long long* __restrict__ base, int* __restrict__ e_src,
+                             int* __restrict__ e_tgt, signed char* __restrict__ e_sdir,
+                             signed char* __restrict__ e_tdir, unsigned int* __restrict__ e_cov,
                              unsigned char* __restrict__ e_alive) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
-  Slot* s = edge_tab + slot_sorted[i];
-  unsigned long long key = s->key, first = first_sorted[i];
+  unsigned long long key = pkey[i], first = pfirst[i];
   int lo = (int)((key >> 32) & 0x7fffffffull);
   int hi = (int)((key & 0xffffffffull) - 1ull);
   int X = (first & 1ull) ? lo : hi, Y = (first & 1ull) ? hi : lo;
   signed char dX = (first & 2ull) ? 1 : -1, dY = (first & 4ull) ? 1 : -1;
   long long e = base[i];
-  s->id = (int)e;
-  unsigned int cnt = s->count;
+  unsigned int cnt = pcnt[i];
   if (lo == hi) {
     // E1 and E2 fall in the same class: one edge, +2 per traversal
     e_src[e] = X; e_tgt[e] = Y; e_sdir[e] = dX; e_tdir[e] = dY;
@@ -341,11 +350,10 @@ __global__ void k_uf_init(int* parent, long long n) {
   if (i < n) parent[i] = (int)i;
 }
 
-__global__ void k_uf_union(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
-                           const Slot* __restrict__ edge_tab, int* parent) {
+__global__ void k_uf_union(const unsigned long long* __restrict__ pkey, long long n_pairs, int* parent) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
-  unsigned long long key = edge_tab[slot_sorted[i]].key;
+  unsigned long long key = pkey[i];
   int a = (int)((key >> 32) & 0x7fffffffull);
   int b = (int)((key & 0xffffffffull) - 1ull);
   while (true) {
@@ -380,6 +388,13 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
 }
 
 // ------------------------------------------------------------------ host orchestration
+// The build is split into stages so that the multi-GPU path (amg_dist.hip) can put its
+// exchanges between them:
+//   bs_nodes_pass        local windows -> local node table (+ compaction list in s1 / s3)
+//   bs_nodes_rank_local  single GPU: node ids from the local table
+//   bs_edges_pass        local adjacencies -> local edge-class table (+ compaction list)
+//   bs_pairs_from_local  single GPU: edge classes in first-seen order as arrays
+//   bs_finish_from_pairs directed edges, components, adjacency lists
 static inline unsigned int blocks_for(long long n, int per) {
   long long b = (n + per - 1) / per;
   return (unsigned int)(b < 1 ? 1 : b);
@@ -392,15 +407,16 @@ static int read_status(amg_ctx* c, unsigned long long* host) {
   return AMG_OK;
 }
 
-static uint64_t pow2_at_least(uint64_t x) {
+uint64_t pow2_at_least(uint64_t x) {
   uint64_t p = 1024;
   while (p < x) p <<= 1;
   return p;
 }
 
-// one attempt; returns AMG_OK, or AMG_E_OVERFLOW (1 = node table, 2 = edge table in
-// *which) / collision (*which = 3) for the caller to retry with other parameters
-static int build_once(amg_ctx* c, int k, int* which) {
+static const unsigned int kProbeLimit = 4096;
+
+// returns AMG_OK, or AMG_E_OVERFLOW with *which = 1 (node table too small)
+int bs_nodes_pass(amg_ctx* c, int k, int* which) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, R = c->n_reads;
@@ -427,17 +443,16 @@ static int build_once(amg_ctx* c, int k, int* which) {
   HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot), st));
   stage_end(c);
 
-  const unsigned int probe_limit = 4096;
   stage_begin(c, "node_upsert");
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_node_upsert, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st,
                        c->tokens.as<int>(), c->read_off.as<long long>(), tile_lo, R, T, k,
                        c->two_v, c->seed, c->node_tab.as<Slot>(),
-                       (unsigned long long)(c->node_slots - 1), probe_limit, c->tok_slot.as<int>(),
-                       c->tok_dir.as<signed char>(), c->status.as<unsigned long long>());
+                       (unsigned long long)(c->node_slots - 1), kProbeLimit, (long long)c->tok_base,
+                       c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                       c->status.as<unsigned long long>());
   stage_end(c);
 
-  // ---- rank nodes by first occurrence
   stage_begin(c, "node_rank");
   // worst case every slot is occupied; size scratch by min(slots, windows upper bound)
   size_t max_nodes = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
@@ -450,48 +465,71 @@ static int build_once(amg_ctx* c, int k, int* which) {
                      c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
                      c->status.as<unsigned long long>() + ST_COMPACT_A);
   AMGCHK(read_status(c, hs));
+  stage_end(c);
   if (hs[ST_PALINDROME])
     return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
   if (hs[ST_OVERFLOW]) {
     *which = 1;
-    stage_end(c);
     return AMG_E_OVERFLOW;
   }
   c->n_windows = (int64_t)hs[ST_N_WINDOWS];
   c->n_short = (int64_t)hs[ST_N_SHORT];
-  c->n_nodes = (int64_t)hs[ST_COMPACT_A];
-  const long long D = c->n_nodes;
-  int first_bits = ilog2_ceil((uint64_t)(T > 0 ? T : 1) * 2 + 2) + 1;
-  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
-                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)D,
-                           first_bits));
-  AMGCHK(c->node_tokens.ensure((size_t)(D * k + 1) * sizeof(int)));
+  c->n_local_nodes = (int64_t)hs[ST_COMPACT_A];
+  return AMG_OK;
+}
+
+int bs_alloc_nodes(amg_ctx* c, long long D) {
+  AMGCHK(c->node_tokens.ensure((size_t)(D * c->k + 1) * sizeof(int)));
   AMGCHK(c->node_cov.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(c->node_first.ensure((size_t)(D + 1) * sizeof(long long)));
   AMGCHK(c->node_comp.ensure((size_t)(D + 1) * sizeof(int)));
   AMGCHK(c->node_alive.ensure((size_t)(D + 1)));
+  return AMG_OK;
+}
+
+int bs_nodes_rank_local(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  stage_begin(c, "node_rank");
+  c->n_nodes = c->n_local_nodes;
+  const long long D = c->n_nodes;
+  int first_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 2 + 2) + 1;
+  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)D,
+                           first_bits));
+  AMGCHK(bs_alloc_nodes(c, D));
   if (D > 0)
     hipLaunchKernelGGL(k_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st,
                        c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), D,
-                       c->node_tab.as<Slot>(), c->tokens.as<int>(), k, c->two_v,
-                       c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
-                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+                       c->node_tab.as<Slot>(), c->tokens.as<int>(), c->k, c->two_v,
+                       (long long)c->tok_base, c->node_tokens.as<int>(),
+                       c->node_cov.as<unsigned int>(), c->node_first.as<long long>(),
+                       c->node_alive.as<unsigned char>());
   stage_end(c);
+  return AMG_OK;
+}
 
-  // ---- edges
+// returns AMG_OK, or AMG_E_OVERFLOW with *which = 2 (edge table) / 3 (fingerprint collision)
+int bs_edges_pass(amg_ctx* c, int* which) {
+  *which = 0;
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, D = c->n_nodes;
+  const long long n_tiles = (T + TILE - 1) / TILE;
+  unsigned long long hs[ST_WORDS];
   if (c->edge_slots < (int64_t)pow2_at_least((uint64_t)D * 4)) c->edge_slots = pow2_at_least((uint64_t)D * 4);
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
   stage_begin(c, "edge_table_clear");
   HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot), st));
+  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_OVERFLOW, 0, sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COMPACT_B, 0, sizeof(unsigned long long), st));
   stage_end(c);
   stage_begin(c, "edge_upsert");
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_edges, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st,
-                       c->tokens.as<int>(), T, k, c->two_v, c->node_tab.as<Slot>(),
+                       c->tokens.as<int>(), T, c->k, c->two_v, c->node_tab.as<Slot>(),
                        c->node_tokens.as<int>(), c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot>(), (unsigned long long)(c->edge_slots - 1),
-                       probe_limit, 1, c->status.as<unsigned long long>());
+                       kProbeLimit, 1, (long long)c->tok_base, c->status.as<unsigned long long>());
   stage_end(c);
 
   stage_begin(c, "edge_rank");
@@ -505,31 +543,57 @@ static int build_once(amg_ctx* c, int k, int* which) {
                      c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
                      c->status.as<unsigned long long>() + ST_COMPACT_B);
   AMGCHK(read_status(c, hs));
+  stage_end(c);
   if (hs[ST_COLLISION]) {
     *which = 3;
-    stage_end(c);
     return AMG_E_OVERFLOW;
   }
   if (hs[ST_OVERFLOW]) {
     *which = 2;
-    stage_end(c);
     return AMG_E_OVERFLOW;
   }
-  c->n_pairs = (int64_t)hs[ST_COMPACT_B];
-  const long long P = c->n_pairs;
-  int efirst_bits = ilog2_ceil((uint64_t)(T > 0 ? T : 1) * 8 + 8) + 1;
-  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+  c->n_local_pairs = (int64_t)hs[ST_COMPACT_B];
+  return AMG_OK;
+}
+
+int bs_alloc_pairs(amg_ctx* c, long long P) {
+  AMGCHK(c->pair_key.ensure((size_t)(P + 2) * sizeof(unsigned long long)));
+  AMGCHK(c->pair_first.ensure((size_t)(P + 2) * sizeof(unsigned long long)));
+  AMGCHK(c->pair_cnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
+  return AMG_OK;
+}
+
+int bs_pairs_from_local(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  stage_begin(c, "edge_rank");
+  const long long P = c->n_local_pairs;
+  c->n_pairs = P;
+  AMGCHK(bs_alloc_pairs(c, P));
+  int efirst_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 8 + 8) + 1;
+  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
                            c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)P,
                            efirst_bits));
-  // widths -> bases (s3 reused for widths, s1 for bases: both free after the sort)
+  if (P > 0)
+    hipLaunchKernelGGL(k_gather_pairs, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                       c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(),
+                       c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+  stage_end(c);
+  return AMG_OK;
+}
+
+// pair_key / pair_cnt / pair_first hold the c->n_pairs edge classes in first-seen order
+int bs_finish_from_pairs(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  const long long P = c->n_pairs, D = c->n_nodes, R = c->n_reads;
+  stage_begin(c, "edge_emit");
+  AMGCHK(c->s3.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(P + 2) * sizeof(long long)));
   unsigned int* width = c->s3.as<unsigned int>();
   long long* base = c->s5.as<long long>();
   if (P > 0) {
-    // one extra zero-width element so that base[P] = total
     HIPCHK(hipMemsetAsync(width + P, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_pair_width, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                       c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(), width);
+                       c->pair_key.as<unsigned long long>(), P, width);
     AMGCHK(prim_exscan_u32_to_i64(c, width, base, (size_t)P + 1));
     long long total = 0;
     HIPCHK(hipMemcpyAsync(&total, base + P, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -547,13 +611,14 @@ static int build_once(amg_ctx* c, int k, int* which) {
   AMGCHK(c->edge_alive.ensure((size_t)(E + 2)));
   if (P > 0)
     hipLaunchKernelGGL(k_emit_edges, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                       c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), P,
-                       c->edge_tab.as<Slot>(), base, c->edge_src.as<int>(), c->edge_tgt.as<int>(),
-                       c->edge_sdir.as<signed char>(), c->edge_tdir.as<signed char>(),
-                       c->edge_cov.as<unsigned int>(), c->edge_alive.as<unsigned char>());
+                       c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(),
+                       c->pair_first.as<unsigned long long>(), P, base, c->edge_src.as<int>(),
+                       c->edge_tgt.as<int>(), c->edge_sdir.as<signed char>(),
+                       c->edge_tdir.as<signed char>(), c->edge_cov.as<unsigned int>(),
+                       c->edge_alive.as<unsigned char>());
   stage_end(c);
 
-  // ---- components (uses the sorted pair list in s4 before it is recycled)
+  // ---- components
   stage_begin(c, "components");
   int* parent = c->node_comp.as<int>();  // holds roots until k_uf_label rewrites it
   AMGCHK(c->s1.ensure((size_t)(D + 2) * sizeof(long long)));  // root ranks
@@ -564,7 +629,7 @@ static int build_once(amg_ctx* c, int k, int* which) {
     hipLaunchKernelGGL(k_uf_init, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D);
     if (P > 0)
       hipLaunchKernelGGL(k_uf_union, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                         c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(), parent);
+                         c->pair_key.as<unsigned long long>(), P, parent);
     hipLaunchKernelGGL(k_uf_roots, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D, is_root);
     HIPCHK(hipMemsetAsync(is_root + D, 0, sizeof(unsigned int), st));
     AMGCHK(prim_exscan_u32_to_i64(c, is_root, c->s1.as<long long>(), (size_t)D + 1));
@@ -611,6 +676,14 @@ static int build_once(amg_ctx* c, int k, int* which) {
   return AMG_OK;
 }
 
+// table sizing: previous distinct-node count when known, otherwise the window bound
+void bs_size_tables(amg_ctx* c) {
+  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 4 : (uint64_t)c->n_tokens * 2;
+  c->node_slots = (int64_t)pow2_at_least(want);
+  if (c->node_slots > (1ll << 30)) c->node_slots = 1ll << 30;
+  c->edge_slots = 1024;
+}
+
 extern "C" int amg_build(amg_ctx* c, int32_t k) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
@@ -621,14 +694,16 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   c->have_corrected = false;
   c->k = k;
   c->retries = 0;
-  // table sizing: previous distinct-node count when known, otherwise the window bound
-  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 4 : (uint64_t)c->n_tokens * 2;
-  c->node_slots = (int64_t)pow2_at_least(want);
-  if (c->node_slots > (1ll << 30)) c->node_slots = 1ll << 30;
-  c->edge_slots = 1024;
+  c->tok_base = 0;
+  c->tok_total = c->n_tokens;
+  bs_size_tables(c);
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;
-    int r = build_once(c, k, &which);
+    int r = bs_nodes_pass(c, k, &which);
+    if (r == AMG_OK) r = bs_nodes_rank_local(c);
+    if (r == AMG_OK) r = bs_edges_pass(c, &which);
+    if (r == AMG_OK) r = bs_pairs_from_local(c);
+    if (r == AMG_OK) r = bs_finish_from_pairs(c);
     if (r == AMG_OK) {
       c->built = true;
       c->node_hint = c->n_nodes > 256 ? c->n_nodes : 256;

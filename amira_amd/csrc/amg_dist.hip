@@ -1,16 +1,503 @@
-// amg_dist.hip — multi-GPU read-sharded build (RCCL all-to-all table merge).  Round-1:
-// entry points exist so the ABI is complete; the exchange itself is not implemented yet.
-#include "amg_internal.h"
+// amg_dist.hip — read-sharded build with a key-owner table merge.
+//
+// Every rank holds a contiguous shard of the reads.  The single-graph result
+// (graph_utils.py:105-124 at cores = 1, i.e. GeneMerGraph over all reads) is obtained in
+// phases; the exchanges between them are done by the CALLER with RCCL (torch.distributed
+// all_to_all_single / all_gather_into_tensor on the device buffers passed here), so the same
+// phases also run in a single process with a loop-back exchange (tests on one GPU):
+//
+//   amg_dist_nodes_local   local windows -> local node table; records bucketed by owner
+//   amg_dist_nodes_pack    records in destination order                     --> all-to-all
+//   amg_dist_nodes_reduce  owner side: equal keys reduced (sum count, min first-seen)
+//   amg_dist_nodes_owned   owned records                                    --> all-gather
+//   amg_dist_nodes_global  all records: global ids = rank of first-seen; local slots -> ids
+//   amg_dist_edges_local / _pack / _reduce / _owned / _global   same for the edge classes,
+//                          keyed by GLOBAL node ids; then edges, components, adjacency
+//
+// After amg_dist_edges_global every rank holds the global node / edge tables and its own
+// reads' node ids: filter / clip run identically everywhere, correct_reads on local reads.
+// first-seen values carry GLOBAL token indices (token_base + local index), so minima over
+// ranks reproduce the single-process insertion order exactly.
+#include "amg_device.h"
 
-extern "C" int amg_dist_unique_id(void* id128) {
-  (void)id128;
-  return amg_fail(AMG_E_DIST, "amg_dist_*: not implemented in this build");
+#define NEED_CTX(c)                                              \
+  do {                                                           \
+    if (!(c)) return amg_fail(AMG_E_ARG, "null ctx");            \
+    HIPCHK(hipSetDevice((c)->device));                           \
+  } while (0)
+
+static inline unsigned int nblk(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned int)(b < 1 ? 1 : b);
 }
-extern "C" int amg_dist_init(amg_ctx* c, const void* id128, int rank, int world) {
-  (void)c; (void)id128; (void)rank; (void)world;
-  return amg_fail(AMG_E_DIST, "amg_dist_*: not implemented in this build");
+
+// node record: {u64 key, u64 first, u32 count, u32 k, i32 tok[k]} padded to 8 bytes
+static inline size_t node_rec_bytes(int k) { return (size_t)((24 + 4 * k + 7) & ~7); }
+#define EDGE_REC_BYTES 24  // {u64 key, u64 first, u32 count, u32 pad}
+
+extern "C" int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes) {
+  if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "bad k");
+  if (node_bytes) *node_bytes = (int64_t)node_rec_bytes(k);
+  if (edge_bytes) *edge_bytes = EDGE_REC_BYTES;
+  return AMG_OK;
 }
-extern "C" int amg_dist_build(amg_ctx* c, int32_t k, int64_t read_index_base, int64_t token_index_base) {
-  (void)c; (void)k; (void)read_index_base; (void)token_index_base;
-  return amg_fail(AMG_E_DIST, "amg_dist_*: not implemented in this build");
+
+__device__ __forceinline__ unsigned int owner_of(unsigned long long key, unsigned int world) {
+  return (unsigned int)(mix64(key ^ 0x5851F42D4C957F2Dull) % world);
+}
+
+// ------------------------------------------------------------------ phase: local nodes
+// destination of every local node (compaction list: first / slot)
+__global__ void k_dist_node_dest(const unsigned int* __restrict__ slots, long long n,
+                                 const Slot* __restrict__ tab, unsigned int world,
+                                 unsigned int* __restrict__ dest, unsigned int* __restrict__ idx,
+                                 unsigned long long* __restrict__ counts) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int d = owner_of(tab[slots[i]].key, world);
+  dest[i] = d;
+  idx[i] = (unsigned int)i;
+  atomicAdd(&counts[d], 1ull);
+}
+
+__global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long long n,
+                                 const unsigned int* __restrict__ slots,
+                                 const unsigned long long* __restrict__ firsts,
+                                 const Slot* __restrict__ tab, const int* __restrict__ tokens, int k,
+                                 int two_v, long long tok_base, unsigned char* __restrict__ out,
+                                 int rec_bytes) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  unsigned int i = order[j];
+  const Slot* s = tab + slots[i];
+  unsigned long long first = firsts[i];
+  unsigned char* rec = out + (size_t)j * rec_bytes;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(rec);
+  q[0] = s->key;
+  q[1] = first;
+  unsigned int* u = reinterpret_cast<unsigned int*>(rec + 16);
+  u[0] = s->count;
+  u[1] = (unsigned int)k;
+  int* tk = reinterpret_cast<int*>(rec + 24);
+  long long t = (long long)(first >> 1) - tok_base;
+  int dir = (first & 1ull) ? -1 : 1;
+  const int flip = two_v - 1;
+  for (int x = 0; x < k; ++x) tk[x] = dir > 0 ? tokens[t + x] : flip - tokens[t + k - 1 - x];
+}
+
+extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, int64_t token_total,
+                                    int32_t world, int64_t* send_counts) {
+  NEED_CTX(c);
+  if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
+  if (world < 1 || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  hipStream_t st = c->stream;
+  stages_reset(c);
+  c->built = false;
+  c->have_corrected = false;
+  c->k = k;
+  c->retries = 0;
+  c->tok_base = token_base;
+  c->tok_total = token_total;
+  c->world = world;
+  bs_size_tables(c);
+  for (int attempt = 0;; ++attempt) {
+    int which = 0;
+    int r = bs_nodes_pass(c, k, &which);
+    if (r == AMG_OK) break;
+    if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
+    ++c->retries;
+    c->node_slots *= 4;
+  }
+  // compaction list lives in s1 (first) / s3 (slot); destination order -> dist_order
+  const long long n = c->n_local_nodes;
+  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
+  unsigned int* dest = c->dist_a.as<unsigned int>();
+  unsigned int* idx = dest + (n + 1);
+  unsigned int* dest_sorted = idx + (n + 1);
+  unsigned int* order = dest_sorted + (n + 1);
+  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
+  // keep the compaction list: the sort below uses the generic scratch
+  AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+  AMGCHK(c->dist_slot.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+  HIPCHK(hipMemcpyAsync(c->dist_first.p, c->s1.p, (size_t)n * sizeof(unsigned long long),
+                        hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->dist_slot.p, c->s3.p, (size_t)n * sizeof(unsigned int),
+                        hipMemcpyDeviceToDevice, st));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_dist_node_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
+                       c->dist_slot.as<unsigned int>(), n, c->node_tab.as<Slot>(), (unsigned int)world,
+                       dest, idx, c->dist_cnt.as<unsigned long long>());
+    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+  }
+  std::vector<unsigned long long> h(world);
+  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
+  return AMG_OK;
+}
+
+extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
+  NEED_CTX(c);
+  const long long n = c->n_local_nodes;
+  if (n == 0) return AMG_OK;
+  if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
+  unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
+  hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                     c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
+                     c->node_tab.as<Slot>(), c->tokens.as<int>(), c->k, c->two_v, (long long)c->tok_base,
+                     reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+// ------------------------------------------------------------------ phase: owner-side reduce
+// Received records are sorted by key; a run of equal keys (one record per contributing rank)
+// collapses to: sum of counts, min first-seen, tokens of the min-first record.  Records of a
+// run must carry the same canonical tuple, otherwise two tuples share a fingerprint.
+__global__ void k_rec_keys(const unsigned char* __restrict__ recs, long long n, int rec_bytes,
+                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = *reinterpret_cast<const unsigned long long*>(recs + (size_t)i * rec_bytes);
+  idx[i] = (unsigned int)i;
+}
+
+__global__ void k_run_heads(const unsigned long long* __restrict__ keys_sorted, long long n,
+                            unsigned int* __restrict__ head) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1u : 0u;
+}
+
+__global__ void k_reduce_runs(const unsigned char* __restrict__ recs, int rec_bytes, int tok_words,
+                              const unsigned long long* __restrict__ keys_sorted,
+                              const unsigned int* __restrict__ idx_sorted,
+                              const unsigned int* __restrict__ head, const long long* __restrict__ pos,
+                              long long n, unsigned char* __restrict__ out, unsigned long long* status) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const unsigned long long key = keys_sorted[i];
+  unsigned long long best_first = ~0ull, total = 0;
+  long long best = -1;
+  for (long long j = i; j < n && keys_sorted[j] == key; ++j) {
+    const unsigned char* r = recs + (size_t)idx_sorted[j] * rec_bytes;
+    unsigned long long f = *reinterpret_cast<const unsigned long long*>(r + 8);
+    total += *reinterpret_cast<const unsigned int*>(r + 16);
+    if (f < best_first) {
+      best_first = f;
+      best = j;
+    }
+  }
+  const unsigned char* b = recs + (size_t)idx_sorted[best] * rec_bytes;
+  // exact tuple check across the run (fingerprint collision between ranks)
+  for (long long j = i; j < n && keys_sorted[j] == key; ++j) {
+    const int* t1 = reinterpret_cast<const int*>(recs + (size_t)idx_sorted[j] * rec_bytes + 24);
+    const int* t0 = reinterpret_cast<const int*>(b + 24);
+    for (int x = 0; x < tok_words; ++x)
+      if (t1[x] != t0[x]) status[ST_COLLISION] = 1;
+  }
+  unsigned char* o = out + (size_t)pos[i] * rec_bytes;
+  for (int x = 0; x < rec_bytes; x += 8)
+    *reinterpret_cast<unsigned long long*>(o + x) = *reinterpret_cast<const unsigned long long*>(b + x);
+  *reinterpret_cast<unsigned long long*>(o + 8) = best_first;
+  *reinterpret_cast<unsigned int*>(o + 16) = (unsigned int)total;
+}
+
+static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_bytes, int tok_words,
+                          DevBuf& owned, int64_t* n_owned) {
+  hipStream_t st = c->stream;
+  *n_owned = 0;
+  if (n == 0) return AMG_OK;
+  AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+  AMGCHK(c->s2.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+  AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(n + 2) * (sizeof(unsigned int) + sizeof(long long))));
+  const unsigned char* recs = reinterpret_cast<const unsigned char*>(recv);
+  hipLaunchKernelGGL(k_rec_keys, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes,
+                     c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
+  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, 64));
+  long long* pos = c->s5.as<long long>();
+  unsigned int* head = reinterpret_cast<unsigned int*>(pos + (n + 2));
+  hipLaunchKernelGGL(k_run_heads, dim3(nblk(n, 256)), dim3(256), 0, st, c->s2.as<unsigned long long>(), n, head);
+  HIPCHK(hipMemsetAsync(head + n, 0, sizeof(unsigned int), st));
+  AMGCHK(prim_exscan_u32_to_i64(c, head, pos, (size_t)n + 1));
+  long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, pos + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(owned.ensure((size_t)(total + 1) * rec_bytes));
+  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COLLISION, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_reduce_runs, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rec_bytes, tok_words,
+                     c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), head, pos, n,
+                     owned.as<unsigned char>(), c->status.as<unsigned long long>());
+  unsigned long long coll = 0;
+  HIPCHK(hipMemcpyAsync(&coll, c->status.as<unsigned long long>() + ST_COLLISION, sizeof(coll),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (coll) return amg_fail(AMG_E_OVERFLOW, "fingerprint collision across ranks: rebuild with another seed");
+  *n_owned = total;
+  return AMG_OK;
+}
+
+extern "C" int amg_dist_nodes_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
+  NEED_CTX(c);
+  if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
+  int r = reduce_records(c, recv_buf, n_recv, (int)node_rec_bytes(c->k), c->k, c->dist_owned, n_owned);
+  c->n_owned = *n_owned;
+  return r;
+}
+
+extern "C" int amg_dist_nodes_owned(amg_ctx* c, void* out) {
+  NEED_CTX(c);
+  if (c->n_owned > 0) {
+    if (!out) return amg_fail(AMG_E_ARG, "null out");
+    HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * node_rec_bytes(c->k),
+                          hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return AMG_OK;
+}
+
+// ------------------------------------------------------------------ phase: global node ids
+__global__ void k_rec_firsts(const unsigned char* __restrict__ recs, long long n, int rec_bytes,
+                             unsigned long long* __restrict__ firsts, unsigned int* __restrict__ idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  firsts[i] = *reinterpret_cast<const unsigned long long*>(recs + (size_t)i * rec_bytes + 8);
+  idx[i] = (unsigned int)i;
+}
+
+// node arrays in global id order + key -> id table
+__global__ void k_global_nodes(const unsigned char* __restrict__ recs, int rec_bytes, int k,
+                               const unsigned int* __restrict__ idx_sorted, long long n,
+                               Slot* __restrict__ gtab, unsigned long long gmask,
+                               int* __restrict__ node_tokens, unsigned int* __restrict__ node_cov,
+                               long long* __restrict__ node_first, unsigned char* __restrict__ node_alive,
+                               unsigned long long* status) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* r = recs + (size_t)idx_sorted[i] * rec_bytes;
+  const unsigned long long key = *reinterpret_cast<const unsigned long long*>(r);
+  node_first[i] = (long long)*reinterpret_cast<const unsigned long long*>(r + 8);
+  node_cov[i] = *reinterpret_cast<const unsigned int*>(r + 16);
+  node_alive[i] = 1;
+  const int* tk = reinterpret_cast<const int*>(r + 24);
+  for (int x = 0; x < k; ++x) node_tokens[i * k + x] = tk[x];
+  // insert key -> id (keys are unique after the owner-side reduce)
+  unsigned long long s = (key >> 20) & gmask;
+  for (unsigned int probes = 0;; ++probes) {
+    unsigned long long cur = atomicCAS(&gtab[s].key, 0ull, key);
+    if (cur == 0ull) {
+      gtab[s].id = (int)i;
+      return;
+    }
+    if (cur == key || probes > 1u << 20) {
+      status[ST_OVERFLOW] = 4;  // duplicate key after reduce: cannot happen
+      return;
+    }
+    s = (s + 1) & gmask;
+  }
+}
+
+// local table slot -> global node id (looked up by key)
+__global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_slots,
+                                  const Slot* __restrict__ gtab, unsigned long long gmask,
+                                  unsigned long long* status) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const unsigned long long key = ltab[i].key;
+  if (key == 0ull) return;
+  unsigned long long s = (key >> 20) & gmask;
+  for (unsigned int probes = 0; probes < (1u << 20); ++probes) {
+    unsigned long long cur = gtab[s].key;
+    if (cur == key) {
+      ltab[i].id = gtab[s].id;
+      return;
+    }
+    if (cur == 0ull) break;
+    s = (s + 1) & gmask;
+  }
+  status[ST_OVERFLOW] = 5;  // local key missing from the global table
+}
+
+extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_t n_total) {
+  NEED_CTX(c);
+  hipStream_t st = c->stream;
+  const long long n = n_total;
+  const int rb = (int)node_rec_bytes(c->k);
+  c->n_nodes = n;
+  AMGCHK(bs_alloc_nodes(c, n));
+  uint64_t gslots = pow2_at_least((uint64_t)n * 2 + 16);
+  AMGCHK(c->dist_gtab.ensure((size_t)gslots * sizeof(Slot)));
+  HIPCHK(hipMemsetAsync(c->dist_gtab.p, 0, (size_t)gslots * sizeof(Slot), st));
+  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_OVERFLOW, 0, sizeof(unsigned long long), st));
+  if (n > 0) {
+    if (!all_records) return amg_fail(AMG_E_ARG, "null records");
+    AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+    AMGCHK(c->s2.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+    AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+    AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+    const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
+    hipLaunchKernelGGL(k_rec_firsts, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rb,
+                       c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
+    int first_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 2 + 2) + 1;
+    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, first_bits));
+    hipLaunchKernelGGL(k_global_nodes, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rb, c->k,
+                       c->s4.as<unsigned int>(), n, c->dist_gtab.as<Slot>(), (unsigned long long)(gslots - 1),
+                       c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>(),
+                       c->status.as<unsigned long long>());
+  }
+  hipLaunchKernelGGL(k_local_to_global, dim3(nblk(c->node_slots, 256)), dim3(256), 0, st,
+                     c->node_tab.as<Slot>(), (unsigned long long)c->node_slots, c->dist_gtab.as<Slot>(),
+                     (unsigned long long)(gslots - 1), c->status.as<unsigned long long>());
+  unsigned long long ov = 0;
+  HIPCHK(hipMemcpyAsync(&ov, c->status.as<unsigned long long>() + ST_OVERFLOW, sizeof(ov),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (ov) return amg_fail(AMG_E_DIST, "global node table inconsistent (code %llu)", ov);
+  return AMG_OK;
+}
+
+// ------------------------------------------------------------------ phase: edges
+__global__ void k_dist_edge_dest(const unsigned int* __restrict__ slots, long long n,
+                                 const Slot* __restrict__ tab, unsigned int world,
+                                 unsigned int* __restrict__ dest, unsigned int* __restrict__ idx,
+                                 unsigned long long* __restrict__ counts) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int d = owner_of(tab[slots[i]].key, world);
+  dest[i] = d;
+  idx[i] = (unsigned int)i;
+  atomicAdd(&counts[d], 1ull);
+}
+
+__global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long long n,
+                                 const unsigned int* __restrict__ slots,
+                                 const unsigned long long* __restrict__ firsts,
+                                 const Slot* __restrict__ tab, unsigned char* __restrict__ out) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  unsigned int i = order[j];
+  const Slot* s = tab + slots[i];
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
+  q[0] = s->key;
+  q[1] = firsts[i];
+  q[2] = (unsigned long long)s->count;
+}
+
+extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_counts) {
+  NEED_CTX(c);
+  if (world < 1 || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
+  hipStream_t st = c->stream;
+  for (int attempt = 0;; ++attempt) {
+    int which = 0;
+    int r = bs_edges_pass(c, &which);
+    if (r == AMG_OK) break;
+    if (r != AMG_E_OVERFLOW || which != 2 || attempt >= 8) {
+      if (which == 3) return amg_fail(AMG_E_OVERFLOW, "fingerprint collision: rebuild with another seed");
+      return r;
+    }
+    ++c->retries;
+    c->edge_slots *= 4;
+  }
+  const long long n = c->n_local_pairs;
+  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
+  unsigned int* dest = c->dist_a.as<unsigned int>();
+  unsigned int* idx = dest + (n + 1);
+  unsigned int* dest_sorted = idx + (n + 1);
+  unsigned int* order = dest_sorted + (n + 1);
+  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
+  AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+  AMGCHK(c->dist_slot.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+  HIPCHK(hipMemcpyAsync(c->dist_first.p, c->s1.p, (size_t)n * sizeof(unsigned long long),
+                        hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->dist_slot.p, c->s3.p, (size_t)n * sizeof(unsigned int),
+                        hipMemcpyDeviceToDevice, st));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_dist_edge_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
+                       c->dist_slot.as<unsigned int>(), n, c->edge_tab.as<Slot>(), (unsigned int)world,
+                       dest, idx, c->dist_cnt.as<unsigned long long>());
+    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+  }
+  std::vector<unsigned long long> h(world);
+  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
+  return AMG_OK;
+}
+
+extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
+  NEED_CTX(c);
+  const long long n = c->n_local_pairs;
+  if (n == 0) return AMG_OK;
+  if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
+  unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
+  hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                     c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
+                     c->edge_tab.as<Slot>(), reinterpret_cast<unsigned char*>(send_buf));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+extern "C" int amg_dist_edges_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
+  NEED_CTX(c);
+  if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
+  int r = reduce_records(c, recv_buf, n_recv, EDGE_REC_BYTES, 0, c->dist_owned, n_owned);
+  c->n_owned = *n_owned;
+  return r;
+}
+
+extern "C" int amg_dist_edges_owned(amg_ctx* c, void* out) {
+  NEED_CTX(c);
+  if (c->n_owned > 0) {
+    if (!out) return amg_fail(AMG_E_ARG, "null out");
+    HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * EDGE_REC_BYTES,
+                          hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return AMG_OK;
+}
+
+__global__ void k_global_pairs(const unsigned char* __restrict__ recs, const unsigned int* __restrict__ idx_sorted,
+                               long long n, unsigned long long* __restrict__ pkey,
+                               unsigned int* __restrict__ pcnt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long* q =
+      reinterpret_cast<const unsigned long long*>(recs + (size_t)idx_sorted[i] * EDGE_REC_BYTES);
+  pkey[i] = q[0];
+  pcnt[i] = (unsigned int)q[2];
+}
+
+extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_t n_total) {
+  NEED_CTX(c);
+  hipStream_t st = c->stream;
+  const long long n = n_total;
+  c->n_pairs = n;
+  AMGCHK(bs_alloc_pairs(c, n));
+  if (n > 0) {
+    if (!all_records) return amg_fail(AMG_E_ARG, "null records");
+    AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+    AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+    AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
+    const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
+    hipLaunchKernelGGL(k_rec_firsts, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, EDGE_REC_BYTES,
+                       c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
+    int efirst_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 8 + 8) + 1;
+    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
+                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, efirst_bits));
+    hipLaunchKernelGGL(k_global_pairs, dim3(nblk(n, 256)), dim3(256), 0, st, recs, c->s4.as<unsigned int>(), n,
+                       c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+  }
+  AMGCHK(bs_finish_from_pairs(c));
+  c->built = true;
+  c->node_hint = c->n_local_nodes > 256 ? c->n_local_nodes : 256;
+  return AMG_OK;
 }

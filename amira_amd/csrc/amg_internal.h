@@ -118,6 +118,9 @@ struct amg_ctx {
   int64_t n_nodes = 0, n_pairs = 0, n_edges = 0, n_components = 0;
   int64_t node_slots = 0, edge_slots = 0, retries = 0;
   int64_t node_hint = 0;  // distinct-node estimate carried between builds
+  int64_t n_local_nodes = 0, n_local_pairs = 0;  // before a multi-GPU merge
+  int64_t tok_base = 0;   // global index of this shard's first token (0 on a single GPU)
+  int64_t tok_total = 0;  // tokens over all shards
 
   DevBuf node_tab;   // Slot[node_slots]
   DevBuf edge_tab;   // Slot[edge_slots]
@@ -135,6 +138,9 @@ struct amg_ctx {
   DevBuf edge_sdir, edge_tdir;  // int8[n_edges]
   DevBuf edge_cov;              // uint32[n_edges]
   DevBuf edge_alive;            // uint8[n_edges]
+  // edge classes in first-seen order (input of the edge emission)
+  DevBuf pair_key, pair_first;  // uint64[n_pairs]
+  DevBuf pair_cnt;              // uint32[n_pairs]
   // adjacency CSR, row 2n = forward list of node n, 2n+1 = backward list
   DevBuf adj_off;   // int64[2 n_nodes + 1]
   DevBuf adj_edge;  // int32[n_edges]
@@ -150,6 +156,11 @@ struct amg_ctx {
   bool have_corrected = false;
   int64_t c_reads = 0, c_tokens = 0;
   DevBuf c_tokens_buf, c_read_off, c_orig, c_changed, c_gstart, c_gend, c_read_len;
+
+  // ---- multi-GPU merge (amg_dist.hip)
+  int world = 1;
+  int64_t n_owned = 0;
+  DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab;
 
   // ---- scratch
   DevBuf status;       // unsigned long long[ST_WORDS]
@@ -173,8 +184,16 @@ void stage_begin(amg_ctx* c, const char* name);
 void stage_end(amg_ctx* c);
 void stages_reset(amg_ctx* c);
 
-// passes (amg_passes.hip)
-int amg_reset_passes(amg_ctx* c);
+// build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
+uint64_t pow2_at_least(uint64_t x);
+void bs_size_tables(amg_ctx* c);
+int bs_nodes_pass(amg_ctx* c, int k, int* which);
+int bs_alloc_nodes(amg_ctx* c, long long D);
+int bs_nodes_rank_local(amg_ctx* c);
+int bs_edges_pass(amg_ctx* c, int* which);
+int bs_alloc_pairs(amg_ctx* c, long long P);
+int bs_pairs_from_local(amg_ctx* c);
+int bs_finish_from_pairs(amg_ctx* c);
 
 static inline int ilog2_ceil(uint64_t x) {
   int b = 0;

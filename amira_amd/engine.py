@@ -159,3 +159,38 @@ class Engine:
 
     def adopt_corrected(self):
         check(_ffi.lib.amg_adopt_corrected(self._h))
+
+    # ---- multi-GPU merge phases (device pointers in / out; see amira_amd/dist.py)
+    @staticmethod
+    def dist_record_bytes(k):
+        nb, eb = C.c_int64(0), C.c_int64(0)
+        check(_ffi.lib.amg_dist_record_bytes(int(k), C.byref(nb), C.byref(eb)))
+        return nb.value, eb.value
+
+    def dist_nodes_local(self, k, token_base, token_total, world):
+        counts = np.zeros(world, np.int64)
+        check(_ffi.lib.amg_dist_nodes_local(self._h, int(k), int(token_base), int(token_total),
+                                            int(world), ptr(counts)))
+        return counts.tolist()
+
+    def dist_edges_local(self, world):
+        counts = np.zeros(world, np.int64)
+        check(_ffi.lib.amg_dist_edges_local(self._h, int(world), ptr(counts)))
+        return counts.tolist()
+
+    def _dist_call(self, name, *args):
+        check(getattr(_ffi.lib, name)(self._h, *args))
+
+    def dist_pack(self, what, dev_ptr):
+        self._dist_call(f"amg_dist_{what}_pack", C.c_void_p(dev_ptr))
+
+    def dist_reduce(self, what, dev_ptr, n_recv):
+        n = C.c_int64(0)
+        self._dist_call(f"amg_dist_{what}_reduce", C.c_void_p(dev_ptr), int(n_recv), C.byref(n))
+        return n.value
+
+    def dist_owned(self, what, dev_ptr):
+        self._dist_call(f"amg_dist_{what}_owned", C.c_void_p(dev_ptr))
+
+    def dist_global(self, what, dev_ptr, n_total):
+        self._dist_call(f"amg_dist_{what}_global", C.c_void_p(dev_ptr), int(n_total))

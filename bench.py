@@ -12,8 +12,11 @@ token arrays (and gene positions) are already resident in HBM:
   cfg3       the first build of that sweep only
   cfg2       100 k reads x 40 genes, k=5, 5 k-gene vocabulary: build + coverage (configs[1])
 Prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
-Multi-GPU (torch.distributed.run): every rank processes its own N-read shard of the global
-stream (weak scaling, no data-path collective in this round).
+Multi-GPU (torch.distributed.run, one rank per GPU, RCCL): every rank holds its own N-read
+shard of the global stream (weak scaling); EVERY build of the step merges the per-shard node /
+edge tables by key owner (all-to-all + all-gather, amira_amd/dist.py), so all ranks hold the
+single-graph result; filtering and clipping run on that graph, correction on the local reads.
+`--no-merge` builds the shards independently instead.
 """
 import argparse
 import json
@@ -117,6 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -130,6 +134,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from amira_amd import Engine
+    from amira_amd.dist import dist_build
+    merge = world > 1 and not args.no_merge
+
+    def build():
+        if merge:
+            dist_build(eng, k)
+        else:
+            eng.build(k)
 
     # weak scaling: rank r holds reads [r N, (r+1) N) of the global stream
     N, L, k = w["N"], w["L"], w["k"]
@@ -158,7 +170,7 @@ def main():
         eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v)
         if w["sweep"]:
             eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr())
-        eng.build(k)
+        build()
         if record:
             tally()
         if not w["sweep"]:
@@ -171,7 +183,7 @@ def main():
         if record:
             tally()
         eng.adopt_corrected()
-        eng.build(k)
+        build()
         if record:
             tally()
         eng.remove_short_linear_paths(k)
@@ -181,7 +193,7 @@ def main():
         if record:
             tally()
         eng.adopt_corrected()
-        eng.build(k)
+        build()
         if record:
             tally()
 
@@ -226,7 +238,9 @@ def main():
             "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": L, "k": k,
                        "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
                        "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
-                       "multi_gpu": "independent read shards, no table merge (round 1)" if world > 1 else "n/a"},
+                       "multi_gpu": ("n/a" if world == 1 else
+                                     "read shards + key-owner table merge per build (RCCL all-to-all + all-gather)"
+                                     if merge else "independent read shards, no table merge")},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": cands[dom],

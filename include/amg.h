@@ -53,7 +53,7 @@ enum {
                          /* (construct_gene_mer.py:23-25) -> AssertionError in Python  */
   AMG_E_OVERFLOW = -5,   /* internal table overflow that retries could not resolve     */
   AMG_E_NOMEM = -6,
-  AMG_E_DIST = -7        /* RCCL / multi-GPU exchange failure                          */
+  AMG_E_DIST = -7        /* multi-GPU merge inconsistency                              */
 };
 
 #define AMG_MAX_K 16
@@ -170,15 +170,32 @@ int amg_match_patterns(amg_ctx* ctx, int which, const int32_t* pat, const int64_
                        int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read,
                        int32_t* hit_pos);
 
-/* ---- multi-GPU (read-sharded build with an RCCL all-to-all table merge;
- *      the single-graph result of graph_utils.py:105-124 at cores = 1) --------------- */
-int amg_dist_unique_id(void* id128);                        /* ncclGetUniqueId, 128 bytes */
-int amg_dist_init(amg_ctx* ctx, const void* id128, int rank, int world);
-/* like amg_build, but ctx holds only this rank's contiguous read shard;
- * read_index_base / token_index_base = global index of the shard's first read / token.
- * After it returns every rank holds the GLOBAL node/edge tables and its own reads'
- * node ids. */
-int amg_dist_build(amg_ctx* ctx, int32_t k, int64_t read_index_base, int64_t token_index_base);
+/* ---- multi-GPU: read-sharded build with a key-owner table merge — the single-graph result of
+ *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
+ *      Every rank holds a contiguous shard of the reads.  The library runs the device phases;
+ *      the CALLER moves the record buffers between ranks with RCCL (torch.distributed
+ *      all_to_all_single / all_gather on the device pointers below), see amira_amd/dist.py.
+ *      All buffers here are DEVICE pointers.  Record sizes: amg_dist_record_bytes. ------- */
+int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes);
+/* local node table of this shard; token_base = global index of the shard's first token,
+ * token_total = tokens over all shards; send_counts[world] = records per destination rank */
+int amg_dist_nodes_local(amg_ctx* ctx, int32_t k, int64_t token_base, int64_t token_total,
+                         int32_t world, int64_t* send_counts);
+int amg_dist_nodes_pack(amg_ctx* ctx, void* send_buf);              /* destination order   */
+/* after the all-to-all: reduce the received records (sum count, min first-seen) */
+int amg_dist_nodes_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int64_t* n_owned);
+int amg_dist_nodes_owned(amg_ctx* ctx, void* out_buf);              /* n_owned records     */
+/* after the all-gather of every rank's owned records: global node ids (rank of first-seen),
+ * global node arrays on this rank, local windows mapped to global ids */
+int amg_dist_nodes_global(amg_ctx* ctx, const void* all_records, int64_t n_total);
+/* same five phases for the edge classes (keyed by global node ids); the last call also emits
+ * the directed edges, components and adjacency lists, after which the ctx behaves as after
+ * amg_build (global graph, local reads) */
+int amg_dist_edges_local(amg_ctx* ctx, int32_t world, int64_t* send_counts);
+int amg_dist_edges_pack(amg_ctx* ctx, void* send_buf);
+int amg_dist_edges_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int64_t* n_owned);
+int amg_dist_edges_owned(amg_ctx* ctx, void* out_buf);
+int amg_dist_edges_global(amg_ctx* ctx, const void* all_records, int64_t n_total);
 
 /* ---- per-stage device time of the last call, for bench.py ------------------------- */
 /* names[i] points at static strings; returns the number of stages (<= cap). */

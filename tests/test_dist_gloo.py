@@ -1,0 +1,75 @@
+"""world_size-2 gloo test (CPU) of the N > 1 exchange plumbing used by amira_amd.dist: the
+variable-size record all-to-all and all-gather must deliver exactly what the single-process
+loop-back driver delivers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REC = 48
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _payload(rank, world):
+    rng = np.random.default_rng(100 + rank)
+    counts = [int(x) for x in rng.integers(0, 7, world)]
+    if rank == 1:
+        counts[0] = 0  # an empty bucket
+    data = rng.integers(0, 256, sum(counts) * REC, dtype=np.uint8)
+    return counts, data
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from amira_amd.dist import exchange_a2a, exchange_ag
+    counts, data = _payload(rank, world)
+    recv, n = exchange_a2a(torch.from_numpy(data.copy()), counts, REC)
+    owned = torch.from_numpy(data[: (rank + 2) * REC].copy()) if len(data) >= (rank + 2) * REC else torch.zeros(0, dtype=torch.uint8)
+    n_owned = len(owned) // REC
+    everything, total = exchange_ag(owned if n_owned else torch.zeros(REC, dtype=torch.uint8), n_owned, REC)
+    q.put((rank, recv[: n * REC].numpy().copy(), n, everything[: total * REC].numpy().copy(), total, n_owned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, recv, n, everything, total, n_owned = q.get(timeout=120)
+        got[r] = (recv, n, everything, total, n_owned)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    payload = [_payload(r, world) for r in range(world)]
+    for dst in range(world):
+        parts = []
+        for src in range(world):
+            counts, data = payload[src]
+            off = sum(counts[:dst]) * REC
+            parts.append(data[off: off + counts[dst] * REC])
+        want = np.concatenate(parts)
+        assert got[dst][1] == len(want) // REC
+        assert np.array_equal(got[dst][0], want)
+    owned = [payload[r][1][: got[r][4] * REC] for r in range(world)]
+    for r in range(world):
+        assert got[r][3] == sum(got[x][4] for x in range(world))
+        assert np.array_equal(got[r][2], np.concatenate(owned))

@@ -1,0 +1,136 @@
+"""Read-sharded build + table merge: W emulated ranks on ONE GPU (loop-back exchange) must
+reproduce the unsharded graph exactly — node / edge tables on every rank, and each rank's
+window -> node ids equal to its slice of the unsharded result."""
+import numpy as np
+import pytest
+
+import procedures as P
+from helpers import csr_lists
+from test_gpu_sweep import flat_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def shard_bounds(n_reads, world):
+    return [(r * n_reads) // world for r in range(world + 1)]
+
+
+def make_shards(toks, offs, world):
+    b = shard_bounds(len(offs) - 1, world)
+    out = []
+    for r in range(world):
+        lo, hi = b[r], b[r + 1]
+        o = offs[lo:hi + 1] - offs[lo]
+        out.append((toks[offs[lo]:offs[hi]], o, lo, hi))
+    return out
+
+
+def graph_state(eng):
+    n, e = eng.nodes(), eng.edges()
+    off, adj = eng.node_adj()
+    return {"tokens": n["tokens"], "coverage": n["coverage"], "first_dir": n["first_dir"],
+            "component": n["component"], "alive": n["alive"], "src": e["src"], "tgt": e["tgt"],
+            "sdir": e["sdir"], "tdir": e["tdir"], "ecov": e["coverage"], "ealive": e["alive"],
+            "adj_off": off, "adj": adj}
+
+
+def assert_same_graph(a, b):
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [("synth", 7, 400, 30, 300, 5, 0.03), ("synth", 13, 300, 40, 250, 7, 0.02),
+                                  ("fixture", "nine", 3), ("fixture", "five", 5)])
+def test_sharded_build_equals_unsharded(world, case):
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    if case[0] == "synth":
+        _, seed, N, L, V, k, err = case
+        reads, _, _ = P.synth_inputs(seed, N, L, V, err)
+    else:
+        reads, _ = P.fixture(case[1])
+        k = case[2]
+    vocab, toks, offs, read_ids = tokenize(reads)
+    ref = Engine(0)
+    ref.set_reads(toks, offs, vocab.two_v)
+    ref.build(k)
+    want = graph_state(ref)
+    want_node, want_dir = ref.read_nodes()
+    engines = []
+    for t, o, lo, hi in make_shards(toks, offs, world):
+        e = Engine(0)
+        e.set_reads(t, o, vocab.two_v)
+        engines.append(e)
+    dist_build_loopback(engines, k)
+    for r, (e, (t, o, lo, hi)) in enumerate(zip(engines, make_shards(toks, offs, world))):
+        assert_same_graph(graph_state(e), want)
+        node, d = e.read_nodes()
+        assert np.array_equal(node, want_node[offs[lo]:offs[hi]])
+        assert np.array_equal(d, want_dir[offs[lo]:offs[hi]])
+        c = e.counts()
+        assert c["n_nodes"] == ref.counts()["n_nodes"] and c["n_edges"] == ref.counts()["n_edges"]
+        assert c["n_components"] == ref.counts()["n_components"]
+    for e in engines + [ref]:
+        e.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sweep_equals_unsharded(world):
+    """build -> filter -> correct -> build -> clip -> correct -> build with every build merged
+    across the emulated ranks; the concatenation of the ranks' corrected reads must equal the
+    single-GPU sweep."""
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    k = 5
+    vocab, toks, offs, read_ids = tokenize(reads)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+
+    def sweep_single():
+        e = Engine(0)
+        e.set_reads(toks, offs, vocab.two_v)
+        e.set_positions(gs, ge, rl)
+        outs = []
+        e.build(k); e.filter(3, 1)
+        n = e.correct_reads(); outs.append(e.corrected(*n, True)); e.adopt_corrected()
+        e.build(k); e.remove_short_linear_paths(k)
+        n = e.correct_reads(); outs.append(e.corrected(*n, True)); e.adopt_corrected()
+        e.build(k)
+        g = graph_state(e)
+        e.close()
+        return outs, g
+
+    want_outs, want_graph = sweep_single()
+    engines, bounds = [], shard_bounds(len(read_ids), world)
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        e = Engine(0)
+        e.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
+        e.set_positions(gs[offs[lo]:offs[hi]], ge[offs[lo]:offs[hi]], rl[lo:hi])
+        engines.append(e)
+    got_outs = []
+    dist_build_loopback(engines, k)
+    for e in engines:
+        e.filter(3, 1)
+    got_outs.append([e.corrected(*e.correct_reads(), True) for e in engines])
+    for e in engines:
+        e.adopt_corrected()
+    dist_build_loopback(engines, k)
+    removed = [sorted(e.remove_short_linear_paths(k).tolist()) for e in engines]
+    assert all(x == removed[0] for x in removed)
+    got_outs.append([e.corrected(*e.correct_reads(), True) for e in engines])
+    for e in engines:
+        e.adopt_corrected()
+    dist_build_loopback(engines, k)
+    for e in engines:
+        assert_same_graph(graph_state(e), want_graph)
+    for stage in range(2):
+        for key in ("tokens", "gene_start", "gene_end", "changed"):
+            cat = np.concatenate([o[key] for o in got_outs[stage]])
+            assert np.array_equal(cat, want_outs[stage][key]), (stage, key)
+        lens = np.concatenate([np.diff(o["read_offsets"]) for o in got_outs[stage]])
+        assert np.array_equal(lens, np.diff(want_outs[stage]["read_offsets"]))
+    for e in engines:
+        e.close()
