@@ -134,3 +134,27 @@ def test_sharded_sweep_equals_unsharded(world):
         assert np.array_equal(lens, np.diff(want_outs[stage]["read_offsets"]))
     for e in engines:
         e.close()
+
+
+def test_dist_build_over_rccl_world1():
+    """the torch.distributed driver itself (RCCL collectives on device tensors), world = 1"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+        vocab, toks, offs, _ = tokenize(reads)
+        ref = Engine(0); ref.set_reads(toks, offs, vocab.two_v); ref.build(5)
+        eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v); dist_build(eng, 5)
+        assert_same_graph(graph_state(eng), graph_state(ref))
+        assert np.array_equal(eng.read_nodes()[0], ref.read_nodes()[0])
+        eng.close(); ref.close()
+    finally:
+        dist.destroy_process_group()
