@@ -43,7 +43,6 @@ from .path_finding_utils import (
     get_suffixes_from_initial_tree,
     is_sublist as _is_sublist,
     process_anchors,
-    process_combinations_for_i,
 )
 from .tokens import tokenize
 
@@ -783,15 +782,56 @@ class GeneMerGraph:
     def get_reads_supporting_path(self, path, suffix_tree):
         return {rid.replace("_reverse", "") for rid, _ in suffix_tree.find_all(list(path))}
 
+    def _match_gene_lists(self, gene_lists):
+        """Exact occurrences of every gene-string list in every read, on the device (kernel
+        k_match, the batched form of is_sublist / find_sublist_indices / Tree.find_all).
+        Returns one dict {read index: [start positions]} per list, reads ascending."""
+        table = self._vocab._tok
+        pats, usable = [], []
+        for genes in gene_lists:
+            toks = [table.get(g) for g in genes]
+            ok = len(toks) > 0 and None not in toks  # an unknown gene cannot occur in any read
+            pats.append(toks if ok else None)
+            if ok:
+                usable.append(toks)
+        found = []
+        for lo in range(0, len(usable), 60000):
+            off, hit_read, hit_pos = self._engine.match_patterns(0, usable[lo:lo + 60000])
+            for j in range(len(off) - 1):
+                d = {}
+                for r, p in zip(hit_read[off[j]:off[j + 1]].tolist(), hit_pos[off[j]:off[j + 1]].tolist()):
+                    d.setdefault(r, []).append(p)
+                found.append(d)
+        it = iter(found)
+        return [next(it) if p is not None else {} for p in pats]
+
     def get_all_sublists(self, lst, gene_call_subset, threshold, geneOfInterest, cores):
-        """windows of a block's gene path with enough read support (:2711-2723); the
-        reference maps the window length over a process pool, results are merged in order."""
-        sublists = {}
+        """windows of a block's gene path that hold every copy of the gene and are carried by
+        >= threshold reads (:2711-2723, path_finding_utils.py:296-310).  The reference builds a
+        suffix tree per window length in a process pool; here all windows (and their reverse
+        complements) are matched against all reads in one device call.  A read supports a
+        window if the window occurs in it in either orientation; reads without nodes (< k
+        genes) are not in gene_call_subset and do not count."""
+        plus, minus = f"+{geneOfInterest}", f"-{geneOfInterest}"
+        wanted = lst.count(plus) + lst.count(minus)
+        combs = []
         for i in range(1, len(lst) + 1):
-            found = process_combinations_for_i((i, threshold, geneOfInterest, lst, gene_call_subset))
-            for sub in found:
-                if sub:
-                    sublists[sub] = found[sub]
+            for start in range(len(lst) - i + 1):
+                comb = tuple(lst[start:start + i])
+                if comb.count(plus) + comb.count(minus) == wanted:
+                    combs.append(comb)
+        uniq = list(dict.fromkeys(combs))
+        hits = self._match_gene_lists([list(c) for c in uniq] +
+                                      [self.reverse_list_of_genes(list(c)) for c in uniq])
+        read_ids = self._read_ids
+        support = {}
+        for j, comb in enumerate(uniq):
+            reads = set(hits[j]) | set(hits[j + len(uniq)])
+            support[comb] = sum(1 for r in reads if read_ids[r] in gene_call_subset)
+        sublists = {}
+        for comb in combs:
+            if comb and support[comb] >= threshold:
+                sublists[comb] = support[comb]
         return sublists
 
     def get_full_paths(self, node_tree, reads, nodeAnchors, threshold, gene_call_subset,
@@ -846,14 +886,20 @@ class GeneMerGraph:
 
     def split_into_subpaths(self, geneOfInterest, pathsOfinterest, path_coverages, path_reads,
                             mean_node_coverage=None):
-        """allele clusters: reads holding a path exactly once, forward first (:2360-2455)."""
+        """allele clusters: reads holding a path exactly once, forward orientation first, the
+        reverse complement only when there is no forward occurrence (:2360-2455).  The
+        reference scans every read for every path on the host; here all paths and their
+        reverse complements are matched against all reads in one device call."""
         allele_count = 1
         gene_clusters, read_tracking = {}, {}
         if mean_node_coverage is None:
             mean_node_coverage = self.get_mean_node_coverage()
-        for path in pathsOfinterest:
-            fwd = list(path)
-            rev = self.reverse_list_of_genes(fwd)
+        paths = list(pathsOfinterest)
+        fwd_lists = [list(p) for p in paths]
+        rev_lists = [self.reverse_list_of_genes(f) for f in fwd_lists]
+        hits = self._match_gene_lists(fwd_lists + rev_lists)
+        for pi, path in enumerate(paths):
+            fwd = fwd_lists[pi]
             named = list(path)
             fw_idx, rv_idx = {}, {}
             for g, gene in enumerate(fwd):
@@ -864,19 +910,20 @@ class GeneMerGraph:
                     named[g] = f"{gene[0]}{allele}"
                     allele_count += 1
             named = tuple(named)
-            for read_id, genes_on_read in self._reads.items():
-                hits, idx = _find_sublist_indices(genes_on_read, fwd), fw_idx
-                if not hits:
-                    hits, idx = _find_sublist_indices(genes_on_read, rev), rv_idx
-                    if not hits:
-                        continue
-                if len(hits) != 1:
+            fw_hits, rv_hits = hits[pi], hits[pi + len(paths)]
+            for r in sorted(set(fw_hits) | set(rv_hits)):  # read order == dict order of _reads
+                if r in fw_hits:
+                    starts, idx = fw_hits[r], fw_idx
+                else:
+                    starts, idx = rv_hits[r], rv_idx
+                if len(starts) != 1:
                     continue
+                read_id = self._read_ids[r]
+                genes_on_read = self._reads[read_id]
                 path_reads.setdefault(named, set()).add(read_id)
-                path_start = hits[0][0]
                 for gene_index in idx:
-                    assert genes_on_read[path_start + gene_index][1:] == geneOfInterest
-                    s, e = self._genePositions[read_id][path_start + gene_index]
+                    assert genes_on_read[starts[0] + gene_index][1:] == geneOfInterest
+                    s, e = self._genePositions[read_id][starts[0] + gene_index]
                     entry = f"{read_id}_{s}_{e}"
                     gene_clusters[idx[gene_index]].append(entry)
                     read_tracking[idx[gene_index]].add(entry)

@@ -162,6 +162,11 @@ struct amg_ctx {
   int64_t n_owned = 0;
   DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab;
 
+  // ---- K6 result cache (two-call protocol of amg_match_patterns)
+  bool match_valid = false;
+  int64_t match_total = 0, match_npat = 0;
+  DevBuf match_read, match_pos, match_off;
+
   // ---- scratch
   DevBuf status;       // unsigned long long[ST_WORDS]
   DevBuf sort_tmp;     // rocPRIM temp storage

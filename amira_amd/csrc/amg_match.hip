@@ -1,0 +1,188 @@
+// amg_match.hip — K6: batched exact sub-list search of P patterns in every read
+// (is_sublist / find_sublist_indices, construct_graph.py:1957-1966, 2117-2123; the
+// Tree.find_all call sites of path_finding_utils.py:244, 290, 300-308).
+//
+// Patterns are bucketed by their first symbol (direct index over the symbol domain: tokens for
+// which = 0, node ids for which = 1).  One wave per read: each lane takes a position, looks up
+// the bucket of the symbol there and verifies the candidates against the read (the read slice
+// is L1/L2 resident).  Hits are packed as (pattern, read, position) keys, radix-sorted, and
+// split per pattern — i.e. ordered by pattern, then read, then position.
+#include "amg_device.h"
+
+static inline unsigned int nblk(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned int)(b < 1 ? 1 : b);
+}
+
+#define POS_BITS 20
+#define READ_BITS 28
+#define PAT_BITS 16
+
+struct MatchArgs {
+  const int* seq;             // tokens or tok_node
+  const long long* read_off;
+  long long n_reads;
+  int tail;                   // positions at the end of a read that are not symbols (k-1 for nodes)
+  const int* pat;             // pattern symbols (device)
+  const long long* pat_off;
+  const long long* bucket_off;  // [domain + 1] -> range in bucket_pat
+  const int* bucket_pat;
+  long long domain;
+  unsigned long long* hits;   // nullptr: count only
+  unsigned long long* counter;
+  unsigned long long cap;
+};
+
+__global__ __launch_bounds__(256) void k_match(MatchArgs A) {
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= A.n_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long t0 = A.read_off[r];
+  const long long len = A.read_off[r + 1] - t0 - A.tail;
+  for (long long i = lane; i < len; i += 64) {
+    const int sym = A.seq[t0 + i];
+    if (sym < 0 || sym >= A.domain) continue;
+    for (long long b = A.bucket_off[sym]; b < A.bucket_off[sym + 1]; ++b) {
+      const int p = A.bucket_pat[b];
+      const long long po = A.pat_off[p], m = A.pat_off[p + 1] - po;
+      if (i + m > len) continue;
+      bool same = true;
+      for (long long j = 1; j < m && same; ++j) same = (A.seq[t0 + i + j] == A.pat[po + j]);
+      if (!same) continue;
+      unsigned long long at = atomicAdd(A.counter, 1ull);
+      if (A.hits && at < A.cap)
+        A.hits[at] = ((unsigned long long)p << (READ_BITS + POS_BITS)) |
+                     ((unsigned long long)r << POS_BITS) | (unsigned long long)i;
+    }
+  }
+}
+
+__global__ void k_pat_first(const int* __restrict__ pat, const long long* __restrict__ pat_off,
+                            long long n_pat, long long domain, unsigned int* __restrict__ first,
+                            unsigned int* __restrict__ idx, unsigned int* __restrict__ hist) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pat) return;
+  long long m = pat_off[p + 1] - pat_off[p];
+  long long f = m > 0 ? (long long)pat[pat_off[p]] : -1;
+  bool ok = f >= 0 && f < domain;
+  unsigned int key = ok ? (unsigned int)f : (unsigned int)domain;  // unusable patterns go last
+  first[p] = key;
+  idx[p] = (unsigned int)p;
+  if (ok) atomicAdd(&hist[key], 1u);
+}
+
+__global__ void k_hit_split(const unsigned long long* __restrict__ keys, long long n,
+                            int* __restrict__ hit_read, int* __restrict__ hit_pos,
+                            unsigned int* __restrict__ per_pat) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long k = keys[i];
+  hit_pos[i] = (int)(k & ((1ull << POS_BITS) - 1));
+  hit_read[i] = (int)((k >> POS_BITS) & ((1ull << READ_BITS) - 1));
+  atomicAdd(&per_pat[k >> (READ_BITS + POS_BITS)], 1u);
+}
+
+extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, const int64_t* pat_offsets,
+                                  int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read, int32_t* hit_pos) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  if (which == 1 && !c->built) return amg_fail(AMG_E_STATE, "amg_build first");
+  if (n_pat < 0 || !pat_offsets || !hit_offsets) return amg_fail(AMG_E_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  // second call of the two-call protocol: hand out the cached result
+  if (hit_read || hit_pos) {
+    if (!c->match_valid || c->match_npat != n_pat)
+      return amg_fail(AMG_E_STATE, "call amg_match_patterns with NULL hit arrays first");
+    if (c->match_total > 0) {
+      if (hit_read)
+        HIPCHK(hipMemcpyAsync(hit_read, c->match_read.p, (size_t)c->match_total * sizeof(int),
+                              hipMemcpyDeviceToHost, st));
+      if (hit_pos)
+        HIPCHK(hipMemcpyAsync(hit_pos, c->match_pos.p, (size_t)c->match_total * sizeof(int),
+                              hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipMemcpyAsync(hit_offsets, c->match_off.p, (size_t)(n_pat + 1) * sizeof(long long),
+                          hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return AMG_OK;
+  }
+  c->match_valid = false;
+  if (n_pat >= (1ll << PAT_BITS)) return amg_fail(AMG_E_ARG, "at most %d patterns per call", (1 << PAT_BITS) - 1);
+  if (c->n_reads >= (1ll << READ_BITS)) return amg_fail(AMG_E_ARG, "too many reads for amg_match_patterns");
+  const long long n_sym = pat_offsets[n_pat];
+  const long long domain = which == 1 ? c->n_nodes : c->two_v;
+  AMGCHK(c->match_off.ensure((size_t)(n_pat + 2) * sizeof(long long)));
+  if (n_pat == 0) {
+    hit_offsets[0] = 0;
+    c->match_total = 0; c->match_npat = 0; c->match_valid = true;
+    return AMG_OK;
+  }
+  // ---- upload patterns, bucket them by first symbol
+  AMGCHK(c->s0.ensure((size_t)(n_sym + 1) * sizeof(int)));
+  AMGCHK(c->s1.ensure((size_t)(n_pat + 2) * sizeof(long long)));
+  AMGCHK(c->s2.ensure((size_t)(n_pat + 2) * sizeof(unsigned int) * 4));
+  AMGCHK(c->s3.ensure((size_t)(domain + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(domain + 2) * sizeof(long long)));
+  if (n_sym > 0)
+    HIPCHK(hipMemcpyAsync(c->s0.p, pat, (size_t)n_sym * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->s1.p, pat_offsets, (size_t)(n_pat + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+  unsigned int* first = c->s2.as<unsigned int>();
+  unsigned int* idx = first + (n_pat + 2);
+  unsigned int* first_sorted = idx + (n_pat + 2);
+  unsigned int* idx_sorted = first_sorted + (n_pat + 2);
+  HIPCHK(hipMemsetAsync(c->s3.p, 0, (size_t)(domain + 2) * sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_pat_first, dim3(nblk(n_pat, 256)), dim3(256), 0, st, c->s0.as<int>(),
+                     c->s1.as<long long>(), (long long)n_pat, domain, first, idx, c->s3.as<unsigned int>());
+  AMGCHK(prim_sort_u32_u32(c, first, first_sorted, idx, idx_sorted, (size_t)n_pat,
+                           ilog2_ceil((uint64_t)domain + 2) + 1));
+  AMGCHK(prim_exscan_u32_to_i64(c, c->s3.as<unsigned int>(), c->s4.as<long long>(), (size_t)domain + 1));
+  MatchArgs A;
+  A.seq = which == 1 ? c->tok_node.as<int>() : c->tokens.as<int>();
+  A.read_off = c->read_off.as<long long>();
+  A.n_reads = c->n_reads;
+  A.tail = which == 1 ? c->k - 1 : 0;
+  A.pat = c->s0.as<int>();
+  A.pat_off = c->s1.as<long long>();
+  A.bucket_off = c->s4.as<long long>();
+  A.bucket_pat = reinterpret_cast<const int*>(idx_sorted);
+  A.domain = domain;
+  A.hits = nullptr;
+  A.counter = c->status.as<unsigned long long>() + ST_MISC;
+  A.cap = 0;
+  // ---- pass 1: count, pass 2: fill
+  HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
+  if (c->n_reads > 0) hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+  unsigned long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, A.counter, sizeof(total), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(c->match_read.ensure((size_t)(total + 1) * sizeof(int)));
+  AMGCHK(c->match_pos.ensure((size_t)(total + 1) * sizeof(int)));
+  AMGCHK(c->s5.ensure((size_t)(total + 1) * sizeof(unsigned long long) * 2 + (size_t)(n_pat + 2) * sizeof(unsigned int)));
+  unsigned long long* keys = c->s5.as<unsigned long long>();
+  unsigned long long* keys_sorted = keys + (total + 1);
+  unsigned int* per_pat = reinterpret_cast<unsigned int*>(keys_sorted + (total + 1));
+  HIPCHK(hipMemsetAsync(per_pat, 0, (size_t)(n_pat + 2) * sizeof(unsigned int), st));
+  if (total > 0) {
+    A.hits = keys;
+    A.cap = total;
+    HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+    // sort by (pattern, read, position); the values of the pair sort are not needed
+    AMGCHK(c->s2.ensure((size_t)(total + 1) * sizeof(unsigned int) * 2 + (size_t)(n_pat + 2) * sizeof(unsigned int) * 4));
+    // NB: s2 may have been reallocated — bucket arrays are no longer needed after pass 2
+    unsigned int* dummy_in = c->s2.as<unsigned int>();
+    unsigned int* dummy_out = dummy_in + (total + 1);
+    AMGCHK(prim_sort_u64_u32(c, keys, keys_sorted, dummy_in, dummy_out, (size_t)total, 64));
+    hipLaunchKernelGGL(k_hit_split, dim3(nblk((long long)total, 256)), dim3(256), 0, st, keys_sorted,
+                       (long long)total, c->match_read.as<int>(), c->match_pos.as<int>(), per_pat);
+  }
+  AMGCHK(prim_exscan_u32_to_i64(c, per_pat, c->match_off.as<long long>(), (size_t)n_pat + 1));
+  HIPCHK(hipMemcpyAsync(hit_offsets, c->match_off.p, (size_t)(n_pat + 1) * sizeof(long long),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c->match_total = (int64_t)total;
+  c->match_npat = n_pat;
+  c->match_valid = true;
+  return AMG_OK;
+}

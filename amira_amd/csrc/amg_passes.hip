@@ -1666,8 +1666,3 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   return AMG_OK;
 }
 
-extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, const int64_t* pat_offsets,
-                                  int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read, int32_t* hit_pos) {
-  (void)c; (void)which; (void)pat; (void)pat_offsets; (void)n_pat; (void)hit_offsets; (void)hit_read; (void)hit_pos;
-  return amg_fail(AMG_E_STATE, "amg_match_patterns: not implemented yet");
-}

@@ -160,6 +160,24 @@ class Engine:
     def adopt_corrected(self):
         check(_ffi.lib.amg_adopt_corrected(self._h))
 
+    # ---- K6: batched exact sub-list search
+    def match_patterns(self, which, patterns):
+        """patterns: list of int lists (tokens for which=0, node ids for which=1).
+        Returns (offsets[n_pat + 1], hit_read, hit_pos), hits ordered by pattern, read, position."""
+        n = len(patterns)
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum([len(p) for p in patterns], out=offs[1:])
+        flat = np.fromiter((x for p in patterns for x in p), dtype=np.int32, count=int(offs[-1]))
+        hit_off = np.zeros(n + 1, np.int64)
+        check(_ffi.lib.amg_match_patterns(self._h, int(which), ptr(flat) if len(flat) else None,
+                                          ptr(offs), n, ptr(hit_off), None, None))
+        total = int(hit_off[-1])
+        hr, hp = np.empty(total, np.int32), np.empty(total, np.int32)
+        if total:
+            check(_ffi.lib.amg_match_patterns(self._h, int(which), ptr(flat) if len(flat) else None,
+                                              ptr(offs), n, ptr(hit_off), ptr(hr), ptr(hp)))
+        return hit_off, hr, hp
+
     # ---- multi-GPU merge phases (device pointers in / out; see amira_amd/dist.py)
     @staticmethod
     def dist_record_bytes(k):

@@ -95,3 +95,32 @@ def test_rebuild_on_same_context(eng):
     b = _run(eng, reads, 3)
     c = _run(eng, reads, 5)
     assert a["n_nodes"] == c["n_nodes"] and b["n_nodes"] != 0
+
+
+def test_match_patterns_against_brute_force(eng):
+    """K6 (amg_match_patterns) vs find_sublist_indices over every read, tokens and node ids."""
+    from amira_amd import tokenize
+    import random
+    reads, _, _ = P.synth_inputs(31, 300, 30, 60, 0.05)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    eng.build(3)
+    tok_node, _ = eng.read_nodes()
+    rng = random.Random(3)
+    for which, seq, tail in ((0, toks, 0), (1, tok_node, 2)):
+        rows = [seq[offs[r]:offs[r + 1] - tail].tolist() for r in range(len(read_ids))]
+        pats = []
+        for _ in range(200):
+            row = rows[rng.randrange(len(rows))]
+            if len(row) < 2:
+                continue
+            m = rng.randint(1, min(6, len(row)))
+            s = rng.randrange(len(row) - m + 1)
+            pats.append(row[s:s + m])
+        pats += [[10 ** 6], [rows[0][0], 10 ** 6], []]  # cannot match / empty
+        off, hr, hp = eng.match_patterns(which, pats)
+        for j, p in enumerate(pats):
+            want = [(r, i) for r, row in enumerate(rows) for i in range(len(row) - len(p) + 1)
+                    if p and row[i:i + len(p)] == p]
+            got = list(zip(hr[off[j]:off[j + 1]].tolist(), hp[off[j]:off[j + 1]].tolist()))
+            assert got == want, (which, j)
