@@ -647,6 +647,57 @@ class GeneMerGraph:
         genes = walk(False)
         return genes if genes is not None else walk(True)
 
+    # ------------------------------------------------------------------ GML output (:542-586, :873-909)
+    def write_node_entry(self, node_id, node_string, node_coverage, reads, component_ID, nodeColor):
+        rows = ["\tnode\t[", f"\t\tid\t{node_id}", f'\t\tlabel\t"{node_string}"',
+                f"\t\tcoverage\t{node_coverage}"]
+        if component_ID:
+            rows.append(f"\t\tcomponent\t{component_ID}")
+        rows.append('\t\treads\t"' + ",".join(reads) + '"')
+        if nodeColor:
+            rows.append(f'\t\tcolor\t"{nodeColor}"')
+        rows.append("\t]")
+        return "\n".join(rows)
+
+    def write_edge_entry(self, source_node, target_node, source_edge_direction, target_edge_direction,
+                         edge_coverage):
+        return "\n".join(["\tedge\t[", f"\t\tsource\t{source_node}", f"\t\ttarget\t{target_node}",
+                          f"\t\tsource_direction\t{source_edge_direction}",
+                          f"\t\ttarget_direction\t{target_edge_direction}",
+                          f"\t\tweight\t{edge_coverage}", "\t]"])
+
+    def assign_Id_to_nodes(self):
+        for i, node in enumerate(self.all_nodes()):
+            assert node.assign_node_Id(i) == i, "This node was assigned an incorrect ID"
+
+    def write_gml_to_file(self, output_file, gml_content):
+        import os
+        folder = os.path.dirname(output_file)
+        if folder != "" and not os.path.exists(folder):
+            os.mkdir(folder)
+        with open(output_file + ".gml", "w") as fh:
+            fh.write("\n".join(gml_content))
+
+    def generate_gml(self, output_file, geneMerSize, min_node_coverage, min_edge_coverage):
+        """nodes in dict order, each followed by its forward then backward edges (:873-909)"""
+        graph_data = ["graph\t[", "multigraph 1"]
+        self.assign_Id_to_nodes()
+        for node in self.all_nodes():
+            graph_data.append(self.write_node_entry(node.get_node_Id(), self.get_gene_mer_label(node),
+                                                    node.get_node_coverage(), [r for r in node.get_reads()],
+                                                    node.get_component(), node.get_color()))
+            for edge in self.get_forward_edges(node) + self.get_backward_edges(node):
+                if edge.get_edge_coverage() == 0:
+                    continue
+                graph_data.append(self.write_edge_entry(node.get_node_Id(), edge.get_targetNode().get_node_Id(),
+                                                        edge.get_sourceNodeDirection(),
+                                                        edge.get_targetNodeDirection(),
+                                                        edge.get_edge_coverage()))
+        graph_data.append("]")
+        self.write_gml_to_file(".".join([output_file, str(geneMerSize), str(min_node_coverage),
+                                         str(min_edge_coverage)]), graph_data)
+        return graph_data
+
     # ------------------------------------------------------------------ linear paths (:722-861)
     def _linear_step(self, node, forward):
         hashes = node.get_forward_edge_hashes() if forward else node.get_backward_edge_hashes()
