@@ -91,7 +91,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   stages_reset(c);
   DevBuf* all[] = {&c->tokens,    &c->read_off,  &c->gene_start, &c->gene_end,  &c->read_len,
-                   &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir,
+                   &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,
                    &c->edge_src,  &c->edge_tgt,  &c->edge_sdir,  &c->edge_tdir, &c->edge_cov,
                    &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_cnt, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
     const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k,
     int two_v, unsigned long long seed, Slot* __restrict__ tab, unsigned long long mask,
     unsigned int probe_limit, long long tok_base, int* __restrict__ tok_slot,
-    signed char* __restrict__ tok_dir, unsigned long long* status) {
+    signed char* __restrict__ tok_dir, unsigned long long* status, int count_inline) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
   const long long t0 = (long long)blockIdx.x * TILE;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
       } else {
         unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed);
         unsigned long long first = ((unsigned long long)(tok_base + t) << 1) | (dir < 0 ? 1ull : 0ull);
-        long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit);
+        long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit, count_inline != 0);
         if (slot < 0) {
           status[ST_OVERFLOW] = 1;
         } else {
@@ -199,7 +199,7 @@ __global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sort
   unsigned long long first = first_sorted[i];
   unsigned int slot = slot_sorted[i];
   tab[slot].id = (int)i;
-  node_cov[i] = tab[slot].count;
+  node_cov[i] = tab[slot].count;  // 0 when counting is deferred to k_count_ids
   node_first[i] = (long long)first;
   node_alive[i] = 1;
   long long t = (long long)(first >> 1) - tok_base;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
     const Slot* __restrict__ node_tab, const int* __restrict__ node_tokens,
     const int* __restrict__ tok_slot, const signed char* __restrict__ tok_dir,
     int* __restrict__ tok_node, Slot* __restrict__ edge_tab, unsigned long long edge_mask,
-    unsigned int probe_limit, int verify, long long tok_base, unsigned long long* status) {
+    unsigned int probe_limit, int verify, long long tok_base, unsigned long long* status,
+    int count_inline, int* __restrict__ tok_pair) {
   __shared__ int s_id[TILE + 1];
   __shared__ int s_raw[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
   for (int it = 0; it < TILE_ITEMS; ++it) {
     int i = threadIdx.x + it * TILE_THREADS;
     int raw = s_raw[i];
-    if (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) continue;
+    if (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) {
+      if (tok_pair && t0 + i < n_tokens) tok_pair[t0 + i] = -1;
+      continue;
+    }
     // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
     unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
     int dA = s_dir[i], dB = s_dir[i + 1];
@@ -265,8 +269,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
     unsigned long long orient = (a == lo ? 1ull : 0ull) | (dA > 0 ? 2ull : 0ull) |
                                 (dB > 0 ? 4ull : 0ull);
     unsigned long long first = ((unsigned long long)(tok_base + t0 + i) << 3) | orient;
-    long long slot = table_upsert(edge_tab, edge_mask, key, mix64(key), first, probe_limit);
+    long long slot = table_upsert(edge_tab, edge_mask, key, mix64(key), first, probe_limit,
+                                  count_inline != 0);
     if (slot < 0) status[ST_OVERFLOW] = 2;
+    if (tok_pair) tok_pair[t0 + i] = (int)slot;
   }
 }
 
@@ -387,6 +393,72 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
   comp[i] = (int)(root_rank[r] + 1);
 }
 
+
+// ------------------------------------------------------------------ deferred counting
+// Occurrence counts without one global atomic per window.  Persistent 1024-thread blocks keep
+// HOT_IDS counters in LDS for the id range [lo, lo + HOT_IDS) and sweep the whole id array;
+// ids are first-seen ranks, so the frequently hit (genome) nodes / edges are the LOW ids and
+// a few ranges absorb almost every increment.  The last sweep sends the ids beyond the covered
+// ranges to global atomics.  With GATHER the array holds table slots on entry and is rewritten
+// to dense ids (tab[slot].id) during the first sweep.
+#define HOT_IDS 32768
+template <bool GATHER>
+__global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long long n,
+                                                    const Slot* __restrict__ tab, long long lo,
+                                                    long long tail_from, unsigned int* __restrict__ out) {
+  __shared__ unsigned int s_cnt[HOT_IDS];
+  for (int i = threadIdx.x; i < HOT_IDS; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * 1024;
+  for (long long t = (long long)blockIdx.x * 1024 + threadIdx.x; t < n; t += stride) {
+    int id = ids[t];
+    if (GATHER) {
+      id = id < 0 ? -1 : tab[id].id;
+      ids[t] = id;
+    }
+    if (id < 0) continue;
+    const long long rel = (long long)id - lo;
+    if (rel >= 0 && rel < HOT_IDS)
+      atomicAdd(&s_cnt[rel], 1u);
+    else if (tail_from >= 0 && id >= tail_from)
+      atomicAdd(&out[id], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HOT_IDS; i += 1024) {
+    const unsigned int cnt = s_cnt[i];
+    if (cnt) atomicAdd(&out[lo + i], cnt);
+  }
+}
+
+// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids
+static int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
+                     unsigned int* out) {
+  hipStream_t st = c->stream;
+  HIPCHK(hipMemsetAsync(out, 0, (size_t)(n_ids + 1) * sizeof(unsigned int), st));
+  if (n <= 0 || n_ids <= 0) return AMG_OK;
+  long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
+  if (ranges > 4) ranges = 4;
+  long long want_blocks = (n + 1023) / 1024;
+  unsigned int blocks = (unsigned int)(want_blocks < 256 ? want_blocks : 256);
+  for (long long r = 0; r < ranges; ++r) {
+    const long long lo = r * HOT_IDS;
+    const long long tail_from = (r == ranges - 1) ? ranges * HOT_IDS : -1;
+    if (gather_tab && r == 0)
+      hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
+                         tail_from, out);
+    else
+      hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
+                         tail_from, out);
+  }
+  return AMG_OK;
+}
+
+__global__ void k_set_pair_ids(const unsigned int* __restrict__ slot_sorted, long long n_pairs,
+                               Slot* __restrict__ edge_tab) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pairs) edge_tab[slot_sorted[i]].id = (int)i;
+}
+
 // ------------------------------------------------------------------ host orchestration
 // The build is split into stages so that the multi-GPU path (amg_dist.hip) can put its
 // exchanges between them:
@@ -450,7 +522,7 @@ int bs_nodes_pass(amg_ctx* c, int k, int* which) {
                        c->two_v, c->seed, c->node_tab.as<Slot>(),
                        (unsigned long long)(c->node_slots - 1), kProbeLimit, (long long)c->tok_base,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                       c->status.as<unsigned long long>());
+                       c->status.as<unsigned long long>(), c->count_inline ? 1 : 0);
   stage_end(c);
 
   stage_begin(c, "node_rank");
@@ -516,6 +588,7 @@ int bs_edges_pass(amg_ctx* c, int* which) {
   const long long n_tiles = (T + TILE - 1) / TILE;
   unsigned long long hs[ST_WORDS];
   if (c->edge_slots < (int64_t)pow2_at_least((uint64_t)D * 4)) c->edge_slots = pow2_at_least((uint64_t)D * 4);
+  if (!c->count_inline) AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
   stage_begin(c, "edge_table_clear");
   HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot), st));
@@ -529,7 +602,8 @@ int bs_edges_pass(amg_ctx* c, int* which) {
                        c->node_tokens.as<int>(), c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot>(), (unsigned long long)(c->edge_slots - 1),
-                       kProbeLimit, 1, (long long)c->tok_base, c->status.as<unsigned long long>());
+                       kProbeLimit, 1, (long long)c->tok_base, c->status.as<unsigned long long>(),
+                       c->count_inline ? 1 : 0, c->count_inline ? (int*)nullptr : c->tok_pair.as<int>());
   stage_end(c);
 
   stage_begin(c, "edge_rank");
@@ -553,6 +627,12 @@ int bs_edges_pass(amg_ctx* c, int* which) {
     return AMG_E_OVERFLOW;
   }
   c->n_local_pairs = (int64_t)hs[ST_COMPACT_B];
+  if (!c->count_inline) {
+    // node coverage (construct_node.py:33-36) from the per-window node ids
+    stage_begin(c, "node_count");
+    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>()));
+    stage_end(c);
+  }
   return AMG_OK;
 }
 
@@ -578,6 +658,15 @@ int bs_pairs_from_local(amg_ctx* c) {
                        c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>(),
                        c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
   stage_end(c);
+  if (!c->count_inline && P > 0) {
+    // edge-class coverage: pair ids into the table, then count the per-adjacency slots
+    stage_begin(c, "edge_count");
+    hipLaunchKernelGGL(k_set_pair_ids, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                       c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>());
+    AMGCHK(count_ids(c, c->tok_pair.as<int>(), c->n_tokens, c->edge_tab.as<Slot>(), P,
+                     c->pair_cnt.as<unsigned int>()));
+    stage_end(c);
+  }
   return AMG_OK;
 }
 
@@ -696,6 +785,10 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   c->retries = 0;
   c->tok_base = 0;
   c->tok_total = c->n_tokens;
+  {
+    const char* e = getenv("AMG_COUNT_INLINE");  // A/B switch: 1 = one global atomic per window
+    c->count_inline = e && e[0] == '1';
+  }
   bs_size_tables(c);
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;

@@ -66,7 +66,8 @@ __device__ __forceinline__ unsigned long long canon_fingerprint(const View& w, i
 __device__ __forceinline__ long long table_upsert(Slot* tab, unsigned long long mask,
                                                   unsigned long long key,
                                                   unsigned long long start,
-                                                  unsigned long long first, unsigned int limit) {
+                                                  unsigned long long first, unsigned int limit,
+                                                  bool count_inline = true) {
   unsigned long long idx = start & mask;
   for (unsigned int probes = 0;; ++probes) {
     Slot* s = tab + idx;
@@ -76,7 +77,10 @@ __device__ __forceinline__ long long table_upsert(Slot* tab, unsigned long long 
       if (cur == 0ull) cur = key;
     }
     if (cur == key) {
-      atomicAdd(&s->count, 1u);
+      // scattered atomics run at ~27 G/s on MI355X against ~255 G/s for cached loads
+      // (tools/ubench/atomic_bench.hip), so the single-GPU build counts occurrences in a
+      // separate LDS-privatised pass (k_count_ids) and only the merge path counts here
+      if (count_inline) atomicAdd(&s->count, 1u);
       unsigned long long fi = ~first;
       if (ld_u64(&s->first_inv) < fi) atomicMax(&s->first_inv, fi);
       return (long long)idx;

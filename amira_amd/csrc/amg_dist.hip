@@ -100,6 +100,7 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   c->tok_base = token_base;
   c->tok_total = token_total;
   c->world = world;
+  c->count_inline = true;  // the records exchanged between ranks carry the local counts
   bs_size_tables(c);
   for (int attempt = 0;; ++attempt) {
     int which = 0;

@@ -127,6 +127,8 @@ struct amg_ctx {
   DevBuf tok_slot;   // int32[n_tokens]  slot index | LAST flag, -1 = no window
   DevBuf tok_node;   // int32[n_tokens]  node id, -1 no window, -2 removed
   DevBuf tok_dir;    // int8 [n_tokens]
+  DevBuf tok_pair;   // int32[n_tokens]  edge-class slot (then id) of the adjacency t -> t+1
+  bool count_inline = false;  // true: count by one global atomic per window (merge path)
   // nodes (id order)
   DevBuf node_tokens;  // int32[n_nodes * k]
   DevBuf node_cov;     // uint32[n_nodes]
