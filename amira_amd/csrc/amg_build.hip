@@ -135,7 +135,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
       } else {
         unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed);
         unsigned long long first = ((unsigned long long)(tok_base + t) << 1) | (dir < 0 ? 1ull : 0ull);
-        long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit, count_inline != 0);
+        long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit, count_inline != 0,
+                                      status + ST_OVERFLOW);
         if (slot < 0) {
           status[ST_OVERFLOW] = 1;
         } else {
@@ -485,7 +486,7 @@ uint64_t pow2_at_least(uint64_t x) {
   return p;
 }
 
-static const unsigned int kProbeLimit = 4096;
+static const unsigned int kProbeLimit = 1024;
 
 // returns AMG_OK, or AMG_E_OVERFLOW with *which = 1 (node table too small)
 int bs_nodes_pass(amg_ctx* c, int k, int* which) {
@@ -767,7 +768,10 @@ int bs_finish_from_pairs(amg_ctx* c) {
 
 // table sizing: previous distinct-node count when known, otherwise the window bound
 void bs_size_tables(amg_ctx* c) {
-  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 4 : (uint64_t)c->n_tokens * 2;
+  // no history: half a slot per token.  Real gene-call data repeat every gene-mer tens to
+  // thousands of times, so this is already generous; inputs with more distinct gene-mers than
+  // that overflow once (cheaply, see table_upsert's abort flag) and are rebuilt 4x larger.
+  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 4 : (uint64_t)c->n_tokens / 2;
   c->node_slots = (int64_t)pow2_at_least(want);
   if (c->node_slots > (1ll << 30)) c->node_slots = 1ll << 30;
   c->edge_slots = 1024;

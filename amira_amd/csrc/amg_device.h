@@ -67,9 +67,14 @@ __device__ __forceinline__ long long table_upsert(Slot* tab, unsigned long long 
                                                   unsigned long long key,
                                                   unsigned long long start,
                                                   unsigned long long first, unsigned int limit,
-                                                  bool count_inline = true) {
+                                                  bool count_inline = true,
+                                                  const unsigned long long* abort_flag = nullptr) {
   unsigned long long idx = start & mask;
   for (unsigned int probes = 0;; ++probes) {
+    // a table that turned out too small is abandoned quickly: once any thread has run out
+    // of probes the others stop walking long chains (the host rebuilds with a larger table)
+    if (abort_flag && (probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
+      return -1;
     Slot* s = tab + idx;
     unsigned long long cur = ld_u64(&s->key);
     if (cur == 0ull) {
