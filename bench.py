@@ -43,13 +43,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def stage_bytes(stage, k, L, n_windows, n_reads, n_gapped):
-    """ALGORITHMIC bytes one launch of the named stage's dominant kernel moves (DESIGN.md
-    "Kernels"): tokens int32, slot/node id int32, dir int8, counters uint32, first-seen
-    uint64, positions 2 x int64."""
-    tok = 4.0 * L / (L - k + 1)
+    """ALGORITHMIC bytes one launch of the named stage's dominant kernel moves: SURVEY.md
+    section 8(d)'s 56.9 B per gene-mer (k=5) split over the kernels that implement each term
+    (DESIGN.md "Kernels"): tokens int32, node id int32, dir int8, counters uint32 RMW = 8 B,
+    edge key 12 B, positions 2 x int64."""
+    adj = (L - k) / (L - k + 1)
     per_window = {
-        "node_upsert": tok + 5 + (4 * k + 8),
-        "edge_upsert": 5 + 4 + (12 + 8) * (L - k) / (L - k + 1),
+        "node_upsert": 4.0 * L / (L - k + 1) + 5 + 4 * k,   # token read + (id, dir) write + key compare-read
+        "node_count": 8.0,                                   # node counter RMW
+        "edge_upsert": 12.0 * adj,                           # edge record key read per adjacency
+        "edge_count": 8.0 * adj,                             # edge counter RMW per adjacency
     }
     if stage in per_window:
         return per_window[stage] * n_windows
@@ -226,8 +229,14 @@ def main():
         cands = {s: stage_bytes(s, k, L, n_windows, N, n_gapped) for s in stage_tot}
         dom = max((s for s in cands if cands[s]), key=lambda s: stage_tot[s])
         achieved = cands[dom] / (stage_avg[dom] * 1e-3) / 1e9
-        kernel_of = {"node_upsert": "k_node_upsert", "edge_upsert": "k_edges",
-                     "correct_positions": "k_corr_nw", "correct_gapped": "k_corr_gapped"}
+        kernel_of = {"node_upsert": "k_node_upsert", "edge_upsert": "k_edges", "node_count": "k_count_ids",
+                     "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
+                     "correct_gapped": "k_corr_gapped_fast"}
+        build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "node_table_clear", "node_upsert", "node_rank",
+                                                        "edge_table_clear", "edge_upsert", "edge_rank", "node_count",
+                                                        "edge_count", "edge_emit", "components", "adjacency"))
+        n_builds = max(stage_ms.get("node_upsert", [0, 1])[1], 1)
+        survey_b = 4.0 * L / (L - k + 1) + 5 + (4 * k + 8) + 20.0 * (L - k) / (L - k + 1)
         out = {
             "metric": "gene-mers/s to corrected GeneMerGraph" if w["sweep"] else "gene-mers/s to GeneMerGraph (build + coverage)",
             "value": world * n_windows * args.steps / dt, "unit": "gene-mers/s",
@@ -244,7 +253,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": cands[dom],
-                         "avg_launch_ms": stage_avg[dom], "launches_per_step": stage_ms[dom][1]},
+                         "avg_launch_ms": stage_avg[dom], "launches_per_step": stage_ms[dom][1],
+                         "whole_build": {"algorithmic_bytes_per_gene_mer": survey_b,
+                                         "ms_per_build": build_ms / n_builds,
+                                         "achieved": survey_b * n_windows / (build_ms / n_builds * 1e-3) / 1e9,
+                                         "unit": "GB/s"}},
             "stages_ms_per_step": {n: round(v, 3) for n, v in stage_tot.items()},
         }
         if not args.no_cpu_baseline:
