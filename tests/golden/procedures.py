@@ -130,6 +130,25 @@ def p_misc_passes(impl, name, k):
     return entry
 
 
+def p_drivers(impl, name):
+    """graph_utils drivers on a fixture: get_overall_mean_node_coverages (:299-313),
+    choose_kmer_size (:258-296, seven builds k = 3..15) and remove_non_AMR_associated_nodes
+    (construct_graph.py:2941-2959) for the three most frequent genes of the fixture."""
+    from collections import Counter
+    calls, pos = fixture(name)
+    pos = {r: list(v) for r, v in pos.items()}
+    counts = Counter(g[1:] for genes in calls.values() for g in genes)
+    genes = [g for g, _ in sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:3]]
+    g = impl.GeneMerGraph(calls, 3, pos)
+    cov = impl.get_overall_mean_node_coverages(g)
+    entry = {"genes": genes, "mean_cov": {str(k): float(v) for k, v in cov.items()}}
+    entry["chosen_k"] = impl.choose_kmer_size(cov[3], calls, 1, pos, genes)
+    entry["chosen_k_low_cov"] = impl.choose_kmer_size(1, calls, 1, pos, genes)
+    g.remove_non_AMR_associated_nodes(genes[:1])
+    entry["after_remove_non_AMR"] = D.summarise(D.dump_graph(g))
+    return entry
+
+
 def p_values(impl):
     """Known-answer hashes of the value objects (pins the host-side sha256 hashing)."""
     names = ["+gene1", "-gene2", "+blaTEM-1", "-group_1234", "+g0", "+two words"]
@@ -163,6 +182,8 @@ CASES["sweep_small_k7"] = (p_sweep, (13, 300, 40, 250, 7, 0.02), False)
 CASES["sweep_dense_k5"] = (p_sweep, (17, 800, 40, 150, 5, 0.05), False)
 CASES["misc_nine_k3"] = (p_misc_passes, ("nine", 3), False)
 CASES["misc_four_k5"] = (p_misc_passes, ("four", 5), False)
+CASES["drivers_eight"] = (p_drivers, ("eight",), False)
+CASES["drivers_nine"] = (p_drivers, ("nine",), False)
 CASES["cluster_eight_k3"] = (p_cluster_fixture, ("eight", 3, ["dfrA17"]), False)
 CASES["planted_s20250909"] = (p_planted, (20250909, 1500, 40, 1000, 5), True)
 CASES["planted_small"] = (p_planted, (5, 300, 40, 1000, 5), False)

@@ -24,10 +24,14 @@ def _impl(kind):
     if kind == "oracle":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from amira_oracle import Gene, GeneMer, GeneMerGraph
+        from amira_oracle.driver import choose_kmer_size, get_overall_mean_node_coverages
     else:
         sys.path.insert(0, ROOT)
         from amira_amd import Gene, GeneMer, GeneMerGraph
-    return types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer)
+        from amira_amd.graph_utils import choose_kmer_size, get_overall_mean_node_coverages
+    return types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
+                                 choose_kmer_size=choose_kmer_size,
+                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages)
 
 
 if __name__ == "__main__":

@@ -16,8 +16,10 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens
 
 def _product():
     import amira_amd
+    from amira_amd.graph_utils import choose_kmer_size, get_overall_mean_node_coverages
     return types.SimpleNamespace(GeneMerGraph=amira_amd.GeneMerGraph, Gene=amira_amd.Gene,
-                                 GeneMer=amira_amd.GeneMer)
+                                 GeneMer=amira_amd.GeneMer, choose_kmer_size=choose_kmer_size,
+                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages)
 
 
 @pytest.mark.parametrize("name", list(P.CASES))
