@@ -149,6 +149,7 @@ struct amg_ctx {
   // live adjacency (only alive edges, targets inline) — rebuilt lazily after removals
   DevBuf ladj_off;  // int64[2 n_nodes + 1]
   DevBuf ladj;      // int2[n_live_edges]  {target node, target direction}
+  DevBuf ladj_rows; // int4[2 n_nodes]  {offset, live count, first target, first direction}
   DevBuf ladj_cnt;  // uint32[2 n_nodes + 1] scratch of its own (callers hold s0..s5)
   bool ladj_valid = false;
   // reads

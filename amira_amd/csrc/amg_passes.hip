@@ -114,6 +114,8 @@ struct GView {
   // edges, in list order, with the target inline (.x = target node, .y = target direction)
   const long long* lrow;
   const int2* lent;
+  const int4* lrows;  // per row {offset, live count, first target, first direction}: one 16-B load
+                      // tells a walker everything about a row with <= 1 live edge (most rows)
   const unsigned char* n_alive;
   const unsigned int* n_cov;
   const int* n_tok;
@@ -135,14 +137,22 @@ __global__ void k_live_count(const long long* __restrict__ adj_off, const int* _
 __global__ void k_live_fill(const long long* __restrict__ adj_off, const int* __restrict__ adj_edge,
                             const unsigned char* __restrict__ e_alive, const int* __restrict__ e_tgt,
                             const signed char* __restrict__ e_tdir, long long n_rows,
-                            const long long* __restrict__ lrow, int2* __restrict__ lent) {
+                            const long long* __restrict__ lrow, int2* __restrict__ lent,
+                            int4* __restrict__ lrows) {
   long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_rows) return;
-  long long o = lrow[row];
+  const long long o0 = lrow[row];
+  long long o = o0;
+  int2 first = make_int2(-1, 0);
   for (long long p = adj_off[row]; p < adj_off[row + 1]; ++p) {
     int e = adj_edge[p];
-    if (e_alive[e]) lent[o++] = make_int2(e_tgt[e], (int)e_tdir[e]);
+    if (e_alive[e]) {
+      int2 ent = make_int2(e_tgt[e], (int)e_tdir[e]);
+      if (o == o0) first = ent;
+      lent[o++] = ent;
+    }
   }
+  lrows[row] = make_int4((int)o0, (int)(o - o0), first.x, first.y);
 }
 
 // forward/backward edge lists with the removed edges squeezed out: the walkers below then
@@ -164,10 +174,12 @@ static int ensure_live_adj(amg_ctx* c) {
                         hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   AMGCHK(c->ladj.ensure((size_t)(total + 1) * sizeof(int2)));
+  AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
   if (rows > 0)
     hipLaunchKernelGGL(k_live_fill, dim3(nblk(rows, 256)), dim3(256), 0, st, c->adj_off.as<long long>(),
                        c->adj_edge.as<int>(), c->edge_alive.as<unsigned char>(), c->edge_tgt.as<int>(),
-                       c->edge_tdir.as<signed char>(), rows, c->ladj_off.as<long long>(), c->ladj.as<int2>());
+                       c->edge_tdir.as<signed char>(), rows, c->ladj_off.as<long long>(), c->ladj.as<int2>(),
+                       c->ladj_rows.as<int4>());
   c->ladj_valid = true;
   return AMG_OK;
 }
@@ -176,6 +188,7 @@ static GView make_view(amg_ctx* c) {
   GView g;
   g.lrow = c->ladj_off.as<long long>();
   g.lent = c->ladj.as<int2>();
+  g.lrows = c->ladj_rows.as<int4>();
   g.n_alive = c->node_alive.as<unsigned char>();
   g.n_cov = c->node_cov.as<unsigned int>();
   g.n_tok = c->node_tokens.as<int>();
@@ -188,7 +201,7 @@ static GView make_view(amg_ctx* c) {
 
 // get_degree (:326-329): live edge classes on both sides
 __device__ __forceinline__ int node_degree(const GView& g, int n) {
-  return (int)(g.lrow[2ll * n + 2] - g.lrow[2ll * n]);
+  return g.lrows[2ll * n].y + g.lrows[2ll * n + 1].y;
 }
 
 // get_forward_node_from_node (:722-741) / get_backward_node_from_node (:781-802):
@@ -196,11 +209,10 @@ __device__ __forceinline__ int node_degree(const GView& g, int n) {
 // returns 0 = no edge, 1 = edge but cannot extend, 2 = extend
 __device__ __forceinline__ int lin_step(const GView& g, int n, bool use_forward, int* tgt, int* tdir) {
   const long long row = 2ll * n + (use_forward ? 0 : 1);
-  const long long a = g.lrow[row], cnt = g.lrow[row + 1] - a;
-  if (cnt == 0 || (use_forward && cnt != 1)) return 0;
-  const int2 ent = g.lent[a];
-  *tgt = ent.x;
-  *tdir = ent.y;
+  const int4 rw = g.lrows[row];
+  if (rw.y == 0 || (use_forward && rw.y != 1)) return 0;
+  *tgt = rw.z;
+  *tdir = rw.w;
   const int deg = node_degree(g, *tgt);
   return ((deg == 1 || deg == 2) && *tgt != n) ? 2 : 1;
 }
@@ -819,71 +831,92 @@ __device__ __forceinline__ bool nw_fast_ok(long long N, long long M) {
 #define GF_CAND 192     // nodes of a candidate
 #define GF_MAXCOMBO 256
 
-// DFS of one None run with its stack in LDS (no private arrays: per-lane scratch would be
-// allocated for all 64 lanes and throttle occupancy).  Run by ONE lane of the wave.
+// DFS of one None run, executed COOPERATIVELY by the whole wave: control flow is uniform,
+// stack level d lives in the registers of lane d (node, direction, row cursor), levels are
+// read with v_readlane, the "already on the path" test is one ballot, and an accepted path is
+// written to the pool by lanes 0..len-1 at once.  (A one-lane DFS with its stack in LDS or
+// scratch spends its time in dependent LDS/scratch round trips.)
 // Emits [run, len, nodes, dirs] records; returns the number of paths, -1 on pool overflow.
-struct DfsStack {
-  int* node;   // [DFS_MAX]
-  int* dir;    // [DFS_MAX]
-  int* cur;    // [DFS_MAX]  position in the adjacency row (edge ids are int32, so offsets fit)
-  int* lim;    // [DFS_MAX]
-};
-
-__device__ int dfs_paths_lds(const GView& g, const DfsStack& st, int s, int sdir, int e, int distance,
-                             int run, int* pool, int* used) {
+__device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distance, int run, int* pool,
+                              int* used, int lane) {
+  int my_node = 0, my_dir = 0, my_cur = 0, my_lim = 0, my_off = 0;
   int depth = 0, n_paths = 0;
   bool overflow = false;
-  st.node[0] = s;
-  st.dir[0] = sdir;
+  if (lane == 0) {
+    my_node = s;
+    my_dir = sdir;
+  }
   bool entering = true;
+  int2 first_ent = make_int2(-1, 0);
   while (depth >= 0) {
+    const int d = __builtin_amdgcn_readfirstlane(depth);
     if (entering) {
-      const int L = depth + 1;
-      if (st.node[depth] == e && L <= distance) {
+      const int L = d + 1;
+      const int cur_node = __builtin_amdgcn_readlane(my_node, d);
+      if (cur_node == e && L <= distance) {
         const int off = *used;
-        *used = off + 2 + 2 * L;
         if (off + 2 + 2 * L <= GF_POOL) {
-          int* o = pool + off;
-          o[0] = run;
-          o[1] = L;
-          for (int j = 0; j < L; ++j) {
-            o[2 + j] = st.node[j];
-            o[2 + L + j] = st.dir[j];
+          if (lane == 0) {
+            pool[off] = run;
+            pool[off + 1] = L;
+          }
+          if (lane < L) {
+            pool[off + 2 + lane] = my_node;
+            pool[off + 2 + L + lane] = my_dir;
           }
         } else {
           overflow = true;
         }
+        wave_sync();
+        if (lane == 0) *used = off + 2 + 2 * L;
+        wave_sync();
         ++n_paths;
         --depth;
         entering = false;
+        first_ent.x = -1;
         continue;
       }
       if (L - 1 > distance) {
         --depth;
         entering = false;
+        first_ent.x = -1;
         continue;
       }
-      const long long row = 2ll * st.node[depth] + (st.dir[depth] == 1 ? 0 : 1);
-      st.cur[depth] = (int)g.lrow[row];
-      st.lim[depth] = (int)g.lrow[row + 1];
+      const int cur_dir = __builtin_amdgcn_readlane(my_dir, d);
+      const int4 rw = g.lrows[2ll * cur_node + (cur_dir == 1 ? 0 : 1)];  // uniform address
+      if (lane == d) {
+        my_cur = 0;
+        my_lim = rw.y;
+        my_off = rw.x;
+      }
+      first_ent = make_int2(rw.z, rw.w);
       entering = false;
     }
+    int c = __builtin_amdgcn_readlane(my_cur, d);
+    const int lim = __builtin_amdgcn_readlane(my_lim, d);
+    const int row_off = __builtin_amdgcn_readlane(my_off, d);
     bool pushed = false;
-    while (st.cur[depth] < st.lim[depth]) {
-      const int2 ent = g.lent[st.cur[depth]];
-      st.cur[depth] += 1;
-      const int t = ent.x;
-      bool seen = false;
-      for (int j = 0; j <= depth; ++j) seen = seen || (st.node[j] == t);
-      if (seen) continue;
-      st.node[depth + 1] = t;
-      st.dir[depth + 1] = ent.y;
+    while (c < lim) {
+      int2 ent = first_ent;
+      if (!(c == 0 && first_ent.x >= 0)) ent = g.lent[row_off + c];  // uniform address
+      ++c;
+      const int t = __builtin_amdgcn_readfirstlane(ent.x);
+      const int td = __builtin_amdgcn_readfirstlane(ent.y);
+      if (__ballot(lane <= d && my_node == t) != 0ull) continue;  // no node twice on a path
+      if (lane == d) my_cur = c;
+      if (lane == d + 1) {
+        my_node = t;
+        my_dir = td;
+      }
       ++depth;
       entering = true;
       pushed = true;
       break;
     }
-    if (!pushed) --depth;
+    if (!pushed) {
+      --depth;
+      first_ent.x = -1;  // back in an older row: its first entry was consumed long ago
+    }
   }
   return overflow ? -1 : n_paths;
 }
@@ -900,7 +933,6 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
   __shared__ int s_gene[4][GF_CAND + AMG_MAX_K];
   __shared__ int s_best[4][GF_CAND + AMG_MAX_K];
   __shared__ int s_misc[4][4];
-  __shared__ int s_stack[4][4 * DFS_MAX];
   const CorrArgs& a = A.a;
   const GView& g = A.g;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -951,18 +983,15 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
     return;
   }
   wave_sync();
-  // ---- one DFS per run (lane 0, runs in read order)
+  // ---- one wave-cooperative DFS per run, runs in read order
   bool bad = false;
-  if (lane == 0) {
-    DfsStack stk{s_stack[wv], s_stack[wv] + DFS_MAX, s_stack[wv] + 2 * DFS_MAX, s_stack[wv] + 3 * DFS_MAX};
-    for (int q = 0; q < n_gaps && !bad; ++q) {
-      const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
-      const int np = dfs_paths_lds(g, stk, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv]);
-      GAP[3 * q + 2] = np < 0 ? 0 : np;
-      bad = np < 0;
-    }
+  for (int q = 0; q < n_gaps && !bad; ++q) {
+    const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
+    const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane);
+    if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
+    bad = np < 0;
   }
-  if (__any(bad)) {
+  if (bad) {
     if (lane == 0) A.need_slow[gi] = 1;
     return;
   }
