@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_compact_slots(const Slot* __restrict__ 
 __global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sorted,
                                const unsigned int* __restrict__ slot_sorted, long long n_nodes,
                                Slot* __restrict__ tab, const int* __restrict__ tokens, int k,
-                               int two_v, long long tok_base, int* __restrict__ node_tokens,
+                               int two_v, long long tok_base, int packed, int* __restrict__ node_tokens,
                                unsigned int* __restrict__ node_cov,
                                long long* __restrict__ node_first,
                                unsigned char* __restrict__ node_alive) {
@@ -206,8 +206,12 @@ __global__ void k_assign_nodes(const unsigned long long* __restrict__ first_sort
   long long t = (long long)(first >> 1) - tok_base;
   int dir = (first & 1ull) ? -1 : 1;
   const int flip = two_v - 1;
-  for (int j = 0; j < k; ++j)
-    node_tokens[i * k + j] = dir > 0 ? tokens[t + j] : flip - tokens[t + k - 1 - j];
+  int canon[AMG_MAX_K];
+  for (int j = 0; j < k; ++j) {
+    canon[j] = dir > 0 ? tokens[t + j] : flip - tokens[t + k - 1 - j];
+    node_tokens[i * k + j] = canon[j];
+  }
+  if (packed) slot_pack(tab + slot, (int)i, canon, k);
 }
 
 // ------------------------------------------------------------------ K3 + K4
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
     const int* __restrict__ tok_slot, const signed char* __restrict__ tok_dir,
     int* __restrict__ tok_node, Slot* __restrict__ edge_tab, unsigned long long edge_mask,
     unsigned int probe_limit, int verify, long long tok_base, unsigned long long* status,
-    int count_inline, int* __restrict__ tok_pair) {
+    int count_inline, int* __restrict__ tok_pair, int packed) {
   __shared__ int s_id[TILE + 1];
   __shared__ int s_raw[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];
@@ -232,7 +236,21 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
       d = tok_dir[t];
     }
     int id = -1;
-    if (raw != -1) {
+    if (raw != -1 && packed) {
+      // one 32-byte gather: node id + the node's canonical tuple (16-bit tokens)
+      const uint4* rec = reinterpret_cast<const uint4*>(node_tab + ((unsigned int)raw & ~AMG_LAST_FLAG));
+      const uint4 lo = rec[0], hi = rec[1];
+      id = (int)hi.y;
+      if (verify && i < TILE) {
+        const int* w = tokens + t;
+        bool same = true;
+        for (int j = 0; j < k; ++j) {
+          int cj = d > 0 ? w[j] : flip - w[k - 1 - j];
+          same = same && ((unsigned int)cj == packed_tok(lo, hi, j));
+        }
+        if (!same) status[ST_COLLISION] = 1;
+      }
+    } else if (raw != -1) {
       id = node_tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
       if (verify && i < TILE) {
         // exact check: the window's canonical tuple must equal the node's tuple
@@ -563,6 +581,7 @@ int bs_alloc_nodes(amg_ctx* c, long long D) {
 int bs_nodes_rank_local(amg_ctx* c) {
   hipStream_t st = c->stream;
   stage_begin(c, "node_rank");
+  c->packed_nodes = (c->two_v <= 65536 && c->k <= AMG_PACK_MAX_K);
   c->n_nodes = c->n_local_nodes;
   const long long D = c->n_nodes;
   int first_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 2 + 2) + 1;
@@ -574,7 +593,7 @@ int bs_nodes_rank_local(amg_ctx* c) {
     hipLaunchKernelGGL(k_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st,
                        c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), D,
                        c->node_tab.as<Slot>(), c->tokens.as<int>(), c->k, c->two_v,
-                       (long long)c->tok_base, c->node_tokens.as<int>(),
+                       (long long)c->tok_base, c->packed_nodes ? 1 : 0, c->node_tokens.as<int>(),
                        c->node_cov.as<unsigned int>(), c->node_first.as<long long>(),
                        c->node_alive.as<unsigned char>());
   stage_end(c);
@@ -604,7 +623,8 @@ int bs_edges_pass(amg_ctx* c, int* which) {
                        c->tok_dir.as<signed char>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot>(), (unsigned long long)(c->edge_slots - 1),
                        kProbeLimit, 1, (long long)c->tok_base, c->status.as<unsigned long long>(),
-                       c->count_inline ? 1 : 0, c->count_inline ? (int*)nullptr : c->tok_pair.as<int>());
+                       c->count_inline ? 1 : 0, c->count_inline ? (int*)nullptr : c->tok_pair.as<int>(),
+                       c->packed_nodes ? 1 : 0);
   stage_end(c);
 
   stage_begin(c, "edge_rank");

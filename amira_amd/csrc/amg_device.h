@@ -95,6 +95,31 @@ __device__ __forceinline__ long long table_upsert(Slot* tab, unsigned long long 
   }
 }
 
+// After node ranking a node slot is rewritten as a PACKED record so that the edge pass needs
+// ONE 32-byte gather per window for both the node id and the exact tuple check:
+//   bytes  0..19  tokens 0..9 as uint16      bytes 20..23  node id
+//   bytes 24..31  tokens 10..13 as uint16
+// (possible when every token fits 16 bits and k <= 14; otherwise the id stays in Slot::id and
+// the tuple is gathered from node_tokens).
+#define AMG_PACK_MAX_K 14
+__device__ __forceinline__ void slot_pack(Slot* s, int id, const int* tok, int k) {
+  unsigned int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < k; ++j) {
+    const int word = j < 10 ? (j >> 1) : 6 + ((j - 10) >> 1);
+    w[word] |= ((unsigned int)tok[j] & 0xffffu) << ((j & 1) * 16);
+  }
+  w[5] = (unsigned int)id;
+  uint4* p = reinterpret_cast<uint4*>(s);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ unsigned int packed_tok(const uint4& lo, const uint4& hi, int j) {
+  const int word = j < 10 ? (j >> 1) : 6 + ((j - 10) >> 1);
+  unsigned int w = word == 0 ? lo.x : word == 1 ? lo.y : word == 2 ? lo.z : word == 3 ? lo.w
+                 : word == 4 ? hi.x : word == 6 ? hi.z : hi.w;
+  return (w >> ((j & 1) * 16)) & 0xffffu;
+}
+
 // block-wide exclusive prefix of a per-thread count (256 threads = 4 waves); returns the
 // thread's offset inside the block and the block total in *total.
 __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigned int* total,

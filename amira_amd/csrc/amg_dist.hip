@@ -307,6 +307,7 @@ __global__ void k_global_nodes(const unsigned char* __restrict__ recs, int rec_b
 // local table slot -> global node id (looked up by key)
 __global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_slots,
                                   const Slot* __restrict__ gtab, unsigned long long gmask,
+                                  const int* __restrict__ node_tokens, int k, int packed,
                                   unsigned long long* status) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_slots) return;
@@ -316,7 +317,11 @@ __global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_
   for (unsigned int probes = 0; probes < (1u << 20); ++probes) {
     unsigned long long cur = gtab[s].key;
     if (cur == key) {
-      ltab[i].id = gtab[s].id;
+      const int gid = gtab[s].id;
+      if (packed)
+        slot_pack(ltab + i, gid, node_tokens + (long long)gid * k, k);
+      else
+        ltab[i].id = gid;
       return;
     }
     if (cur == 0ull) break;
@@ -330,6 +335,7 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
   hipStream_t st = c->stream;
   const long long n = n_total;
   const int rb = (int)node_rec_bytes(c->k);
+  c->packed_nodes = (c->two_v <= 65536 && c->k <= AMG_PACK_MAX_K);
   c->n_nodes = n;
   AMGCHK(bs_alloc_nodes(c, n));
   uint64_t gslots = pow2_at_least((uint64_t)n * 2 + 16);
@@ -356,7 +362,8 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
   }
   hipLaunchKernelGGL(k_local_to_global, dim3(nblk(c->node_slots, 256)), dim3(256), 0, st,
                      c->node_tab.as<Slot>(), (unsigned long long)c->node_slots, c->dist_gtab.as<Slot>(),
-                     (unsigned long long)(gslots - 1), c->status.as<unsigned long long>());
+                     (unsigned long long)(gslots - 1), c->node_tokens.as<int>(), c->k,
+                     c->packed_nodes ? 1 : 0, c->status.as<unsigned long long>());
   unsigned long long ov = 0;
   HIPCHK(hipMemcpyAsync(&ov, c->status.as<unsigned long long>() + ST_OVERFLOW, sizeof(ov),
                         hipMemcpyDeviceToHost, st));

@@ -128,6 +128,7 @@ struct amg_ctx {
   DevBuf tok_node;   // int32[n_tokens]  node id, -1 no window, -2 removed
   DevBuf tok_dir;    // int8 [n_tokens]
   DevBuf tok_pair;   // int32[n_tokens]  edge-class slot (then id) of the adjacency t -> t+1
+  bool packed_nodes = false;  // node slots rewritten as packed {id, tuple} records (amg_device.h)
   bool count_inline = false;  // true: count by one global atomic per window (merge path)
   // nodes (id order)
   DevBuf node_tokens;  // int32[n_nodes * k]
