@@ -72,6 +72,10 @@ class GeneMerGraph:
         self._vocab, toks, offs, self._read_ids = tokenize(readDict)
         self._read_off = offs
         self._read_index = {r: i for i, r in enumerate(self._read_ids)}
+        if kmerSize < 1 and len(toks) == 0:
+            kmerSize_dev = 1  # GeneMerGraph({}, 0) is legal in the reference: nothing to build
+        else:
+            kmerSize_dev = kmerSize
         self._engine.set_reads(toks, offs, self._vocab.two_v)
         self._tokens = toks
         self._gs = self._ge = None
@@ -88,7 +92,7 @@ class GeneMerGraph:
             self._gs, self._ge = gs, ge
             self._engine.set_positions(gs, ge, None)
         try:
-            self._engine.build(kmerSize)
+            self._engine.build(kmerSize_dev)
         except _ffi.AmgError as err:
             if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
                 raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None

@@ -1,0 +1,88 @@
+"""Host-side API of the HIP-backed GeneMerGraph against the CPU oracle on real fixtures:
+topology queries, linear paths, unitig gene strings, gene lookups, single-node removal."""
+import pytest
+
+import dump as D
+import procedures as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name, k, with_pos=True):
+    from amira_amd import GeneMerGraph as Product
+    from amira_oracle import GeneMerGraph as Oracle
+    calls, pos = P.fixture(name)
+    mk = lambda cls: cls(dict(calls), k, {r: list(v) for r, v in pos.items()} if with_pos else None)
+    return mk(Product), mk(Oracle)
+
+
+@pytest.mark.parametrize("name,k", [("eight", 3), ("nine", 5), ("seven", 3)])
+def test_topology_and_path_queries(name, k):
+    p, o = _pair(name, k)
+    assert list(p.get_nodes()) == list(o.get_nodes())
+    assert list(p.get_edges()) == list(o.get_edges())
+    assert p.components() == o.components() and p.get_number_of_component() == o.get_number_of_component()
+    assert p.get_mean_node_coverage() == o.get_mean_node_coverage()
+    assert p.get_all_node_coverages() == o.get_all_node_coverages()
+    hashes = list(o.get_nodes())
+    for h in hashes[:150] + hashes[-50:]:
+        pn, on = p.get_node_by_hash(h), o.get_node_by_hash(h)
+        assert p.get_degree(pn) == o.get_degree(on)
+        assert [n.__hash__() for n in p.get_forward_neighbors(pn)] == [n.__hash__() for n in o.get_forward_neighbors(on)]
+        assert [n.__hash__() for n in p.get_backward_neighbors(pn)] == [n.__hash__() for n in o.get_backward_neighbors(on)]
+        assert p.get_all_neighbor_hashes(pn) == o.get_all_neighbor_hashes(on)
+        assert p.get_gene_mer_label(pn) == o.get_gene_mer_label(on)
+        assert p.get_reverse_gene_mer_genes(pn) == o.get_reverse_gene_mer_genes(on)
+        lp, lo = p.get_linear_path_for_node(pn), o.get_linear_path_for_node(on)
+        assert lp == lo
+        assert p.get_linear_path_for_node(pn, True) == o.get_linear_path_for_node(on, True)
+        if 1 < len(lo) <= 30:
+            assert p.get_genes_in_unitig(lp) == o.get_genes_in_unitig(lo)
+        for nb in o.get_all_neighbors(on)[:2]:
+            pnb = p.get_node_by_hash(nb.__hash__())
+            assert p.check_if_nodes_are_adjacent(pn, pnb) == o.check_if_nodes_are_adjacent(on, nb)
+            if nb.__hash__() != h:
+                assert p.get_edge_hashes_between_nodes(pn, pnb) == o.get_edge_hashes_between_nodes(on, nb)
+    for deg in (1, 2, 3):
+        assert [n.__hash__() for n in p.get_nodes_with_degree(deg)] == [n.__hash__() for n in o.get_nodes_with_degree(deg)]
+    for c in o.components()[:3]:
+        assert [n.__hash__() for n in p.get_nodes_in_component(c)] == [n.__hash__() for n in o.get_nodes_in_component(c)]
+    some_reads = list(o.get_readNodes())[:40]
+    for r in some_reads:
+        assert [n.__hash__() for n in p.get_nodes_containing_read(r)] == [n.__hash__() for n in o.get_nodes_containing_read(r)]
+    genes = sorted({g[1:] for r in some_reads for g in o.get_reads()[r]})[:8]
+    for g in genes:
+        assert [n.__hash__() for n in p.get_nodes_containing(g)] == [n.__hash__() for n in o.get_nodes_containing(g)]
+    assert set(p.get_AMR_nodes(genes)) == set(o.get_AMR_nodes(genes))
+    assert p.collect_reads_in_path(hashes[:20]) == o.collect_reads_in_path(hashes[:20])
+    assert p.get_reads_for_nodes(hashes[:20]) == o.get_reads_for_nodes(hashes[:20])
+
+
+def test_remove_node_and_friends():
+    p, o = _pair("eight", 3)
+    victims = list(o.get_nodes())[5:60:7]
+    for h in victims:
+        p.remove_node(p.get_node_by_hash(h))
+        o.remove_node(o.get_node_by_hash(h))
+    assert D.dump_graph(p) == D.dump_graph(o)
+    assert p.get_reads_to_correct() == o.get_reads_to_correct()
+    assert p.get_valid_reads_only() == o.get_valid_reads_only()
+    assert p.remove_junk_reads(0.8) == o.remove_junk_reads(0.8)
+    # and the passes after manual removals behave identically
+    assert sorted(p.remove_short_linear_paths(3)) == sorted(o.remove_short_linear_paths(3))
+    assert D.dump_graph(p) == D.dump_graph(o)
+    fq = P.FakeFastq({r: 10 ** 6 for r in o.get_reads()})
+    pg, pp = p.correct_reads(fq)
+    og, op = o.correct_reads(fq)
+    assert D.dump_corrected(pg, pp) == D.dump_corrected(og, op)
+
+
+def test_empty_and_degenerate_graphs():
+    from amira_amd import GeneMerGraph
+    g = GeneMerGraph({}, 0)
+    assert g.get_reads() == {} and g.get_kmerSize() == 0 and g.get_minNodeCoverage() == 1
+    assert g.get_nodes() == {} and g.get_edges() == {} and g.get_minEdgeCoverage() == 1
+    g = GeneMerGraph({"a": [], "b": ["+x"]}, 3)
+    assert g.get_nodes() == {} and g.get_short_read_annotations() == {"a": [], "b": ["+x"]}
+    assert g.components() == [] and g.correct_reads({}) == ({}, {})
+    assert g.filter_graph(3, 1) is g and g.get_total_number_of_reads() == 2
