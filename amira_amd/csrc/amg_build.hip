@@ -241,7 +241,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
       const uint4* rec = reinterpret_cast<const uint4*>(node_tab + ((unsigned int)raw & ~AMG_LAST_FLAG));
       const uint4 lo = rec[0], hi = rec[1];
       id = (int)hi.y;
-      if (verify && i < TILE) {
+      if (verify && i < TILE && id >= 0) {
         const int* w = tokens + t;
         bool same = true;
         for (int j = 0; j < k; ++j) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
       }
     } else if (raw != -1) {
       id = node_tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
-      if (verify && i < TILE) {
+      if (verify && i < TILE && id >= 0) {
         // exact check: the window's canonical tuple must equal the node's tuple
         const int* w = tokens + t;
         const int* nt = node_tokens + (long long)id * k;
@@ -278,7 +278,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges(
       if (tok_pair && t0 + i < n_tokens) tok_pair[t0 + i] = -1;
       continue;
     }
-    // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
+    // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read.  (ids < 0 only in a
+    // merged build with a fused coverage filter: the node was dropped, no edge is recorded)
+    if (s_id[i] < 0 || s_id[i + 1] < 0) {
+      if (tok_pair && t0 + i < n_tokens) tok_pair[t0 + i] = -1;
+      continue;
+    }
     unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
     int dA = s_dir[i], dB = s_dir[i + 1];
     unsigned int lo = a < b ? a : b, hi = a < b ? b : a;

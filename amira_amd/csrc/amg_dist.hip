@@ -42,6 +42,13 @@ extern "C" int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* ed
   return AMG_OK;
 }
 
+extern "C" int amg_dist_set_filter(amg_ctx* c, uint32_t min_node_cov, uint32_t min_edge_cov) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  c->dist_min_node = min_node_cov < 1 ? 1 : min_node_cov;
+  c->dist_min_edge = min_edge_cov < 1 ? 1 : min_edge_cov;
+  return AMG_OK;
+}
+
 __device__ __forceinline__ unsigned int owner_of(unsigned long long key, unsigned int world) {
   return (unsigned int)(mix64(key ^ 0x5851F42D4C957F2Dull) % world);
 }
@@ -166,11 +173,28 @@ __global__ void k_rec_keys(const unsigned char* __restrict__ recs, long long n, 
   idx[i] = (unsigned int)i;
 }
 
-__global__ void k_run_heads(const unsigned long long* __restrict__ keys_sorted, long long n,
-                            unsigned int* __restrict__ head) {
+// head[i] = 1 for the first record of a run of equal keys whose reduced coverage reaches
+// min_cov (edge classes that are self-loops count twice)
+__global__ void k_run_heads(const unsigned char* __restrict__ recs, int rec_bytes, int is_edge,
+                            const unsigned long long* __restrict__ keys_sorted,
+                            const unsigned int* __restrict__ idx_sorted, long long n,
+                            unsigned int min_cov, unsigned int* __restrict__ head) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  head[i] = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1u : 0u;
+  unsigned int h = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1u : 0u;
+  if (h && min_cov > 1) {
+    const unsigned long long key = keys_sorted[i];
+    unsigned long long total = 0;
+    for (long long j = i; j < n && keys_sorted[j] == key; ++j)
+      total += *reinterpret_cast<const unsigned int*>(recs + (size_t)idx_sorted[j] * rec_bytes + 16);
+    if (is_edge) {
+      unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
+      unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
+      if (lo == hi) total *= 2;
+    }
+    if (total < min_cov) h = 0;
+  }
+  head[i] = h;
 }
 
 __global__ void k_reduce_runs(const unsigned char* __restrict__ recs, int rec_bytes, int tok_words,
@@ -208,7 +232,7 @@ __global__ void k_reduce_runs(const unsigned char* __restrict__ recs, int rec_by
 }
 
 static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_bytes, int tok_words,
-                          DevBuf& owned, int64_t* n_owned) {
+                          unsigned int min_cov, DevBuf& owned, int64_t* n_owned) {
   hipStream_t st = c->stream;
   *n_owned = 0;
   if (n == 0) return AMG_OK;
@@ -224,7 +248,8 @@ static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_byt
                            c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, 64));
   long long* pos = c->s5.as<long long>();
   unsigned int* head = reinterpret_cast<unsigned int*>(pos + (n + 2));
-  hipLaunchKernelGGL(k_run_heads, dim3(nblk(n, 256)), dim3(256), 0, st, c->s2.as<unsigned long long>(), n, head);
+  hipLaunchKernelGGL(k_run_heads, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rec_bytes, tok_words == 0 ? 1 : 0,
+                     c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), n, min_cov, head);
   HIPCHK(hipMemsetAsync(head + n, 0, sizeof(unsigned int), st));
   AMGCHK(prim_exscan_u32_to_i64(c, head, pos, (size_t)n + 1));
   long long total = 0;
@@ -247,7 +272,8 @@ static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_byt
 extern "C" int amg_dist_nodes_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
   NEED_CTX(c);
   if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
-  int r = reduce_records(c, recv_buf, n_recv, (int)node_rec_bytes(c->k), c->k, c->dist_owned, n_owned);
+  int r = reduce_records(c, recv_buf, n_recv, (int)node_rec_bytes(c->k), c->k, c->dist_min_node,
+                         c->dist_owned, n_owned);
   c->n_owned = *n_owned;
   return r;
 }
@@ -307,7 +333,7 @@ __global__ void k_global_nodes(const unsigned char* __restrict__ recs, int rec_b
 // local table slot -> global node id (looked up by key)
 __global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_slots,
                                   const Slot* __restrict__ gtab, unsigned long long gmask,
-                                  const int* __restrict__ node_tokens, int k, int packed,
+                                  const int* __restrict__ node_tokens, int k, int packed, int allow_missing,
                                   unsigned long long* status) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_slots) return;
@@ -326,6 +352,16 @@ __global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_
     }
     if (cur == 0ull) break;
     s = (s + 1) & gmask;
+  }
+  if (allow_missing) {
+    // the node did not reach the fused coverage threshold: its windows become None (-2)
+    if (packed) {
+      int none[AMG_MAX_K] = {0};
+      slot_pack(ltab + i, -2, none, k);
+    } else {
+      ltab[i].id = -2;
+    }
+    return;
   }
   status[ST_OVERFLOW] = 5;  // local key missing from the global table
 }
@@ -363,7 +399,8 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
   hipLaunchKernelGGL(k_local_to_global, dim3(nblk(c->node_slots, 256)), dim3(256), 0, st,
                      c->node_tab.as<Slot>(), (unsigned long long)c->node_slots, c->dist_gtab.as<Slot>(),
                      (unsigned long long)(gslots - 1), c->node_tokens.as<int>(), c->k,
-                     c->packed_nodes ? 1 : 0, c->status.as<unsigned long long>());
+                     c->packed_nodes ? 1 : 0, c->dist_min_node > 1 ? 1 : 0,
+                     c->status.as<unsigned long long>());
   unsigned long long ov = 0;
   HIPCHK(hipMemcpyAsync(&ov, c->status.as<unsigned long long>() + ST_OVERFLOW, sizeof(ov),
                         hipMemcpyDeviceToHost, st));
@@ -457,7 +494,7 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
 extern "C" int amg_dist_edges_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
   NEED_CTX(c);
   if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
-  int r = reduce_records(c, recv_buf, n_recv, EDGE_REC_BYTES, 0, c->dist_owned, n_owned);
+  int r = reduce_records(c, recv_buf, n_recv, EDGE_REC_BYTES, 0, c->dist_min_edge, c->dist_owned, n_owned);
   c->n_owned = *n_owned;
   return r;
 }
@@ -471,6 +508,17 @@ extern "C" int amg_dist_edges_owned(amg_ctx* c, void* out) {
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   return AMG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_flag_dead_reads(const int* __restrict__ tok_node,
+                                                          const long long* __restrict__ read_off,
+                                                          long long n_reads, unsigned char* __restrict__ read_fix) {
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_reads) return;
+  const int lane = threadIdx.x & 63;
+  bool hit = false;
+  for (long long t = read_off[r] + lane; t < read_off[r + 1]; t += 64) hit = hit || (tok_node[t] == -2);
+  if (__any(hit) && lane == 0) read_fix[r] = 1;
 }
 
 __global__ void k_global_pairs(const unsigned char* __restrict__ recs, const unsigned int* __restrict__ idx_sorted,
@@ -505,6 +553,13 @@ extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_
                        c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
   }
   AMGCHK(bs_finish_from_pairs(c));
+  if (c->dist_min_node > 1 && c->n_reads > 0) {
+    // fused filter: reads that lost a node join _readsToCorrect (remove_node_from_reads :442-461)
+    hipLaunchKernelGGL(k_flag_dead_reads, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, c->tok_node.as<int>(),
+                       c->read_off.as<long long>(), c->n_reads, c->read_fix.as<unsigned char>());
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  c->dist_min_node = c->dist_min_edge = 1;
   c->built = true;
   c->node_hint = c->n_local_nodes > 256 ? c->n_local_nodes : 256;
   return AMG_OK;

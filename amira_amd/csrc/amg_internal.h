@@ -164,6 +164,7 @@ struct amg_ctx {
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
   int64_t n_owned = 0;
+  uint32_t dist_min_node = 1, dist_min_edge = 1;  // fused filter of the next merged build
   DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab;
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)

@@ -13,11 +13,13 @@ driver `dist_build_loopback` that tests use to emulate W ranks on one GPU.
 import torch
 
 
-def steps(engine, k, world, rank, token_base, token_total):
-    """yield ("a2a", send_tensor, send_counts, rec_bytes) -> (recv_tensor, n_recv)
+def steps(engine, k, world, rank, token_base, token_total, min_node_cov=1, min_edge_cov=1):
+    """min_node_cov / min_edge_cov > 1 fuse filter_graph into the merge (amg_dist_set_filter).
+       yield ("a2a", send_tensor, send_counts, rec_bytes) -> (recv_tensor, n_recv)
        yield ("ag", owned_tensor, n_owned, rec_bytes)      -> (all_tensor, n_total)"""
     node_bytes, edge_bytes = engine.dist_record_bytes(k)
     dev = torch.device("cuda", engine.device)
+    engine.dist_set_filter(min_node_cov, min_edge_cov)
     for what, rec_bytes in (("nodes", node_bytes), ("edges", edge_bytes)):
         if what == "nodes":
             send_counts = engine.dist_nodes_local(k, token_base, token_total, world)
@@ -70,7 +72,7 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     return everything.contiguous(), total
 
 
-def dist_build(engine, k, group=None):
+def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
     """Collective: call on every rank with its own engine (reads already set)."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -79,7 +81,7 @@ def dist_build(engine, k, group=None):
     gathered = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(gathered, n_local, group=group)
     tokens = gathered.tolist()
-    gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens))
+    gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens), min_node_cov, min_edge_cov)
     reply = None
     while True:
         try:
@@ -90,12 +92,13 @@ def dist_build(engine, k, group=None):
         torch.cuda.current_stream(dev).synchronize()
 
 
-def dist_build_loopback(engines, k):
+def dist_build_loopback(engines, k, min_node_cov=1, min_edge_cov=1):
     """Emulate len(engines) ranks in ONE process (tests on a single GPU): the exchanges are
     plain tensor copies, the device phases are exactly those of dist_build."""
     world = len(engines)
     tokens = [e.counts()["n_tokens"] for e in engines]
-    gens = [steps(e, k, world, r, sum(tokens[:r]), sum(tokens)) for r, e in enumerate(engines)]
+    gens = [steps(e, k, world, r, sum(tokens[:r]), sum(tokens), min_node_cov, min_edge_cov)
+            for r, e in enumerate(engines)]
     replies = [None] * world
     while True:
         reqs = []

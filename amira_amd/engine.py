@@ -185,6 +185,9 @@ class Engine:
         check(_ffi.lib.amg_dist_record_bytes(int(k), C.byref(nb), C.byref(eb)))
         return nb.value, eb.value
 
+    def dist_set_filter(self, min_node_cov, min_edge_cov):
+        check(_ffi.lib.amg_dist_set_filter(self._h, int(min_node_cov), int(min_edge_cov)))
+
     def dist_nodes_local(self, k, token_base, token_total, world):
         counts = np.zeros(world, np.int64)
         check(_ffi.lib.amg_dist_nodes_local(self._h, int(k), int(token_base), int(token_total),

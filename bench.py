@@ -140,9 +140,11 @@ def main():
     from amira_amd.dist import dist_build
     merge = world > 1 and not args.no_merge
 
-    def build():
+    def build(fused_filter=None):
         if merge:
-            dist_build(eng, k)
+            # first build of the sweep: filter_graph(3,1) is fused into the merge so that the
+            # low-coverage nodes (90 % of an uncorrected graph) are never replicated
+            dist_build(eng, k, None, *(fused_filter or (1, 1)))
         else:
             eng.build(k)
 
@@ -173,12 +175,13 @@ def main():
         eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v)
         if w["sweep"]:
             eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr())
-        build()
+        build((3, 1) if w["sweep"] else None)
         if record:
             tally()
         if not w["sweep"]:
             return
-        eng.filter(3, 1)
+        if not merge:
+            eng.filter(3, 1)
         if record:
             tally()
             info["marked_reads"] = eng.counts()["n_reads_to_correct"] if "marked_reads" not in info else info["marked_reads"]

@@ -177,6 +177,14 @@ int amg_match_patterns(amg_ctx* ctx, int which, const int32_t* pat, const int64_
  *      all_to_all_single / all_gather on the device pointers below), see amira_amd/dist.py.
  *      All buffers here are DEVICE pointers.  Record sizes: amg_dist_record_bytes. ------- */
 int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes);
+/* Optional: fuse filter_graph(min_node_cov, min_edge_cov) (construct_graph.py:523-540) into
+ * the NEXT merged build.  Owners then keep only nodes / edge classes that reach the thresholds,
+ * so the (often 10x larger) set of low-coverage nodes is never replicated.  The resulting
+ * state equals amg_dist build followed by amg_filter for everything the correction reads
+ * (live nodes and edges, their coverages and list orders, masked windows, reads to correct);
+ * ids number the surviving nodes / edges only and component ids are those of the filtered
+ * graph.  Thresholds reset to (1, 1) = keep everything after the build. */
+int amg_dist_set_filter(amg_ctx* ctx, uint32_t min_node_cov, uint32_t min_edge_cov);
 /* local node table of this shard; token_base = global index of the shard's first token,
  * token_total = tokens over all shards; send_counts[world] = records per destination rank */
 int amg_dist_nodes_local(amg_ctx* ctx, int32_t k, int64_t token_base, int64_t token_total,

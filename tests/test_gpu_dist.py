@@ -158,3 +158,85 @@ def test_dist_build_over_rccl_world1():
         eng.close(); ref.close()
     finally:
         dist.destroy_process_group()
+
+
+def live_state(eng):
+    """graph restricted to live nodes / edges with dense renumbering (component ids left out:
+    a fused-filter build labels the components of the FILTERED graph)."""
+    n, e = eng.nodes(), eng.edges()
+    off, adj = eng.node_adj()
+    nk, ek = n["alive"] != 0, e["alive"] != 0
+    nmap, emap = np.cumsum(nk) - 1, np.cumsum(ek) - 1
+    rows = csr_lists(off, adj, e["alive"])
+    tok_node, tok_dir = eng.read_nodes()
+    mapped = tok_node.copy()
+    m = tok_node >= 0
+    mapped[m] = nmap[tok_node[m]]
+    return {"tokens": n["tokens"][nk], "coverage": n["coverage"][nk], "first_dir": n["first_dir"][nk],
+            "src": nmap[e["src"][ek]], "tgt": nmap[e["tgt"][ek]], "sdir": e["sdir"][ek], "tdir": e["tdir"][ek],
+            "ecov": e["coverage"][ek],
+            "adj": [[int(emap[x]) for x in rows[r]] for i in np.nonzero(nk)[0] for r in (2 * i, 2 * i + 1)],
+            "tok_node": mapped, "tok_dir": np.where(m, tok_dir, 0), "to_correct": eng.reads_to_correct()}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("thr", [(3, 1), (2, 2)])
+def test_fused_filter_merge_equals_build_then_filter(world, thr):
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    reads, _, _ = P.synth_inputs(17, 800, 40, 150, 0.05)
+    k = 5
+    vocab, toks, offs, _ = tokenize(reads)
+    ref = Engine(0)
+    ref.set_reads(toks, offs, vocab.two_v)
+    ref.build(k)
+    ref.filter(*thr)
+    want = live_state(ref)
+    engines = []
+    for t, o, lo, hi in make_shards(toks, offs, world):
+        e = Engine(0)
+        e.set_reads(t, o, vocab.two_v)
+        engines.append(e)
+    dist_build_loopback(engines, k, *thr)
+    bounds = shard_bounds(len(offs) - 1, world)
+    for r, e in enumerate(engines):
+        got = live_state(e)
+        lo, hi = bounds[r], bounds[r + 1]
+        for key in ("tokens", "coverage", "first_dir", "src", "tgt", "sdir", "tdir", "ecov"):
+            assert np.array_equal(got[key], want[key]), key
+        assert got["adj"] == want["adj"]
+        assert np.array_equal(got["tok_node"], want["tok_node"][offs[lo]:offs[hi]])
+        assert np.array_equal(got["tok_dir"], want["tok_dir"][offs[lo]:offs[hi]])
+        assert np.array_equal(got["to_correct"], want["to_correct"][lo:hi])
+        assert e.counts()["n_nodes"] == len(want["coverage"])  # only survivors were replicated
+    for e in engines + [ref]:
+        e.close()
+
+
+def test_sharded_sweep_with_fused_first_filter():
+    """the bench's N > 1 sweep: first build merged WITH filter_graph(3,1) fused in"""
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    k, world = 5, 3
+    vocab, toks, offs, read_ids = tokenize(reads)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+    single = Engine(0)
+    single.set_reads(toks, offs, vocab.two_v)
+    single.set_positions(gs, ge, rl)
+    single.build(k); single.filter(3, 1)
+    want = single.corrected(*single.correct_reads(), True)
+    engines, bounds = [], shard_bounds(len(read_ids), world)
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        e = Engine(0)
+        e.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
+        e.set_positions(gs[offs[lo]:offs[hi]], ge[offs[lo]:offs[hi]], rl[lo:hi])
+        engines.append(e)
+    dist_build_loopback(engines, k, 3, 1)
+    got = [e.corrected(*e.correct_reads(), True) for e in engines]
+    for key in ("tokens", "gene_start", "gene_end", "changed"):
+        assert np.array_equal(np.concatenate([o[key] for o in got]), want[key]), key
+    for e in engines + [single]:
+        e.close()
