@@ -64,7 +64,24 @@ __global__ void k_dist_node_dest(const unsigned int* __restrict__ slots, long lo
   unsigned int d = owner_of(tab[slots[i]].key, world);
   dest[i] = d;
   idx[i] = (unsigned int)i;
-  atomicAdd(&counts[d], 1ull);
+  (void)counts;  // per-destination counts come from the sorted array (k_dest_counts): millions of
+                 // atomics on `world` addresses would serialise
+}
+
+// counts[d] = number of entries equal to d in the ascending array dest_sorted[0..n)
+__global__ void k_dest_counts(const unsigned int* __restrict__ dest_sorted, long long n, unsigned int world,
+                              unsigned long long* __restrict__ counts) {
+  unsigned int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= world) return;
+  auto lower = [&](unsigned int v) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+      long long mid = (lo + hi) >> 1;
+      if (dest_sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  counts[d] = (unsigned long long)(lower(d + 1) - lower(d));
 }
 
 __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long long n,
@@ -138,6 +155,8 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
                        c->dist_slot.as<unsigned int>(), n, c->node_tab.as<Slot>(), (unsigned int)world,
                        dest, idx, c->dist_cnt.as<unsigned long long>());
     AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
+                       c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
   HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
@@ -419,7 +438,7 @@ __global__ void k_dist_edge_dest(const unsigned int* __restrict__ slots, long lo
   unsigned int d = owner_of(tab[slots[i]].key, world);
   dest[i] = d;
   idx[i] = (unsigned int)i;
-  atomicAdd(&counts[d], 1ull);
+  (void)counts;
 }
 
 __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long long n,
@@ -469,6 +488,8 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
                        c->dist_slot.as<unsigned int>(), n, c->edge_tab.as<Slot>(), (unsigned int)world,
                        dest, idx, c->dist_cnt.as<unsigned long long>());
     AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
+                       c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
   HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
