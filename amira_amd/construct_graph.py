@@ -24,6 +24,7 @@ clustering).
 import os
 import statistics
 import sys
+from collections.abc import Mapping
 from itertools import product
 
 import numpy as np
@@ -47,6 +48,55 @@ from .path_finding_utils import (
 from .tokens import tokenize
 
 sys.setrecursionlimit(50000)  # construct_graph.py:27
+
+
+class _LazyReadLists(Mapping):
+    """dict-like {read id: per-window list} whose lists are built from the device arrays the
+    first time a read is looked up (read-path clustering touches a few thousand of millions)."""
+
+    def __init__(self, read_ids, index, make):
+        self._ids, self._index, self._make, self._cache = read_ids, index, make, {}
+
+    def __getitem__(self, rid):
+        got = self._cache.get(rid)
+        if got is None:
+            r = self._index.get(rid)
+            if r is None:
+                raise KeyError(rid)
+            got = self._cache[rid] = self._make(r)
+        return got
+
+    def __setitem__(self, rid, value):  # remove_node_from_reads-style updates by callers
+        if rid not in self._index:
+            raise KeyError(rid)
+        self._cache[rid] = value
+
+    def __iter__(self):
+        return iter(self._ids)
+
+    def __len__(self):
+        return len(self._ids)
+
+    def __contains__(self, rid):
+        return rid in self._index
+
+
+class _GraphNode(Node):
+    """Node view whose read list is cut out of the device's node->reads CSR on first use."""
+
+    def _lazy(self, maker):
+        self._reads_maker = maker
+        self._reads_list = None
+
+    @property
+    def listOfReads(self):
+        if self._reads_list is None:
+            self._reads_list = self._reads_maker() if getattr(self, "_reads_maker", None) else []
+        return self._reads_list
+
+    @listOfReads.setter
+    def listOfReads(self, value):
+        self._reads_list = value
 
 
 class _View:
@@ -138,10 +188,10 @@ class GeneMerGraph:
             canon = [self._gene_obj(t) for t in toks]
             rc = [self._gene_obj(vocab.flip(t)) for t in reversed(toks)]
             h = self._hash_of_tokens(toks)
-            node = Node(GeneMer._from_parts(canon, rc, int(nodes["first_dir"][i]), h))
+            node = _GraphNode(GeneMer._from_parts(canon, rc, int(nodes["first_dir"][i]), h))
             node.nodeCoverage = int(nodes["coverage"][i])
             node._component_ID = int(nodes["component"][i])
-            node.listOfReads = [read_ids[r] for r in nr_idx[nr_off[i]:nr_off[i + 1]].tolist()]
+            node._lazy(lambda a=int(nr_off[i]), b=int(nr_off[i + 1]): [read_ids[r] for r in nr_idx[a:b].tolist()])
             node._amg_id = i
             v.node_hash[i] = h
             v.nodes[h] = node
@@ -167,21 +217,32 @@ class GeneMerGraph:
                                       if edges["alive"][e]]
             node.backwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i + 1]:adj_off[2 * i + 2]].tolist()
                                        if edges["alive"][e]]
-        v.readNodes, v.readNodeDirections, v.readNodePositions = {}, {}, {}
         offs, nh = self._read_off, v.node_hash
-        for r, rid in enumerate(read_ids):
+        with_windows = [rid for r, rid in enumerate(read_ids) if offs[r + 1] - offs[r] >= k]
+        index = {rid: self._read_index[rid] for rid in with_windows}
+
+        def window_ids(r):
             a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
-            if n <= 0:
-                continue
-            ids = tok_node[a:a + n].tolist()
-            v.readNodes[rid] = [nh[x] if x >= 0 else None for x in ids]
-            dirs = tok_dir[a:a + n].tolist()
-            v.readNodeDirections[rid] = [d if x >= 0 else None for d, x in zip(dirs, ids)]
-            if self._gs is not None:
-                s, e = self._gs[a:a + n].tolist(), self._ge[a + k - 1:a + k - 1 + n].tolist()
-                v.readNodePositions[rid] = [(s[j], e[j]) if ids[j] >= 0 else None for j in range(n)]
-            else:
-                v.readNodePositions[rid] = [None] * n
+            return a, n, tok_node[a:a + n].tolist()
+
+        def make_nodes(r):
+            _, _, ids = window_ids(r)
+            return [nh[x] if x >= 0 else None for x in ids]
+
+        def make_dirs(r):
+            a, n, ids = window_ids(r)
+            return [d if x >= 0 else None for d, x in zip(tok_dir[a:a + n].tolist(), ids)]
+
+        def make_positions(r):
+            a, n, ids = window_ids(r)
+            if self._gs is None:
+                return [None] * n
+            s, e = self._gs[a:a + n].tolist(), self._ge[a + k - 1:a + k - 1 + n].tolist()
+            return [(s[j], e[j]) if ids[j] >= 0 else None for j in range(n)]
+
+        v.readNodes = _LazyReadLists(with_windows, index, make_nodes)
+        v.readNodeDirections = _LazyReadLists(with_windows, index, make_dirs)
+        v.readNodePositions = _LazyReadLists(with_windows, index, make_positions)
         self._view = v
         return v
 

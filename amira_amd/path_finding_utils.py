@@ -48,6 +48,8 @@ Tree = _ExternalTree or _ScanTree
 
 
 def _suffix_ints(path):
+    if isinstance(path, _Suffix):  # our own tree: no need to print and re-parse the suffix
+        return None if path.items[0] is None else list(path.items)
     parts = str(path).split(" ")
     if parts[0] == "None":
         return None
