@@ -94,7 +94,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,
                    &c->edge_src,  &c->edge_tgt,  &c->edge_sdir,  &c->edge_tdir, &c->edge_cov,
-                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
+                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp,   &c->s0, &c->s1, &c->s2, &c->s3,
                    &c->s4, &c->s5};

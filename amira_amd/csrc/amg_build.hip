@@ -483,6 +483,29 @@ __global__ void k_set_pair_ids(const unsigned int* __restrict__ slot_sorted, lon
   if (i < n_pairs) edge_tab[slot_sorted[i]].id = (int)i;
 }
 
+__global__ void k_slots_to_ids(const int* __restrict__ slots, long long n, const Slot* __restrict__ tab,
+                               int* __restrict__ ids) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int raw = slots[t];
+  ids[t] = raw == -1 ? -1 : tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
+}
+
+// Occurrences per table entry without per-window atomics, for the merge path: entries get
+// dense ids in first-seen order (slot_sorted), the per-window slots are turned into ids
+// (ids_scratch may alias slots) and counted by k_count_ids.  out[i] = count of entry i.
+int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
+                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out) {
+  hipStream_t st = c->stream;
+  if (n_ids > 0)
+    hipLaunchKernelGGL(k_set_pair_ids, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, st, slot_sorted,
+                       n_ids, tab);
+  if (n > 0)
+    hipLaunchKernelGGL(k_slots_to_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slots, n, tab,
+                       ids_scratch);
+  return count_ids(c, ids_scratch, n, nullptr, n_ids, out);
+}
+
 // ------------------------------------------------------------------ host orchestration
 // The build is split into stages so that the multi-GPU path (amg_dist.hip) can put its
 // exchanges between them:
@@ -653,7 +676,7 @@ int bs_edges_pass(amg_ctx* c, int* which) {
     return AMG_E_OVERFLOW;
   }
   c->n_local_pairs = (int64_t)hs[ST_COMPACT_B];
-  if (!c->count_inline) {
+  if (!c->count_inline && !c->dist_mode) {
     // node coverage (construct_node.py:33-36) from the per-window node ids
     stage_begin(c, "node_count");
     AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>()));
@@ -814,6 +837,7 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   c->retries = 0;
   c->tok_base = 0;
   c->tok_total = c->n_tokens;
+  c->dist_mode = false;
   {
     const char* e = getenv("AMG_COUNT_INLINE");  // A/B switch: 1 = one global atomic per window
     c->count_inline = e && e[0] == '1';

@@ -87,7 +87,8 @@ __global__ void k_dest_counts(const unsigned int* __restrict__ dest_sorted, long
 __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long long n,
                                  const unsigned int* __restrict__ slots,
                                  const unsigned long long* __restrict__ firsts,
-                                 const Slot* __restrict__ tab, const int* __restrict__ tokens, int k,
+                                 const Slot* __restrict__ tab, const unsigned int* __restrict__ lcnt,
+                                 const int* __restrict__ tokens, int k,
                                  int two_v, long long tok_base, unsigned char* __restrict__ out,
                                  int rec_bytes) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,7 +101,7 @@ __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long lo
   q[0] = s->key;
   q[1] = first;
   unsigned int* u = reinterpret_cast<unsigned int*>(rec + 16);
-  u[0] = s->count;
+  u[0] = lcnt[s->id];  // s->id is still the LOCAL first-seen rank here
   u[1] = (unsigned int)k;
   int* tk = reinterpret_cast<int*>(rec + 24);
   long long t = (long long)(first >> 1) - tok_base;
@@ -124,7 +125,8 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   c->tok_base = token_base;
   c->tok_total = token_total;
   c->world = world;
-  c->count_inline = true;  // the records exchanged between ranks carry the local counts
+  c->dist_mode = true;
+  c->count_inline = false;  // local occurrence counts come from bs_count_by_slot, not per-window atomics
   bs_size_tables(c);
   for (int attempt = 0;; ++attempt) {
     int which = 0;
@@ -136,6 +138,17 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   }
   // compaction list lives in s1 (first) / s3 (slot); destination order -> dist_order
   const long long n = c->n_local_nodes;
+  {
+    // local occurrence counts: rank the local nodes by first-seen (hot nodes get low ids),
+    // count through LDS (tok_node is free scratch until the edge pass writes it)
+    int first_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 2 + 2) + 1;
+    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, first_bits));
+    AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+    AMGCHK(bs_count_by_slot(c, c->tok_slot.as<int>(), c->tok_node.as<int>(), c->n_tokens,
+                            c->node_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
+                            c->dist_lcnt.as<unsigned int>()));
+  }
   AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
   unsigned int* dest = c->dist_a.as<unsigned int>();
   unsigned int* idx = dest + (n + 1);
@@ -174,7 +187,8 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
   unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
   hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                      c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
-                     c->node_tab.as<Slot>(), c->tokens.as<int>(), c->k, c->two_v, (long long)c->tok_base,
+                     c->node_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(), c->tokens.as<int>(), c->k,
+                     c->two_v, (long long)c->tok_base,
                      reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
   HIPCHK(hipStreamSynchronize(c->stream));
   return AMG_OK;
@@ -444,7 +458,8 @@ __global__ void k_dist_edge_dest(const unsigned int* __restrict__ slots, long lo
 __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long long n,
                                  const unsigned int* __restrict__ slots,
                                  const unsigned long long* __restrict__ firsts,
-                                 const Slot* __restrict__ tab, unsigned char* __restrict__ out) {
+                                 const Slot* __restrict__ tab, const unsigned int* __restrict__ lcnt,
+                                 unsigned char* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   unsigned int i = order[j];
@@ -452,7 +467,7 @@ __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long lo
   unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
   q[0] = s->key;
   q[1] = firsts[i];
-  q[2] = (unsigned long long)s->count;
+  q[2] = (unsigned long long)lcnt[s->id];
 }
 
 extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_counts) {
@@ -471,6 +486,15 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
     c->edge_slots *= 4;
   }
   const long long n = c->n_local_pairs;
+  {
+    int efirst_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 8 + 8) + 1;
+    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
+                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, efirst_bits));
+    AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+    AMGCHK(bs_count_by_slot(c, c->tok_pair.as<int>(), c->tok_pair.as<int>(), c->n_tokens,
+                            c->edge_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
+                            c->dist_lcnt.as<unsigned int>()));
+  }
   AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
   unsigned int* dest = c->dist_a.as<unsigned int>();
   unsigned int* idx = dest + (n + 1);
@@ -507,7 +531,8 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
   unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
   hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                      c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
-                     c->edge_tab.as<Slot>(), reinterpret_cast<unsigned char*>(send_buf));
+                     c->edge_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(),
+                     reinterpret_cast<unsigned char*>(send_buf));
   HIPCHK(hipStreamSynchronize(c->stream));
   return AMG_OK;
 }

@@ -129,6 +129,7 @@ struct amg_ctx {
   DevBuf tok_dir;    // int8 [n_tokens]
   DevBuf tok_pair;   // int32[n_tokens]  edge-class slot (then id) of the adjacency t -> t+1
   bool packed_nodes = false;  // node slots rewritten as packed {id, tuple} records (amg_device.h)
+  bool dist_mode = false;     // building a shard of a merged (multi-GPU) graph
   bool count_inline = false;  // true: count by one global atomic per window (merge path)
   // nodes (id order)
   DevBuf node_tokens;  // int32[n_nodes * k]
@@ -165,7 +166,7 @@ struct amg_ctx {
   int world = 1;
   int64_t n_owned = 0;
   uint32_t dist_min_node = 1, dist_min_edge = 1;  // fused filter of the next merged build
-  DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab;
+  DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab, dist_lcnt;
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
   bool match_valid = false;
@@ -204,6 +205,8 @@ int bs_edges_pass(amg_ctx* c, int* which);
 int bs_alloc_pairs(amg_ctx* c, long long P);
 int bs_pairs_from_local(amg_ctx* c);
 int bs_finish_from_pairs(amg_ctx* c);
+int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
+                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out);
 
 static inline int ilog2_ceil(uint64_t x) {
   int b = 0;
