@@ -468,11 +468,12 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
   unsigned char cls;
   int start = 0, end = -1;
   unsigned int bound = 0;
+  unsigned int len_out = 0;  // genes of the corrected read, known here unless it has None runs
   if (n <= 0) {
     cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
   } else if (!a.read_fix[r]) {
     cls = RC_COPY;
-    bound = (unsigned int)L;
+    len_out = (unsigned int)L;
   } else {
     long long first = n, last = -1;
     for (long long i = lane; i < n; i += 64)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
       }
       if (runs == 0) {
         cls = RC_TRIM;
-        bound = (unsigned int)(end - start + a.k);
+        len_out = (unsigned int)(end - start + a.k);
       } else {
         cls = RC_GAPPED;
         unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
@@ -515,35 +516,9 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
     a.cls[r] = cls;
     a.r_start[r] = start;
     a.r_end[r] = end;
-    a.bound[r] = bound;
+    a.bound[r] = bound;    // temp space: only re-threaded reads are staged
+    a.new_len[r] = len_out;
   }
-}
-
-__global__ __launch_bounds__(256) void k_corr_simple(CorrArgs a) {
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.n_reads) return;
-  const int lane = threadIdx.x & 63;
-  const unsigned char cls = a.cls[r];
-  if (cls == RC_GAPPED) return;
-  unsigned int len = 0;
-  if (cls == RC_COPY || cls == RC_TRIM) {
-    const long long t0 = a.read_off[r];
-    long long src = t0, cnt = a.read_off[r + 1] - t0;
-    if (cls == RC_TRIM) {
-      src = t0 + a.r_start[r];
-      cnt = a.r_end[r] - a.r_start[r] + a.k;
-    }
-    const long long dst = a.tmp_off[r];
-    for (long long i = lane; i < cnt; i += 64) {
-      a.tmp_tok[dst + i] = a.tokens[src + i];
-      if (a.have_pos) {
-        a.tmp_gs[dst + i] = a.gstart[src + i];
-        a.tmp_ge[dst + i] = a.gend[src + i];
-      }
-    }
-    len = (unsigned int)cnt;
-  }
-  if (lane == 0) a.new_len[r] = len;
 }
 
 // ---- gapped reads
@@ -747,14 +722,7 @@ __global__ __launch_bounds__(64) void k_corr_gapped(GapArgs A) {
         ++q;
       }
     }
-    if (keep_orig) {
-      for (int i = 0; i < L0; ++i) {
-        a.tmp_tok[dst + i] = a.tokens[t0 + i];
-        if (a.have_pos) {
-          a.tmp_gs[dst + i] = a.gstart[t0 + i];
-          a.tmp_ge[dst + i] = a.gend[t0 + i];
-        }
-      }
+    if (keep_orig) {  // the pack step copies the original genes and positions
       a.new_len[r] = (unsigned int)L0;
       A.final_cls[r] = RC_KEEP_ORIG;
       continue;
@@ -1005,14 +973,8 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
     if (n_combo > GF_MAXCOMBO) break;
   }
   if (dead_end) {
-    // possible_paths == []: the original genes (and positions) are kept (:1292-1293)
-    for (int i = lane; i < L0; i += 64) {
-      a.tmp_tok[dst + i] = TK[i];
-      if (a.have_pos) {
-        a.tmp_gs[dst + i] = a.gstart[t0 + i];
-        a.tmp_ge[dst + i] = a.gend[t0 + i];
-      }
-    }
+    // possible_paths == []: the original genes (and positions) are kept (:1292-1293);
+    // the pack step copies them
     if (lane == 0) {
       a.new_len[r] = (unsigned int)L0;
       A.final_cls[r] = RC_KEEP_ORIG;
@@ -1387,12 +1349,25 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.n_reads || !A.keep[r]) return;
   const int lane = threadIdx.x & 63;
-  const long long src = a.tmp_off[r], dst = A.new_off[r], n = a.new_len[r];
-  for (long long i = lane; i < n; i += 64) {
-    A.o_tok[dst + i] = a.tmp_tok[src + i];
-    if (a.have_pos) {
-      A.o_gs[dst + i] = a.tmp_gs[src + i];
-      A.o_ge[dst + i] = a.tmp_ge[src + i];
+  const long long dst = A.new_off[r], n = a.new_len[r];
+  const unsigned char fc = A.final_cls[r];
+  if (fc == RC_GAPPED) {  // re-threaded read: staged in the temp area
+    const long long src = a.tmp_off[r];
+    for (long long i = lane; i < n; i += 64) {
+      A.o_tok[dst + i] = a.tmp_tok[src + i];
+      if (a.have_pos) {
+        A.o_gs[dst + i] = a.tmp_gs[src + i];
+        A.o_ge[dst + i] = a.tmp_ge[src + i];
+      }
+    }
+  } else {  // untouched read, kept original, or a slice [start : end + k] of the original (:1277-1285)
+    const long long src = a.read_off[r] + (fc == RC_TRIM ? a.r_start[r] : 0);
+    for (long long i = lane; i < n; i += 64) {
+      A.o_tok[dst + i] = a.tokens[src + i];
+      if (a.have_pos) {
+        A.o_gs[dst + i] = a.gstart[src + i];
+        A.o_ge[dst + i] = a.gend[src + i];
+      }
     }
   }
   if (lane == 0) {
@@ -1420,7 +1395,8 @@ __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const lo
 // global NW scratch size of gapped read gi (0 when it fits the LDS path)
 __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
                            const long long* __restrict__ read_off, const unsigned int* __restrict__ new_len,
-                           const unsigned char* __restrict__ final_cls, long long* __restrict__ size) {
+                           const unsigned char* __restrict__ final_cls, long long* __restrict__ size,
+                           int allow_fast, unsigned long long* n_general) {
   long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= n_gapped) return;
   long long r = gapped[gi];
@@ -1430,6 +1406,7 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
   if (!small && final_cls[r] != RC_KEEP_ORIG)
     bytes = ((N * M + N + M + 15) & ~15ll) + ((3 * (N + 1) * 4 + 15) & ~15ll);
   size[gi] = bytes;
+  if (final_cls[r] != RC_KEEP_ORIG && !(allow_fast && nw_fast_ok(N, M))) atomicAdd(n_general, 1ull);
 }
 
 __global__ void k_max_u32(const unsigned int* __restrict__ v, const unsigned char* __restrict__ cls,
@@ -1490,7 +1467,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
 
   stage_begin(c, "correct_classify");
   HIPCHK(hipMemsetAsync(bound, 0, per_read * sizeof(unsigned int) * 3, st));
-  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);
+  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);  // also new_len
   AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
   long long tmp_total = 0;
   unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
@@ -1518,10 +1495,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     a.tmp_ge = a.tmp_gs + (tmp_total + 4);
   }
   HIPCHK(hipMemcpyAsync(final_cls, cls, (size_t)R, hipMemcpyDeviceToDevice, st));
-
-  stage_begin(c, "correct_simple");
-  if (R > 0) hipLaunchKernelGGL(k_corr_simple, dim3(nblk(R, 4)), dim3(256), 0, st, a);
-  stage_end(c);
 
   if (n_gapped > 0) {
     stage_begin(c, "live_adjacency");
@@ -1585,11 +1558,17 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
           ((uintptr_t)(c->s1.as<int>() + 2 * per_read) + 15) & ~(uintptr_t)15);
       long long* nw_off = nw_size + per_read;
       HIPCHK(hipMemsetAsync(nw_size, 0, (size_t)(n_gapped + 1) * sizeof(long long), st));
+      const char* nfn = getenv("AMG_NO_FAST_NW");
+      const int allow_fast = !(nfn && nfn[0] == '1');
+      unsigned long long* n_general_d = c->status.as<unsigned long long>() + ST_MISC;
+      HIPCHK(hipMemsetAsync(n_general_d, 0, sizeof(unsigned long long), st));
       hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
-                         n_gapped, a.read_off, new_len, final_cls, nw_size);
+                         n_gapped, a.read_off, new_len, final_cls, nw_size, allow_fast, n_general_d);
       AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
       long long big_total = 0;
+      unsigned long long n_general = 0;
       HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(&n_general, n_general_d, sizeof(n_general), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       DevBuf& big = c->c_gend;  // the path pool is done
       AMGCHK(big.ensure((size_t)big_total + 64));
@@ -1600,11 +1579,11 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       W.final_cls = final_cls;
       W.big_off = nw_off;
       W.big_buf = big.as<unsigned char>();
-      const char* nfn = getenv("AMG_NO_FAST_NW");
-      W.allow_fast = !(nfn && nfn[0] == '1');
+      W.allow_fast = allow_fast;
       if (W.allow_fast)
         hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, W);
-      hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
+      if (n_general > 0)  // reads too long for the register-resident kernel
+        hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
       stage_end(c);
     }
   }
