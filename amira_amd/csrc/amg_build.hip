@@ -112,7 +112,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
     const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k,
     int two_v, unsigned long long seed, Slot* __restrict__ tab, unsigned long long mask,
     unsigned int probe_limit, long long tok_base, int* __restrict__ tok_slot,
-    signed char* __restrict__ tok_dir, unsigned long long* status, int count_inline) {
+    signed char* __restrict__ tok_dir, unsigned long long* status, int count_inline,
+    unsigned long long fp_mask) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
   const long long t0 = (long long)blockIdx.x * TILE;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
       if (dir == 0) {
         status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
       } else {
-        unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed);
+        unsigned long long fp = canon_fingerprint(w, k, flip, dir, seed) & fp_mask;  // mask: test hook
+        fp = fp ? fp : 1ull;
         unsigned long long first = ((unsigned long long)(tok_base + t) << 1) | (dir < 0 ? 1ull : 0ull);
         long long slot = table_upsert(tab, mask, fp, fp >> 20, first, probe_limit, count_inline != 0,
                                       status + ST_OVERFLOW);
@@ -569,7 +571,8 @@ int bs_nodes_pass(amg_ctx* c, int k, int* which) {
                        c->two_v, c->seed, c->node_tab.as<Slot>(),
                        (unsigned long long)(c->node_slots - 1), kProbeLimit, (long long)c->tok_base,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                       c->status.as<unsigned long long>(), c->count_inline ? 1 : 0);
+                       c->status.as<unsigned long long>(), c->count_inline ? 1 : 0,
+                       c->weak_fp_builds > 0 ? 0x00000FFF00000000ull : ~0ull);
   stage_end(c);
 
   stage_begin(c, "node_rank");
@@ -839,6 +842,12 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   c->tok_total = c->n_tokens;
   c->dist_mode = false;
   {
+    // test hook: the first AMG_TEST_WEAK_FP attempts use a 12-bit fingerprint, which is
+    // certain to collide; the exact verification must catch it and the retry must succeed
+    const char* e = getenv("AMG_TEST_WEAK_FP");
+    c->weak_fp_builds = e ? atoi(e) : 0;
+  }
+  {
     const char* e = getenv("AMG_COUNT_INLINE");  // A/B switch: 1 = one global atomic per window
     c->count_inline = e && e[0] == '1';
   }
@@ -864,6 +873,7 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
       c->edge_slots *= 4;
     } else {
       c->seed = c->seed * 6364136223846793005ull + 1442695040888963407ull;  // new fingerprint
+      if (c->weak_fp_builds > 0) --c->weak_fp_builds;
     }
   }
   return amg_fail(AMG_E_OVERFLOW, "build did not converge after 12 attempts");

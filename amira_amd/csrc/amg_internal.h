@@ -129,6 +129,7 @@ struct amg_ctx {
   DevBuf tok_dir;    // int8 [n_tokens]
   DevBuf tok_pair;   // int32[n_tokens]  edge-class slot (then id) of the adjacency t -> t+1
   bool packed_nodes = false;  // node slots rewritten as packed {id, tuple} records (amg_device.h)
+  int weak_fp_builds = 0;     // test hook, see amg_build
   bool dist_mode = false;     // building a shard of a merged (multi-GPU) graph
   bool count_inline = false;  // true: count by one global atomic per window (merge path)
   // nodes (id order)
