@@ -1232,22 +1232,24 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   for (int i = lane; i < N; i += 64) X[i] = a.tmp_tok[dst + i];
   const int yj = lane < M ? a.tokens[t0 + lane] : -1;
   wave_sync();
-  // ---- fill
-  int prev1 = 0, prev2 = 0;  // this lane's value one / two steps ago
+  // ---- fill.  Lane j owns column j; before it becomes active its registers hold the top
+  // border F[-1, j] = -j, so row 0 needs no special case; the left border F[i, -1] = -i enters
+  // lane 0 as the `old` operand of the DPP wave shift that brings every other lane its
+  // neighbour's value (one VALU op instead of an LDS permute).
+  int prev1 = -lane, prev2 = -lane;  // this lane's value one / two steps ago
   unsigned int acc = 0;
-  for (int s = 0; s <= N + M - 2; ++s) {
+  const int n_steps = N + M - 1;
+  for (int s = 0; s < n_steps; ++s) {
     const int i = s - lane;
-    const int l1 = __shfl_up(prev1, 1, 64);  // F[i, j-1]
-    const int l2 = __shfl_up(prev2, 1, 64);  // F[i-1, j-1]
+    // lane 0 (i == s): F[i, -1] = -s and F[i-1, -1] = -(s-1), with F[-1, -1] = 0
+    const int l1 = __builtin_amdgcn_update_dpp(-s, prev1, 0x138, 0xf, 0xf, false);                 // F[i, j-1]
+    const int l2 = __builtin_amdgcn_update_dpp(s == 0 ? 0 : 1 - s, prev2, 0x138, 0xf, 0xf, false);  // F[i-1, j-1]
     const bool active = (lane < M) && i >= 0 && i < N;
     int best = prev1;
     if (active) {
-      const int f_up = (i == 0) ? -lane : prev1;  // F[i-1, j]
-      const int f_left = (lane == 0) ? -i : l1;   // F[i, j-1]
-      const int f_diag = (i == 0) ? (lane == 0 ? 0 : -(lane - 1)) : (lane == 0 ? -(i - 1) : l2);
-      const int s_d = f_diag + (X[i] == yj ? 1 : 0);
-      const int s_l = f_up - 1;    // pointer LEFT = (-1, 0)
-      const int s_u = f_left - 1;  // pointer UP   = (0, -1)
+      const int s_d = l2 + (X[i] == yj ? 1 : 0);
+      const int s_l = prev1 - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
+      const int s_u = l1 - 1;     // from F[i, j-1]: pointer UP   = (0, -1)
       best = s_d;
       unsigned int ptr = 0;
       if (s_l >= best) { best = s_l; ptr = 1; }
