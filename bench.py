@@ -240,6 +240,23 @@ def main():
                                                         "edge_count", "edge_emit", "components", "adjacency"))
         n_builds = max(stage_ms.get("node_upsert", [0, 1])[1], 1)
         survey_b = 4.0 * L / (L - k + 1) + 5 + (4 * k + 8) + 20.0 * (L - k) / (L - k + 1)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this
+        # process, so the per-launch FETCH_SIZE + WRITE_SIZE of the last committed
+        # `rocprofv3 --pmc` passes over this same command (profiles/) is reported, or null
+        traffic, traffic_note = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r1_v3_sweep_pmc_summary.json")
+        if w["sweep"] and world == 1 and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                row = next(r for r in pmc["kernels"] if r["kernel"].startswith(kernel_of[dom].split("<")[0]))
+                n = min(len(row["FETCH_SIZE_KB_per_launch"]), len(row["WRITE_SIZE_KB_per_launch"]))
+                traffic = sum((row["FETCH_SIZE_KB_per_launch"][i] + row["WRITE_SIZE_KB_per_launch"][i]) * 1024.0
+                              for i in range(n)) / n
+                traffic_note = ("mean over the launches of one sweep, (FETCH_SIZE + WRITE_SIZE) x 1024, separate "
+                                "--pmc passes, from profiles/r1_v3_sweep_pmc_summary.json; not corrected for the "
+                                "gfx950 FETCH_SIZE under-count of wide coalesced streams")
+            except Exception:  # noqa: BLE001
+                traffic = None
         out = {
             "metric": "gene-mers/s to corrected GeneMerGraph" if w["sweep"] else "gene-mers/s to GeneMerGraph (build + coverage)",
             "value": world * n_windows * args.steps / dt, "unit": "gene-mers/s",
@@ -255,7 +272,8 @@ def main():
                                      if merge else "independent read shards, no table merge")},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": cands[dom],
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": cands[dom],
                          "avg_launch_ms": stage_avg[dom], "launches_per_step": stage_ms[dom][1],
                          "whole_build": {"algorithmic_bytes_per_gene_mer": survey_b,
                                          "ms_per_build": build_ms / n_builds,
