@@ -105,3 +105,16 @@ def test_low_coverage_components(eng):
         eng.remove_low_coverage_components(m)
         g.remove_low_coverage_components(m)
         compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
+
+
+@pytest.mark.parametrize("env", [{"AMG_NO_FAST_GAPPED": "1"}, {"AMG_NO_FAST_NW": "1"},
+                                 {"AMG_COUNT_INLINE": "1"}, {"AMG_NO_FAST_GAPPED": "1", "AMG_NO_FAST_NW": "1"}])
+def test_sweep_general_kernels(eng, monkeypatch, env):
+    """the general (any-size) re-threading / alignment kernels and the inline-atomic counting
+    path must give the same results as the fast paths that normally take these reads"""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    run_sweep(eng, reads, pos, fq, 5)
+    reads, pos, fq = P.synth_inputs(13, 300, 40, 250, 0.02)
+    run_sweep(eng, reads, pos, fq, 7)
