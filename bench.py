@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="run the merged (multi-GPU) code path even at world size 1 (self-test)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -133,12 +135,15 @@ def main():
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_merge:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     from amira_amd import Engine
     from amira_amd.dist import dist_build
-    merge = world > 1 and not args.no_merge
+    merge = (world > 1 or args.force_merge) and not args.no_merge
 
     def build(fused_filter=None):
         if merge:
@@ -182,9 +187,10 @@ def main():
             return
         if not merge:
             eng.filter(3, 1)
-        if record:
-            tally()
-            info["marked_reads"] = eng.counts()["n_reads_to_correct"] if "marked_reads" not in info else info["marked_reads"]
+            if record:
+                tally()
+        if record and "marked_reads" not in info:
+            info["marked_reads"] = eng.counts()["n_reads_to_correct"]
         eng.correct_reads()
         if record:
             tally()
@@ -225,6 +231,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    out = None
     if rank == 0:
         stage_avg = {n: v[0] / v[1] for n, v in stage_ms.items()}     # ms per launch
         stage_tot = {n: v[0] for n, v in stage_ms.items()}            # ms per step
@@ -267,7 +274,7 @@ def main():
             "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": L, "k": k,
                        "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
                        "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
-                       "multi_gpu": ("n/a" if world == 1 else
+                       "multi_gpu": ("n/a" if not (world > 1 or merge) else
                                      "read shards + key-owner table merge per build (RCCL all-to-all + all-gather)"
                                      if merge else "independent read shards, no table merge")},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved,
@@ -283,10 +290,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
     eng.close()
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
