@@ -137,6 +137,8 @@ def main():
     dist = None
     if world > 1 or args.force_merge:
         import torch.distributed as dist
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ.pop("NCCL_DEBUG")  # the RCCL version banner goes to stdout at exit, after the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("nccl", rank=rank, world_size=world,
