@@ -81,6 +81,13 @@ def _load():
         "amg_dist_edges_reduce": (C.c_int, [P, P, I64, C.POINTER(I64)]),
         "amg_dist_edges_owned": (C.c_int, [P, P]),
         "amg_dist_edges_global": (C.c_int, [P, P, I64]),
+        "amg_calls_load_json": (C.c_int, [C.c_char_p, C.POINTER(P)]),
+        "amg_calls_counts": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64),
+                                       C.POINTER(I64)]),
+        "amg_calls_get": (C.c_int, [P, P, P, P, P, P]),
+        "amg_calls_load_positions_json": (C.c_int, [P, C.c_char_p, P, P]),
+        "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
+        "amg_calls_free": (C.c_int, [P]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     }
     for name, (res, args) in sig.items():

@@ -119,7 +119,11 @@ class GeneMerGraph:
         self._gene_cache = {}
         dev = int(os.environ.get("AMG_DEVICE", "0")) if device is None else int(device)
         self._engine = Engine(dev)
-        self._vocab, toks, offs, self._read_ids = tokenize(readDict)
+        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):  # amira_amd.io.TokenizedReads
+            self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
+                                                       readDict.read_offsets, list(readDict.read_ids))
+        else:
+            self._vocab, toks, offs, self._read_ids = tokenize(readDict)
         self._read_off = offs
         self._read_index = {r: i for i, r in enumerate(self._read_ids)}
         if kmerSize < 1 and len(toks) == 0:

@@ -1,0 +1,79 @@
+"""Native gene-call I/O: JSON files <-> CSR tokens without a
+per-gene Python loop.  `load_gene_calls` returns a TokenizedReads, which GeneMerGraph /
+build_graph accept in place of the {read: [genes]} dict (it IS a read-only mapping of that
+shape, decoded lazily), so the tokens go straight to the device.
+"""
+import ctypes as C
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+from .tokens import Vocabulary
+
+
+class TokenizedReads(Mapping):
+    """{read id: ["+geneA", ...]} backed by CSR token arrays (lists are decoded on access)."""
+
+    def __init__(self, vocab, tokens, read_offsets, read_ids):
+        self.vocab, self.tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
+        self._index = {r: i for i, r in enumerate(read_ids)}
+        self._cache = {}
+
+    def __getitem__(self, read_id):
+        got = self._cache.get(read_id)
+        if got is None:
+            i = self._index[read_id]
+            got = self._cache[read_id] = self.vocab.decode(
+                self.tokens[self.read_offsets[i]:self.read_offsets[i + 1]])
+        return got
+
+    def __iter__(self):
+        return iter(self.read_ids)
+
+    def __len__(self):
+        return len(self.read_ids)
+
+    def __contains__(self, read_id):
+        return read_id in self._index
+
+
+def _split(buf):
+    return [] if len(buf) == 0 else buf.tobytes()[:-1].decode("utf-8").split("\0")
+
+
+def load_gene_calls(calls_json, positions_json=None):
+    """-> TokenizedReads (and, with positions_json, {read: [(start, end), ...]} as two flat
+    int64 arrays aligned with the tokens: (reads, gene_start, gene_end))."""
+    h = C.c_void_p()
+    check(_ffi.lib.amg_calls_load_json(str(calls_json).encode(), C.byref(h)))
+    try:
+        n = [C.c_int64(0) for _ in range(5)]
+        check(_ffi.lib.amg_calls_counts(h, *[C.byref(x) for x in n]))
+        n_reads, n_tokens, n_genes, names_bytes, ids_bytes = [x.value for x in n]
+        tokens = np.empty(n_tokens, np.int32)
+        offs = np.empty(n_reads + 1, np.int64)
+        names = np.empty(names_bytes, np.uint8)
+        ids = np.empty(ids_bytes, np.uint8)
+        hashes = np.empty(n_genes * 32, np.uint8)
+        check(_ffi.lib.amg_calls_get(h, ptr(tokens), ptr(offs), ptr(names), ptr(ids), ptr(hashes)))
+        vocab = Vocabulary.from_ranked(_split(names), hashes.reshape(n_genes, 32))
+        reads = TokenizedReads(vocab, tokens, offs, _split(ids))
+        if positions_json is None:
+            return reads
+        gs, ge = np.empty(n_tokens, np.int64), np.empty(n_tokens, np.int64)
+        check(_ffi.lib.amg_calls_load_positions_json(h, str(positions_json).encode(), ptr(gs), ptr(ge)))
+        return reads, gs, ge
+    finally:
+        _ffi.lib.amg_calls_free(h)
+
+
+def write_gene_calls(path, vocab, tokens, read_offsets, read_ids):
+    """corrected CSR -> {"read": ["+gene", ...]} JSON (what result_utils.py:1260-1264 dumps)."""
+    tokens = np.ascontiguousarray(tokens, np.int32)
+    read_offsets = np.ascontiguousarray(read_offsets, np.int64)
+    names = ("\0".join(vocab.names) + "\0").encode("utf-8") if vocab.names else b""
+    ids = ("\0".join(read_ids) + "\0").encode("utf-8") if len(read_ids) else b""
+    check(_ffi.lib.amg_calls_write_json(str(path).encode(), ptr(tokens), ptr(read_offsets), len(read_ids),
+                                        names, len(vocab.names), ids))

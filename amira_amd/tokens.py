@@ -48,6 +48,22 @@ class Vocabulary:
             self._tok["+" + n] = V + r
             self._tok["-" + n] = V - 1 - r
 
+    @classmethod
+    def from_ranked(cls, names, digests):
+        """names already in rank order with their 32-byte sha256 digests (native loader)."""
+        self = cls.__new__(cls)
+        self.names = list(names)
+        self.hashes = [int.from_bytes(bytes(d), "big") for d in digests]
+        self.rank = {n: i for i, n in enumerate(self.names)}
+        self.V = len(self.names)
+        self.two_v = 2 * max(self.V, 1)
+        V = max(self.V, 1)
+        self._tok = {}
+        for n, r in self.rank.items():
+            self._tok["+" + n] = V + r
+            self._tok["-" + n] = V - 1 - r
+        return self
+
     # ---- encoding
     def token(self, gene):
         t = self._tok.get(gene)

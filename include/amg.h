@@ -205,6 +205,26 @@ int amg_dist_edges_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, in
 int amg_dist_edges_owned(amg_ctx* ctx, void* out_buf);
 int amg_dist_edges_global(amg_ctx* ctx, const void* all_records, int64_t n_total);
 
+/* ---- native front-end / write-back (host code, no GPU needed):
+ *      gene-call JSON {"read": ["+geneA", "-geneB", ...]} as dumped / reloaded by the reference
+ *      (__main__.py:464-496, result_utils.py:1260-1264) -> vocabulary ranked by the reference's
+ *      gene hash (construct_gene.py:5-10) + CSR tokens; positions JSON {"read": [[s, e], ...]};
+ *      corrected CSR -> JSON ------------------------------------------------------------ */
+typedef struct amg_calls amg_calls;
+int amg_calls_load_json(const char* path, amg_calls** out);
+int amg_calls_counts(amg_calls* calls, int64_t* n_reads, int64_t* n_tokens, int64_t* n_genes,
+                     int64_t* names_bytes, int64_t* ids_bytes);
+/* tokens[n_tokens], read_offsets[n_reads + 1], NUL-separated gene names in RANK order
+ * (names_bytes), NUL-separated read ids in file order (ids_bytes), 32-byte sha256 per gene */
+int amg_calls_get(amg_calls* calls, int32_t* tokens, int64_t* read_offsets, char* gene_names,
+                  char* read_ids, uint8_t* gene_hashes);
+int amg_calls_load_positions_json(amg_calls* calls, const char* path, int64_t* gene_start,
+                                  int64_t* gene_end);
+int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t* read_offsets,
+                         int64_t n_reads, const char* gene_names, int64_t n_genes,
+                         const char* read_ids);
+int amg_calls_free(amg_calls* calls);
+
 /* ---- per-stage device time of the last call, for bench.py ------------------------- */
 /* names[i] points at static strings; returns the number of stages (<= cap). */
 int amg_last_timings(amg_ctx* ctx, const char** names, float* ms, int cap);
