@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -183,6 +184,25 @@ struct Reader {
     ++p;
     return true;
   }
+  // fast path: the string as a view into the file when it has no escapes (then *owned is
+  // empty and [*b, *e) is the content); otherwise falls back to str() into *owned
+  bool str_view(const char** b, const char** e, std::string* owned) {
+    ws();
+    if (p >= end || *p != '"') { err = "expected string"; return false; }
+    const char* q = p + 1;
+    while (q < end && *q != '"' && *q != '\\') ++q;
+    if (q < end && *q == '"') {
+      *b = p + 1;
+      *e = q;
+      p = q + 1;
+      owned->clear();
+      return true;
+    }
+    if (!str(*owned)) return false;
+    *b = owned->data();
+    *e = owned->data() + owned->size();
+    return true;
+  }
   bool integer(long long* v) {
     ws();
     const char* s = p;
@@ -196,6 +216,47 @@ struct Reader {
     *v = (*s == '-') ? -x : x;
     return true;
   }
+};
+
+// name bytes -> first-seen id, open addressing over (offset, length) into one arena
+struct Interner {
+  std::vector<char> arena;
+  std::vector<uint32_t> off, len;
+  std::vector<int32_t> slots;
+  size_t mask = 0;
+  Interner() { slots.assign(1 << 16, -1); mask = slots.size() - 1; }
+  static uint64_t hash(const char* b, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)b[i]) * 1099511628211ull;
+    return h ^ (h >> 29);
+  }
+  void grow() {
+    std::vector<int32_t> bigger(slots.size() * 4, -1);
+    size_t m = bigger.size() - 1;
+    for (size_t id = 0; id < off.size(); ++id) {
+      size_t s = hash(&arena[off[id]], len[id]) & m;
+      while (bigger[s] >= 0) s = (s + 1) & m;
+      bigger[s] = (int32_t)id;
+    }
+    slots.swap(bigger);
+    mask = m;
+  }
+  int32_t intern(const char* b, size_t n) {
+    size_t s = hash(b, n) & mask;
+    while (slots[s] >= 0) {
+      int32_t id = slots[s];
+      if (len[id] == n && memcmp(&arena[off[id]], b, n) == 0) return id;
+      s = (s + 1) & mask;
+    }
+    int32_t id = (int32_t)off.size();
+    off.push_back((uint32_t)arena.size());
+    len.push_back((uint32_t)n);
+    arena.insert(arena.end(), b, b + n);
+    slots[s] = id;
+    if (off.size() * 2 > slots.size()) grow();
+    return id;
+  }
+  std::string name(size_t id) const { return std::string(&arena[off[id]], len[id]); }
 };
 
 bool slurp(const char* path, std::string& out, std::string& err) {
@@ -233,43 +294,46 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
   if (!slurp(path, text, err)) return amg_fail(AMG_E_ARG, "%s", err.c_str());
   Reader r{text.data(), text.data() + text.size(), ""};
   amg_calls* c = new amg_calls();
-  std::unordered_map<std::string, int32_t> gene_id;  // name -> first-seen id
-  std::vector<std::string> names_seen;
+  const bool timing = getenv("AMG_CALLS_TIMING") != nullptr;
+  clock_t t_start = clock();
+  Interner genes;               // name -> first-seen id
   std::vector<int32_t> gid;     // per gene occurrence: first-seen name id
   std::vector<int8_t> strand;   // per gene occurrence
+  gid.reserve(text.size() / 8);
+  strand.reserve(text.size() / 8);
   auto fail = [&](const char* what) {
     std::string m = std::string(what) + (r.err.empty() ? "" : (": " + r.err));
     delete c;
     return amg_fail(AMG_E_ARG, "%s: %s (offset %lld)", path, m.c_str(), (long long)(r.p - text.data()));
   };
   if (!r.lit('{')) return fail("expected an object of read -> gene list");
-  std::string key, gene;
+  std::string key, owned, fixed;
   if (!r.lit('}')) {
     do {
       if (!r.str(key)) return fail("read id");
       if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
       if (!r.lit(']')) {
         do {
-          if (!r.str(gene)) return fail("gene");
-          // construct_gene.py:49-65
-          std::string squeezed = gene;
-          squeezed.erase(std::remove(squeezed.begin(), squeezed.end(), ' '), squeezed.end());
-          if (squeezed.empty()) return fail("Gene information is missing");
-          if (gene[0] != '+' && gene[0] != '-') return fail("Strand information missing for a gene");
-          std::string name = gene.substr(1);
-          std::replace(name.begin(), name.end(), ' ', '_');
-          if (name.empty()) return fail("Gene name information missing for a gene");
-          auto it = gene_id.find(name);
+          const char *gb, *ge;
+          if (!r.str_view(&gb, &ge, &owned)) return fail("gene");
+          // construct_gene.py:49-65: strand = first char, name = rest with ' ' -> '_'
+          bool blank = true, has_space = false;
+          for (const char* q = gb; q < ge; ++q) {
+            if (*q == ' ') has_space = true; else blank = false;
+          }
+          if (blank) return fail("Gene information is missing");
+          if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
+          if (ge - gb < 2) return fail("Gene name information missing for a gene");
           int32_t id;
-          if (it == gene_id.end()) {
-            id = (int32_t)names_seen.size();
-            gene_id.emplace(name, id);
-            names_seen.push_back(name);
+          if (!has_space) {
+            id = genes.intern(gb + 1, (size_t)(ge - gb - 1));
           } else {
-            id = it->second;
+            fixed.assign(gb + 1, ge);
+            std::replace(fixed.begin(), fixed.end(), ' ', '_');
+            id = genes.intern(fixed.data(), fixed.size());
           }
           gid.push_back(id);
-          strand.push_back(gene[0] == '+' ? 1 : -1);
+          strand.push_back(*gb == '+' ? 1 : -1);
         } while (r.lit(','));
         if (!r.lit(']')) return fail("expected ']'");
       }
@@ -284,7 +348,10 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
     } while (r.lit(','));
     if (!r.lit('}')) return fail("expected '}'");
   }
+  if (timing) fprintf(stderr, "parse %.3fs\n", (double)(clock() - t_start) / CLOCKS_PER_SEC);
   // ---- hash every distinct name once, rank by hash, tokens
+  std::vector<std::string> names_seen(genes.off.size());
+  for (size_t i = 0; i < names_seen.size(); ++i) names_seen[i] = genes.name(i);
   const size_t V = names_seen.size();
   std::vector<uint8_t> h(V * 32);
   for (size_t i = 0; i < V; ++i) gene_hash(names_seen[i], &h[i * 32]);
@@ -306,6 +373,7 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
   c->tokens.resize(gid.size());
   for (size_t i = 0; i < gid.size(); ++i)
     c->tokens[i] = strand[i] > 0 ? Vp + rank[gid[i]] : Vp - 1 - rank[gid[i]];
+  if (timing) fprintf(stderr, "total %.3fs\n", (double)(clock() - t_start) / CLOCKS_PER_SEC);
   *out = c;
   return AMG_OK;
 }
