@@ -16,95 +16,12 @@
 //                     construct_edge.py:104-124)
 //   k_compact_slots + sort + k_pair_width + scan + k_emit_edges
 //                     directed edges in _edges insertion order, E1 then E2 (:279-285)
-//   k_adj_keys + stable radix sort + k_row_count + scan
+//   k_adj_keys + stable radix sort + k_row_offsets
 //                     forwardEdgeHashes / backwardEdgeHashes lists (:287-298)
 //   k_uf_*            connected components, ids in DFS discovery order (:911-927)
 #include "amg_device.h"
 
-#define TILE_ITEMS 4
-#define TILE_THREADS 256
-#define TILE (TILE_THREADS * TILE_ITEMS)
-
-// ------------------------------------------------------------------ small kernels
-__global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, int k,
-                             unsigned long long* status) {
-  __shared__ unsigned long long s_w[4], s_s[4];
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long w = 0, sh = 0;
-  if (r < n_reads) {
-    long long len = read_off[r + 1] - read_off[r];
-    if (len >= k)
-      w = (unsigned long long)(len - k + 1);
-    else
-      sh = 1;
-  }
-  for (int d = 32; d > 0; d >>= 1) {
-    w += __shfl_down(w, d, 64);
-    sh += __shfl_down(sh, d, 64);
-  }
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    s_w[wave] = w;
-    s_s[wave] = sh;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long tw = 0, ts = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
-      tw += s_w[i];
-      ts += s_s[i];
-    }
-    if (tw) atomicAdd(&status[ST_N_WINDOWS], tw);
-    if (ts) atomicAdd(&status[ST_N_SHORT], ts);
-  }
-}
-
-// tile_lo[b] = first j in [1, n_reads] with read_off[j] > b * TILE  (n_reads + 1 if none)
-__global__ void k_tile_reads(const long long* __restrict__ read_off, long long n_reads,
-                             long long n_tiles_plus2, long long* __restrict__ tile_lo) {
-  long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_tiles_plus2) return;
-  long long target = b * (long long)TILE;
-  long long lo = 1, hi = n_reads + 1;  // search in [1, n_reads + 1)
-  while (lo < hi) {
-    long long mid = (lo + hi) >> 1;
-    if (read_off[mid] > target)
-      hi = mid;
-    else
-      lo = mid + 1;
-  }
-  tile_lo[b] = lo;
-}
-
-struct LdsView {
-  const int* p;
-  __device__ __forceinline__ int operator[](int j) const { return p[j]; }
-};
-
-// shared by k_node_upsert and k_edges: stage the tile's tokens and read-end flags in LDS
-__device__ __forceinline__ void stage_tile(const int* __restrict__ tokens,
-                                           const long long* __restrict__ read_off,
-                                           const long long* __restrict__ tile_lo,
-                                           long long n_reads, long long n_tokens, int k,
-                                           long long t0, int* s_tok, unsigned char* s_bnd) {
-  const int tid = threadIdx.x;
-  const int span = TILE + k;  // tokens t0 .. t0 + TILE + k - 1, flags 0 .. TILE + k
-  for (int i = tid; i < span; i += TILE_THREADS) {
-    long long t = t0 + i;
-    s_tok[i] = t < n_tokens ? tokens[t] : 0;
-    s_bnd[i] = 0;
-  }
-  if (tid == 0) s_bnd[span] = 0;
-  __syncthreads();
-  // read ends (exclusive) that fall in (t0, t0 + TILE + k]
-  long long b = blockIdx.x;
-  long long lo = tile_lo[b], hi = tile_lo[b + 2];
-  for (long long j = lo + tid; j < hi; j += TILE_THREADS) {
-    long long off = read_off[j] - t0;
-    if (off <= span) s_bnd[off] = 1;
-  }
-  __syncthreads();
-}
+#include "amg_tile.h"
 
 // ------------------------------------------------------------------ K1 + K2
 __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
@@ -356,13 +273,22 @@ __global__ void k_emit_edges(const unsigned long long* __restrict__ pkey,
 // adjacency rows: row = 2 * src + (sdir == +1 ? 0 : 1); edge ids ascending inside a row
 __global__ void k_adj_keys(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir,
                            long long n_edges, unsigned int* __restrict__ keys,
-                           unsigned int* __restrict__ vals, unsigned int* __restrict__ row_count) {
+                           unsigned int* __restrict__ vals) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
-  unsigned int row = 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
-  keys[e] = row;
+  keys[e] = 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
   vals[e] = (unsigned int)e;
-  atomicAdd(&row_count[row], 1u);
+}
+
+// CSR offsets from the sorted row keys, no atomics: position i opens every row in
+// (key[i - 1], key[i]]; the position after the last edge opens the remaining rows and n_rows
+__global__ void k_row_offsets(const unsigned int* __restrict__ keys, long long n_edges, long long n_rows,
+                              long long* __restrict__ off) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_edges) return;
+  const long long prev = i > 0 ? (long long)keys[i - 1] : -1;
+  const long long cur = i < n_edges ? (long long)keys[i] : n_rows;
+  for (long long r = prev + 1; r <= cur; ++r) off[r] = i;
 }
 
 // ------------------------------------------------------------------ components
@@ -423,19 +349,30 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
 // ------------------------------------------------------------------ deferred counting
 // Occurrence counts without one global atomic per window.  Persistent 1024-thread blocks keep
 // HOT_IDS counters in LDS for the id range [lo, lo + HOT_IDS) and sweep the whole id array;
-// ids are first-seen ranks, so the frequently hit (genome) nodes / edges are the LOW ids and
-// a few ranges absorb almost every increment.  The last sweep sends the ids beyond the covered
-// ranges to global atomics.  With GATHER the array holds table slots on entry and is rewritten
-// to dense ids (tab[slot].id) during the first sweep.
+// ids are first-seen ranks (or claim order), so the frequently hit (genome) nodes / edges are
+// the LOW ids and a few ranges absorb almost every increment.  Every sweep also counts the
+// ids that lie beyond its range (state[r]); the next sweep reads that number and, when at
+// most 1/8 of the array is left, finishes the job with global atomics (27 G/s, cheaper than
+// further 4-byte-per-id sweeps at that point); sweeps after that find state == 0 and exit.
+// With GATHER the array holds table slots on entry and is rewritten to dense ids
+// (tab[slot].id) during the first sweep.
 #define HOT_IDS 32768
 template <bool GATHER>
 __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long long n,
                                                     const Slot* __restrict__ tab, long long lo,
-                                                    long long tail_from, unsigned int* __restrict__ out) {
+                                                    int sweep, int last, unsigned long long* state,
+                                                    unsigned int* __restrict__ out) {
   __shared__ unsigned int s_cnt[HOT_IDS];
+  bool tail_all = last != 0;
+  if (sweep > 0) {
+    const unsigned long long left = state[sweep - 1];
+    if (left == 0ull) return;  // an earlier sweep already finished (state[sweep] stays 0)
+    if (left * 8ull <= (unsigned long long)n) tail_all = true;
+  }
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) s_cnt[i] = 0;
   __syncthreads();
   const long long stride = (long long)gridDim.x * 1024;
+  unsigned int beyond = 0;
   for (long long t = (long long)blockIdx.x * 1024 + threadIdx.x; t < n; t += stride) {
     int id = ids[t];
     if (GATHER) {
@@ -444,10 +381,17 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
     }
     if (id < 0) continue;
     const long long rel = (long long)id - lo;
-    if (rel >= 0 && rel < HOT_IDS)
+    if (rel < 0) continue;
+    if (rel < HOT_IDS)
       atomicAdd(&s_cnt[rel], 1u);
-    else if (tail_from >= 0 && id >= tail_from)
+    else if (tail_all)
       atomicAdd(&out[id], 1u);
+    else
+      ++beyond;
+  }
+  if (!tail_all) {
+    for (int d = 32; d > 0; d >>= 1) beyond += __shfl_down(beyond, d, 64);
+    if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) {
@@ -457,24 +401,28 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
 }
 
 // counts[id] += occurrences of id in ids[0..n); n_ids distinct ids
-static int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
-                     unsigned int* out) {
+#define COUNT_MAX_SWEEPS 4
+int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
+              unsigned int* out) {
   hipStream_t st = c->stream;
   HIPCHK(hipMemsetAsync(out, 0, (size_t)(n_ids + 1) * sizeof(unsigned int), st));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
+  AMGCHK(c->cnt_state.ensure(COUNT_MAX_SWEEPS * sizeof(unsigned long long)));
+  unsigned long long* state = c->cnt_state.as<unsigned long long>();
+  HIPCHK(hipMemsetAsync(state, 0, COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
-  if (ranges > 4) ranges = 4;
+  if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
   long long want_blocks = (n + 1023) / 1024;
   unsigned int blocks = (unsigned int)(want_blocks < 256 ? want_blocks : 256);
   for (long long r = 0; r < ranges; ++r) {
     const long long lo = r * HOT_IDS;
-    const long long tail_from = (r == ranges - 1) ? ranges * HOT_IDS : -1;
+    const int last = (r == ranges - 1) ? 1 : 0;
     if (gather_tab && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         tail_from, out);
+                         (int)r, last, state, out);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         tail_from, out);
+                         (int)r, last, state, out);
   }
   return AMG_OK;
 }
@@ -794,20 +742,17 @@ int bs_finish_from_pairs(amg_ctx* c) {
   AMGCHK(c->s1.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->s2.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->s3.ensure((size_t)(E + 2) * sizeof(unsigned int)));
-  AMGCHK(c->s4.ensure((size_t)(2 * D + 2) * sizeof(unsigned int)));
-  HIPCHK(hipMemsetAsync(c->s4.p, 0, (size_t)(2 * D + 2) * sizeof(unsigned int), st));
   if (E > 0) {
     hipLaunchKernelGGL(k_adj_keys, dim3(blocks_for(E, 256)), dim3(256), 0, st,
                        c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), E,
-                       c->s1.as<unsigned int>(), c->s2.as<unsigned int>(),
-                       c->s4.as<unsigned int>());
+                       c->s1.as<unsigned int>(), c->s2.as<unsigned int>());
     AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s3.as<unsigned int>(),
                              c->s2.as<unsigned int>(),
                              reinterpret_cast<unsigned int*>(c->adj_edge.p), (size_t)E,
                              ilog2_ceil((uint64_t)2 * D + 2) + 1));
   }
-  AMGCHK(prim_exscan_u32_to_i64(c, c->s4.as<unsigned int>(), c->adj_off.as<long long>(),
-                                (size_t)(2 * D + 1)));
+  hipLaunchKernelGGL(k_row_offsets, dim3(blocks_for(E + 1, 256)), dim3(256), 0, st,
+                     c->s3.as<unsigned int>(), E, 2 * D, c->adj_off.as<long long>());
   stage_end(c);
 
   c->ladj_valid = false;
@@ -852,12 +797,20 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
     c->count_inline = e && e[0] == '1';
   }
   bs_size_tables(c);
+  c->exact_keys = false;
+  const bool exact = bx_applicable(c, k);  // tuple fits the slot: exact keys + claim ids
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;
-    int r = bs_nodes_pass(c, k, &which);
-    if (r == AMG_OK) r = bs_nodes_rank_local(c);
-    if (r == AMG_OK) r = bs_edges_pass(c, &which);
-    if (r == AMG_OK) r = bs_pairs_from_local(c);
+    int r;
+    if (exact) {
+      r = bx_nodes(c, k, &which);
+      if (r == AMG_OK) r = bx_edges(c, &which);
+    } else {
+      r = bs_nodes_pass(c, k, &which);
+      if (r == AMG_OK) r = bs_nodes_rank_local(c);
+      if (r == AMG_OK) r = bs_edges_pass(c, &which);
+      if (r == AMG_OK) r = bs_pairs_from_local(c);
+    }
     if (r == AMG_OK) r = bs_finish_from_pairs(c);
     if (r == AMG_OK) {
       c->built = true;

@@ -1,0 +1,527 @@
+// amg_build_x.hip — the single-GPU build with EXACT keys and claim ids.
+//
+// Same result as the fingerprint path of amg_build.hip (GeneMerGraph.__init__, reference
+// construct_graph.py:31-102), different bookkeeping, used whenever the canonical k-tuple
+// fits 94 bits (k * ceil(log2(2V)) <= 94: k = 3 for any vocabulary, k = 5 up to 2^18 genes):
+//
+//   * a node slot is 16 bytes: w1 = low 63 bits of the packed tuple (+ a set bit 0), w2 =
+//     {remaining tuple bits + a set bit, claim id + 1}.  The tuple itself is the key, so no
+//     fingerprint verification pass is needed and one 16-byte load per probe decides it.
+//   * the thread that creates a slot gives it a CLAIM id: creators of a block are counted
+//     with a block scan, one atomicAdd per block reserves the ids, the id is published in the
+//     slot (threads that found the key before the id was there wait for it after their own
+//     block has published — a block never waits before publishing, so there is no cycle).
+//   * every per-key quantity lives in DENSE arrays indexed by claim id: first-seen (x_first),
+//     slot (x_slot), final node id (x_final).  Claim order follows the token order, so the
+//     frequently hit genome nodes own the first few ten thousand claims: the per-window
+//     gathers of the edge pass (claim -> node id) and the first-seen updates hit a small
+//     L2-resident region instead of one 128-byte line per hot slot, the occupied slots need
+//     no table scan to be listed, and occurrence counting (k_count_ids) works on claim ids
+//     directly, without a slot -> id gather.
+//   * node id = rank of first-seen among the claims (32-bit keys: tokens < 2^29), as before.
+// Edge classes ((lo id, hi id, sign), construct_edge.py:104-124) use the same scheme with a
+// one-word key.
+#include "amg_tile.h"
+
+struct __attribute__((aligned(16))) Slot16 {
+  unsigned long long w1;
+  unsigned long long w2;
+};
+static_assert(sizeof(Slot16) == 16, "slot16");
+
+__device__ __forceinline__ unsigned int ld_u32(const unsigned int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Slot contents with agent-scope loads.  A plain load would be served by the issuing XCD's L2,
+// which keeps a line fetched while the slot was still empty for the rest of the kernel (the
+// eight L2s are not coherent with each other inside a kernel): every later window of a hot key
+// would then fall into the CAS path (measured: 7x slower).
+__device__ __forceinline__ ulonglong2 ld_slot(const Slot16* s) {
+  ulonglong2 v;
+  v.x = ld_u64(&s->w1);
+  v.y = ld_u64(&s->w2);
+  return v;
+}
+
+// canonical tuple -> (w1, tag): token j occupies bits [j*bits, (j+1)*bits) of a 94-bit value,
+// w1 = (low 63 bits << 1) | 1, tag = (high 31 bits << 1) | 1 — both non-zero by construction
+template <class View>
+__device__ __forceinline__ void x_pack(const View& w, int k, int flip, int dir, int bits,
+                                       unsigned long long& w1, unsigned int& tag) {
+  unsigned long long lo = 0, hi = 0;
+  int sh = 0;
+  for (int j = 0; j < k; ++j, sh += bits) {
+    const unsigned long long c = (unsigned long long)(unsigned int)canon_tok(w, k, flip, dir, j);
+    if (sh < 63) {
+      lo |= c << sh;
+      if (sh + bits > 63) hi |= c >> (63 - sh);
+    } else {
+      hi |= c << (sh - 63);
+    }
+  }
+  w1 = (lo << 1) | 1ull;  // bit 63 of lo (it belongs to hi) falls off here
+  tag = ((unsigned int)hi << 1) | 1u;
+}
+
+__device__ __forceinline__ int x_unpack(unsigned long long w1, unsigned int tag, int bits, int j) {
+  const unsigned long long lo = w1 >> 1, hi = (unsigned long long)(tag >> 1);
+  const int sh = j * bits;
+  unsigned long long v = sh < 63 ? ((lo >> sh) | (hi << (63 - sh))) : (hi >> (sh - 63));
+  return (int)(v & ((1ull << bits) - 1ull));
+}
+
+// Find or create the slot of key (w1, tag) starting at `idx`; `v` is the already loaded
+// content of that first slot.  TWO: the key has a second word (tag) claimed by a second CAS;
+// the slot belongs to whoever sets w2 (a thread that claimed w1 but lost w2 to a different
+// tag moves on, and every later thread of its key takes the same decision at this slot).
+// Returns the slot or -1; id1 = claim id + 1 if already published, created = this thread made it.
+template <bool TWO>
+__device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long mask,
+                                              unsigned long long w1, unsigned int tag,
+                                              unsigned long long idx, ulonglong2 v,
+                                              unsigned int limit, const unsigned long long* abort_flag,
+                                              unsigned int& id1, bool& created) {
+  created = false;
+  id1 = 0;
+  for (unsigned int probes = 0;; ++probes) {
+    Slot16* s = tab + idx;
+    unsigned long long c1 = v.x, c2 = v.y;
+    if (c1 == 0ull) {
+      c1 = atomicCAS(&s->w1, 0ull, w1);
+      if (c1 == 0ull) {
+        c1 = w1;
+        c2 = 0ull;
+        if (!TWO) {
+          created = true;
+          return (long long)idx;
+        }
+      }
+    }
+    if (c1 == w1) {
+      if (TWO) {
+        if ((c2 >> 32) == 0ull) {
+          const unsigned long long old = atomicCAS(&s->w2, 0ull, (unsigned long long)tag << 32);
+          if (old == 0ull) {
+            created = true;
+            return (long long)idx;
+          }
+          c2 = old;
+        }
+        if ((unsigned int)(c2 >> 32) == tag) {
+          id1 = (unsigned int)c2;
+          return (long long)idx;
+        }
+      } else {
+        id1 = (unsigned int)c2;
+        return (long long)idx;
+      }
+    }
+    if (probes >= limit) return -1;
+    if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
+      return -1;
+    idx = (idx + 1) & mask;
+    v = ld_slot(tab + idx);
+  }
+}
+
+// Claim ids for the slots this block created + first-seen bookkeeping.  slot[it] < 0: nothing.
+// On return id1[it] = claim id + 1 of every item with a slot.
+template <bool TWO>
+__device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TILE_ITEMS],
+                                        unsigned int (&id1)[TILE_ITEMS], unsigned int created,
+                                        const unsigned int (&fi)[TILE_ITEMS],
+                                        unsigned int* __restrict__ first_by_claim,
+                                        unsigned int* __restrict__ slot_by_claim,
+                                        unsigned long long* counter, unsigned int* s_wave,
+                                        unsigned long long* s_base) {
+  unsigned int total;
+  const unsigned int off = block_exscan_256((unsigned int)__popc(created), &total, s_wave);
+  if (threadIdx.x == 0) *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  unsigned int claim = (unsigned int)(*s_base) + off;
+  if (created) {
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it)
+      if (created & (1u << it)) {
+        // first_by_claim is zero-initialised and only ever raised by atomicMax (creator or
+        // not), so no ordering between this update and the publication of the id is needed
+        // (a release fence here writes back the L2: measured 7x slower)
+        atomicMax(first_by_claim + claim, fi[it]);
+        slot_by_claim[claim] = (unsigned int)slot[it];
+        id1[it] = claim + 1u;
+        if (TWO)
+          atomicOr(&tab[slot[it]].w2, (unsigned long long)(claim + 1u));
+        else
+          __hip_atomic_store(&tab[slot[it]].w2, (unsigned long long)(claim + 1u), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        ++claim;
+      }
+  }
+  // found keys: wait for an id that is still on its way (its creator's block publishes without
+  // waiting for anybody), then keep the minimum first-seen
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (slot[it] < 0 || (created & (1u << it))) continue;
+    unsigned int id = id1[it];
+    while (id == 0u) {
+      id = (unsigned int)ld_u64(&tab[slot[it]].w2);
+      if (id == 0u) __builtin_amdgcn_s_sleep(2);
+    }
+    id1[it] = id;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (slot[it] < 0 || (created & (1u << it))) continue;
+    unsigned int* f = first_by_claim + (id1[it] - 1u);
+    if (ld_u32(f) < fi[it]) atomicMax(f, fi[it]);
+  }
+}
+
+// ------------------------------------------------------------------ nodes
+__global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
+    const int* __restrict__ tokens, const long long* __restrict__ read_off,
+    const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k, int two_v,
+    int bits, Slot16* tab, unsigned long long mask, unsigned int probe_limit,
+    int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
+    unsigned int* __restrict__ first_by_claim, unsigned int* __restrict__ slot_by_claim) {
+  __shared__ int s_tok[TILE + AMG_MAX_K];
+  __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
+  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned long long s_base;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  stage_tile(tokens, read_off, tile_lo, n_reads, n_tokens, k, t0, s_tok, s_bnd);
+  const int flip = two_v - 1;
+  unsigned long long w1[TILE_ITEMS], idx[TILE_ITEMS];
+  unsigned int tag[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS];
+  long long slot[TILE_ITEMS];
+  ulonglong2 v[TILE_ITEMS];
+  int dirs[TILE_ITEMS];
+  unsigned int valid = 0, created = 0, last = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const int i = threadIdx.x + it * TILE_THREADS;
+    const long long t = t0 + i;
+    bool ok = (t + k <= n_tokens);
+    for (int j = 1; j < k; ++j) ok = ok && (s_bnd[i + j] == 0);
+    dirs[it] = 0;
+    slot[it] = -1;
+    id1[it] = 0;
+    if (ok) {
+      LdsView w{s_tok + i};
+      const int dir = canon_dir(w, k, flip);
+      if (dir == 0) {
+        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+      } else {
+        dirs[it] = dir;
+        x_pack(w, k, flip, dir, bits, w1[it], tag[it]);
+        idx[it] = mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
+        fi[it] = ~(((unsigned int)t << 1) | (dir < 0 ? 1u : 0u));
+        valid |= 1u << it;
+        if (s_bnd[i + k]) last |= 1u << it;
+      }
+    }
+  }
+  // first probe of every window in flight before any of them is examined
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it)
+    if (valid & (1u << it)) v[it] = ld_slot(tab + idx[it]);
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(valid & (1u << it))) continue;
+    bool made;
+    slot[it] = x_upsert<true>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
+                              status + ST_OVERFLOW, id1[it], made);
+    if (slot[it] < 0) status[ST_OVERFLOW] = 1;
+    if (made) created |= 1u << it;
+  }
+  x_claim<true>(tab, slot, id1, created, fi, first_by_claim, slot_by_claim, status + ST_NODE_INSERTS,
+                s_wave, &s_base);
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const long long t = t0 + threadIdx.x + it * TILE_THREADS;
+    if (t >= n_tokens) continue;
+    int out = -1;
+    if (slot[it] >= 0) out = (int)((id1[it] - 1u) | ((last & (1u << it)) ? AMG_LAST_FLAG : 0u));
+    tok_claim[t] = out;
+    tok_dir[t] = slot[it] >= 0 ? (signed char)dirs[it] : (signed char)0;
+  }
+}
+
+__global__ void k_x_sort_keys(const unsigned int* __restrict__ first_by_claim, long long n,
+                              unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = ~first_by_claim[i];
+  vals[i] = (unsigned int)i;
+}
+
+__global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
+                                 const unsigned int* __restrict__ claim_sorted, long long n_nodes,
+                                 const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
+                                 int k, int bits, int* __restrict__ final_of_claim,
+                                 int* __restrict__ node_tokens, long long* __restrict__ node_first,
+                                 unsigned char* __restrict__ node_alive) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const unsigned int c = claim_sorted[i];
+  final_of_claim[c] = (int)i;
+  node_first[i] = (long long)first_sorted[i];
+  node_alive[i] = 1;
+  const Slot16 s = tab[slot_by_claim[c]];
+  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, bits, j);
+}
+
+// ------------------------------------------------------------------ edges
+__global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
+    long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
+    const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
+    unsigned long long emask, unsigned int probe_limit, unsigned long long* status,
+    int* __restrict__ tok_pair, unsigned int* __restrict__ first_by_claim,
+    unsigned int* __restrict__ slot_by_claim) {
+  __shared__ int s_id[TILE + 1];
+  __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
+  __shared__ unsigned char s_last[TILE + 1];
+  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned long long s_base;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
+    const long long t = t0 + i;
+    int raw = -1;
+    signed char d = 0;
+    if (t < n_tokens) {
+      raw = tok_claim[t];
+      d = tok_dir[t];
+    }
+    int id = -1;
+    if (raw != -1) id = final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG];
+    s_id[i] = id;
+    s_dir[i] = d;
+    s_last[i] = (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) ? 1 : 0;
+    if (i < TILE && t < n_tokens) tok_node[t] = id;
+  }
+  __syncthreads();
+  unsigned long long key[TILE_ITEMS], idx[TILE_ITEMS];
+  unsigned int fi[TILE_ITEMS], id1[TILE_ITEMS];
+  long long slot[TILE_ITEMS];
+  ulonglong2 v[TILE_ITEMS];
+  unsigned int valid = 0, created = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const int i = threadIdx.x + it * TILE_THREADS;
+    slot[it] = -1;
+    id1[it] = 0;
+    if (s_last[i] || s_id[i] < 0 || s_id[i + 1] < 0) continue;
+    // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
+    const unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
+    const int dA = s_dir[i], dB = s_dir[i + 1];
+    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+    const unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
+    key[it] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+    const unsigned int orient = (a == lo ? 1u : 0u) | (dA > 0 ? 2u : 0u) | (dB > 0 ? 4u : 0u);
+    fi[it] = ~(((unsigned int)(t0 + i) << 3) | orient);
+    idx[it] = mix64(key[it]) & emask;
+    valid |= 1u << it;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it)
+    if (valid & (1u << it)) v[it] = ld_slot(etab + idx[it]);
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(valid & (1u << it))) continue;
+    bool made;
+    slot[it] = x_upsert<false>(etab, emask, key[it], 0u, idx[it], v[it], probe_limit,
+                               status + ST_OVERFLOW, id1[it], made);
+    if (slot[it] < 0) status[ST_OVERFLOW] = 2;
+    if (made) created |= 1u << it;
+  }
+  x_claim<false>(etab, slot, id1, created, fi, first_by_claim, slot_by_claim, status + ST_PAIR_INSERTS,
+                 s_wave, &s_base);
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const long long t = t0 + threadIdx.x + it * TILE_THREADS;
+    if (t < n_tokens) tok_pair[t] = slot[it] >= 0 ? (int)(id1[it] - 1u) : -1;
+  }
+}
+
+// edge classes in first-seen order: key, first, count (counted per claim by k_count_ids)
+__global__ void k_x_gather_pairs(const unsigned int* __restrict__ first_sorted,
+                                 const unsigned int* __restrict__ claim_sorted, long long n_pairs,
+                                 const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
+                                 const unsigned int* __restrict__ cnt_by_claim,
+                                 unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
+                                 unsigned int* __restrict__ pcnt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const unsigned int c = claim_sorted[i];
+  pkey[i] = etab[slot_by_claim[c]].w1;
+  pfirst[i] = (unsigned long long)first_sorted[i];
+  pcnt[i] = cnt_by_claim[c];
+}
+
+// ------------------------------------------------------------------ host side
+static inline unsigned int blocks_for(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned int)(b < 1 ? 1 : b);
+}
+
+static const unsigned int kProbeLimitX = 1024;
+
+static int read_status(amg_ctx* c, unsigned long long* host) {
+  HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+bool bx_applicable(const amg_ctx* c, int k) {
+  if (c->dist_mode || c->count_inline || c->weak_fp_builds > 0) return false;
+  const char* e = getenv("AMG_KEY_MODE");  // A/B + test switch: "fp" forces the fingerprint path
+  if (e && e[0] == 'f') return false;
+  int bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
+  if ((long long)k * bits > 94) return false;
+  if (c->n_tokens >= (1ll << 29)) return false;  // 32-bit first-seen: (token << 3) | orientation
+  return true;
+}
+
+// windows -> node table, claim ids, node ids, node arrays.  AMG_E_OVERFLOW + *which = 1: table full
+int bx_nodes(amg_ctx* c, int k, int* which) {
+  *which = 0;
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, R = c->n_reads;
+  unsigned long long hs[ST_WORDS];
+  c->exact_keys = true;
+  c->packed_nodes = false;
+  c->x_bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
+  HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+
+  stage_begin(c, "read_stats");
+  long long n_tiles = (T + TILE - 1) / TILE;
+  AMGCHK(c->s0.ensure((size_t)(n_tiles + 2) * sizeof(long long)));
+  long long* tile_lo = c->s0.as<long long>();
+  if (R > 0)
+    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st, c->read_off.as<long long>(),
+                       R, k, c->status.as<unsigned long long>());
+  hipLaunchKernelGGL(k_tile_reads, dim3(blocks_for(n_tiles + 2, 256)), dim3(256), 0, st,
+                     c->read_off.as<long long>(), R, n_tiles + 2, tile_lo);
+  stage_end(c);
+
+  const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
+  AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
+  AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
+  AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
+  AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
+  AMGCHK(c->x_first.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
+
+  stage_begin(c, "node_table_clear");
+  HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot16), st));
+  HIPCHK(hipMemsetAsync(c->x_first.p, 0, max_claims * sizeof(unsigned int), st));
+  stage_end(c);
+
+  stage_begin(c, "node_upsert");
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_nodes_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                       c->read_off.as<long long>(), tile_lo, R, T, k, c->two_v, c->x_bits,
+                       c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
+                       c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                       c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                       c->x_slot.as<unsigned int>());
+  AMGCHK(read_status(c, hs));
+  stage_end(c);
+  if (hs[ST_PALINDROME])
+    return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
+  if (hs[ST_OVERFLOW]) {
+    *which = 1;
+    return AMG_E_OVERFLOW;
+  }
+  c->n_windows = (int64_t)hs[ST_N_WINDOWS];
+  c->n_short = (int64_t)hs[ST_N_SHORT];
+  c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
+
+  stage_begin(c, "node_rank");
+  const long long D = c->n_nodes;
+  AMGCHK(c->s1.ensure((size_t)(D + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(D + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s3.ensure((size_t)(D + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(D + 1) * sizeof(unsigned int)));
+  AMGCHK(bs_alloc_nodes(c, D));
+  if (D > 0) {
+    hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
+                       D, c->s1.as<unsigned int>(), c->s3.as<unsigned int>());
+    AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
+                             c->s4.as<unsigned int>(), (size_t)D, ilog2_ceil((uint64_t)T * 2 + 2) + 1));
+    hipLaunchKernelGGL(k_x_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
+                       c->s4.as<unsigned int>(), D, c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
+                       k, c->x_bits, c->x_final.as<int>(), c->node_tokens.as<int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+  }
+  stage_end(c);
+  return AMG_OK;
+}
+
+// adjacencies -> edge-class table, claims, pair arrays in first-seen order, coverages.
+// AMG_E_OVERFLOW + *which = 2: edge table full
+int bx_edges(amg_ctx* c, int* which) {
+  *which = 0;
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, D = c->n_nodes;
+  const long long n_tiles = (T + TILE - 1) / TILE;
+  unsigned long long hs[ST_WORDS];
+  if (c->edge_slots < (int64_t)pow2_at_least((uint64_t)D * 3)) c->edge_slots = pow2_at_least((uint64_t)D * 3);
+  const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+  AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
+  AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
+  AMGCHK(c->x_efirst.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
+  stage_begin(c, "edge_table_clear");
+  HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
+  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, max_claims * sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
+  stage_end(c);
+  stage_begin(c, "edge_upsert");
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
+                       c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
+                       c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
+                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>());
+  AMGCHK(read_status(c, hs));
+  stage_end(c);
+  if (hs[ST_OVERFLOW]) {
+    *which = 2;
+    return AMG_E_OVERFLOW;
+  }
+  const long long P = (long long)hs[ST_PAIR_INSERTS];
+  c->n_local_pairs = c->n_pairs = P;
+
+  // node coverage (construct_node.py:33-36) from the per-window node ids
+  stage_begin(c, "node_count");
+  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>()));
+  stage_end(c);
+  // edge-class coverage per claim
+  stage_begin(c, "edge_count");
+  AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>()));
+  stage_end(c);
+
+  stage_begin(c, "edge_rank");
+  AMGCHK(bs_alloc_pairs(c, P));
+  AMGCHK(c->s1.ensure((size_t)(P + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(P + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s3.ensure((size_t)(P + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
+  if (P > 0) {
+    hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
+                       P, c->s1.as<unsigned int>(), c->s3.as<unsigned int>());
+    AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
+                             c->s4.as<unsigned int>(), (size_t)P, ilog2_ceil((uint64_t)T * 8 + 8) + 1));
+    hipLaunchKernelGGL(k_x_gather_pairs, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
+                       c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(),
+                       c->x_ecnt.as<unsigned int>(), c->pair_key.as<unsigned long long>(),
+                       c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+  }
+  stage_end(c);
+  return AMG_OK;
+}

@@ -163,6 +163,14 @@ struct amg_ctx {
   int64_t c_reads = 0, c_tokens = 0;
   DevBuf c_tokens_buf, c_read_off, c_orig, c_changed, c_gstart, c_gend, c_read_len;
 
+  // ---- exact-key build (amg_build_x.hip): arrays indexed by CLAIM id (order of slot creation)
+  bool exact_keys = false;   // this build used the exact-key path
+  int x_bits = 0;            // bits per token in the packed tuple
+  DevBuf x_first, x_slot;    // uint32[claims]  ~first_seen of a node claim, its table slot
+  DevBuf x_final;            // int32 [claims]  claim id -> node id
+  DevBuf x_efirst, x_eslot;  // the same for edge-class claims
+  DevBuf x_ecnt;             // uint32[edge claims] occurrences
+
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
   int64_t n_owned = 0;
@@ -178,6 +186,7 @@ struct amg_ctx {
   DevBuf status;       // unsigned long long[ST_WORDS]
   DevBuf sort_tmp;     // rocPRIM temp storage
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
+  DevBuf cnt_state;    // unsigned long long[4]: ids left after each counting sweep
 
   std::vector<StageTime> stages;
   bool timing = true;
@@ -206,6 +215,11 @@ int bs_edges_pass(amg_ctx* c, int* which);
 int bs_alloc_pairs(amg_ctx* c, long long P);
 int bs_pairs_from_local(amg_ctx* c);
 int bs_finish_from_pairs(amg_ctx* c);
+bool bx_applicable(const amg_ctx* c, int k);
+int bx_nodes(amg_ctx* c, int k, int* which);
+int bx_edges(amg_ctx* c, int* which);
+int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
+              unsigned int* out);
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
                      const unsigned int* slot_sorted, long long n_ids, unsigned int* out);
 

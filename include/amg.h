@@ -75,6 +75,9 @@ typedef struct amg_counts_t {
   int64_t build_retries;  /* table growth / fingerprint-collision rebuilds             */
   int32_t k;
   int32_t two_v;
+  int32_t exact_keys;     /* 1: the build keyed nodes by the packed tuple itself (k * bits */
+                          /* per token <= 94), 0: by a verified 64-bit fingerprint        */
+  int32_t reserved;
 } amg_counts_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */

@@ -89,6 +89,25 @@ def test_synthetic_build_and_filter(eng, seed, N, L, V, k, err):
     _run(eng, reads, k, filt=(2, 2))
 
 
+@pytest.mark.parametrize("k", [3, 5])
+def test_fingerprint_key_path(eng, monkeypatch, k):
+    """small k normally takes the exact-key build (the packed tuple is the key); the
+    fingerprint + verification build that large k / large vocabularies and the multi-GPU merge
+    use must give the same graph on the same reads"""
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    assert _run(eng, reads, k, filt=(3, 1))["exact_keys"] == 1
+    monkeypatch.setenv("AMG_KEY_MODE", "fp")
+    assert _run(eng, reads, k, filt=(3, 1))["exact_keys"] == 0
+
+
+def test_key_mode_follows_tuple_width(eng):
+    reads, _, _ = P.synth_inputs(19, 300, 33, 400, 0.02)   # 2V = 800 -> 10 bits per token
+    assert _run(eng, reads, 6)["exact_keys"] == 1           # 60 bits: one word
+    assert _run(eng, reads, 7)["exact_keys"] == 1           # 70 bits: spills into the tag
+    assert _run(eng, reads, 9)["exact_keys"] == 1           # 90 bits
+    assert _run(eng, reads, 10)["exact_keys"] == 0          # 100 bits: fingerprint path
+
+
 def test_rebuild_on_same_context(eng):
     reads, _, _ = P.synth_inputs(3, 200, 30, 100, 0.02)
     a = _run(eng, reads, 5)
