@@ -25,24 +25,24 @@
 
 // ------------------------------------------------------------------ K1 + K2
 __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
-    const int* __restrict__ tokens, const long long* __restrict__ read_off,
-    const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k,
+    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k,
     int two_v, unsigned long long seed, Slot* __restrict__ tab, unsigned long long mask,
     unsigned int probe_limit, long long tok_base, int* __restrict__ tok_slot,
     signed char* __restrict__ tok_dir, unsigned long long* status, int count_inline,
     unsigned long long fp_mask) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
-  __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   const long long t0 = (long long)blockIdx.x * TILE;
-  stage_tile(tokens, read_off, tile_lo, n_reads, n_tokens, k, t0, s_tok, s_bnd);
+  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
   const int flip = two_v - 1;
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     int i = threadIdx.x + it * TILE_THREADS;
     long long t = t0 + i;
     if (t >= n_tokens) continue;
-    bool valid = (t + k <= n_tokens);
-    for (int j = 1; j < k; ++j) valid = valid && (s_bnd[i + j] == 0);
+    bool inside, is_last;
+    tile_window(s_bits, i, k, inside, is_last);
+    const bool valid = (t + k <= n_tokens) && inside;
     int out_slot = -1;
     signed char out_dir = 0;
     if (valid) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
         if (slot < 0) {
           status[ST_OVERFLOW] = 1;
         } else {
-          out_slot = (int)((unsigned int)slot | (s_bnd[i + k] ? AMG_LAST_FLAG : 0u));
+          out_slot = (int)((unsigned int)slot | (is_last ? AMG_LAST_FLAG : 0u));
           out_dir = (signed char)dir;
         }
       }
@@ -484,24 +484,32 @@ uint64_t pow2_at_least(uint64_t x) {
 
 static const unsigned int kProbeLimit = 1024;
 
+// window / short-read counts into the status words + the read-end bitmap the tile kernels use
+int bs_read_stats(amg_ctx* c, int k) {
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, R = c->n_reads;
+  stage_begin(c, "read_stats");
+  const size_t words = (size_t)(T >> 5) + BND_PAD_WORDS;
+  AMGCHK(c->bnd_bits.ensure(words * sizeof(unsigned int)));
+  HIPCHK(hipMemsetAsync(c->bnd_bits.p, 0, words * sizeof(unsigned int), st));
+  if (R > 0)
+    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
+                       c->read_off.as<long long>(), R, k, c->status.as<unsigned long long>(),
+                       c->bnd_bits.as<unsigned int>());
+  stage_end(c);
+  return AMG_OK;
+}
+
 // returns AMG_OK, or AMG_E_OVERFLOW with *which = 1 (node table too small)
 int bs_nodes_pass(amg_ctx* c, int k, int* which) {
   *which = 0;
   hipStream_t st = c->stream;
-  const long long T = c->n_tokens, R = c->n_reads;
+  const long long T = c->n_tokens;
   unsigned long long hs[ST_WORDS];
   HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
 
-  stage_begin(c, "read_stats");
-  long long n_tiles = (T + TILE - 1) / TILE;
-  AMGCHK(c->s0.ensure((size_t)(n_tiles + 2) * sizeof(long long)));
-  long long* tile_lo = c->s0.as<long long>();
-  if (R > 0)
-    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
-                       c->read_off.as<long long>(), R, k, c->status.as<unsigned long long>());
-  hipLaunchKernelGGL(k_tile_reads, dim3(blocks_for(n_tiles + 2, 256)), dim3(256), 0, st,
-                     c->read_off.as<long long>(), R, n_tiles + 2, tile_lo);
-  stage_end(c);
+  AMGCHK(bs_read_stats(c, k));
+  const long long n_tiles = (T + TILE - 1) / TILE;
 
   AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
   AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
@@ -515,7 +523,7 @@ int bs_nodes_pass(amg_ctx* c, int k, int* which) {
   stage_begin(c, "node_upsert");
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_node_upsert, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st,
-                       c->tokens.as<int>(), c->read_off.as<long long>(), tile_lo, R, T, k,
+                       c->tokens.as<int>(), c->bnd_bits.as<unsigned int>(), T, k,
                        c->two_v, c->seed, c->node_tab.as<Slot>(),
                        (unsigned long long)(c->node_slots - 1), kProbeLimit, (long long)c->tok_base,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),

@@ -70,11 +70,17 @@ __device__ __forceinline__ int x_unpack(unsigned long long w1, unsigned int tag,
   return (int)(v & ((1ull << bits) - 1ull));
 }
 
-// Find or create the slot of key (w1, tag) starting at `idx`; `v` is the already loaded
-// content of that first slot.  TWO: the key has a second word (tag) claimed by a second CAS;
-// the slot belongs to whoever sets w2 (a thread that claimed w1 but lost w2 to a different
-// tag moves on, and every later thread of its key takes the same decision at this slot).
-// Returns the slot or -1; id1 = claim id + 1 if already published, created = this thread made it.
+// Find or create the slot of key (w1, tag) starting at `idx`; `v` is the content of that first
+// slot as a PLAIN load returned it.
+//
+// Plain loads are served by the issuing XCD's L2 and may be stale, but a slot only ever moves
+// empty -> w1 -> tag -> id, each step once: a cached view that already shows a complete foreign
+// key, or our key with its id, is final and is trusted (no fabric transaction: agent-scope
+// loads cost one 64-byte fabric request each, ~100 G/s, atomics ~27 G/s, L2 hits ~255 G/s).
+// Anything less (empty, tag or id missing) is re-read with agent scope before acting on it.
+// A CAS on w1 takes the slot.  TWO: the key has a second word (tag), set by a second CAS by
+// whichever thread needs it first; that thread owns the slot ("created").
+// Returns the slot or -1; id1 = claim id + 1 if already published.
 template <bool TWO>
 __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long mask,
                                               unsigned long long w1, unsigned int tag,
@@ -83,22 +89,37 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
                                               unsigned int& id1, bool& created) {
   created = false;
   id1 = 0;
-  for (unsigned int probes = 0;; ++probes) {
+  unsigned int probes = 0;
+  while (true) {
     Slot16* s = tab + idx;
     unsigned long long c1 = v.x, c2 = v.y;
+    const bool mine = c1 == w1 && (!TWO || (unsigned int)(c2 >> 32) == tag);
+    if (mine && (unsigned int)c2 != 0u) {
+      id1 = (unsigned int)c2;
+      return (long long)idx;
+    }
+    // The cached view does not decide.  No step below waits for another thread (lanes of one
+    // wave must never wait for each other inside a loop).
     if (c1 == 0ull) {
+      // looks empty: try to take it — the CAS returns the truth, no coherent re-read needed
       c1 = atomicCAS(&s->w1, 0ull, w1);
       if (c1 == 0ull) {
-        c1 = w1;
-        c2 = 0ull;
         if (!TWO) {
           created = true;
           return (long long)idx;
         }
+        c1 = w1;
+        c2 = 0ull;
+      } else if (c1 == w1) {
+        c2 = ld_u64(&s->w2);  // somebody holds our w1: tag / id with agent scope
       }
+    } else if (c1 == w1 && (mine || (TWO && (c2 >> 32) == 0ull))) {
+      c2 = ld_u64(&s->w2);  // tag or id missing in the cached view
     }
     if (c1 == w1) {
       if (TWO) {
+        // the slot belongs to whoever sets the tag (a thread that claimed w1 but lost w2 to a
+        // different tag moves on, as does every later thread of its key at this slot)
         if ((c2 >> 32) == 0ull) {
           const unsigned long long old = atomicCAS(&s->w2, 0ull, (unsigned long long)tag << 32);
           if (old == 0ull) {
@@ -108,7 +129,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
           c2 = old;
         }
         if ((unsigned int)(c2 >> 32) == tag) {
-          id1 = (unsigned int)c2;
+          id1 = (unsigned int)c2;  // 0: the id is still on its way (x_claim waits for it)
           return (long long)idx;
         }
       } else {
@@ -119,8 +140,9 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
     if (probes >= limit) return -1;
     if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
       return -1;
+    ++probes;
     idx = (idx + 1) & mask;
-    v = ld_slot(tab + idx);
+    v = *reinterpret_cast<const ulonglong2*>(tab + idx);
   }
 }
 
@@ -129,11 +151,12 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
 template <bool TWO>
 __device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TILE_ITEMS],
                                         unsigned int (&id1)[TILE_ITEMS], unsigned int created,
+                                        const unsigned int (&tag)[TILE_ITEMS],
                                         const unsigned int (&fi)[TILE_ITEMS],
-                                        unsigned int* __restrict__ first_by_claim,
+                                        unsigned int* first_by_claim, unsigned int* first_init,
                                         unsigned int* __restrict__ slot_by_claim,
-                                        unsigned long long* counter, unsigned int* s_wave,
-                                        unsigned long long* s_base) {
+                                        unsigned long long* counter, unsigned long long* stuck,
+                                        unsigned int* s_wave, unsigned long long* s_base) {
   unsigned int total;
   const unsigned int off = block_exscan_256((unsigned int)__popc(created), &total, s_wave);
   if (threadIdx.x == 0) *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
@@ -143,17 +166,17 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TIL
 #pragma unroll
     for (int it = 0; it < TILE_ITEMS; ++it)
       if (created & (1u << it)) {
-        // first_by_claim is zero-initialised and only ever raised by atomicMax (creator or
-        // not), so no ordering between this update and the publication of the id is needed
-        // (a release fence here writes back the L2: measured 7x slower)
-        atomicMax(first_by_claim + claim, fi[it]);
+        // the creator's first-seen goes to its own array with a plain store; everybody else
+        // raises first_by_claim with atomicMax (both zero-initialised; first-seen = the larger
+        // of the two), so nothing has to be ordered against the publication of the id (a
+        // release fence here writes back the L2: measured 7x slower) and a creation costs no
+        // read-modify-write beyond the CAS that took the slot
+        first_init[claim] = fi[it];
         slot_by_claim[claim] = (unsigned int)slot[it];
         id1[it] = claim + 1u;
-        if (TWO)
-          atomicOr(&tab[slot[it]].w2, (unsigned long long)(claim + 1u));
-        else
-          __hip_atomic_store(&tab[slot[it]].w2, (unsigned long long)(claim + 1u), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tab[slot[it]].w2,
+                           (TWO ? (unsigned long long)tag[it] << 32 : 0ull) | (unsigned long long)(claim + 1u),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++claim;
       }
   }
@@ -163,33 +186,44 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TIL
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (slot[it] < 0 || (created & (1u << it))) continue;
     unsigned int id = id1[it];
-    while (id == 0u) {
+    for (unsigned int spins = 0; id == 0u; ++spins) {
       id = (unsigned int)ld_u64(&tab[slot[it]].w2);
-      if (id == 0u) __builtin_amdgcn_s_sleep(2);
+      if (id != 0u) break;
+      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
+        *stuck = 1ull;
+        id = 1u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
     }
     id1[it] = id;
   }
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (slot[it] < 0 || (created & (1u << it))) continue;
-    unsigned int* f = first_by_claim + (id1[it] - 1u);
-    if (ld_u32(f) < fi[it]) atomicMax(f, fi[it]);
+    // plain (possibly stale, at worst zero) reads: both arrays only grow, so a stale value can
+    // only cause a superfluous atomicMax, never a missed one
+    const unsigned int c = id1[it] - 1u;
+    unsigned int cur = first_by_claim[c];
+    const unsigned int ini = first_init[c];
+    cur = cur > ini ? cur : ini;
+    if (cur < fi[it]) atomicMax(first_by_claim + c, fi[it]);
   }
 }
 
 // ------------------------------------------------------------------ nodes
+template <bool TWO>
 __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
-    const int* __restrict__ tokens, const long long* __restrict__ read_off,
-    const long long* __restrict__ tile_lo, long long n_reads, long long n_tokens, int k, int two_v,
+    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned long long mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
-    unsigned int* __restrict__ first_by_claim, unsigned int* __restrict__ slot_by_claim) {
+    unsigned int* first_by_claim, unsigned int* first_init, unsigned int* __restrict__ slot_by_claim) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
-  __shared__ unsigned char s_bnd[TILE + AMG_MAX_K + 1];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
   const long long t0 = (long long)blockIdx.x * TILE;
-  stage_tile(tokens, read_off, tile_lo, n_reads, n_tokens, k, t0, s_tok, s_bnd);
+  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
   const int flip = two_v - 1;
   unsigned long long w1[TILE_ITEMS], idx[TILE_ITEMS];
   unsigned int tag[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS];
@@ -201,8 +235,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const int i = threadIdx.x + it * TILE_THREADS;
     const long long t = t0 + i;
-    bool ok = (t + k <= n_tokens);
-    for (int j = 1; j < k; ++j) ok = ok && (s_bnd[i + j] == 0);
+    bool inside, is_last;
+    tile_window(s_bits, i, k, inside, is_last);
+    const bool ok = (t + k <= n_tokens) && inside;
     dirs[it] = 0;
     slot[it] = -1;
     id1[it] = 0;
@@ -217,25 +252,25 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
         idx[it] = mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
         fi[it] = ~(((unsigned int)t << 1) | (dir < 0 ? 1u : 0u));
         valid |= 1u << it;
-        if (s_bnd[i + k]) last |= 1u << it;
+        if (is_last) last |= 1u << it;
       }
     }
   }
   // first probe of every window in flight before any of them is examined
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it)) v[it] = ld_slot(tab + idx[it]);
+    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(tab + idx[it]);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
     bool made;
-    slot[it] = x_upsert<true>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
+    slot[it] = x_upsert<TWO>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
                               status + ST_OVERFLOW, id1[it], made);
     if (slot[it] < 0) status[ST_OVERFLOW] = 1;
     if (made) created |= 1u << it;
   }
-  x_claim<true>(tab, slot, id1, created, fi, first_by_claim, slot_by_claim, status + ST_NODE_INSERTS,
-                s_wave, &s_base);
+  x_claim<TWO>(tab, slot, id1, created, tag, fi, first_by_claim, first_init, slot_by_claim, status + ST_NODE_INSERTS,
+               status + ST_MISC, s_wave, &s_base);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
@@ -247,11 +282,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
   }
 }
 
-__global__ void k_x_sort_keys(const unsigned int* __restrict__ first_by_claim, long long n,
+__global__ void k_x_sort_keys(const unsigned int* __restrict__ first_by_claim,
+                              const unsigned int* __restrict__ first_init, long long n,
                               unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = ~first_by_claim[i];
+  const unsigned int a = first_by_claim[i], b = first_init[i];
+  keys[i] = ~(a > b ? a : b);
   vals[i] = (unsigned int)i;
 }
 
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
     unsigned long long emask, unsigned int probe_limit, unsigned long long* status,
-    int* __restrict__ tok_pair, unsigned int* __restrict__ first_by_claim,
+    int* __restrict__ tok_pair, unsigned int* first_by_claim, unsigned int* first_init,
     unsigned int* __restrict__ slot_by_claim) {
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
   }
   __syncthreads();
   unsigned long long key[TILE_ITEMS], idx[TILE_ITEMS];
-  unsigned int fi[TILE_ITEMS], id1[TILE_ITEMS];
+  unsigned int fi[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {};
   long long slot[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
   unsigned int valid = 0, created = 0;
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
   }
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it)) v[it] = ld_slot(etab + idx[it]);
+    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(etab + idx[it]);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
@@ -335,8 +372,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     if (slot[it] < 0) status[ST_OVERFLOW] = 2;
     if (made) created |= 1u << it;
   }
-  x_claim<false>(etab, slot, id1, created, fi, first_by_claim, slot_by_claim, status + ST_PAIR_INSERTS,
-                 s_wave, &s_base);
+  x_claim<false>(etab, slot, id1, created, tag, fi, first_by_claim, first_init, slot_by_claim, status + ST_PAIR_INSERTS,
+                 status + ST_MISC, s_wave, &s_base);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
@@ -388,50 +425,45 @@ bool bx_applicable(const amg_ctx* c, int k) {
 int bx_nodes(amg_ctx* c, int k, int* which) {
   *which = 0;
   hipStream_t st = c->stream;
-  const long long T = c->n_tokens, R = c->n_reads;
+  const long long T = c->n_tokens;
   unsigned long long hs[ST_WORDS];
   c->exact_keys = true;
   c->packed_nodes = false;
   c->x_bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
   HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
 
-  stage_begin(c, "read_stats");
-  long long n_tiles = (T + TILE - 1) / TILE;
-  AMGCHK(c->s0.ensure((size_t)(n_tiles + 2) * sizeof(long long)));
-  long long* tile_lo = c->s0.as<long long>();
-  if (R > 0)
-    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st, c->read_off.as<long long>(),
-                       R, k, c->status.as<unsigned long long>());
-  hipLaunchKernelGGL(k_tile_reads, dim3(blocks_for(n_tiles + 2, 256)), dim3(256), 0, st,
-                     c->read_off.as<long long>(), R, n_tiles + 2, tile_lo);
-  stage_end(c);
+  AMGCHK(bs_read_stats(c, k));
+  const long long n_tiles = (T + TILE - 1) / TILE;
 
   const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
   AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
   AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
   AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
   AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
-  AMGCHK(c->x_first.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));  // raised-by-others | creator's
   AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
 
   stage_begin(c, "node_table_clear");
   HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->x_first.p, 0, max_claims * sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(c->x_first.p, 0, 2 * max_claims * sizeof(unsigned int), st));
   stage_end(c);
 
   stage_begin(c, "node_upsert");
-  if (n_tiles > 0)
-    hipLaunchKernelGGL(k_nodes_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                       c->read_off.as<long long>(), tile_lo, R, T, k, c->two_v, c->x_bits,
+  if (n_tiles > 0) {
+    auto kern = (long long)k * c->x_bits > 63 ? k_nodes_x<true> : k_nodes_x<false>;  // tuple spills into w2?
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                       c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
                        c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                        c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                       c->x_slot.as<unsigned int>());
+                       c->x_first.as<unsigned int>() + max_claims, c->x_slot.as<unsigned int>());
+  }
   AMGCHK(read_status(c, hs));
   stage_end(c);
   if (hs[ST_PALINDROME])
     return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
+  if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "node pass: a claim id was never published");
   if (hs[ST_OVERFLOW]) {
     *which = 1;
     return AMG_E_OVERFLOW;
@@ -449,7 +481,8 @@ int bx_nodes(amg_ctx* c, int k, int* which) {
   AMGCHK(bs_alloc_nodes(c, D));
   if (D > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
-                       D, c->s1.as<unsigned int>(), c->s3.as<unsigned int>());
+                       c->x_first.as<unsigned int>() + max_claims, D, c->s1.as<unsigned int>(),
+                       c->s3.as<unsigned int>());
     AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
                              c->s4.as<unsigned int>(), (size_t)D, ilog2_ceil((uint64_t)T * 2 + 2) + 1));
     hipLaunchKernelGGL(k_x_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
@@ -473,11 +506,11 @@ int bx_edges(amg_ctx* c, int* which) {
   const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
   AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
-  AMGCHK(c->x_efirst.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
   stage_begin(c, "edge_table_clear");
   HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, max_claims * sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_claims * sizeof(unsigned int), st));
   HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
   stage_end(c);
   stage_begin(c, "edge_upsert");
@@ -486,9 +519,11 @@ int bx_edges(amg_ctx* c, int* which) {
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>());
+                       c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
+                       c->x_eslot.as<unsigned int>());
   AMGCHK(read_status(c, hs));
   stage_end(c);
+  if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");
   if (hs[ST_OVERFLOW]) {
     *which = 2;
     return AMG_E_OVERFLOW;
@@ -514,7 +549,8 @@ int bx_edges(amg_ctx* c, int* which) {
   AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   if (P > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
-                       P, c->s1.as<unsigned int>(), c->s3.as<unsigned int>());
+                       c->x_efirst.as<unsigned int>() + max_claims, P, c->s1.as<unsigned int>(),
+                       c->s3.as<unsigned int>());
     AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
                              c->s4.as<unsigned int>(), (size_t)P, ilog2_ceil((uint64_t)T * 8 + 8) + 1));
     hipLaunchKernelGGL(k_x_gather_pairs, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),

@@ -186,6 +186,7 @@ struct amg_ctx {
   DevBuf status;       // unsigned long long[ST_WORDS]
   DevBuf sort_tmp;     // rocPRIM temp storage
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
+  DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
   DevBuf cnt_state;    // unsigned long long[4]: ids left after each counting sweep
 
   std::vector<StageTime> stages;
@@ -208,6 +209,7 @@ void stages_reset(amg_ctx* c);
 // build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
 uint64_t pow2_at_least(uint64_t x);
 void bs_size_tables(amg_ctx* c);
+int bs_read_stats(amg_ctx* c, int k);
 int bs_nodes_pass(amg_ctx* c, int k, int* which);
 int bs_alloc_nodes(amg_ctx* c, long long D);
 int bs_nodes_rank_local(amg_ctx* c);

@@ -1346,39 +1346,85 @@ struct PackArgs {
   long long* o_rl;
 };
 
+// One wave packs PACK_READS consecutive reads: the per-read records of all of them are loaded
+// first, then every gene load is issued before the first store, so that each wave keeps
+// PACK_READS x 20 bytes per lane in flight (a read of 60 genes alone is a 1.2 KB copy: one read
+// per wave leaves the copy latency-bound at a third of the HBM rate).
+#define PACK_READS 4
 __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   const CorrArgs& a = A.a;
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.n_reads || !A.keep[r]) return;
+  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_READS;
   const int lane = threadIdx.x & 63;
-  const long long dst = A.new_off[r], n = a.new_len[r];
-  const unsigned char fc = A.final_cls[r];
-  if (fc == RC_GAPPED) {  // re-threaded read: staged in the temp area
-    const long long src = a.tmp_off[r];
-    for (long long i = lane; i < n; i += 64) {
-      A.o_tok[dst + i] = a.tmp_tok[src + i];
-      if (a.have_pos) {
-        A.o_gs[dst + i] = a.tmp_gs[src + i];
-        A.o_ge[dst + i] = a.tmp_ge[src + i];
-      }
-    }
-  } else {  // untouched read, kept original, or a slice [start : end + k] of the original (:1277-1285)
-    const long long src = a.read_off[r] + (fc == RC_TRIM ? a.r_start[r] : 0);
-    for (long long i = lane; i < n; i += 64) {
-      A.o_tok[dst + i] = a.tokens[src + i];
-      if (a.have_pos) {
-        A.o_gs[dst + i] = a.gstart[src + i];
-        A.o_ge[dst + i] = a.gend[src + i];
+  long long dst[PACK_READS], n[PACK_READS];
+  const int* stok[PACK_READS];
+  const long long* sgs[PACK_READS];
+  const long long* sge[PACK_READS];
+  unsigned char fcs[PACK_READS];
+#pragma unroll
+  for (int j = 0; j < PACK_READS; ++j) {
+    const long long r = rbase + j;
+    n[j] = 0;
+    dst[j] = 0;
+    stok[j] = a.tokens;
+    sgs[j] = a.gstart;
+    sge[j] = a.gend;
+    fcs[j] = RC_SKIP;
+    if (r < a.n_reads && A.keep[r]) {
+      dst[j] = A.new_off[r];
+      n[j] = a.new_len[r];
+      fcs[j] = A.final_cls[r];
+      if (fcs[j] == RC_GAPPED) {  // re-threaded read: staged in the temp area
+        const long long src = a.tmp_off[r];
+        stok[j] = a.tmp_tok + src;
+        sgs[j] = a.tmp_gs + src;
+        sge[j] = a.tmp_ge + src;
+      } else {  // untouched read, kept original, or a slice [start : end + k] of it (:1277-1285)
+        const long long src = a.read_off[r] + (fcs[j] == RC_TRIM ? a.r_start[r] : 0);
+        stok[j] = a.tokens + src;
+        sgs[j] = a.gstart + src;
+        sge[j] = a.gend + src;
       }
     }
   }
-  if (lane == 0) {
-    long long q = A.new_idx[r];
-    A.o_off[q] = dst;
-    A.o_orig[q] = (int)r;
-    unsigned char cls = A.final_cls[r];
-    A.o_changed[q] = (cls == RC_TRIM || cls == RC_GAPPED) ? 1 : 0;
-    if (a.read_len) A.o_rl[q] = a.read_len[r];
+  int vt[PACK_READS];
+  long long vs[PACK_READS], ve[PACK_READS];
+#pragma unroll
+  for (int j = 0; j < PACK_READS; ++j)
+    if (lane < n[j]) {
+      vt[j] = stok[j][lane];
+      if (a.have_pos) {
+        vs[j] = sgs[j][lane];
+        ve[j] = sge[j][lane];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < PACK_READS; ++j)
+    if (lane < n[j]) {
+      A.o_tok[dst[j] + lane] = vt[j];
+      if (a.have_pos) {
+        A.o_gs[dst[j] + lane] = vs[j];
+        A.o_ge[dst[j] + lane] = ve[j];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < PACK_READS; ++j)
+    for (long long i = 64 + lane; i < n[j]; i += 64) {  // reads longer than one wave
+      A.o_tok[dst[j] + i] = stok[j][i];
+      if (a.have_pos) {
+        A.o_gs[dst[j] + i] = sgs[j][i];
+        A.o_ge[dst[j] + i] = sge[j][i];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < PACK_READS; ++j) {
+    const long long r = rbase + j;
+    if (lane == j && r < a.n_reads && A.keep[r]) {
+      const long long q = A.new_idx[r];
+      A.o_off[q] = dst[j];
+      A.o_orig[q] = (int)r;
+      A.o_changed[q] = (fcs[j] == RC_TRIM || fcs[j] == RC_GAPPED) ? 1 : 0;
+      if (a.read_len) A.o_rl[q] = a.read_len[r];
+    }
   }
 }
 
@@ -1623,7 +1669,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   Pk.o_gs = c->have_pos ? c->c_gstart.as<long long>() : nullptr;
   Pk.o_ge = c->have_pos ? c->c_gend.as<long long>() : nullptr;
   Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
-  if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4)), dim3(256), 0, st, Pk);
+  if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
   HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
                         hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));

@@ -4,21 +4,25 @@
 #pragma once
 #include "amg_device.h"
 
-#define TILE_ITEMS 4
+#define TILE_ITEMS 8
 #define TILE_THREADS 256
 #define TILE (TILE_THREADS * TILE_ITEMS)
 
+// per-read window / short-read counts (construct_graph.py:53-55) and the read-end bitmap:
+// bit t of bnd_bits is set when a read ends (exclusively) at token t
 static __global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, int k,
-                             unsigned long long* status) {
+                                    unsigned long long* status, unsigned int* __restrict__ bnd_bits) {
   __shared__ unsigned long long s_w[4], s_s[4];
   long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long w = 0, sh = 0;
   if (r < n_reads) {
-    long long len = read_off[r + 1] - read_off[r];
+    const long long end = read_off[r + 1];
+    long long len = end - read_off[r];
     if (len >= k)
       w = (unsigned long long)(len - k + 1);
     else
       sh = 1;
+    atomicOr(&bnd_bits[end >> 5], 1u << (end & 31));
   }
   for (int d = 32; d > 0; d >>= 1) {
     w += __shfl_down(w, d, 64);
@@ -41,50 +45,42 @@ static __global__ void k_read_stats(const long long* __restrict__ read_off, long
   }
 }
 
-// tile_lo[b] = first j in [1, n_reads] with read_off[j] > b * TILE  (n_reads + 1 if none)
-static __global__ void k_tile_reads(const long long* __restrict__ read_off, long long n_reads,
-                             long long n_tiles_plus2, long long* __restrict__ tile_lo) {
-  long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_tiles_plus2) return;
-  long long target = b * (long long)TILE;
-  long long lo = 1, hi = n_reads + 1;  // search in [1, n_reads + 1)
-  while (lo < hi) {
-    long long mid = (lo + hi) >> 1;
-    if (read_off[mid] > target)
-      hi = mid;
-    else
-      lo = mid + 1;
-  }
-  tile_lo[b] = lo;
-}
-
 struct LdsView {
   const int* p;
   __device__ __forceinline__ int operator[](int j) const { return p[j]; }
 };
 
-// shared by k_node_upsert and k_edges: stage the tile's tokens and read-end flags in LDS
+// words of the read-end bitmap one tile needs: bits t0 .. t0 + TILE + 63 (t0 is a multiple of 32)
+#define TILE_BIT_WORDS (TILE / 32 + 2)
+#define BND_PAD_WORDS (TILE_BIT_WORDS + 8)  // words allocated beyond (n_tokens >> 5)
+
+// stage the tile's tokens and its slice of the read-end bitmap in LDS: two independent
+// coalesced loads and one barrier (no per-tile search, no dependent loads)
 __device__ __forceinline__ void stage_tile(const int* __restrict__ tokens,
-                                           const long long* __restrict__ read_off,
-                                           const long long* __restrict__ tile_lo,
-                                           long long n_reads, long long n_tokens, int k,
-                                           long long t0, int* s_tok, unsigned char* s_bnd) {
+                                           const unsigned int* __restrict__ bnd_bits,
+                                           long long n_tokens, int k, long long t0, int* s_tok,
+                                           unsigned int* s_bits) {
   const int tid = threadIdx.x;
-  const int span = TILE + k;  // tokens t0 .. t0 + TILE + k - 1, flags 0 .. TILE + k
+  const int span = TILE + k;  // tokens t0 .. t0 + TILE + k - 1
   for (int i = tid; i < span; i += TILE_THREADS) {
     long long t = t0 + i;
     s_tok[i] = t < n_tokens ? tokens[t] : 0;
-    s_bnd[i] = 0;
   }
-  if (tid == 0) s_bnd[span] = 0;
-  __syncthreads();
-  // read ends (exclusive) that fall in (t0, t0 + TILE + k]
-  long long b = blockIdx.x;
-  long long lo = tile_lo[b], hi = tile_lo[b + 2];
-  for (long long j = lo + tid; j < hi; j += TILE_THREADS) {
-    long long off = read_off[j] - t0;
-    if (off <= span) s_bnd[off] = 1;
-  }
+  if (tid < TILE_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
   __syncthreads();
 }
 
+// bits [pos, pos + n) of the tile's bitmap slice, n <= 32
+__device__ __forceinline__ unsigned int tile_bits(const unsigned int* s_bits, int pos, int n) {
+  const unsigned long long w =
+      (unsigned long long)s_bits[pos >> 5] | ((unsigned long long)s_bits[(pos >> 5) + 1] << 32);
+  return (unsigned int)(w >> (pos & 31)) & (unsigned int)((1ull << n) - 1ull);
+}
+// window starting at tile position i: valid when no read ends inside it (bits i+1 .. i+k-1),
+// last of its read when one ends right after it (bit i+k)
+__device__ __forceinline__ void tile_window(const unsigned int* s_bits, int i, int k, bool& inside,
+                                            bool& last) {
+  const unsigned int b = tile_bits(s_bits, i + 1, k);  // bits i+1 .. i+k
+  inside = (b & ((1u << (k - 1)) - 1u)) == 0u;
+  last = (b >> (k - 1)) & 1u;
+}
