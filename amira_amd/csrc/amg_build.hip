@@ -594,7 +594,7 @@ int bs_edges_pass(amg_ctx* c, int* which) {
   const long long T = c->n_tokens, D = c->n_nodes;
   const long long n_tiles = (T + TILE - 1) / TILE;
   unsigned long long hs[ST_WORDS];
-  if (c->edge_slots < (int64_t)pow2_at_least((uint64_t)D * 3)) c->edge_slots = pow2_at_least((uint64_t)D * 3);
+  if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
   if (!c->count_inline) AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
   stage_begin(c, "edge_table_clear");
@@ -770,12 +770,22 @@ int bs_finish_from_pairs(amg_ctx* c) {
   return AMG_OK;
 }
 
+// Slots for n expected keys.  All 64 lanes of a wave wait for the longest probe chain among
+// them, so a low load factor pays even when every probe is an L2 hit (measured on 20 000 hot
+// keys: 0.99 ms per pass at load 0.31, 0.67 ms at 0.02): 32 slots per key while that stays
+// within 4 M slots (a 64 MB table clears in ~25 us), never less than 3 per key.
+uint64_t slots_for(uint64_t n) {
+  const uint64_t lo = n * 3, hi = n * 32, cap = 4ull << 20;
+  const uint64_t want = hi < cap ? hi : cap;
+  return pow2_at_least(want > lo ? want : lo);
+}
+
 // table sizing: previous distinct-node count when known, otherwise the window bound
 void bs_size_tables(amg_ctx* c) {
   // no history: a quarter of a slot per token.  Real gene-call data repeat every gene-mer tens to
   // thousands of times, so this is already generous; inputs with more distinct gene-mers than
   // that overflow once (cheaply, see table_upsert's abort flag) and are rebuilt 4x larger.
-  uint64_t want = c->node_hint > 0 ? (uint64_t)c->node_hint * 3 : (uint64_t)c->n_tokens / 4;
+  uint64_t want = c->node_hint > 0 ? slots_for((uint64_t)c->node_hint) : (uint64_t)c->n_tokens / 4;
   c->node_slots = (int64_t)pow2_at_least(want);
   if (c->node_slots > (1ll << 30)) c->node_slots = 1ll << 30;
   c->edge_slots = 1024;

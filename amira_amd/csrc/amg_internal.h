@@ -208,6 +208,7 @@ void stages_reset(amg_ctx* c);
 
 // build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
 uint64_t pow2_at_least(uint64_t x);
+uint64_t slots_for(uint64_t n_keys);
 void bs_size_tables(amg_ctx* c);
 int bs_read_stats(amg_ctx* c, int k);
 int bs_nodes_pass(amg_ctx* c, int k, int* which);

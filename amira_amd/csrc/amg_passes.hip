@@ -1203,9 +1203,10 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
 
 
 // ---- fast path: M <= 64 original genes, N <= 128 corrected genes.  One wave per read, no
-// workgroup barriers: lane j owns column j of the DP matrix and the wave sweeps anti-diagonals
-// systolically — F[i-1,j] stays in the lane's own register, F[i,j-1] / F[i-1,j-1] arrive from
-// lane j-1 by shuffle.  Pointers are packed 2 bits per cell (16 rows per LDS word per lane).
+// workgroup barriers: lane j owns column j of the DP matrix and the wave computes one row per
+// step — F[i-1,j] stays in the lane's own register, F[i-1,j-1] arrives from lane j-1 by a DPP
+// shift, the dependency along the row is a prefix maximum (DPP scan).  Pointers are packed
+// 2 bits per cell (16 rows per LDS word per lane).
 
 __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   __shared__ unsigned int s_ptr[4][(NWF_MAX_N / 16) * 64];
@@ -1220,8 +1221,9 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   const long long r = A.gapped_reads[gi];
   if (A.final_cls[r] == RC_KEEP_ORIG) return;
   const long long t0 = a.read_off[r];
-  const int M = (int)(a.read_off[r + 1] - t0);
-  const int N = (int)a.new_len[r];
+  // wave-uniform by construction; tell the compiler so that loop control stays scalar
+  const int M = __builtin_amdgcn_readfirstlane((int)(a.read_off[r + 1] - t0));
+  const int N = __builtin_amdgcn_readfirstlane((int)a.new_len[r]);
   if (!nw_fast_ok(N, M)) return;  // k_corr_nw handles it
   const long long dst = a.tmp_off[r];
   unsigned int* P = s_ptr[wv];
@@ -1229,39 +1231,45 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   unsigned char* ops = s_ops[wv];
   long long* GS = s_gs[wv];
   long long* GE = s_ge[wv];
-  for (int i = lane; i < N; i += 64) X[i] = a.tmp_tok[dst + i];
+  const int x0 = lane < N ? a.tmp_tok[dst + lane] : -2;            // corrected genes 0..63
+  const int x1 = lane + 64 < N ? a.tmp_tok[dst + lane + 64] : -2;  // and 64..127, one per lane
+  if (lane < N) X[lane] = x0;
+  if (lane + 64 < N) X[lane + 64] = x1;
   const int yj = lane < M ? a.tokens[t0 + lane] : -1;
   wave_sync();
-  // ---- fill.  Lane j owns column j; before it becomes active its registers hold the top
-  // border F[-1, j] = -j, so row 0 needs no special case; the left border F[i, -1] = -i enters
-  // lane 0 as the `old` operand of the DPP wave shift that brings every other lane its
-  // neighbour's value (one VALU op instead of an LDS permute).
-  int prev1 = -lane, prev2 = -lane;  // this lane's value one / two steps ago
+  // ---- fill, one matrix ROW per step (N steps instead of the N + M - 1 anti-diagonals of a
+  // systolic sweep, which also idles half the lanes while it ramps up and down).  Lane j owns
+  // column j and keeps F[i-1, j].  With c_j = max(F[i-1,j-1] + match, F[i-1,j] - 1) the row is
+  //   F[i, j] = max(c_j, F[i, j-1] - 1) = max_{k <= j} (c_k + k) - j   (F[i,-1] = -i enters as k = -1)
+  // i.e. a prefix maximum over the lanes: six DPP steps.  The pointer follows from the three
+  // candidates with the reference's tie order UP (0,-1) > LEFT (-1,0) > DIAG.
+  int Fp = -lane;  // F[-1, j] = -j
   unsigned int acc = 0;
-  const int n_steps = N + M - 1;
-  for (int s = 0; s < n_steps; ++s) {
-    const int i = s - lane;
-    // lane 0 (i == s): F[i, -1] = -s and F[i-1, -1] = -(s-1), with F[-1, -1] = 0
-    const int l1 = __builtin_amdgcn_update_dpp(-s, prev1, 0x138, 0xf, 0xf, false);                 // F[i, j-1]
-    const int l2 = __builtin_amdgcn_update_dpp(s == 0 ? 0 : 1 - s, prev2, 0x138, 0xf, 0xf, false);  // F[i-1, j-1]
-    const bool active = (lane < M) && i >= 0 && i < N;
-    int best = prev1;
-    if (active) {
-      const int s_d = l2 + (X[i] == yj ? 1 : 0);
-      const int s_l = prev1 - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
-      const int s_u = l1 - 1;     // from F[i, j-1]: pointer UP   = (0, -1)
-      best = s_d;
-      unsigned int ptr = 0;
-      if (s_l >= best) { best = s_l; ptr = 1; }
-      if (s_u >= best) { best = s_u; ptr = 2; }
-      acc |= ptr << ((i & 15) * 2);
-      if ((i & 15) == 15 || i == N - 1) {
-        P[(i >> 4) * 64 + lane] = acc;
-        acc = 0;
-      }
+  for (int i = 0; i < N; ++i) {
+    const int xi = i < 64 ? __builtin_amdgcn_readlane(x0, i) : __builtin_amdgcn_readlane(x1, i - 64);
+    // F[i-1, j-1]; lane 0 takes the border F[i-1, -1] = -(i-1), F[-1,-1] = 0
+    const int fd = __builtin_amdgcn_update_dpp(i == 0 ? 0 : 1 - i, Fp, 0x138, 0xf, 0xf, false);
+    const int s_d = fd + (xi == yj ? 1 : 0);
+    const int s_l = Fp - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
+    const int c = s_d > s_l ? s_d : s_l;
+    int g = c + lane;
+    const int ID = (int)0x80000000;
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    const int Fc = max(g, -i - 1) - lane;  // F[i, j]
+    // F[i, j-1] - 1: pointer UP = (0, -1); lane 0 takes the border F[i, -1] = -i
+    const int s_u = __builtin_amdgcn_update_dpp(-i, Fc, 0x138, 0xf, 0xf, false) - 1;
+    const unsigned int ptr = s_u >= c ? 2u : (s_l >= s_d ? 1u : 0u);
+    acc |= ptr << ((i & 15) * 2);
+    if ((i & 15) == 15 || i == N - 1) {
+      P[(i >> 4) * 64 + lane] = acc;
+      acc = 0;
     }
-    prev2 = prev1;
-    prev1 = best;
+    Fp = Fc;
   }
   wave_sync();
   // ---- traceback (lane 0), ops back to front

@@ -4,7 +4,7 @@
 #pragma once
 #include "amg_device.h"
 
-#define TILE_ITEMS 8
+#define TILE_ITEMS 4
 #define TILE_THREADS 256
 #define TILE (TILE_THREADS * TILE_ITEMS)
 
