@@ -77,7 +77,9 @@ __device__ __forceinline__ int x_unpack(unsigned long long w1, unsigned int tag,
 // empty -> w1 -> tag -> id, each step once: a cached view that already shows a complete foreign
 // key, or our key with its id, is final and is trusted (no fabric transaction: agent-scope
 // loads cost one 64-byte fabric request each, ~100 G/s, atomics ~27 G/s, L2 hits ~255 G/s).
-// Anything less (empty, tag or id missing) is re-read with agent scope before acting on it.
+// Anything less (empty, tag or id missing) is settled by the CAS itself or by an agent-scope
+// re-read of w2.  (Serving the first tiles from a separate launch with agent-scope loads only,
+// so that no L2 caches a hot slot before it is complete, was measured and bought nothing.)
 // A CAS on w1 takes the slot.  TWO: the key has a second word (tag), set by a second CAS by
 // whichever thread needs it first; that thread owns the slot ("created").
 // Returns the slot or -1; id1 = claim id + 1 if already published.
@@ -86,7 +88,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
                                               unsigned long long w1, unsigned int tag,
                                               unsigned long long idx, ulonglong2 v,
                                               unsigned int limit, const unsigned long long* abort_flag,
-                                              unsigned int& id1, bool& created, bool coherent) {
+                                              unsigned int& id1, bool& created) {
   created = false;
   id1 = 0;
   unsigned int probes = 0;
@@ -142,7 +144,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
       return -1;
     ++probes;
     idx = (idx + 1) & mask;
-    v = coherent ? ld_slot(tab + idx) : *reinterpret_cast<const ulonglong2*>(tab + idx);
+    v = *reinterpret_cast<const ulonglong2*>(tab + idx);
   }
 }
 
@@ -220,13 +222,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
     int bits, Slot16* tab, unsigned long long mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
     unsigned int* first_by_claim, unsigned int* first_init, unsigned int* __restrict__ slot_by_claim,
-    int ablate, unsigned int tile0, int coherent_i) {
-  const bool coherent = coherent_i != 0;
+    int ablate) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
-  const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  const long long t0 = (long long)blockIdx.x * TILE;
   stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
   const int flip = two_v - 1;
   unsigned long long w1[TILE_ITEMS], idx[TILE_ITEMS];
@@ -263,8 +264,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
   // first probe of every window in flight before any of them is examined
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it))
-      v[it] = coherent ? ld_slot(tab + idx[it]) : *reinterpret_cast<const ulonglong2*>(tab + idx[it]);
+    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(tab + idx[it]);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
       made = false;
     } else
     slot[it] = x_upsert<TWO>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
-                              status + ST_OVERFLOW, id1[it], made, coherent);
+                              status + ST_OVERFLOW, id1[it], made);
     if (slot[it] < 0) status[ST_OVERFLOW] = 1;
     if (made) created |= 1u << it;
   }
@@ -327,14 +327,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
     unsigned long long emask, unsigned int probe_limit, unsigned long long* status,
     int* __restrict__ tok_pair, unsigned int* first_by_claim, unsigned int* first_init,
-    unsigned int* __restrict__ slot_by_claim, unsigned int tile0, int coherent_i) {
-  const bool coherent = coherent_i != 0;
+    unsigned int* __restrict__ slot_by_claim) {
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
   __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
-  const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  const long long t0 = (long long)blockIdx.x * TILE;
   for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
     const long long t = t0 + i;
     int raw = -1;
@@ -375,14 +374,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
   }
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it))
-      v[it] = coherent ? ld_slot(etab + idx[it]) : *reinterpret_cast<const ulonglong2*>(etab + idx[it]);
+    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(etab + idx[it]);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
     bool made;
     slot[it] = x_upsert<false>(etab, emask, key[it], 0u, idx[it], v[it], probe_limit,
-                               status + ST_OVERFLOW, id1[it], made, coherent);
+                               status + ST_OVERFLOW, id1[it], made);
     if (slot[it] < 0) status[ST_OVERFLOW] = 2;
     if (made) created |= 1u << it;
   }
@@ -417,14 +415,6 @@ static inline unsigned int blocks_for(long long n, int per) {
 }
 
 static const unsigned int kProbeLimitX = 1024;
-
-// tiles of the warm-up launch: ~1/32 of the input, at least one full wave of blocks
-static long long x_warm_tiles(long long n_tiles, int ablate) {
-  if (ablate & 32) return 0;  // timing experiment: single launch
-  long long w = n_tiles / 32;
-  if (w < 2048) w = 2048;
-  return w < n_tiles ? w : n_tiles;
-}
 
 static int read_status(amg_ctx* c, unsigned long long* host) {
   HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -476,25 +466,12 @@ int bx_nodes(amg_ctx* c, int k, int* which) {
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
     auto kern = (long long)k * c->x_bits > 63 ? k_nodes_x<true> : k_nodes_x<false>;  // tuple spills into w2?
-    // Two launches.  The first few tiles create the frequently hit (genome) keys; they use
-    // agent-scope loads only.  At the kernel boundary every L2 drops what it cached meanwhile,
-    // so the main launch, which trusts cached slot views, starts from slots that are final:
-    // in a single launch the lines an XCD fetched before a hot key got its id stay in that L2
-    // — hot lines are never evicted — and every later window of the key pays the agent-scope
-    // re-read (measured on an error-free stream: 0.96 ms against 0.67 ms).
-    const long long warm = x_warm_tiles(n_tiles, ablate);
-    for (int part = 0; part < 2; ++part) {
-      const long long first = part == 0 ? 0 : warm, count = part == 0 ? warm : n_tiles - warm;
-      if (count <= 0) continue;
-      const int coherent = (part == 0 || (ablate & 16)) ? 1 : 0;
-      hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
-                         c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
-                         c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                         c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                         c->x_first.as<unsigned int>() + max_claims, c->x_slot.as<unsigned int>(), ablate,
-                         (unsigned int)first, coherent);
-    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                       c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
+                       c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
+                       c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                       c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                       c->x_first.as<unsigned int>() + max_claims, c->x_slot.as<unsigned int>(), ablate);
   }
   AMGCHK(read_status(c, hs));
   stage_end(c);
@@ -552,19 +529,13 @@ int bx_edges(amg_ctx* c, int* which) {
   HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
   stage_end(c);
   stage_begin(c, "edge_upsert");
-  if (n_tiles > 0) {
-    const long long warm = x_warm_tiles(n_tiles, 0);  // see bx_nodes
-    for (int part = 0; part < 2; ++part) {
-      const long long first = part == 0 ? 0 : warm, count = part == 0 ? warm : n_tiles - warm;
-      if (count <= 0) continue;
-      hipLaunchKernelGGL(k_edges_x, dim3((unsigned)count), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
-                         c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
-                         c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
-                         c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                         c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
-                         c->x_eslot.as<unsigned int>(), (unsigned int)first, part == 0 ? 1 : 0);
-    }
-  }
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
+                       c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
+                       c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
+                       c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
+                       c->x_eslot.as<unsigned int>());
   AMGCHK(read_status(c, hs));
   stage_end(c);
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");

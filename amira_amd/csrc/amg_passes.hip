@@ -1084,8 +1084,14 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
 #define NW_LDS_N 1024       // rows kept in LDS (rolling anti-diagonals, op list)
 #define NW_LDS_CELLS 16384  // pointer-matrix cells kept in LDS (one byte each)
 
+struct __attribute__((aligned(16))) NwRec {
+  int r, M, N, pad;
+  long long t0, dst;
+};
+
 struct NwArgs {
   CorrArgs a;
+  const NwRec* rec;  // per gapped read, written by k_nw_sizes
   const int* gapped_reads;
   long long n_gapped;
   const unsigned char* final_cls;
@@ -1209,84 +1215,120 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
 // 2 bits per cell (16 rows per LDS word per lane).
 
 __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
-  __shared__ unsigned int s_ptr[4][(NWF_MAX_N / 16) * 64];
   __shared__ int s_x[4][NWF_MAX_N];
-  __shared__ unsigned char s_ops[4][NWF_MAX_N + NWF_MAX_M];
+  __shared__ unsigned int s_opw[4][(NWF_MAX_N + NWF_MAX_M) / 16 + 1];  // alignment ops, 2 bits each
   __shared__ long long s_gs[4][NWF_MAX_N];
   __shared__ long long s_ge[4][NWF_MAX_N];
+  __shared__ long long s_ogs[4][NWF_MAX_M];  // positions of the original genes
+  __shared__ long long s_oge[4][NWF_MAX_M];
   const CorrArgs& a = A.a;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long gi = (long long)blockIdx.x * 4 + wv;
   if (gi >= A.n_gapped) return;
-  const long long r = A.gapped_reads[gi];
-  if (A.final_cls[r] == RC_KEEP_ORIG) return;
-  const long long t0 = a.read_off[r];
+  // The kernel is bound by its chain of dependent global loads (one wave per read, ~15 us per
+  // wave at full occupancy), not by the fill: one record load, then every per-gene load of the
+  // read in one batch (the original positions included: the carry-over below reads them from
+  // LDS), then only stores.
+  const NwRec q = A.rec[gi];
   // wave-uniform by construction; tell the compiler so that loop control stays scalar
-  const int M = __builtin_amdgcn_readfirstlane((int)(a.read_off[r + 1] - t0));
-  const int N = __builtin_amdgcn_readfirstlane((int)a.new_len[r]);
-  if (!nw_fast_ok(N, M)) return;  // k_corr_nw handles it
-  const long long dst = a.tmp_off[r];
-  unsigned int* P = s_ptr[wv];
+  const int N = __builtin_amdgcn_readfirstlane(q.N);
+  if (N == 0) return;  // original genes kept, or a read for k_corr_nw
+  const int M = __builtin_amdgcn_readfirstlane(q.M);
+  const long long r = q.r, t0 = q.t0, dst = q.dst;
   int* X = s_x[wv];
-  unsigned char* ops = s_ops[wv];
+  unsigned int* OPW = s_opw[wv];
   long long* GS = s_gs[wv];
   long long* GE = s_ge[wv];
+  long long* OGS = s_ogs[wv];
+  long long* OGE = s_oge[wv];
   const int x0 = lane < N ? a.tmp_tok[dst + lane] : -2;            // corrected genes 0..63
   const int x1 = lane + 64 < N ? a.tmp_tok[dst + lane + 64] : -2;  // and 64..127, one per lane
+  const int yj = lane < M ? a.tokens[t0 + lane] : -1;
+  const long long ogs = lane < M ? a.gstart[t0 + lane] : 0;
+  const long long oge = lane < M ? a.gend[t0 + lane] : 0;
   if (lane < N) X[lane] = x0;
   if (lane + 64 < N) X[lane + 64] = x1;
-  const int yj = lane < M ? a.tokens[t0 + lane] : -1;
-  wave_sync();
+  OGS[lane] = ogs;
+  OGE[lane] = oge;
   // ---- fill, one matrix ROW per step (N steps instead of the N + M - 1 anti-diagonals of a
   // systolic sweep, which also idles half the lanes while it ramps up and down).  Lane j owns
   // column j and keeps F[i-1, j].  With c_j = max(F[i-1,j-1] + match, F[i-1,j] - 1) the row is
   //   F[i, j] = max(c_j, F[i, j-1] - 1) = max_{k <= j} (c_k + k) - j   (F[i,-1] = -i enters as k = -1)
   // i.e. a prefix maximum over the lanes: six DPP steps.  The pointer follows from the three
-  // candidates with the reference's tie order UP (0,-1) > LEFT (-1,0) > DIAG.
+  // candidates with the reference's tie order UP (0,-1) > LEFT (-1,0) > DIAG.  Pointers stay in
+  // registers: 2 bits per cell, word b of lane j = rows 16b .. 16b+15 of column j.
   int Fp = -lane;  // F[-1, j] = -j
-  unsigned int acc = 0;
-  for (int i = 0; i < N; ++i) {
-    const int xi = i < 64 ? __builtin_amdgcn_readlane(x0, i) : __builtin_amdgcn_readlane(x1, i - 64);
-    // F[i-1, j-1]; lane 0 takes the border F[i-1, -1] = -(i-1), F[-1,-1] = 0
-    const int fd = __builtin_amdgcn_update_dpp(i == 0 ? 0 : 1 - i, Fp, 0x138, 0xf, 0xf, false);
-    const int s_d = fd + (xi == yj ? 1 : 0);
-    const int s_l = Fp - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
-    const int c = s_d > s_l ? s_d : s_l;
-    int g = c + lane;
-    const int ID = (int)0x80000000;
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
-    const int Fc = max(g, -i - 1) - lane;  // F[i, j]
-    // F[i, j-1] - 1: pointer UP = (0, -1); lane 0 takes the border F[i, -1] = -i
-    const int s_u = __builtin_amdgcn_update_dpp(-i, Fc, 0x138, 0xf, 0xf, false) - 1;
-    const unsigned int ptr = s_u >= c ? 2u : (s_l >= s_d ? 1u : 0u);
-    acc |= ptr << ((i & 15) * 2);
-    if ((i & 15) == 15 || i == N - 1) {
-      P[(i >> 4) * 64 + lane] = acc;
-      acc = 0;
+  unsigned int ptrs[NWF_MAX_N / 16];
+#pragma unroll
+  for (int blk = 0; blk < NWF_MAX_N / 16; ++blk) {
+    unsigned int acc = 0;
+    const int iend = N < blk * 16 + 16 ? N : blk * 16 + 16;
+    for (int i = blk * 16; i < iend; ++i) {
+      const int xi = blk < 4 ? __builtin_amdgcn_readlane(x0, i) : __builtin_amdgcn_readlane(x1, i - 64);
+      // F[i-1, j-1]; lane 0 takes the border F[i-1, -1] = -(i-1), F[-1,-1] = 0
+      const int fd = __builtin_amdgcn_update_dpp(i == 0 ? 0 : 1 - i, Fp, 0x138, 0xf, 0xf, false);
+      const int s_d = fd + (xi == yj ? 1 : 0);
+      const int s_l = Fp - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
+      const int c = s_d > s_l ? s_d : s_l;
+      int g = c + lane;
+      const int ID = (int)0x80000000;
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
+      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
+      const int Fc = max(g, -i - 1) - lane;  // F[i, j]
+      // F[i, j-1] - 1: pointer UP = (0, -1); lane 0 takes the border F[i, -1] = -i
+      const int s_u = __builtin_amdgcn_update_dpp(-i, Fc, 0x138, 0xf, 0xf, false) - 1;
+      const unsigned int ptr = s_u >= c ? 2u : (s_l >= s_d ? 1u : 0u);
+      acc |= ptr << ((i & 15) * 2);
+      Fp = Fc;
     }
-    Fp = Fc;
+    ptrs[blk] = acc;
   }
-  wave_sync();
-  // ---- traceback (lane 0), ops back to front
+  // ---- traceback on the scalar unit: i, j and the ops are wave-uniform, a pointer is one
+  // v_readlane away (no LDS round trip per step).  Ops are collected back to front, 16 per word.
   int n_ops = 0;
-  if (lane == 0) {
+  {
     int i = N - 1, j = M - 1;
-    while (i >= 0 && j >= 0) {
-      unsigned int p = (P[(i >> 4) * 64 + j] >> ((i & 15) * 2)) & 3u;
-      ops[n_ops++] = (unsigned char)p;
-      if (p == 0) { --i; --j; }
-      else if (p == 1) --i;
-      else --j;
+    unsigned int pack = 0;
+#pragma unroll
+    for (int blk = NWF_MAX_N / 16 - 1; blk >= 0; --blk) {
+      while (i >= blk * 16 && j >= 0) {
+        const unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)ptrs[blk], j);
+        const unsigned int p = (w >> ((i & 15) * 2)) & 3u;
+        pack |= p << ((n_ops & 15) * 2);
+        if ((n_ops & 15) == 15) {
+          if (lane == 0) OPW[n_ops >> 4] = pack;
+          pack = 0;
+        }
+        ++n_ops;
+        if (p == 0) { --i; --j; }
+        else if (p == 1) --i;
+        else --j;
+      }
     }
-    while (i >= 0) { ops[n_ops++] = 1; --i; }
-    while (j >= 0) { ops[n_ops++] = 2; --j; }
+    while (i >= 0) {  // leading corrected genes: LEFT
+      pack |= 1u << ((n_ops & 15) * 2);
+      if ((n_ops & 15) == 15) {
+        if (lane == 0) OPW[n_ops >> 4] = pack;
+        pack = 0;
+      }
+      ++n_ops;
+      --i;
+    }
+    while (j >= 0) {  // leading original genes: UP
+      pack |= 2u << ((n_ops & 15) * 2);
+      if ((n_ops & 15) == 15) {
+        if (lane == 0) OPW[n_ops >> 4] = pack;
+        pack = 0;
+      }
+      ++n_ops;
+      --j;
+    }
+    if ((n_ops & 15) != 0 && lane == 0) OPW[n_ops >> 4] = pack;
   }
-  n_ops = __shfl(n_ops, 0, 64);
   wave_sync();
   // ---- positions, in parallel over the alignment columns (front to back)
   const long long NONE = (long long)0x8000000000000000ull;
@@ -1294,7 +1336,8 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   for (int c0 = 0; c0 < n_ops; c0 += 64) {
     const int f = c0 + lane;
     const bool in = f < n_ops;
-    const unsigned char op = in ? ops[n_ops - 1 - f] : 3;
+    const int g = in ? n_ops - 1 - f : 0;
+    const unsigned int op = in ? (OPW[g >> 4] >> ((g & 15) * 2)) & 3u : 3u;
     const bool isx = in && (op == 0 || op == 1), isy = in && (op == 0 || op == 2);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long bx = __ballot(isx), by = __ballot(isy);
@@ -1305,8 +1348,8 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
     const unsigned long long bc = __ballot(inc);
     const int cur = base_cur + __popcll(bc & lt);
     if (isx) {
-      GS[xi] = match ? a.gstart[t0 + cur] : NONE;
-      GE[xi] = match ? a.gend[t0 + cur] : NONE;
+      GS[xi] = match ? OGS[cur < NWF_MAX_M ? cur : 0] : NONE;
+      GE[xi] = match ? OGE[cur < NWF_MAX_M ? cur : 0] : NONE;
     }
     base_x += __popcll(bx);
     base_y += __popcll(by);
@@ -1451,12 +1494,25 @@ __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const lo
 // global NW scratch size of gapped read gi (0 when it fits the LDS path)
 __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
                            const long long* __restrict__ read_off, const unsigned int* __restrict__ new_len,
+                           const long long* __restrict__ tmp_off,
                            const unsigned char* __restrict__ final_cls, long long* __restrict__ size,
-                           int allow_fast, unsigned long long* n_general) {
+                           int allow_fast, unsigned long long* n_general, NwRec* __restrict__ rec) {
   long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= n_gapped) return;
   long long r = gapped[gi];
   long long N = new_len[r], M = read_off[r + 1] - read_off[r];
+  {
+    // everything k_corr_nw_fast needs to start, in one 32-byte record (instead of a chain of
+    // dependent per-read loads at the head of a latency-bound kernel)
+    NwRec q;
+    q.r = (int)r;
+    q.M = (int)(M > 0x7fffffff ? 0x7fffffff : M);
+    q.N = (final_cls[r] != RC_KEEP_ORIG && allow_fast && nw_fast_ok(N, M)) ? (int)N : 0;  // 0: not for the fast kernel
+    q.pad = 0;
+    q.t0 = read_off[r];
+    q.dst = tmp_off[r];
+    rec[gi] = q;
+  }
   bool small = (N <= NW_LDS_N && M <= NW_LDS_N && N * M <= NW_LDS_CELLS);
   long long bytes = 0;
   if (!small && final_cls[r] != RC_KEEP_ORIG)
@@ -1618,8 +1674,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       const int allow_fast = !(nfn && nfn[0] == '1');
       unsigned long long* n_general_d = c->status.as<unsigned long long>() + ST_MISC;
       HIPCHK(hipMemsetAsync(n_general_d, 0, sizeof(unsigned long long), st));
+      AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
       hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
-                         n_gapped, a.read_off, new_len, final_cls, nw_size, allow_fast, n_general_d);
+                         n_gapped, a.read_off, new_len, tmp_off, final_cls, nw_size, allow_fast, n_general_d,
+                         c->nw_rec.as<NwRec>());
       AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
       long long big_total = 0;
       unsigned long long n_general = 0;
@@ -1630,6 +1688,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       AMGCHK(big.ensure((size_t)big_total + 64));
       NwArgs W;
       W.a = a;
+      W.rec = c->nw_rec.as<NwRec>();
       W.gapped_reads = c->c_orig.as<int>();
       W.n_gapped = n_gapped;
       W.final_cls = final_cls;
