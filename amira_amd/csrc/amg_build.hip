@@ -292,11 +292,22 @@ __global__ void k_row_offsets(const unsigned int* __restrict__ keys, long long n
 }
 
 // ------------------------------------------------------------------ components
+// Union-find with parent[x] <= x.  Only the hook (a root gets a smaller parent) is an atomic;
+// every other access is a PLAIN load or store that the issuing XCD's L2 may serve stale.  That
+// is safe: a node's parent only ever moves to another member of its set with a smaller id, a
+// stale value is an older such ancestor, and a node that has been hooked never becomes a root
+// again — so a walk over stale parents still ends at a member of the set, a hook attempted on a
+// node that only LOOKED like a root fails and returns the truth, and a path-halving store can
+// at worst undo some compression.  (With agent-scope loads and atomicMin halving every step was
+// a fabric transaction: 0.8 ms for 6.3 M pairs.)
+__device__ __forceinline__ int uf_ld(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // plain load, never hoisted
+}
 __device__ __forceinline__ int uf_find(int* parent, int x) {
-  int p = ld_i32(parent + x);
+  int p = uf_ld(parent + x);
   while (p != x) {
-    int g = ld_i32(parent + p);
-    if (g != p) atomicMin(parent + x, g);  // path halving (monotone: only ever lowers)
+    const int g = uf_ld(parent + p);
+    if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // halving
     x = p;
     p = g;
   }
@@ -353,21 +364,33 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
 // the LOW ids and a few ranges absorb almost every increment.  Every sweep also counts the
 // ids that lie beyond its range (state[r]); the next sweep reads that number and, when at
 // most 1/8 of the array is left, finishes the job with global atomics (27 G/s, cheaper than
-// further 4-byte-per-id sweeps at that point); sweeps after that find state == 0 and exit.
+// further 4-byte-per-id sweeps at that point); sweeps after that see its done flag and exit.
+// The first sweep takes the same decision from what the first sweep of the PREVIOUS count of
+// this kind left behind (hint = {beyond, n}; rebuilds of a cleaning sweep look alike).
 // With GATHER the array holds table slots on entry and is rewritten to dense ids
 // (tab[slot].id) during the first sweep.
 #define HOT_IDS 32768
+#define COUNT_MAX_SWEEPS 4
+// state: [0..3] ids beyond the range of sweep r, [4..7] sweep r finished the job
 template <bool GATHER>
 __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long long n,
                                                     const Slot* __restrict__ tab, long long lo,
                                                     int sweep, int last, unsigned long long* state,
-                                                    unsigned int* __restrict__ out) {
+                                                    unsigned long long* hint, unsigned int* __restrict__ out) {
   __shared__ unsigned int s_cnt[HOT_IDS];
   bool tail_all = last != 0;
   if (sweep > 0) {
+    for (int q = 0; q < sweep; ++q)
+      if (state[COUNT_MAX_SWEEPS + q]) return;  // an earlier sweep already finished
     const unsigned long long left = state[sweep - 1];
-    if (left == 0ull) return;  // an earlier sweep already finished (state[sweep] stays 0)
+    if (sweep == 1 && blockIdx.x == 0 && threadIdx.x == 0) {  // what the next count of this kind starts from
+      hint[0] = left;
+      hint[1] = (unsigned long long)n;
+    }
+    if (left == 0ull) return;
     if (left * 8ull <= (unsigned long long)n) tail_all = true;
+  } else if (hint[1] != 0ull && hint[0] * 8ull <= hint[1]) {
+    tail_all = true;
   }
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) s_cnt[i] = 0;
   __syncthreads();
@@ -382,17 +405,16 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
     if (id < 0) continue;
     const long long rel = (long long)id - lo;
     if (rel < 0) continue;
-    if (rel < HOT_IDS)
+    if (rel < HOT_IDS) {
       atomicAdd(&s_cnt[rel], 1u);
-    else if (tail_all)
-      atomicAdd(&out[id], 1u);
-    else
+    } else {
       ++beyond;
+      if (tail_all) atomicAdd(&out[id], 1u);
+    }
   }
-  if (!tail_all) {
-    for (int d = 32; d > 0; d >>= 1) beyond += __shfl_down(beyond, d, 64);
-    if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
-  }
+  for (int d = 32; d > 0; d >>= 1) beyond += __shfl_down(beyond, d, 64);
+  if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
+  if (tail_all && blockIdx.x == 0 && threadIdx.x == 0) state[COUNT_MAX_SWEEPS + sweep] = 1ull;
   __syncthreads();
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) {
     const unsigned int cnt = s_cnt[i];
@@ -400,16 +422,19 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   }
 }
 
-// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids
-#define COUNT_MAX_SWEEPS 4
+// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
-              unsigned int* out) {
+              unsigned int* out, int kind) {
   hipStream_t st = c->stream;
   HIPCHK(hipMemsetAsync(out, 0, (size_t)(n_ids + 1) * sizeof(unsigned int), st));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
-  AMGCHK(c->cnt_state.ensure(COUNT_MAX_SWEEPS * sizeof(unsigned long long)));
+  if (!c->cnt_state.p) {
+    AMGCHK(c->cnt_state.ensure((2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(c->cnt_state.p, 0, (2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long), st));
+  }
   unsigned long long* state = c->cnt_state.as<unsigned long long>();
-  HIPCHK(hipMemsetAsync(state, 0, COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
+  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * (kind ? 1 : 0);
+  HIPCHK(hipMemsetAsync(state, 0, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
   if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
   long long want_blocks = (n + 1023) / 1024;
@@ -419,10 +444,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
     const int last = (r == ranges - 1) ? 1 : 0;
     if (gather_tab && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, out);
+                         (int)r, last, state, hint, out);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, out);
+                         (int)r, last, state, hint, out);
   }
   return AMG_OK;
 }
@@ -445,7 +470,7 @@ __global__ void k_slots_to_ids(const int* __restrict__ slots, long long n, const
 // dense ids in first-seen order (slot_sorted), the per-window slots are turned into ids
 // (ids_scratch may alias slots) and counted by k_count_ids.  out[i] = count of entry i.
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
-                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out) {
+                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out, int kind) {
   hipStream_t st = c->stream;
   if (n_ids > 0)
     hipLaunchKernelGGL(k_set_pair_ids, dim3((unsigned)((n_ids + 255) / 256)), dim3(256), 0, st, slot_sorted,
@@ -453,7 +478,7 @@ int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n
   if (n > 0)
     hipLaunchKernelGGL(k_slots_to_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slots, n, tab,
                        ids_scratch);
-  return count_ids(c, ids_scratch, n, nullptr, n_ids, out);
+  return count_ids(c, ids_scratch, n, nullptr, n_ids, out, kind);
 }
 
 // ------------------------------------------------------------------ host orchestration
@@ -638,7 +663,7 @@ int bs_edges_pass(amg_ctx* c, int* which) {
   if (!c->count_inline && !c->dist_mode) {
     // node coverage (construct_node.py:33-36) from the per-window node ids
     stage_begin(c, "node_count");
-    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>()));
+    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
     stage_end(c);
   }
   return AMG_OK;
@@ -672,7 +697,7 @@ int bs_pairs_from_local(amg_ctx* c) {
     hipLaunchKernelGGL(k_set_pair_ids, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                        c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot>());
     AMGCHK(count_ids(c, c->tok_pair.as<int>(), c->n_tokens, c->edge_tab.as<Slot>(), P,
-                     c->pair_cnt.as<unsigned int>()));
+                     c->pair_cnt.as<unsigned int>(), 1));
     stage_end(c);
   }
   return AMG_OK;

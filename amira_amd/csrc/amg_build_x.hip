@@ -548,12 +548,12 @@ int bx_edges(amg_ctx* c, int* which) {
 
   // node coverage (construct_node.py:33-36) from the per-window node ids
   stage_begin(c, "node_count");
-  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>()));
+  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
   stage_end(c);
   // edge-class coverage per claim
   stage_begin(c, "edge_count");
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>()));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
   stage_end(c);
 
   stage_begin(c, "edge_rank");

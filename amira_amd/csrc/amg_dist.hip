@@ -147,7 +147,7 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
     AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
     AMGCHK(bs_count_by_slot(c, c->tok_slot.as<int>(), c->tok_node.as<int>(), c->n_tokens,
                             c->node_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
-                            c->dist_lcnt.as<unsigned int>()));
+                            c->dist_lcnt.as<unsigned int>(), 0));
   }
   AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
   unsigned int* dest = c->dist_a.as<unsigned int>();
@@ -493,7 +493,7 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
     AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
     AMGCHK(bs_count_by_slot(c, c->tok_pair.as<int>(), c->tok_pair.as<int>(), c->n_tokens,
                             c->edge_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
-                            c->dist_lcnt.as<unsigned int>()));
+                            c->dist_lcnt.as<unsigned int>(), 1));
   }
   AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
   unsigned int* dest = c->dist_a.as<unsigned int>();

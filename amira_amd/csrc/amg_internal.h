@@ -188,7 +188,7 @@ struct amg_ctx {
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
-  DevBuf cnt_state;    // unsigned long long[4]: ids left after each counting sweep
+  DevBuf cnt_state;    // counting sweeps: per-sweep left-over counts and done flags + the hints
 
   std::vector<StageTime> stages;
   bool timing = true;
@@ -223,9 +223,9 @@ bool bx_applicable(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
 int bx_edges(amg_ctx* c, int* which);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
-              unsigned int* out);
+              unsigned int* out, int kind);
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
-                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out);
+                     const unsigned int* slot_sorted, long long n_ids, unsigned int* out, int kind);
 
 static inline int ilog2_ceil(uint64_t x) {
   int b = 0;
