@@ -795,8 +795,8 @@ __device__ __forceinline__ bool nw_fast_ok(long long N, long long M) {
 // DFS order, same product order, same comparisons).
 #define GF_MAXW 128     // windows per read
 #define GF_MAXGAP 16    // None runs per read
-#define GF_POOL 512     // ints of path records per read
-#define GF_CAND 192     // nodes of a candidate
+#define GF_POOL 384     // ints of path records per read
+#define GF_CAND 136     // nodes of a candidate (LDS of the block stays under 20 KB: 8 blocks per CU)
 #define GF_MAXCOMBO 256
 
 // DFS of one None run, executed COOPERATIVELY by the whole wave: control flow is uniform,
