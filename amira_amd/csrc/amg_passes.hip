@@ -1250,110 +1250,140 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   if (lane + 64 < N) X[lane + 64] = x1;
   OGS[lane] = ogs;
   OGE[lane] = oge;
-  // ---- fill, one matrix ROW per step (N steps instead of the N + M - 1 anti-diagonals of a
-  // systolic sweep, which also idles half the lanes while it ramps up and down).  Lane j owns
-  // column j and keeps F[i-1, j].  With c_j = max(F[i-1,j-1] + match, F[i-1,j] - 1) the row is
-  //   F[i, j] = max(c_j, F[i, j-1] - 1) = max_{k <= j} (c_k + k) - j   (F[i,-1] = -i enters as k = -1)
-  // i.e. a prefix maximum over the lanes: six DPP steps.  The pointer follows from the three
-  // candidates with the reference's tie order UP (0,-1) > LEFT (-1,0) > DIAG.  Pointers stay in
-  // registers: 2 bits per cell, word b of lane j = rows 16b .. 16b+15 of column j.
-  int Fp = -lane;  // F[-1, j] = -j
-  unsigned int ptrs[NWF_MAX_N / 16];
-#pragma unroll
-  for (int blk = 0; blk < NWF_MAX_N / 16; ++blk) {
-    unsigned int acc = 0;
-    const int iend = N < blk * 16 + 16 ? N : blk * 16 + 16;
-    for (int i = blk * 16; i < iend; ++i) {
-      const int xi = blk < 4 ? __builtin_amdgcn_readlane(x0, i) : __builtin_amdgcn_readlane(x1, i - 64);
-      // F[i-1, j-1]; lane 0 takes the border F[i-1, -1] = -(i-1), F[-1,-1] = 0
-      const int fd = __builtin_amdgcn_update_dpp(i == 0 ? 0 : 1 - i, Fp, 0x138, 0xf, 0xf, false);
-      const int s_d = fd + (xi == yj ? 1 : 0);
-      const int s_l = Fp - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
-      const int c = s_d > s_l ? s_d : s_l;
-      int g = c + lane;
-      const int ID = (int)0x80000000;
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
-      g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
-      const int Fc = max(g, -i - 1) - lane;  // F[i, j]
-      // F[i, j-1] - 1: pointer UP = (0, -1); lane 0 takes the border F[i, -1] = -i
-      const int s_u = __builtin_amdgcn_update_dpp(-i, Fc, 0x138, 0xf, 0xf, false) - 1;
-      const unsigned int ptr = s_u >= c ? 2u : (s_l >= s_d ? 1u : 0u);
-      acc |= ptr << ((i & 15) * 2);
-      Fp = Fc;
+  // ---- shortcut: equally long gene lists that differ in at most two places.
+  // With the reference's scores (match +1, mismatch 0, gap -1, and borders F[i,-1] = -i,
+  // F[-1,j] = -j that make the first gap of a LEADING run free) an alignment of two lists of
+  // the same length N with p >= 1 gaps in each scores at most (N - p) - 2p + 1 <= N - 2, the
+  // pure diagonal N - m for m mismatching places.  m <= 1: the diagonal is the only optimum.
+  // m == 2: only the two alignments "one leading gap, N - 1 matches, one trailing gap" can tie
+  // (x[1:] == y[:-1] or x[:-1] == y[1:]); if neither holds the diagonal is again the only
+  // optimum.  A unique optimum is what the traceback returns whatever the tie order, so the
+  // matrix is not needed: columns are (x[q], y[q]), a mismatching column gives (None, None)
+  // and does not consume an original position (:1314-1325).
+  const long long NONE = (long long)0x8000000000000000ull;
+  bool diagonal = false;
+  if (N == M) {
+    const unsigned long long mm = __ballot(lane < N && x0 != yj);
+    const int m = __popcll(mm);
+    diagonal = m <= 1;
+    const int x_next = __shfl_down(x0, 1, 64), y_next = __shfl_down(yj, 1, 64);  // every lane shuffles
+    if (m == 2) {
+      const bool tie_a = __ballot(lane < N - 1 && x_next != yj) == 0ull;  // x[1:] == y[:-1]
+      const bool tie_b = __ballot(lane < N - 1 && x0 != y_next) == 0ull;  // x[:-1] == y[1:]
+      diagonal = !tie_a && !tie_b;
     }
-    ptrs[blk] = acc;
+    if (diagonal && lane < N) {
+      const bool match = ((mm >> lane) & 1ull) == 0ull;
+      const int cur = __popcll(~mm & ((1ull << lane) - 1ull));  // matches before this column
+      GS[lane] = match ? OGS[cur] : NONE;
+      GE[lane] = match ? OGE[cur] : NONE;
+    }
   }
-  // ---- traceback on the scalar unit: i, j and the ops are wave-uniform, a pointer is one
-  // v_readlane away (no LDS round trip per step).  Ops are collected back to front, 16 per word.
-  int n_ops = 0;
-  {
-    int i = N - 1, j = M - 1;
-    unsigned int pack = 0;
-#pragma unroll
-    for (int blk = NWF_MAX_N / 16 - 1; blk >= 0; --blk) {
-      while (i >= blk * 16 && j >= 0) {
-        const unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)ptrs[blk], j);
-        const unsigned int p = (w >> ((i & 15) * 2)) & 3u;
-        pack |= p << ((n_ops & 15) * 2);
+  if (!diagonal) {
+    // ---- fill, one matrix ROW per step (N steps instead of the N + M - 1 anti-diagonals of a
+    // systolic sweep, which also idles half the lanes while it ramps up and down).  Lane j owns
+    // column j and keeps F[i-1, j].  With c_j = max(F[i-1,j-1] + match, F[i-1,j] - 1) the row is
+    //   F[i, j] = max(c_j, F[i, j-1] - 1) = max_{k <= j} (c_k + k) - j   (F[i,-1] = -i enters as k = -1)
+    // i.e. a prefix maximum over the lanes: six DPP steps.  The pointer follows from the three
+    // candidates with the reference's tie order UP (0,-1) > LEFT (-1,0) > DIAG.  Pointers stay in
+    // registers: 2 bits per cell, word b of lane j = rows 16b .. 16b+15 of column j.
+    int Fp = -lane;  // F[-1, j] = -j
+    unsigned int ptrs[NWF_MAX_N / 16];
+  #pragma unroll
+    for (int blk = 0; blk < NWF_MAX_N / 16; ++blk) {
+      unsigned int acc = 0;
+      const int iend = N < blk * 16 + 16 ? N : blk * 16 + 16;
+      for (int i = blk * 16; i < iend; ++i) {
+        const int xi = blk < 4 ? __builtin_amdgcn_readlane(x0, i) : __builtin_amdgcn_readlane(x1, i - 64);
+        // F[i-1, j-1]; lane 0 takes the border F[i-1, -1] = -(i-1), F[-1,-1] = 0
+        const int fd = __builtin_amdgcn_update_dpp(i == 0 ? 0 : 1 - i, Fp, 0x138, 0xf, 0xf, false);
+        const int s_d = fd + (xi == yj ? 1 : 0);
+        const int s_l = Fp - 1;  // from F[i-1, j]: pointer LEFT = (-1, 0)
+        const int c = s_d > s_l ? s_d : s_l;
+        int g = c + lane;
+        const int ID = (int)0x80000000;
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
+        const int Fc = max(g, -i - 1) - lane;  // F[i, j]
+        // F[i, j-1] - 1: pointer UP = (0, -1); lane 0 takes the border F[i, -1] = -i
+        const int s_u = __builtin_amdgcn_update_dpp(-i, Fc, 0x138, 0xf, 0xf, false) - 1;
+        const unsigned int ptr = s_u >= c ? 2u : (s_l >= s_d ? 1u : 0u);
+        acc |= ptr << ((i & 15) * 2);
+        Fp = Fc;
+      }
+      ptrs[blk] = acc;
+    }
+    // ---- traceback on the scalar unit: i, j and the ops are wave-uniform, a pointer is one
+    // v_readlane away (no LDS round trip per step).  Ops are collected back to front, 16 per word.
+    int n_ops = 0;
+    {
+      int i = N - 1, j = M - 1;
+      unsigned int pack = 0;
+  #pragma unroll
+      for (int blk = NWF_MAX_N / 16 - 1; blk >= 0; --blk) {
+        while (i >= blk * 16 && j >= 0) {
+          const unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)ptrs[blk], j);
+          const unsigned int p = (w >> ((i & 15) * 2)) & 3u;
+          pack |= p << ((n_ops & 15) * 2);
+          if ((n_ops & 15) == 15) {
+            if (lane == 0) OPW[n_ops >> 4] = pack;
+            pack = 0;
+          }
+          ++n_ops;
+          if (p == 0) { --i; --j; }
+          else if (p == 1) --i;
+          else --j;
+        }
+      }
+      while (i >= 0) {  // leading corrected genes: LEFT
+        pack |= 1u << ((n_ops & 15) * 2);
         if ((n_ops & 15) == 15) {
           if (lane == 0) OPW[n_ops >> 4] = pack;
           pack = 0;
         }
         ++n_ops;
-        if (p == 0) { --i; --j; }
-        else if (p == 1) --i;
-        else --j;
+        --i;
       }
-    }
-    while (i >= 0) {  // leading corrected genes: LEFT
-      pack |= 1u << ((n_ops & 15) * 2);
-      if ((n_ops & 15) == 15) {
-        if (lane == 0) OPW[n_ops >> 4] = pack;
-        pack = 0;
+      while (j >= 0) {  // leading original genes: UP
+        pack |= 2u << ((n_ops & 15) * 2);
+        if ((n_ops & 15) == 15) {
+          if (lane == 0) OPW[n_ops >> 4] = pack;
+          pack = 0;
+        }
+        ++n_ops;
+        --j;
       }
-      ++n_ops;
-      --i;
+      if ((n_ops & 15) != 0 && lane == 0) OPW[n_ops >> 4] = pack;
     }
-    while (j >= 0) {  // leading original genes: UP
-      pack |= 2u << ((n_ops & 15) * 2);
-      if ((n_ops & 15) == 15) {
-        if (lane == 0) OPW[n_ops >> 4] = pack;
-        pack = 0;
+    wave_sync();
+    // ---- positions, in parallel over the alignment columns (front to back)
+    int base_x = 0, base_y = 0, base_cur = 0;
+    for (int c0 = 0; c0 < n_ops; c0 += 64) {
+      const int f = c0 + lane;
+      const bool in = f < n_ops;
+      const int g = in ? n_ops - 1 - f : 0;
+      const unsigned int op = in ? (OPW[g >> 4] >> ((g & 15) * 2)) & 3u : 3u;
+      const bool isx = in && (op == 0 || op == 1), isy = in && (op == 0 || op == 2);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const unsigned long long bx = __ballot(isx), by = __ballot(isy);
+      const int xi = base_x + __popcll(bx & lt), yy = base_y + __popcll(by & lt);
+      const int ysel = __shfl(yj, yy < 64 ? yy : 0, 64);  // all lanes take part in the shuffle
+      const bool match = in && op == 0 && X[xi < NWF_MAX_N ? xi : 0] == ysel;
+      const bool inc = in && (op == 2 || match);
+      const unsigned long long bc = __ballot(inc);
+      const int cur = base_cur + __popcll(bc & lt);
+      if (isx) {
+        GS[xi] = match ? OGS[cur < NWF_MAX_M ? cur : 0] : NONE;
+        GE[xi] = match ? OGE[cur < NWF_MAX_M ? cur : 0] : NONE;
       }
-      ++n_ops;
-      --j;
+      base_x += __popcll(bx);
+      base_y += __popcll(by);
+      base_cur += __popcll(bc);
     }
-    if ((n_ops & 15) != 0 && lane == 0) OPW[n_ops >> 4] = pack;
-  }
-  wave_sync();
-  // ---- positions, in parallel over the alignment columns (front to back)
-  const long long NONE = (long long)0x8000000000000000ull;
-  int base_x = 0, base_y = 0, base_cur = 0;
-  for (int c0 = 0; c0 < n_ops; c0 += 64) {
-    const int f = c0 + lane;
-    const bool in = f < n_ops;
-    const int g = in ? n_ops - 1 - f : 0;
-    const unsigned int op = in ? (OPW[g >> 4] >> ((g & 15) * 2)) & 3u : 3u;
-    const bool isx = in && (op == 0 || op == 1), isy = in && (op == 0 || op == 2);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long bx = __ballot(isx), by = __ballot(isy);
-    const int xi = base_x + __popcll(bx & lt), yy = base_y + __popcll(by & lt);
-    const int ysel = __shfl(yj, yy < 64 ? yy : 0, 64);  // all lanes take part in the shuffle
-    const bool match = in && op == 0 && X[xi < NWF_MAX_N ? xi : 0] == ysel;
-    const bool inc = in && (op == 2 || match);
-    const unsigned long long bc = __ballot(inc);
-    const int cur = base_cur + __popcll(bc & lt);
-    if (isx) {
-      GS[xi] = match ? OGS[cur < NWF_MAX_M ? cur : 0] : NONE;
-      GE[xi] = match ? OGE[cur < NWF_MAX_M ? cur : 0] : NONE;
-    }
-    base_x += __popcll(bx);
-    base_y += __popcll(by);
-    base_cur += __popcll(bc);
   }
   wave_sync();
   // ---- replace_invalid_gene_positions, each lane repairs its own entries
