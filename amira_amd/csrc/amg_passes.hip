@@ -900,7 +900,6 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
   __shared__ signed char s_cdir[4][GF_CAND];
   __shared__ int s_gene[4][GF_CAND + AMG_MAX_K];
   __shared__ int s_best[4][GF_CAND + AMG_MAX_K];
-  __shared__ int s_misc[4][4];
   const CorrArgs& a = A.a;
   const GView& g = A.g;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -993,48 +992,63 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
   int best_shared = 0, best_ng = -1;
   unsigned long long best_sum = 0, best_len = 1;
   for (unsigned long long combo = 0; combo < n_combo; ++combo) {
-    // ---- candidate node list (lane 0): live windows + the chosen path of every run
-    if (lane == 0) {
-      int n = 0, q = 0, i = start, prev_pe = -1;
+    // ---- candidate node list: live windows + the chosen path of every run.  Control flow is
+    // wave-uniform (one step per run, not per window), the copies are lane-parallel.
+    int n = 0;
+    {
+      int i = start, prev_pe = -1;
       bool over = false;
-      while (i <= end && !over) {
-        if (q < n_gaps && GAP[3 * q] == i) {
-          const int ps = GAP[3 * q], pe = GAP[3 * q + 1], np = GAP[3 * q + 2];
-          unsigned long long div = 1;
-          for (int j = q + 1; j < n_gaps; ++j) div *= (unsigned long long)GAP[3 * j + 2];
-          int pick = (int)((combo / div) % (unsigned long long)np);
-          int off = 0;
-          while (off < used) {  // records of run q appear in DFS order
-            if (POOL[off] == q) {
-              if (pick == 0) break;
-              --pick;
+      for (int q = 0; q < n_gaps && !over; ++q) {
+        const int ps = GAP[3 * q], pe = GAP[3 * q + 1], np = GAP[3 * q + 2];
+        // windows [i, ps) are live (a None run is maximal): copied as they are
+        const int cnt = ps - i;
+        if (cnt > 0) {
+          if (n + cnt > GF_CAND) { over = true; break; }
+          for (int j = lane; j < cnt; j += 64) {
+            CN[n + j] = W[i + j];
+            CD[n + j] = Dr[i + j];
+          }
+          n += cnt;
+        }
+        unsigned long long div = 1;
+        for (int j = q + 1; j < n_gaps; ++j) div *= (unsigned long long)GAP[3 * j + 2];
+        int pick = (int)((combo / div) % (unsigned long long)np);
+        int off = 0;
+        while (off < used) {  // records of run q appear in DFS order
+          if (POOL[off] == q) {
+            if (pick == 0) break;
+            --pick;
+          }
+          off += 2 + 2 * POOL[off + 1];
+        }
+        const int L = POOL[off + 1];
+        if (prev_pe == ps && n > 0) --n;  // consecutive runs share their terminal node
+        if (n + L > GF_CAND) { over = true; break; }
+        for (int j = lane; j < L; j += 64) {
+          CN[n + j] = POOL[off + 2 + j];
+          CD[n + j] = (signed char)POOL[off + 2 + L + j];
+        }
+        n += L;
+        prev_pe = pe;
+        i = (q + 1 < n_gaps && GAP[3 * (q + 1)] == pe) ? pe : pe + 1;
+      }
+      if (!over) {
+        const int cnt = end - i + 1;
+        if (cnt > 0) {
+          if (n + cnt > GF_CAND) {
+            over = true;
+          } else {
+            for (int j = lane; j < cnt; j += 64) {
+              CN[n + j] = W[i + j];
+              CD[n + j] = Dr[i + j];
             }
-            off += 2 + 2 * POOL[off + 1];
+            n += cnt;
           }
-          const int L = POOL[off + 1];
-          if (prev_pe == ps && n > 0) --n;
-          if (n + L > GF_CAND) { over = true; break; }
-          for (int j = 0; j < L; ++j) {
-            CN[n] = POOL[off + 2 + j];
-            CD[n] = (signed char)POOL[off + 2 + L + j];
-            ++n;
-          }
-          prev_pe = pe;
-          i = pe;
-          ++q;
-          if (!(q < n_gaps && GAP[3 * q] == pe)) i = pe + 1;
-        } else {
-          if (n + 1 > GF_CAND) { over = true; break; }
-          CN[n] = W[i];
-          CD[n] = Dr[i];
-          ++n;
-          ++i;
         }
       }
-      s_misc[wv][0] = over ? -1 : n;
+      if (over) n = -1;
     }
     wave_sync();
-    const int n = s_misc[wv][0];
     if (n < 0) {
       if (lane == 0) A.need_slow[gi] = 1;
       return;
@@ -1047,8 +1061,10 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
       const int j = q < g.k - 1 ? q : g.k - 1;
       GN[q] = oriented_tok(g, CN[idx], CD[idx], j);
     }
-    for (int q = lane; q < n; q += 64) csum += g.n_cov[CN[q]];
-    for (int d = 32; d > 0; d >>= 1) csum += __shfl_xor(csum, d, 64);
+    if (n_combo > 1) {  // the mean coverage only ranks candidates against each other
+      for (int q = lane; q < n; q += 64) csum += g.n_cov[CN[q]];
+      for (int d = 32; d > 0; d >>= 1) csum += __shfl_xor(csum, d, 64);
+    }
     wave_sync();
     bool better = true;
     if (n_combo > 1) {
