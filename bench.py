@@ -241,7 +241,9 @@ def main():
         cands = {s: stage_bytes(s, k, L, n_windows, N, n_gapped) for s in stage_tot}
         dom = max((s for s in cands if cands[s]), key=lambda s: stage_tot[s])
         achieved = cands[dom] / (stage_avg[dom] * 1e-3) / 1e9
-        kernel_of = {"node_upsert": "k_node_upsert", "edge_upsert": "k_edges", "node_count": "k_count_ids",
+        exact = bool(counts.get("exact_keys"))
+        kernel_of = {"node_upsert": "k_nodes_x" if exact else "k_node_upsert",
+                     "edge_upsert": "k_edges_x" if exact else "k_edges", "node_count": "k_count_ids",
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "node_table_clear", "node_upsert", "node_rank",
@@ -253,16 +255,18 @@ def main():
         # process, so the per-launch FETCH_SIZE + WRITE_SIZE of the last committed
         # `rocprofv3 --pmc` passes over this same command (profiles/) is reported, or null
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r1_v3_sweep_pmc_summary.json")
-        if w["sweep"] and world == 1 and os.path.exists(pmc_path):
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sweep_pmc_summary.json")))
+        pmc_path = pmc_files[-1] if pmc_files else ""
+        if w["sweep"] and world == 1 and pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
-                row = next(r for r in pmc["kernels"] if r["kernel"].startswith(kernel_of[dom].split("<")[0]))
+                row = next(r for r in pmc["kernels"] if r["kernel"].split("<")[0] == kernel_of[dom])
                 n = min(len(row["FETCH_SIZE_KB_per_launch"]), len(row["WRITE_SIZE_KB_per_launch"]))
                 traffic = sum((row["FETCH_SIZE_KB_per_launch"][i] + row["WRITE_SIZE_KB_per_launch"][i]) * 1024.0
                               for i in range(n)) / n
                 traffic_note = ("mean over the launches of one sweep, (FETCH_SIZE + WRITE_SIZE) x 1024, separate "
-                                "--pmc passes, from profiles/r1_v3_sweep_pmc_summary.json; not corrected for the "
+                                "--pmc passes, from profiles/" + os.path.basename(pmc_path) + "; not corrected for the "
                                 "gfx950 FETCH_SIZE under-count of wide coalesced streams")
             except Exception:  # noqa: BLE001
                 traffic = None
