@@ -7,6 +7,12 @@
 
 #include <rocprim/rocprim.hpp>
 
+// rocPRIM switches to a merge sort (two launches per doubling: ~40 launches of ~6 us) below
+// 1 M items; the rebuilds of a cleaning sweep sort 0.5 - 1 M node / edge records three times
+// each, where the onesweep radix sort needs 5 - 6 launches.  Keep merge sort for small inputs only.
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                           rocprim::default_config, 32768>;
+
 template <class F>
 static int with_temp(amg_ctx* c, F&& call) {
   size_t bytes = 0;
@@ -24,7 +30,7 @@ int prim_sort_u64_u32(amg_ctx* c, const unsigned long long* kin, unsigned long l
   if (end_bit < 1) end_bit = 1;
   if (end_bit > 64) end_bit = 64;
   return with_temp(c, [&](void* tmp, size_t& bytes) {
-    return rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream);
+    return rocprim::radix_sort_pairs<SortCfg>(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream);
   });
 }
 
@@ -34,7 +40,7 @@ int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
   if (end_bit < 1) end_bit = 1;
   if (end_bit > 32) end_bit = 32;
   return with_temp(c, [&](void* tmp, size_t& bytes) {
-    return rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream);
+    return rocprim::radix_sort_pairs<SortCfg>(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream);
   });
 }
 
