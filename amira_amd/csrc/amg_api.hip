@@ -202,6 +202,13 @@ static int count_flags(amg_ctx* c, const DevBuf& buf, long long n, int64_t* out)
   return AMG_OK;
 }
 
+extern "C" int amg_sizes(amg_ctx* c, int64_t* n_reads, int64_t* n_tokens) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (n_reads) *n_reads = c->n_reads;
+  if (n_tokens) *n_tokens = c->n_tokens;
+  return AMG_OK;
+}
+
 extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
   if (!c || !o) return amg_fail(AMG_E_ARG, "null argument");
   memset(o, 0, sizeof(*o));

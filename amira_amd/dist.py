@@ -77,7 +77,7 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", engine.device)
-    n_local = torch.tensor([engine.counts()["n_tokens"]], dtype=torch.int64, device=dev)
+    n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)
     gathered = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(gathered, n_local, group=group)
     tokens = gathered.tolist()
@@ -96,7 +96,7 @@ def dist_build_loopback(engines, k, min_node_cov=1, min_edge_cov=1):
     """Emulate len(engines) ranks in ONE process (tests on a single GPU): the exchanges are
     plain tensor copies, the device phases are exactly those of dist_build."""
     world = len(engines)
-    tokens = [e.counts()["n_tokens"] for e in engines]
+    tokens = [e.sizes()[1] for e in engines]
     gens = [steps(e, k, world, r, sum(tokens[:r]), sum(tokens), min_node_cov, min_edge_cov)
             for r, e in enumerate(engines)]
     replies = [None] * world

@@ -55,6 +55,12 @@ class Engine:
     def build(self, k):
         check(_ffi.lib.amg_build(self._h, int(k)))
 
+    def sizes(self):
+        """(reads, genes) of the current read set; no device work"""
+        nr, nt = C.c_int64(0), C.c_int64(0)
+        check(_ffi.lib.amg_sizes(self._h, C.byref(nr), C.byref(nt)))
+        return nr.value, nt.value
+
     def counts(self):
         c = _ffi.Counts()
         check(_ffi.lib.amg_counts(self._h, C.byref(c)))

@@ -109,6 +109,9 @@ int amg_set_read_lengths(amg_ctx* ctx, const int64_t* read_len, int on_device);
  *      add_edge (:300-324), assign_component_ids (:920-927) --------------------------- */
 int amg_build(amg_ctx* ctx, int32_t k);
 int amg_counts(amg_ctx* ctx, amg_counts_t* out);
+/* reads / genes of the current read set, without touching the device (amg_counts recounts the
+ * live flags): len(readDict), sum(len(genes)) */
+int amg_sizes(amg_ctx* ctx, int64_t* n_reads, int64_t* n_tokens);
 
 /* ---- graph read-back (any pointer may be NULL to skip that column) ---------------- */
 /* nodes in id order; canon_tokens is [n_nodes * k]; first_token = token index of the
