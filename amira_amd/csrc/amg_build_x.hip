@@ -22,12 +22,7 @@
 // Edge classes ((lo id, hi id, sign), construct_edge.py:104-124) use the same scheme with a
 // one-word key.
 #include "amg_tile.h"
-
-struct __attribute__((aligned(16))) Slot16 {
-  unsigned long long w1;
-  unsigned long long w2;
-};
-static_assert(sizeof(Slot16) == 16, "slot16");
+#include "amg_x.h"
 
 __device__ __forceinline__ unsigned int ld_u32(const unsigned int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -61,13 +56,6 @@ __device__ __forceinline__ void x_pack(const View& w, int k, int flip, int dir, 
   }
   w1 = (lo << 1) | 1ull;  // bit 63 of lo (it belongs to hi) falls off here
   tag = ((unsigned int)hi << 1) | 1u;
-}
-
-__device__ __forceinline__ int x_unpack(unsigned long long w1, unsigned int tag, int bits, int j) {
-  const unsigned long long lo = w1 >> 1, hi = (unsigned long long)(tag >> 1);
-  const int sh = j * bits;
-  unsigned long long v = sh < 63 ? ((lo >> sh) | (hi << (63 - sh))) : (hi >> (sh - 63));
-  return (int)(v & ((1ull << bits) - 1ull));
 }
 
 // Find or create the slot of key (w1, tag) starting at `idx`; `v` is the content of that first
@@ -424,7 +412,13 @@ static int read_status(amg_ctx* c, unsigned long long* host) {
 }
 
 bool bx_applicable(const amg_ctx* c, int k) {
-  if (c->dist_mode || c->count_inline || c->weak_fp_builds > 0) return false;
+  if (c->dist_mode || c->count_inline) return false;
+  return bx_fits(c, k);
+}
+
+// the tuple fits the slot and first-seen fits 32 bits (per shard in a merged build)
+bool bx_fits(const amg_ctx* c, int k) {
+  if (c->weak_fp_builds > 0) return false;
   const char* e = getenv("AMG_KEY_MODE");  // A/B + test switch: "fp" forces the fingerprint path
   if (e && e[0] == 'f') return false;
   int bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
@@ -435,6 +429,12 @@ bool bx_applicable(const amg_ctx* c, int k) {
 
 // windows -> node table, claim ids, node ids, node arrays.  AMG_E_OVERFLOW + *which = 1: table full
 int bx_nodes(amg_ctx* c, int k, int* which) {
+  AMGCHK(bx_nodes_upsert(c, k, which));
+  return bx_nodes_rank(c);
+}
+
+// the table pass alone: claims 0 .. n_local_nodes-1 with their first-seen / slot arrays
+int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens;
@@ -486,7 +486,16 @@ int bx_nodes(amg_ctx* c, int k, int* which) {
   c->n_windows = (int64_t)hs[ST_N_WINDOWS];
   c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
+  c->x_max_claims = (int64_t)max_claims;
+  return AMG_OK;
+}
 
+// node id = rank of first-seen among the claims; node arrays
+int bx_nodes_rank(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens;
+  const int k = c->k;
+  const size_t max_claims = (size_t)c->x_max_claims;
   stage_begin(c, "node_rank");
   const long long D = c->n_nodes;
   AMGCHK(c->s1.ensure((size_t)(D + 1) * sizeof(unsigned int)));
@@ -512,6 +521,12 @@ int bx_nodes(amg_ctx* c, int k, int* which) {
 // adjacencies -> edge-class table, claims, pair arrays in first-seen order, coverages.
 // AMG_E_OVERFLOW + *which = 2: edge table full
 int bx_edges(amg_ctx* c, int* which) {
+  AMGCHK(bx_edges_upsert(c, which));
+  return bx_edges_rank(c);
+}
+
+// the table pass alone: tok_node from x_final, edge-class claims 0 .. n_local_pairs-1
+int bx_edges_upsert(amg_ctx* c, int* which) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, D = c->n_nodes;
@@ -543,9 +558,16 @@ int bx_edges(amg_ctx* c, int* which) {
     *which = 2;
     return AMG_E_OVERFLOW;
   }
-  const long long P = (long long)hs[ST_PAIR_INSERTS];
-  c->n_local_pairs = c->n_pairs = P;
+  c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
+  c->x_max_eclaims = (int64_t)max_claims;
+  return AMG_OK;
+}
 
+// coverages, edge classes in first-seen order
+int bx_edges_rank(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
+  const size_t max_claims = (size_t)c->x_max_eclaims;
   // node coverage (construct_node.py:33-36) from the per-window node ids
   stage_begin(c, "node_count");
   AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));

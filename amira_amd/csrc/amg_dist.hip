@@ -19,6 +19,7 @@
 // first-seen values carry GLOBAL token indices (token_base + local index), so minima over
 // ranks reproduce the single-process insertion order exactly.
 #include "amg_device.h"
+#include "amg_x.h"
 
 #define NEED_CTX(c)                                              \
   do {                                                           \
@@ -110,6 +111,189 @@ __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long lo
   for (int x = 0; x < k; ++x) tk[x] = dir > 0 ? tokens[t + x] : flip - tokens[t + k - 1 - x];
 }
 
+// ------------------------------------------------------------------ exact local tables
+// When the shard qualifies (bx_fits) the LOCAL passes are those of the single-GPU exact-key
+// build (amg_build_x.hip: 16-byte slots, claim ids, dense per-claim arrays); the records that
+// travel keep the format below — the key is the same 64-bit fingerprint of the tuple, so ranks
+// on either path merge with each other.
+__global__ void k_xd_strip(const int* __restrict__ tok_claim, long long n, int* __restrict__ out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int raw = tok_claim[t];
+  out[t] = raw == -1 ? -1 : (int)((unsigned int)raw & ~AMG_LAST_FLAG);
+}
+
+// fingerprint of a canonical tuple given as tokens: same value as canon_fingerprint()
+__device__ __forceinline__ unsigned long long tuple_fingerprint(const int* tok, int k, unsigned long long seed) {
+  unsigned long long h = seed;
+  for (int j = 0; j < k; ++j) {
+    h = (h ^ (unsigned long long)(unsigned int)tok[j]) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  h = mix64(h);
+  return h ? h : 1ull;
+}
+
+__global__ void k_xd_node_keys(const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
+                               long long n, int k, int bits, unsigned long long seed, unsigned int world,
+                               unsigned long long* __restrict__ keys, unsigned int* __restrict__ dest,
+                               unsigned int* __restrict__ idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Slot16 s = tab[slot_by_claim[i]];
+  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  int tok[AMG_MAX_K];
+  for (int j = 0; j < k; ++j) tok[j] = x_unpack(s.w1, tag, bits, j);
+  const unsigned long long key = tuple_fingerprint(tok, k, seed);
+  keys[i] = key;
+  dest[i] = owner_of(key, world);
+  idx[i] = (unsigned int)i;
+}
+
+__global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long n,
+                               const unsigned long long* __restrict__ keys,
+                               const unsigned int* __restrict__ first_a, const unsigned int* __restrict__ first_b,
+                               long long tok_base, const unsigned int* __restrict__ lcnt,
+                               const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
+                               int k, int bits, unsigned char* __restrict__ out, int rec_bytes) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned int c = order[j];
+  const unsigned int fa = first_a[c], fb = first_b[c];
+  const unsigned long long first = ((unsigned long long)tok_base << 1) + (unsigned long long)(unsigned int)~(fa > fb ? fa : fb);
+  unsigned char* rec = out + (size_t)j * rec_bytes;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(rec);
+  q[0] = keys[c];
+  q[1] = first;
+  unsigned int* u = reinterpret_cast<unsigned int*>(rec + 16);
+  u[0] = lcnt[c];
+  u[1] = (unsigned int)k;
+  const Slot16 s = tab[slot_by_claim[c]];
+  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  int* tk = reinterpret_cast<int*>(rec + 24);
+  for (int x = 0; x < k; ++x) tk[x] = x_unpack(s.w1, tag, bits, x);
+}
+
+// local claim -> global node id (looked up by key); -2 when the node fell to the fused filter
+__global__ void k_xd_claims_to_global(const unsigned long long* __restrict__ keys, long long n,
+                                      const Slot* __restrict__ gtab, unsigned long long gmask,
+                                      int allow_missing, int* __restrict__ final_of_claim,
+                                      unsigned long long* status) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = keys[i];
+  unsigned long long s = (key >> 20) & gmask;
+  for (unsigned int probes = 0; probes < (1u << 20); ++probes) {
+    const unsigned long long cur = gtab[s].key;
+    if (cur == key) {
+      final_of_claim[i] = gtab[s].id;
+      return;
+    }
+    if (cur == 0ull) break;
+    s = (s + 1) & gmask;
+  }
+  final_of_claim[i] = -2;
+  if (!allow_missing) status[ST_OVERFLOW] = 5;  // local key missing from the global table
+}
+
+__global__ void k_xd_edge_dest(const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
+                               long long n, unsigned int world, unsigned int* __restrict__ dest,
+                               unsigned int* __restrict__ idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dest[i] = owner_of(etab[slot_by_claim[i]].w1, world);
+  idx[i] = (unsigned int)i;
+}
+
+__global__ void k_xd_edge_pack(const unsigned int* __restrict__ order, long long n,
+                               const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
+                               const unsigned int* __restrict__ first_a, const unsigned int* __restrict__ first_b,
+                               long long tok_base, const unsigned int* __restrict__ lcnt,
+                               unsigned char* __restrict__ out) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned int c = order[j];
+  const unsigned int fa = first_a[c], fb = first_b[c];
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
+  q[0] = etab[slot_by_claim[c]].w1;
+  q[1] = ((unsigned long long)tok_base << 3) + (unsigned long long)(unsigned int)~(fa > fb ? fa : fb);
+  q[2] = (unsigned long long)lcnt[c];
+}
+
+// per-destination send counts of n records whose destinations are in dest[]: sorts (dest, idx)
+// into (dest_sorted, order) and fills send_counts
+static int dest_counts(amg_ctx* c, long long n, int world, unsigned int* dest, unsigned int* idx,
+                       unsigned int* dest_sorted, unsigned int* order, int64_t* send_counts) {
+  hipStream_t st = c->stream;
+  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
+  if (n > 0) {
+    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
+                       c->dist_cnt.as<unsigned long long>());
+  }
+  std::vector<unsigned long long> h(world);
+  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
+  return AMG_OK;
+}
+
+static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
+  hipStream_t st = c->stream;
+  for (int attempt = 0;; ++attempt) {
+    int which = 0;
+    int r = bx_nodes_upsert(c, k, &which);
+    if (r == AMG_OK) break;
+    if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
+    ++c->retries;
+    c->node_slots *= 4;
+  }
+  const long long n = c->n_local_nodes, T = c->n_tokens;
+  // local occurrence counts per claim (tok_node is free scratch until the edge pass writes it)
+  AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+  if (T > 0)
+    hipLaunchKernelGGL(k_xd_strip, dim3(nblk(T, 256)), dim3(256), 0, st, c->tok_slot.as<int>(), T,
+                       c->tok_node.as<int>());
+  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 0));
+  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
+  unsigned int* dest = c->dist_a.as<unsigned int>();
+  unsigned int* idx = dest + (n + 1);
+  unsigned int* dest_sorted = idx + (n + 1);
+  unsigned int* order = dest_sorted + (n + 1);
+  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
+  AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));  // keys per claim
+  if (n > 0)
+    hipLaunchKernelGGL(k_xd_node_keys, dim3(nblk(n, 256)), dim3(256), 0, st, c->node_tab.as<Slot16>(),
+                       c->x_slot.as<unsigned int>(), n, k, c->x_bits, c->seed, (unsigned int)world,
+                       c->dist_first.as<unsigned long long>(), dest, idx);
+  return dest_counts(c, n, world, dest, idx, dest_sorted, order, send_counts);
+}
+
+static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
+  hipStream_t st = c->stream;
+  for (int attempt = 0;; ++attempt) {
+    int which = 0;
+    int r = bx_edges_upsert(c, &which);
+    if (r == AMG_OK) break;
+    if (r != AMG_E_OVERFLOW || which != 2 || attempt >= 8) return r;
+    ++c->retries;
+    c->edge_slots *= 4;
+  }
+  const long long n = c->n_local_pairs, T = c->n_tokens;
+  AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 1));
+  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
+  unsigned int* dest = c->dist_a.as<unsigned int>();
+  unsigned int* idx = dest + (n + 1);
+  unsigned int* dest_sorted = idx + (n + 1);
+  unsigned int* order = dest_sorted + (n + 1);
+  if (n > 0)
+    hipLaunchKernelGGL(k_xd_edge_dest, dim3(nblk(n, 256)), dim3(256), 0, st, c->edge_tab.as<Slot16>(),
+                       c->x_eslot.as<unsigned int>(), n, (unsigned int)world, dest, idx);
+  return dest_counts(c, n, world, dest, idx, dest_sorted, order, send_counts);
+}
+
 extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, int64_t token_total,
                                     int32_t world, int64_t* send_counts) {
   NEED_CTX(c);
@@ -128,6 +312,9 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   c->dist_mode = true;
   c->count_inline = false;  // local occurrence counts come from bs_count_by_slot, not per-window atomics
   bs_size_tables(c);
+  c->exact_keys = false;
+  c->dist_x = bx_fits(c, k);
+  if (c->dist_x) return nodes_local_x(c, k, world, send_counts);
   for (int attempt = 0;; ++attempt) {
     int which = 0;
     int r = bs_nodes_pass(c, k, &which);
@@ -185,6 +372,15 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
   unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
+  if (c->dist_x) {
+    hipLaunchKernelGGL(k_xd_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                       c->dist_first.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                       c->x_first.as<unsigned int>() + c->x_max_claims, (long long)c->tok_base,
+                       c->dist_lcnt.as<unsigned int>(), c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
+                       c->k, c->x_bits, reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AMG_OK;
+  }
   hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                      c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
                      c->node_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(), c->tokens.as<int>(), c->k,
@@ -429,6 +625,14 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
                        c->node_first.as<long long>(), c->node_alive.as<unsigned char>(),
                        c->status.as<unsigned long long>());
   }
+  if (c->dist_x) {
+    c->packed_nodes = false;
+    if (c->n_local_nodes > 0)
+      hipLaunchKernelGGL(k_xd_claims_to_global, dim3(nblk(c->n_local_nodes, 256)), dim3(256), 0, st,
+                         c->dist_first.as<unsigned long long>(), (long long)c->n_local_nodes,
+                         c->dist_gtab.as<Slot>(), (unsigned long long)(gslots - 1),
+                         c->dist_min_node > 1 ? 1 : 0, c->x_final.as<int>(), c->status.as<unsigned long long>());
+  } else
   hipLaunchKernelGGL(k_local_to_global, dim3(nblk(c->node_slots, 256)), dim3(256), 0, st,
                      c->node_tab.as<Slot>(), (unsigned long long)c->node_slots, c->dist_gtab.as<Slot>(),
                      (unsigned long long)(gslots - 1), c->node_tokens.as<int>(), c->k,
@@ -474,6 +678,7 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
   NEED_CTX(c);
   if (world < 1 || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
   hipStream_t st = c->stream;
+  if (c->dist_x) return edges_local_x(c, world, send_counts);
   for (int attempt = 0;; ++attempt) {
     int which = 0;
     int r = bs_edges_pass(c, &which);
@@ -529,6 +734,14 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
   unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
+  if (c->dist_x) {
+    hipLaunchKernelGGL(k_xd_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                       c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
+                       c->x_efirst.as<unsigned int>() + c->x_max_eclaims, (long long)c->tok_base,
+                       c->dist_lcnt.as<unsigned int>(), reinterpret_cast<unsigned char*>(send_buf));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AMG_OK;
+  }
   hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                      c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
                      c->edge_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(),

@@ -166,6 +166,8 @@ struct amg_ctx {
   // ---- exact-key build (amg_build_x.hip): arrays indexed by CLAIM id (order of slot creation)
   bool exact_keys = false;   // this build used the exact-key path
   int x_bits = 0;            // bits per token in the packed tuple
+  int64_t x_max_claims = 0, x_max_eclaims = 0;  // capacity of the per-claim arrays (second half of x_first / x_efirst starts there)
+  bool dist_x = false;       // this merged build keeps its LOCAL tables in the exact-key layout
   DevBuf x_first, x_slot;    // uint32[claims]  ~first_seen of a node claim, its table slot
   DevBuf x_final;            // int32 [claims]  claim id -> node id
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
@@ -220,8 +222,13 @@ int bs_alloc_pairs(amg_ctx* c, long long P);
 int bs_pairs_from_local(amg_ctx* c);
 int bs_finish_from_pairs(amg_ctx* c);
 bool bx_applicable(const amg_ctx* c, int k);
+bool bx_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
+int bx_nodes_upsert(amg_ctx* c, int k, int* which);
+int bx_nodes_rank(amg_ctx* c);
 int bx_edges(amg_ctx* c, int* which);
+int bx_edges_upsert(amg_ctx* c, int* which);
+int bx_edges_rank(amg_ctx* c);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind);
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,

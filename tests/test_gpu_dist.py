@@ -11,6 +11,15 @@ from test_gpu_sweep import flat_positions
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["exact", "fp"], autouse=True)
+def key_mode(request, monkeypatch):
+    """every test runs twice: shards that keep their local tables in the exact-key layout (the
+    default when the tuple fits) and shards on the fingerprint path (large k / vocabulary)"""
+    if request.param == "fp":
+        monkeypatch.setenv("AMG_KEY_MODE", "fp")
+    return request.param
+
+
 def shard_bounds(n_reads, world):
     return [(r * n_reads) // world for r in range(world + 1)]
 
