@@ -58,6 +58,42 @@ __device__ __forceinline__ void x_pack(const View& w, int k, int flip, int dir, 
   tag = ((unsigned int)hi << 1) | 1u;
 }
 
+// Compile-time k: direction, canonical tuple and packing as straight-line code (no early-exit
+// loop, no per-token branches).  Returns the direction (0: palindrome).
+template <int K, bool TWO>
+__device__ __forceinline__ int x_canon_pack(const int* w, int flip, int bits, unsigned long long& w1,
+                                            unsigned int& tag) {
+  int a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = w[j];
+  int dir = 0;  // the first differing position decides: walk from the last to the first
+#pragma unroll
+  for (int j = K - 1; j >= 0; --j) {
+    const int d = a[j] - (flip - a[K - 1 - j]);
+    dir = d != 0 ? (d < 0 ? 1 : -1) : dir;
+  }
+  if (TWO) {
+    unsigned __int128 v = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const unsigned int c = (unsigned int)(dir > 0 ? a[j] : flip - a[K - 1 - j]);
+      v |= (unsigned __int128)c << (j * bits);
+    }
+    w1 = ((unsigned long long)v << 1) | 1ull;
+    tag = ((unsigned int)(unsigned long long)(v >> 63) << 1) | 1u;
+  } else {
+    unsigned long long v = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const unsigned int c = (unsigned int)(dir > 0 ? a[j] : flip - a[K - 1 - j]);
+      v |= (unsigned long long)c << (j * bits);
+    }
+    w1 = (v << 1) | 1ull;
+    tag = 1u;
+  }
+  return dir;
+}
+
 // Find or create the slot of key (w1, tag) starting at `idx`; `v` is the content of that first
 // slot as a PLAIN load returned it.
 //
@@ -204,7 +240,7 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TIL
 }
 
 // ------------------------------------------------------------------ nodes
-template <bool TWO>
+template <bool TWO, int K>  // K > 0: k known at compile time (the common odd sizes), 0: any k
 __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned long long mask, unsigned int probe_limit,
@@ -236,12 +272,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
     id1[it] = 0;
     if (ok) {
       LdsView w{s_tok + i};
-      const int dir = canon_dir(w, k, flip);
+      int dir;
+      if (K > 0) {
+        dir = x_canon_pack<(K > 0 ? K : 1), TWO>(s_tok + i, flip, bits, w1[it], tag[it]);
+      } else {
+        dir = canon_dir(w, k, flip);
+        if (dir != 0) x_pack(w, k, flip, dir, bits, w1[it], tag[it]);
+      }
       if (dir == 0) {
         status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
       } else {
         dirs[it] = dir;
-        x_pack(w, k, flip, dir, bits, w1[it], tag[it]);
         idx[it] = mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
         fi[it] = ~(((unsigned int)t << 1) | (dir < 0 ? 1u : 0u));
         valid |= 1u << it;
@@ -465,7 +506,13 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   const int ablate = abl ? atoi(abl) : 0;
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
-    auto kern = (long long)k * c->x_bits > 63 ? k_nodes_x<true> : k_nodes_x<false>;  // tuple spills into w2?
+    const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
+    auto kern = two ? k_nodes_x<true, 0> : k_nodes_x<false, 0>;
+    if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
+      if (k == 3) kern = two ? k_nodes_x<true, 3> : k_nodes_x<false, 3>;
+      if (k == 5) kern = two ? k_nodes_x<true, 5> : k_nodes_x<false, 5>;
+      if (k == 7) kern = two ? k_nodes_x<true, 7> : k_nodes_x<false, 7>;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
                        c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
                        c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
