@@ -113,7 +113,14 @@ extern "C" int amg_sync(amg_ctx* c) {
 extern "C" void* amg_stream(amg_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // ------------------------------------------------------------------ inputs
+// on_device: 0 host pointer (copied), 1 device pointer (copied), 2 device pointer BORROWED — no
+// copy, the caller keeps the memory alive and unchanged until the next amg_set_* of that array
+// or amg_adopt_corrected
 static int copy_in(amg_ctx* c, DevBuf& dst, const void* src, size_t bytes, int on_device) {
+  if (on_device == 2) {
+    dst.borrow(src, bytes);
+    return AMG_OK;
+  }
   AMGCHK(dst.ensure(bytes + 64));
   if (bytes)
     HIPCHK(hipMemcpyAsync(dst.p, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,

@@ -32,7 +32,31 @@ int amg_fail(int code, const char* fmt, ...);
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  // a BORROWED view of caller memory (amg_set_reads / amg_set_positions with on_device = 2): the
+  // buffer's own allocation is parked meanwhile and comes back with the first ensure / unborrow;
+  // borrowed memory is never written, resized or freed here
+  void* own_p = nullptr;
+  size_t own_cap = 0;
+  bool borrowed = false;
+  void borrow(const void* ptr, size_t bytes) {
+    if (!borrowed) {
+      own_p = p;
+      own_cap = cap;
+    }
+    p = const_cast<void*>(ptr);
+    cap = bytes;
+    borrowed = true;
+  }
+  void unborrow() {
+    if (!borrowed) return;
+    p = own_p;
+    cap = own_cap;
+    own_p = nullptr;
+    own_cap = 0;
+    borrowed = false;
+  }
   int ensure(size_t bytes) {
+    unborrow();
     if (bytes <= cap) return AMG_OK;
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -47,6 +71,7 @@ struct DevBuf {
     return AMG_OK;
   }
   void release() {
+    unborrow();
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;

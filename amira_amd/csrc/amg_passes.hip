@@ -1821,6 +1821,8 @@ extern "C" int amg_get_corrected(amg_ctx* c, int32_t* tokens, int64_t* read_offs
 extern "C" int amg_adopt_corrected(amg_ctx* c) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
+  // borrowed inputs go back to their owner: the corrected set lives in our own allocations
+  for (DevBuf* b : {&c->tokens, &c->read_off, &c->gene_start, &c->gene_end, &c->read_len}) b->unborrow();
   std::swap(c->tokens, c->c_tokens_buf);
   std::swap(c->read_off, c->c_read_off);
   if (c->have_pos) {

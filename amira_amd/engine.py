@@ -33,9 +33,11 @@ class Engine:
         check(_ffi.lib.amg_set_reads(self._h, ptr(tokens), ptr(read_offsets),
                                      len(read_offsets) - 1, int(two_v), 0))
 
-    def set_reads_device(self, tokens_ptr, read_offsets_ptr, n_reads, two_v):
+    def set_reads_device(self, tokens_ptr, read_offsets_ptr, n_reads, two_v, borrow=False):
+        """device pointers; borrow=True: no copy, the caller keeps the arrays alive and unchanged
+        until the next set_reads* / adopt_corrected"""
         check(_ffi.lib.amg_set_reads(self._h, C.c_void_p(tokens_ptr), C.c_void_p(read_offsets_ptr),
-                                     int(n_reads), int(two_v), 1))
+                                     int(n_reads), int(two_v), 2 if borrow else 1))
 
     def set_positions(self, gene_start, gene_end, read_len=None):
         gs = np.ascontiguousarray(gene_start, dtype=np.int64)
@@ -47,9 +49,9 @@ class Engine:
         rl = np.ascontiguousarray(read_len, dtype=np.int64)
         check(_ffi.lib.amg_set_read_lengths(self._h, ptr(rl), 0))
 
-    def set_positions_device(self, gs_ptr, ge_ptr, rl_ptr):
+    def set_positions_device(self, gs_ptr, ge_ptr, rl_ptr, borrow=False):
         check(_ffi.lib.amg_set_positions(self._h, C.c_void_p(gs_ptr), C.c_void_p(ge_ptr),
-                                         C.c_void_p(rl_ptr) if rl_ptr else None, 1))
+                                         C.c_void_p(rl_ptr) if rl_ptr else None, 2 if borrow else 1))
 
     # ---- build + counts
     def build(self, k):

@@ -178,10 +178,10 @@ def main():
             stage_ms[name][1] += 1
 
     def step(record):
-        # inputs are handed over as device pointers: D2D adoption, no PCIe in the step
-        eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v)
+        # inputs are resident in HBM and handed over as borrowed device pointers (no copy, no PCIe)
+        eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v, borrow=True)
         if w["sweep"]:
-            eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr())
+            eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr(), borrow=True)
         build((3, 1) if w["sweep"] else None)
         if record:
             tally()

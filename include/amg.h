@@ -90,7 +90,9 @@ void* amg_stream(amg_ctx* ctx);
 
 /* ---- input: replaces the readDict / gene_positions arguments of
  *      GeneMerGraph.__init__ (construct_graph.py:31) ------------------------------- */
-/* on_device != 0: pointers are device pointers on ctx's device (copied D2D). */
+/* on_device: 0 = host pointers (copied H2D); 1 = device pointers on ctx's device (copied D2D);
+ * 2 = device pointers BORROWED without a copy: the caller keeps the memory alive and unchanged
+ * until the next amg_set_* call for that array or amg_adopt_corrected; it is never written. */
 int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offsets,
                   int64_t n_reads, int32_t two_v, int on_device);
 /* optional: per-gene [start,end] and per-read sequence length, used only by

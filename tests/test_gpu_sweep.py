@@ -107,6 +107,42 @@ def test_low_coverage_components(eng):
         compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
 
 
+def test_borrowed_device_inputs(eng):
+    """inputs handed over as borrowed device pointers (on_device = 2): same corrected reads as
+    with copied inputs, and the caller's arrays are untouched after build / correct / adopt"""
+    import torch
+    from amira_amd import tokenize
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+
+    def sweep(borrow):
+        d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (toks, offs, gs, ge, rl)]
+        keep = [t.clone() for t in d]
+        eng.set_reads_device(d[0].data_ptr(), d[1].data_ptr(), len(offs) - 1, vocab.two_v, borrow=borrow)
+        eng.set_positions_device(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), borrow=borrow)
+        outs = []
+        for _ in range(2):
+            eng.build(5)
+            eng.filter(3, 1)
+            nr, nt = eng.correct_reads()
+            outs.append(eng.corrected(nr, nt, True))
+            eng.adopt_corrected()
+        eng.build(5)
+        torch.cuda.synchronize()
+        for a, b in zip(d, keep):
+            assert torch.equal(a, b)
+        return outs, eng.nodes()["coverage"].copy()
+
+    a, cov_a = sweep(False)
+    b, cov_b = sweep(True)
+    for x, y in zip(a, b):
+        for key in x:
+            assert np.array_equal(x[key], y[key]), key
+    assert np.array_equal(cov_a, cov_b)
+
+
 def _tandem_reads(seed, n_reads, L, err):
     """reads over a genome with tandem gene arrays: corrected and original gene lists of such
     reads are near-periodic, so shifted alignments tie with the diagonal one (the position
