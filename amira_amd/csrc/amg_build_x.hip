@@ -6,7 +6,8 @@
 //
 //   * a node slot is 16 bytes: w1 = low 63 bits of the packed tuple (+ a set bit 0), w2 =
 //     {remaining tuple bits + a set bit, claim id + 1}.  The tuple itself is the key, so no
-//     fingerprint verification pass is needed and one 16-byte load per probe decides it.
+//     fingerprint verification pass is needed and one 16-byte (plain, L2-served) load per
+//     probe decides it; see x_upsert for when a cached view may be trusted.
 //   * the thread that creates a slot gives it a CLAIM id: creators of a block are counted
 //     with a block scan, one atomicAdd per block reserves the ids, the id is published in the
 //     slot (threads that found the key before the id was there wait for it after their own
@@ -23,20 +24,6 @@
 // one-word key.
 #include "amg_tile.h"
 #include "amg_x.h"
-
-__device__ __forceinline__ unsigned int ld_u32(const unsigned int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Slot contents with agent-scope loads.  A plain load would be served by the issuing XCD's L2,
-// which keeps a line fetched while the slot was still empty for the rest of the kernel (the
-// eight L2s are not coherent with each other inside a kernel): every later window of a hot key
-// would then fall into the CAS path (measured: 7x slower).
-__device__ __forceinline__ ulonglong2 ld_slot(const Slot16* s) {
-  ulonglong2 v;
-  v.x = ld_u64(&s->w1);
-  v.y = ld_u64(&s->w2);
-  return v;
-}
 
 // canonical tuple -> (w1, tag): token j occupies bits [j*bits, (j+1)*bits) of a 94-bit value,
 // w1 = (low 63 bits << 1) | 1, tag = (high 31 bits << 1) | 1 — both non-zero by construction
