@@ -447,6 +447,8 @@ struct CorrArgs {
   long long n_reads;
   int k, flip, have_pos;
   // per read
+  unsigned int* gflag;            // 1: the read is re-threaded (RC_GAPPED)
+  unsigned long long* max_bound;  // largest `bound` of a re-threaded read
   unsigned char* cls;
   int* r_start;
   int* r_end;
@@ -518,6 +520,10 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
     a.r_end[r] = end;
     a.bound[r] = bound;    // temp space: only re-threaded reads are staged
     a.new_len[r] = len_out;
+    a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
+    // largest staging bound of a re-threaded read: a plain (possibly stale, never too large)
+    // read first, so that only the few reads that raise the maximum touch the atomic
+    if (cls == RC_GAPPED && (unsigned long long)bound > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)bound);
   }
 }
 
@@ -614,9 +620,17 @@ struct GapIter {
   }
 };
 
+// what the wave-per-read kernel needs to start on gapped read gi, in one 32-byte record
+// (written by k_scatter_gapped) instead of a chain of dependent per-read loads
+struct __attribute__((aligned(16))) GapRec {
+  int r, L0, start, end;
+  long long t0, dst;
+};
+
 struct GapArgs {
   CorrArgs a;
   GView g;
+  const GapRec* rec;
   const int* gapped_reads;
   long long n_gapped;
   int* pool;               // path pool (ints)
@@ -905,12 +919,11 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long gi = (long long)blockIdx.x * 4 + wv;
   if (gi >= A.n_gapped) return;
-  const long long r = A.gapped_reads[gi];
-  const long long t0 = a.read_off[r];
-  const int L0 = (int)(a.read_off[r + 1] - t0);
+  const GapRec rec = A.rec[gi];
+  const long long r = rec.r, t0 = rec.t0, dst = rec.dst;
+  const int L0 = rec.L0;
   const int nwin = L0 - g.k + 1;
-  const int start = a.r_start[r], end = a.r_end[r];
-  const long long dst = a.tmp_off[r];
+  const int start = rec.start, end = rec.end;
   if (nwin > GF_MAXW) {
     if (lane == 0) A.need_slow[gi] = 1;
     return;
@@ -1525,16 +1538,23 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   }
 }
 
-__global__ void k_list_gapped(const unsigned char* __restrict__ cls, long long n_reads,
-                              unsigned int* __restrict__ flag) {
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads) flag[r] = cls[r] == RC_GAPPED ? 1u : 0u;
-}
-
 __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const long long* __restrict__ pos,
-                                 long long n_reads, int* __restrict__ out) {
+                                 long long n_reads, int* __restrict__ out, const long long* __restrict__ read_off,
+                                 const int* __restrict__ r_start, const int* __restrict__ r_end,
+                                 const long long* __restrict__ tmp_off, GapRec* __restrict__ rec) {
   long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && flag[r]) out[pos[r]] = (int)r;
+  if (r >= n_reads || !flag[r]) return;
+  const long long gi = pos[r];
+  out[gi] = (int)r;
+  GapRec q;
+  q.r = (int)r;
+  q.t0 = read_off[r];
+  const long long len = read_off[r + 1] - q.t0;
+  q.L0 = (int)(len > 0x7fffffff ? 0x7fffffff : len);
+  q.start = r_start[r];
+  q.end = r_end[r];
+  q.dst = tmp_off[r];
+  rec[gi] = q;
 }
 
 // global NW scratch size of gapped read gi (0 when it fits the LDS path)
@@ -1567,16 +1587,6 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
   if (final_cls[r] != RC_KEEP_ORIG && !(allow_fast && nw_fast_ok(N, M))) atomicAdd(n_general, 1ull);
 }
 
-__global__ void k_max_u32(const unsigned int* __restrict__ v, const unsigned char* __restrict__ cls,
-                          long long n, unsigned long long* out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long x = (i < n && cls[i] == RC_GAPPED) ? v[i] : 0;
-  for (int d = 32; d > 0; d >>= 1) {
-    unsigned long long y = __shfl_down(x, d, 64);
-    x = x > y ? x : y;
-  }
-  if ((threadIdx.x & 63) == 0 && x) atomicMax(out, x);
-}
 
 extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_out_tokens) {
   NEED_BUILT(c);
@@ -1625,17 +1635,17 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
 
   stage_begin(c, "correct_classify");
   HIPCHK(hipMemsetAsync(bound, 0, per_read * sizeof(unsigned int) * 3, st));
-  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);  // also new_len
-  AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
-  long long tmp_total = 0;
   unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
   HIPCHK(hipMemsetAsync(mx, 0, sizeof(unsigned long long), st));
-  if (R > 0) hipLaunchKernelGGL(k_max_u32, dim3(nblk(R, 256)), dim3(256), 0, st, bound, cls, R, mx);
+  a.gflag = flag;
+  a.max_bound = mx;
+  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);  // also new_len, flag, max
+  AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
+  long long tmp_total = 0;
   unsigned long long max_bound = 0;
   HIPCHK(hipMemcpyAsync(&tmp_total, tmp_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&max_bound, mx, sizeof(max_bound), hipMemcpyDeviceToHost, st));
   // list of gapped reads
-  if (R > 0) hipLaunchKernelGGL(k_list_gapped, dim3(nblk(R, 256)), dim3(256), 0, st, cls, R, flag);
   AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
   long long n_gapped = 0;
   HIPCHK(hipMemcpyAsync(&n_gapped, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1662,8 +1672,9 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     // gapped read list, path pool, candidate scratch: their own allocations
     DevBuf& glist = c->c_orig;  // free until the pack step
     AMGCHK(glist.ensure((size_t)(n_gapped + 1) * sizeof(int)));
+    AMGCHK(c->gap_rec.ensure((size_t)(n_gapped + 1) * sizeof(GapRec)));
     hipLaunchKernelGGL(k_scatter_gapped, dim3(nblk(R, 256)), dim3(256), 0, st, flag, new_idx, R,
-                       glist.as<int>());
+                       glist.as<int>(), a.read_off, r_start, r_end, tmp_off, c->gap_rec.as<GapRec>());
     const unsigned int threads_total = 64u * 2048u;
     unsigned int cand_stride = (unsigned int)(2 * max_bound + (max_bound + 3) / 4 + c->k + 16);
     DevBuf& cand = c->c_gstart;  // free until the pack step
@@ -1680,6 +1691,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       GapArgs G;
       G.a = a;
       G.g = make_view(c);
+      G.rec = c->gap_rec.as<GapRec>();
       G.gapped_reads = glist.as<int>();
       G.n_gapped = n_gapped;
       G.pool = pool.as<int>();
