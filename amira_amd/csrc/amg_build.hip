@@ -396,22 +396,32 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   __syncthreads();
   const long long stride = (long long)gridDim.x * 1024;
   unsigned int beyond = 0;
-  for (long long t = (long long)blockIdx.x * 1024 + threadIdx.x; t < n; t += stride) {
-    int id = ids[t];
+  auto tally = [&](int id, long long t) {
     if (GATHER) {
       id = id < 0 ? -1 : tab[id].id;
       ids[t] = id;
     }
-    if (id < 0) continue;
+    if (id < 0) return;
     const long long rel = (long long)id - lo;
-    if (rel < 0) continue;
+    if (rel < 0) return;
     if (rel < HOT_IDS) {
       atomicAdd(&s_cnt[rel], 1u);
     } else {
       ++beyond;
       if (tail_all) atomicAdd(&out[id], 1u);
     }
+  };
+  // one block per CU (the counters fill the LDS): four loads in flight per thread make up for
+  // the low occupancy
+  long long t = (long long)blockIdx.x * 1024 + threadIdx.x;
+  for (; t + 3 * stride < n; t += 4 * stride) {
+    const int i0 = ids[t], i1 = ids[t + stride], i2 = ids[t + 2 * stride], i3 = ids[t + 3 * stride];
+    tally(i0, t);
+    tally(i1, t + stride);
+    tally(i2, t + 2 * stride);
+    tally(i3, t + 3 * stride);
   }
+  for (; t < n; t += stride) tally(ids[t], t);
   for (int d = 32; d > 0; d >>= 1) beyond += __shfl_down(beyond, d, 64);
   if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
   if (tail_all && blockIdx.x == 0 && threadIdx.x == 0) state[COUNT_MAX_SWEEPS + sweep] = 1ull;
