@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
     unsigned long long emask, unsigned int probe_limit, unsigned long long* status,
     int* __restrict__ tok_pair, unsigned int* first_by_claim, unsigned int* first_init,
-    unsigned int* __restrict__ slot_by_claim) {
+    unsigned int* __restrict__ slot_by_claim, int ablate) {
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
@@ -359,7 +359,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
       d = tok_dir[t];
     }
     int id = -1;
-    if (raw != -1) id = final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG];
+    if (raw != -1) id = (ablate & 64) ? (int)((unsigned int)raw & ~AMG_LAST_FLAG)  // timing experiment
+                                      : final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG];
     s_id[i] = id;
     s_dir[i] = d;
     s_last[i] = (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) ? 1 : 0;
@@ -490,7 +491,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   stage_end(c);
 
   const char* abl = getenv("AMG_X_ABLATE");  // timing experiments (tools/ablate_probe.py): the build fails
-  const int ablate = abl ? atoi(abl) : 0;
+  const int ablate = abl ? (atoi(abl) & 63) : 0;
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
@@ -577,6 +578,8 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_claims * sizeof(unsigned int), st));
   HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
   stage_end(c);
+  const char* abl = getenv("AMG_X_ABLATE");
+  const int ablate = abl ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
   stage_begin(c, "edge_upsert");
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
@@ -584,9 +587,10 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
                        c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
                        c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
-                       c->x_eslot.as<unsigned int>());
+                       c->x_eslot.as<unsigned int>(), ablate);
   AMGCHK(read_status(c, hs));
   stage_end(c);
+  if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");
   if (hs[ST_OVERFLOW]) {
     *which = 2;
