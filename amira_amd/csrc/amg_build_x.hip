@@ -95,9 +95,9 @@ __device__ __forceinline__ int x_canon_pack(const int* w, int flip, int bits, un
 // whichever thread needs it first; that thread owns the slot ("created").
 // Returns the slot or -1; id1 = claim id + 1 if already published.
 template <bool TWO>
-__device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long mask,
+__device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
                                               unsigned long long w1, unsigned int tag,
-                                              unsigned long long idx, ulonglong2 v,
+                                              unsigned int idx, ulonglong2 v,
                                               unsigned int limit, const unsigned long long* abort_flag,
                                               unsigned int& id1, bool& created) {
   created = false;
@@ -109,7 +109,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
     const bool mine = c1 == w1 && (!TWO || (unsigned int)(c2 >> 32) == tag);
     if (mine && (unsigned int)c2 != 0u) {
       id1 = (unsigned int)c2;
-      return (long long)idx;
+      return (int)idx;
     }
     // The cached view does not decide.  No step below waits for another thread (lanes of one
     // wave must never wait for each other inside a loop).
@@ -119,7 +119,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
       if (c1 == 0ull) {
         if (!TWO) {
           created = true;
-          return (long long)idx;
+          return (int)idx;
         }
         c1 = w1;
         c2 = 0ull;
@@ -137,17 +137,17 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
           const unsigned long long old = atomicCAS(&s->w2, 0ull, (unsigned long long)tag << 32);
           if (old == 0ull) {
             created = true;
-            return (long long)idx;
+            return (int)idx;
           }
           c2 = old;
         }
         if ((unsigned int)(c2 >> 32) == tag) {
           id1 = (unsigned int)c2;  // 0: the id is still on its way (x_claim waits for it)
-          return (long long)idx;
+          return (int)idx;
         }
       } else {
         id1 = (unsigned int)c2;
-        return (long long)idx;
+        return (int)idx;
       }
     }
     if (probes >= limit) return -1;
@@ -162,7 +162,7 @@ __device__ __forceinline__ long long x_upsert(Slot16* tab, unsigned long long ma
 // Claim ids for the slots this block created + first-seen bookkeeping.  slot[it] < 0: nothing.
 // On return id1[it] = claim id + 1 of every item with a slot.
 template <bool TWO>
-__device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TILE_ITEMS],
+__device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEMS],
                                         unsigned int (&id1)[TILE_ITEMS], unsigned int created,
                                         const unsigned int (&tag)[TILE_ITEMS],
                                         const unsigned int (&fi)[TILE_ITEMS],
@@ -228,9 +228,9 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const long long (&slot)[TIL
 
 // ------------------------------------------------------------------ nodes
 template <bool TWO, int K>  // K > 0: k known at compile time (the common odd sizes), 0: any k
-__global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
-    int bits, Slot16* tab, unsigned long long mask, unsigned int probe_limit,
+    int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
     unsigned int* first_by_claim, unsigned int* first_init, unsigned int* __restrict__ slot_by_claim,
     int ablate) {
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
   const long long t0 = (long long)blockIdx.x * TILE;
   stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
   const int flip = two_v - 1;
-  unsigned long long w1[TILE_ITEMS], idx[TILE_ITEMS];
-  unsigned int tag[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS];
-  long long slot[TILE_ITEMS];
+  unsigned long long w1[TILE_ITEMS];
+  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS];
+  int slot[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
   int dirs[TILE_ITEMS];
   unsigned int valid = 0, created = 0, last = 0;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
         status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
       } else {
         dirs[it] = dir;
-        idx[it] = mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
+        idx[it] = (unsigned int)mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
         fi[it] = ~(((unsigned int)t << 1) | (dir < 0 ? 1u : 0u));
         valid |= 1u << it;
         if (is_last) last |= 1u << it;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nodes_x(
     if (!(valid & (1u << it))) continue;
     bool made;
     if (ablate & 8) {  // timing experiment: no probe
-      slot[it] = (long long)idx[it];
+      slot[it] = (int)idx[it];
       id1[it] = 1u + (unsigned int)(w1[it] & 1023ull);
       made = false;
     } else
@@ -338,10 +338,10 @@ __global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
 }
 
 // ------------------------------------------------------------------ edges
-__global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
-    unsigned long long emask, unsigned int probe_limit, unsigned long long* status,
+    unsigned int emask, unsigned int probe_limit, unsigned long long* status,
     int* __restrict__ tok_pair, unsigned int* first_by_claim, unsigned int* first_init,
     unsigned int* __restrict__ slot_by_claim, int ablate) {
   __shared__ int s_id[TILE + 1];
@@ -367,9 +367,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     if (i < TILE && t < n_tokens) tok_node[t] = id;
   }
   __syncthreads();
-  unsigned long long key[TILE_ITEMS], idx[TILE_ITEMS];
-  unsigned int fi[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {};
-  long long slot[TILE_ITEMS];
+  unsigned long long key[TILE_ITEMS];
+  unsigned int idx[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {};
+  int slot[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
   unsigned int valid = 0, created = 0;
 #pragma unroll
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_x(
     key[it] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
     const unsigned int orient = (a == lo ? 1u : 0u) | (dA > 0 ? 2u : 0u) | (dB > 0 ? 4u : 0u);
     fi[it] = ~(((unsigned int)(t0 + i) << 3) | orient);
-    idx[it] = mix64(key[it]) & emask;
+    idx[it] = (unsigned int)mix64(key[it]) & emask;
     valid |= 1u << it;
   }
 #pragma unroll
@@ -503,7 +503,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
                        c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
-                       c->node_tab.as<Slot16>(), (unsigned long long)(c->node_slots - 1), kProbeLimitX,
+                       c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                        c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
                        c->x_first.as<unsigned int>() + max_claims, c->x_slot.as<unsigned int>(), ablate);
@@ -584,7 +584,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
-                       c->edge_tab.as<Slot16>(), (unsigned long long)(c->edge_slots - 1), kProbeLimitX,
+                       c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
                        c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
                        c->x_eslot.as<unsigned int>(), ablate);
