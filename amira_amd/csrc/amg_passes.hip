@@ -35,24 +35,44 @@ __global__ void k_filter_edges(const int* __restrict__ src, const int* __restric
 
 // remove_node_from_reads (:442-461): one wave per read; windows of removed nodes become
 // None (-2) and the read joins _readsToCorrect
+// Wave-per-read kernels move ~60 windows per read: one read per wave is bound by the chain
+// offsets -> ids -> flags of a single short read.  Each wave therefore takes READS_PER_WAVE
+// consecutive reads and issues every load of one stage for all of them before using any.
+#define READS_PER_WAVE 4
 __global__ __launch_bounds__(256) void k_mask_reads(int* __restrict__ tok_node,
                                                     const long long* __restrict__ read_off,
                                                     long long n_reads,
                                                     const unsigned char* __restrict__ node_alive,
                                                     unsigned char* __restrict__ read_fix) {
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_reads) return;
-  int lane = threadIdx.x & 63;
-  long long a = read_off[r], b = read_off[r + 1];
-  bool hit = false;
-  for (long long t = a + lane; t < b; t += 64) {
-    int n = tok_node[t];
-    if (n >= 0 && !node_alive[n]) {
-      tok_node[t] = -2;
-      hit = true;
-    }
+  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * READS_PER_WAVE;
+  if (rbase >= n_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long off_l = (lane <= READS_PER_WAVE && rbase + lane <= n_reads) ? read_off[rbase + lane] : 0;
+  long long a[READS_PER_WAVE], b[READS_PER_WAVE];
+  int v[READS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) {
+    a[j] = __shfl(off_l, j, 64);
+    b[j] = rbase + j < n_reads ? __shfl(off_l, j + 1, 64) : a[j];
   }
-  if (__any(hit) && lane == 0) read_fix[r] = 1;
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) v[j] = a[j] + lane < b[j] ? tok_node[a[j] + lane] : -1;
+  bool dead[READS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) dead[j] = v[j] >= 0 && !node_alive[v[j]];
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) {
+    if (dead[j]) tok_node[a[j] + lane] = -2;
+    bool hit = dead[j];
+    for (long long t = a[j] + 64 + lane; t < b[j]; t += 64) {  // reads longer than one wave
+      const int n = tok_node[t];
+      if (n >= 0 && !node_alive[n]) {
+        tok_node[t] = -2;
+        hit = true;
+      }
+    }
+    if (__any(hit) && lane == 0) read_fix[rbase + j] = 1;
+  }
 }
 
 static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
@@ -64,7 +84,7 @@ static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
                        c->node_alive.as<unsigned char>(), c->edge_alive.as<unsigned char>(),
                        c->n_edges, min_edge_cov);
   if (c->n_reads > 0)
-    hipLaunchKernelGGL(k_mask_reads, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_mask_reads, dim3(nblk(c->n_reads, 4 * READS_PER_WAVE)), dim3(256), 0, st,
                        c->tok_node.as<int>(), c->read_off.as<long long>(), c->n_reads,
                        c->node_alive.as<unsigned char>(), c->read_fix.as<unsigned char>());
   return AMG_OK;
@@ -462,68 +482,101 @@ struct CorrArgs {
 };
 
 __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= a.n_reads) return;
+  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * READS_PER_WAVE;
+  if (rbase >= a.n_reads) return;
   const int lane = threadIdx.x & 63;
-  const long long t0 = a.read_off[r], t1 = a.read_off[r + 1];
-  const long long L = t1 - t0, n = L - a.k + 1;
-  unsigned char cls;
-  int start = 0, end = -1;
-  unsigned int bound = 0;
-  unsigned int len_out = 0;  // genes of the corrected read, known here unless it has None runs
-  if (n <= 0) {
-    cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
-  } else if (!a.read_fix[r]) {
-    cls = RC_COPY;
-    len_out = (unsigned int)L;
-  } else {
-    long long first = n, last = -1;
-    for (long long i = lane; i < n; i += 64)
-      if (a.tok_node[t0 + i] >= 0) {
-        first = first < i ? first : i;
-        last = last > i ? last : i;
-      }
-    for (int d = 32; d > 0; d >>= 1) {
-      long long f2 = __shfl_xor(first, d, 64), l2 = __shfl_xor(last, d, 64);
-      first = first < f2 ? first : f2;
-      last = last > l2 ? last : l2;
-    }
-    if (last < 0) {
-      cls = RC_DROP;  // every node filtered: the read is dropped (:1141,:1150)
-    } else {
-      start = (int)first;
-      end = (int)last;
-      unsigned int runs = 0, live = 0;
-      for (long long i = first + lane; i <= last; i += 64) {
-        bool none = a.tok_node[t0 + i] < 0;
-        live += none ? 0u : 1u;
-        // a None run ends where the next window is live
-        if (none && a.tok_node[t0 + i + 1] >= 0) ++runs;
-      }
-      for (int d = 32; d > 0; d >>= 1) {
-        runs += __shfl_xor(runs, d, 64);
-        live += __shfl_xor(live, d, 64);
-      }
-      if (runs == 0) {
-        cls = RC_TRIM;
-        len_out = (unsigned int)(end - start + a.k);
-      } else {
-        cls = RC_GAPPED;
-        unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
-        bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
-      }
-    }
+  // stage 1: offsets and fix flags of the wave's reads (one load each), stage 2: the first 64
+  // window ids of every read that needs a look, stage 3: ballots instead of reductions
+  const long long off_l = (lane <= READS_PER_WAVE && rbase + lane <= a.n_reads) ? a.read_off[rbase + lane] : 0;
+  const int fix_l = (lane < READS_PER_WAVE && rbase + lane < a.n_reads) ? a.read_fix[rbase + lane] : 0;
+  long long t0[READS_PER_WAVE], n[READS_PER_WAVE];
+  int v[READS_PER_WAVE];
+  bool look[READS_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) {
+    t0[j] = __shfl(off_l, j, 64);
+    const long long t1 = rbase + j < a.n_reads ? __shfl(off_l, j + 1, 64) : t0[j];
+    n[j] = (t1 - t0[j]) - a.k + 1;  // windows; L = n + k - 1
+    look[j] = rbase + j < a.n_reads && n[j] > 0 && __shfl(fix_l, j, 64) != 0;
   }
-  if (lane == 0) {
-    a.cls[r] = cls;
-    a.r_start[r] = start;
-    a.r_end[r] = end;
-    a.bound[r] = bound;    // temp space: only re-threaded reads are staged
-    a.new_len[r] = len_out;
-    a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
-    // largest staging bound of a re-threaded read: a plain (possibly stale, never too large)
-    // read first, so that only the few reads that raise the maximum touch the atomic
-    if (cls == RC_GAPPED && (unsigned long long)bound > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)bound);
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) v[j] = (look[j] && lane < n[j]) ? a.tok_node[t0[j] + lane] : -1;
+#pragma unroll
+  for (int j = 0; j < READS_PER_WAVE; ++j) {
+    const long long r = rbase + j;
+    if (r >= a.n_reads) break;
+    const long long L = n[j] + a.k - 1;
+    unsigned char cls;
+    int start = 0, end = -1;
+    unsigned int bound = 0;
+    unsigned int len_out = 0;  // genes of the corrected read, known here unless it has None runs
+    if (n[j] <= 0) {
+      cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
+    } else if (!look[j]) {
+      cls = RC_COPY;
+      len_out = (unsigned int)L;
+    } else {
+      long long first, last;
+      unsigned int runs = 0, live = 0;
+      if (n[j] <= 64) {
+        const unsigned long long lv = __ballot(v[j] >= 0);  // lanes >= n hold -1
+        first = lv ? (long long)__ffsll((long long)lv) - 1 : n[j];
+        last = lv ? 63 - (long long)__clzll((long long)lv) : -1;
+        live = (unsigned int)__popcll(lv);
+        // a None run ends where the next window is live (windows past `last` are not live)
+        const unsigned long long inside = lv ? ((last == 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << first) - 1ull)) : 0ull;
+        runs = (unsigned int)__popcll(~lv & inside & (lv >> 1));
+      } else {
+        first = n[j];
+        last = -1;
+        for (long long i = lane; i < n[j]; i += 64)
+          if (a.tok_node[t0[j] + i] >= 0) {
+            first = first < i ? first : i;
+            last = last > i ? last : i;
+          }
+        for (int d = 32; d > 0; d >>= 1) {
+          long long f2 = __shfl_xor(first, d, 64), l2 = __shfl_xor(last, d, 64);
+          first = first < f2 ? first : f2;
+          last = last > l2 ? last : l2;
+        }
+        if (last >= 0) {
+          for (long long i = first + lane; i <= last; i += 64) {
+            bool none = a.tok_node[t0[j] + i] < 0;
+            live += none ? 0u : 1u;
+            if (none && a.tok_node[t0[j] + i + 1] >= 0) ++runs;
+          }
+          for (int d = 32; d > 0; d >>= 1) {
+            runs += __shfl_xor(runs, d, 64);
+            live += __shfl_xor(live, d, 64);
+          }
+        }
+      }
+      if (last < 0) {
+        cls = RC_DROP;  // every node filtered: the read is dropped (:1141,:1150)
+      } else {
+        start = (int)first;
+        end = (int)last;
+        if (runs == 0) {
+          cls = RC_TRIM;
+          len_out = (unsigned int)(end - start + a.k);
+        } else {
+          cls = RC_GAPPED;
+          unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
+          bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
+        }
+      }
+    }
+    if (lane == j) {
+      a.cls[r] = cls;
+      a.r_start[r] = start;
+      a.r_end[r] = end;
+      a.bound[r] = bound;    // temp space: only re-threaded reads are staged
+      a.new_len[r] = len_out;
+      a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
+      // largest staging bound of a re-threaded read: a plain (possibly stale, never too large)
+      // read first, so that only the few reads that raise the maximum touch the atomic
+      if (cls == RC_GAPPED && (unsigned long long)bound > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)bound);
+    }
   }
 }
 
@@ -1639,7 +1692,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   HIPCHK(hipMemsetAsync(mx, 0, sizeof(unsigned long long), st));
   a.gflag = flag;
   a.max_bound = mx;
-  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4)), dim3(256), 0, st, a);  // also new_len, flag, max
+  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * READS_PER_WAVE)), dim3(256), 0, st, a);  // also new_len, flag, max
   AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
   long long tmp_total = 0;
   unsigned long long max_bound = 0;
