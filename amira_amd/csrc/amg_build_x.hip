@@ -310,6 +310,70 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
   }
 }
 
+// ---- ranking by first-seen without a sort (graphs up to a few million keys).  A token
+// position opens at most one window / adjacency, so the first-seen token indices of the claims are
+// distinct: set one bit per claim in a bitmap over the tokens, prefix-count the bitmap words, and
+// the rank of a claim is the number of bits before its own.  (A radix sort of 0.5 - 1 M pairs
+// costs ~10 launches and ~0.2 ms however small the input; this costs ~0.06 ms.)
+__global__ void k_x_rank_setbits(const unsigned int* __restrict__ first_by_claim,
+                                 const unsigned int* __restrict__ first_init, long long n, int shift,
+                                 unsigned int* __restrict__ bits) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int a = first_by_claim[i], b = first_init[i];
+  const unsigned int t = (~(a > b ? a : b)) >> shift;
+  atomicOr(&bits[t >> 5], 1u << (t & 31));
+}
+
+__global__ void k_x_rank_popc(const unsigned int* __restrict__ bits, long long n_words,
+                              unsigned int* __restrict__ cnt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) cnt[i] = (unsigned int)__popc(bits[i]);
+}
+
+__device__ __forceinline__ long long x_rank_of(unsigned int t, const unsigned int* __restrict__ bits,
+                                               const long long* __restrict__ prefix) {
+  const unsigned int w = bits[t >> 5];
+  return prefix[t >> 5] + (long long)__popc(w & ((1u << (t & 31)) - 1u));
+}
+
+__global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first_by_claim,
+                                        const unsigned int* __restrict__ first_init, long long n_nodes,
+                                        const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
+                                        const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
+                                        int k, int nbits, int* __restrict__ final_of_claim,
+                                        int* __restrict__ node_tokens, long long* __restrict__ node_first,
+                                        unsigned char* __restrict__ node_alive) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_nodes) return;
+  const unsigned int a = first_by_claim[c], b = first_init[c];
+  const unsigned int first = ~(a > b ? a : b);
+  const long long i = x_rank_of(first >> 1, bits, prefix);
+  final_of_claim[c] = (int)i;
+  node_first[i] = (long long)first;
+  node_alive[i] = 1;
+  const Slot16 s = tab[slot_by_claim[c]];
+  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, nbits, j);
+}
+
+__global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first_by_claim,
+                                        const unsigned int* __restrict__ first_init, long long n_pairs,
+                                        const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
+                                        const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
+                                        const unsigned int* __restrict__ cnt_by_claim,
+                                        unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
+                                        unsigned int* __restrict__ pcnt) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_pairs) return;
+  const unsigned int a = first_by_claim[c], b = first_init[c];
+  const unsigned int first = ~(a > b ? a : b);
+  const long long i = x_rank_of(first >> 3, bits, prefix);
+  pkey[i] = etab[slot_by_claim[c]].w1;
+  pfirst[i] = (unsigned long long)first;
+  pcnt[i] = cnt_by_claim[c];
+}
+
 __global__ void k_x_sort_keys(const unsigned int* __restrict__ first_by_claim,
                               const unsigned int* __restrict__ first_init, long long n,
                               unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
@@ -432,6 +496,23 @@ static inline unsigned int blocks_for(long long n, int per) {
 }
 
 static const unsigned int kProbeLimitX = 1024;
+static const long long kRankBitmapMax = 2ll << 20;  // claims up to which the bitmap ranking beats the sort
+
+// bitmap over the tokens (s1) with one bit per claim + exclusive prefix of the word popcounts (s5)
+static int x_rank_bitmap(amg_ctx* c, const unsigned int* first_a, const unsigned int* first_b, long long n,
+                         int shift) {
+  hipStream_t st = c->stream;
+  const long long words = (c->n_tokens >> 5) + 2;
+  AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(words + 1) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(words + 1) * sizeof(long long)));
+  HIPCHK(hipMemsetAsync(c->s1.p, 0, (size_t)words * sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_x_rank_setbits, dim3(blocks_for(n, 256)), dim3(256), 0, st, first_a, first_b, n, shift,
+                     c->s1.as<unsigned int>());
+  hipLaunchKernelGGL(k_x_rank_popc, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
+                     words, c->s2.as<unsigned int>());
+  return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
+}
 
 static int read_status(amg_ctx* c, unsigned long long* host) {
   HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -538,7 +619,14 @@ int bx_nodes_rank(amg_ctx* c) {
   AMGCHK(c->s3.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(bs_alloc_nodes(c, D));
-  if (D > 0) {
+  if (D > 0 && D <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
+    AMGCHK(x_rank_bitmap(c, c->x_first.as<unsigned int>(), c->x_first.as<unsigned int>() + max_claims, D, 1));
+    hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(D, 256)), dim3(256), 0, st,
+                       c->x_first.as<unsigned int>(), c->x_first.as<unsigned int>() + max_claims, D,
+                       c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
+                       c->x_slot.as<unsigned int>(), k, c->x_bits, c->x_final.as<int>(), c->node_tokens.as<int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+  } else if (D > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
                        c->x_first.as<unsigned int>() + max_claims, D, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());
@@ -622,7 +710,15 @@ int bx_edges_rank(amg_ctx* c) {
   AMGCHK(c->s2.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s3.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
-  if (P > 0) {
+  if (P > 0 && P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
+    AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims, P, 3));
+    hipLaunchKernelGGL(k_x_gather_pairs_ranked, dim3(blocks_for(P, 256)), dim3(256), 0, st,
+                       c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims, P,
+                       c->s1.as<unsigned int>(), c->s5.as<long long>(), c->edge_tab.as<Slot16>(),
+                       c->x_eslot.as<unsigned int>(), c->x_ecnt.as<unsigned int>(),
+                       c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
+                       c->pair_cnt.as<unsigned int>());
+  } else if (P > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
                        c->x_efirst.as<unsigned int>() + max_claims, P, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());
