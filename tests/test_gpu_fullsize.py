@@ -24,16 +24,22 @@ def _invariants(eng, c, L, k):
     assert bool(np.all(np.diff(nodes["first_token"]) > 0))
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
-def test_full_size_build_equals_c_oracle(workload):
+@pytest.mark.parametrize("workload,k,exact", [("cfg2", None, 1), ("cfg3", None, 1), ("cfg3", 3, 1),
+                                                  ("cfg2", 7, 0)])
+def test_full_size_build_equals_c_oracle(workload, k, exact):
+    """k = None: the configuration's own k (5: two-word exact keys); k = 3: one-word exact keys;
+    k = 7 on the 5 000-gene vocabulary (98 bits): the verified-fingerprint path"""
     import bench
     from amira_amd import Engine
-    w = bench.WORKLOADS[workload]
+    w = dict(bench.WORKLOADS[workload])
+    if k is not None:
+        w["k"] = k
     vocab, toks, offs = bench.make_tokens(w, 0, w["N"])
     eng = Engine(0)
     eng.set_reads(toks, offs, vocab.two_v)
     eng.build(w["k"])
     c = eng.counts()
+    assert c["exact_keys"] == exact
     _invariants(eng, c, w["L"], w["k"])
     want = token_oracle.build(toks, offs, w["k"], vocab.two_v)
     nodes, edges = eng.nodes(), eng.edges()
