@@ -52,14 +52,13 @@ def make_case(rng):
     return reads, k, dict(V=V, glen=len(genome), n_reads=n_reads, err=err, indel=indel, k=k)
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+def run(budget, seed, max_cases=None):
+    """returns (sweeps equal to the oracle, palindrome assertions on both sides, failures)"""
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     t_end = time.time() + budget
     n_ok = n_pal = n_fail = 0
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or n_ok + n_pal + n_fail < max_cases):
         reads, k, info = make_case(rng)
         pos = synth.positions_for(reads)
         fq = P.FakeFastq(synth.fake_fastq_lengths(reads))
@@ -82,12 +81,27 @@ def main():
                         print("MISMATCH (palindrome case):", repr(e2), info, flush=True); n_fail += 1
             else:
                 print("MISMATCH:", info, flush=True); traceback.print_exc(); n_fail += 1
-        except Exception:  # noqa: BLE001
-            print("ERROR:", info, flush=True); traceback.print_exc(); n_fail += 1
+        except Exception as e:  # noqa: BLE001
+            if getattr(e, "code", None) == -4:   # the engine met a palindromic gene-mer: so must the oracle
+                from amira_oracle import GeneMerGraph
+                try:
+                    GeneMerGraph(reads, k, pos)
+                    print("MISMATCH: engine asserted a palindrome, oracle built", info, flush=True); n_fail += 1
+                except AssertionError as e2:
+                    if "identical" in str(e2):
+                        n_pal += 1
+                    else:
+                        print("MISMATCH (palindrome case):", repr(e2), info, flush=True); n_fail += 1
+            else:
+                print("ERROR:", info, flush=True); traceback.print_exc(); n_fail += 1
         if n_fail >= 5:
             break
     print(f"fuzz: {n_ok} sweeps equal to the oracle, {n_pal} palindrome assertions on both sides, {n_fail} failures (seed {seed})")
     eng.close()
-    sys.exit(1 if n_fail else 0)
+    return n_ok, n_pal, n_fail
 
-main()
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    sys.exit(1 if run(budget, seed)[2] else 0)
