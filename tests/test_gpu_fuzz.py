@@ -18,3 +18,14 @@ def test_random_sweeps_equal_oracle(seed):
     spec.loader.exec_module(fz)
     n_ok, n_pal, n_fail = fz.run(budget=120.0, seed=seed, max_cases=20)
     assert n_fail == 0 and n_ok + n_pal == 20
+
+
+def test_random_merged_builds_equal_unsharded():
+    """tools/fuzz_dist.py: 2 - 8 emulated ranks with uneven (also empty) shards, plain merge and
+    merge with the fused coverage filter, against the unsharded engine"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_dist", os.path.join(root, "tools", "fuzz_dist.py"))
+    fd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fd)
+    n_ok, n_skip, n_fail = fd.run(budget=120.0, seed=4711, max_cases=150)
+    assert n_fail == 0 and n_ok > 100
