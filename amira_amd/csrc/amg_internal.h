@@ -213,6 +213,7 @@ struct amg_ctx {
   DevBuf status;       // unsigned long long[ST_WORDS]
   DevBuf sort_tmp;     // rocPRIM temp storage
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
+  DevBuf nw_big;       // global scratch of the general position carry-over kernel (long reads)
   DevBuf gap_rec;      // per gapped read: the record k_corr_gapped_fast starts from
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t

@@ -475,10 +475,8 @@ struct CorrArgs {
   unsigned int* bound;
   const long long* tmp_off;
   unsigned int* new_len;
-  // temp output
+  // staged genes of the re-threaded reads
   int* tmp_tok;
-  long long* tmp_gs;
-  long long* tmp_ge;
 };
 
 __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
@@ -1168,12 +1166,16 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
 
 struct __attribute__((aligned(16))) NwRec {
   int r, M, N, pad;
-  long long t0, dst;
+  long long t0, dst;  // first token of the read, first staged gene of its corrected version
+  long long pdst;     // first gene of the read in the CORRECTED set (positions are written in place)
+  long long pad2;
 };
 
 struct NwArgs {
   CorrArgs a;
   const NwRec* rec;  // per gapped read, written by k_nw_sizes
+  long long* o_gs;   // gene positions of the corrected set: the carry-over writes its reads' entries
+  long long* o_ge;   // directly (no staging copy for the pack step to move again)
   const int* gapped_reads;
   long long n_gapped;
   const unsigned char* final_cls;
@@ -1189,7 +1191,8 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
   const CorrArgs& a = A.a;
   const long long gi = blockIdx.x;
   if (gi >= A.n_gapped) return;
-  const long long r = A.gapped_reads[gi];
+  const long long r = A.rec[gi].r;
+  const long long pdst = A.rec[gi].pdst;
   if (A.final_cls[r] == RC_KEEP_ORIG) return;  // original genes kept: positions untouched
   const int lane = threadIdx.x;
   const long long t0 = a.read_off[r];
@@ -1256,17 +1259,17 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
     unsigned char p = ops[o];
     if (p == 0) {
       if (x[xi] == y[yj]) {
-        a.tmp_gs[dst + out] = a.gstart[t0 + cur];
-        a.tmp_ge[dst + out] = a.gend[t0 + cur];
+        A.o_gs[pdst + out] = a.gstart[t0 + cur];
+        A.o_ge[pdst + out] = a.gend[t0 + cur];
         ++cur;
       } else {
-        a.tmp_gs[dst + out] = NONE;
-        a.tmp_ge[dst + out] = NONE;
+        A.o_gs[pdst + out] = NONE;
+        A.o_ge[pdst + out] = NONE;
       }
       ++out; ++xi; ++yj;
     } else if (p == 1) {
-      a.tmp_gs[dst + out] = NONE;
-      a.tmp_ge[dst + out] = NONE;
+      A.o_gs[pdst + out] = NONE;
+      A.o_ge[pdst + out] = NONE;
       ++out; ++xi;
     } else {
       ++cur; ++yj;
@@ -1277,14 +1280,14 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
   long long prev_end = 0;
   const long long rl = a.read_len ? a.read_len[r] : 0;
   for (int q = 0; q < N; ++q) {
-    long long sv = a.tmp_gs[dst + q], ev = a.tmp_ge[dst + q];
+    long long sv = A.o_gs[pdst + q], ev = A.o_ge[pdst + q];
     if (ev != NONE) prev_end = ev;
     if (sv == NONE && ev == NONE) {
       long long nxt = NONE;
       for (int w = q + 1; w < N; ++w)
-        if (a.tmp_gs[dst + w] != NONE) { nxt = a.tmp_gs[dst + w]; break; }
-      a.tmp_gs[dst + q] = prev_end;
-      a.tmp_ge[dst + q] = (nxt != NONE) ? nxt : rl - 1;
+        if (A.o_gs[pdst + w] != NONE) { nxt = A.o_gs[pdst + w]; break; }
+      A.o_gs[pdst + q] = prev_end;
+      A.o_ge[pdst + q] = (nxt != NONE) ? nxt : rl - 1;
     }
   }
 }
@@ -1316,7 +1319,7 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
   const int N = __builtin_amdgcn_readfirstlane(q.N);
   if (N == 0) return;  // original genes kept, or a read for k_corr_nw
   const int M = __builtin_amdgcn_readfirstlane(q.M);
-  const long long r = q.r, t0 = q.t0, dst = q.dst;
+  const long long r = q.r, t0 = q.t0, dst = q.dst, pdst = q.pdst;
   int* X = s_x[wv];
   unsigned int* OPW = s_opw[wv];
   long long* GS = s_gs[wv];
@@ -1482,8 +1485,8 @@ __global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
       sv = prev_end;
       ev = (nxt != NONE) ? nxt : rl - 1;
     }
-    a.tmp_gs[dst + q] = sv;
-    a.tmp_ge[dst + q] = ev;
+    A.o_gs[pdst + q] = sv;
+    A.o_ge[pdst + q] = ev;
   }
 }
 
@@ -1536,11 +1539,9 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
       dst[j] = A.new_off[r];
       n[j] = a.new_len[r];
       fcs[j] = A.final_cls[r];
-      if (fcs[j] == RC_GAPPED) {  // re-threaded read: staged in the temp area
-        const long long src = a.tmp_off[r];
+      if (fcs[j] == RC_GAPPED) {  // re-threaded read: genes staged in the temp area, positions
+        const long long src = a.tmp_off[r];  // already written in place by the carry-over kernels
         stok[j] = a.tmp_tok + src;
-        sgs[j] = a.tmp_gs + src;
-        sge[j] = a.tmp_ge + src;
       } else {  // untouched read, kept original, or a slice [start : end + k] of it (:1277-1285)
         const long long src = a.read_off[r] + (fcs[j] == RC_TRIM ? a.r_start[r] : 0);
         stok[j] = a.tokens + src;
@@ -1555,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   for (int j = 0; j < PACK_READS; ++j)
     if (lane < n[j]) {
       vt[j] = stok[j][lane];
-      if (a.have_pos) {
+      if (a.have_pos && fcs[j] != RC_GAPPED) {
         vs[j] = sgs[j][lane];
         ve[j] = sge[j][lane];
       }
@@ -1564,7 +1565,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   for (int j = 0; j < PACK_READS; ++j)
     if (lane < n[j]) {
       A.o_tok[dst[j] + lane] = vt[j];
-      if (a.have_pos) {
+      if (a.have_pos && fcs[j] != RC_GAPPED) {
         A.o_gs[dst[j] + lane] = vs[j];
         A.o_ge[dst[j] + lane] = ve[j];
       }
@@ -1573,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   for (int j = 0; j < PACK_READS; ++j)
     for (long long i = 64 + lane; i < n[j]; i += 64) {  // reads longer than one wave
       A.o_tok[dst[j] + i] = stok[j][i];
-      if (a.have_pos) {
+      if (a.have_pos && fcs[j] != RC_GAPPED) {
         A.o_gs[dst[j] + i] = sgs[j][i];
         A.o_ge[dst[j] + i] = sge[j][i];
       }
@@ -1613,7 +1614,7 @@ __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const lo
 // global NW scratch size of gapped read gi (0 when it fits the LDS path)
 __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
                            const long long* __restrict__ read_off, const unsigned int* __restrict__ new_len,
-                           const long long* __restrict__ tmp_off,
+                           const long long* __restrict__ tmp_off, const long long* __restrict__ new_off,
                            const unsigned char* __restrict__ final_cls, long long* __restrict__ size,
                            int allow_fast, unsigned long long* n_general, NwRec* __restrict__ rec) {
   long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1630,6 +1631,8 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
     q.pad = 0;
     q.t0 = read_off[r];
     q.dst = tmp_off[r];
+    q.pdst = new_off[r];
+    q.pad2 = 0;
     rec[gi] = q;
   }
   bool small = (N <= NW_LDS_N && M <= NW_LDS_N && N * M <= NW_LDS_CELLS);
@@ -1684,7 +1687,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.tmp_off = tmp_off;
   a.new_len = new_len;
   a.tmp_tok = nullptr;
-  a.tmp_gs = a.tmp_ge = nullptr;
 
   stage_begin(c, "correct_classify");
   HIPCHK(hipMemsetAsync(bound, 0, per_read * sizeof(unsigned int) * 3, st));
@@ -1709,12 +1711,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   DevBuf& tmpTok = c->s4;
   AMGCHK(tmpTok.ensure((size_t)(tmp_total + 4) * sizeof(int)));
   a.tmp_tok = tmpTok.as<int>();
-  DevBuf& tmpPos = c->s5;
-  if (c->have_pos) {
-    AMGCHK(tmpPos.ensure((size_t)(tmp_total + 4) * sizeof(long long) * 2));
-    a.tmp_gs = tmpPos.as<long long>();
-    a.tmp_ge = a.tmp_gs + (tmp_total + 4);
-  }
   HIPCHK(hipMemcpyAsync(final_cls, cls, (size_t)R, hipMemcpyDeviceToDevice, st));
 
   if (n_gapped > 0) {
@@ -1774,47 +1770,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     }
     stage_end(c);
 
-    if (c->have_pos) {
-      stage_begin(c, "correct_positions");
-      // global scratch only for reads too large for the LDS path
-      long long* nw_size = reinterpret_cast<long long*>(
-          ((uintptr_t)(c->s1.as<int>() + 2 * per_read) + 15) & ~(uintptr_t)15);
-      long long* nw_off = nw_size + per_read;
-      HIPCHK(hipMemsetAsync(nw_size, 0, (size_t)(n_gapped + 1) * sizeof(long long), st));
-      const char* nfn = getenv("AMG_NO_FAST_NW");
-      const int allow_fast = !(nfn && nfn[0] == '1');
-      unsigned long long* n_general_d = c->status.as<unsigned long long>() + ST_MISC;
-      HIPCHK(hipMemsetAsync(n_general_d, 0, sizeof(unsigned long long), st));
-      AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
-      hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
-                         n_gapped, a.read_off, new_len, tmp_off, final_cls, nw_size, allow_fast, n_general_d,
-                         c->nw_rec.as<NwRec>());
-      AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
-      long long big_total = 0;
-      unsigned long long n_general = 0;
-      HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipMemcpyAsync(&n_general, n_general_d, sizeof(n_general), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      DevBuf& big = c->c_gend;  // the path pool is done
-      AMGCHK(big.ensure((size_t)big_total + 64));
-      NwArgs W;
-      W.a = a;
-      W.rec = c->nw_rec.as<NwRec>();
-      W.gapped_reads = c->c_orig.as<int>();
-      W.n_gapped = n_gapped;
-      W.final_cls = final_cls;
-      W.big_off = nw_off;
-      W.big_buf = big.as<unsigned char>();
-      W.allow_fast = allow_fast;
-      if (W.allow_fast)
-        hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, W);
-      if (n_general > 0)  // reads too long for the register-resident kernel
-        hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
-      stage_end(c);
-    }
   }
 
-  // ---- pack
+  // ---- shape of the corrected set (before the position carry-over, which writes its reads'
+  // positions straight into the output arrays)
   stage_begin(c, "correct_pack");
   if (R > 0) hipLaunchKernelGGL(k_corr_keep, dim3(nblk(R, 256)), dim3(256), 0, st, new_len, R, flag);
   HIPCHK(hipMemsetAsync(flag + R, 0, sizeof(unsigned int), st));
@@ -1824,7 +1783,32 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   long long out_reads = 0, out_tokens = 0;
   HIPCHK(hipMemcpyAsync(&out_reads, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&out_tokens, new_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  const bool carry = n_gapped > 0 && c->have_pos;
+  long long big_total = 0;
+  unsigned long long n_general = 0;
+  long long* nw_off = nullptr;
+  const char* nfn = getenv("AMG_NO_FAST_NW");
+  const int allow_fast = !(nfn && nfn[0] == '1');
+  if (carry) {
+    // global scratch only for reads too large for the register-resident kernel
+    long long* nw_size = reinterpret_cast<long long*>(
+        ((uintptr_t)(c->s1.as<int>() + 2 * per_read) + 15) & ~(uintptr_t)15);
+    nw_off = nw_size + per_read;
+    HIPCHK(hipMemsetAsync(nw_size, 0, (size_t)(n_gapped + 1) * sizeof(long long), st));
+    unsigned long long* n_general_d = c->status.as<unsigned long long>() + ST_MISC;
+    HIPCHK(hipMemsetAsync(n_general_d, 0, sizeof(unsigned long long), st));
+    AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
+    hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
+                       n_gapped, a.read_off, new_len, tmp_off, new_off, final_cls, nw_size, allow_fast,
+                       n_general_d, c->nw_rec.as<NwRec>());
+    AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
+    HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_general, n_general_d, sizeof(n_general), hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(hipStreamSynchronize(st));
+  stage_end(c);
+  // from here on the scratch roles of the output buffers (gapped read list, path pool, candidate
+  // scratch) are over
   AMGCHK(c->c_tokens_buf.ensure((size_t)(out_tokens + 64) * sizeof(int)));
   AMGCHK(c->c_read_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   AMGCHK(c->c_orig.ensure((size_t)(out_reads + 2) * sizeof(int)));
@@ -1834,6 +1818,30 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     AMGCHK(c->c_gend.ensure((size_t)(out_tokens + 64) * sizeof(long long)));
   }
   if (c->have_read_len) AMGCHK(c->c_read_len.ensure((size_t)(out_reads + 2) * sizeof(long long)));
+
+  if (carry) {
+    stage_begin(c, "correct_positions");
+    AMGCHK(c->nw_big.ensure((size_t)big_total + 64));
+    NwArgs W;
+    W.a = a;
+    W.rec = c->nw_rec.as<NwRec>();
+    W.o_gs = c->c_gstart.as<long long>();
+    W.o_ge = c->c_gend.as<long long>();
+    W.gapped_reads = nullptr;  // the records carry the read ids
+    W.n_gapped = n_gapped;
+    W.final_cls = final_cls;
+    W.big_off = nw_off;
+    W.big_buf = c->nw_big.as<unsigned char>();
+    W.allow_fast = allow_fast;
+    if (W.allow_fast)
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, W);
+    if (n_general > 0)  // reads too long for the register-resident kernel
+      hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
+    stage_end(c);
+  }
+
+  // ---- pack
+  stage_begin(c, "correct_pack");
   PackArgs Pk;
   Pk.a = a;
   Pk.keep = flag;
