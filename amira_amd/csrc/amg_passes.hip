@@ -692,6 +692,7 @@ struct GapArgs {
   unsigned int cand_stride;
   unsigned char* final_cls;
   unsigned char* need_slow;  // per gapped read: 1 = the wave-per-read fast kernel gave up
+  int ablate;                // timing experiments (AMG_GAP_ABLATE): 1 stop before the DFS, 2 stop after it
 };
 
 // build candidate `combo` (mixed radix over the gaps' path choices) into (out_node, out_dir);
@@ -871,7 +872,7 @@ __device__ __forceinline__ bool nw_fast_ok(long long N, long long M) {
 // scratch spends its time in dependent LDS/scratch round trips.)
 // Emits [run, len, nodes, dirs] records; returns the number of paths, -1 on pool overflow.
 __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distance, int run, int* pool,
-                              int* used, int lane) {
+                              int* used, int lane, unsigned long long* dbg = nullptr) {
   int my_node = 0, my_dir = 0, my_cur = 0, my_lim = 0, my_off = 0;
   int depth = 0, n_paths = 0;
   bool overflow = false;
@@ -881,8 +882,11 @@ __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distan
   }
   bool entering = true;
   int2 first_ent = make_int2(-1, 0);
+  unsigned int n_iter = 0, n_enter = 0;
   while (depth >= 0) {
     const int d = __builtin_amdgcn_readfirstlane(depth);
+    ++n_iter;
+    if (entering) ++n_enter;
     if (entering) {
       const int L = d + 1;
       const int cur_node = __builtin_amdgcn_readlane(my_node, d);
@@ -951,24 +955,34 @@ __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distan
       first_ent.x = -1;  // back in an older row: its first entry was consumed long ago
     }
   }
+  if (dbg && lane == 0) {
+    atomicAdd(dbg + 0, (unsigned long long)n_iter);
+    atomicAdd(dbg + 1, (unsigned long long)n_enter);
+    atomicAdd(dbg + 2, 1ull);
+    atomicAdd(dbg + 3, (unsigned long long)n_paths);
+  }
   return overflow ? -1 : n_paths;
 }
 
-__global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
-  __shared__ int s_node[4][GF_MAXW];
-  __shared__ signed char s_dir[4][GF_MAXW];
-  __shared__ int s_tok[4][GF_MAXW + AMG_MAX_K];
-  __shared__ int s_gap[4][GF_MAXGAP * 3];  // ps, pe, n_paths
-  __shared__ int s_pool[4][GF_POOL];
-  __shared__ int s_used[4];
-  __shared__ int s_cnode[4][GF_CAND];
-  __shared__ signed char s_cdir[4][GF_CAND];
-  __shared__ int s_gene[4][GF_CAND + AMG_MAX_K];
-  __shared__ int s_best[4][GF_CAND + AMG_MAX_K];
+// GF_WPB reads (waves) per workgroup.  The LDS of a workgroup is held until its LAST wave is done
+// and reads differ a lot in work (runs, paths): with four waves per workgroup the kernel ran at
+// half its occupancy limit waiting for stragglers (2.05 ms; 1.83 ms with two, 1.80 ms with one).
+#define GF_WPB 1
+__global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) {
+  __shared__ int s_node[GF_WPB][GF_MAXW];
+  __shared__ signed char s_dir[GF_WPB][GF_MAXW];
+  __shared__ int s_tok[GF_WPB][GF_MAXW + AMG_MAX_K];
+  __shared__ int s_gap[GF_WPB][GF_MAXGAP * 3];  // ps, pe, n_paths
+  __shared__ int s_pool[GF_WPB][GF_POOL];
+  __shared__ int s_used[GF_WPB];
+  __shared__ int s_cnode[GF_WPB][GF_CAND];
+  __shared__ signed char s_cdir[GF_WPB][GF_CAND];
+  __shared__ int s_gene[GF_WPB][GF_CAND + AMG_MAX_K];
+  __shared__ int s_best[GF_WPB][GF_CAND + AMG_MAX_K];
   const CorrArgs& a = A.a;
   const GView& g = A.g;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long gi = (long long)blockIdx.x * 4 + wv;
+  const long long gi = (long long)blockIdx.x * GF_WPB + wv;
   if (gi >= A.n_gapped) return;
   const GapRec rec = A.rec[gi];
   const long long r = rec.r, t0 = rec.t0, dst = rec.dst;
@@ -1014,11 +1028,13 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
     return;
   }
   wave_sync();
+  if (A.ablate == 1) return;
   // ---- one wave-cooperative DFS per run, runs in read order
   bool bad = false;
   for (int q = 0; q < n_gaps && !bad; ++q) {
     const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
-    const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane);
+    const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane,
+                                  A.ablate == 3 ? A.status + 8 : nullptr);
     if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
     bad = np < 0;
   }
@@ -1027,6 +1043,7 @@ __global__ __launch_bounds__(256) void k_corr_gapped_fast(GapArgs A) {
     return;
   }
   wave_sync();
+  if (A.ablate == 2) return;
   unsigned long long n_combo = 1;
   bool dead_end = false;
   for (int q = 0; q < n_gaps; ++q) {
@@ -1299,16 +1316,18 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
 // shift, the dependency along the row is a prefix maximum (DPP scan).  Pointers are packed
 // 2 bits per cell (16 rows per LDS word per lane).
 
-__global__ __launch_bounds__(256) void k_corr_nw_fast(NwArgs A) {
-  __shared__ int s_x[4][NWF_MAX_N];
-  __shared__ unsigned int s_opw[4][(NWF_MAX_N + NWF_MAX_M) / 16 + 1];  // alignment ops, 2 bits each
-  __shared__ long long s_gs[4][NWF_MAX_N];
-  __shared__ long long s_ge[4][NWF_MAX_N];
-  __shared__ long long s_ogs[4][NWF_MAX_M];  // positions of the original genes
-  __shared__ long long s_oge[4][NWF_MAX_M];
+#define NWF_WPB 1  // reads per workgroup (see GF_WPB: most reads take the shortcut, some fill a matrix:
+                   // 0.94 ms with four, 0.87 with two, 0.71 with one)
+__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
+  __shared__ int s_x[NWF_WPB][NWF_MAX_N];
+  __shared__ unsigned int s_opw[NWF_WPB][(NWF_MAX_N + NWF_MAX_M) / 16 + 1];  // alignment ops, 2 bits each
+  __shared__ long long s_gs[NWF_WPB][NWF_MAX_N];
+  __shared__ long long s_ge[NWF_WPB][NWF_MAX_N];
+  __shared__ long long s_ogs[NWF_WPB][NWF_MAX_M];  // positions of the original genes
+  __shared__ long long s_oge[NWF_WPB][NWF_MAX_M];
   const CorrArgs& a = A.a;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long gi = (long long)blockIdx.x * 4 + wv;
+  const long long gi = (long long)blockIdx.x * NWF_WPB + wv;
   if (gi >= A.n_gapped) return;
   // The kernel is bound by its chain of dependent global loads (one wave per read, ~15 us per
   // wave at full occupancy), not by the fill: one record load, then every per-gene load of the
@@ -1751,12 +1770,16 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       G.cand_stride = cand_stride;
       G.final_cls = final_cls;
       G.need_slow = need_slow;
+      {
+        const char* ga = getenv("AMG_GAP_ABLATE");
+        G.ablate = ga ? atoi(ga) : 0;
+      }
       if (attempt == 0) {
         const char* nf = getenv("AMG_NO_FAST_GAPPED");  // debugging / A-B switch
         const bool use_fast = !(nf && nf[0] == '1');
         HIPCHK(hipMemsetAsync(need_slow, use_fast ? 0 : 1, (size_t)n_gapped + 1, st));
         if (use_fast)
-          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, G);
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, GF_WPB)), dim3(64 * GF_WPB), 0, st, G);
       }
       unsigned int blocks = (unsigned int)((n_gapped + 63) / 64);
       if (blocks > 2048u) blocks = 2048u;
@@ -1764,6 +1787,9 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       unsigned long long hs[ST_WORDS];
       HIPCHK(hipMemcpyAsync(hs, c->status.p, sizeof(hs), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
+      if (G.ablate == 3)
+        fprintf(stderr, "[amg] DFS: %llu runs, %llu loop iterations, %llu nodes entered, %llu paths\n", hs[10], hs[8],
+                hs[9], hs[11]);
       if (!hs[ST_OVERFLOW]) break;
       if (attempt >= 8) return amg_fail(AMG_E_OVERFLOW, "correct_reads: path pool overflow");
       pool_cap = hs[ST_COMPACT_A] * 2 + (1ull << 20);
@@ -1834,7 +1860,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     W.big_buf = c->nw_big.as<unsigned char>();
     W.allow_fast = allow_fast;
     if (W.allow_fast)
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, 4)), dim3(256), 0, st, W);
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, NWF_WPB)), dim3(64 * NWF_WPB), 0, st, W);
     if (n_general > 0)  // reads too long for the register-resident kernel
       hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
     stage_end(c);
