@@ -172,7 +172,7 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
                                         unsigned int* s_wave, unsigned long long* s_base,
                                         bool skip_first) {
   unsigned int total;
-  const unsigned int off = block_exscan_256((unsigned int)__popc(created), &total, s_wave);
+  const unsigned int off = block_exscan<TILE_THREADS / 64>((unsigned int)__popc(created), &total, s_wave);
   if (threadIdx.x == 0) *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
   __syncthreads();
   unsigned int claim = (unsigned int)(*s_base) + off;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     int ablate) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
-  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64];
   __shared__ unsigned long long s_base;
   const long long t0 = (long long)blockIdx.x * TILE;
   stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
-  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64];
   __shared__ unsigned long long s_base;
   const long long t0 = (long long)blockIdx.x * TILE;
   for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {

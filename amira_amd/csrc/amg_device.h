@@ -120,10 +120,11 @@ __device__ __forceinline__ unsigned int packed_tok(const uint4& lo, const uint4&
   return (w >> ((j & 1) * 16)) & 0xffffu;
 }
 
-// block-wide exclusive prefix of a per-thread count (256 threads = 4 waves); returns the
-// thread's offset inside the block and the block total in *total.
-__device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigned int* total,
-                                                         unsigned int* s_wave /*[4]*/) {
+// block-wide exclusive prefix of a per-thread count (WAVES waves of 64); returns the thread's
+// offset inside the block and the block total in *total.
+template <int WAVES>
+__device__ __forceinline__ unsigned int block_exscan(unsigned int v, unsigned int* total,
+                                                     unsigned int* s_wave /*[WAVES]*/) {
   unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned int x = v;
 #pragma unroll
@@ -135,7 +136,7 @@ __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigne
   __syncthreads();
   unsigned int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < WAVES; ++w) {
     unsigned int c = s_wave[w];
     if ((unsigned)w < wave) base += c;
     tot += c;
@@ -143,4 +144,8 @@ __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigne
   __syncthreads();
   *total = tot;
   return base + x - v;
+}
+__device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigned int* total,
+                                                         unsigned int* s_wave /*[4]*/) {
+  return block_exscan<4>(v, total, s_wave);
 }
