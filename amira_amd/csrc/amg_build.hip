@@ -768,13 +768,10 @@ int bs_finish_from_pairs(amg_ctx* c) {
     HIPCHK(hipMemcpyAsync(root_copy, parent, (size_t)D * sizeof(int), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
                        c->s1.as<long long>(), D, parent);
-    long long ncomp = 0;
-    HIPCHK(hipMemcpyAsync(&ncomp, c->s1.as<long long>() + D, sizeof(long long),
-                          hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    c->n_components = ncomp;
-  } else {
-    c->n_components = 0;
+    // the component count travels with the final synchronisation of the build (one host round
+    // trip fewer); s1 is reused below, so park the value in a status word first
+    HIPCHK(hipMemcpyAsync(c->status.as<unsigned long long>() + ST_COMPACT_A, c->s1.as<long long>() + D,
+                          sizeof(long long), hipMemcpyDeviceToDevice, st));
   }
   stage_end(c);
 
@@ -801,7 +798,12 @@ int bs_finish_from_pairs(amg_ctx* c) {
   c->ladj_valid = false;
   AMGCHK(c->read_fix.ensure((size_t)R + 1));
   HIPCHK(hipMemsetAsync(c->read_fix.p, 0, (size_t)R + 1, st));
+  long long ncomp = 0;
+  if (D > 0)
+    HIPCHK(hipMemcpyAsync(&ncomp, c->status.as<unsigned long long>() + ST_COMPACT_A, sizeof(long long),
+                          hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  c->n_components = ncomp;
   return AMG_OK;
 }
 
