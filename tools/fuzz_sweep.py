@@ -63,7 +63,8 @@ def run(budget, seed, max_cases=None):
         pos = synth.positions_for(reads)
         fq = P.FakeFastq(synth.fake_fastq_lengths(reads))
         try:
-            sw.run_sweep(eng, reads, pos, fq, k, min_cov=int(rng.choice([2, 3])))
+            mc = int(rng.choice([2, 3]))
+            sw.run_sweep(eng, reads, pos, fq, k, min_cov=mc)
             n_ok += 1
         except AssertionError as e:
             msg = str(e)
@@ -82,11 +83,17 @@ def run(budget, seed, max_cases=None):
             else:
                 print("MISMATCH:", info, flush=True); traceback.print_exc(); n_fail += 1
         except Exception as e:  # noqa: BLE001
-            if getattr(e, "code", None) == -4:   # the engine met a palindromic gene-mer: so must the oracle
-                from amira_oracle import GeneMerGraph
+            if getattr(e, "code", None) == -4:   # the engine met a palindromic gene-mer: so must the oracle,
+                from amira_oracle import GeneMerGraph  # in the first build or in a rebuild on corrected reads
                 try:
-                    GeneMerGraph(reads, k, pos)
-                    print("MISMATCH: engine asserted a palindrome, oracle built", info, flush=True); n_fail += 1
+                    g1 = GeneMerGraph(reads, k, {r: list(v) for r, v in pos.items()})
+                    g1.filter_graph(mc, 1)
+                    r2, p2 = g1.correct_reads(fq)
+                    g2 = GeneMerGraph(r2, k, p2)
+                    g2.remove_short_linear_paths(k)
+                    r3, p3 = g2.correct_reads(fq)
+                    GeneMerGraph(r3, k, p3)
+                    print("MISMATCH: engine asserted a palindrome, oracle finished the sweep", info, flush=True); n_fail += 1
                 except AssertionError as e2:
                     if "identical" in str(e2):
                         n_pal += 1
