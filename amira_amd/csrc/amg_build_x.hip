@@ -166,7 +166,7 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
                                         unsigned int (&id1)[TILE_ITEMS], unsigned int created,
                                         const unsigned int (&tag)[TILE_ITEMS],
                                         const unsigned int (&fi)[TILE_ITEMS],
-                                        unsigned int* first_by_claim, unsigned int* first_init,
+                                        unsigned int* first2,
                                         unsigned int* __restrict__ slot_by_claim,
                                         unsigned long long* counter, unsigned long long* stuck,
                                         unsigned int* s_wave, unsigned long long* s_base,
@@ -180,12 +180,12 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
 #pragma unroll
     for (int it = 0; it < TILE_ITEMS; ++it)
       if (created & (1u << it)) {
-        // the creator's first-seen goes to its own array with a plain store; everybody else
-        // raises first_by_claim with atomicMax (both zero-initialised; first-seen = the larger
+        // the creator's first-seen goes to its own word with a plain store; everybody else
+        // raises the claim's other word with atomicMax (both zero-initialised; first-seen = the larger
         // of the two), so nothing has to be ordered against the publication of the id (a
         // release fence here writes back the L2: measured 7x slower) and a creation costs no
         // read-modify-write beyond the CAS that took the slot
-        first_init[claim] = fi[it];
+        first2[2u * claim + 1u] = fi[it];
         slot_by_claim[claim] = (unsigned int)slot[it];
         id1[it] = claim + 1u;
         __hip_atomic_store(&tab[slot[it]].w2,
@@ -219,10 +219,7 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
     // plain (possibly stale, at worst zero) reads: both arrays only grow, so a stale value can
     // only cause a superfluous atomicMax, never a missed one
     const unsigned int c = id1[it] - 1u;
-    unsigned int cur = first_by_claim[c];
-    const unsigned int ini = first_init[c];
-    cur = cur > ini ? cur : ini;
-    if (cur < fi[it]) atomicMax(first_by_claim + c, fi[it]);
+    if (x_first_inv(first2, c) < fi[it]) atomicMax(first2 + 2u * c, fi[it]);
   }
 }
 
@@ -232,8 +229,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
-    unsigned int* first_by_claim, unsigned int* first_init, unsigned int* __restrict__ slot_by_claim,
-    int ablate) {
+    unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64];
@@ -296,7 +292,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     if (made) created |= 1u << it;
   }
   if (!(ablate & 4))
-  x_claim<TWO>(tab, slot, id1, created, tag, fi, first_by_claim, first_init, slot_by_claim, status + ST_NODE_INSERTS,
+  x_claim<TWO>(tab, slot, id1, created, tag, fi, first2, slot_by_claim, status + ST_NODE_INSERTS,
                status + ST_MISC, s_wave, &s_base, (ablate & 2) != 0);
   if (ablate & 1) return;
 #pragma unroll
@@ -315,13 +311,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
 // distinct: set one bit per claim in a bitmap over the tokens, prefix-count the bitmap words, and
 // the rank of a claim is the number of bits before its own.  (A radix sort of 0.5 - 1 M pairs
 // costs ~10 launches and ~0.2 ms however small the input; this costs ~0.06 ms.)
-__global__ void k_x_rank_setbits(const unsigned int* __restrict__ first_by_claim,
-                                 const unsigned int* __restrict__ first_init, long long n, int shift,
+__global__ void k_x_rank_setbits(const unsigned int* __restrict__ first2, long long n, int shift,
                                  unsigned int* __restrict__ bits) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned int a = first_by_claim[i], b = first_init[i];
-  const unsigned int t = (~(a > b ? a : b)) >> shift;
+  const unsigned int t = (~x_first_inv(first2, i)) >> shift;
   atomicOr(&bits[t >> 5], 1u << (t & 31));
 }
 
@@ -337,8 +331,7 @@ __device__ __forceinline__ long long x_rank_of(unsigned int t, const unsigned in
   return prefix[t >> 5] + (long long)__popc(w & ((1u << (t & 31)) - 1u));
 }
 
-__global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first_by_claim,
-                                        const unsigned int* __restrict__ first_init, long long n_nodes,
+__global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2, long long n_nodes,
                                         const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
                                         const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
                                         int k, int nbits, int* __restrict__ final_of_claim,
@@ -346,8 +339,7 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first_b
                                         unsigned char* __restrict__ node_alive) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_nodes) return;
-  const unsigned int a = first_by_claim[c], b = first_init[c];
-  const unsigned int first = ~(a > b ? a : b);
+  const unsigned int first = ~x_first_inv(first2, c);
   const long long i = x_rank_of(first >> 1, bits, prefix);
   final_of_claim[c] = (int)i;
   node_first[i] = (long long)first;
@@ -357,8 +349,7 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first_b
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, nbits, j);
 }
 
-__global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first_by_claim,
-                                        const unsigned int* __restrict__ first_init, long long n_pairs,
+__global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first2, long long n_pairs,
                                         const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
                                         const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
                                         const unsigned int* __restrict__ cnt_by_claim,
@@ -366,21 +357,18 @@ __global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first_b
                                         unsigned int* __restrict__ pcnt) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_pairs) return;
-  const unsigned int a = first_by_claim[c], b = first_init[c];
-  const unsigned int first = ~(a > b ? a : b);
+  const unsigned int first = ~x_first_inv(first2, c);
   const long long i = x_rank_of(first >> 3, bits, prefix);
   pkey[i] = etab[slot_by_claim[c]].w1;
   pfirst[i] = (unsigned long long)first;
   pcnt[i] = cnt_by_claim[c];
 }
 
-__global__ void k_x_sort_keys(const unsigned int* __restrict__ first_by_claim,
-                              const unsigned int* __restrict__ first_init, long long n,
+__global__ void k_x_sort_keys(const unsigned int* __restrict__ first2, long long n,
                               unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned int a = first_by_claim[i], b = first_init[i];
-  keys[i] = ~(a > b ? a : b);
+  keys[i] = ~x_first_inv(first2, i);
   vals[i] = (unsigned int)i;
 }
 
@@ -406,8 +394,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
     unsigned int emask, unsigned int probe_limit, unsigned long long* status,
-    int* __restrict__ tok_pair, unsigned int* first_by_claim, unsigned int* first_init,
-    unsigned int* __restrict__ slot_by_claim, int ablate) {
+    int* __restrict__ tok_pair, unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate) {
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
@@ -465,7 +452,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     if (slot[it] < 0) status[ST_OVERFLOW] = 2;
     if (made) created |= 1u << it;
   }
-  x_claim<false>(etab, slot, id1, created, tag, fi, first_by_claim, first_init, slot_by_claim, status + ST_PAIR_INSERTS,
+  x_claim<false>(etab, slot, id1, created, tag, fi, first2, slot_by_claim, status + ST_PAIR_INSERTS,
                  status + ST_MISC, s_wave, &s_base, false);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
@@ -499,15 +486,14 @@ static const unsigned int kProbeLimitX = 1024;
 static const long long kRankBitmapMax = 2ll << 20;  // claims up to which the bitmap ranking beats the sort
 
 // bitmap over the tokens (s1) with one bit per claim + exclusive prefix of the word popcounts (s5)
-static int x_rank_bitmap(amg_ctx* c, const unsigned int* first_a, const unsigned int* first_b, long long n,
-                         int shift) {
+static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, int shift) {
   hipStream_t st = c->stream;
   const long long words = (c->n_tokens >> 5) + 2;
   AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
   AMGCHK(c->s2.ensure((size_t)(words + 1) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(words + 1) * sizeof(long long)));
   HIPCHK(hipMemsetAsync(c->s1.p, 0, (size_t)words * sizeof(unsigned int), st));
-  hipLaunchKernelGGL(k_x_rank_setbits, dim3(blocks_for(n, 256)), dim3(256), 0, st, first_a, first_b, n, shift,
+  hipLaunchKernelGGL(k_x_rank_setbits, dim3(blocks_for(n, 256)), dim3(256), 0, st, first2, n, shift,
                      c->s1.as<unsigned int>());
   hipLaunchKernelGGL(k_x_rank_popc, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
                      words, c->s2.as<unsigned int>());
@@ -562,7 +548,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
   AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
   AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
-  AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));  // raised-by-others | creator's
+  AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));  // {raised by others, creator's} per claim
   AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
 
@@ -587,7 +573,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                        c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                        c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                       c->x_first.as<unsigned int>() + max_claims, c->x_slot.as<unsigned int>(), ablate);
+                       c->x_slot.as<unsigned int>(), ablate);
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
@@ -611,7 +597,6 @@ int bx_nodes_rank(amg_ctx* c) {
   hipStream_t st = c->stream;
   const long long T = c->n_tokens;
   const int k = c->k;
-  const size_t max_claims = (size_t)c->x_max_claims;
   stage_begin(c, "node_rank");
   const long long D = c->n_nodes;
   AMGCHK(c->s1.ensure((size_t)(D + 1) * sizeof(unsigned int)));
@@ -620,15 +605,15 @@ int bx_nodes_rank(amg_ctx* c) {
   AMGCHK(c->s4.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(bs_alloc_nodes(c, D));
   if (D > 0 && D <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
-    AMGCHK(x_rank_bitmap(c, c->x_first.as<unsigned int>(), c->x_first.as<unsigned int>() + max_claims, D, 1));
+    AMGCHK(x_rank_bitmap(c, c->x_first.as<unsigned int>(), D, 1));
     hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(D, 256)), dim3(256), 0, st,
-                       c->x_first.as<unsigned int>(), c->x_first.as<unsigned int>() + max_claims, D,
+                       c->x_first.as<unsigned int>(), D,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
                        c->x_slot.as<unsigned int>(), k, c->x_bits, c->x_final.as<int>(), c->node_tokens.as<int>(),
                        c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
   } else if (D > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
-                       c->x_first.as<unsigned int>() + max_claims, D, c->s1.as<unsigned int>(),
+                       D, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());
     AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
                              c->s4.as<unsigned int>(), (size_t)D, ilog2_ceil((uint64_t)T * 2 + 2) + 1));
@@ -674,8 +659,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                       c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims,
-                       c->x_eslot.as<unsigned int>(), ablate);
+                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate);
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
@@ -693,7 +677,6 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
 int bx_edges_rank(amg_ctx* c) {
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
-  const size_t max_claims = (size_t)c->x_max_eclaims;
   // node coverage (construct_node.py:33-36) from the per-window node ids
   stage_begin(c, "node_count");
   AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
@@ -711,16 +694,16 @@ int bx_edges_rank(amg_ctx* c) {
   AMGCHK(c->s3.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   if (P > 0 && P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
-    AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims, P, 3));
+    AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), P, 3));
     hipLaunchKernelGGL(k_x_gather_pairs_ranked, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                       c->x_efirst.as<unsigned int>(), c->x_efirst.as<unsigned int>() + max_claims, P,
+                       c->x_efirst.as<unsigned int>(), P,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->edge_tab.as<Slot16>(),
                        c->x_eslot.as<unsigned int>(), c->x_ecnt.as<unsigned int>(),
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
                        c->pair_cnt.as<unsigned int>());
   } else if (P > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
-                       c->x_efirst.as<unsigned int>() + max_claims, P, c->s1.as<unsigned int>(),
+                       P, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());
     AMGCHK(prim_sort_u32_u32(c, c->s1.as<unsigned int>(), c->s2.as<unsigned int>(), c->s3.as<unsigned int>(),
                              c->s4.as<unsigned int>(), (size_t)P, ilog2_ceil((uint64_t)T * 8 + 8) + 1));

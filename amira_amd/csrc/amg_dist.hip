@@ -152,15 +152,14 @@ __global__ void k_xd_node_keys(const Slot16* __restrict__ tab, const unsigned in
 
 __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long n,
                                const unsigned long long* __restrict__ keys,
-                               const unsigned int* __restrict__ first_a, const unsigned int* __restrict__ first_b,
+                               const unsigned int* __restrict__ first2,
                                long long tok_base, const unsigned int* __restrict__ lcnt,
                                const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
                                int k, int bits, unsigned char* __restrict__ out, int rec_bytes) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned int c = order[j];
-  const unsigned int fa = first_a[c], fb = first_b[c];
-  const unsigned long long first = ((unsigned long long)tok_base << 1) + (unsigned long long)(unsigned int)~(fa > fb ? fa : fb);
+  const unsigned long long first = ((unsigned long long)tok_base << 1) + (unsigned long long)(unsigned int)~x_first_inv(first2, c);
   unsigned char* rec = out + (size_t)j * rec_bytes;
   unsigned long long* q = reinterpret_cast<unsigned long long*>(rec);
   q[0] = keys[c];
@@ -207,16 +206,15 @@ __global__ void k_xd_edge_dest(const Slot16* __restrict__ etab, const unsigned i
 
 __global__ void k_xd_edge_pack(const unsigned int* __restrict__ order, long long n,
                                const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
-                               const unsigned int* __restrict__ first_a, const unsigned int* __restrict__ first_b,
+                               const unsigned int* __restrict__ first2,
                                long long tok_base, const unsigned int* __restrict__ lcnt,
                                unsigned char* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned int c = order[j];
-  const unsigned int fa = first_a[c], fb = first_b[c];
   unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
   q[0] = etab[slot_by_claim[c]].w1;
-  q[1] = ((unsigned long long)tok_base << 3) + (unsigned long long)(unsigned int)~(fa > fb ? fa : fb);
+  q[1] = ((unsigned long long)tok_base << 3) + (unsigned long long)(unsigned int)~x_first_inv(first2, c);
   q[2] = (unsigned long long)lcnt[c];
 }
 
@@ -375,7 +373,7 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
   if (c->dist_x) {
     hipLaunchKernelGGL(k_xd_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                        c->dist_first.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                       c->x_first.as<unsigned int>() + c->x_max_claims, (long long)c->tok_base,
+                       (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
                        c->k, c->x_bits, reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -737,7 +735,7 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
   if (c->dist_x) {
     hipLaunchKernelGGL(k_xd_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                        c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
-                       c->x_efirst.as<unsigned int>() + c->x_max_eclaims, (long long)c->tok_base,
+                       (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), reinterpret_cast<unsigned char*>(send_buf));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AMG_OK;

@@ -17,3 +17,12 @@ __device__ __forceinline__ int x_unpack(unsigned long long w1, unsigned int tag,
   return (int)(v & ((1ull << bits) - 1ull));
 }
 
+
+// First-seen of a claim lives in TWO adjacent words, both holding the complement (so that larger =
+// earlier) and both zero-initialised: [2c] is raised with atomicMax by every window that is not
+// the creator, [2c + 1] is the creator's own plain store; the larger one wins.  Adjacent, so
+// that the per-window check is one 8-byte load.
+__device__ __forceinline__ unsigned int x_first_inv(const unsigned int* first2, long long c) {
+  const uint2 f = reinterpret_cast<const uint2*>(first2)[c];
+  return f.x > f.y ? f.x : f.y;
+}
