@@ -93,22 +93,23 @@ __device__ __forceinline__ int x_canon_pack(const int* w, int flip, int bits, un
 // so that no L2 caches a hot slot before it is complete, was measured and bought nothing.)
 // A CAS on w1 takes the slot.  TWO: the key has a second word (tag), set by a second CAS by
 // whichever thread needs it first; that thread owns the slot ("created").
-// Returns the slot or -1; id1 = claim id + 1 if already published.
+// Returns the slot or -1; w2v = the slot's second word as seen (low 32 bits zero: the claim id
+// is not published yet).
 template <bool TWO>
 __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
                                               unsigned long long w1, unsigned int tag,
                                               unsigned int idx, ulonglong2 v,
                                               unsigned int limit, const unsigned long long* abort_flag,
-                                              unsigned int& id1, bool& created) {
+                                              unsigned long long& w2v, bool& created) {
   created = false;
-  id1 = 0;
+  w2v = 0;
   unsigned int probes = 0;
   while (true) {
     Slot16* s = tab + idx;
     unsigned long long c1 = v.x, c2 = v.y;
     const bool mine = c1 == w1 && (!TWO || (unsigned int)(c2 >> 32) == tag);
     if (mine && (unsigned int)c2 != 0u) {
-      id1 = (unsigned int)c2;
+      w2v = c2;
       return (int)idx;
     }
     // The cached view does not decide.  No step below waits for another thread (lanes of one
@@ -142,11 +143,11 @@ __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
           c2 = old;
         }
         if ((unsigned int)(c2 >> 32) == tag) {
-          id1 = (unsigned int)c2;  // 0: the id is still on its way (x_claim waits for it)
+          w2v = c2;  // low word 0: the id is still on its way (x_claim waits for it)
           return (int)idx;
         }
       } else {
-        id1 = (unsigned int)c2;
+        w2v = c2;
         return (int)idx;
       }
     }
@@ -159,18 +160,41 @@ __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
   }
 }
 
-// Claim ids for the slots this block created + first-seen bookkeeping.  slot[it] < 0: nothing.
-// On return id1[it] = claim id + 1 of every item with a slot.
+// Second word of a slot.  TWO (the key spills into it): [63:32] tag, [31:ib] COARSE token position
+// of the creating window (token index >> cshift), [ib-1:0] claim id + 1.  One-word keys: [63:32]
+// the creator's exact first-seen (complemented), [31:0] claim id + 1.  Either way the probe load
+// already tells almost every window that it comes after the creator and cannot be the first
+// occurrence: the first-seen words of the claim are then not even read (one random access per
+// window less; the table passes are bound by the L2 request rate).
+struct XW2 {
+  int ib;       // bits of the id field (TWO)
+  int cshift;   // coarse position = token index >> cshift (TWO)
+};
 template <bool TWO>
+__device__ __forceinline__ unsigned int xw2_id1(unsigned long long w2v, const XW2& f) {
+  return TWO ? ((unsigned int)w2v & ((1u << f.ib) - 1u)) : (unsigned int)w2v;
+}
+
+// Claim ids for the slots this block created + first-seen bookkeeping.  slot[it] < 0: nothing.
+// In: lw[it] / hw[it] = low / high half of the second slot word as seen by the probe (the high half
+// only matters for one-word keys).  Out: id1[it] = claim id + 1 of every
+// item with a slot.  Window `it` of the thread starts at token tbase + it * TILE_THREADS; its
+// first-seen value is (token << FSH) | low bits (lowbits: FSH bits per item, packed), kept
+// complemented.  (Positions and first-seen values are recomputed instead of kept in arrays: the
+// table kernels run 8 waves per SIMD on 64 registers.)
+template <bool TWO, int FSH>
 __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEMS],
+                                        const unsigned int (&lw)[TILE_ITEMS],
+                                        const unsigned int (&hw)[TWO ? 1 : TILE_ITEMS],
                                         unsigned int (&id1)[TILE_ITEMS], unsigned int created,
-                                        const unsigned int (&tag)[TILE_ITEMS],
-                                        const unsigned int (&fi)[TILE_ITEMS],
-                                        unsigned int* first2,
+                                        const unsigned int (&tag)[TILE_ITEMS], unsigned int tbase,
+                                        unsigned int lowbits, const XW2 f, unsigned int* first2,
                                         unsigned int* __restrict__ slot_by_claim,
                                         unsigned long long* counter, unsigned long long* stuck,
                                         unsigned int* s_wave, unsigned long long* s_base,
                                         bool skip_first) {
+  auto tpos = [&](int it) { return tbase + (unsigned int)it * TILE_THREADS; };
+  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   unsigned int total;
   const unsigned int off = block_exscan<TILE_THREADS / 64>((unsigned int)__popc(created), &total, s_wave);
   if (threadIdx.x == 0) *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
@@ -185,41 +209,48 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
         // of the two), so nothing has to be ordered against the publication of the id (a
         // release fence here writes back the L2: measured 7x slower) and a creation costs no
         // read-modify-write beyond the CAS that took the slot
-        first2[2u * claim + 1u] = fi[it];
+        first2[2u * claim + 1u] = fi(it);
         slot_by_claim[claim] = (unsigned int)slot[it];
         id1[it] = claim + 1u;
-        __hip_atomic_store(&tab[slot[it]].w2,
-                           (TWO ? (unsigned long long)tag[it] << 32 : 0ull) | (unsigned long long)(claim + 1u),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long pub =
+            TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
+                      (unsigned long long)(claim + 1u)
+                : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
+        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++claim;
       }
   }
   // found keys: wait for an id that is still on its way (its creator's block publishes without
   // waiting for anybody), then keep the minimum first-seen
+  unsigned int check = 0;
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (slot[it] < 0 || (created & (1u << it))) continue;
-    unsigned int id = id1[it];
-    for (unsigned int spins = 0; id == 0u; ++spins) {
-      id = (unsigned int)ld_u64(&tab[slot[it]].w2);
-      if (id != 0u) break;
+    unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
+    for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
+      w = ld_u64(&tab[slot[it]].w2);
+      if ((unsigned int)w != 0u) break;
       if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
         *stuck = 1ull;
-        id = 1u;
+        w = 1ull;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
-    id1[it] = id;
+    id1[it] = xw2_id1<TWO>(w, f);
+    // can this window precede the creator's?  (coarse positions: same or earlier bucket)
+    const bool maybe_first = TWO ? (tpos(it) >> f.cshift) <= (((unsigned int)w) >> f.ib)
+                                 : fi(it) > (unsigned int)(w >> 32);
+    if (maybe_first) check |= 1u << it;
   }
   if (skip_first) return;  // timing experiment only
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (slot[it] < 0 || (created & (1u << it))) continue;
-    // plain (possibly stale, at worst zero) reads: both arrays only grow, so a stale value can
+    if (!(check & (1u << it))) continue;
+    // plain (possibly stale, at worst zero) reads: both words only grow, so a stale value can
     // only cause a superfluous atomicMax, never a missed one
     const unsigned int c = id1[it] - 1u;
-    if (x_first_inv(first2, c) < fi[it]) atomicMax(first2 + 2u * c, fi[it]);
+    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
   }
 }
 
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
-    unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate) {
+    unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate, XW2 xf) {
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64];
@@ -238,7 +269,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
   stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
   const int flip = two_v - 1;
   unsigned long long w1[TILE_ITEMS];
-  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS];
+  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], id1[TILE_ITEMS], lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
+  unsigned int lowbits = 0;  // per window: 1 = first direction is -1 (low bit of its first-seen value)
   int slot[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
   int dirs[TILE_ITEMS];
@@ -253,6 +285,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     dirs[it] = 0;
     slot[it] = -1;
     id1[it] = 0;
+    lw[it] = 0;
+    if (!TWO) hw[TWO ? 0 : it] = 0;
     if (ok) {
       LdsView w{s_tok + i};
       int dir;
@@ -267,7 +301,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
       } else {
         dirs[it] = dir;
         idx[it] = (unsigned int)mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
-        fi[it] = ~(((unsigned int)t << 1) | (dir < 0 ? 1u : 0u));
+        if (dir < 0) lowbits |= 1u << it;
         valid |= 1u << it;
         if (is_last) last |= 1u << it;
       }
@@ -281,19 +315,26 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
     bool made;
+    unsigned long long w2v;
     if (ablate & 8) {  // timing experiment: no probe
       slot[it] = (int)idx[it];
-      id1[it] = 1u + (unsigned int)(w1[it] & 1023ull);
+      w2v = 1ull + (w1[it] & 1023ull);
       made = false;
     } else
     slot[it] = x_upsert<TWO>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
-                              status + ST_OVERFLOW, id1[it], made);
+                              status + ST_OVERFLOW, w2v, made);
+    lw[it] = (unsigned int)w2v;
+    if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(w2v >> 32);
     if (slot[it] < 0) status[ST_OVERFLOW] = 1;
     if (made) created |= 1u << it;
   }
   if (!(ablate & 4))
-  x_claim<TWO>(tab, slot, id1, created, tag, fi, first2, slot_by_claim, status + ST_NODE_INSERTS,
-               status + ST_MISC, s_wave, &s_base, (ablate & 2) != 0);
+  x_claim<TWO, 1>(tab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + threadIdx.x, lowbits, xf, first2,
+                  slot_by_claim, status + ST_NODE_INSERTS, status + ST_MISC, s_wave, &s_base, (ablate & 2) != 0);
+  else {
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) id1[it] = xw2_id1<TWO>((unsigned long long)lw[it], xf);
+  }
   if (ablate & 1) return;
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
@@ -334,7 +375,7 @@ __device__ __forceinline__ long long x_rank_of(unsigned int t, const unsigned in
 __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2, long long n_nodes,
                                         const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
                                         const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
-                                        int k, int nbits, int* __restrict__ final_of_claim,
+                                        int k, int nbits, int two, int* __restrict__ final_of_claim,
                                         int* __restrict__ node_tokens, long long* __restrict__ node_first,
                                         unsigned char* __restrict__ node_alive) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,7 +386,7 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2,
   node_first[i] = (long long)first;
   node_alive[i] = 1;
   const Slot16 s = tab[slot_by_claim[c]];
-  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys keep the creator's first-seen there
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, nbits, j);
 }
 
@@ -375,7 +416,7 @@ __global__ void k_x_sort_keys(const unsigned int* __restrict__ first2, long long
 __global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
                                  const unsigned int* __restrict__ claim_sorted, long long n_nodes,
                                  const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
-                                 int k, int bits, int* __restrict__ final_of_claim,
+                                 int k, int bits, int two, int* __restrict__ final_of_claim,
                                  int* __restrict__ node_tokens, long long* __restrict__ node_first,
                                  unsigned char* __restrict__ node_alive) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,7 +426,7 @@ __global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
   node_first[i] = (long long)first_sorted[i];
   node_alive[i] = 1;
   const Slot16 s = tab[slot_by_claim[c]];
-  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys keep the creator's first-seen there
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, bits, j);
 }
 
@@ -394,7 +435,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
     unsigned int emask, unsigned int probe_limit, unsigned long long* status,
-    int* __restrict__ tok_pair, unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate) {
+    int* __restrict__ tok_pair, unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate,
+    XW2 xf) {
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
@@ -419,7 +461,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
   }
   __syncthreads();
   unsigned long long key[TILE_ITEMS];
-  unsigned int idx[TILE_ITEMS], fi[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {};
+  unsigned int idx[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {}, lw[TILE_ITEMS], hw[TILE_ITEMS];
+  unsigned int lowbits = 0;  // per adjacency: its 3 orientation bits (low bits of its first-seen value)
   int slot[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
   unsigned int valid = 0, created = 0;
@@ -428,6 +471,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     const int i = threadIdx.x + it * TILE_THREADS;
     slot[it] = -1;
     id1[it] = 0;
+    lw[it] = 0;
+    hw[it] = 0;
     if (s_last[i] || s_id[i] < 0 || s_id[i + 1] < 0) continue;
     // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
     const unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
@@ -436,7 +481,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     const unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
     key[it] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
     const unsigned int orient = (a == lo ? 1u : 0u) | (dA > 0 ? 2u : 0u) | (dB > 0 ? 4u : 0u);
-    fi[it] = ~(((unsigned int)(t0 + i) << 3) | orient);
+    lowbits |= orient << (3 * it);
     idx[it] = (unsigned int)mix64(key[it]) & emask;
     valid |= 1u << it;
   }
@@ -447,13 +492,16 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it))) continue;
     bool made;
+    unsigned long long w2v;
     slot[it] = x_upsert<false>(etab, emask, key[it], 0u, idx[it], v[it], probe_limit,
-                               status + ST_OVERFLOW, id1[it], made);
+                               status + ST_OVERFLOW, w2v, made);
+    lw[it] = (unsigned int)w2v;
+    hw[it] = (unsigned int)(w2v >> 32);
     if (slot[it] < 0) status[ST_OVERFLOW] = 2;
     if (made) created |= 1u << it;
   }
-  x_claim<false>(etab, slot, id1, created, tag, fi, first2, slot_by_claim, status + ST_PAIR_INSERTS,
-                 status + ST_MISC, s_wave, &s_base, false);
+  x_claim<false, 3>(etab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + threadIdx.x, lowbits, xf, first2,
+                    slot_by_claim, status + ST_PAIR_INSERTS, status + ST_MISC, s_wave, &s_base, false);
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
@@ -498,6 +546,17 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   hipLaunchKernelGGL(k_x_rank_popc, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
                      words, c->s2.as<unsigned int>());
   return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
+}
+
+// field widths of a two-word slot's second word for `max_claims` ids over T tokens
+static XW2 xw2_for(size_t max_claims, long long T) {
+  XW2 f;
+  f.ib = ilog2_ceil((uint64_t)max_claims + 2);
+  if (f.ib > 31) f.ib = 31;  // claims < 2^30 (slots are capped there)
+  const int cb = 32 - f.ib;  // bits left for the coarse position (0: every window checks first-seen)
+  const int tb = ilog2_ceil((uint64_t)(T > 0 ? T : 1) + 1);
+  f.cshift = cb <= 0 ? 31 : (tb > cb ? tb - cb : 0);
+  return f;
 }
 
 static int read_status(amg_ctx* c, unsigned long long* host) {
@@ -573,7 +632,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                        c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                        c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                        c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                       c->x_slot.as<unsigned int>(), ablate);
+                       c->x_slot.as<unsigned int>(), ablate, xw2_for(max_claims, T));
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
@@ -609,7 +668,8 @@ int bx_nodes_rank(amg_ctx* c) {
     hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(D, 256)), dim3(256), 0, st,
                        c->x_first.as<unsigned int>(), D,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
-                       c->x_slot.as<unsigned int>(), k, c->x_bits, c->x_final.as<int>(), c->node_tokens.as<int>(),
+                       c->x_slot.as<unsigned int>(), k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->x_final.as<int>(),
+                       c->node_tokens.as<int>(),
                        c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
   } else if (D > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
@@ -619,7 +679,7 @@ int bx_nodes_rank(amg_ctx* c) {
                              c->s4.as<unsigned int>(), (size_t)D, ilog2_ceil((uint64_t)T * 2 + 2) + 1));
     hipLaunchKernelGGL(k_x_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
                        c->s4.as<unsigned int>(), D, c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
-                       k, c->x_bits, c->x_final.as<int>(), c->node_tokens.as<int>(),
+                       k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->x_final.as<int>(), c->node_tokens.as<int>(),
                        c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
   }
   stage_end(c);
@@ -659,7 +719,8 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate);
+                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate,
+                       xw2_for(max_claims, T));
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");

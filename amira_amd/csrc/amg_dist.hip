@@ -135,13 +135,13 @@ __device__ __forceinline__ unsigned long long tuple_fingerprint(const int* tok, 
 }
 
 __global__ void k_xd_node_keys(const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
-                               long long n, int k, int bits, unsigned long long seed, unsigned int world,
+                               long long n, int k, int bits, int two, unsigned long long seed, unsigned int world,
                                unsigned long long* __restrict__ keys, unsigned int* __restrict__ dest,
                                unsigned int* __restrict__ idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Slot16 s = tab[slot_by_claim[i]];
-  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys: no tag there
   int tok[AMG_MAX_K];
   for (int j = 0; j < k; ++j) tok[j] = x_unpack(s.w1, tag, bits, j);
   const unsigned long long key = tuple_fingerprint(tok, k, seed);
@@ -155,7 +155,7 @@ __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long
                                const unsigned int* __restrict__ first2,
                                long long tok_base, const unsigned int* __restrict__ lcnt,
                                const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
-                               int k, int bits, unsigned char* __restrict__ out, int rec_bytes) {
+                               int k, int bits, int two, unsigned char* __restrict__ out, int rec_bytes) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned int c = order[j];
@@ -168,7 +168,7 @@ __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long
   u[0] = lcnt[c];
   u[1] = (unsigned int)k;
   const Slot16 s = tab[slot_by_claim[c]];
-  const unsigned int tag = (unsigned int)(s.w2 >> 32);
+  const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;
   int* tk = reinterpret_cast<int*>(rec + 24);
   for (int x = 0; x < k; ++x) tk[x] = x_unpack(s.w1, tag, bits, x);
 }
@@ -263,7 +263,8 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
   AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));  // keys per claim
   if (n > 0)
     hipLaunchKernelGGL(k_xd_node_keys, dim3(nblk(n, 256)), dim3(256), 0, st, c->node_tab.as<Slot16>(),
-                       c->x_slot.as<unsigned int>(), n, k, c->x_bits, c->seed, (unsigned int)world,
+                       c->x_slot.as<unsigned int>(), n, k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->seed,
+                       (unsigned int)world,
                        c->dist_first.as<unsigned long long>(), dest, idx);
   return dest_counts(c, n, world, dest, idx, dest_sorted, order, send_counts);
 }
@@ -375,7 +376,8 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
                        c->dist_first.as<unsigned long long>(), c->x_first.as<unsigned int>(),
                        (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
-                       c->k, c->x_bits, reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
+                       c->k, c->x_bits, (long long)c->k * c->x_bits > 63 ? 1 : 0,
+                       reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AMG_OK;
   }
