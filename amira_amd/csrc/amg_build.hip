@@ -447,8 +447,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   HIPCHK(hipMemsetAsync(state, 0, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
   if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
-  long long want_blocks = (n + 1023) / 1024;
-  unsigned int blocks = (unsigned int)(want_blocks < 256 ? want_blocks : 256);
+  // every block flushes up to HOT_IDS counters with global atomics at the end of a sweep: give a
+  // block at least twice that many ids to count (small inputs: fewer blocks, not a shorter sweep)
+  long long want_blocks = (n + 2 * HOT_IDS - 1) / (2 * HOT_IDS);
+  unsigned int blocks = (unsigned int)(want_blocks < 1 ? 1 : (want_blocks < 256 ? want_blocks : 256));
   for (long long r = 0; r < ranges; ++r) {
     const long long lo = r * HOT_IDS;
     const int last = (r == ranges - 1) ? 1 : 0;
