@@ -5,15 +5,17 @@
 // fits 94 bits (k * ceil(log2(2V)) <= 94: k = 3 for any vocabulary, k = 5 up to 2^18 genes):
 //
 //   * a node slot is 16 bytes: w1 = low 63 bits of the packed tuple (+ a set bit 0), w2 =
-//     {remaining tuple bits + a set bit, claim id + 1}.  The tuple itself is the key, so no
-//     fingerprint verification pass is needed and one 16-byte (plain, L2-served) load per
-//     probe decides it; see x_upsert for when a cached view may be trusted.
+//     {remaining tuple bits + a set bit, where the creating window was, claim id + 1} (struct
+//     XW2).  The tuple itself is the key, so no fingerprint verification pass is needed and one
+//     16-byte (plain, L2-served) load per probe decides it; see x_upsert for when a cached view
+//     may be trusted.
 //   * the thread that creates a slot gives it a CLAIM id: creators of a block are counted
 //     with a block scan, one atomicAdd per block reserves the ids, the id is published in the
 //     slot (threads that found the key before the id was there wait for it after their own
 //     block has published — a block never waits before publishing, so there is no cycle).
-//   * every per-key quantity lives in DENSE arrays indexed by claim id: first-seen (x_first),
-//     slot (x_slot), final node id (x_final).  Claim order follows the token order, so the
+//   * every per-key quantity lives in DENSE arrays indexed by claim id: first-seen (x_first, two
+//     words per claim, read only by the few windows that might precede the creator), slot
+//     (x_slot), final node id (x_final).  Claim order follows the token order, so the
 //     frequently hit genome nodes own the first few ten thousand claims: the per-window
 //     gathers of the edge pass (claim -> node id) and the first-seen updates hit a small
 //     L2-resident region instead of one 128-byte line per hot slot, the occupied slots need
