@@ -376,7 +376,8 @@ template <bool GATHER>
 __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long long n,
                                                     const Slot* __restrict__ tab, long long lo,
                                                     int sweep, int last, unsigned long long* state,
-                                                    unsigned long long* hint, unsigned int* __restrict__ out) {
+                                                    unsigned long long* hint, unsigned int* __restrict__ out,
+                                                    int strip) {
   __shared__ unsigned int s_cnt[HOT_IDS];
   bool tail_all = last != 0;
   if (sweep > 0) {
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   const long long stride = (long long)gridDim.x * 1024;
   unsigned int beyond = 0;
   auto tally = [&](int id, long long t) {
+    if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);  // claims with the last-window flag
     if (GATHER) {
       id = id < 0 ? -1 : tab[id].id;
       ids[t] = id;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   }
 }
 
-// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes
+// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes,
+// 2 node claims as the table pass wrote them (id | AMG_LAST_FLAG on the last window of a read)
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind) {
   hipStream_t st = c->stream;
@@ -443,7 +446,8 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
     HIPCHK(hipMemsetAsync(c->cnt_state.p, 0, (2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long), st));
   }
   unsigned long long* state = c->cnt_state.as<unsigned long long>();
-  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * (kind ? 1 : 0);
+  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * (kind == 1 ? 1 : 0);
+  const int strip = kind == 2 ? 1 : 0;
   HIPCHK(hipMemsetAsync(state, 0, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
   if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
@@ -456,10 +460,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
     const int last = (r == ranges - 1) ? 1 : 0;
     if (gather_tab && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out);
+                         (int)r, last, state, hint, out, strip);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out);
+                         (int)r, last, state, hint, out, strip);
   }
   return AMG_OK;
 }

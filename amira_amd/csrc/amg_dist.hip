@@ -116,13 +116,6 @@ __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long lo
 // build (amg_build_x.hip: 16-byte slots, claim ids, dense per-claim arrays); the records that
 // travel keep the format below — the key is the same 64-bit fingerprint of the tuple, so ranks
 // on either path merge with each other.
-__global__ void k_xd_strip(const int* __restrict__ tok_claim, long long n, int* __restrict__ out) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int raw = tok_claim[t];
-  out[t] = raw == -1 ? -1 : (int)((unsigned int)raw & ~AMG_LAST_FLAG);
-}
-
 // fingerprint of a canonical tuple given as tokens: same value as canon_fingerprint()
 __device__ __forceinline__ unsigned long long tuple_fingerprint(const int* tok, int k, unsigned long long seed) {
   unsigned long long h = seed;
@@ -248,12 +241,9 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
     c->node_slots *= 4;
   }
   const long long n = c->n_local_nodes, T = c->n_tokens;
-  // local occurrence counts per claim (tok_node is free scratch until the edge pass writes it)
+  // local occurrence counts per claim, straight from the per-window claims
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
-  if (T > 0)
-    hipLaunchKernelGGL(k_xd_strip, dim3(nblk(T, 256)), dim3(256), 0, st, c->tok_slot.as<int>(), T,
-                       c->tok_node.as<int>());
-  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 0));
+  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 2));
   AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
   unsigned int* dest = c->dist_a.as<unsigned int>();
   unsigned int* idx = dest + (n + 1);
