@@ -175,7 +175,7 @@ def test_sweep_tandem_repeats(eng, seed, k):
 
 
 @pytest.mark.parametrize("env", [{"AMG_NO_FAST_GAPPED": "1"}, {"AMG_NO_FAST_NW": "1"},
-                                 {"AMG_COUNT_INLINE": "1"}, {"AMG_KEY_MODE": "fp"}, {"AMG_NO_FAST_GAPPED": "1", "AMG_NO_FAST_NW": "1"}])
+                                 {"AMG_COUNT_INLINE": "1"}, {"AMG_KEY_MODE": "fp"}, {"AMG_X_RANK_SORT": "1"}, {"AMG_NO_FAST_GAPPED": "1", "AMG_NO_FAST_NW": "1"}])
 def test_sweep_general_kernels(eng, monkeypatch, env):
     """the general (any-size) re-threading / alignment kernels and the inline-atomic counting
     path must give the same results as the fast paths that normally take these reads"""
