@@ -1359,11 +1359,15 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   // F[-1,j] = -j that make the first gap of a LEADING run free) an alignment of two lists of
   // the same length N with p >= 1 gaps in each scores at most (N - p) - 2p + 1 <= N - 2, the
   // pure diagonal N - m for m mismatching places.  m <= 1: the diagonal is the only optimum.
-  // m == 2: only the two alignments "one leading gap, N - 1 matches, one trailing gap" can tie
-  // (x[1:] == y[:-1] or x[:-1] == y[1:]); if neither holds the diagonal is again the only
-  // optimum.  A unique optimum is what the traceback returns whatever the tie order, so the
-  // matrix is not needed: columns are (x[q], y[q]), a mismatching column gives (None, None)
-  // and does not consume an original position (:1314-1325).
+  // m == 2 (mismatches at a < b): N - 2 is reached only by "one free leading gap, N - 1
+  // matches, one gap of the other kind somewhere": y[0] skipped, x[i] == y[i+1] up to the gap
+  // that skips x[j], plain matches after it — which needs j >= b (no mismatch may follow the
+  // gap) and therefore x[i] == y[i+1] for all i < b; or the mirror image with x[i+1] == y[i].
+  // If neither holds the diagonal is again the only optimum.  A unique optimum is what the
+  // traceback returns whatever the tie order, so the matrix is not needed: columns are
+  // (x[q], y[q]), a mismatching column gives (None, None) and does not consume an original
+  // position (:1314-1325).  (Tandem gene arrays do produce the tie: found by tools/fuzz_sweep.py,
+  // kept as tests/golden/data/nw_tie_case.json.xz.)
   const long long NONE = (long long)0x8000000000000000ull;
   bool diagonal = false;
   if (N == M) {
@@ -1372,9 +1376,11 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
     diagonal = m <= 1;
     const int x_next = __shfl_down(x0, 1, 64), y_next = __shfl_down(yj, 1, 64);  // every lane shuffles
     if (m == 2) {
-      const bool tie_a = __ballot(lane < N - 1 && x_next != yj) == 0ull;  // x[1:] == y[:-1]
-      const bool tie_b = __ballot(lane < N - 1 && x0 != y_next) == 0ull;  // x[:-1] == y[1:]
-      diagonal = !tie_a && !tie_b;
+      const int b = 63 - __clzll((long long)mm);               // the later mismatch, b >= 1
+      const unsigned long long upto_b = (1ull << b) - 1ull;    // places 0 .. b-1
+      const unsigned long long eq_a = __ballot(lane < N - 1 && x0 == y_next);  // x[i] == y[i+1]
+      const unsigned long long eq_b = __ballot(lane < N - 1 && x_next == yj);  // x[i+1] == y[i]
+      diagonal = (eq_a & upto_b) != upto_b && (eq_b & upto_b) != upto_b;
     }
     if (diagonal && lane < N) {
       const bool match = ((mm >> lane) & 1ull) == 0ull;

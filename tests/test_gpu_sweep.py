@@ -174,6 +174,21 @@ def test_sweep_tandem_repeats(eng, seed, k):
     run_sweep(eng, reads, pos, fq, k)
 
 
+def test_position_carry_over_tie_with_shifted_tandem_array(eng):
+    """a read whose corrected and original gene lists have the same length, differ in two places
+    and are shift-equal up to the second one (a tandem array moved by one gene): a gapped
+    alignment ties with the diagonal one, the reference's tie order picks the gapped one, so
+    the equal-length shortcut of the carry-over kernel must not fire (found by tools/fuzz_sweep.py)"""
+    import json, lzma, os
+    from amira_amd import synth
+    path = os.path.join(os.path.dirname(__file__), "golden", "data", "nw_tie_case.json.xz")
+    d = json.loads(lzma.open(path, "rt").read())
+    reads = d["reads"]
+    pos = synth.positions_for(reads)
+    fq = P.FakeFastq(synth.fake_fastq_lengths(reads))
+    run_sweep(eng, reads, pos, fq, d["k"], min_cov=d["min_cov"])
+
+
 @pytest.mark.parametrize("env", [{"AMG_NO_FAST_GAPPED": "1"}, {"AMG_NO_FAST_NW": "1"},
                                  {"AMG_COUNT_INLINE": "1"}, {"AMG_KEY_MODE": "fp"}, {"AMG_X_RANK_SORT": "1"}, {"AMG_NO_FAST_GAPPED": "1", "AMG_NO_FAST_NW": "1"}])
 def test_sweep_general_kernels(eng, monkeypatch, env):

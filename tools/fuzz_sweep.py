@@ -82,6 +82,11 @@ def run(budget, seed, max_cases=None):
                         print("MISMATCH (palindrome case):", repr(e2), info, flush=True); n_fail += 1
             else:
                 print("MISMATCH:", info, flush=True); traceback.print_exc(); n_fail += 1
+                dump = os.environ.get("FUZZ_DUMP")
+                if dump:  # keep the failing input for a stand-alone reproduction
+                    import json
+                    json.dump({"reads": reads, "k": k, "min_cov": mc, "info": info}, open(dump, "w"))
+                    break
         except Exception as e:  # noqa: BLE001
             if getattr(e, "code", None) == -4:   # the engine met a palindromic gene-mer: so must the oracle,
                 from amira_oracle import GeneMerGraph  # in the first build or in a rebuild on corrected reads
