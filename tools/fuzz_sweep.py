@@ -16,7 +16,8 @@ sw = importlib.util.module_from_spec(spec); spec.loader.exec_module(sw)
 
 def make_case(rng):
     V = int(rng.choice([6, 12, 30, 80, 300]))
-    glen = int(rng.integers(30, 160))
+    long_reads = rng.random() < 0.2     # reads beyond one wave (64 windows) and beyond the fast kernels' limits
+    glen = int(rng.integers(220, 420)) if long_reads else int(rng.integers(30, 160))
     genome = [(1 if rng.random() < 0.5 else -1, f"g{int(rng.integers(0, V))}") for _ in range(glen)]
     for _ in range(int(rng.integers(0, 4))):           # tandem arrays
         at, n = int(rng.integers(0, len(genome))), int(rng.integers(2, 10))
@@ -26,12 +27,14 @@ def make_case(rng):
         at = int(rng.integers(0, len(genome)))
         genome[at:at] = [(-st, g) for st, g in reversed(seg)]
     names = sorted({g for _, g in genome})
-    n_reads = int(rng.integers(150, 700))
+    n_reads = int(rng.integers(120, 320)) if long_reads else int(rng.integers(150, 700))
     err = float(rng.choice([0.0, 0.01, 0.03, 0.06]))
     indel = float(rng.choice([0.0, 0.0, 0.01]))
     reads = {}
     for r in range(n_reads):
         L = int(rng.integers(1, 40)) if rng.random() < 0.1 else int(rng.integers(12, 45))
+        if long_reads and rng.random() < 0.6:
+            L = int(rng.integers(60, 200))
         L = min(L, len(genome))
         s0 = int(rng.integers(0, len(genome) - L + 1))
         seq = list(genome[s0:s0 + L])
