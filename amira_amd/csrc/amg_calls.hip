@@ -256,6 +256,16 @@ struct Interner {
     if (off.size() * 2 > slots.size()) grow();
     return id;
   }
+  int32_t find(const char* b, size_t n) const {
+    size_t s = hash(b, n) & mask;
+    while (slots[s] >= 0) {
+      int32_t id = slots[s];
+      if (len[id] == n && memcmp(&arena[off[id]], b, n) == 0) return id;
+      s = (s + 1) & mask;
+    }
+    return -1;
+  }
+  size_t size() const { return off.size(); }
   std::string name(size_t id) const { return std::string(&arena[off[id]], len[id]); }
 };
 
@@ -274,12 +284,11 @@ bool slurp(const char* path, std::string& out, std::string& err) {
 }  // namespace
 
 struct amg_calls {
-  std::vector<std::string> read_ids;
+  Interner read_ids;  // read ids in file order (id = index), one arena instead of a string per read
   std::vector<int64_t> read_off{0};
   std::vector<int32_t> tokens;
   std::vector<std::string> names;  // rank order
   std::vector<uint8_t> hashes;     // 32 bytes per name, rank order
-  std::unordered_map<std::string, int64_t> read_index;
 };
 
 extern "C" int amg_calls_free(amg_calls* c) {
@@ -310,7 +319,15 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
   std::string key, owned, fixed;
   if (!r.lit('}')) {
     do {
-      if (!r.str(key)) return fail("read id");
+      const char *kb, *ke;
+      if (!r.str_view(&kb, &ke, &key)) return fail("read id");
+      {
+        // json.load keeps the LAST value of a duplicated key at the FIRST key's position;
+        // gene-call files never repeat a read id, so this is rejected rather than emulated
+        const size_t before = c->read_ids.size();
+        const int32_t rid = c->read_ids.intern(kb, (size_t)(ke - kb));
+        if ((size_t)rid != before) return fail("duplicate read id");
+      }
       if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
       if (!r.lit(']')) {
         do {
@@ -337,13 +354,6 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
         } while (r.lit(','));
         if (!r.lit(']')) return fail("expected ']'");
       }
-      if (c->read_index.count(key)) {
-        // json.load keeps the LAST value of a duplicated key at the FIRST key's position;
-        // gene-call files never repeat a read id, so this is rejected rather than emulated
-        return fail("duplicate read id");
-      }
-      c->read_index.emplace(key, (int64_t)c->read_ids.size());
-      c->read_ids.push_back(key);
       c->read_off.push_back((int64_t)gid.size());
     } while (r.lit(','));
     if (!r.lit('}')) return fail("expected '}'");
@@ -386,7 +396,7 @@ extern "C" int amg_calls_counts(amg_calls* c, int64_t* n_reads, int64_t* n_token
   if (n_genes) *n_genes = (int64_t)c->names.size();
   int64_t nb = 0, ib = 0;
   for (auto& s : c->names) nb += (int64_t)s.size() + 1;
-  for (auto& s : c->read_ids) ib += (int64_t)s.size() + 1;
+  for (size_t i = 0; i < c->read_ids.size(); ++i) ib += (int64_t)c->read_ids.len[i] + 1;
   if (names_bytes) *names_bytes = nb;
   if (ids_bytes) *ids_bytes = ib;
   return AMG_OK;
@@ -398,7 +408,13 @@ extern "C" int amg_calls_get(amg_calls* c, int32_t* tokens, int64_t* read_offset
   if (tokens && !c->tokens.empty()) memcpy(tokens, c->tokens.data(), c->tokens.size() * sizeof(int32_t));
   if (read_offsets) memcpy(read_offsets, c->read_off.data(), c->read_off.size() * sizeof(int64_t));
   if (gene_names) for (auto& s : c->names) { memcpy(gene_names, s.c_str(), s.size() + 1); gene_names += s.size() + 1; }
-  if (read_ids) for (auto& s : c->read_ids) { memcpy(read_ids, s.c_str(), s.size() + 1); read_ids += s.size() + 1; }
+  if (read_ids)
+    for (size_t i = 0; i < c->read_ids.size(); ++i) {
+      const size_t n = c->read_ids.len[i];
+      memcpy(read_ids, &c->read_ids.arena[c->read_ids.off[i]], n);
+      read_ids[n] = 0;
+      read_ids += n + 1;
+    }
   if (gene_hashes && !c->hashes.empty()) memcpy(gene_hashes, c->hashes.data(), c->hashes.size());
   return AMG_OK;
 }
@@ -420,11 +436,12 @@ extern "C" int amg_calls_load_positions_json(amg_calls* c, const char* path, int
   std::string key;
   if (!r.lit('}')) {
     do {
-      if (!r.str(key)) return fail("read id");
+      const char *kb, *ke;
+      if (!r.str_view(&kb, &ke, &key)) return fail("read id");
+      const int32_t rid = c->read_ids.find(kb, (size_t)(ke - kb));  // -1: a read that has no gene calls
       if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
-      auto it = c->read_index.find(key);
-      int64_t at = it == c->read_index.end() ? -1 : c->read_off[it->second];
-      int64_t lim = it == c->read_index.end() ? -1 : c->read_off[it->second + 1];
+      int64_t at = rid < 0 ? -1 : c->read_off[rid];
+      int64_t lim = rid < 0 ? -1 : c->read_off[rid + 1];
       if (!r.lit(']')) {
         do {
           long long s, e;
@@ -439,15 +456,15 @@ extern "C" int amg_calls_load_positions_json(amg_calls* c, const char* path, int
         } while (r.lit(','));
         if (!r.lit(']')) return fail("expected ']'");
       }
-      if (it != c->read_index.end()) {
+      if (rid >= 0) {
         if (at != lim) return fail("fewer positions than genes for a read");
-        seen[it->second] = 1;
+        seen[rid] = 1;
       }
     } while (r.lit(','));
     if (!r.lit('}')) return fail("expected '}'");
   }
   for (size_t i = 0; i < seen.size(); ++i)
-    if (!seen[i] && c->read_off[i + 1] > c->read_off[i]) return amg_fail(AMG_E_ARG, "%s: no positions for read %s", path, c->read_ids[i].c_str());
+    if (!seen[i] && c->read_off[i + 1] > c->read_off[i]) return amg_fail(AMG_E_ARG, "%s: no positions for read %s", path, c->read_ids.name(i).c_str());
   return AMG_OK;
 }
 
