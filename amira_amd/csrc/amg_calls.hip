@@ -241,8 +241,9 @@ struct Interner {
     slots.swap(bigger);
     mask = m;
   }
-  int32_t intern(const char* b, size_t n) {
-    size_t s = hash(b, n) & mask;
+  int32_t intern(const char* b, size_t n) { return intern_h(b, n, hash(b, n)); }
+  int32_t intern_h(const char* b, size_t n, uint64_t h) {
+    size_t s = h & mask;
     while (slots[s] >= 0) {
       int32_t id = slots[s];
       if (len[id] == n && memcmp(&arena[off[id]], b, n) == 0) return id;
@@ -331,20 +332,50 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
       if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
       if (!r.lit(']')) {
         do {
-          const char *gb, *ge;
-          if (!r.str_view(&gb, &ge, &owned)) return fail("gene");
-          // construct_gene.py:49-65: strand = first char, name = rest with ' ' -> '_'
-          bool blank = true, has_space = false;
-          for (const char* q = gb; q < ge; ++q) {
-            if (*q == ' ') has_space = true; else blank = false;
+          // one pass over the gene string: closing quote, escapes, blanks and the hash of the name
+          // (construct_gene.py:49-65: strand = first char, name = rest with ' ' -> '_')
+          r.ws();
+          if (r.p >= r.end || *r.p != '"') { r.err = "expected string"; return fail("gene"); }
+          const char* gb = r.p + 1;
+          const char* q = gb;
+          uint64_t hsh = 1469598103934665603ull;
+          bool blank = true, has_space = false, plain = true;
+          if (q < r.end && *q != '"' && *q != '\\') { blank = blank && *q == ' '; ++q; }  // strand char: not hashed
+          while (q < r.end && *q != '"') {
+            const char ch = *q;
+            if (ch == '\\') { plain = false; break; }
+            if (ch == ' ') has_space = true; else blank = false;
+            hsh = (hsh ^ (unsigned char)(ch == ' ' ? '_' : ch)) * 1099511628211ull;
+            ++q;
           }
-          if (blank) return fail("Gene information is missing");
-          if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
-          if (ge - gb < 2) return fail("Gene name information missing for a gene");
+          const char* ge;
           int32_t id;
-          if (!has_space) {
-            id = genes.intern(gb + 1, (size_t)(ge - gb - 1));
-          } else {
+          if (plain && q < r.end) {
+            ge = q;
+            r.p = q + 1;
+            if (blank) return fail("Gene information is missing");
+            if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
+            if (ge - gb < 2) return fail("Gene name information missing for a gene");
+            hsh ^= hsh >> 29;
+            if (!has_space) {
+              id = genes.intern_h(gb + 1, (size_t)(ge - gb - 1), hsh);
+            } else {
+              fixed.assign(gb + 1, ge);
+              std::replace(fixed.begin(), fixed.end(), ' ', '_');
+              id = genes.intern_h(fixed.data(), fixed.size(), hsh);
+            }
+          } else {  // escapes (or a truncated file): the general string reader
+            if (!r.str(owned)) return fail("gene");
+            gb = owned.data();
+            ge = gb + owned.size();
+            blank = true;
+            has_space = false;
+            for (const char* t = gb; t < ge; ++t) {
+              if (*t == ' ') has_space = true; else blank = false;
+            }
+            if (blank) return fail("Gene information is missing");
+            if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
+            if (ge - gb < 2) return fail("Gene name information missing for a gene");
             fixed.assign(gb + 1, ge);
             std::replace(fixed.begin(), fixed.end(), ' ', '_');
             id = genes.intern(fixed.data(), fixed.size());
