@@ -263,6 +263,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
     unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate, XW2 xf) {
+  if (!AMG_EXPERIMENTS) ablate = 0;
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64];
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     unsigned int emask, unsigned int probe_limit, unsigned long long* status,
     int* __restrict__ tok_pair, unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate,
     XW2 xf) {
+  if (!AMG_EXPERIMENTS) ablate = 0;
   __shared__ int s_id[TILE + 1];
   __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
   __shared__ unsigned char s_last[TILE + 1];
@@ -620,7 +622,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   stage_end(c);
 
   const char* abl = getenv("AMG_X_ABLATE");  // timing experiments (tools/ablate_probe.py): the build fails
-  const int ablate = abl ? (atoi(abl) & 63) : 0;
+  const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 63) : 0;
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
@@ -715,7 +717,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
   stage_end(c);
   const char* abl = getenv("AMG_X_ABLATE");
-  const int ablate = abl ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
+  const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
   stage_begin(c, "edge_upsert");
   if (n_tiles > 0)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),

@@ -10,6 +10,13 @@
 
 #include "../../include/amg.h"
 
+// Timing-experiment switches inside the kernels (AMG_X_ABLATE, AMG_GAP_ABLATE; tools/*_probe.py)
+// exist only in builds made with -DAMG_EXPERIMENTS=1 (make EXPERIMENTS=1): the shipped kernels
+// carry no trace of them.
+#ifndef AMG_EXPERIMENTS
+#define AMG_EXPERIMENTS 0
+#endif
+
 // ------------------------------------------------------------------ error plumbing
 extern thread_local std::string g_amg_err;
 int amg_fail(int code, const char* fmt, ...);

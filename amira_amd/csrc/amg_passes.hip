@@ -1028,13 +1028,13 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
     return;
   }
   wave_sync();
-  if (A.ablate == 1) return;
+  if (AMG_EXPERIMENTS && A.ablate == 1) return;
   // ---- one wave-cooperative DFS per run, runs in read order
   bool bad = false;
   for (int q = 0; q < n_gaps && !bad; ++q) {
     const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
     const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane,
-                                  A.ablate == 3 ? A.status + 8 : nullptr);
+                                  (AMG_EXPERIMENTS && A.ablate == 3) ? A.status + 8 : nullptr);
     if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
     bad = np < 0;
   }
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
     return;
   }
   wave_sync();
-  if (A.ablate == 2) return;
+  if (AMG_EXPERIMENTS && A.ablate == 2) return;
   unsigned long long n_combo = 1;
   bool dead_end = false;
   for (int q = 0; q < n_gaps; ++q) {
@@ -1778,7 +1778,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       G.need_slow = need_slow;
       {
         const char* ga = getenv("AMG_GAP_ABLATE");
-        G.ablate = ga ? atoi(ga) : 0;
+        G.ablate = (AMG_EXPERIMENTS && ga) ? atoi(ga) : 0;
       }
       if (attempt == 0) {
         const char* nf = getenv("AMG_NO_FAST_GAPPED");  // debugging / A-B switch
