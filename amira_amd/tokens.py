@@ -13,6 +13,7 @@ flipped tokens — which is all the device needs.
 """
 import hashlib
 import pickle
+from itertools import chain
 
 import numpy as np
 
@@ -99,17 +100,15 @@ def tokenize(read_dict):
     """dict[read_id -> ["+geneA", "-geneB", ...]] -> (Vocabulary, tokens int32, read_offsets
     int64, read_ids list) in the dict's iteration order (== the reference's build order,
     construct_graph.py:45)."""
-    seen = {}
-    for genes in read_dict.values():
-        for g in genes:
-            if g not in seen:
-                seen[g] = split_gene(g)[0]
-    vocab = Vocabulary(seen.values())
+    lists = list(read_dict.values())
+    seen = set(chain.from_iterable(lists))          # distinct "+name" / "-name" strings (C loops:
+    names = {g: split_gene(g)[0] for g in seen}    # the per-gene work stays out of the interpreter)
+    vocab = Vocabulary(names.values())
     table = {g: vocab.token(g) for g in seen}
     read_ids = list(read_dict.keys())
     offs = np.zeros(len(read_ids) + 1, dtype=np.int64)
-    np.cumsum([len(read_dict[r]) for r in read_ids], out=offs[1:])
-    toks = np.fromiter((table[g] for r in read_ids for g in read_dict[r]), dtype=np.int32,
+    np.cumsum(list(map(len, lists)), out=offs[1:])
+    toks = np.fromiter(map(table.__getitem__, chain.from_iterable(lists)), dtype=np.int32,
                        count=int(offs[-1]))
     return vocab, toks, offs, read_ids
 
