@@ -1,0 +1,725 @@
+/*
+ * token_sweep.c — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * Plain-C, strictly sequential restatement, in TOKEN space, of the whole cleaning sweep the
+ * benchmark times (reference graph_utils.py:145-166):
+ *     GeneMerGraph.__init__           construct_graph.py:31-102
+ *     filter_graph                    :523-540  (list_nodes_to_remove :496-503,
+ *                                      list_edges_to_remove :505-521, remove_edge :409-428,
+ *                                      remove_node :463-484, remove_node_from_reads :442-461)
+ *     remove_short_linear_paths       :679-720  (linear walks :722-861, get_degree :326-329,
+ *                                      get_mean_node_coverage :868-871)
+ *     remove_low_coverage_components  :950-958
+ *     correct_reads                   :1123-1134 (correct_single_read :1136-1151,
+ *                                      find_read_boundaries :1153-1164, identify_path_terminals
+ *                                      :1375-1386, new_find_paths_between_nodes :2292-2342,
+ *                                      insert_elements :1166-1203, get_possible_paths :1205-1263,
+ *                                      process_read_correction :1269-1329, get_annotation_for_read
+ *                                      :1331-1373, needleman_wunsch :1433-1480,
+ *                                      replace_invalid_gene_positions :1669-1691)
+ * It exists so that the GPU engine can be compared bit for bit at the FULL benchmark sizes
+ * (1 M and 8 M reads), which the pure-Python oracle (oracle/amira_oracle, pinned to the real
+ * reference by tests/golden/goldens.json) cannot reach.  It is itself pinned against that Python
+ * oracle on the sweep cases of tests/test_token_oracle.py.
+ *
+ * Token space (amira_amd/tokens.py, include/amg.h): integer order of tokens == order of the
+ * reference's signed gene hashes, strand flip == two_v - 1 - token, so canonical orientation
+ * (construct_gene_mer.py:15-39) is the lexicographic minimum of the window and its reverse
+ * complement.  Dict insertion order of the reference == order of first creation here: everything
+ * walks reads in order and windows in order, no parallelism, no cleverness.
+ *
+ * Conventions shared with the engine's arrays: tok_node[t] = node id of the window starting at
+ * token t, -1 where no window starts, -2 where the node was removed (None in _readNodes);
+ * removed nodes / edges keep their ids and get alive = 0 (the reference deletes them from its
+ * dicts; list orders of the survivors are unchanged by that).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct tsw {
+  int32_t k, two_v;
+  int64_t n_reads, T;
+  int32_t* tokens;
+  int64_t* read_off;
+  int64_t *gs, *ge, *read_len; /* gene positions [start, end] per token, sequence length per read */
+  int have_pos;
+  /* graph of the current read set */
+  int64_t D, E, capD, capE, n_windows, n_short, n_comp;
+  int32_t* node_tok; uint32_t* node_cov; int8_t* node_fdir; int32_t* node_comp; uint8_t* node_alive;
+  int32_t *e_src, *e_tgt; int8_t *e_sd, *e_td; uint32_t* e_cov; uint8_t* e_alive;
+  int64_t* adj_off; int32_t* adj_edge; /* row 2n = forwardEdgeHashes of n, 2n+1 = backwardEdgeHashes */
+  int32_t* tok_node; int8_t* tok_dir; uint8_t* read_fix;
+  /* hash maps (ids, -1 empty) */
+  int32_t* nmap; int64_t nmap_cap; int32_t* emap; int64_t emap_cap;
+  /* corrected read set (output of tsw_correct) */
+  int have_corr;
+  int64_t c_reads, c_T;
+  int32_t* c_tok; int64_t* c_off; int32_t* c_orig; uint8_t* c_changed; int64_t *c_gs, *c_ge;
+} tsw;
+
+static uint64_t mix(uint64_t x) { x ^= x >> 31; x *= 0x7fb5d329728ea185ull; x ^= x >> 27; x *= 0x81dadef4bc2dd44dull; x ^= x >> 33; return x; }
+
+static void free_graph(tsw* g) {
+  free(g->node_tok); free(g->node_cov); free(g->node_fdir); free(g->node_comp); free(g->node_alive);
+  free(g->e_src); free(g->e_tgt); free(g->e_sd); free(g->e_td); free(g->e_cov); free(g->e_alive);
+  free(g->adj_off); free(g->adj_edge); free(g->tok_node); free(g->tok_dir); free(g->read_fix);
+  free(g->nmap); free(g->emap);
+  g->node_tok = NULL; g->node_cov = NULL; g->node_fdir = NULL; g->node_comp = NULL; g->node_alive = NULL;
+  g->e_src = g->e_tgt = NULL; g->e_sd = g->e_td = NULL; g->e_cov = NULL; g->e_alive = NULL;
+  g->adj_off = NULL; g->adj_edge = NULL; g->tok_node = NULL; g->tok_dir = NULL; g->read_fix = NULL;
+  g->nmap = g->emap = NULL;
+  g->D = g->E = g->capD = g->capE = 0;
+}
+
+static void free_corr(tsw* g) {
+  free(g->c_tok); free(g->c_off); free(g->c_orig); free(g->c_changed); free(g->c_gs); free(g->c_ge);
+  g->c_tok = NULL; g->c_off = NULL; g->c_orig = NULL; g->c_changed = NULL; g->c_gs = g->c_ge = NULL;
+  g->have_corr = 0;
+}
+
+/* the caller's arrays are copied; gs / ge / read_len may be NULL (no gene positions) */
+tsw* tsw_new(const int32_t* tokens, const int64_t* read_off, int64_t n_reads, int32_t two_v,
+             const int64_t* gs, const int64_t* ge, const int64_t* read_len) {
+  tsw* g = (tsw*)calloc(1, sizeof(tsw));
+  g->n_reads = n_reads; g->T = read_off[n_reads]; g->two_v = two_v;
+  g->tokens = (int32_t*)malloc(sizeof(int32_t) * (size_t)(g->T + 1));
+  memcpy(g->tokens, tokens, sizeof(int32_t) * (size_t)g->T);
+  g->read_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_reads + 1));
+  memcpy(g->read_off, read_off, sizeof(int64_t) * (size_t)(n_reads + 1));
+  if (gs && ge) {
+    g->have_pos = 1;
+    g->gs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(g->T + 1));
+    g->ge = (int64_t*)malloc(sizeof(int64_t) * (size_t)(g->T + 1));
+    memcpy(g->gs, gs, sizeof(int64_t) * (size_t)g->T);
+    memcpy(g->ge, ge, sizeof(int64_t) * (size_t)g->T);
+  }
+  if (read_len) {
+    g->read_len = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_reads + 1));
+    memcpy(g->read_len, read_len, sizeof(int64_t) * (size_t)n_reads);
+  }
+  return g;
+}
+
+void tsw_free(tsw* g) {
+  if (!g) return;
+  free_graph(g); free_corr(g);
+  free(g->tokens); free(g->read_off); free(g->gs); free(g->ge); free(g->read_len);
+  free(g);
+}
+
+/* ------------------------------------------------------------------ build (:31-102) */
+static void grow_nodes(tsw* g) {
+  int64_t cap = g->capD ? g->capD * 2 : 1024;
+  g->node_tok = (int32_t*)realloc(g->node_tok, sizeof(int32_t) * (size_t)cap * g->k);
+  g->node_cov = (uint32_t*)realloc(g->node_cov, sizeof(uint32_t) * (size_t)cap);
+  g->node_fdir = (int8_t*)realloc(g->node_fdir, (size_t)cap);
+  g->capD = cap;
+}
+static void grow_edges(tsw* g) {
+  int64_t cap = g->capE ? g->capE * 2 : 2048;
+  g->e_src = (int32_t*)realloc(g->e_src, sizeof(int32_t) * (size_t)cap);
+  g->e_tgt = (int32_t*)realloc(g->e_tgt, sizeof(int32_t) * (size_t)cap);
+  g->e_sd = (int8_t*)realloc(g->e_sd, (size_t)cap);
+  g->e_td = (int8_t*)realloc(g->e_td, (size_t)cap);
+  g->e_cov = (uint32_t*)realloc(g->e_cov, sizeof(uint32_t) * (size_t)cap);
+  g->capE = cap;
+}
+static uint64_t node_hash(const int32_t* c, int k) {
+  uint64_t h = 1469598103934665603ull;
+  for (int j = 0; j < k; ++j) h = mix(h ^ (uint64_t)(uint32_t)c[j]);
+  return h;
+}
+static uint64_t edge_hash(int32_t s, int32_t t, int sgn) {
+  return mix(mix((uint64_t)(uint32_t)s * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)t) ^ (uint64_t)(sgn + 2));
+}
+static void nmap_rehash(tsw* g) {
+  int64_t cap = g->nmap_cap ? g->nmap_cap * 2 : 4096;
+  free(g->nmap);
+  g->nmap = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  memset(g->nmap, 0xff, sizeof(int32_t) * (size_t)cap);
+  for (int64_t id = 0; id < g->D; ++id) {
+    uint64_t s = node_hash(g->node_tok + id * g->k, g->k) & (uint64_t)(cap - 1);
+    while (g->nmap[s] >= 0) s = (s + 1) & (uint64_t)(cap - 1);
+    g->nmap[s] = (int32_t)id;
+  }
+  g->nmap_cap = cap;
+}
+static void emap_rehash(tsw* g) {
+  int64_t cap = g->emap_cap ? g->emap_cap * 2 : 8192;
+  free(g->emap);
+  g->emap = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  memset(g->emap, 0xff, sizeof(int32_t) * (size_t)cap);
+  for (int64_t e = 0; e < g->E; ++e) {
+    uint64_t s = edge_hash(g->e_src[e], g->e_tgt[e], g->e_sd[e] * g->e_td[e]) & (uint64_t)(cap - 1);
+    while (g->emap[s] >= 0) s = (s + 1) & (uint64_t)(cap - 1);
+    g->emap[s] = (int32_t)e;
+  }
+  g->emap_cap = cap;
+}
+
+/* one directed edge event (src, tgt, ds, dt): the class (src, tgt, ds * dt) keeps its FIRST
+ * object with that object's directions (add_edge_to_edges :268-277, Edge.__hash__
+ * construct_edge.py:104-124); coverage += 1 per event (:81-82 of __init__) */
+static void edge_event(tsw* g, int32_t s, int32_t t, int ds, int dt) {
+  const int sgn = ds * dt;
+  if ((g->E + 1) * 2 > g->emap_cap) emap_rehash(g);
+  uint64_t slot = edge_hash(s, t, sgn) & (uint64_t)(g->emap_cap - 1);
+  int32_t e;
+  while ((e = g->emap[slot]) >= 0) {
+    if (g->e_src[e] == s && g->e_tgt[e] == t && g->e_sd[e] * g->e_td[e] == sgn) break;
+    slot = (slot + 1) & (uint64_t)(g->emap_cap - 1);
+  }
+  if (e < 0) {
+    if (g->E == g->capE) grow_edges(g);
+    e = (int32_t)g->E++;
+    g->e_src[e] = s; g->e_tgt[e] = t; g->e_sd[e] = (int8_t)ds; g->e_td[e] = (int8_t)dt; g->e_cov[e] = 0;
+    g->emap[slot] = e;
+  }
+  g->e_cov[e]++;
+}
+
+/* Returns 0, or -4 when a window equals its reverse complement (construct_gene_mer.py:23-25). */
+int tsw_build(tsw* g, int32_t k) {
+  free_graph(g);
+  g->k = k; g->n_windows = g->n_short = g->n_comp = 0;
+  g->nmap_cap = g->emap_cap = 0;
+  nmap_rehash(g); emap_rehash(g);
+  const int64_t T = g->T;
+  g->tok_node = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+  g->tok_dir = (int8_t*)malloc((size_t)(T + 1));
+  g->read_fix = (uint8_t*)calloc((size_t)(g->n_reads + 1), 1);
+  for (int64_t t = 0; t < T; ++t) { g->tok_node[t] = -1; g->tok_dir[t] = 0; }
+  int32_t canon[64];
+  const int32_t flip = g->two_v - 1;
+  for (int64_t r = 0; r < g->n_reads; ++r) {
+    const int64_t a = g->read_off[r], b = g->read_off[r + 1], n = (b - a) - k + 1;
+    if (n <= 0) { g->n_short++; continue; }           /* _shortReads (:53-55) */
+    int32_t prev = -1; int prev_dir = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t* w = g->tokens + a + i;
+      int dir = 0;
+      for (int j = 0; j < k && !dir; ++j) { int32_t x = w[j], y = flip - w[k - 1 - j]; if (x != y) dir = x < y ? 1 : -1; }
+      if (!dir) return -4;
+      for (int j = 0; j < k; ++j) canon[j] = dir > 0 ? w[j] : flip - w[k - 1 - j];
+      if ((g->D + 1) * 2 > g->nmap_cap) nmap_rehash(g);
+      uint64_t slot = node_hash(canon, k) & (uint64_t)(g->nmap_cap - 1);
+      int32_t id;
+      while ((id = g->nmap[slot]) >= 0) {
+        if (memcmp(g->node_tok + (int64_t)id * k, canon, sizeof(int32_t) * k) == 0) break;
+        slot = (slot + 1) & (uint64_t)(g->nmap_cap - 1);
+      }
+      if (id < 0) {                                    /* add_node_to_nodes (:188-190) */
+        if (g->D == g->capD) grow_nodes(g);
+        id = (int32_t)g->D++;
+        memcpy(g->node_tok + (int64_t)id * k, canon, sizeof(int32_t) * k);
+        g->node_fdir[id] = (int8_t)dir;                /* the first-seen GeneMer object is kept */
+        g->node_cov[id] = 0;
+        g->nmap[slot] = id;
+      }
+      g->node_cov[id]++; g->n_windows++;
+      g->tok_node[a + i] = id; g->tok_dir[a + i] = (int8_t)dir;
+      if (prev >= 0) {                                 /* create_edges (:246-262) */
+        edge_event(g, prev, id, prev_dir, dir);
+        edge_event(g, id, prev, -dir, -prev_dir);
+      }
+      prev = id; prev_dir = dir;
+    }
+  }
+  const int64_t D = g->D, E = g->E;
+  g->node_alive = (uint8_t*)malloc((size_t)D + 1); memset(g->node_alive, 1, (size_t)D + 1);
+  g->e_alive = (uint8_t*)malloc((size_t)E + 1); memset(g->e_alive, 1, (size_t)E + 1);
+  /* forward / backward edge lists (add_edge_to_node :287-298): an edge enters the list chosen by
+   * the STORED object's source direction when it is created and is found there ever after, so
+   * list order = creation order of the edges of that (source, side) */
+  g->adj_off = (int64_t*)calloc((size_t)(2 * D + 2), sizeof(int64_t));
+  g->adj_edge = (int32_t*)malloc(sizeof(int32_t) * (size_t)(E + 1));
+  for (int64_t e = 0; e < E; ++e) g->adj_off[2 * (int64_t)g->e_src[e] + (g->e_sd[e] == 1 ? 0 : 1) + 1]++;
+  for (int64_t r = 0; r < 2 * D; ++r) g->adj_off[r + 1] += g->adj_off[r];
+  {
+    int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)(2 * D + 1));
+    memcpy(cur, g->adj_off, sizeof(int64_t) * (size_t)(2 * D + 1));
+    for (int64_t e = 0; e < E; ++e) g->adj_edge[cur[2 * (int64_t)g->e_src[e] + (g->e_sd[e] == 1 ? 0 : 1)]++] = (int32_t)e;
+    free(cur);
+  }
+  /* assign_component_ids (:920-927): ids 1, 2, ... in order of the first node of each component
+   * (any traversal gives the same labels as the reference's recursive DFS) */
+  g->node_comp = (int32_t*)calloc((size_t)D + 1, sizeof(int32_t));
+  {
+    int32_t* stack = (int32_t*)malloc(sizeof(int32_t) * (size_t)(D + 1));
+    int32_t cid = 0;
+    for (int64_t s = 0; s < D; ++s) {
+      if (g->node_comp[s]) continue;
+      ++cid;
+      int64_t top = 0;
+      stack[top++] = (int32_t)s; g->node_comp[s] = cid;
+      while (top > 0) {
+        const int32_t n = stack[--top];
+        for (int64_t p = g->adj_off[2 * (int64_t)n]; p < g->adj_off[2 * (int64_t)n + 2]; ++p) {
+          const int32_t t = g->e_tgt[g->adj_edge[p]];
+          if (!g->node_comp[t]) { g->node_comp[t] = cid; stack[top++] = t; }
+        }
+      }
+    }
+    g->n_comp = cid;
+    free(stack);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ removals */
+/* remove_node_from_reads (:442-461) for every node whose alive flag was just cleared: all its
+ * occurrences become None in every read that holds it and those reads join _readsToCorrect;
+ * edges with a removed endpoint go with it (remove_node :463-484 / list_edges_to_remove) */
+static void apply_removals(tsw* g) {
+  for (int64_t e = 0; e < g->E; ++e)
+    if (g->e_alive[e] && (!g->node_alive[g->e_src[e]] || !g->node_alive[g->e_tgt[e]])) g->e_alive[e] = 0;
+  for (int64_t r = 0; r < g->n_reads; ++r)
+    for (int64_t t = g->read_off[r]; t < g->read_off[r + 1]; ++t) {
+      const int32_t n = g->tok_node[t];
+      if (n >= 0 && !g->node_alive[n]) { g->tok_node[t] = -2; g->read_fix[r] = 1; }
+    }
+}
+
+/* filter_graph(minNodeCoverage, minEdgeCoverage) (:523-540) */
+void tsw_filter(tsw* g, int64_t min_node_cov, int64_t min_edge_cov) {
+  for (int64_t n = 0; n < g->D; ++n)      /* list_nodes_to_remove: not (coverage > min - 1) */
+    if (g->node_alive[n] && !((int64_t)g->node_cov[n] > min_node_cov - 1)) g->node_alive[n] = 0;
+  for (int64_t e = 0; e < g->E; ++e)      /* list_edges_to_remove: low coverage (doomed endpoints: apply_removals) */
+    if (g->e_alive[e] && !((int64_t)g->e_cov[e] > min_edge_cov - 1)) g->e_alive[e] = 0;
+  apply_removals(g);
+  free_corr(g);
+}
+
+static int live_row(const tsw* g, int32_t n, int side, int32_t* first_edge) {
+  int cnt = 0;
+  for (int64_t p = g->adj_off[2 * (int64_t)n + side]; p < g->adj_off[2 * (int64_t)n + side + 1]; ++p) {
+    const int32_t e = g->adj_edge[p];
+    if (!g->e_alive[e]) continue;
+    if (cnt == 0 && first_edge) *first_edge = e;
+    ++cnt;
+  }
+  return cnt;
+}
+/* get_degree (:326-329) */
+static int degree(const tsw* g, int32_t n) { return live_row(g, n, 0, NULL) + live_row(g, n, 1, NULL); }
+
+/* get_forward_node_from_node (:722-741): needs EXACTLY one forward edge;
+ * get_backward_node_from_node (:781-802): returns on the FIRST backward edge.
+ * 0 = (False, None, None), 1 = (False, tgt, dir), 2 = (True, tgt, dir) */
+static int lin_step(const tsw* g, int32_t n, int use_forward, int32_t* tgt, int* tdir) {
+  int32_t e = -1;
+  const int cnt = live_row(g, n, use_forward ? 0 : 1, &e);
+  if (cnt == 0 || (use_forward && cnt != 1)) return 0;
+  *tgt = g->e_tgt[e]; *tdir = g->e_td[e];
+  const int deg = degree(g, *tgt);
+  return ((deg == 2 || deg == 1) && *tgt != n) ? 2 : 1;
+}
+
+/* remove_short_linear_paths(min_length) (:679-720).  protect[n] != 0: node n is in AMR_nodes.
+ * removed_ids (may be NULL) receives the removed node ids in ascending order.  A walk is cut
+ * short once it holds min_length nodes: such a path is not < min_length whatever follows. */
+int64_t tsw_clip(tsw* g, int32_t min_length, const uint8_t* protect, int32_t* removed_ids) {
+  const int64_t D = g->D;
+  /* get_mean_node_coverage (:868-871): statistics.mean (exact, then correctly rounded) * 1.5 */
+  uint64_t sum = 0, cnt = 0;
+  for (int64_t n = 0; n < D; ++n) if (g->node_alive[n]) { sum += g->node_cov[n]; ++cnt; }
+  if (cnt == 0) return 0;
+  const double thr = ((double)sum / (double)cnt) * 1.5;
+  uint32_t* comp_live = (uint32_t*)calloc((size_t)g->n_comp + 2, sizeof(uint32_t));
+  for (int64_t n = 0; n < D; ++n) if (g->node_alive[n]) comp_live[g->node_comp[n]]++;
+  uint8_t* kill = (uint8_t*)calloc((size_t)D + 1, 1);
+  int32_t* path = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * min_length + 4));
+  for (int64_t i = 0; i < D; ++i) {
+    if (!g->node_alive[i] || degree(g, (int32_t)i) != 1) continue;
+    const int32_t n = (int32_t)i;
+    const int d0 = g->node_fdir[n];   /* node.get_geneMer().get_geneMerDirection() (:852-858) */
+    int len = 0, too_long = 0;
+    path[len++] = n;
+    int32_t tgt = -1; int td = 0;
+    /* get_backward_path_from_node(node, -d0) (:804-847): startDirection == -1 -> backward step */
+    int r = lin_step(g, n, (-d0) == -1 ? 0 : 1, &tgt, &td);
+    while (r == 2) {
+      if (tgt == n) break;
+      if (len >= min_length) { too_long = 1; break; }
+      path[len++] = tgt;
+      r = lin_step(g, tgt, td == -1 ? 0 : 1, &tgt, &td);
+    }
+    /* get_forward_path_from_node(node, d0) (:743-779) */
+    if (!too_long) {
+      r = lin_step(g, n, d0 == 1 ? 1 : 0, &tgt, &td);
+      while (r == 2) {
+        if (tgt == n) break;
+        if (len >= min_length) { too_long = 1; break; }
+        path[len++] = tgt;
+        r = lin_step(g, tgt, td == 1 ? 1 : 0, &tgt, &td);
+      }
+    }
+    if (too_long || !(len > 0 && len < min_length)) continue;
+    int all_high = 1;
+    for (int j = 0; j < len; ++j) all_high = all_high && ((double)g->node_cov[path[j]] > thr);
+    if (all_high) continue;
+    /* a tip that is its whole component stays (:710-713) */
+    uint32_t distinct = 0;
+    for (int j = 0; j < len; ++j) { int dup = 0; for (int q = 0; q < j; ++q) dup = dup || path[q] == path[j]; distinct += dup ? 0 : 1; }
+    if (distinct == comp_live[g->node_comp[n]]) continue;
+    for (int j = 0; j < len; ++j) if (!protect || !protect[path[j]]) kill[path[j]] = 1;
+  }
+  int64_t n_removed = 0;
+  for (int64_t n = 0; n < D; ++n)
+    if (kill[n] && g->node_alive[n]) { g->node_alive[n] = 0; if (removed_ids) removed_ids[n_removed] = (int32_t)n; ++n_removed; }
+  free(kill); free(path); free(comp_live);
+  if (n_removed) apply_removals(g);
+  free_corr(g);
+  return n_removed;
+}
+
+/* remove_low_coverage_components(min) (:950-958): a component goes when ALL its nodes have
+ * coverage < min */
+void tsw_remove_low_coverage_components(tsw* g, int64_t min_cov) {
+  uint8_t* high = (uint8_t*)calloc((size_t)g->n_comp + 2, 1);
+  for (int64_t n = 0; n < g->D; ++n)
+    if (g->node_alive[n] && !((int64_t)g->node_cov[n] < min_cov)) high[g->node_comp[n]] = 1;
+  for (int64_t n = 0; n < g->D; ++n)
+    if (g->node_alive[n] && !high[g->node_comp[n]]) g->node_alive[n] = 0;
+  free(high);
+  apply_removals(g);
+  free_corr(g);
+}
+
+/* ------------------------------------------------------------------ correct_reads (:1123-1134) */
+typedef struct { int32_t* v; int64_t n, cap; } ivec;
+static void iv_push(ivec* a, int32_t x) {
+  if (a->n == a->cap) { a->cap = a->cap ? a->cap * 2 : 256; a->v = (int32_t*)realloc(a->v, sizeof(int32_t) * (size_t)a->cap); }
+  a->v[a->n++] = x;
+}
+
+/* new_find_paths_between_nodes (:2292-2342): the recursion as written.  pn / pd = the path so
+ * far (= `path`, and, as a set, `seen`); records [len, nodes.., dirs..] are appended to out. */
+static void dfs_paths(const tsw* g, int32_t node, int dir, int32_t end, int distance, int32_t* pn,
+                      int8_t* pd, int depth, ivec* out, int64_t* n_paths) {
+  pn[depth] = node; pd[depth] = (int8_t)dir;
+  const int len = depth + 1;
+  if (node == end && len <= distance) {
+    iv_push(out, len);
+    for (int j = 0; j < len; ++j) iv_push(out, pn[j]);
+    for (int j = 0; j < len; ++j) iv_push(out, pd[j]);
+    ++*n_paths;
+    return;
+  }
+  if (len - 1 > distance) return;
+  const int side = dir == 1 ? 0 : 1;   /* forward list when the direction is +1, backward when -1 */
+  for (int64_t p = g->adj_off[2 * (int64_t)node + side]; p < g->adj_off[2 * (int64_t)node + side + 1]; ++p) {
+    const int32_t e = g->adj_edge[p];
+    if (!g->e_alive[e]) continue;
+    const int32_t t = g->e_tgt[e];
+    int seen = 0;
+    for (int j = 0; j <= depth && !seen; ++j) seen = pn[j] == t;
+    if (seen) continue;
+    dfs_paths(g, t, g->e_td[e], end, distance, pn, pd, depth + 1, out, n_paths);
+  }
+}
+
+/* j-th gene of node n read in direction d (get_gene_mer_genes :588 / get_reverse_gene_mer_genes :594) */
+static int32_t oriented_tok(const tsw* g, int32_t n, int d, int j) {
+  const int32_t* nt = g->node_tok + (int64_t)n * g->k;
+  return d == 1 ? nt[j] : (g->two_v - 1) - nt[g->k - 1 - j];
+}
+
+/* get_annotation_for_read (:1331-1373): k-1 genes of the first node, then the last gene of each */
+static int annotate(const tsw* g, const int32_t* nodes, const int8_t* dirs, int n, int32_t* out) {
+  int ng = 0;
+  if (n == 1) { for (int j = 0; j < g->k; ++j) out[ng++] = oriented_tok(g, nodes[0], dirs[0], j); return ng; }
+  for (int j = 0; j < g->k - 1; ++j) out[ng++] = oriented_tok(g, nodes[0], dirs[0], j);
+  for (int i = 0; i < n; ++i) out[ng++] = oriented_tok(g, nodes[i], dirs[i], g->k - 1);
+  return ng;
+}
+
+#define POS_NONE INT64_MIN
+
+/* needleman_wunsch(x, y) (:1433-1480) + the position carry-over of process_read_correction
+ * (:1311-1328) + replace_invalid_gene_positions (:1669-1691).  x = corrected genes (N), y =
+ * original genes (M) with positions ys / ye; writes N positions. */
+static void carry_positions(const int32_t* x, int N, const int32_t* y, int M, const int64_t* ys,
+                            const int64_t* ye, int64_t seq_len, int64_t* os, int64_t* oe) {
+  /* F[i][j] for i, j >= 0; borders F[-1][-1] = 0, F[i][-1] = -i, F[-1][j] = -j (:1439-1445) */
+  int32_t* F = (int32_t*)malloc(sizeof(int32_t) * (size_t)N * (size_t)M);
+  uint8_t* P = (uint8_t*)malloc((size_t)N * (size_t)M);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < M; ++j) {
+      const int f_dd = (i == 0 && j == 0) ? 0 : (i == 0 ? -(j - 1) : (j == 0 ? -(i - 1) : F[(size_t)(i - 1) * M + j - 1]));
+      const int f_up = i == 0 ? -j : F[(size_t)(i - 1) * M + j];      /* F[i-1, j], pointer LEFT = (-1, 0) */
+      const int f_lf = j == 0 ? -i : F[(size_t)i * M + j - 1];        /* F[i, j-1], pointer UP = (0, -1)   */
+      /* max over (score, pointer) tuples: on equal scores UP (0,-1) > LEFT (-1,0) > DIAG (-1,-1) */
+      int best = f_dd + (x[i] == y[j] ? 1 : 0); uint8_t ptr = 0;
+      if (f_up - 1 >= best) { best = f_up - 1; ptr = 1; }
+      if (f_lf - 1 >= best) { best = f_lf - 1; ptr = 2; }
+      F[(size_t)i * M + j] = best; P[(size_t)i * M + j] = ptr;
+    }
+  uint8_t* ops = (uint8_t*)malloc((size_t)(N + M + 2));
+  int n_ops = 0, i = N - 1, j = M - 1;
+  while (i >= 0 && j >= 0) {
+    const uint8_t p = P[(size_t)i * M + j];
+    ops[n_ops++] = p;
+    if (p == 0) { --i; --j; } else if (p == 1) --i; else --j;
+  }
+  while (i >= 0) { ops[n_ops++] = 1; --i; }
+  while (j >= 0) { ops[n_ops++] = 2; --j; }
+  /* alignment columns front to back (:1314-1325): a column with a corrected gene that equals its
+   * partner takes the next original position; any other column with a corrected gene gives
+   * (None, None) WITHOUT consuming one; a gap in the corrected list consumes one */
+  int xi = 0, yj = 0, cur = 0, out = 0;
+  for (int o = n_ops - 1; o >= 0; --o) {
+    const uint8_t p = ops[o];
+    if (p == 0) {
+      if (x[xi] == y[yj]) { os[out] = ys[cur]; oe[out] = ye[cur]; ++cur; } else { os[out] = POS_NONE; oe[out] = POS_NONE; }
+      ++out; ++xi; ++yj;
+    } else if (p == 1) { os[out] = POS_NONE; oe[out] = POS_NONE; ++out; ++xi; }
+    else { ++cur; ++yj; }
+  }
+  /* replace_invalid_gene_positions: prev_end follows the entries as they were BEFORE repair, the
+   * look-ahead sees later entries, which are still unrepaired */
+  int64_t prev_end = 0;
+  for (int q = 0; q < N; ++q) {
+    const int64_t sv = os[q], ev = oe[q];
+    if (ev != POS_NONE) prev_end = ev;
+    if (sv == POS_NONE && ev == POS_NONE) {
+      int64_t nxt = POS_NONE;
+      for (int w = q + 1; w < N; ++w) if (os[w] != POS_NONE) { nxt = os[w]; break; }
+      os[q] = prev_end;
+      oe[q] = nxt != POS_NONE ? nxt : seq_len - 1;
+    }
+  }
+  free(F); free(P); free(ops);
+}
+
+typedef struct { int32_t* tok; int64_t* gs; int64_t* ge; int64_t n, cap; int pos; } outbuf;
+static void ob_reserve(outbuf* o, int64_t extra) {
+  if (o->n + extra <= o->cap) return;
+  while (o->n + extra > o->cap) o->cap = o->cap ? o->cap * 2 : 4096;
+  o->tok = (int32_t*)realloc(o->tok, sizeof(int32_t) * (size_t)o->cap);
+  if (o->pos) {
+    o->gs = (int64_t*)realloc(o->gs, sizeof(int64_t) * (size_t)o->cap);
+    o->ge = (int64_t*)realloc(o->ge, sizeof(int64_t) * (size_t)o->cap);
+  }
+}
+
+/* correct_reads: the corrected read set stays inside g (tsw_corrected reads it, tsw_adopt makes
+ * it the current read set).  Reads without a node (short reads) are not in _readNodes and
+ * therefore not in the output; marked reads whose nodes were all removed are dropped (:1150). */
+void tsw_correct(tsw* g, int64_t* n_out_reads, int64_t* n_out_tokens) {
+  free_corr(g);
+  const int k = g->k;
+  outbuf ob; memset(&ob, 0, sizeof(ob)); ob.pos = g->have_pos;
+  ob_reserve(&ob, g->T + 16);
+  int64_t* c_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(g->n_reads + 1));
+  int32_t* c_orig = (int32_t*)malloc(sizeof(int32_t) * (size_t)(g->n_reads + 1));
+  uint8_t* c_changed = (uint8_t*)malloc((size_t)g->n_reads + 1);
+  int64_t nr = 0;
+  c_off[0] = 0;
+  ivec pool = {0, 0, 0}, gaps = {0, 0, 0};
+  const int distance = 2 * k;
+  int32_t* pn = (int32_t*)malloc(sizeof(int32_t) * (size_t)(distance + 4));
+  int8_t* pd = (int8_t*)malloc((size_t)(distance + 4));
+  int64_t cap_c = 0; int32_t* c_node = NULL; int8_t* c_dir = NULL; int32_t* c_gene = NULL; int32_t* best = NULL;
+  for (int64_t r = 0; r < g->n_reads; ++r) {
+    const int64_t t0 = g->read_off[r], L0 = g->read_off[r + 1] - t0, n = L0 - k + 1;
+    if (n <= 0) continue;
+    const int32_t* W = g->tok_node + t0;
+    const int8_t* Dr = g->tok_dir + t0;
+    if (!g->read_fix[r]) {                       /* not in _readsToCorrect: the same list (:1138-1139) */
+      ob_reserve(&ob, L0);
+      memcpy(ob.tok + ob.n, g->tokens + t0, sizeof(int32_t) * (size_t)L0);
+      if (ob.pos) { memcpy(ob.gs + ob.n, g->gs + t0, sizeof(int64_t) * (size_t)L0); memcpy(ob.ge + ob.n, g->ge + t0, sizeof(int64_t) * (size_t)L0); }
+      ob.n += L0; c_orig[nr] = (int32_t)r; c_changed[nr] = 0; c_off[++nr] = ob.n;
+      continue;
+    }
+    /* find_read_boundaries (:1153-1164) */
+    int64_t start = -1, end = -1;
+    for (int64_t i = 0; i < n; ++i) if (W[i] >= 0) { start = i; break; }
+    if (start < 0) continue;                      /* every node is None: [] -> dropped (:1141,:1150) */
+    for (int64_t i = n - 1; i >= 0; --i) if (W[i] >= 0) { end = i; break; }
+    /* identify_path_terminals (:1375-1386); gaps = (path_start, path_end) pairs */
+    gaps.n = 0;
+    {
+      int64_t path_start = -1;
+      for (int64_t i = start; i <= end; ++i)
+        if (W[i] < 0) {
+          if (W[i - 1] >= 0) path_start = i - 1;
+          if (W[i + 1] >= 0) { iv_push(&gaps, (int32_t)path_start); iv_push(&gaps, (int32_t)(i + 1)); }
+        }
+    }
+    const int n_gaps = (int)(gaps.n / 2);
+    if (n_gaps == 0) {
+      /* only the ends were lost: nodes[start : end + 1], positions[start : end + k] (:1277-1285) */
+      const int64_t len = end - start + k;
+      ob_reserve(&ob, len);
+      if (end - start + 1 >= cap_c) {
+        cap_c = 2 * (end - start + 1) + 64;
+        c_node = (int32_t*)realloc(c_node, sizeof(int32_t) * (size_t)cap_c); c_dir = (int8_t*)realloc(c_dir, (size_t)cap_c);
+        c_gene = (int32_t*)realloc(c_gene, sizeof(int32_t) * (size_t)(cap_c + k)); best = (int32_t*)realloc(best, sizeof(int32_t) * (size_t)(cap_c + k));
+      }
+      const int ng = annotate(g, W + start, Dr + start, (int)(end - start + 1), ob.tok + ob.n);
+      if (ob.pos) { memcpy(ob.gs + ob.n, g->gs + t0 + start, sizeof(int64_t) * (size_t)len); memcpy(ob.ge + ob.n, g->ge + t0 + start, sizeof(int64_t) * (size_t)len); }
+      ob.n += ng; c_orig[nr] = (int32_t)r; c_changed[nr] = 1; c_off[++nr] = ob.n;
+      continue;
+    }
+    /* generate_replacement_dict (:1388-1396) per pair, in pair order */
+    pool.n = 0;
+    ivec first = {0, 0, 0}, count = {0, 0, 0};
+    int dead_end = 0;
+    for (int q = 0; q < n_gaps; ++q) {
+      const int32_t ps = gaps.v[2 * q], pe = gaps.v[2 * q + 1];
+      int64_t np = 0;
+      iv_push(&first, (int32_t)pool.n);
+      dfs_paths(g, W[ps], Dr[ps], W[pe], distance, pn, pd, 0, &pool, &np);
+      iv_push(&count, (int32_t)np);
+      if (np == 0) dead_end = 1;
+    }
+    if (dead_end) {
+      /* product over an empty list: possible_paths == [] -> the original genes, positions untouched (:1292-1293) */
+      ob_reserve(&ob, L0);
+      memcpy(ob.tok + ob.n, g->tokens + t0, sizeof(int32_t) * (size_t)L0);
+      if (ob.pos) { memcpy(ob.gs + ob.n, g->gs + t0, sizeof(int64_t) * (size_t)L0); memcpy(ob.ge + ob.n, g->ge + t0, sizeof(int64_t) * (size_t)L0); }
+      ob.n += L0; c_orig[nr] = (int32_t)r; c_changed[nr] = 0; /* the SAME list object comes back */
+      c_off[++nr] = ob.n;
+      free(first.v); free(count.v);
+      continue;
+    }
+    /* insert_elements (:1166-1203): itertools.product over the pairs' path lists (last pair
+     * fastest), each combination spliced into the full (node, direction) list of the read */
+    int64_t need = n + (int64_t)n_gaps * (distance + 2) + 8;
+    if (need >= cap_c) {
+      cap_c = 2 * need + 64;
+      c_node = (int32_t*)realloc(c_node, sizeof(int32_t) * (size_t)cap_c); c_dir = (int8_t*)realloc(c_dir, (size_t)cap_c);
+      c_gene = (int32_t*)realloc(c_gene, sizeof(int32_t) * (size_t)(cap_c + k)); best = (int32_t*)realloc(best, sizeof(int32_t) * (size_t)(cap_c + k));
+    }
+    int* pick = (int*)calloc((size_t)n_gaps, sizeof(int));
+    int best_shared = 0, best_ng = -1; uint64_t best_sum = 0, best_len = 1;
+    for (;;) {
+      /* insert_single_combination on a copy of nodes_on_read */
+      int64_t cn = n;
+      memcpy(c_node, W, sizeof(int32_t) * (size_t)n);
+      memcpy(c_dir, Dr, (size_t)n);
+      int64_t offset = 0;
+      for (int q = 0; q < n_gaps; ++q) {
+        const int32_t s = gaps.v[2 * q], e = gaps.v[2 * q + 1];
+        const int32_t* p = pool.v + first.v[q];
+        for (int w = 0; w < pick[q]; ++w) p += 1 + 2 * p[0];
+        const int len = p[0];
+        const int64_t ip = s + offset, del = e - s + 1;
+        memmove(c_node + ip + len, c_node + ip + del, sizeof(int32_t) * (size_t)(cn - ip - del));
+        memmove(c_dir + ip + len, c_dir + ip + del, (size_t)(cn - ip - del));
+        for (int w = 0; w < len; ++w) { c_node[ip + w] = p[1 + w]; c_dir[ip + w] = (int8_t)p[1 + len + w]; }
+        cn += len - del;
+        offset += len - del;
+      }
+      /* get_possible_paths (:1205-1263): entries without a node are ignored */
+      int64_t m = 0;
+      for (int64_t i = 0; i < cn; ++i) if (c_node[i] >= 0) { c_node[m] = c_node[i]; c_dir[m] = c_dir[i]; ++m; }
+      /* get_coverage_of_path (:1265-1267) and the genes of the candidate */
+      uint64_t csum = 0;
+      for (int64_t i = 0; i < m; ++i) csum += g->node_cov[c_node[i]];
+      const int ng = annotate(g, c_node, c_dir, (int)m, c_gene);
+      /* len(set(genes).intersection(original genes)) */
+      int shared = 0;
+      for (int i = 0; i < ng; ++i) {
+        int dup = 0;
+        for (int w = 0; w < i && !dup; ++w) dup = c_gene[w] == c_gene[i];
+        if (dup) continue;
+        int hit = 0;
+        for (int64_t w = 0; w < L0 && !hit; ++w) hit = g->tokens[t0 + w] == c_gene[i];
+        shared += hit;
+      }
+      /* more shared genes, or as many and a strictly larger statistics.mean of the node
+       * coverages (:1297-1310; exact comparison of the two fractions) */
+      if (shared > best_shared || (shared == best_shared && csum * best_len > best_sum * (uint64_t)m)) {
+        best_shared = shared; best_sum = csum; best_len = (uint64_t)m; best_ng = ng;
+        memcpy(best, c_gene, sizeof(int32_t) * (size_t)ng);
+      }
+      int q = n_gaps - 1;
+      while (q >= 0 && ++pick[q] == count.v[q]) { pick[q] = 0; --q; }
+      if (q < 0) break;
+    }
+    free(pick); free(first.v); free(count.v);
+    ob_reserve(&ob, best_ng);
+    memcpy(ob.tok + ob.n, best, sizeof(int32_t) * (size_t)best_ng);
+    if (ob.pos)
+      carry_positions(best, best_ng, g->tokens + t0, (int)L0, g->gs + t0, g->ge + t0,
+                      g->read_len ? g->read_len[r] : 0, ob.gs + ob.n, ob.ge + ob.n);
+    ob.n += best_ng; c_orig[nr] = (int32_t)r; c_changed[nr] = 1; c_off[++nr] = ob.n;
+  }
+  free(pool.v); free(gaps.v); free(pn); free(pd); free(c_node); free(c_dir); free(c_gene); free(best);
+  g->c_tok = ob.tok; g->c_gs = ob.gs; g->c_ge = ob.ge; g->c_off = c_off; g->c_orig = c_orig; g->c_changed = c_changed;
+  g->c_reads = nr; g->c_T = ob.n; g->have_corr = 1;
+  if (n_out_reads) *n_out_reads = nr;
+  if (n_out_tokens) *n_out_tokens = ob.n;
+}
+
+/* any pointer may be NULL */
+int tsw_corrected(const tsw* g, int32_t* tokens, int64_t* read_off, int32_t* orig_read, uint8_t* changed,
+                  int64_t* gs, int64_t* ge) {
+  if (!g->have_corr) return -3;
+  if (tokens) memcpy(tokens, g->c_tok, sizeof(int32_t) * (size_t)g->c_T);
+  if (read_off) memcpy(read_off, g->c_off, sizeof(int64_t) * (size_t)(g->c_reads + 1));
+  if (orig_read) memcpy(orig_read, g->c_orig, sizeof(int32_t) * (size_t)g->c_reads);
+  if (changed) memcpy(changed, g->c_changed, (size_t)g->c_reads);
+  if (gs && g->have_pos) memcpy(gs, g->c_gs, sizeof(int64_t) * (size_t)g->c_T);
+  if (ge && g->have_pos) memcpy(ge, g->c_ge, sizeof(int64_t) * (size_t)g->c_T);
+  return 0;
+}
+
+/* the corrected read set becomes the current one (the rebuilds of graph_utils.py:147-150,165);
+ * the per-read sequence lengths follow their reads */
+int tsw_adopt(tsw* g) {
+  if (!g->have_corr) return -3;
+  free_graph(g);
+  free(g->tokens); free(g->read_off); free(g->gs); free(g->ge);
+  if (g->read_len) {
+    int64_t* rl = (int64_t*)malloc(sizeof(int64_t) * (size_t)(g->c_reads + 1));
+    for (int64_t i = 0; i < g->c_reads; ++i) rl[i] = g->read_len[g->c_orig[i]];
+    free(g->read_len); g->read_len = rl;
+  }
+  g->tokens = g->c_tok; g->read_off = g->c_off; g->gs = g->c_gs; g->ge = g->c_ge;
+  g->n_reads = g->c_reads; g->T = g->c_T;
+  g->c_tok = NULL; g->c_off = NULL; g->c_gs = g->c_ge = NULL;
+  free(g->c_orig); free(g->c_changed); g->c_orig = NULL; g->c_changed = NULL;
+  g->have_corr = 0;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ read-back */
+/* out[0..9] = n_reads, n_tokens, n_windows, n_short, n_nodes, n_edges, n_components,
+ *             live nodes, live edges, reads to correct */
+void tsw_counts(const tsw* g, int64_t* out) {
+  int64_t ln = 0, le = 0, fix = 0;
+  for (int64_t n = 0; n < g->D; ++n) ln += g->node_alive[n];
+  for (int64_t e = 0; e < g->E; ++e) le += g->e_alive[e];
+  for (int64_t r = 0; r < g->n_reads; ++r) fix += g->read_fix ? g->read_fix[r] : 0;
+  out[0] = g->n_reads; out[1] = g->T; out[2] = g->n_windows; out[3] = g->n_short; out[4] = g->D;
+  out[5] = g->E; out[6] = g->n_comp; out[7] = ln; out[8] = le; out[9] = fix;
+}
+void tsw_nodes(const tsw* g, int32_t* tokens, uint32_t* cov, int8_t* first_dir, int32_t* comp, uint8_t* alive) {
+  if (tokens) memcpy(tokens, g->node_tok, sizeof(int32_t) * (size_t)g->D * g->k);
+  if (cov) memcpy(cov, g->node_cov, sizeof(uint32_t) * (size_t)g->D);
+  if (first_dir) memcpy(first_dir, g->node_fdir, (size_t)g->D);
+  if (comp) memcpy(comp, g->node_comp, sizeof(int32_t) * (size_t)g->D);
+  if (alive) memcpy(alive, g->node_alive, (size_t)g->D);
+}
+void tsw_edges(const tsw* g, int32_t* src, int32_t* tgt, int8_t* sd, int8_t* td, uint32_t* cov, uint8_t* alive) {
+  if (src) memcpy(src, g->e_src, sizeof(int32_t) * (size_t)g->E);
+  if (tgt) memcpy(tgt, g->e_tgt, sizeof(int32_t) * (size_t)g->E);
+  if (sd) memcpy(sd, g->e_sd, (size_t)g->E);
+  if (td) memcpy(td, g->e_td, (size_t)g->E);
+  if (cov) memcpy(cov, g->e_cov, sizeof(uint32_t) * (size_t)g->E);
+  if (alive) memcpy(alive, g->e_alive, (size_t)g->E);
+}
+void tsw_read_nodes(const tsw* g, int32_t* tok_node, int8_t* tok_dir, uint8_t* read_fix) {
+  if (tok_node) memcpy(tok_node, g->tok_node, sizeof(int32_t) * (size_t)g->T);
+  if (tok_dir) memcpy(tok_dir, g->tok_dir, (size_t)g->T);
+  if (read_fix) memcpy(read_fix, g->read_fix, (size_t)g->n_reads);
+}
+void tsw_adj(const tsw* g, int64_t* offsets, int32_t* edge_ids) {
+  if (offsets) memcpy(offsets, g->adj_off, sizeof(int64_t) * (size_t)(2 * g->D + 1));
+  if (edge_ids) memcpy(edge_ids, g->adj_edge, sizeof(int32_t) * (size_t)g->E);
+}

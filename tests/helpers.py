@@ -109,3 +109,39 @@ def compare_engine_to_oracle(eng, want, live_only=False):
     roff, ridx = eng.node_reads()
     got_reads = [r for n, r in enumerate(csr_lists(roff, ridx)) if nkeep[n]]
     assert got_reads == want["node_reads"]
+
+
+def compare_engine_to_sweep(eng, orc, what=""):
+    """Array-level equality of the engine's current state with the C sweep oracle
+    (tests/token_oracle.Sweep) — vectorised, for the full benchmark sizes.  Both sides keep removed
+    nodes / edges in place with alive = 0, so ids compare directly."""
+    ce, co = eng.counts(), orc.counts()
+    for key in ("n_reads", "n_tokens", "n_windows", "n_short_reads", "n_nodes", "n_edges", "n_components",
+                "n_live_nodes", "n_live_edges", "n_reads_to_correct"):
+        assert ce[key] == co[key], (what, key, ce[key], co[key])
+    ne, no = eng.nodes(), orc.nodes()
+    for key in ("tokens", "coverage", "first_dir", "component", "alive"):
+        assert np.array_equal(ne[key], no[key]), (what, "node", key)
+    ee, eo = eng.edges(), orc.edges()
+    for key in ("src", "tgt", "sdir", "tdir", "coverage", "alive"):
+        assert np.array_equal(ee[key], eo[key]), (what, "edge", key)
+    tn_e, td_e = eng.read_nodes()
+    tn_o, td_o = orc.read_nodes()
+    assert np.array_equal(tn_e, tn_o), (what, "tok_node")
+    assert np.array_equal(np.where(tn_e >= 0, td_e, 0), np.where(tn_o >= 0, td_o, 0)), (what, "tok_dir")
+    off_e, adj_e = eng.node_adj()
+    off_o, adj_o = orc.node_adj()
+    assert np.array_equal(off_e, off_o) and np.array_equal(adj_e, adj_o), (what, "adjacency")
+    assert np.array_equal(eng.reads_to_correct() != 0, orc.reads_to_correct() != 0), (what, "reads to correct")
+
+
+def compare_corrected(eng, orc, with_pos, what=""):
+    """correct_reads on both sides; corrected CSR, origin, changed flags and positions equal"""
+    nr_e, nt_e = eng.correct_reads()
+    nr_o, nt_o = orc.correct_reads()
+    assert (nr_e, nt_e) == (nr_o, nt_o), (what, nr_e, nt_e, nr_o, nt_o)
+    a, b = eng.corrected(nr_e, nt_e, with_pos), orc.corrected(nr_o, nt_o, with_pos)
+    keys = ["tokens", "read_offsets", "orig_read", "changed"] + (["gene_start", "gene_end"] if with_pos else [])
+    for key in keys:
+        assert np.array_equal(a[key], b[key]), (what, key)
+    return a

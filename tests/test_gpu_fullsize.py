@@ -90,3 +90,57 @@ def test_full_size_sweep_properties():
     assert np.array_equal(eng.nodes()["coverage"], want["coverage"])
     assert np.array_equal(eng.read_nodes()[0], want["tok_node"])
     eng.close()
+
+
+def _cfg3_inputs(N):
+    import bench
+    w = bench.WORKLOADS["cfg3-sweep"]
+    vocab, toks, offs = bench.make_tokens(w, 0, N)
+    L = w["L"]
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    return w, vocab, toks, offs, gs, gs + 899, np.full(N, L * 1000 + 100, np.int64)
+
+
+def test_full_size_sweep_equals_c_oracle():
+    """THE benchmarked workload, bit for bit: cfg3 sweep at 1 M reads x 60 genes (build ->
+    filter_graph(3,1) -> correct_reads -> build -> remove_short_linear_paths(5) -> correct_reads
+    -> build) against the sequential C restatement of the reference (oracle/token_sweep.c, pinned
+    to the Python oracle in tests/test_token_oracle.py): every graph array after every stage,
+    masked windows, reads to correct, corrected genes and positions, removed tips."""
+    from amira_amd import Engine
+    from helpers import compare_corrected, compare_engine_to_sweep
+    N = 1_000_000
+    w, vocab, toks, offs, gs, ge, rl = _cfg3_inputs(N)
+    k = w["k"]
+    eng = Engine(0)
+    orc = token_oracle.Sweep(toks, offs, vocab.two_v, gs, ge, rl)
+    try:
+        eng.set_reads(toks, offs, vocab.two_v)
+        eng.set_positions(gs, ge, rl)
+        eng.build(k)
+        orc.build(k)
+        compare_engine_to_sweep(eng, orc, "build 1")
+        eng.filter(3, 1)
+        orc.filter(3, 1)
+        compare_engine_to_sweep(eng, orc, "filter")
+        out = compare_corrected(eng, orc, True, "correct 1")
+        assert int(out["changed"].sum()) > N // 2          # most reads carry an error at 2 % x 60 genes
+        eng.adopt_corrected()
+        orc.adopt_corrected()
+        eng.build(k)
+        orc.build(k)
+        compare_engine_to_sweep(eng, orc, "build 2")
+        got = np.sort(eng.remove_short_linear_paths(k))
+        want = np.sort(orc.remove_short_linear_paths(k))
+        assert len(want) > 0 and np.array_equal(got, want)
+        compare_engine_to_sweep(eng, orc, "clip")
+        compare_corrected(eng, orc, True, "correct 2")
+        eng.adopt_corrected()
+        orc.adopt_corrected()
+        eng.build(k)
+        orc.build(k)
+        compare_engine_to_sweep(eng, orc, "build 3")
+        _invariants(eng, eng.counts(), w["L"], k)
+    finally:
+        eng.close()
+        orc.close()
