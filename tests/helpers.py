@@ -145,3 +145,28 @@ def compare_corrected(eng, orc, with_pos, what=""):
     for key in keys:
         assert np.array_equal(a[key], b[key]), (what, key)
     return a
+
+
+def live_arrays(obj, with_adj=True):
+    """The graph restricted to live nodes / edges, ids renumbered densely in id order (what the
+    reference's dicts hold after removals) — vectorised; obj = Engine or token_oracle.Sweep."""
+    n, e = obj.nodes(), obj.edges()
+    nk, ek = n["alive"] != 0, e["alive"] != 0
+    nmap, emap = np.cumsum(nk) - 1, np.cumsum(ek) - 1
+    tok_node, tok_dir = obj.read_nodes()
+    mapped = tok_node.copy()
+    m = tok_node >= 0
+    mapped[m] = nmap[tok_node[m]]
+    out = {"tokens": n["tokens"][nk], "coverage": n["coverage"][nk], "first_dir": n["first_dir"][nk],
+           "src": nmap[e["src"][ek]], "tgt": nmap[e["tgt"][ek]], "sdir": e["sdir"][ek], "tdir": e["tdir"][ek],
+           "ecov": e["coverage"][ek], "tok_node": mapped, "tok_dir": np.where(m, tok_dir, 0),
+           "to_correct": obj.reads_to_correct() != 0}
+    if with_adj:
+        off, adj = obj.node_adj()
+        keep = ek[adj]
+        csum = np.concatenate([[0], np.cumsum(keep)])
+        row_cnt = csum[off[1:]] - csum[off[:-1]]
+        rows = np.repeat(nk, 2)
+        out["adj_off"] = np.concatenate([[0], np.cumsum(row_cnt[rows])])
+        out["adj"] = emap[adj[keep]]
+    return out

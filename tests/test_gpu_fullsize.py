@@ -144,3 +144,105 @@ def test_full_size_sweep_equals_c_oracle():
     finally:
         eng.close()
         orc.close()
+
+
+def test_cfg5_emulated_8_ranks_equal_c_oracle():
+    """BASELINE config 5 as far as one GPU can take it: the 8 M-read stream cut into 8 shards of
+    1 M reads, one Engine per emulated rank on this GPU, every build merged by key owner through the
+    loop-back exchange (the device phases bench.py --gpus 8 runs; only the wire is missing), the
+    first one with filter_graph(3,1) fused in — against the sequential C restatement of the
+    reference run on the WHOLE 8 M-read stream.  Every rank must hold the single-graph result."""
+    import bench
+    from amira_amd import Engine
+    from amira_amd.dist import dist_build_loopback
+    from helpers import compare_engine_to_sweep, live_arrays
+    world, N = 8, 1_000_000
+    w = bench.WORKLOADS["cfg3-sweep"]          # bench.py: rank r holds reads [r N, (r + 1) N) of this stream
+    L, k = w["L"], w["k"]
+    vocab, toks, offs = bench.make_tokens(w, 0, world * N)
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, world * N)
+    ge = gs + 899
+    rl = np.full(world * N, L * 1000 + 100, np.int64)
+    orc = token_oracle.Sweep(toks, offs, vocab.two_v, gs, ge, rl)
+    engines = []
+    try:
+        for r in range(world):
+            lo, hi = r * N, (r + 1) * N
+            e = Engine(0)
+            e.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
+            e.set_positions(gs[offs[lo]:offs[hi]], ge[offs[lo]:offs[hi]], rl[lo:hi])
+            engines.append(e)
+        del gs, ge
+
+        # ---- build 1, merged, filter_graph(3, 1) fused in == build + filter on the whole stream
+        dist_build_loopback(engines, k, 3, 1)
+        orc.build(k)
+        orc.filter(3, 1)
+        want = live_arrays(orc)
+        tok_lo = 0
+        for r, e in enumerate(engines):
+            got = live_arrays(e, with_adj=(r in (0, world - 1)))
+            n_tok = len(got["tok_node"])
+            for key in ("tokens", "coverage", "first_dir", "src", "tgt", "sdir", "tdir", "ecov"):
+                assert np.array_equal(got[key], want[key]), (r, key)
+            if "adj" in got:
+                assert np.array_equal(got["adj_off"], want["adj_off"]) and np.array_equal(got["adj"], want["adj"]), r
+            assert np.array_equal(got["tok_node"], want["tok_node"][tok_lo:tok_lo + n_tok]), r
+            assert np.array_equal(got["tok_dir"], want["tok_dir"][tok_lo:tok_lo + n_tok]), r
+            assert np.array_equal(got["to_correct"], want["to_correct"][r * N:(r + 1) * N]), r
+            assert e.counts()["n_nodes"] == len(want["coverage"])       # only survivors were replicated
+            tok_lo += n_tok
+        del want
+
+        def correct_all(stage):
+            """correct_reads on every rank; the ranks' corrected reads, concatenated, equal the oracle's"""
+            nr, nt = orc.correct_reads()
+            ref = orc.corrected(nr, nt, True)
+            outs = [e.corrected(*e.correct_reads(), True) for e in engines]
+            for key in ("tokens", "gene_start", "gene_end", "changed"):
+                assert np.array_equal(np.concatenate([o[key] for o in outs]), ref[key]), (stage, key)
+            assert np.array_equal(np.concatenate([np.diff(o["read_offsets"]) for o in outs]), np.diff(ref["read_offsets"]))
+            base = np.cumsum([0] + [e.sizes()[0] for e in engines])
+            assert np.array_equal(np.concatenate([o["orig_read"] + base[r] for r, o in enumerate(outs)]), ref["orig_read"])
+            for e in engines:
+                e.adopt_corrected()
+            orc.adopt_corrected()
+
+        def merged_build_equals(stage):
+            dist_build_loopback(engines, k)
+            orc.build(k)
+            tn_o, td_o = orc.read_nodes()
+            tok_lo = 0
+            for r, e in enumerate(engines):
+                n_tok = e.sizes()[1]
+                if r in (0, world - 1):
+                    # the whole replicated graph: compare through a view of the oracle cut to this shard
+                    ne, no = e.nodes(), orc.nodes()
+                    for key in ("tokens", "coverage", "first_dir", "component", "alive"):
+                        assert np.array_equal(ne[key], no[key]), (stage, r, key)
+                    ee, eo = e.edges(), orc.edges()
+                    for key in ("src", "tgt", "sdir", "tdir", "coverage", "alive"):
+                        assert np.array_equal(ee[key], eo[key]), (stage, r, key)
+                    a, b = e.node_adj(), orc.node_adj()
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (stage, r)
+                c, co = e.counts(), orc.counts()
+                for key in ("n_nodes", "n_edges", "n_components"):
+                    assert c[key] == co[key], (stage, r, key)
+                tn, td = e.read_nodes()
+                assert np.array_equal(tn, tn_o[tok_lo:tok_lo + n_tok]), (stage, r)
+                assert np.array_equal(td, td_o[tok_lo:tok_lo + n_tok]), (stage, r)
+                tok_lo += n_tok
+            assert tok_lo == len(tn_o)
+
+        correct_all("correct 1")
+        merged_build_equals("build 2")
+        want_removed = np.sort(orc.remove_short_linear_paths(k))
+        assert len(want_removed) > 0
+        for e in engines:
+            assert np.array_equal(np.sort(e.remove_short_linear_paths(k)), want_removed)
+        correct_all("correct 2")
+        merged_build_equals("build 3")
+    finally:
+        for e in engines:
+            e.close()
+        orc.close()
