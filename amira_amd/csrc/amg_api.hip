@@ -154,6 +154,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
   c->have_pos = c->have_read_len = false;
   c->built = false;
   c->have_corrected = false;
+  c->match_valid = false;
   c->node_hint = 0;
   return AMG_OK;
 }

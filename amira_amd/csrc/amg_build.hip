@@ -33,7 +33,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_node_upsert(
   __shared__ int s_tok[TILE + AMG_MAX_K];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   const long long t0 = (long long)blockIdx.x * TILE;
-  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
+  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits, two_v, status);
   const int flip = two_v - 1;
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
@@ -535,7 +535,7 @@ int bs_read_stats(amg_ctx* c, int k) {
   HIPCHK(hipMemsetAsync(c->bnd_bits.p, 0, words * sizeof(unsigned int), st));
   if (R > 0)
     hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
-                       c->read_off.as<long long>(), R, k, c->status.as<unsigned long long>(),
+                       c->read_off.as<long long>(), R, T, k, c->status.as<unsigned long long>(),
                        c->bnd_bits.as<unsigned int>());
   stage_end(c);
   return AMG_OK;
@@ -585,6 +585,9 @@ int bs_nodes_pass(amg_ctx* c, int k, int* which) {
                      c->status.as<unsigned long long>() + ST_COMPACT_A);
   AMGCHK(read_status(c, hs));
   stage_end(c);
+  if (hs[ST_BADINPUT])
+    return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
+                                                    : "a token lies outside [0, two_v)");
   if (hs[ST_PALINDROME])
     return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
   if (hs[ST_OVERFLOW]) {
@@ -842,6 +845,7 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   stages_reset(c);
   c->built = false;
   c->have_corrected = false;
+  c->match_valid = false;
   c->k = k;
   c->retries = 0;
   c->tok_base = 0;
@@ -882,7 +886,7 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
     ++c->retries;
     if (which == 1) {
       if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
-      c->node_slots *= 4;
+      c->node_slots = c->node_slots * 4 > (1ll << 30) ? (1ll << 30) : c->node_slots * 4;
     } else if (which == 2) {
       c->edge_slots *= 4;
     } else {

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
   __shared__ unsigned int s_wave[TILE_THREADS / 64];
   __shared__ unsigned long long s_base;
   const long long t0 = (long long)blockIdx.x * TILE;
-  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits);
+  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits, two_v, status);
   const int flip = two_v - 1;
   unsigned long long w1[TILE_ITEMS];
   unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], id1[TILE_ITEMS], lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
@@ -642,6 +642,9 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
+  if (hs[ST_BADINPUT])
+    return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
+                                                    : "a token lies outside [0, two_v)");
   if (hs[ST_PALINDROME])
     return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "node pass: a claim id was never published");

@@ -238,7 +238,8 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
     ++c->retries;
-    c->node_slots *= 4;
+    if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
+    c->node_slots = c->node_slots * 4 > (1ll << 30) ? (1ll << 30) : c->node_slots * 4;
   }
   const long long n = c->n_local_nodes, T = c->n_tokens;
   // local occurrence counts per claim, straight from the per-window claims
@@ -293,12 +294,16 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   stages_reset(c);
   c->built = false;
   c->have_corrected = false;
+  c->match_valid = false;
   c->k = k;
   c->retries = 0;
   c->tok_base = token_base;
   c->tok_total = token_total;
   c->world = world;
   c->dist_mode = true;
+  // merge keys and key owners are fingerprints of this seed: every rank must use the SAME one,
+  // whatever collision retries an earlier single-GPU build on this ctx went through
+  c->seed = kAmgSeed0;
   c->count_inline = false;  // local occurrence counts come from bs_count_by_slot, not per-window atomics
   bs_size_tables(c);
   c->exact_keys = false;
@@ -310,7 +315,8 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
     ++c->retries;
-    c->node_slots *= 4;
+    if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
+    c->node_slots = c->node_slots * 4 > (1ll << 30) ? (1ll << 30) : c->node_slots * 4;
   }
   // compaction list lives in s1 (first) / s3 (slot); destination order -> dist_order
   const long long n = c->n_local_nodes;

@@ -119,6 +119,7 @@ enum {
   ST_COMPACT_A = 7,      // scratch counters for compaction kernels
   ST_COMPACT_B = 8,
   ST_MISC = 9,
+  ST_BADINPUT = 10,      // malformed CSR: 1 = read offsets, 2 = a token outside [0, two_v)
   ST_WORDS = 16
 };
 
@@ -127,6 +128,8 @@ struct StageTime {
   hipEvent_t a, b;
   float ms;
 };
+
+static const uint64_t kAmgSeed0 = 0x9E3779B97F4A7C15ull;  // initial fingerprint seed (amg_build re-seeds on a collision)
 
 struct amg_ctx {
   int device = 0;
@@ -145,7 +148,7 @@ struct amg_ctx {
   // ---- build products
   bool built = false;
   int32_t k = 0;
-  uint64_t seed = 0x9E3779B97F4A7C15ull;
+  uint64_t seed = kAmgSeed0;
   int64_t n_windows = 0, n_short = 0;
   int64_t n_nodes = 0, n_pairs = 0, n_edges = 0, n_components = 0;
   int64_t node_slots = 0, edge_slots = 0, retries = 0;

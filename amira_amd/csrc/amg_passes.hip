@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_mask_reads(int* __restrict__ tok_node,
 static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
   hipStream_t st = c->stream;
   c->ladj_valid = false;
+  c->match_valid = false;  // node-id patterns of a cached K6 result may name removed nodes
   if (c->n_edges > 0)
     hipLaunchKernelGGL(k_filter_edges, dim3(nblk(c->n_edges, 256)), dim3(256), 0, st,
                        c->edge_src.as<int>(), c->edge_tgt.as<int>(), c->edge_cov.as<unsigned int>(),
@@ -1939,6 +1940,7 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   c->n_tokens = c->c_tokens;
   c->have_corrected = false;
   c->built = false;
+  c->match_valid = false;
   return AMG_OK;
 }
 

@@ -10,19 +10,27 @@
 
 // per-read window / short-read counts (construct_graph.py:53-55) and the read-end bitmap:
 // bit t of bnd_bits is set when a read ends (exclusively) at token t
-static __global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, int k,
-                                    unsigned long long* status, unsigned int* __restrict__ bnd_bits) {
+static __global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, long long n_tokens,
+                                    int k, unsigned long long* status, unsigned int* __restrict__ bnd_bits) {
   __shared__ unsigned long long s_w[4], s_s[4];
   long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long w = 0, sh = 0;
   if (r < n_reads) {
-    const long long end = read_off[r + 1];
-    long long len = end - read_off[r];
-    if (len >= k)
-      w = (unsigned long long)(len - k + 1);
-    else
-      sh = 1;
-    atomicOr(&bnd_bits[end >> 5], 1u << (end & 31));
+    const long long beg = read_off[r], end = read_off[r + 1];
+    // the CSR may be caller-owned device memory nobody has looked at yet: offsets must start at 0,
+    // never decrease and end at the token count before anything is indexed with them
+    const bool bad = beg < 0 || end < beg || end > n_tokens || (r == 0 && beg != 0) ||
+                     (r == n_reads - 1 && end != n_tokens);
+    if (bad) {
+      status[ST_BADINPUT] = 1;  // benign race: every writer stores 1
+    } else {
+      const long long len = end - beg;
+      if (len >= k)
+        w = (unsigned long long)(len - k + 1);
+      else
+        sh = 1;
+      atomicOr(&bnd_bits[end >> 5], 1u << (end & 31));
+    }
   }
   for (int d = 32; d > 0; d >>= 1) {
     w += __shfl_down(w, d, 64);
@@ -59,13 +67,19 @@ struct LdsView {
 __device__ __forceinline__ void stage_tile(const int* __restrict__ tokens,
                                            const unsigned int* __restrict__ bnd_bits,
                                            long long n_tokens, int k, long long t0, int* s_tok,
-                                           unsigned int* s_bits) {
+                                           unsigned int* s_bits, int two_v, unsigned long long* status) {
   const int tid = threadIdx.x;
   const int span = TILE + k;  // tokens t0 .. t0 + TILE + k - 1
+  bool bad = false;
   for (int i = tid; i < span; i += TILE_THREADS) {
     long long t = t0 + i;
-    s_tok[i] = t < n_tokens ? tokens[t] : 0;
+    const int v = t < n_tokens ? tokens[t] : 0;
+    // a token outside [0, two_v) would alias another tuple in the packed key (and index the
+    // vocabulary out of range on the way back): refuse the build
+    bad = bad || (unsigned int)v >= (unsigned int)two_v;
+    s_tok[i] = v;
   }
+  if (bad) status[ST_BADINPUT] = 2;
   if (tid < TILE_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
   __syncthreads();
 }

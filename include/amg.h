@@ -92,7 +92,13 @@ void* amg_stream(amg_ctx* ctx);
  *      GeneMerGraph.__init__ (construct_graph.py:31) ------------------------------- */
 /* on_device: 0 = host pointers (copied H2D); 1 = device pointers on ctx's device (copied D2D);
  * 2 = device pointers BORROWED without a copy: the caller keeps the memory alive and unchanged
- * until the next amg_set_* call for that array or amg_adopt_corrected; it is never written. */
+ * until the next amg_set_* call for that array or amg_adopt_corrected; it is never written.
+ * Stream contract for on_device != 0: the library reads the arrays on ITS OWN stream (amg_stream),
+ * which is not ordered against the stream that produced them — the caller synchronises its
+ * producer stream (or device) before the call.
+ * Validation: host inputs are checked here; device inputs are checked by the first kernel of
+ * amg_build (read_offsets[0] == 0, non-decreasing, read_offsets[n_reads] == number of tokens;
+ * 0 <= token < two_v), which then fails with AMG_E_ARG before anything is indexed with them. */
 int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offsets,
                   int64_t n_reads, int32_t two_v, int on_device);
 /* optional: per-gene [start,end] and per-read sequence length, used only by

@@ -42,3 +42,47 @@ def test_fingerprint_collisions_are_detected_and_rebuilt(monkeypatch):
     assert eng.counts()["build_retries"] >= 1
     compare_engine_to_oracle(eng, oracle_arrays(GeneMerGraph(reads, 5), vocab, read_ids, offs, 5))
     eng.close()
+
+
+@pytest.mark.parametrize("key_mode", ["exact", "fp"])
+@pytest.mark.parametrize("damage", ["first_offset", "decreasing", "last_offset", "token_high", "token_negative"])
+def test_malformed_device_csr_is_refused(monkeypatch, key_mode, damage):
+    """device-resident (copied or borrowed) inputs cannot be validated on the host: the first
+    kernel of the build checks the offsets and the token range and the build fails with
+    AMG_E_ARG instead of indexing out of bounds or aliasing tuples"""
+    import torch
+    import procedures as P
+    from amira_amd import Engine, tokenize, _ffi
+    if key_mode == "fp":
+        monkeypatch.setenv("AMG_KEY_MODE", "fp")
+    reads, _, _ = P.synth_inputs(7, 200, 20, 100, 0.02)
+    vocab, toks, offs, _ = tokenize(reads)
+    toks, offs = toks.copy(), offs.copy()
+    n_reads = len(offs) - 1
+    if damage == "first_offset":
+        offs[0] = 3
+    elif damage == "decreasing":
+        offs[50] = offs[49] - 2
+    elif damage == "last_offset":
+        offs = np.concatenate([offs, [offs[-1] - 5]])  # one more read whose end lies before its start
+        n_reads += 1
+    elif damage == "token_high":
+        toks[1234] = vocab.two_v + 7
+    else:
+        toks[77] = -3
+    d_t, d_o = torch.from_numpy(toks).cuda(), torch.from_numpy(offs).cuda()
+    torch.cuda.synchronize()
+    eng = Engine(0)
+    try:
+        for borrow in (False, True):
+            eng.set_reads_device(d_t.data_ptr(), d_o.data_ptr(), n_reads, vocab.two_v, borrow=borrow)
+            with pytest.raises(_ffi.AmgError) as ei:
+                eng.build(5)
+            assert ei.value.code == -2
+        # the ctx is still usable afterwards
+        vocab2, t2, o2, _ = tokenize(reads)
+        eng.set_reads(t2, o2, vocab2.two_v)
+        eng.build(5)
+        assert eng.counts()["n_nodes"] > 0
+    finally:
+        eng.close()
