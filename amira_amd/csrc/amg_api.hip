@@ -144,6 +144,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
         return amg_fail(AMG_E_ARG, "read_offsets not monotone at read %lld", (long long)r);
     n_tokens = read_offsets[n_reads];
   }
+  if (n_tokens < 0) return amg_fail(AMG_E_ARG, "read_offsets[n_reads] is negative");
   if (n_tokens > 0 && !tokens) return amg_fail(AMG_E_ARG, "null tokens");
   AMGCHK(copy_in(c, c->tokens, tokens, (size_t)n_tokens * sizeof(int32_t), on_device));
   AMGCHK(copy_in(c, c->read_off, read_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), on_device));

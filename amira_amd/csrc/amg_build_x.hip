@@ -27,235 +27,6 @@
 #include "amg_tile.h"
 #include "amg_x.h"
 
-// canonical tuple -> (w1, tag): token j occupies bits [j*bits, (j+1)*bits) of a 94-bit value,
-// w1 = (low 63 bits << 1) | 1, tag = (high 31 bits << 1) | 1 — both non-zero by construction
-template <class View>
-__device__ __forceinline__ void x_pack(const View& w, int k, int flip, int dir, int bits,
-                                       unsigned long long& w1, unsigned int& tag) {
-  unsigned long long lo = 0, hi = 0;
-  int sh = 0;
-  for (int j = 0; j < k; ++j, sh += bits) {
-    const unsigned long long c = (unsigned long long)(unsigned int)canon_tok(w, k, flip, dir, j);
-    if (sh < 63) {
-      lo |= c << sh;
-      if (sh + bits > 63) hi |= c >> (63 - sh);
-    } else {
-      hi |= c << (sh - 63);
-    }
-  }
-  w1 = (lo << 1) | 1ull;  // bit 63 of lo (it belongs to hi) falls off here
-  tag = ((unsigned int)hi << 1) | 1u;
-}
-
-// Compile-time k: direction, canonical tuple and packing as straight-line code (no early-exit
-// loop, no per-token branches).  Returns the direction (0: palindrome).
-template <int K, bool TWO>
-__device__ __forceinline__ int x_canon_pack(const int* w, int flip, int bits, unsigned long long& w1,
-                                            unsigned int& tag) {
-  int a[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = w[j];
-  int dir = 0;  // the first differing position decides: walk from the last to the first
-#pragma unroll
-  for (int j = K - 1; j >= 0; --j) {
-    const int d = a[j] - (flip - a[K - 1 - j]);
-    dir = d != 0 ? (d < 0 ? 1 : -1) : dir;
-  }
-  if (TWO) {
-    unsigned __int128 v = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const unsigned int c = (unsigned int)(dir > 0 ? a[j] : flip - a[K - 1 - j]);
-      v |= (unsigned __int128)c << (j * bits);
-    }
-    w1 = ((unsigned long long)v << 1) | 1ull;
-    tag = ((unsigned int)(unsigned long long)(v >> 63) << 1) | 1u;
-  } else {
-    unsigned long long v = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const unsigned int c = (unsigned int)(dir > 0 ? a[j] : flip - a[K - 1 - j]);
-      v |= (unsigned long long)c << (j * bits);
-    }
-    w1 = (v << 1) | 1ull;
-    tag = 1u;
-  }
-  return dir;
-}
-
-// Find or create the slot of key (w1, tag) starting at `idx`; `v` is the content of that first
-// slot as a PLAIN load returned it.
-//
-// Plain loads are served by the issuing XCD's L2 and may be stale, but a slot only ever moves
-// empty -> w1 -> tag -> id, each step once: a cached view that already shows a complete foreign
-// key, or our key with its id, is final and is trusted (no fabric transaction: agent-scope
-// loads cost one 64-byte fabric request each, ~100 G/s, atomics ~27 G/s, L2 hits ~255 G/s).
-// Anything less (empty, tag or id missing) is settled by the CAS itself or by an agent-scope
-// re-read of w2.  (Serving the first tiles from a separate launch with agent-scope loads only,
-// so that no L2 caches a hot slot before it is complete, was measured and bought nothing.)
-// A CAS on w1 takes the slot.  TWO: the key has a second word (tag), set by a second CAS by
-// whichever thread needs it first; that thread owns the slot ("created").
-// Returns the slot or -1; w2v = the slot's second word as seen (low 32 bits zero: the claim id
-// is not published yet).
-template <bool TWO>
-__device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
-                                              unsigned long long w1, unsigned int tag,
-                                              unsigned int idx, ulonglong2 v,
-                                              unsigned int limit, const unsigned long long* abort_flag,
-                                              unsigned long long& w2v, bool& created) {
-  created = false;
-  w2v = 0;
-  unsigned int probes = 0;
-  while (true) {
-    Slot16* s = tab + idx;
-    unsigned long long c1 = v.x, c2 = v.y;
-    const bool mine = c1 == w1 && (!TWO || (unsigned int)(c2 >> 32) == tag);
-    if (mine && (unsigned int)c2 != 0u) {
-      w2v = c2;
-      return (int)idx;
-    }
-    // The cached view does not decide.  No step below waits for another thread (lanes of one
-    // wave must never wait for each other inside a loop).
-    if (c1 == 0ull) {
-      // looks empty: try to take it — the CAS returns the truth, no coherent re-read needed
-      c1 = atomicCAS(&s->w1, 0ull, w1);
-      if (c1 == 0ull) {
-        if (!TWO) {
-          created = true;
-          return (int)idx;
-        }
-        c1 = w1;
-        c2 = 0ull;
-      } else if (c1 == w1) {
-        c2 = ld_u64(&s->w2);  // somebody holds our w1: tag / id with agent scope
-      }
-    } else if (c1 == w1 && (mine || (TWO && (c2 >> 32) == 0ull))) {
-      c2 = ld_u64(&s->w2);  // tag or id missing in the cached view
-    }
-    if (c1 == w1) {
-      if (TWO) {
-        // the slot belongs to whoever sets the tag (a thread that claimed w1 but lost w2 to a
-        // different tag moves on, as does every later thread of its key at this slot)
-        if ((c2 >> 32) == 0ull) {
-          const unsigned long long old = atomicCAS(&s->w2, 0ull, (unsigned long long)tag << 32);
-          if (old == 0ull) {
-            created = true;
-            return (int)idx;
-          }
-          c2 = old;
-        }
-        if ((unsigned int)(c2 >> 32) == tag) {
-          w2v = c2;  // low word 0: the id is still on its way (x_claim waits for it)
-          return (int)idx;
-        }
-      } else {
-        w2v = c2;
-        return (int)idx;
-      }
-    }
-    if (probes >= limit) return -1;
-    if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
-      return -1;
-    ++probes;
-    idx = (idx + 1) & mask;
-    v = *reinterpret_cast<const ulonglong2*>(tab + idx);
-  }
-}
-
-// Second word of a slot.  TWO (the key spills into it): [63:32] tag, [31:ib] COARSE token position
-// of the creating window (token index >> cshift), [ib-1:0] claim id + 1.  One-word keys: [63:32]
-// the creator's exact first-seen (complemented), [31:0] claim id + 1.  Either way the probe load
-// already tells almost every window that it comes after the creator and cannot be the first
-// occurrence: the first-seen words of the claim are then not even read (one random access per
-// window less; the table passes are bound by the L2 request rate).
-struct XW2 {
-  int ib;       // bits of the id field (TWO)
-  int cshift;   // coarse position = token index >> cshift (TWO)
-};
-template <bool TWO>
-__device__ __forceinline__ unsigned int xw2_id1(unsigned long long w2v, const XW2& f) {
-  return TWO ? ((unsigned int)w2v & ((1u << f.ib) - 1u)) : (unsigned int)w2v;
-}
-
-// Claim ids for the slots this block created + first-seen bookkeeping.  slot[it] < 0: nothing.
-// In: lw[it] / hw[it] = low / high half of the second slot word as seen by the probe (the high half
-// only matters for one-word keys).  Out: id1[it] = claim id + 1 of every
-// item with a slot.  Window `it` of the thread starts at token tbase + it * TILE_THREADS; its
-// first-seen value is (token << FSH) | low bits (lowbits: FSH bits per item, packed), kept
-// complemented.  (Positions and first-seen values are recomputed instead of kept in arrays: the
-// table kernels run 8 waves per SIMD on 64 registers.)
-template <bool TWO, int FSH>
-__device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEMS],
-                                        const unsigned int (&lw)[TILE_ITEMS],
-                                        const unsigned int (&hw)[TWO ? 1 : TILE_ITEMS],
-                                        unsigned int (&id1)[TILE_ITEMS], unsigned int created,
-                                        const unsigned int (&tag)[TILE_ITEMS], unsigned int tbase,
-                                        unsigned int lowbits, const XW2 f, unsigned int* first2,
-                                        unsigned int* __restrict__ slot_by_claim,
-                                        unsigned long long* counter, unsigned long long* stuck,
-                                        unsigned int* s_wave, unsigned long long* s_base,
-                                        bool skip_first) {
-  auto tpos = [&](int it) { return tbase + (unsigned int)it * TILE_THREADS; };
-  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
-  unsigned int total;
-  const unsigned int off = block_exscan<TILE_THREADS / 64>((unsigned int)__popc(created), &total, s_wave);
-  if (threadIdx.x == 0) *s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
-  __syncthreads();
-  unsigned int claim = (unsigned int)(*s_base) + off;
-  if (created) {
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it)
-      if (created & (1u << it)) {
-        // the creator's first-seen goes to its own word with a plain store; everybody else
-        // raises the claim's other word with atomicMax (both zero-initialised; first-seen = the larger
-        // of the two), so nothing has to be ordered against the publication of the id (a
-        // release fence here writes back the L2: measured 7x slower) and a creation costs no
-        // read-modify-write beyond the CAS that took the slot
-        first2[2u * claim + 1u] = fi(it);
-        slot_by_claim[claim] = (unsigned int)slot[it];
-        id1[it] = claim + 1u;
-        const unsigned long long pub =
-            TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
-                      (unsigned long long)(claim + 1u)
-                : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
-        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++claim;
-      }
-  }
-  // found keys: wait for an id that is still on its way (its creator's block publishes without
-  // waiting for anybody), then keep the minimum first-seen
-  unsigned int check = 0;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (slot[it] < 0 || (created & (1u << it))) continue;
-    unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
-    for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
-      w = ld_u64(&tab[slot[it]].w2);
-      if ((unsigned int)w != 0u) break;
-      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
-        *stuck = 1ull;
-        w = 1ull;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    id1[it] = xw2_id1<TWO>(w, f);
-    // can this window precede the creator's?  (coarse positions: same or earlier bucket)
-    const bool maybe_first = TWO ? (tpos(it) >> f.cshift) <= (((unsigned int)w) >> f.ib)
-                                 : fi(it) > (unsigned int)(w >> 32);
-    if (maybe_first) check |= 1u << it;
-  }
-  if (skip_first) return;  // timing experiment only
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (!(check & (1u << it))) continue;
-    // plain (possibly stale, at worst zero) reads: both words only grow, so a stale value can
-    // only cause a superfluous atomicMax, never a missed one
-    const unsigned int c = id1[it] - 1u;
-    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
-  }
-}
-
 // ------------------------------------------------------------------ nodes
 template <bool TWO, int K>  // K > 0: k known at compile time (the common odd sizes), 0: any k
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
