@@ -57,6 +57,7 @@ def _load():
         "amg_build": (C.c_int, [P, I32]),
         "amg_counts": (C.c_int, [P, C.POINTER(Counts)]),
         "amg_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
+        "amg_graph_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
         "amg_get_nodes": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_get_edges": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_get_read_nodes": (C.c_int, [P, P, P]),

@@ -218,6 +218,15 @@ extern "C" int amg_sizes(amg_ctx* c, int64_t* n_reads, int64_t* n_tokens) {
   return AMG_OK;
 }
 
+extern "C" int amg_graph_sizes(amg_ctx* c, int64_t* n_nodes, int64_t* n_edges, int32_t* k) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!c->built) return amg_fail(AMG_E_STATE, "amg_build first");
+  if (n_nodes) *n_nodes = c->n_nodes;
+  if (n_edges) *n_edges = c->n_edges;
+  if (k) *k = c->k;
+  return AMG_OK;
+}
+
 extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
   if (!c || !o) return amg_fail(AMG_E_ARG, "null argument");
   memset(o, 0, sizeof(*o));

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
                                                     const Slot* __restrict__ tab, long long lo,
                                                     int sweep, int last, unsigned long long* state,
                                                     unsigned long long* hint, unsigned int* __restrict__ out,
-                                                    int strip) {
+                                                    int strip, const int* __restrict__ remap) {
   __shared__ unsigned int s_cnt[HOT_IDS];
   bool tail_all = last != 0;
   if (sweep > 0) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   auto tally = [&](int id, long long t) {
     if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);  // claims with the last-window flag
     if (GATHER) {
-      id = id < 0 ? -1 : tab[id].id;
+      id = id < 0 ? -1 : (remap ? remap[id] : tab[id].id);
       ids[t] = id;
     }
     if (id < 0) return;
@@ -436,8 +436,12 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
 
 // counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes,
 // 2 node claims as the table pass wrote them (id | AMG_LAST_FLAG on the last window of a read)
+int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out) {
+  return count_ids(c, claims, n, nullptr, n_ids, out, 2, remap);
+}
+
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
-              unsigned int* out, int kind) {
+              unsigned int* out, int kind, const int* remap) {
   hipStream_t st = c->stream;
   HIPCHK(hipMemsetAsync(out, 0, (size_t)(n_ids + 1) * sizeof(unsigned int), st));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
@@ -458,12 +462,12 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   for (long long r = 0; r < ranges; ++r) {
     const long long lo = r * HOT_IDS;
     const int last = (r == ranges - 1) ? 1 : 0;
-    if (gather_tab && r == 0)
+    if ((gather_tab || remap) && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, strip);
+                         (int)r, last, state, hint, out, strip, remap);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, strip);
+                         (int)r, last, state, hint, out, remap ? 0 : strip, remap);
   }
   return AMG_OK;
 }
@@ -867,7 +871,11 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;
     int r;
-    if (exact) {
+    if (exact && bf_applicable(c, k)) {  // one fused table pass (amg_build_f.hip)
+      r = bf_tables(c, k, &which);
+      if (r == AMG_OK) r = bx_nodes_rank(c);
+      if (r == AMG_OK) r = bf_finish(c);
+    } else if (exact) {
       r = bx_nodes(c, k, &which);
       if (r == AMG_OK) r = bx_edges(c, &which);
     } else {

@@ -1,0 +1,398 @@
+// amg_build_f.hip — the single-GPU build's table pass, FUSED: one kernel takes every window of a
+// tile through the node table AND every adjacency through the edge-class table
+// (GeneMerGraph.__init__, reference construct_graph.py:31-102: Read.get_geneMers
+// construct_read.py:37-59, define_geneMer construct_gene_mer.py:42-56, add_node :196-212,
+// add_edge :300-324 with the edge classes of construct_edge.py:104-124).
+//
+// What changed against the two passes of amg_build_x.hip (which stay for the multi-GPU shards):
+//   * edge classes are keyed by CLAIM ids of their two nodes, not by final node ids.  A claim id is
+//     stable from the moment it is published, so the adjacency of windows t and t + 1 can be
+//     inserted right after their nodes, while both still sit in registers / LDS: no second pass
+//     over the tokens that re-reads (claim, direction), gathers claim -> node id and writes node
+//     ids per window.  The (lo, hi) order of a class and its "first event ran lo -> hi" bit are
+//     re-expressed in final node ids where the classes are ranked (E-sized, k_x_gather_pairs*).
+//     Per-window node ids are produced by the coverage count's first sweep, which reads the
+//     claims anyway (count_ids with a remap).
+//   * a thread takes FOUR CONSECUTIVE windows: its 4 + k - 1 tokens come out of LDS with 128-bit
+//     reads, canonical orientation is decided from the pair sums x[j] + x[k-1-j] (the window is
+//     below its reverse complement at the first j where the sum is below 2V - 1 — both orders
+//     compare the same two sums), the packed tuple of the common 16-bit case is assembled from
+//     shared half-words, three of the four adjacencies never leave the thread, and the results
+//     leave as one 16-byte store per array.  The two-pass kernels spent ~270 vector + ~240 scalar
+//     instructions per window on this front end, more than on the table probe.
+//   * tiles advance by 1020 windows and compute 1024: the last four belong to the next tile and
+//     only the first of them is used (as the right-hand neighbour of window 1019); its insert is
+//     the same find-or-create the owning tile performs, so whichever comes first creates the slot.
+#include "amg_tile.h"
+#include "amg_x.h"
+
+#define F_STRIDE 1020  // windows a tile owns (threads 0..254 x 4)
+#define F_SPAN 1024    // windows a tile computes
+#define F_BIT_WORDS ((31 + F_SPAN + AMG_MAX_K + 2 + 31) / 32 + 1)
+#define F_DIRBIT 0x40000000u  // in the LDS exchange word: the window's direction is -1
+
+static_assert(F_BIT_WORDS <= BND_PAD_WORDS, "read-end bitmap padding too small for the fused tiles");
+
+// Canonical orientation + packed key of the window a[0..K-1] for 16-bit tokens (two_v <= 65536),
+// K odd.  p[j] = a[j] | a[j+1] << 16, q[j] = (F | F << 16) - (a[j+1] | a[j] << 16): the same
+// half-words serve every window of the thread.  Encoding == x_pack with bits = 16.
+template <int K, bool TWO>
+__device__ __forceinline__ int f_canon_pack16(const int* a, const unsigned int* p, const unsigned int* q, int flip,
+                                              unsigned long long& w1, unsigned int& tag) {
+  int dir = (2 * a[K / 2] < flip) ? 1 : -1;  // 2 x != 2V - 1: an odd k has no palindromes
+#pragma unroll
+  for (int j = K / 2 - 1; j >= 0; --j) {
+    const int s = a[j] + a[K - 1 - j];
+    dir = s != flip ? (s < flip ? 1 : -1) : dir;
+  }
+  unsigned int word[K / 2 + 1];
+#pragma unroll
+  for (int m = 0; m < K / 2; ++m) word[m] = dir > 0 ? p[2 * m] : q[K - 2 - 2 * m];
+  word[K / 2] = (unsigned int)(dir > 0 ? a[K - 1] : flip - a[0]);
+  const unsigned long long v = (unsigned long long)word[0] | ((unsigned long long)word[1] << 32);
+  w1 = (v << 1) | 1ull;
+  if constexpr (K == 3)
+    tag = 1u;
+  else  // K == 5
+    tag = (((word[1] >> 31) | (word[K / 2] << 1)) << 1) | 1u;
+  return dir;
+}
+
+template <int K, bool TWO, bool B16>  // K > 0: k known at compile time; B16: 16 bits per token (K = 3 or 5)
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
+    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
+    int bits, Slot16* ntab, unsigned int nmask, Slot16* etab, unsigned int emask, unsigned int probe_limit,
+    int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, int* __restrict__ tok_pair,
+    unsigned long long* status, unsigned int* nfirst2, unsigned int* __restrict__ nslot_by_claim,
+    unsigned int* efirst2, unsigned int* __restrict__ eslot_by_claim, XW2 nxf, XW2 exf) {
+  __shared__ __attribute__((aligned(16))) int s_tok[F_SPAN + AMG_MAX_K + 4];
+  __shared__ unsigned int s_bits[F_BIT_WORDS];
+  __shared__ __attribute__((aligned(16))) int s_claim[F_SPAN + 4];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x;
+  const long long t0 = (long long)blockIdx.x * F_STRIDE;  // 16-byte aligned in every per-token array
+  const int flip = two_v - 1;
+  // ---- stage tokens t0 .. t0 + F_SPAN + k - 2 and the tile's slice of the read-end bitmap
+  {
+    bool bad = false;
+    if (t0 + F_SPAN <= n_tokens) {
+      const int4 v = reinterpret_cast<const int4*>(tokens + t0)[tid];
+      bad = (unsigned int)v.x >= (unsigned int)two_v || (unsigned int)v.y >= (unsigned int)two_v ||
+            (unsigned int)v.z >= (unsigned int)two_v || (unsigned int)v.w >= (unsigned int)two_v;
+      reinterpret_cast<int4*>(s_tok)[tid] = v;
+    } else {
+      for (int i = tid; i < F_SPAN; i += TILE_THREADS) {
+        const long long t = t0 + i;
+        const int v = t < n_tokens ? tokens[t] : 0;
+        bad = bad || (unsigned int)v >= (unsigned int)two_v;
+        s_tok[i] = v;
+      }
+    }
+    if (tid < k + 3) {  // the k - 1 tokens the last windows reach into (+ padding read by 128-bit loads)
+      const long long t = t0 + F_SPAN + tid;
+      const int v = t < n_tokens ? tokens[t] : 0;
+      bad = bad || (unsigned int)v >= (unsigned int)two_v;
+      s_tok[F_SPAN + tid] = v;
+    }
+    if (bad) status[ST_BADINPUT] = 2;  // a token outside [0, two_v) would alias another tuple
+    if (tid < F_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
+  }
+  __syncthreads();
+
+  // ---- nodes: four consecutive windows per thread
+  const int i0 = 4 * tid;
+  unsigned long long w1[TILE_ITEMS];
+  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], id1[TILE_ITEMS], lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
+  unsigned int lowbits = 0;  // per window: 1 = its direction is -1 (low bit of its first-seen value)
+  int slot[TILE_ITEMS];
+  ulonglong2 v[TILE_ITEMS];
+  unsigned int valid = 0, created = 0, last = 0;
+  {
+    // windows whose k tokens lie in one read: no read ends at the positions t + 1 .. t + k - 1
+    // (a read that ends right after the window makes it the last of its read)
+    const unsigned int b = tile_bits(s_bits, (int)(t0 & 31) + i0 + 1, k + 3);
+    constexpr int NA = K > 0 ? 4 + K - 1 : 1;
+    int a[NA];
+    unsigned int p[NA], q[NA];
+    if constexpr (K > 0) {
+#pragma unroll
+      for (int j = 0; j < (NA + 3) / 4; ++j) {
+        const int4 x = reinterpret_cast<const int4*>(s_tok + i0)[j];
+        if (4 * j + 0 < NA) a[4 * j + 0] = x.x;
+        if (4 * j + 1 < NA) a[4 * j + 1] = x.y;
+        if (4 * j + 2 < NA) a[4 * j + 2] = x.z;
+        if (4 * j + 3 < NA) a[4 * j + 3] = x.w;
+      }
+      if constexpr (B16) {
+        const unsigned int ff = (unsigned int)flip | ((unsigned int)flip << 16);
+#pragma unroll
+        for (int j = 0; j + 1 < NA; ++j) {
+          p[j] = (unsigned int)a[j] | ((unsigned int)a[j + 1] << 16);
+          q[j] = ff - ((unsigned int)a[j + 1] | ((unsigned int)a[j] << 16));
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      slot[w] = -1;
+      id1[w] = 0;
+      lw[w] = 0;
+      if (!TWO) hw[TWO ? 0 : w] = 0;
+      const long long t = t0 + i0 + w;
+      const bool inside = ((b >> w) & ((1u << (k - 1)) - 1u)) == 0u;
+      const bool ok = (t + k <= n_tokens) && inside && (tid < TILE_THREADS - 1 || w == 0);
+      if (!ok) continue;
+      int dir;
+      if constexpr (K > 0 && B16) {
+        dir = f_canon_pack16<K, TWO>(a + w, p + w, q + w, flip, w1[w], tag[w]);
+      } else if constexpr (K > 0) {
+        dir = x_canon_pack<K, TWO>(a + w, flip, bits, w1[w], tag[w]);
+      } else {
+        LdsView win{s_tok + i0 + w};
+        dir = canon_dir(win, k, flip);
+        if (dir != 0) x_pack(win, k, flip, dir, bits, w1[w], tag[w]);
+      }
+      if (dir == 0) {
+        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+        continue;
+      }
+      idx[w] = (unsigned int)mix64(w1[w] ^ ((unsigned long long)tag[w] * 0x9E3779B97F4A7C15ull)) & nmask;
+      if (dir < 0) lowbits |= 1u << w;
+      valid |= 1u << w;
+      if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
+    }
+  }
+  // first probe of every window in flight before any of them is examined
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w)
+    if (valid & (1u << w)) v[w] = *reinterpret_cast<const ulonglong2*>(ntab + idx[w]);
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w) {
+    if (!(valid & (1u << w))) continue;
+    bool made;
+    unsigned long long w2v;
+    slot[w] = x_upsert<TWO>(ntab, nmask, w1[w], tag[w], idx[w], v[w], probe_limit, status + ST_OVERFLOW, w2v, made);
+    lw[w] = (unsigned int)w2v;
+    if (!TWO) hw[TWO ? 0 : w] = (unsigned int)(w2v >> 32);
+    if (slot[w] < 0) status[ST_OVERFLOW] = 1;
+    if (made) created |= 1u << w;
+  }
+  x_claim<TWO, 1, 1>(ntab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + i0, lowbits, nxf, nfirst2,
+                     nslot_by_claim, status + ST_NODE_INSERTS, status + ST_MISC, s_wave, &s_base, false);
+
+  // ---- hand the claims to the neighbours: word = claim | last-of-read << 31 | (direction -1) << 30
+  int cw[TILE_ITEMS + 1];
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w)
+    cw[w] = slot[w] >= 0 ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
+                                 ((lowbits & (1u << w)) ? F_DIRBIT : 0u))
+                         : -1;
+  reinterpret_cast<int4*>(s_claim)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
+  __syncthreads();
+  cw[TILE_ITEMS] = tid < TILE_THREADS - 1 ? s_claim[i0 + TILE_ITEMS] : -1;
+
+  // ---- per-window outputs of the node half (the halo thread owns none)
+  if (tid < TILE_THREADS - 1) {
+    int oc[TILE_ITEMS];
+    unsigned int od = 0;
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      oc[w] = cw[w] == -1 ? -1 : (int)((unsigned int)cw[w] & ~F_DIRBIT);
+      const unsigned int d = cw[w] == -1 ? 0u : (((unsigned int)cw[w] & F_DIRBIT) ? 0xffu : 1u);
+      od |= d << (8 * w);
+    }
+    const long long t = t0 + i0;
+    if (t + TILE_ITEMS <= n_tokens) {
+      *reinterpret_cast<int4*>(tok_claim + t) = make_int4(oc[0], oc[1], oc[2], oc[3]);
+      *reinterpret_cast<unsigned int*>(tok_dir + t) = od;
+    } else {
+#pragma unroll
+      for (int w = 0; w < TILE_ITEMS; ++w)
+        if (t + w < n_tokens) {
+          tok_claim[t + w] = oc[w];
+          tok_dir[t + w] = (signed char)(od >> (8 * w));
+        }
+    }
+  }
+
+  // ---- edges: adjacency (A, dA) -> (B, dB) of windows t and t + 1 of one read (create_edges :246-262);
+  // class key = (smaller claim, larger claim, dA * dB), first-seen = (token << 3) | orientation
+  unsigned long long key[TILE_ITEMS];
+  unsigned int etag[TILE_ITEMS] = {}, ehw[TILE_ITEMS];
+  valid = 0;
+  created = 0;
+  lowbits = 0;
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w) {
+    slot[w] = -1;
+    id1[w] = 0;
+    lw[w] = 0;
+    ehw[w] = 0;
+    const int A = cw[w], B = cw[w + 1];
+    if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
+    const unsigned int ca = (unsigned int)A & 0x3fffffffu, cb = (unsigned int)B & 0x3fffffffu;
+    const bool negA = ((unsigned int)A & F_DIRBIT) != 0u, negB = ((unsigned int)B & F_DIRBIT) != 0u;
+    const unsigned int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+    const unsigned long long sign = negA != negB ? 1ull : 0ull;
+    key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+    const unsigned int orient = (ca == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
+    lowbits |= orient << (3 * w);
+    idx[w] = (unsigned int)mix64(key[w]) & emask;
+    valid |= 1u << w;
+  }
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w)
+    if (valid & (1u << w)) v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w) {
+    if (!(valid & (1u << w))) continue;
+    bool made;
+    unsigned long long w2v;
+    slot[w] = x_upsert<false>(etab, emask, key[w], 0u, idx[w], v[w], probe_limit, status + ST_OVERFLOW, w2v, made);
+    lw[w] = (unsigned int)w2v;
+    ehw[w] = (unsigned int)(w2v >> 32);
+    if (slot[w] < 0) status[ST_OVERFLOW] = 2;
+    if (made) created |= 1u << w;
+  }
+  x_claim<false, 3, 1>(etab, slot, lw, ehw, id1, created, etag, (unsigned int)t0 + i0, lowbits, exf, efirst2,
+                       eslot_by_claim, status + ST_PAIR_INSERTS, status + ST_MISC, s_wave, &s_base, false);
+  if (tid < TILE_THREADS - 1) {
+    int op[TILE_ITEMS];
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) op[w] = slot[w] >= 0 ? (int)(id1[w] - 1u) : -1;
+    const long long t = t0 + i0;
+    if (t + TILE_ITEMS <= n_tokens) {
+      *reinterpret_cast<int4*>(tok_pair + t) = make_int4(op[0], op[1], op[2], op[3]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < TILE_ITEMS; ++w)
+        if (t + w < n_tokens) tok_pair[t + w] = op[w];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static const unsigned int kProbeLimitF = 1024;
+
+// bits per token of the packed tuple: 16 whenever that fits (constant shifts in the kernels)
+int bx_bits(const amg_ctx* c, int k) {
+  const int need = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
+  if (need <= 16 && (long long)k * 16 <= 94 && !getenv("AMG_X_TIGHT_BITS")) return 16;
+  return need;
+}
+
+bool bf_applicable(const amg_ctx* c, int k) {
+  if (!bx_applicable(c, k)) return false;
+  const char* e = getenv("AMG_FUSED");  // A/B + test switch: "0" = the two table passes of amg_build_x.hip
+  if (e && e[0] == '0') return false;
+  return c->n_tokens < (1ll << 29);  // claims carry two flag bits in the LDS exchange
+}
+
+static int f_read_status(amg_ctx* c, unsigned long long* host) {
+  HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
+// node table + edge-class table in one pass: node claims 0 .. n_nodes-1 and edge-class claims
+// 0 .. n_pairs-1 with their first-seen / slot arrays, per-window node claims, directions and
+// edge-class claims.  AMG_E_OVERFLOW + *which = 1 / 2: node / edge table full.
+int bf_tables(amg_ctx* c, int k, int* which) {
+  *which = 0;
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens;
+  unsigned long long hs[ST_WORDS];
+  c->exact_keys = true;
+  c->packed_nodes = false;
+  c->x_bits = bx_bits(c, k);
+  HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+  AMGCHK(bs_read_stats(c, k));
+  const long long n_tiles = (T + F_STRIDE - 1) / F_STRIDE;
+
+  // the edge table is sized before the node count is known: ~2.2 classes per node on gene-call
+  // graphs; an overflow rebuilds with a table four times the size
+  {
+    const uint64_t est_nodes = c->node_hint > 0 ? (uint64_t)c->node_hint : (uint64_t)T / 8;
+    const int64_t want = (int64_t)slots_for(est_nodes * 5 / 2 + 16);
+    if (c->edge_slots < want) c->edge_slots = want;
+    if (c->edge_slots > (1ll << 30)) c->edge_slots = 1ll << 30;
+  }
+  const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
+  const size_t max_eclaims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+  AMGCHK(c->tok_slot.ensure((size_t)(T + 8) * sizeof(int)));
+  AMGCHK(c->tok_node.ensure((size_t)(T + 8) * sizeof(int)));
+  AMGCHK(c->tok_dir.ensure((size_t)(T + 8)));
+  AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
+  AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
+  AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
+  AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
+  AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
+  AMGCHK(c->x_efirst.ensure(2 * max_eclaims * sizeof(unsigned int)));
+  AMGCHK(c->x_eslot.ensure(max_eclaims * sizeof(unsigned int)));
+
+  stage_begin(c, "table_clear");
+  HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot16), st));
+  HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
+  HIPCHK(hipMemsetAsync(c->x_first.p, 0, 2 * max_claims * sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_eclaims * sizeof(unsigned int), st));
+  stage_end(c);
+
+  stage_begin(c, "graph_upsert");
+  if (n_tiles > 0) {
+    const bool two = (long long)k * c->x_bits > 63;  // tuple spills into the second slot word?
+    const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
+    auto kern = two ? k_graph_x<0, true, false> : k_graph_x<0, false, false>;
+    if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
+      if (b16 && k == 3) kern = k_graph_x<3, false, true>;
+      else if (b16 && k == 5) kern = k_graph_x<5, true, true>;
+      else if (k == 3) kern = two ? k_graph_x<3, true, false> : k_graph_x<3, false, false>;
+      else if (k == 5) kern = two ? k_graph_x<5, true, false> : k_graph_x<5, false, false>;
+      else if (k == 7) kern = two ? k_graph_x<7, true, false> : k_graph_x<7, false, false>;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                       c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits, c->node_tab.as<Slot16>(),
+                       (unsigned int)(c->node_slots - 1), c->edge_tab.as<Slot16>(),
+                       (unsigned int)(c->edge_slots - 1), kProbeLimitF, c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->tok_pair.as<int>(), c->status.as<unsigned long long>(),
+                       c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
+                       c->x_eslot.as<unsigned int>(), xw2_for(max_claims, T), xw2_for(max_eclaims, T));
+  }
+  stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
+  AMGCHK(f_read_status(c, hs));
+  if (hs[ST_BADINPUT])
+    return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
+                                                    : "a token lies outside [0, two_v)");
+  if (hs[ST_PALINDROME])
+    return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
+  if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "table pass: a claim id was never published");
+  if (hs[ST_OVERFLOW]) {
+    *which = (int)hs[ST_OVERFLOW];
+    return AMG_E_OVERFLOW;
+  }
+  c->n_windows = (int64_t)hs[ST_N_WINDOWS];
+  c->n_short = (int64_t)hs[ST_N_SHORT];
+  c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
+  c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
+  c->x_max_claims = (int64_t)max_claims;
+  c->x_max_eclaims = (int64_t)max_eclaims;
+  return AMG_OK;
+}
+
+// after bx_nodes_rank: coverages, per-window node ids, edge classes in first-seen order keyed by
+// final node ids
+int bf_finish(amg_ctx* c) {
+  const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
+  // node coverage (construct_node.py:33-36); the first sweep turns the per-window claims into node ids
+  stage_begin(c, "node_count");
+  AMGCHK(count_ids_remap(c, c->tok_slot.as<int>(), T, c->x_final.as<int>(), D, c->node_cov.as<unsigned int>()));
+  std::swap(c->tok_slot, c->tok_node);  // tok_node: node id per window; tok_slot: scratch again
+  stage_end(c);
+  stage_begin(c, "edge_count");
+  AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
+  stage_end(c);
+  return bx_pairs_rank(c, c->x_final.as<int>());
+}

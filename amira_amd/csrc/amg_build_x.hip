@@ -164,17 +164,33 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2,
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, nbits, j);
 }
 
+// An edge class recorded by the fused table pass is keyed by the CLAIM ids of its two nodes; here,
+// where the classes are ranked, key and orientation bit are re-expressed in final node ids:
+// key = (sign, smaller id, larger id + 1), bit 0 of first-seen = "the first event ran smaller -> larger"
+__device__ __forceinline__ void pair_to_final(unsigned long long& key, unsigned int& first,
+                                              const int* __restrict__ fin) {
+  const unsigned int lo_c = (unsigned int)((key >> 32) & 0x7fffffffull);
+  const unsigned int hi_c = (unsigned int)(key & 0xffffffffull) - 1u;
+  const bool a_is_lo = (first & 1u) != 0u;
+  const unsigned int X = (unsigned int)fin[a_is_lo ? lo_c : hi_c], Y = (unsigned int)fin[a_is_lo ? hi_c : lo_c];
+  const unsigned int lo = X < Y ? X : Y, hi = X < Y ? Y : X;
+  key = (key & (1ull << 63)) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+  first = (first & ~1u) | (X == lo ? 1u : 0u);
+}
+
 __global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first2, long long n_pairs,
                                         const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
                                         const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
                                         const unsigned int* __restrict__ cnt_by_claim,
                                         unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
-                                        unsigned int* __restrict__ pcnt) {
+                                        unsigned int* __restrict__ pcnt, const int* __restrict__ fin) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_pairs) return;
-  const unsigned int first = ~x_first_inv(first2, c);
+  unsigned int first = ~x_first_inv(first2, c);
   const long long i = x_rank_of(first >> 3, bits, prefix);
-  pkey[i] = etab[slot_by_claim[c]].w1;
+  unsigned long long key = etab[slot_by_claim[c]].w1;
+  if (fin) pair_to_final(key, first, fin);
+  pkey[i] = key;
   pfirst[i] = (unsigned long long)first;
   pcnt[i] = cnt_by_claim[c];
 }
@@ -290,12 +306,15 @@ __global__ void k_x_gather_pairs(const unsigned int* __restrict__ first_sorted,
                                  const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
                                  const unsigned int* __restrict__ cnt_by_claim,
                                  unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
-                                 unsigned int* __restrict__ pcnt) {
+                                 unsigned int* __restrict__ pcnt, const int* __restrict__ fin) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
   const unsigned int c = claim_sorted[i];
-  pkey[i] = etab[slot_by_claim[c]].w1;
-  pfirst[i] = (unsigned long long)first_sorted[i];
+  unsigned long long key = etab[slot_by_claim[c]].w1;
+  unsigned int first = first_sorted[i];
+  if (fin) pair_to_final(key, first, fin);
+  pkey[i] = key;
+  pfirst[i] = (unsigned long long)first;
   pcnt[i] = cnt_by_claim[c];
 }
 
@@ -324,17 +343,6 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
-// field widths of a two-word slot's second word for `max_claims` ids over T tokens
-static XW2 xw2_for(size_t max_claims, long long T) {
-  XW2 f;
-  f.ib = ilog2_ceil((uint64_t)max_claims + 2);
-  if (f.ib > 31) f.ib = 31;  // claims < 2^30 (slots are capped there)
-  const int cb = 32 - f.ib;  // bits left for the coarse position (0: every window checks first-seen)
-  const int tb = ilog2_ceil((uint64_t)(T > 0 ? T : 1) + 1);
-  f.cshift = cb <= 0 ? 31 : (tb > cb ? tb - cb : 0);
-  return f;
-}
-
 static int read_status(amg_ctx* c, unsigned long long* host) {
   HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                         c->stream));
@@ -352,8 +360,7 @@ bool bx_fits(const amg_ctx* c, int k) {
   if (c->weak_fp_builds > 0) return false;
   const char* e = getenv("AMG_KEY_MODE");  // A/B + test switch: "fp" forces the fingerprint path
   if (e && e[0] == 'f') return false;
-  int bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
-  if ((long long)k * bits > 94) return false;
+  if ((long long)k * bx_bits(c, k) > 94) return false;
   if (c->n_tokens >= (1ll << 29)) return false;  // 32-bit first-seen: (token << 3) | orientation
   return true;
 }
@@ -372,7 +379,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   unsigned long long hs[ST_WORDS];
   c->exact_keys = true;
   c->packed_nodes = false;
-  c->x_bits = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
+  c->x_bits = bx_bits(c, k);
   HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
 
   AMGCHK(bs_read_stats(c, k));
@@ -515,7 +522,6 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
 
 // coverages, edge classes in first-seen order
 int bx_edges_rank(amg_ctx* c) {
-  hipStream_t st = c->stream;
   const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
   // node coverage (construct_node.py:33-36) from the per-window node ids
   stage_begin(c, "node_count");
@@ -526,7 +532,14 @@ int bx_edges_rank(amg_ctx* c) {
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
   stage_end(c);
+  return bx_pairs_rank(c, nullptr);
+}
 
+// edge classes in first-seen order (pair_key / pair_first / pair_cnt) from the claims' arrays;
+// final_of_claim != nullptr: the classes are keyed by node CLAIM ids (fused table pass)
+int bx_pairs_rank(amg_ctx* c, const int* final_of_claim) {
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens, P = c->n_pairs;
   stage_begin(c, "edge_rank");
   AMGCHK(bs_alloc_pairs(c, P));
   AMGCHK(c->s1.ensure((size_t)(P + 1) * sizeof(unsigned int)));
@@ -540,7 +553,7 @@ int bx_edges_rank(amg_ctx* c) {
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->edge_tab.as<Slot16>(),
                        c->x_eslot.as<unsigned int>(), c->x_ecnt.as<unsigned int>(),
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
-                       c->pair_cnt.as<unsigned int>());
+                       c->pair_cnt.as<unsigned int>(), final_of_claim);
   } else if (P > 0) {
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
                        P, c->s1.as<unsigned int>(),
@@ -550,7 +563,7 @@ int bx_edges_rank(amg_ctx* c) {
     hipLaunchKernelGGL(k_x_gather_pairs, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
                        c->s4.as<unsigned int>(), P, c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(),
                        c->x_ecnt.as<unsigned int>(), c->pair_key.as<unsigned long long>(),
-                       c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+                       c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(), final_of_claim);
   }
   stage_end(c);
   return AMG_OK;

@@ -267,7 +267,15 @@ int bx_edges(amg_ctx* c, int* which);
 int bx_edges_upsert(amg_ctx* c, int* which);
 int bx_edges_rank(amg_ctx* c);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
-              unsigned int* out, int kind);
+              unsigned int* out, int kind, const int* remap = nullptr);
+// counts of remap[claim] over per-window node claims (claim | AMG_LAST_FLAG, -1 none); the array is
+// rewritten to the remapped ids
+int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out);
+int bx_bits(const amg_ctx* c, int k);
+int bx_pairs_rank(amg_ctx* c, const int* final_of_claim);
+bool bf_applicable(const amg_ctx* c, int k);
+int bf_tables(amg_ctx* c, int k, int* which);
+int bf_finish(amg_ctx* c);
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
                      const unsigned int* slot_sorted, long long n_ids, unsigned int* out, int kind);
 

@@ -260,3 +260,15 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
   }
 }
 
+
+// field widths of a two-word slot's second word for `max_claims` ids over T tokens
+static inline XW2 xw2_for(size_t max_claims, long long T) {
+  XW2 f;
+  f.ib = ilog2_ceil((uint64_t)max_claims + 2);
+  if (f.ib > 31) f.ib = 31;  // claims < 2^30 (slots are capped there)
+  const int cb = 32 - f.ib;  // bits left for the coarse position (0: every window checks first-seen)
+  const int tb = ilog2_ceil((uint64_t)(T > 0 ? T : 1) + 1);
+  f.cshift = cb <= 0 ? 31 : (tb > cb ? tb - cb : 0);
+  return f;
+}
+

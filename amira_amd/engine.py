@@ -63,6 +63,12 @@ class Engine:
         check(_ffi.lib.amg_sizes(self._h, C.byref(nr), C.byref(nt)))
         return nr.value, nt.value
 
+    def graph_sizes(self):
+        """(nodes, directed edges, k) of the built graph; no device work"""
+        nn, ne, k = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        check(_ffi.lib.amg_graph_sizes(self._h, C.byref(nn), C.byref(ne), C.byref(k)))
+        return nn.value, ne.value, k.value
+
     def counts(self):
         c = _ffi.Counts()
         check(_ffi.lib.amg_counts(self._h, C.byref(c)))
@@ -82,8 +88,7 @@ class Engine:
 
     # ---- read-back
     def nodes(self):
-        c = self.counts()
-        D, k = c["n_nodes"], c["k"]
+        D, _, k = self.graph_sizes()
         out = {
             "tokens": np.empty((D, k), np.int32), "coverage": np.empty(D, np.uint32),
             "first_token": np.empty(D, np.int64), "first_dir": np.empty(D, np.int8),
@@ -95,7 +100,7 @@ class Engine:
         return out
 
     def edges(self):
-        E = self.counts()["n_edges"]
+        E = self.graph_sizes()[1]
         out = {"src": np.empty(E, np.int32), "tgt": np.empty(E, np.int32),
                "sdir": np.empty(E, np.int8), "tdir": np.empty(E, np.int8),
                "coverage": np.empty(E, np.uint32), "alive": np.empty(E, np.uint8)}
@@ -104,19 +109,19 @@ class Engine:
         return out
 
     def read_nodes(self):
-        T = self.counts()["n_tokens"]
+        T = self.sizes()[1]
         node, d = np.empty(T, np.int32), np.empty(T, np.int8)
         check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), ptr(d)))
         return node, d
 
     def node_adj(self):
-        c = self.counts()
-        off, ids = np.empty(2 * c["n_nodes"] + 1, np.int64), np.empty(c["n_edges"], np.int32)
+        D, E, _ = self.graph_sizes()
+        off, ids = np.empty(2 * D + 1, np.int64), np.empty(E, np.int32)
         check(_ffi.lib.amg_get_node_adj(self._h, ptr(off), ptr(ids)))
         return off, ids
 
     def node_reads(self):
-        D = self.counts()["n_nodes"]
+        D = self.graph_sizes()[0]
         off = np.empty(D + 1, np.int64)
         check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), None))
         idx = np.empty(int(off[-1]) if D else 0, np.int32)
@@ -125,7 +130,7 @@ class Engine:
         return off, idx
 
     def reads_to_correct(self):
-        f = np.empty(self.counts()["n_reads"], np.uint8)
+        f = np.empty(self.sizes()[0], np.uint8)
         check(_ffi.lib.amg_get_reads_to_correct(self._h, ptr(f)))
         return f
 
@@ -138,7 +143,7 @@ class Engine:
         check(_ffi.lib.amg_remove_nodes(self._h, ptr(ids), len(ids)))
 
     def remove_short_linear_paths(self, min_length, protect=None):
-        D = self.counts()["n_nodes"]
+        D = self.graph_sizes()[0]
         n = C.c_int64(0)
         ids = np.empty(D, np.int32)
         pr = None if protect is None else np.ascontiguousarray(protect, dtype=np.uint8)

@@ -120,6 +120,9 @@ int amg_counts(amg_ctx* ctx, amg_counts_t* out);
 /* reads / genes of the current read set, without touching the device (amg_counts recounts the
  * live flags): len(readDict), sum(len(genes)) */
 int amg_sizes(amg_ctx* ctx, int64_t* n_reads, int64_t* n_tokens);
+/* array sizes of the built graph (nodes / directed edges ever inserted) and its k, without touching
+ * the device: what the read-back calls below need to size their buffers */
+int amg_graph_sizes(amg_ctx* ctx, int64_t* n_nodes, int64_t* n_edges, int32_t* k);
 
 /* ---- graph read-back (any pointer may be NULL to skip that column) ---------------- */
 /* nodes in id order; canon_tokens is [n_nodes * k]; first_token = token index of the
