@@ -34,20 +34,24 @@
 static_assert(F_BIT_WORDS <= BND_PAD_WORDS, "read-end bitmap padding too small for the fused tiles");
 
 // Canonical orientation + packed key of the window a[0..K-1] for 16-bit tokens (two_v <= 65536),
-// K odd.  p[j] = a[j] | a[j+1] << 16, q[j] = (F | F << 16) - (a[j+1] | a[j] << 16): the same
-// half-words serve every window of the thread.  Encoding == x_pack with bits = 16.
+// K odd.  Forward half-words a[j] | a[j+1] << 16, reverse-complement half-words
+// (F | F << 16) - (a[j+1] | a[j] << 16).  Encoding == x_pack with bits = 16.
 template <int K, bool TWO>
-__device__ __forceinline__ int f_canon_pack16(const int* a, const unsigned int* p, const unsigned int* q, int flip,
-                                              unsigned long long& w1, unsigned int& tag) {
+__device__ __forceinline__ int f_canon_pack16(const int* a, int flip, unsigned long long& w1, unsigned int& tag) {
   int dir = (2 * a[K / 2] < flip) ? 1 : -1;  // 2 x != 2V - 1: an odd k has no palindromes
 #pragma unroll
   for (int j = K / 2 - 1; j >= 0; --j) {
     const int s = a[j] + a[K - 1 - j];
     dir = s != flip ? (s < flip ? 1 : -1) : dir;
   }
+  const unsigned int ff = (unsigned int)flip | ((unsigned int)flip << 16);
   unsigned int word[K / 2 + 1];
 #pragma unroll
-  for (int m = 0; m < K / 2; ++m) word[m] = dir > 0 ? p[2 * m] : q[K - 2 - 2 * m];
+  for (int m = 0; m < K / 2; ++m) {
+    const unsigned int fw = (unsigned int)a[2 * m] | ((unsigned int)a[2 * m + 1] << 16);
+    const unsigned int rc = ff - ((unsigned int)a[K - 1 - 2 * m] | ((unsigned int)a[K - 2 - 2 * m] << 16));
+    word[m] = dir > 0 ? fw : rc;
+  }
   word[K / 2] = (unsigned int)(dir > 0 ? a[K - 1] : flip - a[0]);
   const unsigned long long v = (unsigned long long)word[0] | ((unsigned long long)word[1] << 32);
   w1 = (v << 1) | 1ull;
@@ -58,63 +62,215 @@ __device__ __forceinline__ int f_canon_pack16(const int* a, const unsigned int* 
   return dir;
 }
 
+// ---- one table phase for the four items of a thread: probe, insert, claim ids, first-seen.
+//
+// Claim ids come from F_SHARDS counters, one per shard (a wave belongs to one shard): a single
+// counter word takes ~90 returning atomics per microsecond, which is what a tile per 1024 tokens
+// asks of it at the speed of this pass; 64 words do not notice.  Claims are INTERLEAVED, claim =
+// local index * F_SHARDS + shard, so that the early (hot) claims of every shard are small numbers
+// and the claim space [0, F_SHARDS * largest local count) has few holes (entries of the per-claim
+// arrays that nobody claimed keep first-seen == 0 and are skipped wherever claims are listed).
+// The creators of a wave are counted with ballots and served by one atomicAdd of the wave:
+// no LDS, no workgroup barrier.
+#define F_SHARDS 64
+#define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
+
+template <class T>
+__device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
+  return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3];
+}
+
+template <bool TWO, int FSH>
+__device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
+                                              const unsigned long long (&w1)[TILE_ITEMS],
+                                              const unsigned int (&tag)[TILE_ITEMS],
+                                              const unsigned int (&idx)[TILE_ITEMS],
+                                              const ulonglong2 (&v)[TILE_ITEMS], unsigned int tbase,
+                                              unsigned int lowbits, const XW2 f, unsigned int* first2,
+                                              unsigned int* __restrict__ slot_by_claim,
+                                              unsigned long long* ctr, unsigned int shard, unsigned int cap,
+                                              unsigned int probe_limit, unsigned long long* status, int which,
+                                              unsigned int (&id1)[TILE_ITEMS]) {
+  auto tpos = [&](int it) { return tbase + (unsigned int)it; };
+  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
+  unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
+  int slot[TILE_ITEMS];
+  // ---- the key with its id, as the first probe load returned it: done (almost every window of a
+  // rebuild).  Anything else goes through x_upsert below, one item at a time, in ONE copy of that code.
+  unsigned int need = 0, created = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    id1[it] = 0;
+    lw[it] = 0;
+    slot[it] = (int)idx[it];
+    if (!TWO) hw[TWO ? 0 : it] = 0;
+    if (!(valid & (1u << it))) continue;
+    const unsigned long long c1 = v[it].x, c2 = v[it].y;
+    const bool mine = c1 == w1[it] && (!TWO || (unsigned int)(c2 >> 32) == tag[it]);
+    if (mine && (unsigned int)c2 != 0u) {
+      lw[it] = (unsigned int)c2;
+      if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(c2 >> 32);
+    } else {
+      need |= 1u << it;
+    }
+  }
+  while (need) {
+    const int it = __ffs((int)need) - 1;
+    need &= need - 1u;
+    bool made;
+    unsigned long long w2v;
+    // (the slot is loaded again rather than picked out of v[]: a register array indexed at run time
+    // lives in scratch memory)
+    const unsigned int ix = f_pick(idx, it);
+    const int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
+                                 *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit,
+                                 status + ST_OVERFLOW, w2v, made);
+    if (sl < 0) {
+      status[ST_OVERFLOW] = (unsigned long long)which;
+      valid &= ~(1u << it);
+    }
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j)
+      if (j == it) {
+        slot[j] = sl;
+        lw[j] = (unsigned int)w2v;
+        if (!TWO) hw[TWO ? 0 : j] = (unsigned int)(w2v >> 32);
+      }
+    if (made) created |= 1u << it;
+  }
+  // ---- claim ids of the wave's creators
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned int n = 0, pre[TILE_ITEMS];
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const unsigned long long m = __ballot((created >> it) & 1u);
+    pre[it] = n + (unsigned int)__popcll(m & below);
+    n += (unsigned int)__popcll(m);
+  }
+  unsigned int base = 0;
+  if (n) {  // wave-uniform
+    unsigned int b = 0;
+    if (lane == 0) b = (unsigned int)atomicAdd(ctr, (unsigned long long)n);
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+  }
+  if (created) {
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it)
+      if (created & (1u << it)) {
+        unsigned int li = base + pre[it];
+        if (li >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
+          status[ST_OVERFLOW] = (unsigned long long)which;
+          li = 0;
+        }
+        const unsigned int claim = li * F_SHARDS + shard;
+        // the creator's first-seen goes to its own word with a plain store; everybody else raises the
+        // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
+        // has to be ordered against the publication of the id
+        first2[2u * claim + 1u] = fi(it);
+        slot_by_claim[claim] = (unsigned int)slot[it];
+        id1[it] = claim + 1u;
+        const unsigned long long pub =
+            TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
+                      (unsigned long long)(claim + 1u)
+                : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
+        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  // ---- found keys: wait for an id that is still on its way (a creator publishes without waiting
+  // for anybody, after at most its own wave's atomicAdd), then keep the minimum first-seen
+  unsigned int check = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(valid & (1u << it)) || (created & (1u << it))) continue;
+    unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
+    for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
+      w = ld_u64(&tab[slot[it]].w2);
+      if ((unsigned int)w != 0u) break;
+      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
+        status[ST_MISC] = 1ull;
+        w = 1ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    id1[it] = xw2_id1<TWO>(w, f);
+    // can this window precede the creator's?  (coarse positions: same or earlier bucket)
+    const bool maybe_first = TWO ? (tpos(it) >> f.cshift) <= (((unsigned int)w) >> f.ib)
+                                 : fi(it) > (unsigned int)(w >> 32);
+    if (maybe_first) check |= 1u << it;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(check & (1u << it))) continue;
+    // plain (possibly stale, at worst zero) reads: both words only grow, so a stale value can only
+    // cause a superfluous atomicMax, never a missed one
+    const unsigned int c = id1[it] - 1u;
+    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
+  }
+}
+
 template <int K, bool TWO, bool B16>  // K > 0: k known at compile time; B16: 16 bits per token (K = 3 or 5)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* ntab, unsigned int nmask, Slot16* etab, unsigned int emask, unsigned int probe_limit,
     int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, int* __restrict__ tok_pair,
     unsigned long long* status, unsigned int* nfirst2, unsigned int* __restrict__ nslot_by_claim,
-    unsigned int* efirst2, unsigned int* __restrict__ eslot_by_claim, XW2 nxf, XW2 exf) {
+    unsigned int* efirst2, unsigned int* __restrict__ eslot_by_claim, XW2 nxf, XW2 exf,
+    unsigned long long* ctrs, unsigned int ncap, unsigned int ecap, unsigned long long* stamps) {
+  // timing experiment (make EXPERIMENTS=1, AMG_F_STAMPS=1): wave 0 of every block stamps its phases
+#define F_STAMP(i)                                                                     \
+  if (AMG_EXPERIMENTS && stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
+  F_STAMP(0);
   __shared__ __attribute__((aligned(16))) int s_tok[F_SPAN + AMG_MAX_K + 4];
   __shared__ unsigned int s_bits[F_BIT_WORDS];
   __shared__ __attribute__((aligned(16))) int s_claim[F_SPAN + 4];
-  __shared__ unsigned int s_wave[TILE_THREADS / 64];
-  __shared__ unsigned long long s_base;
   const int tid = threadIdx.x;
   const long long t0 = (long long)blockIdx.x * F_STRIDE;  // 16-byte aligned in every per-token array
   const int flip = two_v - 1;
+  const unsigned int shard = (blockIdx.x * (TILE_THREADS / 64) + (tid >> 6)) & (F_SHARDS - 1);
   // ---- stage tokens t0 .. t0 + F_SPAN + k - 2 and the tile's slice of the read-end bitmap
   {
     bool bad = false;
     if (t0 + F_SPAN <= n_tokens) {
-      const int4 v = reinterpret_cast<const int4*>(tokens + t0)[tid];
-      bad = (unsigned int)v.x >= (unsigned int)two_v || (unsigned int)v.y >= (unsigned int)two_v ||
-            (unsigned int)v.z >= (unsigned int)two_v || (unsigned int)v.w >= (unsigned int)two_v;
-      reinterpret_cast<int4*>(s_tok)[tid] = v;
+      const int4 x = reinterpret_cast<const int4*>(tokens + t0)[tid];
+      bad = (unsigned int)x.x >= (unsigned int)two_v || (unsigned int)x.y >= (unsigned int)two_v ||
+            (unsigned int)x.z >= (unsigned int)two_v || (unsigned int)x.w >= (unsigned int)two_v;
+      reinterpret_cast<int4*>(s_tok)[tid] = x;
     } else {
       for (int i = tid; i < F_SPAN; i += TILE_THREADS) {
         const long long t = t0 + i;
-        const int v = t < n_tokens ? tokens[t] : 0;
-        bad = bad || (unsigned int)v >= (unsigned int)two_v;
-        s_tok[i] = v;
+        const int x = t < n_tokens ? tokens[t] : 0;
+        bad = bad || (unsigned int)x >= (unsigned int)two_v;
+        s_tok[i] = x;
       }
     }
     if (tid < k + 3) {  // the k - 1 tokens the last windows reach into (+ padding read by 128-bit loads)
       const long long t = t0 + F_SPAN + tid;
-      const int v = t < n_tokens ? tokens[t] : 0;
-      bad = bad || (unsigned int)v >= (unsigned int)two_v;
-      s_tok[F_SPAN + tid] = v;
+      const int x = t < n_tokens ? tokens[t] : 0;
+      bad = bad || (unsigned int)x >= (unsigned int)two_v;
+      s_tok[F_SPAN + tid] = x;
     }
     if (bad) status[ST_BADINPUT] = 2;  // a token outside [0, two_v) would alias another tuple
     if (tid < F_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
   }
   __syncthreads();
+  F_STAMP(1);
 
   // ---- nodes: four consecutive windows per thread
   const int i0 = 4 * tid;
-  unsigned long long w1[TILE_ITEMS];
-  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], id1[TILE_ITEMS], lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
-  unsigned int lowbits = 0;  // per window: 1 = its direction is -1 (low bit of its first-seen value)
-  int slot[TILE_ITEMS];
-  ulonglong2 v[TILE_ITEMS];
-  unsigned int valid = 0, created = 0, last = 0;
+  unsigned int id1[TILE_ITEMS];
+  unsigned int last = 0, ndir = 0;  // per window: last of its read; direction -1
   {
+    unsigned long long w1[TILE_ITEMS];
+    unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS];
+    ulonglong2 v[TILE_ITEMS];
+    unsigned int valid = 0;
     // windows whose k tokens lie in one read: no read ends at the positions t + 1 .. t + k - 1
     // (a read that ends right after the window makes it the last of its read)
     const unsigned int b = tile_bits(s_bits, (int)(t0 & 31) + i0 + 1, k + 3);
     constexpr int NA = K > 0 ? 4 + K - 1 : 1;
     int a[NA];
-    unsigned int p[NA], q[NA];
     if constexpr (K > 0) {
 #pragma unroll
       for (int j = 0; j < (NA + 3) / 4; ++j) {
@@ -124,28 +280,19 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
         if (4 * j + 2 < NA) a[4 * j + 2] = x.z;
         if (4 * j + 3 < NA) a[4 * j + 3] = x.w;
       }
-      if constexpr (B16) {
-        const unsigned int ff = (unsigned int)flip | ((unsigned int)flip << 16);
-#pragma unroll
-        for (int j = 0; j + 1 < NA; ++j) {
-          p[j] = (unsigned int)a[j] | ((unsigned int)a[j + 1] << 16);
-          q[j] = ff - ((unsigned int)a[j + 1] | ((unsigned int)a[j] << 16));
-        }
-      }
     }
 #pragma unroll
     for (int w = 0; w < TILE_ITEMS; ++w) {
-      slot[w] = -1;
-      id1[w] = 0;
-      lw[w] = 0;
-      if (!TWO) hw[TWO ? 0 : w] = 0;
+      w1[w] = 0;
+      tag[w] = 0;
+      idx[w] = 0;
       const long long t = t0 + i0 + w;
       const bool inside = ((b >> w) & ((1u << (k - 1)) - 1u)) == 0u;
       const bool ok = (t + k <= n_tokens) && inside && (tid < TILE_THREADS - 1 || w == 0);
       if (!ok) continue;
       int dir;
       if constexpr (K > 0 && B16) {
-        dir = f_canon_pack16<K, TWO>(a + w, p + w, q + w, flip, w1[w], tag[w]);
+        dir = f_canon_pack16<K, TWO>(a + w, flip, w1[w], tag[w]);
       } else if constexpr (K > 0) {
         dir = x_canon_pack<K, TWO>(a + w, flip, bits, w1[w], tag[w]);
       } else {
@@ -158,36 +305,24 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
         continue;
       }
       idx[w] = (unsigned int)mix64(w1[w] ^ ((unsigned long long)tag[w] * 0x9E3779B97F4A7C15ull)) & nmask;
-      if (dir < 0) lowbits |= 1u << w;
+      v[w] = *reinterpret_cast<const ulonglong2*>(ntab + idx[w]);  // in flight while the next window is prepared
+      if (dir < 0) ndir |= 1u << w;
       valid |= 1u << w;
       if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
     }
+    F_STAMP(2);
+    f_table_phase<TWO, 1>(ntab, nmask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, nxf, nfirst2,
+                          nslot_by_claim, ctrs + (size_t)shard * F_CTR_STRIDE, shard, ncap, probe_limit, status, 1, id1);
   }
-  // first probe of every window in flight before any of them is examined
-#pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w)
-    if (valid & (1u << w)) v[w] = *reinterpret_cast<const ulonglong2*>(ntab + idx[w]);
-#pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w) {
-    if (!(valid & (1u << w))) continue;
-    bool made;
-    unsigned long long w2v;
-    slot[w] = x_upsert<TWO>(ntab, nmask, w1[w], tag[w], idx[w], v[w], probe_limit, status + ST_OVERFLOW, w2v, made);
-    lw[w] = (unsigned int)w2v;
-    if (!TWO) hw[TWO ? 0 : w] = (unsigned int)(w2v >> 32);
-    if (slot[w] < 0) status[ST_OVERFLOW] = 1;
-    if (made) created |= 1u << w;
-  }
-  x_claim<TWO, 1, 1>(ntab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + i0, lowbits, nxf, nfirst2,
-                     nslot_by_claim, status + ST_NODE_INSERTS, status + ST_MISC, s_wave, &s_base, false);
+  F_STAMP(3);
 
   // ---- hand the claims to the neighbours: word = claim | last-of-read << 31 | (direction -1) << 30
   int cw[TILE_ITEMS + 1];
 #pragma unroll
   for (int w = 0; w < TILE_ITEMS; ++w)
-    cw[w] = slot[w] >= 0 ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
-                                 ((lowbits & (1u << w)) ? F_DIRBIT : 0u))
-                         : -1;
+    cw[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
+                           ((ndir & (1u << w)) ? F_DIRBIT : 0u))
+                   : -1;
   reinterpret_cast<int4*>(s_claim)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
   __syncthreads();
   cw[TILE_ITEMS] = tid < TILE_THREADS - 1 ? s_claim[i0 + TILE_ITEMS] : -1;
@@ -215,60 +350,67 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
         }
     }
   }
+  F_STAMP(4);
 
   // ---- edges: adjacency (A, dA) -> (B, dB) of windows t and t + 1 of one read (create_edges :246-262);
   // class key = (smaller claim, larger claim, dA * dB), first-seen = (token << 3) | orientation
-  unsigned long long key[TILE_ITEMS];
-  unsigned int etag[TILE_ITEMS] = {}, ehw[TILE_ITEMS];
-  valid = 0;
-  created = 0;
-  lowbits = 0;
+  {
+    unsigned long long key[TILE_ITEMS];
+    unsigned int idx[TILE_ITEMS], etag[TILE_ITEMS];
+    ulonglong2 v[TILE_ITEMS];
+    unsigned int valid = 0, orient3 = 0;
 #pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w) {
-    slot[w] = -1;
-    id1[w] = 0;
-    lw[w] = 0;
-    ehw[w] = 0;
-    const int A = cw[w], B = cw[w + 1];
-    if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
-    const unsigned int ca = (unsigned int)A & 0x3fffffffu, cb = (unsigned int)B & 0x3fffffffu;
-    const bool negA = ((unsigned int)A & F_DIRBIT) != 0u, negB = ((unsigned int)B & F_DIRBIT) != 0u;
-    const unsigned int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
-    const unsigned long long sign = negA != negB ? 1ull : 0ull;
-    key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
-    const unsigned int orient = (ca == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
-    lowbits |= orient << (3 * w);
-    idx[w] = (unsigned int)mix64(key[w]) & emask;
-    valid |= 1u << w;
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      key[w] = 0;
+      idx[w] = 0;
+      etag[w] = 0;
+      const int A = cw[w], B = cw[w + 1];
+      if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
+      const unsigned int ca = (unsigned int)A & 0x3fffffffu, cb = (unsigned int)B & 0x3fffffffu;
+      const bool negA = ((unsigned int)A & F_DIRBIT) != 0u, negB = ((unsigned int)B & F_DIRBIT) != 0u;
+      const unsigned int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+      const unsigned long long sign = negA != negB ? 1ull : 0ull;
+      key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+      const unsigned int orient = (ca == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
+      orient3 |= orient << (3 * w);
+      idx[w] = (unsigned int)mix64(key[w]) & emask;
+      v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
+      valid |= 1u << w;
+    }
+    F_STAMP(5);
+    f_table_phase<false, 3>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, exf, efirst2,
+                            eslot_by_claim, ctrs + (size_t)(F_SHARDS + shard) * F_CTR_STRIDE, shard, ecap, probe_limit,
+                            status, 2, id1);
   }
-#pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w)
-    if (valid & (1u << w)) v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
-#pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w) {
-    if (!(valid & (1u << w))) continue;
-    bool made;
-    unsigned long long w2v;
-    slot[w] = x_upsert<false>(etab, emask, key[w], 0u, idx[w], v[w], probe_limit, status + ST_OVERFLOW, w2v, made);
-    lw[w] = (unsigned int)w2v;
-    ehw[w] = (unsigned int)(w2v >> 32);
-    if (slot[w] < 0) status[ST_OVERFLOW] = 2;
-    if (made) created |= 1u << w;
-  }
-  x_claim<false, 3, 1>(etab, slot, lw, ehw, id1, created, etag, (unsigned int)t0 + i0, lowbits, exf, efirst2,
-                       eslot_by_claim, status + ST_PAIR_INSERTS, status + ST_MISC, s_wave, &s_base, false);
+  F_STAMP(6);
   if (tid < TILE_THREADS - 1) {
-    int op[TILE_ITEMS];
-#pragma unroll
-    for (int w = 0; w < TILE_ITEMS; ++w) op[w] = slot[w] >= 0 ? (int)(id1[w] - 1u) : -1;
     const long long t = t0 + i0;
     if (t + TILE_ITEMS <= n_tokens) {
-      *reinterpret_cast<int4*>(tok_pair + t) = make_int4(op[0], op[1], op[2], op[3]);
+      *reinterpret_cast<int4*>(tok_pair + t) =
+          make_int4((int)id1[0] - 1, (int)id1[1] - 1, (int)id1[2] - 1, (int)id1[3] - 1);
     } else {
 #pragma unroll
       for (int w = 0; w < TILE_ITEMS; ++w)
-        if (t + w < n_tokens) tok_pair[t + w] = op[w];
+        if (t + w < n_tokens) tok_pair[t + w] = (int)id1[w] - 1;
     }
+  }
+  F_STAMP(7);
+#undef F_STAMP
+}
+
+// claims handed out: sum and largest per-shard count of the node / edge-class counters
+__global__ void k_f_ctr_reduce(const unsigned long long* __restrict__ ctrs, unsigned long long* status) {
+  const int which = blockIdx.x;  // 0 nodes, 1 edge classes
+  unsigned long long v = ctrs[(size_t)(which * F_SHARDS + threadIdx.x) * F_CTR_STRIDE];
+  unsigned long long sum = v, mx = v;
+  for (int d = 32; d > 0; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    const unsigned long long o = __shfl_xor(mx, d, 64);
+    mx = mx > o ? mx : o;
+  }
+  if (threadIdx.x == 0) {
+    status[which == 0 ? ST_NODE_INSERTS : ST_PAIR_INSERTS] = sum;
+    status[which == 0 ? ST_COMPACT_A : ST_COMPACT_B] = mx;
   }
 }
 
@@ -286,6 +428,7 @@ bool bf_applicable(const amg_ctx* c, int k) {
   if (!bx_applicable(c, k)) return false;
   const char* e = getenv("AMG_FUSED");  // A/B + test switch: "0" = the two table passes of amg_build_x.hip
   if (e && e[0] == '0') return false;
+  if (getenv("AMG_X_RANK_SORT")) return false;  // test switch of the two-pass path's sort ranking
   return c->n_tokens < (1ll << 29);  // claims carry two flag bits in the LDS exchange
 }
 
@@ -319,8 +462,17 @@ int bf_tables(amg_ctx* c, int k, int* which) {
     if (c->edge_slots < want) c->edge_slots = want;
     if (c->edge_slots > (1ll << 30)) c->edge_slots = 1ll << 30;
   }
-  const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
-  const size_t max_eclaims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+  // claim arrays: F_SHARDS interleaved shares; a share holds at least what one wave can create
+  auto share = [&](long long slots) {
+    const long long bound = (slots < T ? slots : T) + 1;
+    // every shard sees every 64th wave of the stream: shares fill evenly up to statistics (a quarter
+    // of slack) and up to what one wave creates in one go
+    const long long even = (bound + F_SHARDS - 1) / F_SHARDS;
+    return (unsigned int)(even + even / 4 + (T < 256 ? T : 256) + 1);
+  };
+  const unsigned int ncap = share(c->node_slots), ecap = share(c->edge_slots);
+  const size_t max_claims = (size_t)ncap * F_SHARDS + 1, max_eclaims = (size_t)ecap * F_SHARDS + 1;
+  AMGCHK(c->f_ctrs.ensure(2 * F_SHARDS * F_CTR_STRIDE * sizeof(unsigned long long)));
   AMGCHK(c->tok_slot.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_node.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_dir.ensure((size_t)(T + 8)));
@@ -338,8 +490,14 @@ int bf_tables(amg_ctx* c, int k, int* which) {
   HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
   HIPCHK(hipMemsetAsync(c->x_first.p, 0, 2 * max_claims * sizeof(unsigned int), st));
   HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_eclaims * sizeof(unsigned int), st));
+  HIPCHK(hipMemsetAsync(c->f_ctrs.p, 0, 2 * F_SHARDS * F_CTR_STRIDE * sizeof(unsigned long long), st));
   stage_end(c);
 
+  unsigned long long* stamps = nullptr;
+  if (AMG_EXPERIMENTS && getenv("AMG_F_STAMPS")) {
+    AMGCHK(c->s0.ensure((size_t)(n_tiles + 1) * 8 * sizeof(unsigned long long)));
+    stamps = c->s0.as<unsigned long long>();
+  }
   stage_begin(c, "graph_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into the second slot word?
@@ -358,10 +516,25 @@ int bf_tables(amg_ctx* c, int k, int* which) {
                        (unsigned int)(c->edge_slots - 1), kProbeLimitF, c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->tok_pair.as<int>(), c->status.as<unsigned long long>(),
                        c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
-                       c->x_eslot.as<unsigned int>(), xw2_for(max_claims, T), xw2_for(max_eclaims, T));
+                       c->x_eslot.as<unsigned int>(), xw2_for(max_claims, T), xw2_for(max_eclaims, T),
+                       c->f_ctrs.as<unsigned long long>(), ncap, ecap, stamps);
+    hipLaunchKernelGGL(k_f_ctr_reduce, dim3(2), dim3(64), 0, st, c->f_ctrs.as<unsigned long long>(),
+                       c->status.as<unsigned long long>());
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(f_read_status(c, hs));
+  if (stamps && n_tiles > 0) {
+    std::vector<unsigned long long> h((size_t)n_tiles * 8);
+    HIPCHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static const char* names[7] = {"stage", "node probe", "node claim", "exchange+node stores", "edge probe", "edge claim", "edge stores"};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long b = 0; b < n_tiles; ++b)
+      for (int i = 0; i < 7; ++i) sum[i] += (double)(h[b * 8 + i + 1] - h[b * 8 + i]);
+    fprintf(stderr, "[amg] k_graph_x phases, mean cycles of wave 0 per tile (%lld tiles):", n_tiles);
+    double tot = 0;
+    for (int i = 0; i < 7; ++i) { fprintf(stderr, " %s %.0f;", i < 7 ? names[i] : "?", sum[i] / n_tiles); tot += sum[i] / n_tiles; }
+    fprintf(stderr, " total %.0f\n", tot);
+  }
   if (hs[ST_BADINPUT])
     return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
                                                     : "a token lies outside [0, two_v)");
@@ -376,6 +549,8 @@ int bf_tables(amg_ctx* c, int k, int* which) {
   c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
   c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
+  c->x_nspace = (int64_t)hs[ST_COMPACT_A] * F_SHARDS;  // claim ids in use lie below these bounds
+  c->x_espace = (int64_t)hs[ST_COMPACT_B] * F_SHARDS;
   c->x_max_claims = (int64_t)max_claims;
   c->x_max_eclaims = (int64_t)max_eclaims;
   return AMG_OK;
@@ -384,7 +559,7 @@ int bf_tables(amg_ctx* c, int k, int* which) {
 // after bx_nodes_rank: coverages, per-window node ids, edge classes in first-seen order keyed by
 // final node ids
 int bf_finish(amg_ctx* c) {
-  const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
+  const long long T = c->n_tokens, D = c->n_nodes, P = c->x_espace;  // edge-class counts are per CLAIM
   // node coverage (construct_node.py:33-36); the first sweep turns the per-window claims into node ids
   stage_begin(c, "node_count");
   AMGCHK(count_ids_remap(c, c->tok_slot.as<int>(), T, c->x_final.as<int>(), D, c->node_cov.as<unsigned int>()));

@@ -130,7 +130,9 @@ __global__ void k_x_rank_setbits(const unsigned int* __restrict__ first2, long l
                                  unsigned int* __restrict__ bits) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const unsigned int t = (~x_first_inv(first2, i)) >> shift;
+  const unsigned int fi = x_first_inv(first2, i);
+  if (fi == 0u) return;  // a claim id nobody took (interleaved shards, amg_build_f.hip)
+  const unsigned int t = (~fi) >> shift;
   atomicOr(&bits[t >> 5], 1u << (t & 31));
 }
 
@@ -154,6 +156,7 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2,
                                         unsigned char* __restrict__ node_alive) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_nodes) return;
+  if (x_first_inv(first2, c) == 0u) return;  // unclaimed
   const unsigned int first = ~x_first_inv(first2, c);
   const long long i = x_rank_of(first >> 1, bits, prefix);
   final_of_claim[c] = (int)i;
@@ -186,6 +189,7 @@ __global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first2,
                                         unsigned int* __restrict__ pcnt, const int* __restrict__ fin) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_pairs) return;
+  if (x_first_inv(first2, c) == 0u) return;  // unclaimed
   unsigned int first = ~x_first_inv(first2, c);
   const long long i = x_rank_of(first >> 3, bits, prefix);
   unsigned long long key = etab[slot_by_claim[c]].w1;
@@ -433,6 +437,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   c->n_windows = (int64_t)hs[ST_N_WINDOWS];
   c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
+  c->x_nspace = c->n_nodes;
   c->x_max_claims = (int64_t)max_claims;
   return AMG_OK;
 }
@@ -449,10 +454,11 @@ int bx_nodes_rank(amg_ctx* c) {
   AMGCHK(c->s3.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(D + 1) * sizeof(unsigned int)));
   AMGCHK(bs_alloc_nodes(c, D));
-  if (D > 0 && D <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
-    AMGCHK(x_rank_bitmap(c, c->x_first.as<unsigned int>(), D, 1));
-    hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(D, 256)), dim3(256), 0, st,
-                       c->x_first.as<unsigned int>(), D,
+  const long long S = c->x_nspace;  // claim ids in use (== D unless handed out in interleaved shards)
+  if (D > 0 && ((D <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) || S != D)) {
+    AMGCHK(x_rank_bitmap(c, c->x_first.as<unsigned int>(), S, 1));
+    hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(S, 256)), dim3(256), 0, st,
+                       c->x_first.as<unsigned int>(), S,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
                        c->x_slot.as<unsigned int>(), k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->x_final.as<int>(),
                        c->node_tokens.as<int>(),
@@ -516,6 +522,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     return AMG_E_OVERFLOW;
   }
   c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
+  c->x_espace = c->n_pairs;
   c->x_max_eclaims = (int64_t)max_claims;
   return AMG_OK;
 }
@@ -546,10 +553,11 @@ int bx_pairs_rank(amg_ctx* c, const int* final_of_claim) {
   AMGCHK(c->s2.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s3.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
-  if (P > 0 && P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) {
-    AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), P, 3));
-    hipLaunchKernelGGL(k_x_gather_pairs_ranked, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                       c->x_efirst.as<unsigned int>(), P,
+  const long long S = c->x_espace;
+  if (P > 0 && ((P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) || S != P)) {
+    AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), S, 3));
+    hipLaunchKernelGGL(k_x_gather_pairs_ranked, dim3(blocks_for(S, 256)), dim3(256), 0, st,
+                       c->x_efirst.as<unsigned int>(), S,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->edge_tab.as<Slot16>(),
                        c->x_eslot.as<unsigned int>(), c->x_ecnt.as<unsigned int>(),
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),

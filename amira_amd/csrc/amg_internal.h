@@ -201,12 +201,15 @@ struct amg_ctx {
   // ---- exact-key build (amg_build_x.hip): arrays indexed by CLAIM id (order of slot creation)
   bool exact_keys = false;   // this build used the exact-key path
   int x_bits = 0;            // bits per token in the packed tuple
+  int64_t x_nspace = 0, x_espace = 0;  // claim ids in use are below these (== n_nodes / n_pairs unless the
+                                       // claims were handed out in interleaved shards: amg_build_f.hip)
   int64_t x_max_claims = 0, x_max_eclaims = 0;  // capacity of the per-claim arrays (second half of x_first / x_efirst starts there)
   bool dist_x = false;       // this merged build keeps its LOCAL tables in the exact-key layout
   DevBuf x_first, x_slot;    // uint32[claims]  ~first_seen of a node claim, its table slot
   DevBuf x_final;            // int32 [claims]  claim id -> node id
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
+  DevBuf f_ctrs;             // fused table pass: per-shard claim counters
 
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
