@@ -56,6 +56,48 @@ extern "C" int amg_last_timings(amg_ctx* c, const char** names, float* ms, int c
   return n;
 }
 
+// ------------------------------------------------------------------ clear_many
+struct ClearArgs {
+  void* p[8];
+  unsigned long long words[8];  // 4-byte words per range
+  int n;
+};
+__global__ __launch_bounds__(256) void k_clear_many(ClearArgs a) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+  for (int r = 0; r < a.n; ++r) {
+    unsigned int* p = reinterpret_cast<unsigned int*>(a.p[r]);
+    const unsigned long long w = a.words[r];
+    // 16-byte stores over the aligned middle, words at the ragged ends
+    const unsigned long long head = ((16u - ((unsigned long long)(uintptr_t)p & 15u)) & 15u) >> 2;
+    const unsigned long long h = head < w ? head : w;
+    const unsigned long long quads = (w - h) >> 2;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < quads; i += stride)
+      q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+      for (unsigned long long i = threadIdx.x; i < h; i += 256) p[i] = 0u;
+      for (unsigned long long i = h + quads * 4 + threadIdx.x; i < w; i += 256) p[i] = 0u;
+    }
+  }
+}
+
+int clear_many(amg_ctx* c, const ClearList& l) {
+  if (l.n == 0) return AMG_OK;
+  ClearArgs a;
+  unsigned long long most = 0;
+  a.n = l.n;
+  for (int i = 0; i < l.n; ++i) {
+    a.p[i] = l.p[i];
+    a.words[i] = l.bytes[i] >> 2;
+    most = a.words[i] > most ? a.words[i] : most;
+  }
+  unsigned long long blocks = (most / 4 + 256 * 8 - 1) / (256 * 8);  // ~8 quads per thread at the largest range
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_clear_many, dim3((unsigned int)blocks), dim3(256), 0, c->stream, a);
+  return AMG_OK;
+}
+
 // ------------------------------------------------------------------ lifetime
 extern "C" int amg_create(int device, amg_ctx** out) {
   if (!out) return amg_fail(AMG_E_ARG, "null out pointer");
@@ -97,7 +139,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp,   &c->s0, &c->s1, &c->s2, &c->s3,
-                   &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->f_ctrs};
+                   &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->f_ctrs, &c->x_efinal, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
   for (DevBuf* b : all) b->release();
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -157,6 +199,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
   c->have_corrected = false;
   c->match_valid = false;
   c->node_hint = 0;
+  c->cnt_hint_reset = true;  // what the counting sweeps learned belongs to the previous read set
   return AMG_OK;
 }
 
@@ -169,6 +212,10 @@ extern "C" int amg_set_positions(amg_ctx* c, const int64_t* gene_start, const in
   AMGCHK(copy_in(c, c->gene_start, gene_start, (size_t)c->n_tokens * sizeof(int64_t), on_device));
   AMGCHK(copy_in(c, c->gene_end, gene_end, (size_t)c->n_tokens * sizeof(int64_t), on_device));
   c->have_pos = true;
+  c->pos_identity = true;
+  c->pos_n0 = c->n_tokens;
+  c->pos1_used = c->c_pos1_used = 0;
+  c->have_corrected = false;
   c->have_read_len = false;
   if (read_len) {
     AMGCHK(copy_in(c, c->read_len, read_len, (size_t)c->n_reads * sizeof(int64_t), on_device));

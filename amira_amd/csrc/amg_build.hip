@@ -435,24 +435,26 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
 }
 
 // counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes,
-// 2 node claims as the table pass wrote them (id | AMG_LAST_FLAG on the last window of a read)
-int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out) {
-  return count_ids(c, claims, n, nullptr, n_ids, out, 2, remap);
+// 2 / 3 node / edge-class claims as the table pass wrote them (id | AMG_LAST_FLAG on the last window of a read)
+int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out,
+                    int edges) {
+  return count_ids(c, claims, n, nullptr, n_ids, out, edges ? 3 : 2, remap);
 }
 
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind, const int* remap) {
   hipStream_t st = c->stream;
-  HIPCHK(hipMemsetAsync(out, 0, (size_t)(n_ids + 1) * sizeof(unsigned int), st));
-  if (n <= 0 || n_ids <= 0) return AMG_OK;
-  if (!c->cnt_state.p) {
-    AMGCHK(c->cnt_state.ensure((2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(c->cnt_state.p, 0, (2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long), st));
-  }
+  ClearList cl;
+  cl.add(out, (size_t)(n_ids + 1) * sizeof(unsigned int));
+  const bool fresh = !c->cnt_state.p || c->cnt_hint_reset;
+  AMGCHK(c->cnt_state.ensure((2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
+  c->cnt_hint_reset = false;
   unsigned long long* state = c->cnt_state.as<unsigned long long>();
-  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * (kind == 1 ? 1 : 0);
-  const int strip = kind == 2 ? 1 : 0;
-  HIPCHK(hipMemsetAsync(state, 0, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long), st));
+  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * ((kind == 1 || kind == 3) ? 1 : 0);
+  const int strip = kind >= 2 ? 1 : 0;
+  cl.add(state, (fresh ? 2 * COUNT_MAX_SWEEPS + 4 : 2 * COUNT_MAX_SWEEPS) * sizeof(unsigned long long));
+  AMGCHK(clear_many(c, cl));
+  if (n <= 0 || n_ids <= 0) return AMG_OK;
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
   if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
   // every block flushes up to HOT_IDS counters with global atomics at the end of a sweep: give a

@@ -454,11 +454,11 @@ int bf_tables(amg_ctx* c, int k, int* which) {
   AMGCHK(bs_read_stats(c, k));
   const long long n_tiles = (T + F_STRIDE - 1) / F_STRIDE;
 
-  // the edge table is sized before the node count is known: ~2.2 classes per node on gene-call
-  // graphs; an overflow rebuilds with a table four times the size
+  // the edge table is sized before the node count is known: ~1.1 classes (2.2 directed edges) per
+  // node on gene-call graphs; an overflow rebuilds with a table four times the size
   {
     const uint64_t est_nodes = c->node_hint > 0 ? (uint64_t)c->node_hint : (uint64_t)T / 8;
-    const int64_t want = (int64_t)slots_for(est_nodes * 5 / 2 + 16);
+    const int64_t want = (int64_t)slots_for(est_nodes * 5 / 4 + 16);  // classes, not directed edges
     if (c->edge_slots < want) c->edge_slots = want;
     if (c->edge_slots > (1ll << 30)) c->edge_slots = 1ll << 30;
   }
@@ -486,11 +486,15 @@ int bf_tables(amg_ctx* c, int k, int* which) {
   AMGCHK(c->x_eslot.ensure(max_eclaims * sizeof(unsigned int)));
 
   stage_begin(c, "table_clear");
-  HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->x_first.p, 0, 2 * max_claims * sizeof(unsigned int), st));
-  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_eclaims * sizeof(unsigned int), st));
-  HIPCHK(hipMemsetAsync(c->f_ctrs.p, 0, 2 * F_SHARDS * F_CTR_STRIDE * sizeof(unsigned long long), st));
+  {
+    ClearList cl;
+    cl.add(c->node_tab.p, (size_t)c->node_slots * sizeof(Slot16));
+    cl.add(c->edge_tab.p, (size_t)c->edge_slots * sizeof(Slot16));
+    cl.add(c->x_first.p, 2 * max_claims * sizeof(unsigned int));
+    cl.add(c->x_efirst.p, 2 * max_eclaims * sizeof(unsigned int));
+    cl.add(c->f_ctrs.p, 2 * F_SHARDS * F_CTR_STRIDE * sizeof(unsigned long long));
+    AMGCHK(clear_many(c, cl));
+  }
   stage_end(c);
 
   unsigned long long* stamps = nullptr;
@@ -557,17 +561,20 @@ int bf_tables(amg_ctx* c, int k, int* which) {
 }
 
 // after bx_nodes_rank: coverages, per-window node ids, edge classes in first-seen order keyed by
-// final node ids
+// final node ids.  Both counts run on RANKED ids (node ids, edge-class ids): first-seen order puts
+// the genome's nodes / classes first, so the LDS-privatised ranges of count_ids hold them.
 int bf_finish(amg_ctx* c) {
-  const long long T = c->n_tokens, D = c->n_nodes, P = c->x_espace;  // edge-class counts are per CLAIM
+  const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
   // node coverage (construct_node.py:33-36); the first sweep turns the per-window claims into node ids
   stage_begin(c, "node_count");
-  AMGCHK(count_ids_remap(c, c->tok_slot.as<int>(), T, c->x_final.as<int>(), D, c->node_cov.as<unsigned int>()));
+  AMGCHK(count_ids_remap(c, c->tok_slot.as<int>(), T, c->x_final.as<int>(), D, c->node_cov.as<unsigned int>(), 0));
   std::swap(c->tok_slot, c->tok_node);  // tok_node: node id per window; tok_slot: scratch again
   stage_end(c);
+  AMGCHK(c->x_efinal.ensure((size_t)(c->x_espace + 2) * sizeof(int)));
+  AMGCHK(bx_pairs_rank(c, c->x_final.as<int>(), c->x_efinal.as<int>()));
+  // edge-class coverage (construct_edge.py:87-90), per class id
   stage_begin(c, "edge_count");
-  AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
+  AMGCHK(count_ids_remap(c, c->tok_pair.as<int>(), T, c->x_efinal.as<int>(), P, c->pair_cnt.as<unsigned int>(), 1));
   stage_end(c);
-  return bx_pairs_rank(c, c->x_final.as<int>());
+  return AMG_OK;
 }

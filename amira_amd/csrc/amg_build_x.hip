@@ -126,20 +126,29 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
 // distinct: set one bit per claim in a bitmap over the tokens, prefix-count the bitmap words, and
 // the rank of a claim is the number of bits before its own.  (A radix sort of 0.5 - 1 M pairs
 // costs ~10 launches and ~0.2 ms however small the input; this costs ~0.06 ms.)
-__global__ void k_x_rank_setbits(const unsigned int* __restrict__ first2, long long n, int shift,
-                                 unsigned int* __restrict__ bits) {
+// (one BYTE per token first, set with plain stores: 5.4 M scattered atomicOr on bitmap words ran at the
+// memory-side atomic rate, 0.2 ms per ranking of the first build; the bytes are folded into the
+// bitmap words by the pass that counts them)
+__global__ void k_x_rank_setflags(const unsigned int* __restrict__ first2, long long n, int shift,
+                                  unsigned char* __restrict__ flags) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned int fi = x_first_inv(first2, i);
   if (fi == 0u) return;  // a claim id nobody took (interleaved shards, amg_build_f.hip)
-  const unsigned int t = (~fi) >> shift;
-  atomicOr(&bits[t >> 5], 1u << (t & 31));
+  flags[(~fi) >> shift] = 1;
 }
 
-__global__ void k_x_rank_popc(const unsigned int* __restrict__ bits, long long n_words,
-                              unsigned int* __restrict__ cnt) {
+__global__ void k_x_rank_words(const unsigned char* __restrict__ flags, long long n_words,
+                               unsigned int* __restrict__ bits, unsigned int* __restrict__ cnt) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_words) cnt[i] = (unsigned int)__popc(bits[i]);
+  if (i >= n_words) return;
+  const uint4* p = reinterpret_cast<const uint4*>(flags + 32 * i);
+  const uint4 a = p[0], b = p[1];
+  auto nib = [](unsigned int x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };
+  const unsigned int w = nib(a.x) | (nib(a.y) << 4) | (nib(a.z) << 8) | (nib(a.w) << 12) | (nib(b.x) << 16) |
+                         (nib(b.y) << 20) | (nib(b.z) << 24) | (nib(b.w) << 28);
+  bits[i] = w;
+  cnt[i] = (unsigned int)__popc(w);
 }
 
 __device__ __forceinline__ long long x_rank_of(unsigned int t, const unsigned int* __restrict__ bits,
@@ -186,7 +195,8 @@ __global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first2,
                                         const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
                                         const unsigned int* __restrict__ cnt_by_claim,
                                         unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
-                                        unsigned int* __restrict__ pcnt, const int* __restrict__ fin) {
+                                        unsigned int* __restrict__ pcnt, const int* __restrict__ fin,
+                                        int* __restrict__ efinal) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_pairs) return;
   if (x_first_inv(first2, c) == 0u) return;  // unclaimed
@@ -196,7 +206,10 @@ __global__ void k_x_gather_pairs_ranked(const unsigned int* __restrict__ first2,
   if (fin) pair_to_final(key, first, fin);
   pkey[i] = key;
   pfirst[i] = (unsigned long long)first;
-  pcnt[i] = cnt_by_claim[c];
+  if (efinal)
+    efinal[c] = (int)i;  // the occurrences are counted afterwards, per class id (bf_finish)
+  else
+    pcnt[i] = cnt_by_claim[c];
 }
 
 __global__ void k_x_sort_keys(const unsigned int* __restrict__ first2, long long n,
@@ -339,11 +352,14 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
   AMGCHK(c->s2.ensure((size_t)(words + 1) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(words + 1) * sizeof(long long)));
-  HIPCHK(hipMemsetAsync(c->s1.p, 0, (size_t)words * sizeof(unsigned int), st));
-  hipLaunchKernelGGL(k_x_rank_setbits, dim3(blocks_for(n, 256)), dim3(256), 0, st, first2, n, shift,
-                     c->s1.as<unsigned int>());
-  hipLaunchKernelGGL(k_x_rank_popc, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
-                     words, c->s2.as<unsigned int>());
+  AMGCHK(c->s0.ensure((size_t)words * 32 + 64));
+  ClearList cl;
+  cl.add(c->s0.p, (size_t)words * 32);
+  AMGCHK(clear_many(c, cl));
+  hipLaunchKernelGGL(k_x_rank_setflags, dim3(blocks_for(n, 256)), dim3(256), 0, st, first2, n, shift,
+                     c->s0.as<unsigned char>());
+  hipLaunchKernelGGL(k_x_rank_words, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
+                     words, c->s1.as<unsigned int>(), c->s2.as<unsigned int>());
   return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
@@ -539,12 +555,13 @@ int bx_edges_rank(amg_ctx* c) {
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
   stage_end(c);
-  return bx_pairs_rank(c, nullptr);
+  return bx_pairs_rank(c, nullptr, nullptr);
 }
 
 // edge classes in first-seen order (pair_key / pair_first / pair_cnt) from the claims' arrays;
 // final_of_claim != nullptr: the classes are keyed by node CLAIM ids (fused table pass)
-int bx_pairs_rank(amg_ctx* c, const int* final_of_claim) {
+// efinal != nullptr: class id per claim is written there and pair_cnt is left to the caller
+int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal) {
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, P = c->n_pairs;
   stage_begin(c, "edge_rank");
@@ -554,15 +571,16 @@ int bx_pairs_rank(amg_ctx* c, const int* final_of_claim) {
   AMGCHK(c->s3.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   AMGCHK(c->s4.ensure((size_t)(P + 1) * sizeof(unsigned int)));
   const long long S = c->x_espace;
-  if (P > 0 && ((P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) || S != P)) {
+  if (P > 0 && ((P <= kRankBitmapMax && !getenv("AMG_X_RANK_SORT")) || S != P || efinal)) {
     AMGCHK(x_rank_bitmap(c, c->x_efirst.as<unsigned int>(), S, 3));
     hipLaunchKernelGGL(k_x_gather_pairs_ranked, dim3(blocks_for(S, 256)), dim3(256), 0, st,
                        c->x_efirst.as<unsigned int>(), S,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->edge_tab.as<Slot16>(),
                        c->x_eslot.as<unsigned int>(), c->x_ecnt.as<unsigned int>(),
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
-                       c->pair_cnt.as<unsigned int>(), final_of_claim);
+                       c->pair_cnt.as<unsigned int>(), final_of_claim, efinal);
   } else if (P > 0) {
+    if (efinal) return amg_fail(AMG_E_STATE, "bx_pairs_rank: class ids per claim need the bitmap ranking");
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
                        P, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());

@@ -142,6 +142,13 @@ struct amg_ctx {
   DevBuf gene_end;    // int64[n_tokens]
   DevBuf read_len;    // int64[n_reads]
   bool have_pos = false, have_read_len = false;
+  // where the positions of the CURRENT reads' genes are (amg_passes.hip, CorrArgs): offsets into
+  // gene_start / gene_end as handed to amg_set_positions (pos_n0 entries) or, from pos_n0 on, into
+  // the pool of positions the carry-over kernels produced
+  DevBuf pos_off, c_pos_off;   // int64[n_reads] (pos_identity: the read's token offset, array unused)
+  DevBuf pos1_s, pos1_e;       // int64[pos1_used]
+  bool pos_identity = true;
+  int64_t pos_n0 = 0, pos1_used = 0, c_pos1_used = 0;
   int64_t n_reads = 0, n_tokens = 0;
   int32_t two_v = 0;
 
@@ -210,6 +217,7 @@ struct amg_ctx {
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
   DevBuf f_ctrs;             // fused table pass: per-shard claim counters
+  DevBuf x_efinal;           // int32 [edge claims] claim id -> edge-class id
 
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
@@ -231,6 +239,7 @@ struct amg_ctx {
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
   DevBuf cnt_state;    // counting sweeps: per-sweep left-over counts and done flags + the hints
+  bool cnt_hint_reset = false;
 
   std::vector<StageTime> stages;
   bool timing = true;
@@ -243,6 +252,21 @@ int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
                       const unsigned int* vin, unsigned int* vout, size_t n, int end_bit);
 int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n);
 int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n);
+
+// one launch that zeroes up to 8 device ranges (a hipMemsetAsync is a kernel launch of its own: ~5 us
+// each, and a build issued ~40 of them); sizes are rounded up to 4 bytes — pad the allocations
+struct ClearList {
+  void* p[8];
+  unsigned long long bytes[8];
+  int n = 0;
+  void add(void* ptr, size_t b) {
+    if (b == 0) return;
+    p[n] = ptr;
+    bytes[n] = (unsigned long long)((b + 3) & ~(size_t)3);
+    ++n;
+  }
+};
+int clear_many(amg_ctx* c, const ClearList& l);
 
 // ------------------------------------------------------------------ stage timing
 void stage_begin(amg_ctx* c, const char* name);
@@ -273,9 +297,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
               unsigned int* out, int kind, const int* remap = nullptr);
 // counts of remap[claim] over per-window node claims (claim | AMG_LAST_FLAG, -1 none); the array is
 // rewritten to the remapped ids
-int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out);
+int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out,
+                    int edges);
 int bx_bits(const amg_ctx* c, int k);
-int bx_pairs_rank(amg_ctx* c, const int* final_of_claim);
+int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal);
 bool bf_applicable(const amg_ctx* c, int k);
 int bf_tables(amg_ctx* c, int k, int* which);
 int bf_finish(amg_ctx* c);

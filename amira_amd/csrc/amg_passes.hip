@@ -283,13 +283,29 @@ __global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double t
     if (!protect || !protect[path[j]]) kill[path[j]] = 1;
 }
 
+// (grid-stride: a thread first sums up runs of equal ids along its own nodes, so that the giant
+// component costs one atomic per WAVE of a small grid — one per wave of a node-sized grid still put
+// thousands of atomics on one address, ~90 per microsecond)
 __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* __restrict__ alive,
                             const unsigned int* __restrict__ cov, long long n, unsigned int min_cov,
                             unsigned int* __restrict__ live_cnt, unsigned int* __restrict__ high_cnt) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool active = i < n && alive[i];
-  const int cid = active ? comp[i] : -1;
-  const bool high = active && high_cnt && cov[i] >= min_cov;
+  int cid = -1;
+  unsigned int n_live = 0, n_high = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (!alive[i]) continue;
+    const int id = comp[i];
+    if (id != cid) {
+      if (cid >= 0) {
+        atomicAdd(&live_cnt[cid], n_live);
+        if (high_cnt && n_high) atomicAdd(&high_cnt[cid], n_high);
+      }
+      cid = id;
+      n_live = n_high = 0;
+    }
+    ++n_live;
+    n_high += (high_cnt && cov[i] >= min_cov) ? 1u : 0u;
+  }
+  bool active = cid >= 0;
   const int lane = threadIdx.x & 63;
   // most nodes share one giant component: aggregate equal ids inside the wave so that a
   // wave issues one atomic per distinct component instead of one per node
@@ -299,10 +315,14 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
     const int lc = __shfl(cid, leader, 64);
     const bool same = active && cid == lc;
     const unsigned long long m = __ballot(same);
-    const unsigned long long mh = __ballot(same && high);
+    unsigned int sl = same ? n_live : 0u, sh = same ? n_high : 0u;
+    for (int d = 32; d > 0; d >>= 1) {
+      sl += __shfl_xor(sl, d, 64);
+      sh += __shfl_xor(sh, d, 64);
+    }
     if (lane == leader) {
-      atomicAdd(&live_cnt[lc], (unsigned int)__popcll(m));
-      if (high_cnt && mh) atomicAdd(&high_cnt[lc], (unsigned int)__popcll(mh));
+      atomicAdd(&live_cnt[lc], sl);
+      if (high_cnt && sh) atomicAdd(&high_cnt[lc], sh);
     }
     active = active && !same;
     todo &= ~m;
@@ -311,12 +331,12 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
 
 __global__ void k_cov_sum(const unsigned int* __restrict__ cov, const unsigned char* __restrict__ alive,
                           long long n, unsigned long long* out /*[2]: sum, count*/) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long s = 0, c = 0;
-  if (i < n && alive[i]) {
-    s = cov[i];
-    c = 1;
-  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (alive[i]) {
+      s += cov[i];
+      c += 1;
+    }
   for (int d = 32; d > 0; d >>= 1) {
     s += __shfl_down(s, d, 64);
     c += __shfl_down(c, d, 64);
@@ -381,7 +401,7 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   // mean node coverage (:868-871): statistics.mean over live nodes, * 1.5 in double
   unsigned long long* acc = c->status.as<unsigned long long>() + ST_COMPACT_A;
   HIPCHK(hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(k_cov_sum, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_cov.as<unsigned int>(),
+  hipLaunchKernelGGL(k_cov_sum, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_cov.as<unsigned int>(),
                      c->node_alive.as<unsigned char>(), D, acc);
   unsigned long long h[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -393,7 +413,7 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
   HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)D + 8, st));
   HIPCHK(hipMemsetAsync(c->s4.p, 0, (size_t)(c->n_components + 2) * sizeof(unsigned int), st));
-  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
+  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
                      c->s4.as<unsigned int>(), (unsigned int*)nullptr);
   unsigned char* d_protect = nullptr;
@@ -431,7 +451,7 @@ extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t min_cov) 
   HIPCHK(hipMemsetAsync(c->s4.p, 0, 2 * nc * sizeof(unsigned int), st));
   unsigned int* live = c->s4.as<unsigned int>();
   unsigned int* high = live + nc;
-  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
+  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, min_cov, live, high);
   hipLaunchKernelGGL(k_kill_low_components, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), high, D, c->s0.as<unsigned char>());
@@ -462,8 +482,17 @@ struct CorrArgs {
   const int* tok_node;
   const signed char* tok_dir;
   const unsigned char* read_fix;
-  const long long* gstart;
-  const long long* gend;
+  // gene positions are NOT moved with the genes when reads are corrected: a read carries an offset
+  // (pos_off[r]; nullptr = its token offset) into one of two pools — the caller's arrays as handed to
+  // amg_set_positions (indices < n0) or the positions the carry-over kernels produced (p1*, indices
+  // from n0 on).  An untouched read keeps its offset, a trimmed one adds its start, a re-threaded one
+  // points at its new positions; the corrected set is gathered only when the host asks for it.
+  const long long* p0s;
+  const long long* p0e;
+  const long long* p1s;
+  const long long* p1e;
+  long long n0;
+  const long long* pos_off;
   const long long* read_len;
   long long n_reads;
   int k, flip, have_pos;
@@ -479,6 +508,17 @@ struct CorrArgs {
   // staged genes of the re-threaded reads
   int* tmp_tok;
 };
+
+// positions of the genes that start at pool index `off`
+__device__ __forceinline__ void pos_base(const CorrArgs& a, long long off, const long long*& gs, const long long*& ge) {
+  if (off < a.n0) {
+    gs = a.p0s + off;
+    ge = a.p0e + off;
+  } else {
+    gs = a.p1s + (off - a.n0);
+    ge = a.p1e + (off - a.n0);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
   const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * READS_PER_WAVE;
@@ -1185,8 +1225,8 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
 struct __attribute__((aligned(16))) NwRec {
   int r, M, N, pad;
   long long t0, dst;  // first token of the read, first staged gene of its corrected version
-  long long pdst;     // first gene of the read in the CORRECTED set (positions are written in place)
-  long long pad2;
+  long long pdst;     // where the read's new positions go in the pool of produced positions
+  long long poff;     // pool index of the read's ORIGINAL positions
 };
 
 struct NwArgs {
@@ -1220,6 +1260,8 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
   const long long dst = a.tmp_off[r];
   const int* x = a.tmp_tok + dst;
   const int* y = a.tokens + t0;
+  const long long *ogs, *oge;
+  pos_base(a, A.rec[gi].poff, ogs, oge);
   unsigned char* P = s_ptr;
   int* dg = s_diag;
   unsigned char* ops = s_ops;
@@ -1277,8 +1319,8 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
     unsigned char p = ops[o];
     if (p == 0) {
       if (x[xi] == y[yj]) {
-        A.o_gs[pdst + out] = a.gstart[t0 + cur];
-        A.o_ge[pdst + out] = a.gend[t0 + cur];
+        A.o_gs[pdst + out] = ogs[cur];
+        A.o_ge[pdst + out] = oge[cur];
         ++cur;
       } else {
         A.o_gs[pdst + out] = NONE;
@@ -1349,8 +1391,10 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   const int x0 = lane < N ? a.tmp_tok[dst + lane] : -2;            // corrected genes 0..63
   const int x1 = lane + 64 < N ? a.tmp_tok[dst + lane + 64] : -2;  // and 64..127, one per lane
   const int yj = lane < M ? a.tokens[t0 + lane] : -1;
-  const long long ogs = lane < M ? a.gstart[t0 + lane] : 0;
-  const long long oge = lane < M ? a.gend[t0 + lane] : 0;
+  const long long *pgs, *pge;
+  pos_base(a, q.poff, pgs, pge);
+  const long long ogs = lane < M ? pgs[lane] : 0;
+  const long long oge = lane < M ? pge[lane] : 0;
   if (lane < N) X[lane] = x0;
   if (lane + 64 < N) X[lane + 64] = x1;
   OGS[lane] = ogs;
@@ -1533,15 +1577,15 @@ struct PackArgs {
   long long* o_off;
   int* o_orig;
   unsigned char* o_changed;
-  long long* o_gs;
-  long long* o_ge;
+  const long long* pos_new;  // per read: pool index of a re-threaded read's new positions
+  long long* o_posoff;       // per corrected read: pool index of its positions
   long long* o_rl;
 };
 
 // One wave packs PACK_READS consecutive reads: the per-read records of all of them are loaded
-// first, then every gene load is issued before the first store, so that each wave keeps
-// PACK_READS x 20 bytes per lane in flight (a read of 60 genes alone is a 1.2 KB copy: one read
-// per wave leaves the copy latency-bound at a third of the HBM rate).
+// first, then every gene load is issued before the first store (a read of 60 genes alone is a
+// 240-byte copy: one read per wave leaves it latency-bound).  Gene positions stay where they are:
+// the corrected read only records where its positions begin (CorrArgs).
 #define PACK_READS 4
 __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   const CorrArgs& a = A.a;
@@ -1549,8 +1593,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   const int lane = threadIdx.x & 63;
   long long dst[PACK_READS], n[PACK_READS];
   const int* stok[PACK_READS];
-  const long long* sgs[PACK_READS];
-  const long long* sge[PACK_READS];
+  long long poff[PACK_READS];
   unsigned char fcs[PACK_READS];
 #pragma unroll
   for (int j = 0; j < PACK_READS; ++j) {
@@ -1558,53 +1601,34 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
     n[j] = 0;
     dst[j] = 0;
     stok[j] = a.tokens;
-    sgs[j] = a.gstart;
-    sge[j] = a.gend;
+    poff[j] = 0;
     fcs[j] = RC_SKIP;
     if (r < a.n_reads && A.keep[r]) {
       dst[j] = A.new_off[r];
       n[j] = a.new_len[r];
       fcs[j] = A.final_cls[r];
       if (fcs[j] == RC_GAPPED) {  // re-threaded read: genes staged in the temp area, positions
-        const long long src = a.tmp_off[r];  // already written in place by the carry-over kernels
+        const long long src = a.tmp_off[r];  // written to the pool by the carry-over kernels
         stok[j] = a.tmp_tok + src;
+        if (a.have_pos) poff[j] = A.pos_new[r];
       } else {  // untouched read, kept original, or a slice [start : end + k] of it (:1277-1285)
-        const long long src = a.read_off[r] + (fcs[j] == RC_TRIM ? a.r_start[r] : 0);
-        stok[j] = a.tokens + src;
-        sgs[j] = a.gstart + src;
-        sge[j] = a.gend + src;
+        const long long cut = fcs[j] == RC_TRIM ? a.r_start[r] : 0;
+        stok[j] = a.tokens + a.read_off[r] + cut;
+        if (a.have_pos) poff[j] = (a.pos_off ? a.pos_off[r] : a.read_off[r]) + cut;
       }
     }
   }
   int vt[PACK_READS];
-  long long vs[PACK_READS], ve[PACK_READS];
 #pragma unroll
   for (int j = 0; j < PACK_READS; ++j)
-    if (lane < n[j]) {
-      vt[j] = stok[j][lane];
-      if (a.have_pos && fcs[j] != RC_GAPPED) {
-        vs[j] = sgs[j][lane];
-        ve[j] = sge[j][lane];
-      }
-    }
+    if (lane < n[j]) vt[j] = stok[j][lane];
 #pragma unroll
   for (int j = 0; j < PACK_READS; ++j)
-    if (lane < n[j]) {
-      A.o_tok[dst[j] + lane] = vt[j];
-      if (a.have_pos && fcs[j] != RC_GAPPED) {
-        A.o_gs[dst[j] + lane] = vs[j];
-        A.o_ge[dst[j] + lane] = ve[j];
-      }
-    }
+    if (lane < n[j]) A.o_tok[dst[j] + lane] = vt[j];
 #pragma unroll
   for (int j = 0; j < PACK_READS; ++j)
-    for (long long i = 64 + lane; i < n[j]; i += 64) {  // reads longer than one wave
+    for (long long i = 64 + lane; i < n[j]; i += 64)  // reads longer than one wave
       A.o_tok[dst[j] + i] = stok[j][i];
-      if (a.have_pos && fcs[j] != RC_GAPPED) {
-        A.o_gs[dst[j] + i] = sgs[j][i];
-        A.o_ge[dst[j] + i] = sge[j][i];
-      }
-    }
 #pragma unroll
   for (int j = 0; j < PACK_READS; ++j) {
     const long long r = rbase + j;
@@ -1613,6 +1637,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
       A.o_off[q] = dst[j];
       A.o_orig[q] = (int)r;
       A.o_changed[q] = (fcs[j] == RC_TRIM || fcs[j] == RC_GAPPED) ? 1 : 0;
+      if (a.have_pos) A.o_posoff[q] = poff[j];
       if (a.read_len) A.o_rl[q] = a.read_len[r];
     }
   }
@@ -1642,7 +1667,8 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
                            const long long* __restrict__ read_off, const unsigned int* __restrict__ new_len,
                            const long long* __restrict__ tmp_off, const long long* __restrict__ new_off,
                            const unsigned char* __restrict__ final_cls, long long* __restrict__ size,
-                           int allow_fast, unsigned long long* n_general, NwRec* __restrict__ rec) {
+                           int allow_fast, unsigned long long* n_general, NwRec* __restrict__ rec,
+                           const long long* __restrict__ pos_off, long long* __restrict__ plen) {
   long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= n_gapped) return;
   long long r = gapped[gi];
@@ -1657,9 +1683,10 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
     q.pad = 0;
     q.t0 = read_off[r];
     q.dst = tmp_off[r];
-    q.pdst = new_off[r];
-    q.pad2 = 0;
+    q.pdst = 0;  // k_nw_place
+    q.poff = pos_off ? pos_off[r] : read_off[r];
     rec[gi] = q;
+    plen[gi] = final_cls[r] != RC_KEEP_ORIG ? N : 0;  // new positions of this read
   }
   bool small = (N <= NW_LDS_N && M <= NW_LDS_N && N * M <= NW_LDS_CELLS);
   long long bytes = 0;
@@ -1669,6 +1696,53 @@ __global__ void k_nw_sizes(const int* __restrict__ gapped, long long n_gapped,
   if (final_cls[r] != RC_KEEP_ORIG && !(allow_fast && nw_fast_ok(N, M))) atomicAdd(n_general, 1ull);
 }
 
+
+// where the new positions of gapped read gi go (pool of produced positions, after `base`)
+__global__ void k_nw_place(long long n_gapped, const long long* __restrict__ poffs, long long base, long long n0,
+                           NwRec* __restrict__ rec, long long* __restrict__ pos_new) {
+  long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= n_gapped) return;
+  const long long at = base + poffs[gi];
+  rec[gi].pdst = at;
+  pos_new[rec[gi].r] = n0 + at;
+}
+
+// positions of the corrected set, gathered from the pools (only when the host asks for them)
+__global__ __launch_bounds__(256) void k_gather_positions(CorrArgs a, const long long* __restrict__ c_off,
+                                                          const long long* __restrict__ c_posoff, long long c_reads,
+                                                          long long* __restrict__ o_gs, long long* __restrict__ o_ge) {
+  const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= c_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long a0 = c_off[q], n = c_off[q + 1] - a0;
+  const long long *gs, *ge;
+  pos_base(a, c_posoff[q], gs, ge);
+  for (long long i = lane; i < n; i += 64) {
+    o_gs[a0 + i] = gs[i];
+    o_ge[a0 + i] = ge[i];
+  }
+}
+
+// device allocation that keeps its first `used` bytes when it has to grow
+static int grow_keep(amg_ctx* c, DevBuf& b, size_t need, size_t used) {
+  if (need <= b.cap && !b.borrowed) return AMG_OK;
+  DevBuf nb;
+  AMGCHK(nb.ensure(need + need / 2));
+  if (used && b.p) HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  b.release();
+  b = nb;
+  return AMG_OK;
+}
+
+static void fill_pos_args(amg_ctx* c, CorrArgs& a) {
+  a.p0s = c->have_pos ? c->gene_start.as<long long>() : nullptr;
+  a.p0e = c->have_pos ? c->gene_end.as<long long>() : nullptr;
+  a.p1s = c->pos1_s.as<long long>();
+  a.p1e = c->pos1_e.as<long long>();
+  a.n0 = c->pos_n0;
+  a.pos_off = (c->have_pos && !c->pos_identity) ? c->pos_off.as<long long>() : nullptr;
+}
 
 extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_out_tokens) {
   NEED_BUILT(c);
@@ -1699,8 +1773,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.tok_node = c->tok_node.as<int>();
   a.tok_dir = c->tok_dir.as<signed char>();
   a.read_fix = c->read_fix.as<unsigned char>();
-  a.gstart = c->have_pos ? c->gene_start.as<long long>() : nullptr;
-  a.gend = c->have_pos ? c->gene_end.as<long long>() : nullptr;
+  fill_pos_args(c, a);
   a.read_len = c->have_read_len ? c->read_len.as<long long>() : nullptr;
   a.n_reads = R;
   a.k = c->k;
@@ -1817,9 +1890,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   HIPCHK(hipMemcpyAsync(&out_reads, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&out_tokens, new_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
   const bool carry = n_gapped > 0 && c->have_pos;
-  long long big_total = 0;
+  long long big_total = 0, pos_total = 0;
   unsigned long long n_general = 0;
   long long* nw_off = nullptr;
+  long long *plen = nullptr, *poffs = nullptr, *pos_new = nullptr;
   const char* nfn = getenv("AMG_NO_FAST_NW");
   const int allow_fast = !(nfn && nfn[0] == '1');
   if (carry) {
@@ -1827,15 +1901,27 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     long long* nw_size = reinterpret_cast<long long*>(
         ((uintptr_t)(c->s1.as<int>() + 2 * per_read) + 15) & ~(uintptr_t)15);
     nw_off = nw_size + per_read;
-    HIPCHK(hipMemsetAsync(nw_size, 0, (size_t)(n_gapped + 1) * sizeof(long long), st));
+    // per gapped read: number of new positions and their place in the pool; per read: pool index
+    AMGCHK(c->s5.ensure((size_t)(2 * (n_gapped + 2) + R + 2) * sizeof(long long)));
+    plen = c->s5.as<long long>();
+    poffs = plen + (n_gapped + 2);
+    pos_new = poffs + (n_gapped + 2);
     unsigned long long* n_general_d = c->status.as<unsigned long long>() + ST_MISC;
-    HIPCHK(hipMemsetAsync(n_general_d, 0, sizeof(unsigned long long), st));
+    {
+      ClearList cl;
+      cl.add(nw_size, (size_t)(n_gapped + 1) * sizeof(long long));
+      cl.add(plen, (size_t)(n_gapped + 1) * sizeof(long long));
+      cl.add(n_general_d, sizeof(unsigned long long));
+      AMGCHK(clear_many(c, cl));
+    }
     AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
     hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
                        n_gapped, a.read_off, new_len, tmp_off, new_off, final_cls, nw_size, allow_fast,
-                       n_general_d, c->nw_rec.as<NwRec>());
+                       n_general_d, c->nw_rec.as<NwRec>(), a.pos_off, plen);
     AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
+    AMGCHK(prim_exscan_i64(c, plen, poffs, (size_t)n_gapped + 1));
     HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&pos_total, poffs + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&n_general, n_general_d, sizeof(n_general), hipMemcpyDeviceToHost, st));
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -1846,20 +1932,26 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   AMGCHK(c->c_read_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   AMGCHK(c->c_orig.ensure((size_t)(out_reads + 2) * sizeof(int)));
   AMGCHK(c->c_changed.ensure((size_t)(out_reads + 2)));
-  if (c->have_pos) {
-    AMGCHK(c->c_gstart.ensure((size_t)(out_tokens + 64) * sizeof(long long)));
-    AMGCHK(c->c_gend.ensure((size_t)(out_tokens + 64) * sizeof(long long)));
-  }
+  if (c->have_pos) AMGCHK(c->c_pos_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   if (c->have_read_len) AMGCHK(c->c_read_len.ensure((size_t)(out_reads + 2) * sizeof(long long)));
 
   if (carry) {
     stage_begin(c, "correct_positions");
     AMGCHK(c->nw_big.ensure((size_t)big_total + 64));
+    // the pool of produced positions grows by what this correction adds (earlier entries stay:
+    // reads corrected before keep pointing at them)
+    const size_t used = (size_t)c->pos1_used * sizeof(long long);
+    const size_t need = (size_t)(c->pos1_used + pos_total + 64) * sizeof(long long);
+    AMGCHK(grow_keep(c, c->pos1_s, need, used));
+    AMGCHK(grow_keep(c, c->pos1_e, need, used));
+    fill_pos_args(c, a);
+    hipLaunchKernelGGL(k_nw_place, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, n_gapped, poffs,
+                       (long long)c->pos1_used, (long long)c->pos_n0, c->nw_rec.as<NwRec>(), pos_new);
     NwArgs W;
     W.a = a;
     W.rec = c->nw_rec.as<NwRec>();
-    W.o_gs = c->c_gstart.as<long long>();
-    W.o_ge = c->c_gend.as<long long>();
+    W.o_gs = c->pos1_s.as<long long>();
+    W.o_ge = c->pos1_e.as<long long>();
     W.gapped_reads = nullptr;  // the records carry the read ids
     W.n_gapped = n_gapped;
     W.final_cls = final_cls;
@@ -1885,8 +1977,8 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   Pk.o_off = c->c_read_off.as<long long>();
   Pk.o_orig = c->c_orig.as<int>();
   Pk.o_changed = c->c_changed.as<unsigned char>();
-  Pk.o_gs = c->have_pos ? c->c_gstart.as<long long>() : nullptr;
-  Pk.o_ge = c->have_pos ? c->c_gend.as<long long>() : nullptr;
+  Pk.pos_new = pos_new;
+  Pk.o_posoff = c->have_pos ? c->c_pos_off.as<long long>() : nullptr;
   Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
   if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
   HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
@@ -1895,6 +1987,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   stage_end(c);
   c->c_reads = out_reads;
   c->c_tokens = out_tokens;
+  c->c_pos1_used = c->pos1_used + (carry ? pos_total : 0);  // becomes current with amg_adopt_corrected
   c->have_corrected = true;
   if (n_out_reads) *n_out_reads = out_reads;
   if (n_out_tokens) *n_out_tokens = out_tokens;
@@ -1916,7 +2009,15 @@ extern "C" int amg_get_corrected(amg_ctx* c, int32_t* tokens, int64_t* read_offs
   AMGCHK(get(read_offsets, c->c_read_off, (size_t)(c->c_reads + 1) * sizeof(int64_t)));
   AMGCHK(get(orig_read, c->c_orig, (size_t)c->c_reads * sizeof(int32_t)));
   AMGCHK(get(changed, c->c_changed, (size_t)c->c_reads));
-  if (c->have_pos) {
+  if (c->have_pos && (gene_start || gene_end) && c->c_tokens > 0) {
+    AMGCHK(c->c_gstart.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+    AMGCHK(c->c_gend.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+    CorrArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_pos_args(c, a);
+    hipLaunchKernelGGL(k_gather_positions, dim3(nblk(c->c_reads, 4)), dim3(256), 0, st, a,
+                       c->c_read_off.as<long long>(), c->c_pos_off.as<long long>(), (long long)c->c_reads,
+                       c->c_gstart.as<long long>(), c->c_gend.as<long long>());
     AMGCHK(get(gene_start, c->c_gstart, (size_t)c->c_tokens * sizeof(int64_t)));
     AMGCHK(get(gene_end, c->c_gend, (size_t)c->c_tokens * sizeof(int64_t)));
   }
@@ -1927,13 +2028,16 @@ extern "C" int amg_get_corrected(amg_ctx* c, int32_t* tokens, int64_t* read_offs
 extern "C" int amg_adopt_corrected(amg_ctx* c) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
-  // borrowed inputs go back to their owner: the corrected set lives in our own allocations
-  for (DevBuf* b : {&c->tokens, &c->read_off, &c->gene_start, &c->gene_end, &c->read_len}) b->unborrow();
+  // borrowed genes / offsets / lengths go back to their owner: the corrected set lives in our own
+  // allocations.  The position arrays stay where they are (borrowed or not): corrected reads point
+  // into them and into the pool of produced positions.
+  for (DevBuf* b : {&c->tokens, &c->read_off, &c->read_len}) b->unborrow();
   std::swap(c->tokens, c->c_tokens_buf);
   std::swap(c->read_off, c->c_read_off);
   if (c->have_pos) {
-    std::swap(c->gene_start, c->c_gstart);
-    std::swap(c->gene_end, c->c_gend);
+    std::swap(c->pos_off, c->c_pos_off);
+    c->pos_identity = false;
+    c->pos1_used = c->c_pos1_used;
   }
   if (c->have_read_len) std::swap(c->read_len, c->c_read_len);
   c->n_reads = c->c_reads;

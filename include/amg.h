@@ -103,7 +103,10 @@ int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offse
                   int64_t n_reads, int32_t two_v, int on_device);
 /* optional: per-gene [start,end] and per-read sequence length, used only by
  * amg_correct_reads to carry gene positions (construct_graph.py:1311-1328,1669-1691).
- * read_len may be NULL when no read will need position inference. */
+ * read_len may be NULL when no read will need position inference.
+ * Call it after amg_set_reads of the same read set.  BORROWED position arrays (on_device = 2) are
+ * read until the next amg_set_positions / amg_set_reads, across amg_adopt_corrected: corrected
+ * reads keep pointing at the positions of their unchanged genes instead of copying them. */
 int amg_set_positions(amg_ctx* ctx, const int64_t* gene_start, const int64_t* gene_end,
                       const int64_t* read_len, int on_device);
 
