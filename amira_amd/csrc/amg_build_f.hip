@@ -426,8 +426,14 @@ int bx_bits(const amg_ctx* c, int k) {
 
 bool bf_applicable(const amg_ctx* c, int k) {
   if (!bx_applicable(c, k)) return false;
-  const char* e = getenv("AMG_FUSED");  // A/B + test switch: "0" = the two table passes of amg_build_x.hip
-  if (e && e[0] == '0') return false;
+  // Measured (DESIGN.md "One table pass or two"): the fused pass costs as many wave-cycles as the two
+  // passes together — a tile's time is its chain of dependent L2 / fabric round trips, which fusion
+  // does not shorten — while both tables' hot lines now compete for the same 4 MB of L2 per XCD
+  // (misses 30 M -> 62 M per pass) and the per-window node ids need a remap in the counting sweep.
+  // cfg 3 sweep: 15.5 ms fused against 14.2 ms with two passes.  It is therefore OFF unless
+  // AMG_FUSED=1 asks for it (tests run both).
+  const char* e = getenv("AMG_FUSED");
+  if (!(e && e[0] == '1')) return false;
   if (getenv("AMG_X_RANK_SORT")) return false;  // test switch of the two-pass path's sort ranking
   return c->n_tokens < (1ll << 29);  // claims carry two flag bits in the LDS exchange
 }
