@@ -13,12 +13,13 @@ from collections import deque
 from itertools import product
 
 from . import paths as pf
+from .bubbles import BubbleMixin
 from .values import Edge, GeneMer, Node, Read, _INT2STR
 
 sys.setrecursionlimit(50000)  # construct_graph.py:27
 
 
-class GeneMerGraph:
+class GeneMerGraph(BubbleMixin):
     # ------------------------------------------------------------------ build
     def __init__(self, readDict, kmerSize, gene_positions=None):
         # construct_graph.py:31-102
@@ -504,6 +505,9 @@ class GeneMerGraph:
 
     def get_mean_node_coverage(self):
         return statistics.mean(self.get_all_node_coverages())
+
+    def calculate_mean_node_coverage(self):
+        return statistics.mean(self.get_all_node_coverages())  # :2565-2569
 
     def get_AMR_nodes(self, genes):
         out = {}
