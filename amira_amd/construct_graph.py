@@ -30,6 +30,7 @@ from itertools import product
 import numpy as np
 
 from . import _ffi
+from .bubble_popping import BubblePopping
 from .construct_edge import Edge
 from .construct_gene import Gene, convert_int_strand_to_string, hashlib_hash
 from .construct_gene_mer import GeneMer
@@ -66,9 +67,10 @@ class _LazyReadLists(Mapping):
             got = self._cache[rid] = self._make(r)
         return got
 
-    def __setitem__(self, rid, value):  # remove_node_from_reads-style updates by callers
-        if rid not in self._index:
-            raise KeyError(rid)
+    def __setitem__(self, rid, value):  # remove_node_from_reads / add_node_to_read style updates
+        if rid not in self._index:   # a read the build did not see (add_node_to_read, :165-178)
+            self._index[rid] = None
+            self._ids.append(rid)
         self._cache[rid] = value
 
     def __iter__(self):
@@ -106,7 +108,7 @@ class _View:
                  "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
 
 
-class GeneMerGraph:
+class GeneMerGraph(BubblePopping):
     # ------------------------------------------------------------------ build
     def __init__(self, readDict, kmerSize, gene_positions=None, device=None):
         self._reads = readDict
@@ -115,6 +117,7 @@ class GeneMerGraph:
         self._minEdgeCoverage = 1
         self._genePositions = gene_positions
         self._view = None
+        self._host_edits = False   # add_node / add_edge / remove_edge ... changed the host view
         self._extra_to_correct = set()
         self._gene_cache = {}
         dev = int(os.environ.get("AMG_DEVICE", "0")) if device is None else int(device)
@@ -159,6 +162,14 @@ class GeneMerGraph:
     # ------------------------------------------------------------------ view plumbing
     def _invalidate(self):
         self._view = None
+
+    def _device_pass(self, what):
+        """The incremental mutators of the reference class (add_node, add_edge, remove_edge,
+        remove_node_from_reads, ... — used by its unit tests and its multi-process merge) edit the
+        HOST view only; the device arrays no longer describe that graph, so device passes refuse it."""
+        if self._host_edits:
+            raise RuntimeError(f"{what}: this graph was edited through add_node / add_edge / remove_edge on the "
+                               "host; build a GeneMerGraph from reads to run device passes")
 
     def _gene_obj(self, token):
         g = self._gene_cache.get(token)
@@ -362,6 +373,121 @@ class GeneMerGraph:
         mask = np.isin(nt, np.asarray(toks, dtype=nt.dtype)).any(axis=1) & (v.alive != 0)
         return np.nonzero(mask)[0].tolist()
 
+    # ------------------------------------------------------------------ incremental construction (:165-324)
+    # The reference builds its graph through these calls; here the device builds it and they remain
+    # for callers that edit a graph by hand (the reference's unit tests, its multi-process merge).
+    # They work on the materialised host view and switch the graph to host-only (_device_pass).
+    def add_node_to_read(self, node, readId, node_direction, node_position=None):
+        v = self._v()
+        self._host_edits = True
+        if readId not in v.readNodes:
+            v.readNodes[readId], v.readNodeDirections[readId], v.readNodePositions[readId] = [], [], []
+        v.readNodes[readId].append(node.__hash__())
+        v.readNodeDirections[readId].append(node_direction)
+        v.readNodePositions[readId].append(node_position)
+        return v.readNodes[readId]
+
+    def add_node_to_nodes(self, node, nodeHash):
+        self._host_edits = True
+        self._v().nodes[nodeHash] = node
+
+    def add_node(self, geneMer, reads):
+        """insert-or-find by hash; the first GeneMer object seen stays on the node (:196-212)"""
+        nodes = self._v().nodes
+        h = geneMer.__hash__()
+        node = nodes.get(h)
+        if node is None:
+            node = _GraphNode(geneMer)
+            node._lazy(None)
+            node.listOfReads = []
+            self.add_node_to_nodes(node, h)
+        for r in reads:
+            node.add_read(r)
+            self._host_edits = True
+        return node
+
+    def create_edges(self, sourceNode, targetNode, sourceGeneMerDirection, targetGeneMerDirection):
+        """the adjacency as seen from either end: (A, B, dA, dB) and (B, A, -dB, -dA) (:246-262)"""
+        return (Edge(sourceNode, targetNode, sourceGeneMerDirection, targetGeneMerDirection),
+                Edge(targetNode, sourceNode, targetGeneMerDirection * -1, sourceGeneMerDirection * -1))
+
+    def add_edge_to_edges(self, edge):
+        edges = self._v().edges
+        h = edge.__hash__()
+        if h not in edges:   # the first object of a class is the one that stays (:268-277)
+            self._host_edits = True
+            edges[h] = edge
+        return edges[h]
+
+    def add_edges_to_graph(self, sourceToTargetEdge, reverseTargetToSourceEdge):
+        return self.add_edge_to_edges(sourceToTargetEdge), self.add_edge_to_edges(reverseTargetToSourceEdge)
+
+    def add_edge_to_node(self, node, edge):
+        """forward or backward list by the STORED edge's source direction (:287-298)"""
+        self._host_edits = True
+        if edge.get_sourceNodeDirection() == 1:
+            node.add_forward_edge_hash(edge.__hash__())
+        if edge.get_sourceNodeDirection() == -1:
+            node.add_backward_edge_hash(edge.__hash__())
+        return node
+
+    def add_edge(self, sourceGeneMer, targetGeneMer):
+        sourceNode = self.add_node(sourceGeneMer, [])
+        targetNode = self.add_node(targetGeneMer, [])
+        forward, backward = self.add_edges_to_graph(*self.create_edges(
+            sourceNode, targetNode, sourceGeneMer.get_geneMerDirection(), targetGeneMer.get_geneMerDirection()))
+        self.add_edge_to_node(sourceNode, forward)
+        self.add_edge_to_node(targetNode, backward)
+        return forward, backward
+
+    def remove_edge_from_edges(self, edgeHash):
+        self._host_edits = True
+        del self._v().edges[edgeHash]
+
+    def remove_edge(self, edgeHash):
+        """drop an edge from the graph and from its source node's list; unknown hashes are ignored (:409-428)"""
+        edges = self._v().edges
+        if edgeHash not in edges:
+            return
+        edge = edges[edgeHash]
+        source = edge.get_sourceNode()
+        if edge.get_sourceNodeDirection() == 1:
+            source.remove_forward_edge_hash(edgeHash)
+        if edge.get_sourceNodeDirection() == -1:
+            source.remove_backward_edge_hash(edgeHash)
+        self.remove_edge_from_edges(edgeHash)
+
+    def remove_node_from_reads(self, node_to_remove):
+        """every occurrence of the node becomes None on its reads, which join the reads to correct (:442-461)"""
+        v = self._v()
+        self._host_edits = True
+        h = node_to_remove.__hash__()
+        for read_id in node_to_remove.get_reads():
+            keep = [x != h for x in v.readNodes[read_id]]
+            for lists in (v.readNodes, v.readNodeDirections, v.readNodePositions):
+                lists[read_id] = [x if k else None for x, k in zip(lists[read_id], keep)]
+            self._extra_to_correct.add(read_id)
+
+    def dfs_component(self, start, component_id, visited=None):
+        visited = set() if visited is None else visited
+        visited.add(start.__hash__())
+        start.set_component(component_id)
+        for neighbor in self.get_all_neighbors(start):
+            if neighbor.__hash__() not in visited:
+                self.dfs_component(neighbor, component_id, visited)
+
+    def assign_component_ids(self):
+        """component ids 1, 2, ... in order of each component's first node (:920-927); the device
+        build has already done this — the method re-labels the host view (after host edits)"""
+        visited, component_id = set(), 1
+        for h, node in self.get_nodes().items():
+            if h not in visited:
+                self.dfs_component(node, component_id, visited)
+                component_id += 1
+
+    def calculate_mean_node_coverage(self):
+        return statistics.mean(self.get_all_node_coverages())
+
     # ------------------------------------------------------------------ topology (:326-400)
     def get_degree(self, node):
         return len(node.get_forward_edge_hashes()) + len(node.get_backward_edge_hashes())
@@ -412,6 +538,14 @@ class GeneMerGraph:
         h = node.__hash__()
         assert h in self.get_nodes(), "This node is not in the graph"
         assert node == self.get_node_by_hash(h)
+        if self._host_edits:   # host-edited graph: the reference's own steps on the view
+            self.remove_node_from_reads(node)
+            for edge_hash in set(node.get_forward_edge_hashes() + node.get_backward_edge_hashes()):
+                target = self.get_edge_by_hash(edge_hash).get_targetNode()
+                for e in self.get_edge_hashes_between_nodes(node, target):
+                    self.remove_edge(e)
+            del self.get_nodes()[h]
+            return
         self._engine.remove_nodes([self._node_id(h)])
         self._invalidate()
 
@@ -436,6 +570,7 @@ class GeneMerGraph:
         """device coverage filter: nodes with coverage < minNodeCoverage, edges with coverage
         < minEdgeCoverage or a removed endpoint; reads through removed nodes are masked and
         queued for correction (:523-540)."""
+        self._device_pass("filter_graph")
         self.set_minNodeCoverage(minNodeCoverage)
         self.set_minEdgeCoverage(minEdgeCoverage)
         self._engine.filter(max(int(minNodeCoverage), 0), max(int(minEdgeCoverage), 0))
@@ -443,11 +578,13 @@ class GeneMerGraph:
         return self
 
     def remove_low_coverage_components(self, min_component_coverage):
+        self._device_pass("remove_low_coverage_components")
         self._engine.remove_low_coverage_components(max(int(min_component_coverage), 0))
         self._invalidate()
 
     def remove_short_linear_paths(self, min_length, sample_genesOfInterest={}):
         """tip clipping on the device (:679-720); returns the hashes of the removed nodes."""
+        self._device_pass("remove_short_linear_paths")
         protect = None
         if sample_genesOfInterest:
             ids = self._node_ids_containing(list(sample_genesOfInterest))
@@ -501,6 +638,7 @@ class GeneMerGraph:
         (corrected gene calls, corrected gene positions) like the reference: untouched reads
         keep their original list objects, reads whose nodes were all removed disappear,
         self._genePositions is updated in place for changed reads."""
+        self._device_pass("correct_reads")
         eng, vocab = self._engine, self._vocab
         have_pos = bool(self._genePositions)
         if have_pos:
@@ -529,6 +667,69 @@ class GeneMerGraph:
             if have_pos:
                 corrected_gene_positions[read_id] = self._genePositions[read_id]
         return corrected_genes, corrected_gene_positions
+
+    def correct_single_read(self, read_id, readNodes, fastq_data):
+        """host twin of one read of the device correction (:1136-1151), for callers that correct a
+        single read by hand; correct_reads runs all of them on the device"""
+        if read_id not in self.get_reads_to_correct():
+            return self.get_reads()[read_id]
+        if all(n is None for n in readNodes[read_id]):
+            return []
+        start, end = self.find_read_boundaries(readNodes[read_id])
+        new_genes_on_read = self.process_read_correction(read_id, readNodes, start, end, fastq_data)
+        if self.get_gene_positions():
+            assert len(new_genes_on_read) == len(self.get_gene_positions()[read_id])
+        return new_genes_on_read
+
+    def generate_replacement_dict(self, corrected, pair):
+        first, last = pair
+        return {pair: self.new_find_paths_between_nodes(corrected[first][0], corrected[last][0],
+                                                        self.get_kmerSize() * 2, corrected[first][1])}
+
+    def get_possible_paths(self, nodes_on_read, replacementDict, start, end):
+        """every way of filling the read's None runs, as (node hashes, directions); windows without a
+        node are skipped (the reference's upstream / downstream extension is disabled, :1205-1263)"""
+        return [([n for n, _ in filled if n], [d for n, d in filled if n])
+                for filled in self.insert_elements(nodes_on_read, replacementDict)]
+
+    def process_read_correction(self, read_id, readNodes, start, end, fastq_data):
+        k = self.get_kmerSize()
+        directions = self.get_readNodeDirections()[read_id]
+        nodes_on_read = [(readNodes[read_id][i], directions[i]) for i in range(len(readNodes[read_id]))]
+        path_terminals = self.identify_path_terminals(readNodes[read_id], start, end)
+        if len(path_terminals) == 0:   # only the ends were lost: slice genes and positions
+            if self.get_gene_positions():
+                self.get_gene_positions()[read_id] = self.get_gene_positions()[read_id][start:end + k]
+            kept = nodes_on_read[start:end + 1]
+            return self.get_annotation_for_read([n for n, _ in kept], [d for _, d in kept], read_id)
+        replacementDict = {}
+        for pair in path_terminals:
+            replacementDict.update(self.generate_replacement_dict(nodes_on_read, pair))
+        possible_paths = self.get_possible_paths(nodes_on_read, replacementDict, start, end)
+        if possible_paths == []:
+            return self.get_reads()[read_id]
+        original = self.get_reads()[read_id]
+        best_shared, best_coverage = 0, 0
+        for nodes, dirs in possible_paths:   # most shared genes, then strictly higher mean coverage
+            coverage = self.get_coverage_of_path(nodes)
+            genes = self.get_annotation_for_read(nodes, dirs, read_id)
+            shared = len(set(genes).intersection(original))
+            if shared > best_shared or (shared == best_shared and coverage > best_coverage):
+                closest, best_shared, best_coverage = genes, shared, coverage
+        old_positions, taken, new_positions = self.get_gene_positions()[read_id], 0, []
+        for new_gene, old_gene in self.needleman_wunsch(closest, original):
+            if new_gene == "*":
+                taken += 1
+            elif old_gene != new_gene:
+                new_positions.append((None, None))
+            else:
+                new_positions.append(old_positions[taken])
+                taken += 1
+        self.get_gene_positions()[read_id] = self.replace_invalid_gene_positions(new_positions, fastq_data, read_id)
+        return closest
+
+    def score(self, x, y):
+        return int(x == y)
 
     def find_read_boundaries(self, readNode):
         start, end = 0, len(readNode) - 1
@@ -1093,11 +1294,6 @@ class GeneMerGraph:
                     bucket.append(f"{read_id}_{s}_{e}")
                 path_reads.setdefault(key, set()).add(read_id)
             allele_counts[geneOfInterest] += 1
-
-    def correct_low_coverage_paths(self, *args, **kwargs):
-        raise NotImplementedError(
-            "bubble popping (construct_graph.py:2196-2250) needs nucleotide reads and sourmash "
-            "MinHash; it is row f1 of SURVEY.md section 8 and outside this round's hot path")
 
     def assign_reads_to_genes(self, listOfGenes, cores, allele_counts={}, mean_node_coverage=None,
                               path_threshold=5):

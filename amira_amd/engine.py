@@ -191,6 +191,35 @@ class Engine:
                                               ptr(offs), n, ptr(hit_off), ptr(hr), ptr(hp)))
         return hit_off, hr, hp
 
+    # ---- scaled MinHash of nucleotide segments (bubble popping)
+    def minhash(self, segments, set_ids, ksize, scaled):
+        """segments: list of str / bytes; set_ids: sketch id per segment.  Returns {sketch id: set of
+        hashes} with sourmash's definition (MinHash(n=0, ksize, scaled).add_sequence(seg, force=True))."""
+        out = {int(s): set() for s in set_ids}
+        if not segments:
+            return out
+        blobs = [s.encode() if isinstance(s, str) else bytes(s) for s in segments]
+        offs = np.zeros(len(blobs) + 1, np.int64)
+        np.cumsum([len(b) for b in blobs], out=offs[1:])
+        bases = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        if len(bases) == 0:
+            return out
+        sets = np.ascontiguousarray(set_ids, dtype=np.int32)
+        n = C.c_int64(0)
+        check(_ffi.lib.amg_minhash(self._h, ptr(bases), ptr(offs), ptr(sets), len(blobs), int(ksize), int(scaled),
+                                   None, None, 0, C.byref(n)))
+        if n.value == 0:
+            return out
+        o_set, o_hash = np.empty(n.value, np.int32), np.empty(n.value, np.uint64)
+        check(_ffi.lib.amg_minhash(self._h, ptr(bases), ptr(offs), ptr(sets), len(blobs), int(ksize), int(scaled),
+                                   ptr(o_set), ptr(o_hash), n.value, C.byref(n)))
+        order = np.lexsort((o_hash, o_set))
+        o_set, o_hash = o_set[order], o_hash[order]
+        cuts = np.flatnonzero(np.diff(o_set)) + 1
+        for ids, hs in zip(np.split(o_set, cuts), np.split(o_hash, cuts)):
+            out[int(ids[0])] = set(np.unique(hs).tolist())
+        return out
+
     # ---- multi-GPU merge phases (device pointers in / out; see amira_amd/dist.py)
     @staticmethod
     def dist_record_bytes(k):

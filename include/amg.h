@@ -190,6 +190,20 @@ int amg_match_patterns(amg_ctx* ctx, int which, const int32_t* pat, const int64_
                        int64_t n_pat, int64_t* hit_offsets, int32_t* hit_read,
                        int32_t* hit_pos);
 
+/* ---- bubble popping support: scaled MinHash of nucleotide segments, the
+ *      sketches sourmash.MinHash(n=0, ksize, scaled).add_sequence(seq, force=True) builds at
+ *      construct_graph.py:1567-1575 (per path, ksize 9, scaled 1) and :2148-2158 (per node, ksize 11,
+ *      scaled 10).  sourmash is a third-party dependency of the reference (pyproject.toml:28); its
+ *      published definition is implemented: upper-cased bases, windows holding a character outside ACGT
+ *      skipped, canonical k-mer = min(k-mer, reverse complement), hash = first 64 bits of
+ *      MurmurHash3_x64_128(seed 42), kept when <= round(2^64 / scaled) (all for scaled = 1).
+ *      bases[seg_off[s] .. seg_off[s+1]) is segment s and belongs to sketch seg_set[s] (HOST arrays).
+ *      Output: one (sketch id, hash) pair per kept k-mer occurrence, unordered; *n_out = their number
+ *      (call with out_set = NULL for the count). ------------------------------------------------ */
+int amg_minhash(amg_ctx* ctx, const uint8_t* bases, const int64_t* seg_off, const int32_t* seg_set,
+                int64_t n_seg, int32_t ksize, uint64_t scaled, int32_t* out_set, uint64_t* out_hash,
+                int64_t cap, int64_t* n_out);
+
 /* ---- multi-GPU: read-sharded build with a key-owner table merge — the single-graph result of
  *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
  *      Every rank holds a contiguous shard of the reads.  The library runs the device phases;

@@ -86,3 +86,28 @@ def choose_kmer_size(mean_cov, reads, cores, positions, genes_of_interest):
             else:
                 break
     return chosen
+
+
+def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleaning_iterations, geneMer_size, cores,
+                             short_reads, short_read_gene_positions, fastq_content, output_dir, node_min_coverage,
+                             sample_genesOfInterest, min_path_coverage):
+    # graph_utils.py:127-181 — the whole cleaning driver, bubble popping included
+    prev_nodes, components_to_skip = 0, set()
+    for _ in range(cleaning_iterations):
+        g = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        g.filter_graph(node_min_coverage, 1)
+        new_annotatedReads, new_gene_position_dict = g.correct_reads(fastq_content)
+        g = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        if len(g.get_nodes()) == prev_nodes:
+            break
+        prev_nodes = len(g.get_nodes())
+        short_reads.update(g.get_short_read_annotations())
+        short_read_gene_positions.update(g.get_short_read_gene_positions())
+        g.remove_short_linear_paths(geneMer_size)
+        new_annotatedReads, new_gene_position_dict = g.correct_reads(fastq_content)
+        g = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+        short_reads.update(g.get_short_read_annotations())
+        short_read_gene_positions.update(g.get_short_read_gene_positions())
+        new_annotatedReads, new_gene_position_dict, _, min_path_coverage = g.correct_low_coverage_paths(
+            fastq_content, sample_genesOfInterest, cores, min_path_coverage, components_to_skip, True)
+    return new_annotatedReads, new_gene_position_dict

@@ -23,11 +23,13 @@ import procedures as P  # noqa: E402
 from amira.construct_gene import Gene  # noqa: E402  (the reference)
 from amira.construct_gene_mer import GeneMer  # noqa: E402
 from amira.construct_graph import GeneMerGraph  # noqa: E402
-from amira.graph_utils import choose_kmer_size, get_overall_mean_node_coverages  # noqa: E402
+from amira.graph_utils import (choose_kmer_size, get_overall_mean_node_coverages,  # noqa: E402
+                               iterative_bubble_popping)
 
 REFERENCE = types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
                                   choose_kmer_size=choose_kmer_size,
-                                  get_overall_mean_node_coverages=get_overall_mean_node_coverages)
+                                  get_overall_mean_node_coverages=get_overall_mean_node_coverages,
+                                  iterative_bubble_popping=iterative_bubble_popping)
 
 
 def main():

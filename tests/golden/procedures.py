@@ -169,6 +169,231 @@ def p_values(impl):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# bubble popping (row f1), GML / unitig writers (row f4), the incremental mutators (row b)
+def real_fastq():
+    """tests/test_1.fastq.gz of the reference (a data file its own tests read), as parse_fastq gives it"""
+    import gzip
+    out = {}
+    with gzip.open(os.path.join(HERE, "data", "test_1.fastq.gz"), "rt") as fh:
+        while True:
+            head = fh.readline()
+            if not head:
+                break
+            seq = fh.readline().rstrip("\n")
+            fh.readline()
+            qual = fh.readline().rstrip("\n")
+            out[head[1:].split()[0]] = {"sequence": seq, "quality": qual}
+    return out
+
+
+def _bases(key, n):
+    """n pseudo-random bases determined by `key` alone (sha256 in counter mode)"""
+    import hashlib
+    out, i = [], 0
+    while len(out) * 128 < n:
+        d = hashlib.sha256(f"{key}/{i}".encode()).digest()
+        out.append("".join("ACGT"[(b >> s) & 3] for b in d for s in (0, 2, 4, 6)))
+        i += 1
+    return "".join(out)[:n]
+
+
+_RC = str.maketrans("ACGT", "TGCA")
+
+
+def synth_fastq(calls, positions, flank=150):
+    """nucleotide reads consistent with gene calls + positions: every gene name owns one
+    sequence, laid down (reverse-complemented for '-') at its [start, end] on each read, random
+    filler in between — so that reads through the same genes share their k-mers."""
+    fq = {}
+    for rid, genes in calls.items():
+        pos = positions[rid]
+        total = (max(p[1] for p in pos) if pos else 0) + flank
+        seq = list(_bases("read:" + rid, total))
+        for g, (s, e) in zip(genes, pos):
+            piece = _bases("gene:" + g[1:], e - s + 1)
+            if g[0] == "-":
+                piece = piece.translate(_RC)[::-1]
+            seq[s:e + 1] = piece
+        fq[rid] = {"sequence": "".join(seq), "quality": "I" * len(seq)}
+    return fq
+
+
+def _label_path(g, hashes):
+    return [g.get_gene_mer_label(g.get_node_by_hash(h)) for h in hashes]
+
+
+def _bubble_entry(g, fq, genes_of_interest):
+    starts = g.identify_potential_bubble_starts()
+    entry = {"starts": {str(c): [[g.get_gene_mer_label(g.get_node_by_hash(h)), d] for h, d in v]
+                        for c, v in starts.items()}}
+    per_component = []
+    for component in g.components():
+        if component not in starts:
+            continue
+        unique = g.get_all_paths_between_junctions_in_component(starts[component], g.get_kmerSize() * 4, 1)
+        filtered = g.filter_paths_between_bubble_starts(unique)
+        per_component.append({"component": component, "n_unique": len(unique),
+                              "unique_digest": D.digest(sorted(_label_path(g, [n[0] for n in p]) for p in unique)),
+                              "filtered": sorted([_label_path(g, [n[0] for n in p]), float(c)] for p, c in filtered)})
+    entry["paths"] = per_component
+    reads, pos, covs, mpc = g.correct_low_coverage_paths(fq, genes_of_interest, 1, 2, set(), True)
+    entry["path_coverages"] = [float(c) for c in covs]
+    entry["reads_digest"] = D.digest({r: list(v) for r, v in reads.items()})
+    entry["positions_digest"] = D.digest({r: [list(p) for p in v] for r, v in pos.items()})
+    entry["n_genes"] = sum(len(v) for v in reads.values())
+    return entry
+
+
+def p_bubbles_real(impl):
+    """correct_low_coverage_paths with MinHash on the reference's own FASTQ fixture
+    (tests/test_path_calls.json + tests/test_1.fastq.gz, the data of test_gene_mer_graph.py:5119-5155)"""
+    calls, pos = D.load_fixture("test_path_calls"), D.load_fixture("test_path_positions")
+    pos = {r: [tuple(p) for p in v] for r, v in pos.items()}
+    g = impl.GeneMerGraph(calls, 3, pos)
+    return _bubble_entry(g, real_fastq(), set())
+
+
+def p_bubbles_synth(impl, name, k, min_cov):
+    """the same on a larger fixture with synthetic reads (synth_fastq), after filter + correction
+    as the cleaning loop runs it (graph_utils.py:145-178)"""
+    calls, pos = fixture(name)
+    pos = {r: [tuple(p) for p in v] for r, v in pos.items()}
+    fq = synth_fastq(calls, pos)
+    g = impl.GeneMerGraph(calls, k, pos)
+    g.filter_graph(min_cov, 1)
+    calls, pos = g.correct_reads(fq)
+    g = impl.GeneMerGraph(calls, k, pos)
+    return _bubble_entry(g, fq, set())
+
+
+def p_iterative(impl, which):
+    """the whole cleaning driver iterative_bubble_popping (graph_utils.py:127-181)"""
+    if which == "real":
+        calls, pos = D.load_fixture("test_path_calls"), D.load_fixture("test_path_positions")
+        fq, k, min_cov = real_fastq(), 3, 3
+    else:
+        calls, pos = fixture(which)
+        fq, k, min_cov = None, 3, 3
+    pos = {r: [tuple(p) for p in v] for r, v in pos.items()}
+    if fq is None:
+        fq = synth_fastq(calls, pos)
+    short, short_pos = {}, {}
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        reads, positions = impl.iterative_bubble_popping(calls, pos, 3, k, 1, short, short_pos, fq, tmp,
+                                                         min_cov, set(), 2)
+    return {"n_reads": len(reads), "n_genes": sum(len(v) for v in reads.values()),
+            "reads_digest": D.digest({r: list(v) for r, v in reads.items()}),
+            "positions_digest": D.digest({r: [list(p) for p in v] for r, v in positions.items()}),
+            "short_reads": sorted(short)}
+
+
+def p_outputs(impl, name, k):
+    """generate_gml (:873-909) and get_unitigs_in_graph (:2961-2975) on a fixture"""
+    import tempfile
+    calls, pos = fixture(name)
+    g = impl.GeneMerGraph(calls, k, pos)
+    g.filter_graph(2, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        data = g.generate_gml(os.path.join(tmp, "graph"), k, 2, 1)
+        written = open(os.path.join(tmp, f"graph.{k}.2.1.gml")).read()
+        g.get_unitigs_in_graph(os.path.join(tmp, "unitigs.txt"))
+        unitigs = sorted(open(os.path.join(tmp, "unitigs.txt")).read().split("\n"))
+    import hashlib
+    return {"gml_lines": len(data), "gml_head": data[:6], "gml_sha256": hashlib.sha256(written.encode()).hexdigest(),
+            "gml_equals_returned": written == "\n".join(data),
+            "n_unitigs": len(unitigs), "unitigs_digest": D.digest(unitigs), "unitigs_head": unitigs[:3]}
+
+
+def _mini_dump(g):
+    nodes = []
+    for h, n in g.get_nodes().items():
+        nodes.append([g.get_gene_mer_label(n), n.get_node_coverage(), n.get_component(), list(n.get_list_of_reads()),
+                      [D._edge_desc(g, g.get_edges()[e]) for e in n.get_forward_edge_hashes()],
+                      [D._edge_desc(g, g.get_edges()[e]) for e in n.get_backward_edge_hashes()], str(h)])
+    edges = [D._edge_desc(g, e) + [str(h)] for h, e in g.get_edges().items()]
+    rn = {r: [None if x is None else str(x) for x in v] for r, v in g.get_readNodes().items()}
+    return {"nodes": nodes, "edges": edges, "readNodes": rn,
+            "readDirs": {r: list(v) for r, v in g.get_readNodeDirections().items()},
+            "to_correct": sorted(g.get_reads_to_correct())}
+
+
+def p_mutators(impl):
+    """a graph assembled by hand through add_node / add_edge / add_node_to_read, the way the
+    reference's own unit tests do it (tests/test_gene_mer_graph.py:202-275, :476-1475), then
+    remove_edge, remove_node_from_reads, assign_component_ids and remove_node on it"""
+    def mers(genes, k=3):
+        objs = [impl.Gene(x) for x in genes]
+        return [impl.GeneMer(objs[i:i + k]) for i in range(len(objs) - k + 1)]
+
+    g = impl.GeneMerGraph({}, 3)
+    out = {"empty": _mini_dump(g)}
+    reads = {"r1": ["+gene1", "-gene2", "+gene3", "-gene4", "+gene5"],
+             "r2": ["-gene5", "+gene4", "-gene3", "+gene2", "-gene1"],      # r1 reverse-complemented
+             "r3": ["+gene1", "-gene2", "+gene3", "+gene7", "+gene8"],
+             "r4": ["+gene9", "+gene9", "+gene9", "+gene9"]}                 # tandem self-loop
+    for rid, genes in reads.items():
+        ms = mers(genes)
+        for i, m in enumerate(ms):
+            node = g.add_node(m, [rid])
+            g.add_node_to_read(node, rid, m.get_geneMerDirection(), None)
+            node.increment_node_coverage()
+            if i + 1 < len(ms):
+                g.add_node(ms[i + 1], [rid])
+                e1, e2 = g.add_edge(m, ms[i + 1])
+                e1.increment_edge_coverage()
+                e2.increment_edge_coverage()
+    g.assign_component_ids()
+    out["built"] = _mini_dump(g)
+    out["degrees"] = [g.get_degree(n) for n in g.all_nodes()]
+    out["mean_cov"] = float(g.calculate_mean_node_coverage())
+    a, b = mers(reads["r1"])[0], mers(reads["r1"])[1]
+    s2t, t2s = g.get_edge_hashes_between_nodes(g.get_node(a), g.get_node(b))
+    g.remove_edge(s2t)
+    g.remove_edge(s2t)                      # unknown hashes are ignored
+    out["after_remove_edge"] = _mini_dump(g)
+    g.remove_node_from_reads(g.get_node(mers(reads["r3"])[2]))
+    out["after_remove_from_reads"] = _mini_dump(g)
+    src, tgt = g.get_node(mers(reads["r3"])[1]), g.get_node(mers(reads["r3"])[2])
+    c1, c2 = g.create_edges(src, tgt, 1, -1)
+    out["create_edges"] = [D._edge_desc(g, c1) + [str(c1.__hash__())], D._edge_desc(g, c2) + [str(c2.__hash__())]]
+    g.remove_node(g.get_node(mers(reads["r4"])[0]))
+    out["after_remove_node"] = _mini_dump(g)
+    return out
+
+
+def p_read_helpers(impl, name, k):
+    """the per-read correction helpers called directly (correct_single_read :1136, generate_replacement_dict
+    :1388, get_possible_paths :1205, process_read_correction :1269, score :1429) against correct_reads"""
+    calls, pos = fixture(name)
+    pos = {r: [tuple(p) for p in v] for r, v in pos.items()}
+    lengths = {r: (pos[r][-1][1] + 200 if pos[r] else 100) for r in pos}
+    fq = FakeFastq(lengths)
+    g = impl.GeneMerGraph(calls, k, pos)
+    g.filter_graph(3, 1)
+    marked = sorted(g.get_reads_to_correct())
+    rows = []
+    for rid in marked:
+        nodes = g.get_readNodes()[rid]
+        if all(n is None for n in nodes):
+            rows.append([rid, "dropped"])
+            continue
+        start, end = g.find_read_boundaries(nodes)
+        tagged = list(zip(nodes, g.get_readNodeDirections()[rid]))
+        terminals = g.identify_path_terminals(nodes, start, end)
+        repl = {}
+        for pair in terminals:
+            repl.update(g.generate_replacement_dict(tagged, pair))
+        options = g.get_possible_paths(tagged, repl, start, end)
+        rows.append([rid, start, end, [list(t) for t in terminals], [len(v) for v in repl.values()], len(options)])
+    single = {rid: list(g.correct_single_read(rid, g.get_readNodes(), fq)) for rid in marked}
+    positions_after = {rid: [list(p) for p in g.get_gene_positions()[rid]] for rid in marked}
+    return {"marked": len(marked), "rows_digest": D.digest(rows), "rows_head": rows[:5],
+            "single_digest": D.digest(single), "positions_digest": D.digest(positions_after),
+            "score": [g.score("+a", "+a"), g.score("+a", "-a")]}
+
+
 # name -> (procedure, args, slow?)   slow cases are skipped by `gen_goldens.py --quick`
 CASES = {"values": (p_values, (), False)}
 for _n in ("five", "six", "seven", "eight", "four", "three", "nine"):
@@ -187,3 +412,17 @@ CASES["drivers_nine"] = (p_drivers, ("nine",), False)
 CASES["cluster_eight_k3"] = (p_cluster_fixture, ("eight", 3, ["dfrA17"]), False)
 CASES["planted_s20250909"] = (p_planted, (20250909, 1500, 40, 1000, 5), True)
 CASES["planted_small"] = (p_planted, (5, 300, 40, 1000, 5), False)
+CASES["cluster_five_k3"] = (p_cluster_fixture, ("five", 3, ["blaCTXM110NG_0489052"]), False)
+CASES["cluster_six_k3"] = (p_cluster_fixture, ("six", 3, ["blaTEM239NG_0766451"]), False)
+CASES["cluster_seven_k3"] = (p_cluster_fixture, ("seven", 3, ["blaIMI9NG_0491711"]), False)
+CASES["cluster_three_k3"] = (p_cluster_fixture, ("three", 3, ["mphANG_0479861"]), True)
+CASES["bubbles_real_fastq"] = (p_bubbles_real, (), False)
+CASES["bubbles_synth_four_k5"] = (p_bubbles_synth, ("four", 5, 3), True)
+CASES["bubbles_synth_nine_k3"] = (p_bubbles_synth, ("nine", 3, 3), True)
+CASES["iterative_real_fastq"] = (p_iterative, ("real",), False)
+CASES["iterative_synth_five"] = (p_iterative, ("five",), True)
+CASES["outputs_five_k3"] = (p_outputs, ("five", 3), False)
+CASES["outputs_nine_k5"] = (p_outputs, ("nine", 5), False)
+CASES["mutators"] = (p_mutators, (), False)
+CASES["read_helpers_nine_k3"] = (p_read_helpers, ("nine", 3), False)
+CASES["read_helpers_four_k5"] = (p_read_helpers, ("four", 5), False)

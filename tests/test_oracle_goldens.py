@@ -14,11 +14,12 @@ import pytest
 import procedures as P
 from seed0 import run_case_seed0
 from amira_oracle import Gene, GeneMer, GeneMerGraph
-from amira_oracle.driver import choose_kmer_size, get_overall_mean_node_coverages
+from amira_oracle.driver import choose_kmer_size, get_overall_mean_node_coverages, iterative_bubble_popping
 
 ORACLE = types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
                                choose_kmer_size=choose_kmer_size,
-                               get_overall_mean_node_coverages=get_overall_mean_node_coverages)
+                               get_overall_mean_node_coverages=get_overall_mean_node_coverages,
+                               iterative_bubble_popping=iterative_bubble_popping)
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens.json")))
 
 # the two largest cases take ~1 min each in pure Python; they run in the default CPU

@@ -16,10 +16,11 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens
 
 def _product():
     import amira_amd
-    from amira_amd.graph_utils import choose_kmer_size, get_overall_mean_node_coverages
+    from amira_amd.graph_utils import choose_kmer_size, get_overall_mean_node_coverages, iterative_bubble_popping
     return types.SimpleNamespace(GeneMerGraph=amira_amd.GeneMerGraph, Gene=amira_amd.Gene,
                                  GeneMer=amira_amd.GeneMer, choose_kmer_size=choose_kmer_size,
-                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages)
+                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages,
+                                 iterative_bubble_popping=iterative_bubble_popping)
 
 
 @pytest.mark.parametrize("name", list(P.CASES))
