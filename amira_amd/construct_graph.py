@@ -24,6 +24,7 @@ clustering).
 import os
 import statistics
 import sys
+import weakref
 from collections.abc import Mapping
 from itertools import product
 
@@ -52,35 +53,53 @@ sys.setrecursionlimit(50000)  # construct_graph.py:27
 
 
 class _LazyReadLists(Mapping):
-    """dict-like {read id: per-window list} whose lists are built from the device arrays the
-    first time a read is looked up (read-path clustering touches a few thousand of millions)."""
+    """dict-like {read id: per-window list} over the reads that have a window, whose lists are built
+    from the device arrays the first time a read is looked up (read-path clustering touches a few
+    thousand of millions).  The key list and the id -> row index are only made when asked for."""
 
-    def __init__(self, read_ids, index, make):
-        self._ids, self._index, self._make, self._cache = read_ids, index, make, {}
+    def __init__(self, graph, make):
+        self._g, self._make, self._cache = weakref.proxy(graph), make, {}   # no cycle graph <-> view
+        self._ids = None       # reads with >= 1 window, in read order (+ reads added by hand)
+        self._extra = []       # reads added through add_node_to_read
+
+    def _row(self, rid):
+        r = self._g._read_index.get(rid)
+        if r is None:
+            return None
+        off = self._g._read_off
+        return r if off[r + 1] - off[r] >= self._g._kmerSize else None
 
     def __getitem__(self, rid):
         got = self._cache.get(rid)
         if got is None:
-            r = self._index.get(rid)
+            r = self._row(rid)
             if r is None:
                 raise KeyError(rid)
             got = self._cache[rid] = self._make(r)
         return got
 
     def __setitem__(self, rid, value):  # remove_node_from_reads / add_node_to_read style updates
-        if rid not in self._index:   # a read the build did not see (add_node_to_read, :165-178)
-            self._index[rid] = None
-            self._ids.append(rid)
+        if rid not in self._cache and self._row(rid) is None:   # a read the build did not see (:165-178)
+            self._extra.append(rid)
+            if self._ids is not None:
+                self._ids.append(rid)
         self._cache[rid] = value
 
+    def _keys(self):
+        if self._ids is None:
+            g = self._g
+            rows = np.flatnonzero(np.diff(g._read_off) >= g._kmerSize).tolist() if len(g._read_off) > 1 else []
+            self._ids = [g._read_ids[r] for r in rows] + self._extra
+        return self._ids
+
     def __iter__(self):
-        return iter(self._ids)
+        return iter(self._keys())
 
     def __len__(self):
-        return len(self._ids)
+        return len(self._keys())
 
     def __contains__(self, rid):
-        return rid in self._index
+        return rid in self._cache or self._row(rid) is not None
 
 
 class _GraphNode(Node):
@@ -108,6 +127,26 @@ class _View:
                  "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
 
 
+# Engines (a HIP stream + grow-only device buffers each) are pooled per device: the reference's
+# drivers build graph after graph (three per cleaning iteration, seven in choose_kmer_size), and an
+# engine that has already sized its buffers for the read set makes the next build allocation-free.
+_ENGINE_POOL = {}
+
+
+def _acquire_engine(device):
+    free = _ENGINE_POOL.setdefault(device, [])
+    while free:
+        engine = free.pop()
+        if engine._h:   # (an engine finalised by the cycle collector together with its graph is closed)
+            return engine
+    return Engine(device)
+
+
+def _release_engine(engine):
+    if engine is not None and engine._h:
+        _ENGINE_POOL.setdefault(engine.device, []).append(engine)
+
+
 class GeneMerGraph(BubblePopping):
     # ------------------------------------------------------------------ build
     def __init__(self, readDict, kmerSize, gene_positions=None, device=None):
@@ -121,14 +160,14 @@ class GeneMerGraph(BubblePopping):
         self._extra_to_correct = set()
         self._gene_cache = {}
         dev = int(os.environ.get("AMG_DEVICE", "0")) if device is None else int(device)
-        self._engine = Engine(dev)
+        self._engine = _acquire_engine(dev)
         if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):  # amira_amd.io.TokenizedReads
             self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
                                                        readDict.read_offsets, list(readDict.read_ids))
         else:
             self._vocab, toks, offs, self._read_ids = tokenize(readDict)
         self._read_off = offs
-        self._read_index = {r: i for i, r in enumerate(self._read_ids)}
+        self._read_index_ = None
         if kmerSize < 1 and len(toks) == 0:
             kmerSize_dev = 1  # GeneMerGraph({}, 0) is legal in the reference: nothing to build
         else:
@@ -136,7 +175,12 @@ class GeneMerGraph(BubblePopping):
         self._engine.set_reads(toks, offs, self._vocab.two_v)
         self._tokens = toks
         self._gs = self._ge = None
-        if gene_positions:
+        if gene_positions is not None and hasattr(gene_positions, "gene_start"):  # io.TokenizedPositions
+            self._gs = np.ascontiguousarray(gene_positions.gene_start, np.int64)
+            self._ge = np.ascontiguousarray(gene_positions.gene_end, np.int64)
+            assert len(self._gs) == int(offs[-1]) == len(self._ge), "positions do not match the gene calls"
+            self._engine.set_positions(self._gs, self._ge, None)
+        elif gene_positions:
             n = int(offs[-1])
             gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
             for r, rid in enumerate(self._read_ids):
@@ -154,10 +198,32 @@ class GeneMerGraph(BubblePopping):
             if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
                 raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None
             raise
-        counts = self._engine.counts()
-        self._shortReads = {rid: readDict[rid] for r, rid in enumerate(self._read_ids)
-                            if offs[r + 1] - offs[r] < kmerSize}
-        assert counts["n_short_reads"] == len(self._shortReads)
+        short = np.flatnonzero(np.diff(offs) < kmerSize).tolist() if len(offs) > 1 else []
+        self._shortReads = {self._read_ids[r]: readDict[self._read_ids[r]] for r in short}   # :53-55
+
+    @property
+    def _read_index(self):
+        if self._read_index_ is None:
+            self._read_index_ = {r: i for i, r in enumerate(self._read_ids)}
+        return self._read_index_
+
+    def close(self):
+        """hand the device engine back (the graph can no longer be queried); also done when the object dies"""
+        engine, self._engine = getattr(self, "_engine", None), None
+        self._view = None
+        _release_engine(engine)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # ------------------------------------------------------------------ view plumbing
     def _invalidate(self):
@@ -233,8 +299,6 @@ class GeneMerGraph(BubblePopping):
             node.backwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i + 1]:adj_off[2 * i + 2]].tolist()
                                        if edges["alive"][e]]
         offs, nh = self._read_off, v.node_hash
-        with_windows = [rid for r, rid in enumerate(read_ids) if offs[r + 1] - offs[r] >= k]
-        index = {rid: self._read_index[rid] for rid in with_windows}
 
         def window_ids(r):
             a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
@@ -248,16 +312,18 @@ class GeneMerGraph(BubblePopping):
             a, n, ids = window_ids(r)
             return [d if x >= 0 else None for d, x in zip(tok_dir[a:a + n].tolist(), ids)]
 
+        gs_all, ge_all = self._gs, self._ge
+
         def make_positions(r):
             a, n, ids = window_ids(r)
-            if self._gs is None:
+            if gs_all is None:
                 return [None] * n
-            s, e = self._gs[a:a + n].tolist(), self._ge[a + k - 1:a + k - 1 + n].tolist()
+            s, e = gs_all[a:a + n].tolist(), ge_all[a + k - 1:a + k - 1 + n].tolist()
             return [(s[j], e[j]) if ids[j] >= 0 else None for j in range(n)]
 
-        v.readNodes = _LazyReadLists(with_windows, index, make_nodes)
-        v.readNodeDirections = _LazyReadLists(with_windows, index, make_dirs)
-        v.readNodePositions = _LazyReadLists(with_windows, index, make_positions)
+        v.readNodes = _LazyReadLists(self, make_nodes)
+        v.readNodeDirections = _LazyReadLists(self, make_dirs)
+        v.readNodePositions = _LazyReadLists(self, make_positions)
         self._view = v
         return v
 
@@ -1013,7 +1079,10 @@ class GeneMerGraph(BubblePopping):
         return backward[:-1] + [node.__hash__()] + forward[1:]
 
     def get_all_node_coverages(self):
-        return [n.get_node_coverage() for n in self.all_nodes()]
+        if self._host_edits:
+            return [n.get_node_coverage() for n in self.all_nodes()]
+        nodes = self._v().arrays["nodes"] if self._view is not None else self._engine.nodes()
+        return nodes["coverage"][nodes["alive"] != 0].tolist()   # straight from the device arrays
 
     def get_mean_node_coverage(self):
         return statistics.mean(self.get_all_node_coverages())

@@ -87,30 +87,41 @@ class Engine:
         return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
 
     # ---- read-back
-    def nodes(self):
+    @staticmethod
+    def _take(buf, key, shape, dtype):
+        """an output array: a view of the caller's (e.g. pinned) buffer buf[key] when given, else a new one"""
+        n = int(np.prod(shape))
+        if buf is not None and key in buf:
+            a = buf[key]
+            assert a.dtype == dtype and a.size >= n and a.flags["C_CONTIGUOUS"], key
+            return a.reshape(-1)[:n].reshape(shape)
+        return np.empty(shape, dtype)
+
+    def nodes(self, buf=None):
+        """buf: optional dict of preallocated arrays (capacity >= needed) the columns are read back into"""
         D, _, k = self.graph_sizes()
         out = {
-            "tokens": np.empty((D, k), np.int32), "coverage": np.empty(D, np.uint32),
-            "first_token": np.empty(D, np.int64), "first_dir": np.empty(D, np.int8),
-            "component": np.empty(D, np.int32), "alive": np.empty(D, np.uint8),
+            "tokens": self._take(buf, "tokens", (D, k), np.int32), "coverage": self._take(buf, "coverage", (D,), np.uint32),
+            "first_token": self._take(buf, "first_token", (D,), np.int64), "first_dir": self._take(buf, "first_dir", (D,), np.int8),
+            "component": self._take(buf, "component", (D,), np.int32), "alive": self._take(buf, "alive", (D,), np.uint8),
         }
         check(_ffi.lib.amg_get_nodes(self._h, ptr(out["tokens"]), ptr(out["coverage"]),
                                      ptr(out["first_token"]), ptr(out["first_dir"]),
                                      ptr(out["component"]), ptr(out["alive"])))
         return out
 
-    def edges(self):
+    def edges(self, buf=None):
         E = self.graph_sizes()[1]
-        out = {"src": np.empty(E, np.int32), "tgt": np.empty(E, np.int32),
-               "sdir": np.empty(E, np.int8), "tdir": np.empty(E, np.int8),
-               "coverage": np.empty(E, np.uint32), "alive": np.empty(E, np.uint8)}
+        out = {"src": self._take(buf, "src", (E,), np.int32), "tgt": self._take(buf, "tgt", (E,), np.int32),
+               "sdir": self._take(buf, "sdir", (E,), np.int8), "tdir": self._take(buf, "tdir", (E,), np.int8),
+               "coverage": self._take(buf, "ecoverage", (E,), np.uint32), "alive": self._take(buf, "ealive", (E,), np.uint8)}
         check(_ffi.lib.amg_get_edges(self._h, ptr(out["src"]), ptr(out["tgt"]), ptr(out["sdir"]),
                                      ptr(out["tdir"]), ptr(out["coverage"]), ptr(out["alive"])))
         return out
 
-    def read_nodes(self):
+    def read_nodes(self, buf=None):
         T = self.sizes()[1]
-        node, d = np.empty(T, np.int32), np.empty(T, np.int8)
+        node, d = self._take(buf, "tok_node", (T,), np.int32), self._take(buf, "tok_dir", (T,), np.int8)
         check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), ptr(d)))
         return node, d
 
@@ -159,12 +170,15 @@ class Engine:
         check(_ffi.lib.amg_correct_reads(self._h, C.byref(nr), C.byref(nt)))
         return nr.value, nt.value
 
-    def corrected(self, n_reads, n_tokens, with_positions):
-        out = {"tokens": np.empty(n_tokens, np.int32), "read_offsets": np.empty(n_reads + 1, np.int64),
-               "orig_read": np.empty(n_reads, np.int32), "changed": np.empty(n_reads, np.uint8)}
+    def corrected(self, n_reads, n_tokens, with_positions, buf=None):
+        out = {"tokens": self._take(buf, "c_tokens", (n_tokens,), np.int32),
+               "read_offsets": self._take(buf, "c_read_offsets", (n_reads + 1,), np.int64),
+               "orig_read": self._take(buf, "c_orig_read", (n_reads,), np.int32),
+               "changed": self._take(buf, "c_changed", (n_reads,), np.uint8)}
         gs = ge = None
         if with_positions:
-            gs, ge = np.empty(n_tokens, np.int64), np.empty(n_tokens, np.int64)
+            gs = self._take(buf, "c_gene_start", (n_tokens,), np.int64)
+            ge = self._take(buf, "c_gene_end", (n_tokens,), np.int64)
         check(_ffi.lib.amg_get_corrected(self._h, ptr(out["tokens"]), ptr(out["read_offsets"]),
                                          ptr(out["orig_read"]), ptr(out["changed"]), ptr(gs), ptr(ge)))
         out["gene_start"], out["gene_end"] = gs, ge

@@ -18,13 +18,18 @@ class TokenizedReads(Mapping):
 
     def __init__(self, vocab, tokens, read_offsets, read_ids):
         self.vocab, self.tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
-        self._index = {r: i for i, r in enumerate(read_ids)}
+        self._index = None   # built on the first lookup by name (a million reads: ~0.2 s)
         self._cache = {}
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {r: i for i, r in enumerate(self.read_ids)}
+        return self._index
 
     def __getitem__(self, read_id):
         got = self._cache.get(read_id)
         if got is None:
-            i = self._index[read_id]
+            i = self._idx()[read_id]
             got = self._cache[read_id] = self.vocab.decode(
                 self.tokens[self.read_offsets[i]:self.read_offsets[i + 1]])
         return got
@@ -36,7 +41,44 @@ class TokenizedReads(Mapping):
         return len(self.read_ids)
 
     def __contains__(self, read_id):
-        return read_id in self._index
+        return read_id in self._idx()
+
+
+class TokenizedPositions(Mapping):
+    """{read id: [(start, end), ...]} backed by two flat int64 arrays aligned with the tokens of a
+    TokenizedReads; GeneMerGraph hands the arrays to the device as they are (no per-read loop)."""
+
+    def __init__(self, read_ids, read_offsets, gene_start, gene_end):
+        self.read_ids, self.read_offsets = read_ids, read_offsets
+        self.gene_start, self.gene_end = gene_start, gene_end
+        self._index = None
+        self._cache = {}
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {r: i for i, r in enumerate(self.read_ids)}
+        return self._index
+
+    def __getitem__(self, read_id):
+        got = self._cache.get(read_id)
+        if got is None:
+            i = self._idx()[read_id]
+            a, b = int(self.read_offsets[i]), int(self.read_offsets[i + 1])
+            got = self._cache[read_id] = list(zip(self.gene_start[a:b].tolist(), self.gene_end[a:b].tolist()))
+        return got
+
+    def __setitem__(self, read_id, value):   # correct_reads / bubble popping replace a read's positions
+        self._idx()
+        self._cache[read_id] = value
+
+    def __iter__(self):
+        return iter(self.read_ids)
+
+    def __len__(self):
+        return len(self.read_ids)
+
+    def __contains__(self, read_id):
+        return read_id in self._idx()
 
 
 def _split(buf):

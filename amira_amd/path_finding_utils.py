@@ -24,24 +24,51 @@ class _Suffix:
 
 
 class _ScanTree:
+    """Exact sub-list search over a {key: sequence} mapping with the call shape of suffix_tree.Tree
+    (`Tree(dict)`, `find_all(seq) -> [(key, suffix from the match start)]`, hits in key order then
+    position).  Items are interned to small integers and all sequences laid end to end in one numpy
+    array, so a query is a handful of vectorised comparisons instead of a Python loop over every
+    read (the read-path clustering of a million-read graph issues hundreds of queries over tens of
+    thousands of node lists)."""
+
     def __init__(self, data=None):
-        self._seqs = [(key, list(seq)) for key, seq in (data or {}).items()]
+        import numpy as np
+        self._np = np
+        self._keys, self._seqs = [], []
+        code = self._code = {}
+        flat, starts = [], [0]
+        for key, seq in (data or {}).items():
+            seq = list(seq)
+            self._keys.append(key)
+            self._seqs.append(seq)
+            flat.extend(code.setdefault(x, len(code)) for x in seq)
+            starts.append(len(flat))
+        self._flat = np.asarray(flat, dtype=np.int64)
+        self._starts = np.asarray(starts, dtype=np.int64)
 
     def find_all(self, query):
+        np = self._np
         query = list(query)
         m = len(query)
-        hits = []
-        if m == 0:
-            return hits
-        first = query[0]
-        for key, seq in self._seqs:
-            stop = len(seq) - m
-            i = 0
-            while i <= stop:
-                if seq[i] == first and seq[i:i + m] == query:
-                    hits.append((key, _Suffix(seq[i:])))
-                i += 1
-        return hits
+        if m == 0 or len(self._flat) == 0:
+            return []
+        codes = [self._code.get(x) for x in query]
+        if None in codes:   # an item no sequence holds
+            return []
+        flat, starts = self._flat, self._starts
+        at = np.flatnonzero(flat == codes[0])
+        if len(at) == 0:
+            return []
+        row = np.searchsorted(starts, at, side="right") - 1
+        ok = at + m <= starts[row + 1]          # the match must end inside its own sequence
+        at, row = at[ok], row[ok]
+        for j in range(1, m):
+            if len(at) == 0:
+                return []
+            keep = flat[at + j] == codes[j]
+            at, row = at[keep], row[keep]
+        begin = (at - starts[row]).tolist()
+        return [(self._keys[r], _Suffix(self._seqs[r][i:])) for r, i in zip(row.tolist(), begin)]
 
 
 Tree = _ExternalTree or _ScanTree

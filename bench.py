@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — read -> corrected gene-mer graph hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3-sweep|cfg3|cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3-sweep|cfg3|cfg2|cfg4]
 
 A "step" is one pass of the hot path over one batch of synthetic gene calls whose CSR
 token arrays (and gene positions) are already resident in HBM:
@@ -11,7 +11,13 @@ token arrays (and gene positions) are already resident in HBM:
              (the cleaning sweep of graph_utils.py:145-166; BASELINE.json configs[2])
   cfg3       the first build of that sweep only
   cfg2       100 k reads x 40 genes, k=5, 5 k-gene vocabulary: build + coverage (configs[1])
-Prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+  cfg4       1 M error-free reads with 10 planted multi-copy AMR genes, k=5: build +
+             assign_reads_to_genes through the reference-shaped Python API (configs[3])
+Prints ONE JSON line (driver contract): `value` is the device-resident rate (inputs in HBM when
+the clock starts, nothing read back); `e2e` (N = 1) is SURVEY 8(d)'s timed region — host CSR arrays
+-> host graph arrays, H2D and D2H inside the clock, pinned buffers, the position upload overlapped
+with the first build on a second stream; `roofline` prices the dominant kernel with HIP events of
+the engine's own stream; `cpu_baseline` / `cpu_baseline_ncore` time the CPU oracle on this box.
 Multi-GPU (torch.distributed.run, one rank per GPU, RCCL): every rank holds its own N-read
 shard of the global stream (weak scaling); EVERY build of the step merges the per-shard node /
 edge tables by key owner (all-to-all + all-gather, amira_amd/dist.py), so all ranks hold the
@@ -38,6 +44,9 @@ WORKLOADS = {
                        desc="synthetic 1M reads x 60 genes, k=5, 20k-gene vocab: build + "
                             "error-correction sweep (build, filter(3,1), correct, build, clip(5), "
                             "correct, build)"),
+    "cfg4": dict(N=1_000_000, L=60, V=20_000, k=5, err=0.0, seed=20250905 + 4, sweep=False, n_amr=10,
+                 desc="synthetic 1M error-free reads x 60 genes with 10 planted multi-copy AMR genes, k=5, "
+                      "20k-gene vocab: build + read-path clustering (assign_reads_to_genes)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -67,54 +76,175 @@ def stage_bytes(stage, k, L, n_windows, n_reads, n_gapped):
 def make_tokens(w, lo, hi):
     from amira_amd import synth
     from amira_amd.tokens import Vocabulary
-    ids, sts = synth.block_reads(w["seed"], lo, hi, w["L"], w["V"], w["err"])
-    vocab = Vocabulary(synth.gene_names(w["V"]))
-    rank = np.array([vocab.rank[n] for n in synth.gene_names(w["V"])], dtype=np.int64)
+    n_amr = w.get("n_amr", 0)
+    ids, sts = synth.block_reads(w["seed"], lo, hi, w["L"], w["V"], w["err"], n_amr=n_amr)
+    names = synth.gene_names(w["V"], n_amr)
+    vocab = Vocabulary(names)
+    rank = np.array([vocab.rank[n] for n in names], dtype=np.int64)
     r = rank[ids]
     toks = np.where(sts == 1, vocab.V + r, vocab.V - 1 - r).astype(np.int32)
     offs = (np.arange(hi - lo + 1, dtype=np.int64) * w["L"])
     return vocab, toks.reshape(-1), offs
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """Pure-Python restatement of the reference (oracle/: same sha256 + pickle work per
-    gene-mer as construct_gene.py:5-10) on a bounded sample of the same workload, 1 core —
-    the reference pipeline always builds with cores=1."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (pure-Python restatement of the reference, same sha256 + pickle work per
+# gene-mer as construct_gene.py:5-10) on this box's host cores.  Test infrastructure used as the
+# checker / yardstick only; nothing below is on the product path.
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from amira_amd import synth
     from amira_oracle import GeneMerGraph, driver, values
+    return synth, GeneMerGraph, driver, values
+
+
+def _cpu_sweep_or_build(w, first, n):
+    """reads [first, first + n) of the workload's own stream through the oracle; returns (gene-mers, seconds).
+    Runs in a thread with a 1 GB stack: the reference labels components by RECURSIVE depth-first search
+    (construct_graph.py:911-918, recursion limit 50 000 at :27), which the oracle restates; ten thousand
+    reads make one component of tens of thousands of nodes and overflow the default 8 MB stack."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = _cpu_sweep_or_build_here(w, first, n)
+        except BaseException as err:  # noqa: BLE001
+            box["err"] = err
+
+    old = threading.stack_size(1 << 30)
+    try:
+        t = threading.Thread(target=run)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(old)
+    if "err" in box:
+        raise box["err"]
+    return box["out"]
+
+
+def _cpu_sweep_or_build_here(w, first, n):
+    synth, GeneMerGraph, driver, values = _oracle()
+    sys.setrecursionlimit(2_000_000)  # beyond the reference's 50 000 (:27): the sample's component may be larger
     values.CACHE_HASHES = False
     L, k = w["L"], w["k"]
     try:
-        if not w["sweep"]:
-            n, done, spent, first = 250, 0, 0.0, 0
-            while spent < budget_s and first < w["N"]:
-                ids, sts = synth.block_reads(w["seed"], first, first + n, L, w["V"], w["err"])
-                reads = synth.to_read_dict(ids, sts, synth.gene_names(w["V"]), first=first)
-                t = time.perf_counter()
-                GeneMerGraph(reads, k)
-                spent += time.perf_counter() - t
-                done += n * (L - k + 1)
-                first += n
-            sample = (f"{first} reads of the same stream, build only, pure-Python oracle with "
-                      f"per-call sha256+pickle (reference cost model), {spent:.1f} s")
-        else:
-            # a sweep needs depth to leave anything after filter_graph(3,1): same L, k, error
-            # rate, vocabulary scaled down so 1 200 reads give ~140x depth
-            n, V = 1200, 500
-            ids, sts = synth.block_reads(w["seed"], 0, n, L, V, w["err"])
-            reads = synth.to_read_dict(ids, sts, synth.gene_names(V))
+        ids, sts = synth.block_reads(w["seed"], first, first + n, L, w["V"], w["err"], n_amr=w.get("n_amr", 0))
+        reads = synth.to_read_dict(ids, sts, synth.gene_names(w["V"], w.get("n_amr", 0)), first=first)
+        t = time.perf_counter()
+        if w["sweep"]:
             pos = synth.positions_for(reads)
             fq = driver.FakeFastq(synth.fake_fastq_lengths(reads))
             t = time.perf_counter()
             driver.correction_sweep(reads, pos, k, fq, 3)
-            spent = time.perf_counter() - t
-            done = n * (L - k + 1)
-            sample = (f"{n} reads x {L} genes, {V}-gene vocab (depth-preserving down-scale of the "
-                      f"workload), full sweep, pure-Python oracle with per-call sha256+pickle, {spent:.1f} s")
+        else:
+            GeneMerGraph(reads, k)
+        return n * (L - k + 1), time.perf_counter() - t
     finally:
         values.CACHE_HASHES = True
-    return {"value": done / spent, "unit": "gene-mers/s", "cores": 1, "kind": "port", "sample": sample}
+
+
+def _cpu_worker(args):
+    w, first, n = args
+    return _cpu_sweep_or_build(w, first, n)
+
+
+def cpu_baseline(w, frac=0.01):
+    """1 core — the reference pipeline always builds with cores=1 — on a 1 % read
+    subsample of the SAME stream, the whole step (sweep workloads: the whole sweep)."""
+    # sized to ~25 s of CPU work from a 250-read pilot, at most the 1 % subsample of SURVEY 8(d)
+    pilot_done, pilot_s = _cpu_sweep_or_build(w, w["N"] - 250, 250)
+    per_read = pilot_s / 250 * (6.0 if w["sweep"] else 1.0)   # a deeper sample re-threads more reads per read
+    n = max(min(int(w["N"] * frac), int(25.0 / max(per_read, 1e-6))), 250)
+    done, spent = _cpu_sweep_or_build(w, 0, n)
+    what = "full sweep" if w["sweep"] else "build"
+    return {"value": done / spent, "unit": "gene-mers/s", "cores": 1, "kind": "port",
+            "sample": f"the first {n} reads ({100.0 * n / w['N']:.2g} %) of the same stream, {what}, pure-Python oracle "
+                      f"with per-call sha256+pickle (the reference's cost model), {spent:.1f} s; extrapolates "
+                      f"linearly in reads (depth is {frac:.2g}x the workload's, so fewer nodes survive the filter)"}
+
+
+def cpu_baseline_ncore(w, per_worker=2500, max_workers=64):
+    """N host cores, read-sharded: the model of build_multiprocessed_graph (graph_utils.py:105-124) WITHOUT
+    its merge (which the reference does sequentially and gets wrong for edge coverages)
+    — an upper bound of what N processes of the reference's Python could build."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, max_workers))
+    build_only = dict(w, sweep=False)
+    jobs = [(build_only, i * per_worker, per_worker) for i in range(workers)]
+    t = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t
+    done = sum(r[0] for r in res)
+    return {"value": done / wall, "unit": "gene-mers/s", "cores": workers, "host_cores": cores, "kind": "port",
+            "sample": f"{workers} processes x {per_worker} reads of the same stream, build only, no merge "
+                      f"(upper bound of graph_utils.py:105-124), wall {wall:.1f} s incl. process start-up"}
+
+
+# ---------------------------------------------------------------------------------------------
+def run_cfg4(args, w, rank, world, local_rank):
+    """BASELINE configs[3]: build + read-path clustering through amira_amd.GeneMerGraph (the reference's
+    API: GeneMerGraph(reads, k, positions).assign_reads_to_genes(genes, 1, {}, None)).  Reads are handed
+    over tokenised (amira_amd.io.TokenizedReads is the {read: [genes]} mapping the API takes, decoded
+    lazily), so the step is H2D + device build + clustering."""
+    import torch
+    torch.cuda.set_device(local_rank)
+    from amira_amd import GeneMerGraph, synth
+    from amira_amd.io import TokenizedPositions, TokenizedReads
+    N, L, k = w["N"], w["L"], w["k"]
+    vocab, toks, offs = make_tokens(w, rank * N, (rank + 1) * N)
+    read_ids = synth.read_names(rank * N, (rank + 1) * N)
+    reads = TokenizedReads(vocab, toks, offs, read_ids)
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    positions = TokenizedPositions(read_ids, offs, gs, gs + 899)
+    genes = [f"amr{j}" for j in range(w["n_amr"])]
+    n_windows = N * (L - k + 1)
+    stage = {"build_s": [], "cluster_s": [], "device_build_ms": []}
+    info = {}
+
+    def step(record):
+        t0 = time.perf_counter()
+        g = GeneMerGraph(reads, k, positions)
+        t1 = time.perf_counter()
+        dev_ms = sum(m for _, m in g._engine.timings()) if record else 0.0
+        clustered, path_reads = g.assign_reads_to_genes(genes, 1, {}, None)
+        t2 = time.perf_counter()
+        if record:
+            stage["build_s"].append(t1 - t0)
+            stage["cluster_s"].append(t2 - t1)
+            stage["device_build_ms"].append(dev_ms)
+            info["alleles"] = {gene: sorted(len(v) for v in d.values())
+                               for comp in clustered.values() for gene, d in comp.items()}
+            info["nodes"] = g.get_total_number_of_nodes()
+        g.close()
+
+    for _ in range(args.warmup):
+        step(False)
+    step(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {
+        "metric": "gene-mers/s to GeneMerGraph + read-path clusters", "value": world * n_windows * args.steps / dt,
+        "unit": "gene-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic", "reads_per_s": world * N * args.steps / dt,
+        "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": L, "k": k, "vocab": w["V"],
+                   "genes_of_interest": genes, "nodes": info.get("nodes"),
+                   "alleles_found": sum(len(v) for v in info.get("alleles", {}).values()),
+                   "allele_sizes": info.get("alleles")},
+        "stages_s_per_step": {"build_incl_h2d_and_view": round(float(np.mean(stage["build_s"])), 4),
+                              "device_build_ms": round(float(np.mean(stage["device_build_ms"])), 3),
+                              "assign_reads_to_genes": round(float(np.mean(stage["cluster_s"])), 4)},
+        "roofline": None,
+    }
+    return out
 
 
 def main():
@@ -124,6 +254,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the merged (multi-GPU) code path even at world size 1 (self-test)")
@@ -133,6 +264,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # CPU yardsticks first (rank 0, N = 1), before this process touches the GPU: the N-core line
+    # starts worker processes
+    cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu["cpu_baseline"] = cpu_baseline(w)
+        cpu["cpu_baseline_ncore"] = cpu_baseline_ncore(w)
+
+    if args.workload == "cfg4":
+        out = run_cfg4(args, w, rank, world, local_rank)
+        out.update(cpu)
+        print(json.dumps(out), flush=True)
+        return
+
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
@@ -178,16 +323,7 @@ def main():
             stage_ms[name][0] += ms
             stage_ms[name][1] += 1
 
-    def step(record):
-        # inputs are resident in HBM and handed over as borrowed device pointers (no copy, no PCIe)
-        eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v, borrow=True)
-        if w["sweep"]:
-            eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr(), borrow=True)
-        build((3, 1) if w["sweep"] else None)
-        if record:
-            tally()
-        if not w["sweep"]:
-            return
+    def sweep_after_first_build(record, readback=None):
         if not merge:
             eng.filter(3, 1)
             if record:
@@ -204,13 +340,26 @@ def main():
         eng.remove_short_linear_paths(k)
         if record:
             tally()
-        eng.correct_reads()
+        n_out = eng.correct_reads()
         if record:
             tally()
+        if readback is not None:   # the corrected calls + positions the reference hands on (graph_utils.py:165)
+            eng.corrected(*n_out, True, buf=readback)
         eng.adopt_corrected()
         build()
         if record:
             tally()
+
+    def step(record):
+        # inputs are resident in HBM and handed over as borrowed device pointers (no copy, no PCIe)
+        eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v, borrow=True)
+        if w["sweep"]:
+            eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr(), borrow=True)
+        build((3, 1) if w["sweep"] else None)
+        if record:
+            tally()
+        if w["sweep"]:
+            sweep_after_first_build(record)
 
     for _ in range(args.warmup):
         step(False)
@@ -234,6 +383,74 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- SURVEY 8(d)'s timed region: host CSR -> host graph arrays (N = 1)
+    e2e = None
+    if world == 1 and not merge and not args.no_e2e:
+        pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+        h_toks, h_offs = pin(toks), pin(offs)
+        T = len(toks)
+        h_gs = h_ge = h_rl = None
+        if w["sweep"]:
+            h_gs = pin(np.tile(np.arange(L, dtype=np.int64) * 1000, N))
+            h_ge = pin(h_gs.numpy() + 899)
+            h_rl = pin(np.full(N, L * 1000 + 100, np.int64))
+        cap_t, cap_r = T + T // 8 + 1024, N + 1024
+        cap_d, cap_e = max(counts["n_nodes"] * 2, T // 8) + 1024, max(counts["n_edges"] * 2, T // 4) + 1024
+        pinned = lambda n, dt_: torch.empty(n, dtype=dt_).pin_memory().numpy()
+        buf = {"tokens": pinned(cap_d * k, torch.int32), "coverage": pinned(cap_d, torch.int32).view(np.uint32),
+               "first_token": pinned(cap_d, torch.int64), "first_dir": pinned(cap_d, torch.int8),
+               "component": pinned(cap_d, torch.int32), "alive": pinned(cap_d, torch.uint8),
+               "src": pinned(cap_e, torch.int32), "tgt": pinned(cap_e, torch.int32), "sdir": pinned(cap_e, torch.int8),
+               "tdir": pinned(cap_e, torch.int8), "ecoverage": pinned(cap_e, torch.int32).view(np.uint32),
+               "ealive": pinned(cap_e, torch.uint8), "tok_node": pinned(cap_t, torch.int32),
+               "tok_dir": pinned(cap_t, torch.int8)}
+        if w["sweep"]:
+            buf.update({"c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
+                        "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
+                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)})
+        side = torch.cuda.Stream(device=dev)
+        ev_reads, ev_pos = torch.cuda.Event(), torch.cuda.Event()
+
+        def e2e_step():
+            with torch.cuda.stream(side):
+                d_toks.copy_(h_toks, non_blocking=True)
+                d_offs.copy_(h_offs, non_blocking=True)
+                ev_reads.record(side)
+                if w["sweep"]:   # 4x the bytes of the genes: uploaded while the first build runs
+                    d_gs.copy_(h_gs, non_blocking=True)
+                    d_ge.copy_(h_ge, non_blocking=True)
+                    d_rl.copy_(h_rl, non_blocking=True)
+                    ev_pos.record(side)
+            ev_reads.synchronize()
+            eng.set_reads_device(d_toks.data_ptr(), d_offs.data_ptr(), N, vocab.two_v, borrow=True)
+            build()
+            if w["sweep"]:
+                ev_pos.synchronize()
+                eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr(), borrow=True)
+                sweep_after_first_build(False, readback=buf)
+            eng.nodes(buf)
+            eng.edges(buf)
+            eng.read_nodes(buf)
+
+        e2e_step()
+        torch.cuda.synchronize()
+        n_e2e = max(2, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            e2e_step()
+        torch.cuda.synchronize()
+        de = (time.perf_counter() - t0) / n_e2e
+        h2d = T * 4 + (N + 1) * 8 + (T * 16 + N * 8 if w["sweep"] else 0)
+        c_fin = eng.counts()
+        d2h = (c_fin["n_nodes"] * (4 * k + 4 + 8 + 1 + 4 + 1) + c_fin["n_edges"] * 14 + c_fin["n_tokens"] * 5
+               + (c_fin["n_tokens"] * 20 + c_fin["n_reads"] * 13 if w["sweep"] else 0))
+        e2e = {"value": n_windows / de, "unit": "gene-mers/s", "ms_per_step": de * 1e3, "steps": n_e2e,
+               "h2d_bytes": int(h2d), "d2h_bytes": int(d2h),
+               "region": "pinned host CSR (genes, offsets, gene positions, read lengths) -> H2D -> the step -> D2H of the "
+                         "final graph (node + edge arrays, node id and direction per window)"
+                         + (" and of the corrected calls with their positions" if w["sweep"] else "")
+                         + "; position upload overlapped with the first build on a second stream"}
+
     out = None
     if rank == 0:
         stage_avg = {n: v[0] / v[1] for n, v in stage_ms.items()}     # ms per launch
@@ -253,9 +470,10 @@ def main():
                      "edge_upsert": "k_edges_x" if exact else "k_edges", "node_count": "k_count_ids",
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_fast"}
-        build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear", "node_upsert", "node_rank",
-                                                        "edge_table_clear", "edge_upsert", "edge_rank", "node_count",
-                                                        "edge_count", "edge_emit", "components", "adjacency"))
+        build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
+                                                        "node_upsert", "node_rank", "edge_table_clear", "edge_upsert",
+                                                        "edge_rank", "node_count", "edge_count", "edge_emit",
+                                                        "components", "adjacency"))
         n_builds = max(stage_ms.get("graph_upsert", stage_ms.get("node_upsert", [0, 1]))[1], 1)
         survey_b = 4.0 * L / (L - k + 1) + 5 + (4 * k + 8) + 20.0 * (L - k) / (L - k + 1)
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this
@@ -302,8 +520,9 @@ def main():
                                          "unit": "GB/s"}},
             "stages_ms_per_step": {n: round(v, 3) for n, v in stage_tot.items()},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+        if e2e is not None:
+            out["e2e"] = e2e
+        out.update(cpu)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
