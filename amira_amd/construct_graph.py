@@ -1175,7 +1175,7 @@ class GeneMerGraph(BubblePopping):
     def _match_gene_lists(self, gene_lists):
         """Exact occurrences of every gene-string list in every read, on the device (kernel
         k_match, the batched form of is_sublist / find_sublist_indices / Tree.find_all).
-        Returns one dict {read index: [start positions]} per list, reads ascending."""
+        Returns one (read indices, start positions) pair of arrays per list, ordered by read, position."""
         table = self._vocab._tok
         pats, usable = [], []
         for genes in gene_lists:
@@ -1187,13 +1187,11 @@ class GeneMerGraph(BubblePopping):
         found = []
         for lo in range(0, len(usable), 60000):
             off, hit_read, hit_pos = self._engine.match_patterns(0, usable[lo:lo + 60000])
-            for j in range(len(off) - 1):
-                d = {}
-                for r, p in zip(hit_read[off[j]:off[j + 1]].tolist(), hit_pos[off[j]:off[j + 1]].tolist()):
-                    d.setdefault(r, []).append(p)
-                found.append(d)
+            off = off.tolist()
+            found.extend((hit_read[off[j]:off[j + 1]], hit_pos[off[j]:off[j + 1]]) for j in range(len(off) - 1))
+        nothing = (np.zeros(0, np.int32), np.zeros(0, np.int32))
         it = iter(found)
-        return [next(it) if p is not None else {} for p in pats]
+        return [next(it) if p is not None else nothing for p in pats]
 
     def get_all_sublists(self, lst, gene_call_subset, threshold, geneOfInterest, cores):
         """windows of a block's gene path that hold every copy of the gene and are carried by
@@ -1213,11 +1211,14 @@ class GeneMerGraph(BubblePopping):
         uniq = list(dict.fromkeys(combs))
         hits = self._match_gene_lists([list(c) for c in uniq] +
                                       [self.reverse_list_of_genes(list(c)) for c in uniq])
-        read_ids = self._read_ids
+        in_subset = np.zeros(len(self._read_ids) + 1, bool)   # reads that count (by row)
+        index = self._read_index
+        rows = [index.get(rid) for rid in gene_call_subset]
+        in_subset[[r for r in rows if r is not None]] = True
         support = {}
         for j, comb in enumerate(uniq):
-            reads = set(hits[j]) | set(hits[j + len(uniq)])
-            support[comb] = sum(1 for r in reads if read_ids[r] in gene_call_subset)
+            reads = np.union1d(hits[j][0], hits[j + len(uniq)][0])
+            support[comb] = int(in_subset[reads].sum())
         sublists = {}
         for comb in combs:
             if comb and support[comb] >= threshold:
@@ -1228,8 +1229,11 @@ class GeneMerGraph(BubblePopping):
                        geneOfInterest, cores):
         full_blocks = {}
         for a1 in nodeAnchors:
-            suffixes = get_suffixes_from_initial_tree(node_tree, a1)
-            sub_tree = Tree({r: list(reversed(s)) for r, s in suffixes.items()})
+            if hasattr(node_tree, "reversed_suffix_tree"):   # both steps at once, nothing re-interned
+                sub_tree = node_tree.reversed_suffix_tree(a1)
+            else:
+                suffixes = get_suffixes_from_initial_tree(node_tree, a1)
+                sub_tree = Tree({r: list(reversed(s)) for r, s in suffixes.items()})
             process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, node_tree, threshold)
         gene_blocks = {}
         for f in full_blocks:
@@ -1300,21 +1304,27 @@ class GeneMerGraph(BubblePopping):
                     named[g] = f"{gene[0]}{allele}"
                     allele_count += 1
             named = tuple(named)
-            fw_hits, rv_hits = hits[pi], hits[pi + len(paths)]
-            for r in sorted(set(fw_hits) | set(rv_hits)):  # read order == dict order of _reads
-                if r in fw_hits:
-                    starts, idx = fw_hits[r], fw_idx
-                else:
-                    starts, idx = rv_hits[r], rv_idx
-                if len(starts) != 1:
-                    continue
+            # reads that hold the path exactly once: forward occurrences decide; the reverse complement
+            # only counts for reads without any forward occurrence (:2401-2439)
+            (fw_reads, fw_pos), (rv_reads, rv_pos) = hits[pi], hits[pi + len(paths)]
+            fw_u, fw_first, fw_cnt = np.unique(fw_reads, return_index=True, return_counts=True)
+            rv_u, rv_first, rv_cnt = np.unique(rv_reads, return_index=True, return_counts=True)
+            rv_only = ~np.isin(rv_u, fw_u)
+            chosen = [(fw_u[fw_cnt == 1], fw_pos[fw_first[fw_cnt == 1]], fw_idx),
+                      (rv_u[rv_only & (rv_cnt == 1)], rv_pos[rv_first[rv_only & (rv_cnt == 1)]], rv_idx)]
+            rows = np.concatenate([c[0] for c in chosen])
+            starts = np.concatenate([c[1] for c in chosen])
+            which = np.concatenate([np.zeros(len(chosen[0][0]), np.int8), np.ones(len(chosen[1][0]), np.int8)])
+            order = np.argsort(rows, kind="stable")   # read order == dict order of _reads
+            for r, start, w in zip(rows[order].tolist(), starts[order].tolist(), which[order].tolist()):
+                idx = rv_idx if w else fw_idx
                 read_id = self._read_ids[r]
                 genes_on_read = self._reads[read_id]
                 path_reads.setdefault(named, set()).add(read_id)
                 for gene_index in idx:
-                    assert genes_on_read[starts[0] + gene_index][1:] == geneOfInterest
-                    s, e = self._genePositions[read_id][starts[0] + gene_index]
-                    entry = f"{read_id}_{s}_{e}"
+                    assert genes_on_read[start + gene_index][1:] == geneOfInterest
+                    s_, e_ = self._genePositions[read_id][start + gene_index]
+                    entry = f"{read_id}_{s_}_{e_}"
                     gene_clusters[idx[gene_index]].append(entry)
                     read_tracking[idx[gene_index]].add(entry)
         ranked = sorted([a for a in read_tracking], key=lambda x: len(read_tracking[x]), reverse=True)
@@ -1368,13 +1378,55 @@ class GeneMerGraph(BubblePopping):
                               path_threshold=5):
         """per gene of interest: anchors -> full blocks -> differentiating gene paths -> allele
         clusters (:2880-2939)."""
+        import gc
+        # No reference cycles are made below, but millions of live containers (a million-read graph)
+        # make every pass of the cyclic collector expensive and the clustering allocates enough to
+        # trigger thousands of them (measured: 8.6 of 21.7 s at BASELINE config 4): pause it.
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._assign_reads_to_genes(listOfGenes, cores, allele_counts, mean_node_coverage)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _node_tree_from_device_ids(self, reads_with_gene):
+        """construct_suffix_tree({r: readNodes[r]}) (path_finding_utils.py:79-85) without interning the
+        256-bit node hashes item by item: the search codes are the DEVICE node ids of the per-window
+        array (None = -2), the sequences stay lists of hashes.  Entry order as the reference builds it:
+        the reads in the given order, then '<read>_reverse' for every read with more than one distinct node."""
+        if not hasattr(Tree, "from_codes"):
+            return None   # the external suffix_tree package is in use
+        v = self._v()
+        tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
+        index, read_nodes = self._read_index, v.readNodes
+        keys, seqs, codes, late_keys, late_seqs, late_codes = [], [], [], [], [], []
+        for rid in reads_with_gene:
+            r = index[rid]
+            a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
+            ids = tok_node[a:a + n]
+            nodes = read_nodes[rid]
+            keys.append(rid)
+            seqs.append(nodes)
+            codes.append(ids)
+            if len(set(nodes)) != 1:
+                late_keys.append(rid + "_reverse")
+                late_seqs.append(nodes[::-1])
+                late_codes.append(ids[::-1])
+        to_id = v.node_of_hash
+        return Tree.from_codes(keys + late_keys, seqs + late_seqs, codes + late_codes,
+                               lambda x: -2 if x is None else to_id.get(x))
+
+    def _assign_reads_to_genes(self, listOfGenes, cores, allele_counts, mean_node_coverage):
         clustered_reads, path_reads = {}, {}
         if mean_node_coverage is None:
             mean_node_coverage = self.get_mean_node_coverage()
         for geneOfInterest in listOfGenes:
             hashes = [n.__hash__() for n in self.get_nodes_containing(geneOfInterest)]
             reads_with_gene = self.collect_reads_in_path(hashes)
-            node_tree = construct_suffix_tree({r: self.get_readNodes()[r] for r in reads_with_gene})
+            node_tree = None if self._host_edits else self._node_tree_from_device_ids(reads_with_gene)
+            if node_tree is None:
+                node_tree = construct_suffix_tree({r: self.get_readNodes()[r] for r in reads_with_gene})
             gene_call_subset = {r: self._reads[r] for r in reads_with_gene}
             flipped = {r + "_reverse": self.reverse_list_of_genes(g) for r, g in gene_call_subset.items()}
             gene_call_subset.update(flipped)

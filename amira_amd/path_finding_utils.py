@@ -33,18 +33,76 @@ class _ScanTree:
 
     def __init__(self, data=None):
         import numpy as np
+        from itertools import chain
         self._np = np
-        self._keys, self._seqs = [], []
-        code = self._code = {}
-        flat, starts = [], [0]
-        for key, seq in (data or {}).items():
-            seq = list(seq)
-            self._keys.append(key)
-            self._seqs.append(seq)
-            flat.extend(code.setdefault(x, len(code)) for x in seq)
-            starts.append(len(flat))
-        self._flat = np.asarray(flat, dtype=np.int64)
-        self._starts = np.asarray(starts, dtype=np.int64)
+        self._keys = list((data or {}).keys())
+        self._seqs = [list(seq) for seq in (data or {}).values()]
+        starts = np.zeros(len(self._seqs) + 1, dtype=np.int64)
+        np.cumsum([len(seq) for seq in self._seqs], out=starts[1:])
+        self._starts = starts
+        try:
+            # items that are machine integers already (node ids) need no interning: one C-level pass
+            self._flat = np.fromiter(chain.from_iterable(self._seqs), dtype=np.int64, count=int(starts[-1]))
+            self._code = None
+        except (TypeError, ValueError, OverflowError):
+            code = self._code = {}   # 256-bit node hashes, None for masked nodes, strings, ...
+            flat = []
+            for seq in self._seqs:
+                flat.extend(code.setdefault(x, len(code)) for x in seq)
+            self._flat = np.asarray(flat, dtype=np.int64)
+
+    @classmethod
+    def from_codes(cls, keys, seqs, code_arrays, code_of):
+        """sequences whose integer codes are known already (device node ids of the per-window array):
+        `seqs` are the item lists themselves (what suffixes are cut from), `code_arrays` their codes as
+        numpy arrays, `code_of(item)` the code of a query item (None: no sequence holds it)"""
+        import numpy as np
+        self = cls.__new__(cls)
+        self._np = np
+        self._keys, self._seqs = list(keys), list(seqs)
+        starts = np.zeros(len(code_arrays) + 1, dtype=np.int64)
+        np.cumsum([len(a) for a in code_arrays], out=starts[1:])
+        self._starts = starts
+        self._flat = (np.concatenate(code_arrays).astype(np.int64) if len(code_arrays) else np.zeros(0, np.int64))
+        self._code = code_of
+        return self
+
+    def _codes_of(self, query):
+        np = self._np
+        if self._code is None:
+            if not all(isinstance(x, (int, np.integer)) and not isinstance(x, bool) for x in query):
+                return None
+            return query
+        lookup = self._code if callable(self._code) else self._code.get
+        codes = [lookup(x) for x in query]
+        return None if None in codes else codes
+
+    def reversed_suffix_tree(self, item):
+        """get_suffixes_from_initial_tree(self, item) followed by Tree({key: reversed(suffix)}) (the two
+        steps of get_full_paths, path_finding_utils.py:88-100 + construct_graph.py:2732-2735) without
+        re-interning a single item: per key the LONGEST suffix that starts at an occurrence of `item`
+        (= its first occurrence), reversed; codes are cut out of this tree's own code array."""
+        np = self._np
+        codes = self._codes_of([item])
+        sub = type(self).__new__(type(self))
+        sub._np, sub._code = np, self._code
+        if codes is None or len(self._flat) == 0:
+            sub._keys, sub._seqs = [], []
+            sub._starts, sub._flat = np.zeros(1, np.int64), np.zeros(0, np.int64)
+            return sub
+        at = np.flatnonzero(self._flat == codes[0])
+        row = np.searchsorted(self._starts, at, side="right") - 1
+        first = np.concatenate([[True], row[1:] != row[:-1]]) if len(row) else np.zeros(0, bool)
+        at, row = at[first], row[first]
+        ends = self._starts[row + 1]
+        sub._keys = [self._keys[r] for r in row.tolist()]
+        sub._seqs = [self._seqs[r][a - s:][::-1] for r, a, s in zip(row.tolist(), at.tolist(), self._starts[row].tolist())]
+        pieces = [self._flat[a:e][::-1] for a, e in zip(at.tolist(), ends.tolist())]
+        starts = np.zeros(len(pieces) + 1, dtype=np.int64)
+        np.cumsum(ends - at, out=starts[1:])
+        sub._starts = starts
+        sub._flat = np.concatenate(pieces) if pieces else np.zeros(0, np.int64)
+        return sub
 
     def find_all(self, query):
         np = self._np
@@ -52,8 +110,8 @@ class _ScanTree:
         m = len(query)
         if m == 0 or len(self._flat) == 0:
             return []
-        codes = [self._code.get(x) for x in query]
-        if None in codes:   # an item no sequence holds
+        codes = self._codes_of(query)
+        if codes is None:   # an item no sequence holds
             return []
         flat, starts = self._flat, self._starts
         at = np.flatnonzero(flat == codes[0])

@@ -249,3 +249,69 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
         for e in engines:
             e.close()
         orc.close()
+
+
+def test_cfg4_full_size_build_and_planted_alleles():
+    """BASELINE config 4 at full size (1 M error-free reads, 10 AMR genes planted in 2 - 3 genome
+    contexts each): the device build equals the sequential C oracle, and the read-path clustering
+    through the reference-shaped API finds exactly the planted alleles, each path's read set equal to a
+    direct token-space computation (reads that hold the path exactly once, forward occurrences first —
+    construct_graph.py:2401-2439 — found by sliding comparisons over the raw token array)."""
+    import re
+    import bench
+    from amira_amd import Engine, GeneMerGraph, synth
+    from amira_amd.io import TokenizedPositions, TokenizedReads
+    w = bench.WORKLOADS["cfg4"]
+    N, L, k = w["N"], w["L"], w["k"]
+    vocab, toks, offs = bench.make_tokens(w, 0, N)
+    # ---- build == C oracle
+    eng = Engine(0)
+    eng.set_reads(toks, offs, vocab.two_v)
+    eng.build(k)
+    want = token_oracle.build(toks, offs, k, vocab.two_v)
+    nodes, edges = eng.nodes(), eng.edges()
+    assert np.array_equal(nodes["tokens"], want["tokens"]) and np.array_equal(nodes["coverage"], want["coverage"])
+    for a, b in (("src", "src"), ("tgt", "tgt"), ("sdir", "sdir"), ("tdir", "tdir"), ("coverage", "ecov")):
+        assert np.array_equal(edges[a], want[b]), a
+    assert np.array_equal(eng.read_nodes()[0], want["tok_node"])
+    eng.close()
+    # ---- clustering
+    read_ids = synth.read_names(0, N)
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    g = GeneMerGraph(TokenizedReads(vocab, toks, offs, read_ids), k, TokenizedPositions(read_ids, offs, gs, gs + 899))
+    genes = [f"amr{j}" for j in range(w["n_amr"])]
+    clustered, path_reads = g.assign_reads_to_genes(genes, 1, {}, None)
+    alleles = {gene: d for comp in clustered.values() for gene, d in comp.items()}
+    assert [len(alleles[f"amr{j}"]) for j in range(10)] == [2 + (j % 2) for j in range(10)]   # the planted copies
+
+    mat = toks.reshape(N, L)
+
+    def occurrences(pattern):
+        """(read, count) of the token pattern, by direct comparison of shifted columns"""
+        m = len(pattern)
+        hit = np.ones((N, L - m + 1), bool)
+        for j, t in enumerate(pattern):
+            hit &= mat[:, j:L - m + 1 + j] == t
+        return hit.sum(axis=1)
+
+    flip = vocab.two_v - 1
+    checked = 0
+    for named, reads in path_reads.items():
+        genes_on_path = [re.sub(r"^([+-]amr\d+)_\d+$", r"\1", x) for x in named]
+        fwd = [vocab.token(x) for x in genes_on_path]
+        rev = [flip - t for t in reversed(fwd)]
+        n_fw, n_rv = occurrences(fwd), occurrences(rev)
+        holds = (n_fw == 1) | ((n_fw == 0) & (n_rv == 1))
+        assert set(np.flatnonzero(holds).tolist()) == {int(r[1:]) for r in reads}, named
+        checked += 1
+    assert checked >= 25
+    for gene, d in alleles.items():
+        seen = set()
+        token_p, token_m = vocab.token("+" + gene), vocab.token("-" + gene)
+        carriers = set(np.flatnonzero(((mat == token_p) | (mat == token_m)).any(axis=1)).tolist())
+        for allele, entries in d.items():
+            rows = {int(e.split("_")[0][1:]) for e in entries}
+            assert rows <= carriers and not (rows & seen), (gene, allele)   # alleles of a gene share no read
+            assert 2000 < len(rows) < 4000                                    # ~3 000x depth per copy
+            seen |= rows
+    g.close()
