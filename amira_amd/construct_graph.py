@@ -1427,9 +1427,11 @@ class GeneMerGraph(BubblePopping):
             node_tree = None if self._host_edits else self._node_tree_from_device_ids(reads_with_gene)
             if node_tree is None:
                 node_tree = construct_suffix_tree({r: self.get_readNodes()[r] for r in reads_with_gene})
-            gene_call_subset = {r: self._reads[r] for r in reads_with_gene}
-            flipped = {r + "_reverse": self.reverse_list_of_genes(g) for r, g in gene_call_subset.items()}
-            gene_call_subset.update(flipped)
+            # (the reference hands the gene lists of these reads and of their reverse complements to a
+            # suffix tree per window length; get_all_sublists here only asks WHICH reads count, so the
+            # keys are enough and no read is decoded into strings)
+            gene_call_subset = dict.fromkeys(reads_with_gene)
+            gene_call_subset.update(dict.fromkeys([r + "_reverse" for r in reads_with_gene]))
             paths, coverages = self.get_paths_for_gene(node_tree, gene_call_subset, hashes,
                                                        mean_node_coverage / 20, geneOfInterest, cores)
             alleles, path_reads = self.split_into_subpaths(geneOfInterest, paths, coverages, path_reads,
