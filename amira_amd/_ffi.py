@@ -56,6 +56,7 @@ def _load():
         "amg_set_read_lengths": (C.c_int, [P, P, C.c_int]),
         "amg_build": (C.c_int, [P, I32]),
         "amg_counts": (C.c_int, [P, C.POINTER(Counts)]),
+        "amg_finalize": (C.c_int, [P]),
         "amg_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
         "amg_graph_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),
         "amg_get_nodes": (C.c_int, [P, P, P, P, P, P, P]),

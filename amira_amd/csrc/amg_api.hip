@@ -136,7 +136,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,
                    &c->edge_src,  &c->edge_tgt,  &c->edge_sdir,  &c->edge_tdir, &c->edge_cov,
-                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
+                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->ladj_pos, &c->ladj_keys, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_owned, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp,   &c->s0, &c->s1, &c->s2, &c->s3,
                    &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->f_ctrs, &c->x_efinal, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
@@ -288,6 +288,7 @@ extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
   o->n_nodes = c->n_nodes;
   o->n_edges = c->n_edges;
   o->n_pairs = c->n_pairs;
+  AMGCHK(ensure_components(c));
   o->n_components = c->n_components;
   o->node_table_slots = c->node_slots;
   o->edge_table_slots = c->edge_slots;
@@ -327,6 +328,7 @@ extern "C" int amg_get_nodes(amg_ctx* c, int32_t* canon_tokens, uint32_t* covera
                              uint8_t* alive) {
   NEED_BUILT(c);
   const size_t D = (size_t)c->n_nodes;
+  if (component) AMGCHK(ensure_components(c));
   AMGCHK(d2h(c, canon_tokens, c->node_tokens, D * c->k * sizeof(int32_t)));
   AMGCHK(d2h(c, coverage, c->node_cov, D * sizeof(uint32_t)));
   AMGCHK(d2h(c, component, c->node_comp, D * sizeof(int32_t)));
@@ -368,6 +370,7 @@ extern "C" int amg_get_read_nodes(amg_ctx* c, int32_t* tok_node, int8_t* tok_dir
 
 extern "C" int amg_get_node_adj(amg_ctx* c, int64_t* offsets, int32_t* edge_ids) {
   NEED_BUILT(c);
+  AMGCHK(ensure_adjacency(c));
   AMGCHK(d2h(c, offsets, c->adj_off, (size_t)(2 * c->n_nodes + 1) * sizeof(int64_t)));
   AMGCHK(d2h(c, edge_ids, c->adj_edge, (size_t)c->n_edges * sizeof(int32_t)));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -728,50 +728,71 @@ int bs_pairs_from_local(amg_ctx* c) {
   return AMG_OK;
 }
 
-// pair_key / pair_cnt / pair_first hold the c->n_pairs edge classes in first-seen order
+// pair_key / pair_cnt / pair_first hold the c->n_pairs edge classes in first-seen order: directed
+// edges in _edges order.  Component ids and the forward / backward edge lists are made when
+// somebody asks for them (ensure_components / ensure_adjacency; amg_finalize does both): of the three
+// graphs of a cleaning sweep only the second needs its components (tip clipping) and none needs the
+// lists of removed edges — the correction walks the LIVE adjacency, built from the live edges alone.
 int bs_finish_from_pairs(amg_ctx* c) {
   hipStream_t st = c->stream;
-  const long long P = c->n_pairs, D = c->n_nodes, R = c->n_reads;
+  const long long P = c->n_pairs, R = c->n_reads;
   stage_begin(c, "edge_emit");
   AMGCHK(c->s3.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(P + 2) * sizeof(long long)));
   unsigned int* width = c->s3.as<unsigned int>();
   long long* base = c->s5.as<long long>();
+  // at most two directed edges per class: the arrays are sized before the exact count is known
+  const long long cap = 2 * P;
+  AMGCHK(c->edge_src.ensure((size_t)(cap + 2) * sizeof(int)));
+  AMGCHK(c->edge_tgt.ensure((size_t)(cap + 2) * sizeof(int)));
+  AMGCHK(c->edge_sdir.ensure((size_t)(cap + 2)));
+  AMGCHK(c->edge_tdir.ensure((size_t)(cap + 2)));
+  AMGCHK(c->edge_cov.ensure((size_t)(cap + 2) * sizeof(unsigned int)));
+  AMGCHK(c->edge_alive.ensure((size_t)(cap + 2)));
+  AMGCHK(c->read_fix.ensure((size_t)R + 1));
+  {
+    ClearList cl;
+    if (P > 0) cl.add(width + P, sizeof(unsigned int));
+    cl.add(c->read_fix.p, (size_t)R + 1);
+    AMGCHK(clear_many(c, cl));
+  }
+  long long total = 0;
   if (P > 0) {
-    HIPCHK(hipMemsetAsync(width + P, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k_pair_width, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                        c->pair_key.as<unsigned long long>(), P, width);
     AMGCHK(prim_exscan_u32_to_i64(c, width, base, (size_t)P + 1));
-    long long total = 0;
-    HIPCHK(hipMemcpyAsync(&total, base + P, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    c->n_edges = total;
-  } else {
-    c->n_edges = 0;
-  }
-  const long long E = c->n_edges;
-  AMGCHK(c->edge_src.ensure((size_t)(E + 2) * sizeof(int)));
-  AMGCHK(c->edge_tgt.ensure((size_t)(E + 2) * sizeof(int)));
-  AMGCHK(c->edge_sdir.ensure((size_t)(E + 2)));
-  AMGCHK(c->edge_tdir.ensure((size_t)(E + 2)));
-  AMGCHK(c->edge_cov.ensure((size_t)(E + 2) * sizeof(unsigned int)));
-  AMGCHK(c->edge_alive.ensure((size_t)(E + 2)));
-  if (P > 0)
     hipLaunchKernelGGL(k_emit_edges, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                        c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(),
                        c->pair_first.as<unsigned long long>(), P, base, c->edge_src.as<int>(),
                        c->edge_tgt.as<int>(), c->edge_sdir.as<signed char>(),
                        c->edge_tdir.as<signed char>(), c->edge_cov.as<unsigned int>(),
                        c->edge_alive.as<unsigned char>());
+    HIPCHK(hipMemcpyAsync(&total, base + P, sizeof(long long), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));  // the build's one final synchronisation
+  c->n_edges = total;
   stage_end(c);
+  c->ladj_valid = false;
+  c->comp_valid = false;
+  c->adj_valid = false;
+  c->n_components = 0;
+  return AMG_OK;
+}
 
-  // ---- components
+// assign_component_ids (construct_graph.py:920-927) of the graph AS BUILT (all edge classes, whatever was
+// removed since: the reference labels once, in __init__)
+int ensure_components(amg_ctx* c) {
+  if (c->comp_valid) return AMG_OK;
+  hipStream_t st = c->stream;
+  const long long P = c->n_pairs, D = c->n_nodes;
   stage_begin(c, "components");
+  AMGCHK(c->node_comp.ensure((size_t)(D + 1) * sizeof(int)));
   int* parent = c->node_comp.as<int>();  // holds roots until k_uf_label rewrites it
   AMGCHK(c->s1.ensure((size_t)(D + 2) * sizeof(long long)));  // root ranks
   AMGCHK(c->s2.ensure((size_t)(D + 2) * sizeof(unsigned int) + (size_t)(D + 2) * sizeof(int)));
   unsigned int* is_root = c->s2.as<unsigned int>();
   int* root_copy = reinterpret_cast<int*>(is_root + (D + 2));
+  long long ncomp = 0;
   if (D > 0) {
     hipLaunchKernelGGL(k_uf_init, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D);
     if (P > 0)
@@ -783,14 +804,21 @@ int bs_finish_from_pairs(amg_ctx* c) {
     HIPCHK(hipMemcpyAsync(root_copy, parent, (size_t)D * sizeof(int), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
                        c->s1.as<long long>(), D, parent);
-    // the component count travels with the final synchronisation of the build (one host round
-    // trip fewer); s1 is reused below, so park the value in a status word first
-    HIPCHK(hipMemcpyAsync(c->status.as<unsigned long long>() + ST_COMPACT_A, c->s1.as<long long>() + D,
-                          sizeof(long long), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(&ncomp, c->s1.as<long long>() + D, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
   }
   stage_end(c);
+  c->n_components = ncomp;
+  c->comp_valid = true;
+  return AMG_OK;
+}
 
-  // ---- adjacency lists
+// forwardEdgeHashes / backwardEdgeHashes of every node (construct_node.py:79-101): all edges ever
+// inserted, in list order; removed edges stay listed (test `alive`)
+int ensure_adjacency(amg_ctx* c) {
+  if (c->adj_valid) return AMG_OK;
+  hipStream_t st = c->stream;
+  const long long D = c->n_nodes, E = c->n_edges;
   stage_begin(c, "adjacency");
   AMGCHK(c->adj_off.ensure((size_t)(2 * D + 2) * sizeof(long long)));
   AMGCHK(c->adj_edge.ensure((size_t)(E + 2) * sizeof(int)));
@@ -809,16 +837,18 @@ int bs_finish_from_pairs(amg_ctx* c) {
   hipLaunchKernelGGL(k_row_offsets, dim3(blocks_for(E + 1, 256)), dim3(256), 0, st,
                      c->s3.as<unsigned int>(), E, 2 * D, c->adj_off.as<long long>());
   stage_end(c);
+  c->adj_valid = true;
+  return AMG_OK;
+}
 
-  c->ladj_valid = false;
-  AMGCHK(c->read_fix.ensure((size_t)R + 1));
-  HIPCHK(hipMemsetAsync(c->read_fix.p, 0, (size_t)R + 1, st));
-  long long ncomp = 0;
-  if (D > 0)
-    HIPCHK(hipMemcpyAsync(&ncomp, c->status.as<unsigned long long>() + ST_COMPACT_A, sizeof(long long),
-                          hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  c->n_components = ncomp;
+extern "C" int amg_finalize(amg_ctx* c) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!c->built) return amg_fail(AMG_E_STATE, "amg_build first");
+  HIPCHK(hipSetDevice(c->device));
+  stages_reset(c);
+  AMGCHK(ensure_components(c));
+  AMGCHK(ensure_adjacency(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return AMG_OK;
 }
 

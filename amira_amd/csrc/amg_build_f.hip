@@ -23,6 +23,8 @@
 //   * tiles advance by 1020 windows and compute 1024: the last four belong to the next tile and
 //     only the first of them is used (as the right-hand neighbour of window 1019); its insert is
 //     the same find-or-create the owning tile performs, so whichever comes first creates the slot.
+#include <type_traits>
+#include <vector>
 #include "amg_tile.h"
 #include "amg_x.h"
 
@@ -33,184 +35,10 @@
 
 static_assert(F_BIT_WORDS <= BND_PAD_WORDS, "read-end bitmap padding too small for the fused tiles");
 
-// Canonical orientation + packed key of the window a[0..K-1] for 16-bit tokens (two_v <= 65536),
-// K odd.  Forward half-words a[j] | a[j+1] << 16, reverse-complement half-words
-// (F | F << 16) - (a[j+1] | a[j] << 16).  Encoding == x_pack with bits = 16.
-template <int K, bool TWO>
-__device__ __forceinline__ int f_canon_pack16(const int* a, int flip, unsigned long long& w1, unsigned int& tag) {
-  int dir = (2 * a[K / 2] < flip) ? 1 : -1;  // 2 x != 2V - 1: an odd k has no palindromes
-#pragma unroll
-  for (int j = K / 2 - 1; j >= 0; --j) {
-    const int s = a[j] + a[K - 1 - j];
-    dir = s != flip ? (s < flip ? 1 : -1) : dir;
-  }
-  const unsigned int ff = (unsigned int)flip | ((unsigned int)flip << 16);
-  unsigned int word[K / 2 + 1];
-#pragma unroll
-  for (int m = 0; m < K / 2; ++m) {
-    const unsigned int fw = (unsigned int)a[2 * m] | ((unsigned int)a[2 * m + 1] << 16);
-    const unsigned int rc = ff - ((unsigned int)a[K - 1 - 2 * m] | ((unsigned int)a[K - 2 - 2 * m] << 16));
-    word[m] = dir > 0 ? fw : rc;
-  }
-  word[K / 2] = (unsigned int)(dir > 0 ? a[K - 1] : flip - a[0]);
-  const unsigned long long v = (unsigned long long)word[0] | ((unsigned long long)word[1] << 32);
-  w1 = (v << 1) | 1ull;
-  if constexpr (K == 3)
-    tag = 1u;
-  else  // K == 5
-    tag = (((word[1] >> 31) | (word[K / 2] << 1)) << 1) | 1u;
-  return dir;
-}
-
-// ---- one table phase for the four items of a thread: probe, insert, claim ids, first-seen.
-//
-// Claim ids come from F_SHARDS counters, one per shard (a wave belongs to one shard): a single
-// counter word takes ~90 returning atomics per microsecond, which is what a tile per 1024 tokens
-// asks of it at the speed of this pass; 64 words do not notice.  Claims are INTERLEAVED, claim =
-// local index * F_SHARDS + shard, so that the early (hot) claims of every shard are small numbers
-// and the claim space [0, F_SHARDS * largest local count) has few holes (entries of the per-claim
-// arrays that nobody claimed keep first-seen == 0 and are skipped wherever claims are listed).
-// The creators of a wave are counted with ballots and served by one atomicAdd of the wave:
-// no LDS, no workgroup barrier.
-#define F_SHARDS 64
-#define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
-
-template <class T>
-__device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
-  return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3];
-}
-
-template <bool TWO, int FSH>
-__device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
-                                              const unsigned long long (&w1)[TILE_ITEMS],
-                                              const unsigned int (&tag)[TILE_ITEMS],
-                                              const unsigned int (&idx)[TILE_ITEMS],
-                                              const ulonglong2 (&v)[TILE_ITEMS], unsigned int tbase,
-                                              unsigned int lowbits, const XW2 f, unsigned int* first2,
-                                              unsigned int* __restrict__ slot_by_claim,
-                                              unsigned long long* ctr, unsigned int shard, unsigned int cap,
-                                              unsigned int probe_limit, unsigned long long* status, int which,
-                                              unsigned int (&id1)[TILE_ITEMS]) {
-  auto tpos = [&](int it) { return tbase + (unsigned int)it; };
-  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
-  unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
-  int slot[TILE_ITEMS];
-  // ---- the key with its id, as the first probe load returned it: done (almost every window of a
-  // rebuild).  Anything else goes through x_upsert below, one item at a time, in ONE copy of that code.
-  unsigned int need = 0, created = 0;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    id1[it] = 0;
-    lw[it] = 0;
-    slot[it] = (int)idx[it];
-    if (!TWO) hw[TWO ? 0 : it] = 0;
-    if (!(valid & (1u << it))) continue;
-    const unsigned long long c1 = v[it].x, c2 = v[it].y;
-    const bool mine = c1 == w1[it] && (!TWO || (unsigned int)(c2 >> 32) == tag[it]);
-    if (mine && (unsigned int)c2 != 0u) {
-      lw[it] = (unsigned int)c2;
-      if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(c2 >> 32);
-    } else {
-      need |= 1u << it;
-    }
-  }
-  while (need) {
-    const int it = __ffs((int)need) - 1;
-    need &= need - 1u;
-    bool made;
-    unsigned long long w2v;
-    // (the slot is loaded again rather than picked out of v[]: a register array indexed at run time
-    // lives in scratch memory)
-    const unsigned int ix = f_pick(idx, it);
-    const int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
-                                 *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit,
-                                 status + ST_OVERFLOW, w2v, made);
-    if (sl < 0) {
-      status[ST_OVERFLOW] = (unsigned long long)which;
-      valid &= ~(1u << it);
-    }
-#pragma unroll
-    for (int j = 0; j < TILE_ITEMS; ++j)
-      if (j == it) {
-        slot[j] = sl;
-        lw[j] = (unsigned int)w2v;
-        if (!TWO) hw[TWO ? 0 : j] = (unsigned int)(w2v >> 32);
-      }
-    if (made) created |= 1u << it;
-  }
-  // ---- claim ids of the wave's creators
-  const unsigned int lane = threadIdx.x & 63u;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  unsigned int n = 0, pre[TILE_ITEMS];
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    const unsigned long long m = __ballot((created >> it) & 1u);
-    pre[it] = n + (unsigned int)__popcll(m & below);
-    n += (unsigned int)__popcll(m);
-  }
-  unsigned int base = 0;
-  if (n) {  // wave-uniform
-    unsigned int b = 0;
-    if (lane == 0) b = (unsigned int)atomicAdd(ctr, (unsigned long long)n);
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
-  }
-  if (created) {
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it)
-      if (created & (1u << it)) {
-        unsigned int li = base + pre[it];
-        if (li >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
-          status[ST_OVERFLOW] = (unsigned long long)which;
-          li = 0;
-        }
-        const unsigned int claim = li * F_SHARDS + shard;
-        // the creator's first-seen goes to its own word with a plain store; everybody else raises the
-        // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
-        // has to be ordered against the publication of the id
-        first2[2u * claim + 1u] = fi(it);
-        slot_by_claim[claim] = (unsigned int)slot[it];
-        id1[it] = claim + 1u;
-        const unsigned long long pub =
-            TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
-                      (unsigned long long)(claim + 1u)
-                : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
-        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-  }
-  // ---- found keys: wait for an id that is still on its way (a creator publishes without waiting
-  // for anybody, after at most its own wave's atomicAdd), then keep the minimum first-seen
-  unsigned int check = 0;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (!(valid & (1u << it)) || (created & (1u << it))) continue;
-    unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
-    for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
-      w = ld_u64(&tab[slot[it]].w2);
-      if ((unsigned int)w != 0u) break;
-      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
-        status[ST_MISC] = 1ull;
-        w = 1ull;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    id1[it] = xw2_id1<TWO>(w, f);
-    // can this window precede the creator's?  (coarse positions: same or earlier bucket)
-    const bool maybe_first = TWO ? (tpos(it) >> f.cshift) <= (((unsigned int)w) >> f.ib)
-                                 : fi(it) > (unsigned int)(w >> 32);
-    if (maybe_first) check |= 1u << it;
-  }
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (!(check & (1u << it))) continue;
-    // plain (possibly stale, at worst zero) reads: both words only grow, so a stale value can only
-    // cause a superfluous atomicMax, never a missed one
-    const unsigned int c = id1[it] - 1u;
-    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
-  }
-}
-
-template <int K, bool TWO, bool B16>  // K > 0: k known at compile time; B16: 16 bits per token (K = 3 or 5)
+// PHASE 0: both halves in one launch.  PHASE 1 / 2: the node half / the edge half alone (two launches, the
+// per-window claims and directions travel through tok_claim / tok_dir): each launch then keeps ONE
+// table's hot lines in the L2s.
+template <int K, bool TWO, bool B16, int PHASE>  // K > 0: k known at compile time; B16: 16 bits per token (K = 3 or 5)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* ntab, unsigned int nmask, Slot16* etab, unsigned int emask, unsigned int probe_limit,
@@ -222,15 +50,15 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
 #define F_STAMP(i)                                                                     \
   if (AMG_EXPERIMENTS && stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime()
   F_STAMP(0);
-  __shared__ __attribute__((aligned(16))) int s_tok[F_SPAN + AMG_MAX_K + 4];
-  __shared__ unsigned int s_bits[F_BIT_WORDS];
-  __shared__ __attribute__((aligned(16))) int s_claim[F_SPAN + 4];
+  __shared__ __attribute__((aligned(16))) int s_tok[PHASE == 2 ? 4 : F_SPAN + AMG_MAX_K + 4];
+  __shared__ unsigned int s_bits[PHASE == 2 ? 1 : F_BIT_WORDS];
+  __shared__ __attribute__((aligned(16))) int s_claim[PHASE == 1 ? 4 : F_SPAN + 4];
   const int tid = threadIdx.x;
   const long long t0 = (long long)blockIdx.x * F_STRIDE;  // 16-byte aligned in every per-token array
   const int flip = two_v - 1;
   const unsigned int shard = (blockIdx.x * (TILE_THREADS / 64) + (tid >> 6)) & (F_SHARDS - 1);
   // ---- stage tokens t0 .. t0 + F_SPAN + k - 2 and the tile's slice of the read-end bitmap
-  {
+  if constexpr (PHASE != 2) {
     bool bad = false;
     if (t0 + F_SPAN <= n_tokens) {
       const int4 x = reinterpret_cast<const int4*>(tokens + t0)[tid];
@@ -253,15 +81,16 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
     }
     if (bad) status[ST_BADINPUT] = 2;  // a token outside [0, two_v) would alias another tuple
     if (tid < F_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
+    __syncthreads();
   }
-  __syncthreads();
   F_STAMP(1);
 
   // ---- nodes: four consecutive windows per thread
   const int i0 = 4 * tid;
   unsigned int id1[TILE_ITEMS];
   unsigned int last = 0, ndir = 0;  // per window: last of its read; direction -1
-  {
+  int cw[TILE_ITEMS + 1];
+  if constexpr (PHASE != 2) {
     unsigned long long w1[TILE_ITEMS];
     unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS];
     ulonglong2 v[TILE_ITEMS];
@@ -288,7 +117,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
       idx[w] = 0;
       const long long t = t0 + i0 + w;
       const bool inside = ((b >> w) & ((1u << (k - 1)) - 1u)) == 0u;
-      const bool ok = (t + k <= n_tokens) && inside && (tid < TILE_THREADS - 1 || w == 0);
+      const bool ok = (t + k <= n_tokens) && inside && (tid < TILE_THREADS - 1 || (w == 0 && PHASE == 0));
       if (!ok) continue;
       int dir;
       if constexpr (K > 0 && B16) {
@@ -311,24 +140,46 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
       if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
     }
     F_STAMP(2);
-    f_table_phase<TWO, 1>(ntab, nmask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, nxf, nfirst2,
+    f_table_phase<TWO, 1, true>(ntab, nmask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, nxf, nfirst2,
                           nslot_by_claim, ctrs + (size_t)shard * F_CTR_STRIDE, shard, ncap, probe_limit, status, 1, id1);
   }
   F_STAMP(3);
 
   // ---- hand the claims to the neighbours: word = claim | last-of-read << 31 | (direction -1) << 30
-  int cw[TILE_ITEMS + 1];
+  if constexpr (PHASE != 2) {
 #pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w)
-    cw[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
-                           ((ndir & (1u << w)) ? F_DIRBIT : 0u))
-                   : -1;
-  reinterpret_cast<int4*>(s_claim)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
-  __syncthreads();
-  cw[TILE_ITEMS] = tid < TILE_THREADS - 1 ? s_claim[i0 + TILE_ITEMS] : -1;
+    for (int w = 0; w < TILE_ITEMS; ++w)
+      cw[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
+                             ((ndir & (1u << w)) ? F_DIRBIT : 0u))
+                     : -1;
+  } else {
+    // the node half's outputs of this tile (the halo thread takes the next tile's first window)
+    const long long t = t0 + i0;
+    int4 x = make_int4(-1, -1, -1, -1);
+    unsigned int d = 0;
+    if (t + TILE_ITEMS <= n_tokens) {
+      x = *reinterpret_cast<const int4*>(tok_claim + t);
+      d = *reinterpret_cast<const unsigned int*>(tok_dir + t);
+    } else {
+      if (t + 0 < n_tokens) { x.x = tok_claim[t + 0]; d |= (unsigned int)(unsigned char)tok_dir[t + 0]; }
+      if (t + 1 < n_tokens) { x.y = tok_claim[t + 1]; d |= (unsigned int)(unsigned char)tok_dir[t + 1] << 8; }
+      if (t + 2 < n_tokens) { x.z = tok_claim[t + 2]; d |= (unsigned int)(unsigned char)tok_dir[t + 2] << 16; }
+      if (t + 3 < n_tokens) { x.w = tok_claim[t + 3]; d |= (unsigned int)(unsigned char)tok_dir[t + 3] << 24; }
+    }
+    cw[0] = x.x == -1 ? -1 : (int)((unsigned int)x.x | ((d & 0x80u) ? F_DIRBIT : 0u));
+    cw[1] = x.y == -1 ? -1 : (int)((unsigned int)x.y | ((d & 0x8000u) ? F_DIRBIT : 0u));
+    cw[2] = x.z == -1 ? -1 : (int)((unsigned int)x.z | ((d & 0x800000u) ? F_DIRBIT : 0u));
+    cw[3] = x.w == -1 ? -1 : (int)((unsigned int)x.w | ((d & 0x80000000u) ? F_DIRBIT : 0u));
+    if (tid == TILE_THREADS - 1) cw[1] = cw[2] = cw[3] = -1;  // they are the next tile's
+  }
+  if constexpr (PHASE != 1) {
+    reinterpret_cast<int4*>(s_claim)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
+    __syncthreads();
+    cw[TILE_ITEMS] = tid < TILE_THREADS - 1 ? s_claim[i0 + TILE_ITEMS] : -1;
+  }
 
   // ---- per-window outputs of the node half (the halo thread owns none)
-  if (tid < TILE_THREADS - 1) {
+  if (PHASE != 2 && tid < TILE_THREADS - 1) {
     int oc[TILE_ITEMS];
     unsigned int od = 0;
 #pragma unroll
@@ -354,7 +205,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
 
   // ---- edges: adjacency (A, dA) -> (B, dB) of windows t and t + 1 of one read (create_edges :246-262);
   // class key = (smaller claim, larger claim, dA * dB), first-seen = (token << 3) | orientation
-  {
+  if constexpr (PHASE != 1) {
     unsigned long long key[TILE_ITEMS];
     unsigned int idx[TILE_ITEMS], etag[TILE_ITEMS];
     ulonglong2 v[TILE_ITEMS];
@@ -378,12 +229,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_graph_x(
       valid |= 1u << w;
     }
     F_STAMP(5);
-    f_table_phase<false, 3>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, exf, efirst2,
+    f_table_phase<false, 3, true>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, exf, efirst2,
                             eslot_by_claim, ctrs + (size_t)(F_SHARDS + shard) * F_CTR_STRIDE, shard, ecap, probe_limit,
                             status, 2, id1);
   }
   F_STAMP(6);
-  if (tid < TILE_THREADS - 1) {
+  if (PHASE != 1 && tid < TILE_THREADS - 1) {
     const long long t = t0 + i0;
     if (t + TILE_ITEMS <= n_tokens) {
       *reinterpret_cast<int4*>(tok_pair + t) =
@@ -424,6 +275,14 @@ int bx_bits(const amg_ctx* c, int k) {
   return need;
 }
 
+// AMG_FUSED: 0 = the two passes of amg_build_x.hip, 1 = one fused launch, 2 = this file's kernel as two
+// launches (node half, edge half)
+static int f_mode() {
+  const char* e = getenv("AMG_FUSED");
+  if (!e) return 0;
+  return e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0;
+}
+
 bool bf_applicable(const amg_ctx* c, int k) {
   if (!bx_applicable(c, k)) return false;
   // Measured (DESIGN.md "One table pass or two"): the fused pass costs as many wave-cycles as the two
@@ -432,8 +291,7 @@ bool bf_applicable(const amg_ctx* c, int k) {
   // (misses 30 M -> 62 M per pass) and the per-window node ids need a remap in the counting sweep.
   // cfg 3 sweep: 15.5 ms fused against 14.2 ms with two passes.  It is therefore OFF unless
   // AMG_FUSED=1 asks for it (tests run both).
-  const char* e = getenv("AMG_FUSED");
-  if (!(e && e[0] == '1')) return false;
+  if (f_mode() == 0) return false;
   if (getenv("AMG_X_RANK_SORT")) return false;  // test switch of the two-pass path's sort ranking
   return c->n_tokens < (1ll << 29);  // claims carry two flag bits in the LDS exchange
 }
@@ -508,26 +366,40 @@ int bf_tables(amg_ctx* c, int k, int* which) {
     AMGCHK(c->s0.ensure((size_t)(n_tiles + 1) * 8 * sizeof(unsigned long long)));
     stamps = c->s0.as<unsigned long long>();
   }
-  stage_begin(c, "graph_upsert");
+  stage_begin(c, f_mode() == 1 ? "graph_upsert" : "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into the second slot word?
     const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
-    auto kern = two ? k_graph_x<0, true, false> : k_graph_x<0, false, false>;
-    if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
-      if (b16 && k == 3) kern = k_graph_x<3, false, true>;
-      else if (b16 && k == 5) kern = k_graph_x<5, true, true>;
-      else if (k == 3) kern = two ? k_graph_x<3, true, false> : k_graph_x<3, false, false>;
-      else if (k == 5) kern = two ? k_graph_x<5, true, false> : k_graph_x<5, false, false>;
-      else if (k == 7) kern = two ? k_graph_x<7, true, false> : k_graph_x<7, false, false>;
+    const bool generic = getenv("AMG_X_GENERIC_K") != nullptr;  // A/B switch
+    const char* sp = getenv("AMG_F_STAMPS");  // "1": the fused launch or the node half, "2": the edge half
+    auto launch = [&](auto phase) {
+      constexpr int PH = decltype(phase)::value;
+      auto kern = two ? k_graph_x<0, true, false, PH> : k_graph_x<0, false, false, PH>;
+      if (!generic) {
+        if (b16 && k == 3) kern = k_graph_x<3, false, true, PH>;
+        else if (b16 && k == 5) kern = k_graph_x<5, true, true, PH>;
+        else if (k == 3) kern = two ? k_graph_x<3, true, false, PH> : k_graph_x<3, false, false, PH>;
+        else if (k == 5) kern = two ? k_graph_x<5, true, false, PH> : k_graph_x<5, false, false, PH>;
+        else if (k == 7) kern = two ? k_graph_x<7, true, false, PH> : k_graph_x<7, false, false, PH>;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits, c->node_tab.as<Slot16>(),
+                         (unsigned int)(c->node_slots - 1), c->edge_tab.as<Slot16>(),
+                         (unsigned int)(c->edge_slots - 1), kProbeLimitF, c->tok_slot.as<int>(),
+                         c->tok_dir.as<signed char>(), c->tok_pair.as<int>(), c->status.as<unsigned long long>(),
+                         c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
+                         c->x_eslot.as<unsigned int>(), xw2_for(max_claims, T), xw2_for(max_eclaims, T),
+                         c->f_ctrs.as<unsigned long long>(), ncap, ecap,
+                         (stamps && sp && (PH == 2) == (sp[0] == '2')) ? stamps : (unsigned long long*)nullptr);
+    };
+    if (f_mode() == 1) {
+      launch(std::integral_constant<int, 0>{});
+    } else {
+      launch(std::integral_constant<int, 1>{});
+      stage_end(c);
+      stage_begin(c, "edge_upsert");
+      launch(std::integral_constant<int, 2>{});
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                       c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits, c->node_tab.as<Slot16>(),
-                       (unsigned int)(c->node_slots - 1), c->edge_tab.as<Slot16>(),
-                       (unsigned int)(c->edge_slots - 1), kProbeLimitF, c->tok_slot.as<int>(),
-                       c->tok_dir.as<signed char>(), c->tok_pair.as<int>(), c->status.as<unsigned long long>(),
-                       c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
-                       c->x_eslot.as<unsigned int>(), xw2_for(max_claims, T), xw2_for(max_eclaims, T),
-                       c->f_ctrs.as<unsigned long long>(), ncap, ecap, stamps);
     hipLaunchKernelGGL(k_f_ctr_reduce, dim3(2), dim3(64), 0, st, c->f_ctrs.as<unsigned long long>(),
                        c->status.as<unsigned long long>());
   }

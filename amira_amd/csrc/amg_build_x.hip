@@ -116,8 +116,133 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     if (t >= n_tokens) continue;
     int out = -1;
     if (slot[it] >= 0) out = (int)((id1[it] - 1u) | ((last & (1u << it)) ? AMG_LAST_FLAG : 0u));
-    tok_claim[t] = out;
-    tok_dir[t] = slot[it] >= 0 ? (signed char)dirs[it] : (signed char)0;
+    __builtin_nontemporal_store(out, tok_claim + t);
+    __builtin_nontemporal_store(slot[it] >= 0 ? (signed char)dirs[it] : (signed char)0, tok_dir + t);
+  }
+}
+
+// ------------------------------------------------------------------ nodes, four consecutive windows per thread
+// Same result as k_nodes_x with less around the probe: a thread's 4 + k - 1 tokens leave LDS in 128-bit reads, the
+// common 16-bit packing shares half-words between the windows, the results leave as one 16-byte and one 4-byte
+// store per thread, creators are counted with ballots, and the hit path (the key with its id in the first slot
+// probed: nearly every window of a rebuild) is straight-line code.  Streams are non-temporal so that the L2s keep
+// the table's hot lines (tools/ubench/pass_bench.hip: a pass of this shape is bound by the line requests of its
+// probes, 0.2 ms per 56 M, plus its streams; whatever else it does has to hide behind those).
+template <bool TWO, int K, bool B16>
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
+    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
+    int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
+    signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf) {
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
+  const int tid = threadIdx.x;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  const int flip = two_v - 1;
+  {
+    bool bad = false;
+    if (t0 + TILE <= n_tokens && (reinterpret_cast<uintptr_t>(tokens) & 15) == 0) {  // (a borrowed array may sit anywhere)
+      const i4 x = __builtin_nontemporal_load(reinterpret_cast<const i4*>(tokens + t0) + tid);
+      bad = (unsigned int)x.x >= (unsigned int)two_v || (unsigned int)x.y >= (unsigned int)two_v ||
+            (unsigned int)x.z >= (unsigned int)two_v || (unsigned int)x.w >= (unsigned int)two_v;
+      reinterpret_cast<i4*>(s_tok)[tid] = x;
+    } else {
+      for (int i = tid; i < TILE; i += TILE_THREADS) {
+        const long long t = t0 + i;
+        const int x = t < n_tokens ? tokens[t] : 0;
+        bad = bad || (unsigned int)x >= (unsigned int)two_v;
+        s_tok[i] = x;
+      }
+    }
+    if (tid < k + 3) {  // the k - 1 tokens the last windows reach into (+ padding read by the 128-bit loads)
+      const long long t = t0 + TILE + tid;
+      const int x = t < n_tokens ? tokens[t] : 0;
+      bad = bad || (unsigned int)x >= (unsigned int)two_v;
+      s_tok[TILE + tid] = x;
+    }
+    if (bad) status[ST_BADINPUT] = 2;  // a token outside [0, two_v) would alias another tuple
+    if (tid < TILE_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
+  }
+  __syncthreads();
+  const int i0 = 4 * tid;
+  unsigned int id1[TILE_ITEMS];
+  unsigned int last = 0, ndir = 0, valid = 0;  // per window: last of its read; direction -1; has a node
+  {
+    unsigned long long w1[TILE_ITEMS];
+    unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS];
+    ulonglong2 v[TILE_ITEMS];
+    // windows whose k tokens lie in one read: no read ends at the positions t + 1 .. t + k - 1 (a read that ends
+    // right after the window makes it the last of its read)
+    const unsigned int b = tile_bits(s_bits, i0 + 1, k + 3);
+    constexpr int NA = K > 0 ? 4 + K - 1 : 1;
+    int a[NA];
+    if constexpr (K > 0) {
+#pragma unroll
+      for (int j = 0; j < (NA + 3) / 4; ++j) {
+        const int4 x = reinterpret_cast<const int4*>(s_tok + i0)[j];
+        if (4 * j + 0 < NA) a[4 * j + 0] = x.x;
+        if (4 * j + 1 < NA) a[4 * j + 1] = x.y;
+        if (4 * j + 2 < NA) a[4 * j + 2] = x.z;
+        if (4 * j + 3 < NA) a[4 * j + 3] = x.w;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      w1[w] = 0;
+      tag[w] = 0;
+      idx[w] = 0;
+      const long long t = t0 + i0 + w;
+      const bool inside = ((b >> w) & ((1u << (k - 1)) - 1u)) == 0u;
+      if (!((t + k <= n_tokens) && inside)) continue;
+      int dir;
+      if constexpr (K > 0 && B16) {
+        dir = f_canon_pack16<K, TWO>(a + w, flip, w1[w], tag[w]);
+      } else if constexpr (K > 0) {
+        dir = x_canon_pack<K, TWO>(a + w, flip, bits, w1[w], tag[w]);
+      } else {
+        LdsView win{s_tok + i0 + w};
+        dir = canon_dir(win, k, flip);
+        if (dir != 0) x_pack(win, k, flip, dir, bits, w1[w], tag[w]);
+      }
+      if (dir == 0) {
+        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+        continue;
+      }
+      idx[w] = (unsigned int)mix64(w1[w] ^ ((unsigned long long)tag[w] * 0x9E3779B97F4A7C15ull)) & mask;
+#ifndef AMG_ABLATE_NOPROBE
+      v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
+#endif
+      if (dir < 0) ndir |= 1u << w;
+      valid |= 1u << w;
+      if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
+    }
+    f_table_phase<TWO, 1, false>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2,
+                                 slot_by_claim, status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave);
+  }
+  i4 oc;
+  unsigned int od = 0;
+  {
+    int o[TILE_ITEMS];
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      o[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u)) : -1;
+      od |= (id1[w] ? ((ndir & (1u << w)) ? 0xffu : 1u) : 0u) << (8 * w);
+    }
+    oc = i4{o[0], o[1], o[2], o[3]};
+  }
+  const long long t = t0 + i0;
+  if (t + TILE_ITEMS <= n_tokens) {
+    __builtin_nontemporal_store(oc, reinterpret_cast<i4*>(tok_claim + t));
+    __builtin_nontemporal_store(od, reinterpret_cast<unsigned int*>(tok_dir + t));
+  } else {
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w)
+      if (t + w < n_tokens) {
+        tok_claim[t + w] = oc[w];
+        tok_dir[t + w] = (signed char)(od >> (8 * w));
+      }
   }
 }
 
@@ -256,8 +381,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     int raw = -1;
     signed char d = 0;
     if (t < n_tokens) {
-      raw = tok_claim[t];
-      d = tok_dir[t];
+      raw = __builtin_nontemporal_load(tok_claim + t);
+      d = __builtin_nontemporal_load(tok_dir + t);
     }
     int id = -1;
     if (raw != -1) id = (ablate & 64) ? (int)((unsigned int)raw & ~AMG_LAST_FLAG)  // timing experiment
@@ -265,7 +390,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
     s_id[i] = id;
     s_dir[i] = d;
     s_last[i] = (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) ? 1 : 0;
-    if (i < TILE && t < n_tokens) tok_node[t] = id;
+    if (i < TILE && t < n_tokens) __builtin_nontemporal_store(id, tok_node + t);
   }
   __syncthreads();
   unsigned long long key[TILE_ITEMS];
@@ -313,7 +438,109 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
-    if (t < n_tokens) tok_pair[t] = slot[it] >= 0 ? (int)(id1[it] - 1u) : -1;
+    if (t < n_tokens) __builtin_nontemporal_store(slot[it] >= 0 ? (int)(id1[it] - 1u) : -1, tok_pair + t);
+  }
+}
+
+// ------------------------------------------------------------------ edges, four consecutive adjacencies per thread
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
+    long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
+    const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
+    unsigned int probe_limit, unsigned long long* status, int* __restrict__ tok_pair, unsigned int* first2,
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf) {
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  // word per window: node id | (direction -1) << 30 | last-of-read << 31, -1: no node
+  constexpr unsigned int DIRBIT = 0x40000000u;
+  __shared__ __attribute__((aligned(16))) int s_w[TILE + 4];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
+  const int tid = threadIdx.x;
+  const long long t0 = (long long)blockIdx.x * TILE;
+  const int i0 = 4 * tid;
+  const long long t = t0 + i0;
+  // node id of a window: -1 no node, -2 a node the merge's fused filter dropped (amg_dist.hip)
+  auto node_of = [&](int raw) { return raw == -1 ? -1 : final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG]; };
+  auto word = [&](int raw, int id, unsigned int d) {  // d: the direction byte
+    if (id < 0) return -1;
+    return (int)((unsigned int)id | ((unsigned int)raw & AMG_LAST_FLAG) | ((d & 0x80u) ? DIRBIT : 0u));
+  };
+  int cw[TILE_ITEMS + 1];
+  {
+    i4 x = {-1, -1, -1, -1};
+    unsigned int d = 0;
+    if (t + TILE_ITEMS <= n_tokens) {
+      x = __builtin_nontemporal_load(reinterpret_cast<const i4*>(tok_claim + t));
+      d = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(tok_dir + t));
+    } else {
+#pragma unroll
+      for (int w = 0; w < TILE_ITEMS; ++w)
+        if (t + w < n_tokens) {
+          x[w] = tok_claim[t + w];
+          d |= (unsigned int)(unsigned char)tok_dir[t + w] << (8 * w);
+        }
+    }
+    // node id per window (construct_read.py get_geneMers order), as every later stage wants it
+    i4 ids;
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      ids[w] = node_of(x[w]);
+      cw[w] = word(x[w], ids[w], d >> (8 * w));
+    }
+    if (t + TILE_ITEMS <= n_tokens) {
+      __builtin_nontemporal_store(ids, reinterpret_cast<i4*>(tok_node + t));
+    } else {
+#pragma unroll
+      for (int w = 0; w < TILE_ITEMS; ++w)
+        if (t + w < n_tokens) tok_node[t + w] = ids[w];
+    }
+  }
+  reinterpret_cast<int4*>(s_w)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
+  if (tid == 0) {  // the next tile's first window: right-hand neighbour of this tile's last
+    const long long tn = t0 + TILE;
+    int wn = -1;
+    if (tn < n_tokens) {
+      const int raw = tok_claim[tn];
+      wn = word(raw, node_of(raw), (unsigned int)(unsigned char)tok_dir[tn]);
+    }
+    s_w[TILE] = wn;
+  }
+  __syncthreads();
+  cw[TILE_ITEMS] = s_w[i0 + TILE_ITEMS];
+
+  // adjacency (A, dA) -> (B, dB) of windows t and t + 1 of one read (create_edges :246-262); class key =
+  // (smaller id, larger id, dA * dB), first-seen = (token << 3) | orientation
+  unsigned long long key[TILE_ITEMS];
+  unsigned int idx[TILE_ITEMS], etag[TILE_ITEMS], id1[TILE_ITEMS];
+  ulonglong2 v[TILE_ITEMS];
+  unsigned int valid = 0, orient3 = 0;
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w) {
+    key[w] = 0;
+    idx[w] = 0;
+    etag[w] = 0;
+    const int A = cw[w], B = cw[w + 1];
+    if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
+    const unsigned int a = (unsigned int)A & (DIRBIT - 1u), b = (unsigned int)B & (DIRBIT - 1u);
+    const bool negA = ((unsigned int)A & DIRBIT) != 0u, negB = ((unsigned int)B & DIRBIT) != 0u;
+    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+    const unsigned long long sign = negA != negB ? 1ull : 0ull;
+    key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+    const unsigned int orient = (a == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
+    orient3 |= orient << (3 * w);
+    idx[w] = (unsigned int)mix64(key[w]) & emask;
+#ifndef AMG_ABLATE_NOPROBE
+    v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
+#endif
+    valid |= 1u << w;
+  }
+  f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
+                                 slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave);
+  const i4 op = {(int)id1[0] - 1, (int)id1[1] - 1, (int)id1[2] - 1, (int)id1[3] - 1};
+  if (t + TILE_ITEMS <= n_tokens) {
+    __builtin_nontemporal_store(op, reinterpret_cast<i4*>(tok_pair + t));
+  } else {
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w)
+      if (t + w < n_tokens) tok_pair[t + w] = op[w];
   }
 }
 
@@ -406,9 +633,9 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   const long long n_tiles = (T + TILE - 1) / TILE;
 
   const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
-  AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
-  AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
-  AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
+  AMGCHK(c->tok_slot.ensure((size_t)(T + 8) * sizeof(int)));
+  AMGCHK(c->tok_node.ensure((size_t)(T + 8) * sizeof(int)));
+  AMGCHK(c->tok_dir.ensure((size_t)(T + 8)));
   AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
   AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));  // {raised by others, creator's} per claim
   AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
@@ -424,18 +651,36 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
-    auto kern = two ? k_nodes_x<true, 0> : k_nodes_x<false, 0>;
-    if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
-      if (k == 3) kern = two ? k_nodes_x<true, 3> : k_nodes_x<false, 3>;
-      if (k == 5) kern = two ? k_nodes_x<true, 5> : k_nodes_x<false, 5>;
-      if (k == 7) kern = two ? k_nodes_x<true, 7> : k_nodes_x<false, 7>;
+    if (getenv("AMG_X_OLD_PASS")) {  // A/B switch: one window per lane, strided (the round-1 kernel)
+      auto kern = two ? k_nodes_x<true, 0> : k_nodes_x<false, 0>;
+      if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
+        if (k == 3) kern = two ? k_nodes_x<true, 3> : k_nodes_x<false, 3>;
+        if (k == 5) kern = two ? k_nodes_x<true, 5> : k_nodes_x<false, 5>;
+        if (k == 7) kern = two ? k_nodes_x<true, 7> : k_nodes_x<false, 7>;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
+                         c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
+                         c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                         c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                         c->x_slot.as<unsigned int>(), ablate, xw2_for(max_claims, T));
+    } else {
+      const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
+      auto kern = two ? k_nodes_v<true, 0, false> : k_nodes_v<false, 0, false>;
+      if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
+        if (b16 && k == 3) kern = k_nodes_v<false, 3, true>;
+        else if (b16 && k == 5) kern = k_nodes_v<true, 5, true>;
+        else if (k == 3) kern = two ? k_nodes_v<true, 3, false> : k_nodes_v<false, 3, false>;
+        else if (k == 5) kern = two ? k_nodes_v<true, 5, false> : k_nodes_v<false, 5, false>;
+        else if (k == 7) kern = two ? k_nodes_v<true, 7, false> : k_nodes_v<false, 7, false>;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
+                         c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
+                         c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                         c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                         c->x_slot.as<unsigned int>(), (unsigned int)max_claims, xw2_for(max_claims, T));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                       c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
-                       c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
-                       c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                       c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                       c->x_slot.as<unsigned int>(), ablate, xw2_for(max_claims, T));
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
@@ -510,7 +755,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   unsigned long long hs[ST_WORDS];
   if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
   const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
-  AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
+  AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
@@ -522,12 +767,19 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   const char* abl = getenv("AMG_X_ABLATE");
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
   stage_begin(c, "edge_upsert");
-  if (n_tiles > 0)
+  if (n_tiles > 0 && getenv("AMG_X_OLD_PASS"))  // A/B switch: one adjacency per lane, strided (the round-1 kernel)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                        c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
                        c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate,
+                       xw2_for(max_claims, T));
+  else if (n_tiles > 0)
+    hipLaunchKernelGGL(k_edges_v, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+                       c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
+                       c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
+                       c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
+                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), (unsigned int)max_claims,
                        xw2_for(max_claims, T));
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));

@@ -195,8 +195,9 @@ struct amg_ctx {
   DevBuf ladj_off;  // int64[2 n_nodes + 1]
   DevBuf ladj;      // int2[n_live_edges]  {target node, target direction}
   DevBuf ladj_rows; // int4[2 n_nodes]  {offset, live count, first target, first direction}
-  DevBuf ladj_cnt;  // uint32[2 n_nodes + 1] scratch of its own (callers hold s0..s5)
+  DevBuf ladj_cnt, ladj_pos, ladj_keys;  // scratch of the live-adjacency build (callers hold s0..s5)
   bool ladj_valid = false;
+  bool comp_valid = false, adj_valid = false;  // component ids / full edge lists of the built graph are made on demand
   // reads
   DevBuf read_fix;  // uint8[n_reads]  read is in _readsToCorrect
 
@@ -285,6 +286,8 @@ int bs_edges_pass(amg_ctx* c, int* which);
 int bs_alloc_pairs(amg_ctx* c, long long P);
 int bs_pairs_from_local(amg_ctx* c);
 int bs_finish_from_pairs(amg_ctx* c);
+int ensure_components(amg_ctx* c);
+int ensure_adjacency(amg_ctx* c);
 bool bx_applicable(const amg_ctx* c, int k);
 bool bx_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);

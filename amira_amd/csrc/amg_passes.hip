@@ -133,7 +133,6 @@ extern "C" int amg_remove_nodes(amg_ctx* c, const int32_t* node_ids, int64_t n) 
 struct GView {
   // live adjacency: row 2n = forward list of node n, row 2n+1 = backward list, only ALIVE
   // edges, in list order, with the target inline (.x = target node, .y = target direction)
-  const long long* lrow;
   const int2* lent;
   const int4* lrows;  // per row {offset, live count, first target, first direction}: one 16-B load
                       // tells a walker everything about a row with <= 1 live edge (most rows)
@@ -145,61 +144,80 @@ struct GView {
   int k, flip;
 };
 
-__global__ void k_live_count(const long long* __restrict__ adj_off, const int* __restrict__ adj_edge,
-                             const unsigned char* __restrict__ e_alive, long long n_rows,
-                             unsigned int* __restrict__ cnt) {
-  long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_rows) return;
-  unsigned int n = 0;
-  for (long long p = adj_off[row]; p < adj_off[row + 1]; ++p) n += e_alive[adj_edge[p]] ? 1u : 0u;
-  cnt[row] = n;
+// Live adjacency straight from the live edges: flag + scan squeezes the removed edges out in edge
+// order, a stable sort by row (2 * source + side) groups them, so a row lists its live edges in
+// the order of the reference's forward / backward lists (edge ids ascend in insertion order).
+__global__ void k_live_flags(const unsigned char* __restrict__ e_alive, long long n_edges,
+                             unsigned int* __restrict__ flags) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e <= n_edges) flags[e] = (e < n_edges && e_alive[e]) ? 1u : 0u;
 }
 
-__global__ void k_live_fill(const long long* __restrict__ adj_off, const int* __restrict__ adj_edge,
-                            const unsigned char* __restrict__ e_alive, const int* __restrict__ e_tgt,
-                            const signed char* __restrict__ e_tdir, long long n_rows,
-                            const long long* __restrict__ lrow, int2* __restrict__ lent,
+__global__ void k_live_keys(const unsigned char* __restrict__ e_alive, const int* __restrict__ e_src,
+                            const signed char* __restrict__ e_sdir, const long long* __restrict__ pos,
+                            long long n_edges, unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges || !e_alive[e]) return;
+  const long long o = pos[e];
+  keys[o] = 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
+  vals[o] = (unsigned int)e;
+}
+
+__global__ void k_live_ent(const unsigned int* __restrict__ edge_of, const int* __restrict__ e_tgt,
+                           const signed char* __restrict__ e_tdir, long long n_live, int2* __restrict__ lent) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_live) return;
+  const unsigned int e = edge_of[i];
+  lent[i] = make_int2(e_tgt[e], (int)e_tdir[e]);
+}
+
+// one row record per run of equal keys (rows without a live edge keep the zero record of the memset:
+// every reader tests the count first); runs are short — the live edges of one side of one node
+__global__ void k_live_rows(const unsigned int* __restrict__ keys, const int2* __restrict__ lent, long long n_live,
                             int4* __restrict__ lrows) {
-  long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_rows) return;
-  const long long o0 = lrow[row];
-  long long o = o0;
-  int2 first = make_int2(-1, 0);
-  for (long long p = adj_off[row]; p < adj_off[row + 1]; ++p) {
-    int e = adj_edge[p];
-    if (e_alive[e]) {
-      int2 ent = make_int2(e_tgt[e], (int)e_tdir[e]);
-      if (o == o0) first = ent;
-      lent[o++] = ent;
-    }
-  }
-  lrows[row] = make_int4((int)o0, (int)(o - o0), first.x, first.y);
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_live) return;
+  const unsigned int key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;
+  long long j = i + 1;
+  while (j < n_live && keys[j] == key) ++j;
+  const int2 first = lent[i];
+  lrows[key] = make_int4((int)i, (int)(j - i), first.x, first.y);
 }
 
 // forward/backward edge lists with the removed edges squeezed out: the walkers below then
-// never touch a dead edge (a hub node of an uncorrected graph lists hundreds of them)
+// never touch a dead edge (a hub node of an uncorrected graph lists hundreds of them), and the
+// lists of the removed edges are never made at all
 static int ensure_live_adj(amg_ctx* c) {
   if (c->ladj_valid) return AMG_OK;
   hipStream_t st = c->stream;
-  const long long rows = 2 * c->n_nodes;
-  AMGCHK(c->ladj_off.ensure((size_t)(rows + 2) * sizeof(long long)));
-  AMGCHK(c->ladj_cnt.ensure((size_t)(rows + 2) * sizeof(unsigned int)));
-  HIPCHK(hipMemsetAsync(c->ladj_cnt.p, 0, (size_t)(rows + 2) * sizeof(unsigned int), st));
-  if (rows > 0)
-    hipLaunchKernelGGL(k_live_count, dim3(nblk(rows, 256)), dim3(256), 0, st, c->adj_off.as<long long>(),
-                       c->adj_edge.as<int>(), c->edge_alive.as<unsigned char>(), rows,
-                       c->ladj_cnt.as<unsigned int>());
-  AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_off.as<long long>(), (size_t)rows + 1));
+  const long long rows = 2 * c->n_nodes, E = c->n_edges;
+  AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
+  HIPCHK(hipMemsetAsync(c->ladj_rows.p, 0, (size_t)(rows + 2) * sizeof(int4), st));
+  AMGCHK(c->ladj_cnt.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  AMGCHK(c->ladj_pos.ensure((size_t)(E + 2) * sizeof(long long)));
+  hipLaunchKernelGGL(k_live_flags, dim3(nblk(E + 1, 256)), dim3(256), 0, st, c->edge_alive.as<unsigned char>(), E,
+                     c->ladj_cnt.as<unsigned int>());
+  AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_pos.as<long long>(), (size_t)E + 1));
   long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, c->ladj_off.as<long long>() + rows, sizeof(long long),
-                        hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&total, c->ladj_pos.as<long long>() + E, sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   AMGCHK(c->ladj.ensure((size_t)(total + 1) * sizeof(int2)));
-  AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
-  if (rows > 0)
-    hipLaunchKernelGGL(k_live_fill, dim3(nblk(rows, 256)), dim3(256), 0, st, c->adj_off.as<long long>(),
-                       c->adj_edge.as<int>(), c->edge_alive.as<unsigned char>(), c->edge_tgt.as<int>(),
-                       c->edge_tdir.as<signed char>(), rows, c->ladj_off.as<long long>(), c->ladj.as<int2>(),
+  AMGCHK(c->ladj_keys.ensure(4 * (size_t)(total + 2) * sizeof(unsigned int)));
+  unsigned int* k_in = c->ladj_keys.as<unsigned int>();
+  unsigned int* v_in = k_in + (total + 2);
+  unsigned int* k_out = v_in + (total + 2);
+  unsigned int* v_out = k_out + (total + 2);
+  if (total > 0) {
+    hipLaunchKernelGGL(k_live_keys, dim3(nblk(E, 256)), dim3(256), 0, st, c->edge_alive.as<unsigned char>(),
+                       c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), c->ladj_pos.as<long long>(), E, k_in,
+                       v_in);
+    AMGCHK(prim_sort_u32_u32(c, k_in, k_out, v_in, v_out, (size_t)total, ilog2_ceil((uint64_t)rows + 2) + 1));
+    hipLaunchKernelGGL(k_live_ent, dim3(nblk(total, 256)), dim3(256), 0, st, v_out, c->edge_tgt.as<int>(),
+                       c->edge_tdir.as<signed char>(), total, c->ladj.as<int2>());
+  }
+  if (total > 0)
+    hipLaunchKernelGGL(k_live_rows, dim3(nblk(total, 256)), dim3(256), 0, st, k_out, c->ladj.as<int2>(), total,
                        c->ladj_rows.as<int4>());
   c->ladj_valid = true;
   return AMG_OK;
@@ -207,7 +225,6 @@ static int ensure_live_adj(amg_ctx* c) {
 
 static GView make_view(amg_ctx* c) {
   GView g;
-  g.lrow = c->ladj_off.as<long long>();
   g.lent = c->ladj.as<int2>();
   g.lrows = c->ladj_rows.as<int4>();
   g.n_alive = c->node_alive.as<unsigned char>();
@@ -397,6 +414,7 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   if (n_removed) *n_removed = 0;
   if (D == 0) return AMG_OK;
   stages_reset(c);
+  AMGCHK(ensure_components(c));
   stage_begin(c, "clip");
   // mean node coverage (:868-871): statistics.mean over live nodes, * 1.5 in double
   unsigned long long* acc = c->status.as<unsigned long long>() + ST_COMPACT_A;
@@ -444,6 +462,7 @@ extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t min_cov) 
   hipStream_t st = c->stream;
   const long long D = c->n_nodes;
   if (D == 0) return AMG_OK;
+  AMGCHK(ensure_components(c));
   size_t nc = (size_t)(c->n_components + 2);
   AMGCHK(c->s0.ensure((size_t)D + 8));
   AMGCHK(c->s4.ensure(2 * nc * sizeof(unsigned int)));
@@ -662,8 +681,9 @@ __device__ void dfs_paths(const GView& g, int s, int sdir, int e, int distance, 
         continue;
       }
       long long row = 2ll * node[depth] + (dir[depth] == 1 ? 0 : 1);
-      cur[depth] = g.lrow[row];
-      lim[depth] = g.lrow[row + 1];
+      const int4 rw = g.lrows[row];
+      cur[depth] = rw.x;
+      lim[depth] = rw.x + rw.y;
       entering = false;
     }
     bool pushed = false;

@@ -261,6 +261,207 @@ __device__ __forceinline__ void x_claim(Slot16* tab, const int (&slot)[TILE_ITEM
 }
 
 
+// Canonical orientation + packed key of the window a[0..K-1] for 16-bit tokens (two_v <= 65536),
+// K odd.  Forward half-words a[j] | a[j+1] << 16, reverse-complement half-words
+// (F | F << 16) - (a[j+1] | a[j] << 16).  Encoding == x_pack with bits = 16.
+template <int K, bool TWO>
+__device__ __forceinline__ int f_canon_pack16(const int* a, int flip, unsigned long long& w1, unsigned int& tag) {
+  int dir = (2 * a[K / 2] < flip) ? 1 : -1;  // 2 x != 2V - 1: an odd k has no palindromes
+#pragma unroll
+  for (int j = K / 2 - 1; j >= 0; --j) {
+    const int s = a[j] + a[K - 1 - j];
+    dir = s != flip ? (s < flip ? 1 : -1) : dir;
+  }
+  const unsigned int ff = (unsigned int)flip | ((unsigned int)flip << 16);
+  unsigned int word[K / 2 + 1];
+#pragma unroll
+  for (int m = 0; m < K / 2; ++m) {
+    const unsigned int fw = (unsigned int)a[2 * m] | ((unsigned int)a[2 * m + 1] << 16);
+    const unsigned int rc = ff - ((unsigned int)a[K - 1 - 2 * m] | ((unsigned int)a[K - 2 - 2 * m] << 16));
+    word[m] = dir > 0 ? fw : rc;
+  }
+  word[K / 2] = (unsigned int)(dir > 0 ? a[K - 1] : flip - a[0]);
+  const unsigned long long v = (unsigned long long)word[0] | ((unsigned long long)word[1] << 32);
+  w1 = (v << 1) | 1ull;
+  if constexpr (K == 3)
+    tag = 1u;
+  else  // K == 5
+    tag = (((word[1] >> 31) | (word[K / 2] << 1)) << 1) | 1u;
+  return dir;
+}
+
+// ---- one table phase for the four items of a thread: probe, insert, claim ids, first-seen.
+//
+// Claim ids come from F_SHARDS counters, one per shard (a wave belongs to one shard): a single
+// counter word takes ~90 returning atomics per microsecond, which is what a tile per 1024 tokens
+// asks of it at the speed of this pass; 64 words do not notice.  Claims are INTERLEAVED, claim =
+// local index * F_SHARDS + shard, so that the early (hot) claims of every shard are small numbers
+// and the claim space [0, F_SHARDS * largest local count) has few holes (entries of the per-claim
+// arrays that nobody claimed keep first-seen == 0 and are skipped wherever claims are listed).
+// The creators of a wave are counted with ballots and served by one atomicAdd of the wave:
+// no LDS, no workgroup barrier.
+#define F_SHARDS 64
+#define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
+
+template <class T>
+__device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
+  return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3];
+}
+
+template <bool TWO, int FSH, bool SHARDED>
+__device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
+                                              const unsigned long long (&w1)[TILE_ITEMS],
+                                              const unsigned int (&tag)[TILE_ITEMS],
+                                              const unsigned int (&idx)[TILE_ITEMS],
+                                              const ulonglong2 (&v)[TILE_ITEMS], unsigned int tbase,
+                                              unsigned int lowbits, const XW2 f, unsigned int* first2,
+                                              unsigned int* __restrict__ slot_by_claim,
+                                              unsigned long long* ctr, unsigned int shard, unsigned int cap,
+                                              unsigned int probe_limit, unsigned long long* status, int which,
+                                              unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr) {
+  auto tpos = [&](int it) { return tbase + (unsigned int)it; };
+  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
+  unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
+  int slot[TILE_ITEMS];
+  // ---- the key with its id, as the first probe load returned it: done (almost every window of a
+  // rebuild).  Anything else goes through x_upsert below, one item at a time, in ONE copy of that code.
+  unsigned int need = 0, created = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    id1[it] = 0;
+    lw[it] = 0;
+    slot[it] = (int)idx[it];
+    if (!TWO) hw[TWO ? 0 : it] = 0;
+    if (!(valid & (1u << it))) continue;
+#ifdef AMG_ABLATE_NOPROBE  // timing experiment (tools/noprobe_probe.sh): every window "finds" its key; no graph
+    const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx[it] & 1023ull));
+#else
+    const unsigned long long c1 = v[it].x, c2 = v[it].y;
+#endif
+    const bool mine = c1 == w1[it] && (!TWO || (unsigned int)(c2 >> 32) == tag[it]);
+    if (mine && (unsigned int)c2 != 0u) {
+      lw[it] = (unsigned int)c2;
+      if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(c2 >> 32);
+    } else {
+      need |= 1u << it;
+    }
+  }
+  while (need) {
+    const int it = __ffs((int)need) - 1;
+    need &= need - 1u;
+    bool made;
+    unsigned long long w2v;
+    // (the slot is loaded again rather than picked out of v[]: a register array indexed at run time
+    // lives in scratch memory)
+    const unsigned int ix = f_pick(idx, it);
+    const int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
+                                 *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit,
+                                 status + ST_OVERFLOW, w2v, made);
+    if (sl < 0) {
+      status[ST_OVERFLOW] = (unsigned long long)which;
+      valid &= ~(1u << it);
+    }
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j)
+      if (j == it) {
+        slot[j] = sl;
+        lw[j] = (unsigned int)w2v;
+        if (!TWO) hw[TWO ? 0 : j] = (unsigned int)(w2v >> 32);
+      }
+    if (made) created |= 1u << it;
+  }
+  // ---- claim ids of the wave's creators
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned int n = 0, pre[TILE_ITEMS];
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    const unsigned long long m = __ballot((created >> it) & 1u);
+    pre[it] = n + (unsigned int)__popcll(m & below);
+    n += (unsigned int)__popcll(m);
+  }
+  unsigned int base = 0;
+  if constexpr (SHARDED) {
+    if (n) {  // wave-uniform
+      unsigned int b = 0;
+      if (lane == 0) b = (unsigned int)atomicAdd(ctr, (unsigned long long)n);
+      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+    }
+  } else {
+    // one atomicAdd per workgroup on the single counter (claims are then dense: 0 .. number of keys - 1);
+    // s_wave: TILE_THREADS / 64 wave totals + the workgroup's base
+    const unsigned int wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = n;
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+#pragma unroll
+    for (unsigned int w = 0; w < TILE_THREADS / 64; ++w) {
+      const unsigned int cnt = s_wave[w];
+      before += w < wave ? cnt : 0u;
+      total += cnt;
+    }
+    if (total) {  // workgroup-uniform
+      if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total);
+      __syncthreads();
+      base = s_wave[TILE_THREADS / 64] + before;
+    }
+  }
+  if (created) {
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it)
+      if (created & (1u << it)) {
+        unsigned int li = base + pre[it];
+        if (li >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
+          status[ST_OVERFLOW] = (unsigned long long)which;
+          li = 0;
+        }
+        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : li;
+        // the creator's first-seen goes to its own word with a plain store; everybody else raises the
+        // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
+        // has to be ordered against the publication of the id
+        first2[2u * claim + 1u] = fi(it);
+        slot_by_claim[claim] = (unsigned int)slot[it];
+        id1[it] = claim + 1u;
+        const unsigned long long pub =
+            TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
+                      (unsigned long long)(claim + 1u)
+                : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
+        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  // ---- found keys: wait for an id that is still on its way (a creator publishes without waiting
+  // for anybody, after at most its own wave's atomicAdd), then keep the minimum first-seen
+  unsigned int check = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(valid & (1u << it)) || (created & (1u << it))) continue;
+    unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
+    for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
+      w = ld_u64(&tab[slot[it]].w2);
+      if ((unsigned int)w != 0u) break;
+      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
+        status[ST_MISC] = 1ull;
+        w = 1ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    id1[it] = xw2_id1<TWO>(w, f);
+    // can this window precede the creator's?  (coarse positions: same or earlier bucket)
+    const bool maybe_first = TWO ? (tpos(it) >> f.cshift) <= (((unsigned int)w) >> f.ib)
+                                 : fi(it) > (unsigned int)(w >> 32);
+    if (maybe_first) check |= 1u << it;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(check & (1u << it))) continue;
+    // plain (possibly stale, at worst zero) reads: both words only grow, so a stale value can only
+    // cause a superfluous atomicMax, never a missed one
+    const unsigned int c = id1[it] - 1u;
+    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
+  }
+}
+
 // field widths of a two-word slot's second word for `max_claims` ids over T tokens
 static inline XW2 xw2_for(size_t max_claims, long long T) {
   XW2 f;

@@ -57,6 +57,10 @@ class Engine:
     def build(self, k):
         check(_ffi.lib.amg_build(self._h, int(k)))
 
+    def finalize(self):
+        """component ids + per-node edge lists of the built graph now (they are otherwise made on first use)"""
+        check(_ffi.lib.amg_finalize(self._h))
+
     def sizes(self):
         """(reads, genes) of the current read set; no device work"""
         nr, nt = C.c_int64(0), C.c_int64(0)

@@ -360,6 +360,11 @@ def main():
             tally()
         if w["sweep"]:
             sweep_after_first_build(record)
+        # component ids + per-node edge lists of the step's final graph (made on demand otherwise): the
+        # step leaves behind everything GeneMerGraph.__init__ would
+        eng.finalize()
+        if record:
+            tally()
 
     for _ in range(args.warmup):
         step(False)

@@ -120,6 +120,11 @@ int amg_set_read_lengths(amg_ctx* ctx, const int64_t* read_len, int on_device);
  *      add_edge (:300-324), assign_component_ids (:920-927) --------------------------- */
 int amg_build(amg_ctx* ctx, int32_t k);
 int amg_counts(amg_ctx* ctx, amg_counts_t* out);
+/* amg_build leaves component ids (assign_component_ids, construct_graph.py:920-927) and the per-node
+ * forward / backward edge lists (construct_node.py:79-101) to the first call that needs them
+ * (amg_counts, amg_get_nodes with `component`, amg_get_node_adj, tip clipping, component filter);
+ * amg_finalize computes both now, so that the ctx holds everything GeneMerGraph.__init__ leaves behind. */
+int amg_finalize(amg_ctx* ctx);
 /* reads / genes of the current read set, without touching the device (amg_counts recounts the
  * live flags): len(readDict), sum(len(genes)) */
 int amg_sizes(amg_ctx* ctx, int64_t* n_reads, int64_t* n_tokens);
