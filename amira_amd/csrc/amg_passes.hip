@@ -539,103 +539,135 @@ __device__ __forceinline__ void pos_base(const CorrArgs& a, long long off, const
   }
 }
 
+__device__ __forceinline__ long long bcast_i64(long long v, int lane) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// One wave classifies 64 consecutive reads.  Lane l owns read l: its offsets, fix flag and results are loaded and
+// stored coalesced, one read per lane.  What needs the read's windows — which are live — is a 64-bit mask per read:
+// the wave loads the windows of one flagged read at a time (lanes = windows, four reads in flight), ballots, and
+// hands the mask to the owning lane; everything else is bit arithmetic on that mask.  (A wave per four reads
+// stored every result with its own one-lane instruction: ~8 vector-memory instructions per read.)
+#define CLS_READS 64
 __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
-  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * READS_PER_WAVE;
+  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CLS_READS;
   if (rbase >= a.n_reads) return;
   const int lane = threadIdx.x & 63;
-  // stage 1: offsets and fix flags of the wave's reads (one load each), stage 2: the first 64
-  // window ids of every read that needs a look, stage 3: ballots instead of reductions
-  const long long off_l = (lane <= READS_PER_WAVE && rbase + lane <= a.n_reads) ? a.read_off[rbase + lane] : 0;
-  const int fix_l = (lane < READS_PER_WAVE && rbase + lane < a.n_reads) ? a.read_fix[rbase + lane] : 0;
-  long long t0[READS_PER_WAVE], n[READS_PER_WAVE];
-  int v[READS_PER_WAVE];
-  bool look[READS_PER_WAVE];
+  const long long r = rbase + lane;
+  const bool have = r < a.n_reads;
+  const long long t0 = have ? a.read_off[r] : 0;
+  const long long n = have ? (a.read_off[r + 1] - t0) - a.k + 1 : 0;  // windows; L = n + k - 1
+  const bool look = have && n > 0 && a.read_fix[r] != 0;
+  // live-window masks of the flagged reads with <= 64 windows
+  unsigned long long lv = 0;
+  unsigned long long todo = __ballot(look && n <= 64);
+  while (todo) {
+    int who[4];
+    long long tj[4];
+    int nj[4], v[4];
 #pragma unroll
-  for (int j = 0; j < READS_PER_WAVE; ++j) {
-    t0[j] = __shfl(off_l, j, 64);
-    const long long t1 = rbase + j < a.n_reads ? __shfl(off_l, j + 1, 64) : t0[j];
-    n[j] = (t1 - t0[j]) - a.k + 1;  // windows; L = n + k - 1
-    look[j] = rbase + j < a.n_reads && n[j] > 0 && __shfl(fix_l, j, 64) != 0;
+    for (int q = 0; q < 4; ++q) {
+      who[q] = todo ? __ffsll((long long)todo) - 1 : -1;
+      if (todo) todo &= todo - 1ull;
+      tj[q] = who[q] >= 0 ? bcast_i64(t0, who[q]) : 0;
+      nj[q] = who[q] >= 0 ? __builtin_amdgcn_readlane((int)n, who[q]) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = lane < nj[q] ? a.tok_node[tj[q] + lane] : -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long m = __ballot(v[q] >= 0);  // lanes >= n hold -1
+      if (lane == who[q]) lv = m;
+    }
   }
-#pragma unroll
-  for (int j = 0; j < READS_PER_WAVE; ++j) v[j] = (look[j] && lane < n[j]) ? a.tok_node[t0[j] + lane] : -1;
-#pragma unroll
-  for (int j = 0; j < READS_PER_WAVE; ++j) {
-    const long long r = rbase + j;
-    if (r >= a.n_reads) break;
-    const long long L = n[j] + a.k - 1;
-    unsigned char cls;
-    int start = 0, end = -1;
-    unsigned int bound = 0;
-    unsigned int len_out = 0;  // genes of the corrected read, known here unless it has None runs
-    if (n[j] <= 0) {
-      cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
-    } else if (!look[j]) {
-      cls = RC_COPY;
-      len_out = (unsigned int)L;
+  long long first = n, last = -1;
+  unsigned int runs = 0, live = 0;
+  if (look && n <= 64) {
+    first = lv ? (long long)__ffsll((long long)lv) - 1 : n;
+    last = lv ? 63 - (long long)__clzll((long long)lv) : -1;
+    live = (unsigned int)__popcll(lv);
+    // a None run ends where the next window is live (windows past `last` are not live)
+    const unsigned long long inside =
+        lv ? ((last == 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << first) - 1ull)) : 0ull;
+    runs = (unsigned int)__popcll(~lv & inside & (lv >> 1));
+  }
+  // flagged reads longer than one wave: the wave walks each of them
+  unsigned long long big = __ballot(look && n > 64);
+  while (big) {
+    const int w = __ffsll((long long)big) - 1;
+    big &= big - 1ull;
+    const long long tw = bcast_i64(t0, w), nw = bcast_i64(n, w);
+    long long f = nw, l = -1;
+    for (long long i = lane; i < nw; i += 64)
+      if (a.tok_node[tw + i] >= 0) {
+        f = f < i ? f : i;
+        l = l > i ? l : i;
+      }
+    for (int d = 32; d > 0; d >>= 1) {
+      const long long f2 = __shfl_xor(f, d, 64), l2 = __shfl_xor(l, d, 64);
+      f = f < f2 ? f : f2;
+      l = l > l2 ? l : l2;
+    }
+    unsigned int ru = 0, li = 0;
+    if (l >= 0) {
+      for (long long i = f + lane; i <= l; i += 64) {
+        const bool none = a.tok_node[tw + i] < 0;
+        li += none ? 0u : 1u;
+        if (none && a.tok_node[tw + i + 1] >= 0) ++ru;
+      }
+      for (int d = 32; d > 0; d >>= 1) {
+        ru += __shfl_xor(ru, d, 64);
+        li += __shfl_xor(li, d, 64);
+      }
+    }
+    if (lane == w) {
+      first = f;
+      last = l;
+      runs = ru;
+      live = li;
+    }
+  }
+  if (!have) return;
+  const long long L = n + a.k - 1;
+  unsigned char cls;
+  int start = 0, end = -1;
+  unsigned int bound = 0;
+  unsigned int len_out = 0;  // genes of the corrected read, known here unless it has None runs
+  if (n <= 0) {
+    cls = RC_SKIP;  // no entry in _readNodes: correct_reads never sees the read (:1128)
+  } else if (!look) {
+    cls = RC_COPY;
+    len_out = (unsigned int)L;
+  } else if (last < 0) {
+    cls = RC_DROP;  // every node filtered: the read is dropped (:1141,:1150)
+  } else {
+    start = (int)first;
+    end = (int)last;
+    if (runs == 0) {
+      cls = RC_TRIM;
+      len_out = (unsigned int)(end - start + a.k);
     } else {
-      long long first, last;
-      unsigned int runs = 0, live = 0;
-      if (n[j] <= 64) {
-        const unsigned long long lv = __ballot(v[j] >= 0);  // lanes >= n hold -1
-        first = lv ? (long long)__ffsll((long long)lv) - 1 : n[j];
-        last = lv ? 63 - (long long)__clzll((long long)lv) : -1;
-        live = (unsigned int)__popcll(lv);
-        // a None run ends where the next window is live (windows past `last` are not live)
-        const unsigned long long inside = lv ? ((last == 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << first) - 1ull)) : 0ull;
-        runs = (unsigned int)__popcll(~lv & inside & (lv >> 1));
-      } else {
-        first = n[j];
-        last = -1;
-        for (long long i = lane; i < n[j]; i += 64)
-          if (a.tok_node[t0[j] + i] >= 0) {
-            first = first < i ? first : i;
-            last = last > i ? last : i;
-          }
-        for (int d = 32; d > 0; d >>= 1) {
-          long long f2 = __shfl_xor(first, d, 64), l2 = __shfl_xor(last, d, 64);
-          first = first < f2 ? first : f2;
-          last = last > l2 ? last : l2;
-        }
-        if (last >= 0) {
-          for (long long i = first + lane; i <= last; i += 64) {
-            bool none = a.tok_node[t0[j] + i] < 0;
-            live += none ? 0u : 1u;
-            if (none && a.tok_node[t0[j] + i + 1] >= 0) ++runs;
-          }
-          for (int d = 32; d > 0; d >>= 1) {
-            runs += __shfl_xor(runs, d, 64);
-            live += __shfl_xor(live, d, 64);
-          }
-        }
-      }
-      if (last < 0) {
-        cls = RC_DROP;  // every node filtered: the read is dropped (:1141,:1150)
-      } else {
-        start = (int)first;
-        end = (int)last;
-        if (runs == 0) {
-          cls = RC_TRIM;
-          len_out = (unsigned int)(end - start + a.k);
-        } else {
-          cls = RC_GAPPED;
-          unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
-          bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
-        }
-      }
-    }
-    if (lane == j) {
-      a.cls[r] = cls;
-      a.r_start[r] = start;
-      a.r_end[r] = end;
-      a.bound[r] = bound;    // temp space: only re-threaded reads are staged
-      a.new_len[r] = len_out;
-      a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
-      // largest staging bound of a re-threaded read: a plain (possibly stale, never too large)
-      // read first, so that only the few reads that raise the maximum touch the atomic
-      if (cls == RC_GAPPED && (unsigned long long)bound > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)bound);
+      cls = RC_GAPPED;
+      const unsigned int b1 = live + runs * (unsigned int)(2 * a.k) + (unsigned int)a.k;
+      bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
     }
   }
+  a.cls[r] = cls;
+  a.r_start[r] = start;
+  a.r_end[r] = end;
+  a.bound[r] = bound;    // temp space: only re-threaded reads are staged
+  a.new_len[r] = len_out;
+  a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
+  // largest staging bound of a re-threaded read: one atomic per wave, and only when it raises a plain (possibly
+  // stale, never too large) read of the maximum
+  unsigned int mb = cls == RC_GAPPED ? bound : 0u;
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned int o = (unsigned int)__shfl_xor((int)mb, d, 64);
+    mb = mb > o ? mb : o;
+  }
+  if (lane == 0 && (unsigned long long)mb > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)mb);
 }
 
 // ---- gapped reads
@@ -1602,64 +1634,62 @@ struct PackArgs {
   long long* o_rl;
 };
 
-// One wave packs PACK_READS consecutive reads: the per-read records of all of them are loaded
-// first, then every gene load is issued before the first store (a read of 60 genes alone is a
-// 240-byte copy: one read per wave leaves it latency-bound).  Gene positions stay where they are:
-// the corrected read only records where its positions begin (CorrArgs).
-#define PACK_READS 4
+// One wave packs 64 consecutive reads.  Lane l owns read l's record: where its genes come from (the read itself,
+// a slice of it, or the temp area of a re-threaded read), where they go, how many, and its entry of the corrected
+// CSR — all of it loaded and stored coalesced, one read per lane.  Then the 64 lanes copy the reads' genes one read
+// at a time (source / destination / length broadcast with v_readlane), four reads in flight.  (A wave per four
+// reads issued ~20 small vector-memory instructions per read and was bound by their issue, not by bytes: 0.6 ms for
+// 0.56 GB.)  Gene positions stay where they are: the corrected read only records where its positions begin
+// (CorrArgs).
+#define PACK_READS 64
 __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   const CorrArgs& a = A.a;
-  const long long rbase = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_READS;
   const int lane = threadIdx.x & 63;
-  long long dst[PACK_READS], n[PACK_READS];
-  const int* stok[PACK_READS];
-  long long poff[PACK_READS];
-  unsigned char fcs[PACK_READS];
-#pragma unroll
-  for (int j = 0; j < PACK_READS; ++j) {
-    const long long r = rbase + j;
-    n[j] = 0;
-    dst[j] = 0;
-    stok[j] = a.tokens;
-    poff[j] = 0;
-    fcs[j] = RC_SKIP;
-    if (r < a.n_reads && A.keep[r]) {
-      dst[j] = A.new_off[r];
-      n[j] = a.new_len[r];
-      fcs[j] = A.final_cls[r];
-      if (fcs[j] == RC_GAPPED) {  // re-threaded read: genes staged in the temp area, positions
-        const long long src = a.tmp_off[r];  // written to the pool by the carry-over kernels
-        stok[j] = a.tmp_tok + src;
-        if (a.have_pos) poff[j] = A.pos_new[r];
-      } else {  // untouched read, kept original, or a slice [start : end + k] of it (:1277-1285)
-        const long long cut = fcs[j] == RC_TRIM ? a.r_start[r] : 0;
-        stok[j] = a.tokens + a.read_off[r] + cut;
-        if (a.have_pos) poff[j] = (a.pos_off ? a.pos_off[r] : a.read_off[r]) + cut;
-      }
+  const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_READS + lane;
+  long long dst = 0, src = 0;  // src: token index; bit 62 set = in the temp area
+  int n = 0;
+  if (r < a.n_reads && A.keep[r]) {
+    dst = A.new_off[r];
+    n = (int)a.new_len[r];
+    const unsigned char fc = A.final_cls[r];
+    long long poff = 0;
+    if (fc == RC_GAPPED) {  // re-threaded read: genes staged in the temp area, positions written to the pool by
+      src = a.tmp_off[r] | (1ll << 62);  // the carry-over kernels
+      if (a.have_pos) poff = A.pos_new[r];
+    } else {  // untouched read, kept original, or a slice [start : end + k] of it (:1277-1285)
+      const long long cut = fc == RC_TRIM ? a.r_start[r] : 0;
+      src = a.read_off[r] + cut;
+      if (a.have_pos) poff = (a.pos_off ? a.pos_off[r] : a.read_off[r]) + cut;
     }
+    const long long q = A.new_idx[r];
+    A.o_off[q] = dst;
+    A.o_orig[q] = (int)r;
+    A.o_changed[q] = (fc == RC_TRIM || fc == RC_GAPPED) ? 1 : 0;
+    if (a.have_pos) A.o_posoff[q] = poff;
+    if (a.read_len) A.o_rl[q] = a.read_len[r];
   }
-  int vt[PACK_READS];
+  if (__ballot(n > 0) == 0ull) return;
+  for (int j0 = 0; j0 < PACK_READS; j0 += 4) {
+    const int* sp[4];
+    long long d[4];
+    int nn[4], vt[4];
 #pragma unroll
-  for (int j = 0; j < PACK_READS; ++j)
-    if (lane < n[j]) vt[j] = stok[j][lane];
-#pragma unroll
-  for (int j = 0; j < PACK_READS; ++j)
-    if (lane < n[j]) A.o_tok[dst[j] + lane] = vt[j];
-#pragma unroll
-  for (int j = 0; j < PACK_READS; ++j)
-    for (long long i = 64 + lane; i < n[j]; i += 64)  // reads longer than one wave
-      A.o_tok[dst[j] + i] = stok[j][i];
-#pragma unroll
-  for (int j = 0; j < PACK_READS; ++j) {
-    const long long r = rbase + j;
-    if (lane == j && r < a.n_reads && A.keep[r]) {
-      const long long q = A.new_idx[r];
-      A.o_off[q] = dst[j];
-      A.o_orig[q] = (int)r;
-      A.o_changed[q] = (fcs[j] == RC_TRIM || fcs[j] == RC_GAPPED) ? 1 : 0;
-      if (a.have_pos) A.o_posoff[q] = poff[j];
-      if (a.read_len) A.o_rl[q] = a.read_len[r];
+    for (int j = 0; j < 4; ++j) {
+      nn[j] = __builtin_amdgcn_readlane(n, j0 + j);
+      const long long sj = bcast_i64(src, j0 + j);
+      d[j] = bcast_i64(dst, j0 + j);
+      sp[j] = ((sj >> 62) & 1 ? a.tmp_tok : a.tokens) + (sj & ~(1ll << 62));
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane < nn[j]) vt[j] = sp[j][lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane < nn[j]) A.o_tok[d[j] + lane] = vt[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (int i = 64 + lane; i < nn[j]; i += 64)  // reads longer than one wave
+        A.o_tok[d[j] + i] = sp[j][i];
   }
 }
 
@@ -1813,7 +1843,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   HIPCHK(hipMemsetAsync(mx, 0, sizeof(unsigned long long), st));
   a.gflag = flag;
   a.max_bound = mx;
-  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * READS_PER_WAVE)), dim3(256), 0, st, a);  // also new_len, flag, max
+  if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * CLS_READS)), dim3(256), 0, st, a);  // also new_len, flag, max
   AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
   long long tmp_total = 0;
   unsigned long long max_bound = 0;
