@@ -81,6 +81,56 @@ __global__ __launch_bounds__(256) void k_clear_many(ClearArgs a) {
   }
 }
 
+#define MAIL_TICKET FETCH_MAX
+__global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long long ticket) {
+  const int i = threadIdx.x;
+  if (i < l.n) mail[i] = *l.p[i];
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) __hip_atomic_store(mail + MAIL_TICKET, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out) {
+  static const bool plain = getenv("AMG_PLAIN_SYNC") != nullptr;  // A/B switch: hipMemcpyAsync + hipStreamSynchronize
+  if (plain) {
+    for (int i = 0; i < l.n; ++i)
+      HIPCHK(hipMemcpyAsync(out + i, l.p[i], sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return AMG_OK;
+  }
+  if (!c->mail_host) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->mail_host), (FETCH_MAX + 8) * sizeof(unsigned long long),
+                         hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->mail_dev), c->mail_host, 0));
+    for (int i = 0; i < FETCH_MAX + 8; ++i) c->mail_host[i] = 0;
+  }
+  const unsigned long long ticket = ++c->mail_ticket;
+  hipLaunchKernelGGL(k_fetch, dim3(1), dim3(64), 0, c->stream, l, c->mail_dev, ticket);
+  volatile unsigned long long* t = c->mail_host + MAIL_TICKET;
+  for (unsigned long long spins = 0; *t != ticket; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfffffull) == 0xfffffull) {  // ~ms: a launch that failed never delivers the ticket
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return amg_fail(AMG_E_HIP, "%s", hipGetErrorString(e));
+      if (e == hipSuccess && *t != ticket) return amg_fail(AMG_E_HIP, "read-back kernel did not run");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < l.n; ++i) out[i] = c->mail_host[i];
+  return AMG_OK;
+}
+
+int stream_wait(amg_ctx* c) {
+  FetchList l;
+  return fetch(c, l, nullptr);
+}
+
+int fetch_status(amg_ctx* c, unsigned long long* out) {
+  FetchList l;
+  l.add_words(c->status.p, ST_WORDS);
+  return fetch(c, l, out);
+}
+
 int clear_many(amg_ctx* c, const ClearList& l) {
   if (l.n == 0) return AMG_OK;
   ClearArgs a;
@@ -141,6 +191,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->c_read_len, &c->status,   &c->sort_tmp,   &c->s0, &c->s1, &c->s2, &c->s3,
                    &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->f_ctrs, &c->x_efinal, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
   for (DevBuf* b : all) b->release();
+  if (c->mail_host) (void)hipHostFree(c->mail_host);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return AMG_OK;

@@ -517,10 +517,7 @@ static inline unsigned int blocks_for(long long n, int per) {
 }
 
 static int read_status(amg_ctx* c, unsigned long long* host) {
-  HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long),
-                        hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return AMG_OK;
+  return fetch_status(c, host);
 }
 
 uint64_t pow2_at_least(uint64_t x) {
@@ -767,9 +764,14 @@ int bs_finish_from_pairs(amg_ctx* c) {
                        c->edge_tgt.as<int>(), c->edge_sdir.as<signed char>(),
                        c->edge_tdir.as<signed char>(), c->edge_cov.as<unsigned int>(),
                        c->edge_alive.as<unsigned char>());
-    HIPCHK(hipMemcpyAsync(&total, base + P, sizeof(long long), hipMemcpyDeviceToHost, st));
   }
-  HIPCHK(hipStreamSynchronize(st));  // the build's one final synchronisation
+  {  // the build's final synchronisation
+    FetchList l;
+    l.add(P > 0 ? static_cast<const void*>(base + P) : c->status.p);
+    unsigned long long v = 0;
+    AMGCHK(fetch(c, l, &v));
+    if (P > 0) total = (long long)v;
+  }
   c->n_edges = total;
   stage_end(c);
   c->ladj_valid = false;
@@ -804,8 +806,9 @@ int ensure_components(amg_ctx* c) {
     HIPCHK(hipMemcpyAsync(root_copy, parent, (size_t)D * sizeof(int), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
                        c->s1.as<long long>(), D, parent);
-    HIPCHK(hipMemcpyAsync(&ncomp, c->s1.as<long long>() + D, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    FetchList l;
+    l.add(c->s1.as<long long>() + D);
+    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&ncomp)));
   }
   stage_end(c);
   c->n_components = ncomp;

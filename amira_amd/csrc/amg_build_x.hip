@@ -590,12 +590,7 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
-static int read_status(amg_ctx* c, unsigned long long* host) {
-  HIPCHK(hipMemcpyAsync(host, c->status.p, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                        c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return AMG_OK;
-}
+static int read_status(amg_ctx* c, unsigned long long* host) { return fetch_status(c, host); }
 
 bool bx_applicable(const amg_ctx* c, int k) {
   if (c->dist_mode || c->count_inline) return false;

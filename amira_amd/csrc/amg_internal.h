@@ -233,6 +233,11 @@ struct amg_ctx {
 
   // ---- scratch
   DevBuf status;       // unsigned long long[ST_WORDS]
+  // mailbox for the few words the host reads back between launches (fetch(), amg_api.hip): pinned host memory
+  // the device writes, a ticket last; the host spins on the ticket instead of sleeping in hipStreamSynchronize
+  unsigned long long* mail_host = nullptr;
+  unsigned long long* mail_dev = nullptr;
+  unsigned long long mail_ticket = 0;
   DevBuf sort_tmp;     // rocPRIM temp storage
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
   DevBuf nw_big;       // global scratch of the general position carry-over kernel (long reads)
@@ -268,6 +273,20 @@ struct ClearList {
   }
 };
 int clear_many(amg_ctx* c, const ClearList& l);
+
+// Device words the host needs NOW (counts that size the next allocation, status flags): everything queued on the
+// stream before the call has finished when fetch() returns, like hipMemcpyAsync + hipStreamSynchronize, at a
+// fraction of the latency (the stream stays idle ~10 us per read-back instead of ~40).
+#define FETCH_MAX 32
+struct FetchList {
+  const unsigned long long* p[FETCH_MAX];
+  int n = 0;
+  void add(const void* q) { if (n < FETCH_MAX) p[n++] = static_cast<const unsigned long long*>(q); }
+  void add_words(const void* q, int words) { for (int i = 0; i < words; ++i) add(static_cast<const unsigned long long*>(q) + i); }
+};
+int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out);
+int fetch_status(amg_ctx* c, unsigned long long* out /*[ST_WORDS]*/);
+int stream_wait(amg_ctx* c);  // hipStreamSynchronize at the latency of fetch()
 
 // ------------------------------------------------------------------ stage timing
 void stage_begin(amg_ctx* c, const char* name);

@@ -200,8 +200,11 @@ static int ensure_live_adj(amg_ctx* c) {
                      c->ladj_cnt.as<unsigned int>());
   AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_pos.as<long long>(), (size_t)E + 1));
   long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, c->ladj_pos.as<long long>() + E, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(c->ladj_pos.as<long long>() + E);
+    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&total)));
+  }
   AMGCHK(c->ladj.ensure((size_t)(total + 1) * sizeof(int2)));
   AMGCHK(c->ladj_keys.ensure(4 * (size_t)(total + 2) * sizeof(unsigned int)));
   unsigned int* k_in = c->ladj_keys.as<unsigned int>();
@@ -390,8 +393,11 @@ static int finish_kill(amg_ctx* c, int64_t* n_removed, int32_t* removed_ids) {
   HIPCHK(hipMemsetAsync(c->s1.as<unsigned int>() + D, 0, sizeof(unsigned int), st));
   AMGCHK(prim_exscan_u32_to_i64(c, c->s1.as<unsigned int>(), c->s2.as<long long>(), (size_t)D + 1));
   long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, c->s2.as<long long>() + D, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(c->s2.as<long long>() + D);
+    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&total)));
+  }
   if (n_removed) *n_removed = total;
   if (removed_ids && total > 0) {
     AMGCHK(c->s3.ensure((size_t)total * sizeof(int)));
@@ -400,7 +406,7 @@ static int finish_kill(amg_ctx* c, int64_t* n_removed, int32_t* removed_ids) {
     HIPCHK(hipMemcpyAsync(removed_ids, c->s3.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, st));
   }
   if (total > 0) AMGCHK(apply_removals(c, 0));
-  HIPCHK(hipStreamSynchronize(st));
+  if (removed_ids && total > 0) HIPCHK(hipStreamSynchronize(st));  // (nothing else here is read by the host)
   return AMG_OK;
 }
 
@@ -422,8 +428,11 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   hipLaunchKernelGGL(k_cov_sum, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_cov.as<unsigned int>(),
                      c->node_alive.as<unsigned char>(), D, acc);
   unsigned long long h[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add_words(acc, 2);
+    AMGCHK(fetch(c, l, h));
+  }
   if (h[1] == 0) { stage_end(c); return AMG_OK; }
   double mean = (double)h[0] / (double)h[1];  // correctly rounded, == float(Fraction(sum, n))
   double thr = mean * 1.5;
@@ -1847,13 +1856,21 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
   long long tmp_total = 0;
   unsigned long long max_bound = 0;
-  HIPCHK(hipMemcpyAsync(&tmp_total, tmp_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&max_bound, mx, sizeof(max_bound), hipMemcpyDeviceToHost, st));
+
   // list of gapped reads
   AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
   long long n_gapped = 0;
-  HIPCHK(hipMemcpyAsync(&n_gapped, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(tmp_off + R);
+    l.add(mx);
+    l.add(new_idx + R);
+    unsigned long long v[3];
+    AMGCHK(fetch(c, l, v));
+    tmp_total = (long long)v[0];
+    max_bound = v[1];
+    n_gapped = (long long)v[2];
+  }
   stage_end(c);
 
   AMGCHK(c->c_tokens_buf.ensure((size_t)(tmp_total + 4) * sizeof(int)));  // temp tokens live here first
@@ -1915,8 +1932,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       if (blocks > 2048u) blocks = 2048u;
       hipLaunchKernelGGL(k_corr_gapped, dim3(blocks), dim3(64), 0, st, G);
       unsigned long long hs[ST_WORDS];
-      HIPCHK(hipMemcpyAsync(hs, c->status.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      AMGCHK(fetch_status(c, hs));
       if (G.ablate == 3)
         fprintf(stderr, "[amg] DFS: %llu runs, %llu loop iterations, %llu nodes entered, %llu paths\n", hs[10], hs[8],
                 hs[9], hs[11]);
@@ -1937,8 +1953,9 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
   AMGCHK(prim_exscan_u32_to_i64(c, new_len, new_off, (size_t)R + 1));
   long long out_reads = 0, out_tokens = 0;
-  HIPCHK(hipMemcpyAsync(&out_reads, new_idx + R, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&out_tokens, new_off + R, sizeof(long long), hipMemcpyDeviceToHost, st));
+  FetchList shape;
+  shape.add(new_idx + R);
+  shape.add(new_off + R);
   const bool carry = n_gapped > 0 && c->have_pos;
   long long big_total = 0, pos_total = 0;
   unsigned long long n_general = 0;
@@ -1970,11 +1987,19 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
                        n_general_d, c->nw_rec.as<NwRec>(), a.pos_off, plen);
     AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
     AMGCHK(prim_exscan_i64(c, plen, poffs, (size_t)n_gapped + 1));
-    HIPCHK(hipMemcpyAsync(&big_total, nw_off + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&pos_total, poffs + n_gapped, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&n_general, n_general_d, sizeof(n_general), hipMemcpyDeviceToHost, st));
+    shape.add(nw_off + n_gapped);
+    shape.add(poffs + n_gapped);
+    shape.add(n_general_d);
   }
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    unsigned long long v[5] = {0, 0, 0, 0, 0};
+    AMGCHK(fetch(c, shape, v));
+    out_reads = (long long)v[0];
+    out_tokens = (long long)v[1];
+    big_total = (long long)v[2];
+    pos_total = (long long)v[3];
+    n_general = v[4];
+  }
   stage_end(c);
   // from here on the scratch roles of the output buffers (gapped read list, path pool, candidate
   // scratch) are over
@@ -2033,7 +2058,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
   HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
                         hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(stream_wait(c));
   stage_end(c);
   c->c_reads = out_reads;
   c->c_tokens = out_tokens;
