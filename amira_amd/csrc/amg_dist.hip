@@ -111,6 +111,18 @@ __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long lo
   for (int x = 0; x < k; ++x) tk[x] = dir > 0 ? tokens[t + x] : flip - tokens[t + k - 1 - x];
 }
 
+// per-destination record counts of a phase (dist_cnt[0 .. world))
+static int fetch_counts(amg_ctx* c, unsigned long long* h, int world) {
+  if (world <= FETCH_MAX) {
+    FetchList l;
+    l.add_words(c->dist_cnt.p, world);
+    return fetch(c, l, h);
+  }
+  HIPCHK(hipMemcpyAsync(h, c->dist_cnt.p, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return AMG_OK;
+}
+
 // ------------------------------------------------------------------ exact local tables
 // When the shard qualifies (bx_fits) the LOCAL passes are those of the single-GPU exact-key
 // build (amg_build_x.hip: 16-byte slots, claim ids, dense per-claim arrays); the records that
@@ -223,9 +235,7 @@ static int dest_counts(amg_ctx* c, long long n, int world, unsigned int* dest, u
                        c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
-  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(fetch_counts(c, h.data(), world));
   for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
   return AMG_OK;
 }
@@ -354,9 +364,7 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
                        c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
-  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(fetch_counts(c, h.data(), world));
   for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
   return AMG_OK;
 }
@@ -374,7 +382,7 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
                        c->dist_lcnt.as<unsigned int>(), c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
                        c->k, c->x_bits, (long long)c->k * c->x_bits > 63 ? 1 : 0,
                        reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    AMGCHK(stream_wait(c));
     return AMG_OK;
   }
   hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
@@ -382,7 +390,7 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
                      c->node_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(), c->tokens.as<int>(), c->k,
                      c->two_v, (long long)c->tok_base,
                      reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  AMGCHK(stream_wait(c));
   return AMG_OK;
 }
 
@@ -478,17 +486,22 @@ static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_byt
   HIPCHK(hipMemsetAsync(head + n, 0, sizeof(unsigned int), st));
   AMGCHK(prim_exscan_u32_to_i64(c, head, pos, (size_t)n + 1));
   long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, pos + n, sizeof(long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(pos + n);
+    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&total)));
+  }
   AMGCHK(owned.ensure((size_t)(total + 1) * rec_bytes));
   HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COLLISION, 0, sizeof(unsigned long long), st));
   hipLaunchKernelGGL(k_reduce_runs, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rec_bytes, tok_words,
                      c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), head, pos, n,
                      owned.as<unsigned char>(), c->status.as<unsigned long long>());
   unsigned long long coll = 0;
-  HIPCHK(hipMemcpyAsync(&coll, c->status.as<unsigned long long>() + ST_COLLISION, sizeof(coll),
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(c->status.as<unsigned long long>() + ST_COLLISION);
+    AMGCHK(fetch(c, l, &coll));
+  }
   if (coll) return amg_fail(AMG_E_OVERFLOW, "fingerprint collision across ranks: rebuild with another seed");
   *n_owned = total;
   return AMG_OK;
@@ -509,7 +522,7 @@ extern "C" int amg_dist_nodes_owned(amg_ctx* c, void* out) {
     if (!out) return amg_fail(AMG_E_ARG, "null out");
     HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * node_rec_bytes(c->k),
                           hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    AMGCHK(stream_wait(c));
   }
   return AMG_OK;
 }
@@ -635,9 +648,11 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
                      c->packed_nodes ? 1 : 0, c->dist_min_node > 1 ? 1 : 0,
                      c->status.as<unsigned long long>());
   unsigned long long ov = 0;
-  HIPCHK(hipMemcpyAsync(&ov, c->status.as<unsigned long long>() + ST_OVERFLOW, sizeof(ov),
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(c->status.as<unsigned long long>() + ST_OVERFLOW);
+    AMGCHK(fetch(c, l, &ov));
+  }
   if (ov) return amg_fail(AMG_E_DIST, "global node table inconsistent (code %llu)", ov);
   return AMG_OK;
 }
@@ -717,9 +732,7 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
                        c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
-  HIPCHK(hipMemcpyAsync(h.data(), c->dist_cnt.p, (size_t)world * sizeof(unsigned long long),
-                        hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  AMGCHK(fetch_counts(c, h.data(), world));
   for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
   return AMG_OK;
 }
@@ -735,14 +748,14 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
                        c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
                        (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), reinterpret_cast<unsigned char*>(send_buf));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    AMGCHK(stream_wait(c));
     return AMG_OK;
   }
   hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                      c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
                      c->edge_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(),
                      reinterpret_cast<unsigned char*>(send_buf));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  AMGCHK(stream_wait(c));
   return AMG_OK;
 }
 
@@ -760,7 +773,7 @@ extern "C" int amg_dist_edges_owned(amg_ctx* c, void* out) {
     if (!out) return amg_fail(AMG_E_ARG, "null out");
     HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * EDGE_REC_BYTES,
                           hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    AMGCHK(stream_wait(c));
   }
   return AMG_OK;
 }
@@ -812,7 +825,7 @@ extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_
     // fused filter: reads that lost a node join _readsToCorrect (remove_node_from_reads :442-461)
     hipLaunchKernelGGL(k_flag_dead_reads, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, c->tok_node.as<int>(),
                        c->read_off.as<long long>(), c->n_reads, c->read_fix.as<unsigned char>());
-    HIPCHK(hipStreamSynchronize(st));
+    AMGCHK(stream_wait(c));
   }
   c->dist_min_node = c->dist_min_edge = 1;
   c->built = true;

@@ -88,6 +88,10 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
             op, buf, arg, rec_bytes = gen.send(reply)
         except StopIteration:
             return
+        if world == 1:  # nothing to exchange: the rank's own records are all there are
+            n = sum(arg) if op == "a2a" else arg
+            reply = (buf, n)
+            continue
         reply = (exchange_a2a if op == "a2a" else exchange_ag)(buf, arg, rec_bytes, group)
         torch.cuda.current_stream(dev).synchronize()
 

@@ -471,8 +471,11 @@ def main():
         per_kernel = {s: {"ms_per_step": round(stage_tot[s], 3), "avg_launch_ms": round(stage_avg[s], 4),
                           "achieved_GBs": round(cands[s] / (stage_avg[s] * 1e-3) / 1e9, 1)} for s in ranked[:4]}
         exact = bool(counts.get("exact_keys"))
-        kernel_of = {"graph_upsert": "k_graph_x", "node_upsert": "k_nodes_x" if exact else "k_node_upsert",
-                     "edge_upsert": "k_edges_x" if exact else "k_edges", "node_count": "k_count_ids",
+        old_pass = bool(os.environ.get("AMG_X_OLD_PASS"))
+        kernel_of = {"graph_upsert": "k_graph_x",
+                     "node_upsert": ("k_nodes_x" if old_pass else "k_nodes_v") if exact else "k_node_upsert",
+                     "edge_upsert": ("k_edges_x" if old_pass else "k_edges_v") if exact else "k_edges",
+                     "node_count": "k_count_ids",
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
@@ -493,11 +496,14 @@ def main():
                 pmc = json.load(open(pmc_path))
                 row = next(r for r in pmc["kernels"] if r["kernel"].split("<")[0] == kernel_of[dom])
                 n = min(len(row["FETCH_SIZE_KB_per_launch"]), len(row["WRITE_SIZE_KB_per_launch"]))
-                traffic = sum((row["FETCH_SIZE_KB_per_launch"][i] + row["WRITE_SIZE_KB_per_launch"][i]) * 1024.0
+                # gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads at 64 bytes (MI355X_MICROARCH.md,
+                # HBM): every load of the table passes is such a load (token stream, slot probes), so the read side is
+                # doubled; WRITE_SIZE is exact for the 16-byte-per-lane stores
+                traffic = sum((2.0 * row["FETCH_SIZE_KB_per_launch"][i] + row["WRITE_SIZE_KB_per_launch"][i]) * 1024.0
                               for i in range(n)) / n
-                traffic_note = ("mean over the launches of one sweep, (FETCH_SIZE + WRITE_SIZE) x 1024, separate "
-                                "--pmc passes, from profiles/" + os.path.basename(pmc_path) + "; not corrected for the "
-                                "gfx950 FETCH_SIZE under-count of wide coalesced streams")
+                traffic_note = ("mean over the launches of one sweep, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 counts the "
+                                "128-byte requests of 16-byte-per-lane loads at 64 bytes; calibrated for streams, assumed for "
+                                "the slot probes), separate --pmc passes, from profiles/" + os.path.basename(pmc_path))
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
