@@ -20,6 +20,27 @@ def build_graph(read_dict, kmer_size, gene_positions=None):
     return GeneMerGraph(read_dict, kmer_size, gene_positions)
 
 
+def _tokenized(reads, gene_positions):
+    """(TokenizedReads, TokenizedPositions or None) of a {read: genes} / {read: [(start, end)]} pair"""
+    from .io import TokenizedPositions, TokenizedReads
+    from .tokens import tokenize
+    if hasattr(reads, "tokens") and hasattr(reads, "read_offsets"):
+        reads_t = reads
+    else:
+        reads_t = TokenizedReads(*tokenize(reads))
+    if gene_positions is None or hasattr(gene_positions, "gene_start"):
+        return reads_t, gene_positions
+    offs, n = reads_t.read_offsets, int(reads_t.read_offsets[-1])
+    gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
+    for r, rid in enumerate(reads_t.read_ids):
+        a, b = int(offs[r]), int(offs[r + 1])
+        if b > a:
+            p = gene_positions[rid]
+            gs[a:b] = [x[0] for x in p[: b - a]]
+            ge[a:b] = [x[1] for x in p[: b - a]]
+    return reads_t, TokenizedPositions(reads_t.read_ids, offs, gs, ge)
+
+
 def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positions=None):
     """single-graph result (what cores=1 gives in the reference), built on the GPU."""
     reads = {r: annotatedReads[r] for r in annotatedReads}
@@ -79,9 +100,11 @@ def choose_kmer_size(overall_mean_node_coverage, new_annotatedReads, cores, new_
     AMR nodes have >= 2k-1 genes (graph_utils.py:258-296)."""
     geneMer_size = 3
     if overall_mean_node_coverage >= 20:
+        # the seven builds see the same reads: gene names are hashed and ranked, reads and positions
+        # flattened ONCE; every build then hands the same arrays to the (pooled) engine
+        reads_t, pos_t = _tokenized(new_annotatedReads, new_gene_position_dict)
         for k in range(3, 16, 2):
-            graph = build_multiprocessed_graph(new_annotatedReads.copy(), k, cores,
-                                               new_gene_position_dict.copy())
+            graph = build_graph(reads_t, k, pos_t)
             amr = {n.__hash__() for g in sample_genesOfInterest for n in graph.get_nodes_containing(g)}
 
             def is_component_valid(component):
