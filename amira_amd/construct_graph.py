@@ -1125,6 +1125,20 @@ class GeneMerGraph(BubblePopping):
         for both sides of the first test."""
         readNodes = self.get_readNodes()
         anchors, terminals = set(), {}
+        per_read = {}  # read -> (AMR flag per node of the read, positions of every AMR node on it): a read is
+                       # looked at once, not once per AMR node it carries
+
+        def on_read_info(r, on_read):
+            got = per_read.get(r)
+            if got is None:
+                amr, where = [0] * len(on_read), {}
+                for i, n in enumerate(on_read):
+                    if n in AMRNodes:
+                        amr[i] = 1
+                        where.setdefault(n, []).append(i)
+                got = per_read[r] = (amr, where)
+            return got
+
         for h in AMRNodes:
             flags = terminals[h] = []
             node = self.get_node_by_hash(h)
@@ -1139,8 +1153,8 @@ class GeneMerGraph(BubblePopping):
                     flags.append(True)
                     break
                 singletons.append(False)
-                amr = [1 if n in AMRNodes else 0 for n in on_read]
-                for idx in [i for i, n in enumerate(on_read) if n == h]:
+                amr, where = on_read_info(r, on_read)
+                for idx in where.get(h, ()):
                     if idx == 0 or idx == len(on_read) - 1:
                         flags.append(True)
                         continue
@@ -1316,14 +1330,16 @@ class GeneMerGraph(BubblePopping):
             starts = np.concatenate([c[1] for c in chosen])
             which = np.concatenate([np.zeros(len(chosen[0][0]), np.int8), np.ones(len(chosen[1][0]), np.int8)])
             order = np.argsort(rows, kind="stable")   # read order == dict order of _reads
+            # (single genes / positions of a read: tokenised containers answer without decoding the read)
+            gene_at = getattr(self._reads, "gene_at", None) or (lambda rid, i: self._reads[rid][i])
+            pos_at = getattr(self._genePositions, "pos_at", None) or (lambda rid, i: self._genePositions[rid][i])
             for r, start, w in zip(rows[order].tolist(), starts[order].tolist(), which[order].tolist()):
                 idx = rv_idx if w else fw_idx
                 read_id = self._read_ids[r]
-                genes_on_read = self._reads[read_id]
                 path_reads.setdefault(named, set()).add(read_id)
                 for gene_index in idx:
-                    assert genes_on_read[start + gene_index][1:] == geneOfInterest
-                    s_, e_ = self._genePositions[read_id][start + gene_index]
+                    assert gene_at(read_id, start + gene_index)[1:] == geneOfInterest
+                    s_, e_ = pos_at(read_id, start + gene_index)
                     entry = f"{read_id}_{s_}_{e_}"
                     gene_clusters[idx[gene_index]].append(entry)
                     read_tracking[idx[gene_index]].add(entry)

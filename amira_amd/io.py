@@ -34,6 +34,19 @@ class TokenizedReads(Mapping):
                 self.tokens[self.read_offsets[i]:self.read_offsets[i + 1]])
         return got
 
+    def gene_at(self, read_id, i):
+        """self[read_id][i] without decoding the rest of the read"""
+        got = self._cache.get(read_id)
+        if got is not None:
+            return got[i]
+        r = self._idx()[read_id]
+        a, b = int(self.read_offsets[r]), int(self.read_offsets[r + 1])
+        if i < 0:
+            i += b - a
+        if not 0 <= i < b - a:
+            raise IndexError(i)
+        return self.vocab.gene(int(self.tokens[a + i]))
+
     def __iter__(self):
         return iter(self.read_ids)
 
@@ -66,6 +79,19 @@ class TokenizedPositions(Mapping):
             a, b = int(self.read_offsets[i]), int(self.read_offsets[i + 1])
             got = self._cache[read_id] = list(zip(self.gene_start[a:b].tolist(), self.gene_end[a:b].tolist()))
         return got
+
+    def pos_at(self, read_id, i):
+        """self[read_id][i] without building the read's list of pairs"""
+        got = self._cache.get(read_id)
+        if got is not None:
+            return got[i]
+        r = self._idx()[read_id]
+        a, b = int(self.read_offsets[r]), int(self.read_offsets[r + 1])
+        if i < 0:
+            i += b - a
+        if not 0 <= i < b - a:
+            raise IndexError(i)
+        return int(self.gene_start[a + i]), int(self.gene_end[a + i])
 
     def __setitem__(self, read_id, value):   # correct_reads / bubble popping replace a read's positions
         self._idx()

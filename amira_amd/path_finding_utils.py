@@ -216,9 +216,11 @@ def get_blocks_from_subtree(sub_tree, a2, nodeAnchors):
 
 
 def get_all_context_options(nodes_on_reads, start, end):
-    up, down = nodes_on_reads[:start], nodes_on_reads[end + 1:]
-    up_options = {tuple(up[-i:]) for i in range(1, len(up) + 1)} | {()}
-    down_options = {tuple(down[:i]) for i in range(1, len(down) + 1)} | {()}
+    up, down = tuple(nodes_on_reads[:start]), tuple(nodes_on_reads[end + 1:])
+    up_options = {up[-i:] for i in range(1, len(up) + 1)}     # (slices of a tuple are tuples)
+    up_options.add(())
+    down_options = {down[:i] for i in range(1, len(down) + 1)}
+    down_options.add(())
     return up_options, down_options
 
 

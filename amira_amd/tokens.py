@@ -93,7 +93,15 @@ class Vocabulary:
         return self.two_v - 1 - token
 
     def decode(self, tokens):
-        return [self.gene(int(t)) for t in tokens]
+        """strings of a token sequence: one table lookup per token, built once (token -> "+name" / "-name")"""
+        table = getattr(self, "_strings", None)
+        if table is None:
+            V = max(self.V, 1)
+            table = self._strings = (["-" + n for n in reversed(self.names)] + [""] * (V - self.V)
+                                     + ["+" + n for n in self.names])
+        if hasattr(tokens, "tolist"):
+            tokens = tokens.tolist()
+        return [table[t] for t in tokens]
 
 
 def tokenize(read_dict):
