@@ -35,6 +35,14 @@ def steps(engine, k, world, rank, token_base, token_total, min_node_cov=1, min_e
         engine.dist_global(what, everything.data_ptr(), n_total)
 
 
+class PeerFailed(RuntimeError):
+    """a rank's device phase failed (table overflow, fingerprint collision, bad input): the build is off on every rank"""
+
+    def __init__(self, ranks):
+        super().__init__(f"merged build abandoned: device phase failed on rank(s) {ranks}")
+        self.ranks = ranks
+
+
 def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     """variable-size all-to-all of whole records (works on device tensors with RCCL and on CPU
     tensors with gloo): returns (recv tensor, number of records received)."""
@@ -44,6 +52,8 @@ def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     rc = torch.empty_like(sc)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.tolist()
+    if min(recv_counts, default=0) < 0 or min(send_counts, default=0) < 0:   # see dist_build
+        raise PeerFailed([r for r, n in enumerate(recv_counts) if n < 0])
     n_send, n_recv = sum(send_counts), sum(recv_counts)
     recv = torch.empty(max(n_recv, 1) * rec_bytes, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(recv[: n_recv * rec_bytes], buf[: n_send * rec_bytes],
@@ -61,6 +71,8 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     allno = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allno, no, group=group)
     counts = allno.tolist()
+    if min(counts) < 0:   # see dist_build
+        raise PeerFailed([r for r, n in enumerate(counts) if n < 0])
     m = max(max(counts), 1)  # equal-size contributions: pad to the largest, compact afterwards
     padded = torch.zeros(m * rec_bytes, dtype=torch.uint8, device=dev)
     padded[: n_owned * rec_bytes] = buf[: n_owned * rec_bytes]
@@ -83,11 +95,27 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
     tokens = gathered.tolist()
     gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens), min_node_cov, min_edge_cov)
     reply = None
+    expected = iter(("a2a", "ag", "a2a", "ag"))
     while True:
+        nxt = next(expected, None)
         try:
             op, buf, arg, rec_bytes = gen.send(reply)
         except StopIteration:
             return
+        except Exception:
+            # A failing device phase must not leave the other ranks waiting in the collective they enter next:
+            # take part in its count exchange with negative counts — every rank (this one included) then sees
+            # them and leaves before any data moves — and re-raise the local error.
+            if world > 1 and nxt is not None:
+                dummy = torch.zeros(1, dtype=torch.uint8, device=dev)
+                try:
+                    if nxt == "a2a":
+                        exchange_a2a(dummy, [-1] * world, 1, group)
+                    else:
+                        exchange_ag(dummy, -1, 1, group)
+                except PeerFailed:
+                    pass
+            raise
         if world == 1:  # nothing to exchange: the rank's own records are all there are
             n = sum(arg) if op == "a2a" else arg
             reply = (buf, n)

@@ -73,3 +73,45 @@ def test_exchange_world2_gloo():
     for r in range(world):
         assert got[r][3] == sum(got[x][4] for x in range(world))
         assert np.array_equal(got[r][2], np.concatenate(owned))
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from amira_amd.dist import PeerFailed, exchange_a2a, exchange_ag
+    seen = []
+    # rank 1's device phase "failed" before the all-to-all: it signals with negative counts
+    try:
+        counts = [-1] * world if rank == 1 else [2, 3]
+        exchange_a2a(torch.zeros(max(sum(c for c in counts if c > 0), 1) * REC, dtype=torch.uint8), counts, REC)
+        seen.append("a2a went through")
+    except PeerFailed as e:
+        seen.append(("a2a", e.ranks if rank != 1 else "self"))
+    # ... and before the all-gather
+    try:
+        exchange_ag(torch.zeros(REC, dtype=torch.uint8), -1 if rank == 1 else 1, REC)
+        seen.append("ag went through")
+    except PeerFailed as e:
+        seen.append(("ag", e.ranks))
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_rank_releases_its_peers_gloo():
+    """a rank whose device phase failed takes part in the next count exchange with negative counts: nobody hangs,
+    everybody raises (amira_amd.dist.dist_build)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == [("a2a", [1]), ("ag", [1])]
+    assert got[1] == [("a2a", "self"), ("ag", [1])]

@@ -249,3 +249,62 @@ def test_sharded_sweep_with_fused_first_filter():
         assert np.array_equal(np.concatenate([o[key] for o in got]), want[key]), key
     for e in engines + [single]:
         e.close()
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """one rank of a REAL multi-process merged build over RCCL (needs >= world GPUs on the node)"""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    vocab, toks, offs, _ = tokenize(reads)
+    t, o, lo, hi = make_shards(toks, offs, world)[rank]
+    eng = Engine(rank)
+    eng.set_reads(t, o, vocab.two_v)
+    dist_build(eng, 5)
+    st = graph_state(eng)
+    st["tok_node"] = eng.read_nodes()[0]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **st)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dist_build_over_rccl_two_processes(tmp_path):
+    """two processes, two GPUs, RCCL all-to-all / all-gather between them: every rank must end with the graph the
+    unsharded engine builds (skipped on a single-GPU box; the driver's multi-GPU tier runs it)"""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from amira_amd import Engine, tokenize
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    vocab, toks, offs, _ = tokenize(reads)
+    ref = Engine(0)
+    ref.set_reads(toks, offs, vocab.two_v)
+    ref.build(5)
+    want = graph_state(ref)
+    ref_nodes = ref.read_nodes()[0]
+    bounds = shard_bounds(len(offs) - 1, world)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (r, key)
+        assert np.array_equal(got["tok_node"], ref_nodes[offs[bounds[r]]:offs[bounds[r + 1]]])
+    ref.close()
