@@ -529,13 +529,18 @@ uint64_t pow2_at_least(uint64_t x) {
 static const unsigned int kProbeLimit = 1024;
 
 // window / short-read counts into the status words + the read-end bitmap the tile kernels use
-int bs_read_stats(amg_ctx* c, int k) {
+int bs_read_stats(amg_ctx* c, int k, const ClearList* also) {
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, R = c->n_reads;
   stage_begin(c, "read_stats");
   const size_t words = (size_t)(T >> 5) + BND_PAD_WORDS;
   AMGCHK(c->bnd_bits.ensure(words * sizeof(unsigned int)));
-  HIPCHK(hipMemsetAsync(c->bnd_bits.p, 0, words * sizeof(unsigned int), st));
+  {  // the read-end bitmap and whatever else the caller wants zeroed before its table pass: one launch
+    ClearList cl;
+    if (also) cl = *also;
+    cl.add(c->bnd_bits.p, words * sizeof(unsigned int));
+    AMGCHK(clear_many(c, cl));
+  }
   if (R > 0)
     hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
                        c->read_off.as<long long>(), R, T, k, c->status.as<unsigned long long>(),

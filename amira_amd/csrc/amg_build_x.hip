@@ -622,9 +622,6 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   c->exact_keys = true;
   c->packed_nodes = false;
   c->x_bits = bx_bits(c, k);
-  HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
-
-  AMGCHK(bs_read_stats(c, k));
   const long long n_tiles = (T + TILE - 1) / TILE;
 
   const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
@@ -636,10 +633,13 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
 
-  stage_begin(c, "node_table_clear");
-  HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->x_first.p, 0, 2 * max_claims * sizeof(unsigned int), st));
-  stage_end(c);
+  {  // status words, table, first-seen words and the read-end bitmap are zeroed by ONE launch
+    ClearList cl;
+    cl.add(c->status.p, ST_WORDS * sizeof(unsigned long long));
+    cl.add(c->node_tab.p, (size_t)c->node_slots * sizeof(Slot16));
+    cl.add(c->x_first.p, 2 * max_claims * sizeof(unsigned int));
+    AMGCHK(bs_read_stats(c, k, &cl));
+  }
 
   const char* abl = getenv("AMG_X_ABLATE");  // timing experiments (tools/ablate_probe.py): the build fails
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 63) : 0;
@@ -755,9 +755,13 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
   stage_begin(c, "edge_table_clear");
-  HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot16), st));
-  HIPCHK(hipMemsetAsync(c->x_efirst.p, 0, 2 * max_claims * sizeof(unsigned int), st));
-  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 0, 2 * sizeof(unsigned long long), st));
+  {
+    ClearList cl;
+    cl.add(c->edge_tab.p, (size_t)c->edge_slots * sizeof(Slot16));
+    cl.add(c->x_efirst.p, 2 * max_claims * sizeof(unsigned int));
+    cl.add(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 2 * sizeof(unsigned long long));
+    AMGCHK(clear_many(c, cl));
+  }
   stage_end(c);
   const char* abl = getenv("AMG_X_ABLATE");
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather

@@ -297,7 +297,7 @@ void stages_reset(amg_ctx* c);
 uint64_t pow2_at_least(uint64_t x);
 uint64_t slots_for(uint64_t n_keys);
 void bs_size_tables(amg_ctx* c);
-int bs_read_stats(amg_ctx* c, int k);
+int bs_read_stats(amg_ctx* c, int k, const ClearList* also = nullptr);
 int bs_nodes_pass(amg_ctx* c, int k, int* which);
 int bs_alloc_nodes(amg_ctx* c, long long D);
 int bs_nodes_rank_local(amg_ctx* c);

@@ -438,8 +438,12 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   double thr = mean * 1.5;
   AMGCHK(c->s0.ensure((size_t)D + 8));
   AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
-  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)D + 8, st));
-  HIPCHK(hipMemsetAsync(c->s4.p, 0, (size_t)(c->n_components + 2) * sizeof(unsigned int), st));
+  {
+    ClearList cl;
+    cl.add(c->s0.p, (size_t)D + 8);
+    cl.add(c->s4.p, (size_t)(c->n_components + 2) * sizeof(unsigned int));
+    AMGCHK(clear_many(c, cl));
+  }
   hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
                      c->s4.as<unsigned int>(), (unsigned int*)nullptr);
@@ -475,8 +479,12 @@ extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t min_cov) 
   size_t nc = (size_t)(c->n_components + 2);
   AMGCHK(c->s0.ensure((size_t)D + 8));
   AMGCHK(c->s4.ensure(2 * nc * sizeof(unsigned int)));
-  HIPCHK(hipMemsetAsync(c->s0.p, 0, (size_t)D + 8, st));
-  HIPCHK(hipMemsetAsync(c->s4.p, 0, 2 * nc * sizeof(unsigned int), st));
+  {
+    ClearList cl;
+    cl.add(c->s0.p, (size_t)D + 8);
+    cl.add(c->s4.p, 2 * nc * sizeof(unsigned int));
+    AMGCHK(clear_many(c, cl));
+  }
   unsigned int* live = c->s4.as<unsigned int>();
   unsigned int* high = live + nc;
   hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
@@ -1456,6 +1464,7 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   pos_base(a, q.poff, pgs, pge);
   const long long ogs = lane < M ? pgs[lane] : 0;
   const long long oge = lane < M ? pge[lane] : 0;
+  const long long rl = a.read_len ? a.read_len[r] : 0;  // (with the batch: not a third dependent round trip)
   if (lane < N) X[lane] = x0;
   if (lane + 64 < N) X[lane + 64] = x1;
   OGS[lane] = ogs;
@@ -1603,7 +1612,6 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   }
   wave_sync();
   // ---- replace_invalid_gene_positions, each lane repairs its own entries
-  const long long rl = a.read_len ? a.read_len[r] : 0;
   for (int q = lane; q < N; q += 64) {
     long long sv = GS[q], ev = GE[q];
     if (sv == NONE && ev == NONE) {
@@ -1847,9 +1855,13 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.tmp_tok = nullptr;
 
   stage_begin(c, "correct_classify");
-  HIPCHK(hipMemsetAsync(bound, 0, per_read * sizeof(unsigned int) * 3, st));
   unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
-  HIPCHK(hipMemsetAsync(mx, 0, sizeof(unsigned long long), st));
+  {
+    ClearList cl;
+    cl.add(bound, per_read * sizeof(unsigned int) * 3);
+    cl.add(mx, sizeof(unsigned long long));
+    AMGCHK(clear_many(c, cl));
+  }
   a.gflag = flag;
   a.max_bound = mx;
   if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * CLS_READS)), dim3(256), 0, st, a);  // also new_len, flag, max
@@ -1948,8 +1960,12 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   // positions straight into the output arrays)
   stage_begin(c, "correct_pack");
   if (R > 0) hipLaunchKernelGGL(k_corr_keep, dim3(nblk(R, 256)), dim3(256), 0, st, new_len, R, flag);
-  HIPCHK(hipMemsetAsync(flag + R, 0, sizeof(unsigned int), st));
-  HIPCHK(hipMemsetAsync(new_len + R, 0, sizeof(unsigned int), st));
+  {
+    ClearList cl;
+    cl.add(flag + R, sizeof(unsigned int));
+    cl.add(new_len + R, sizeof(unsigned int));
+    AMGCHK(clear_many(c, cl));
+  }
   AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
   AMGCHK(prim_exscan_u32_to_i64(c, new_len, new_off, (size_t)R + 1));
   long long out_reads = 0, out_tokens = 0;
