@@ -217,10 +217,10 @@ def get_blocks_from_subtree(sub_tree, a2, nodeAnchors):
 
 def get_all_context_options(nodes_on_reads, start, end):
     up, down = tuple(nodes_on_reads[:start]), tuple(nodes_on_reads[end + 1:])
-    up_options = {up[-i:] for i in range(1, len(up) + 1)}     # (slices of a tuple are tuples)
-    up_options.add(())
-    down_options = {down[:i] for i in range(1, len(down) + 1)}
-    down_options.add(())
+    # (slices of a tuple are tuples; same elements inserted in the same order as the reference's
+    # {tuple(up[-i:]) ...} | {()}, so the sets iterate alike)
+    up_options = {up[-i:] for i in range(1, len(up) + 1)} | {()}
+    down_options = {down[:i] for i in range(1, len(down) + 1)} | {()}
     return up_options, down_options
 
 
@@ -249,13 +249,43 @@ def get_full_path_contexts(positions_of_path, contexts, reads, read_id, block_re
 
 
 def generate_contexts(block_reads, block_duplicates, reads):
+    """contexts of every block (path_finding_utils.py:150-201), with the same final state as the
+    reference's read-by-read loop at a fraction of its work:
+      * a read whose block is in the NON-canonical orientation replaces the block's entry by sets made from
+        that read alone, so whatever earlier reads contributed is gone — only the LAST such read of a block
+        and the canonical reads after it are looked at;
+      * the context sets are suffix- / prefix-closed (every update adds all suffixes of an upstream list,
+        all prefixes of a downstream list), so a list that is already in the set brings nothing new and
+        its O(L^2) options are not generated (adding present elements does not touch a set)."""
     contexts = {}
+    todo = {}  # key -> [(read_id, where, is_canonical), ...] in read order
     for read_id, block in block_reads.items():
-        where = find_sublist_indices(reads[read_id], block)
+        on_read = reads[read_id]
+        where = find_sublist_indices(on_read, block)
         assert len(where) > 0
-        update_duplicates(block_duplicates, tuple(get_canonical_representation(block)), where)
+        canonical = get_canonical_representation(block)
+        key = tuple(canonical)
+        update_duplicates(block_duplicates, key, where)
         if len(where) == 1:
-            get_full_path_contexts(where, contexts, reads, read_id, block_reads)
+            contexts.setdefault(key, {"upstream": set(), "downstream": set()})   # dict order = first read
+            todo.setdefault(key, []).append((read_id, where, canonical == block))
+    for key, entries in todo.items():
+        first = 0
+        for i, (_, _, is_canonical) in enumerate(entries):
+            if not is_canonical:
+                first = i
+        for read_id, where, is_canonical in entries[first:]:
+            if not is_canonical:
+                get_full_path_contexts(where, contexts, reads, read_id, block_reads)
+                continue
+            start, end = where[0]
+            on_read = reads[read_id]
+            ups, downs = contexts[key]["upstream"], contexts[key]["downstream"]
+            up, down = tuple(on_read[:start]), tuple(on_read[end + 1:])
+            if up not in ups or () not in ups:
+                ups.update({up[-i:] for i in range(1, len(up) + 1)} | {()})
+            if down not in downs or () not in downs:
+                downs.update({down[:i] for i in range(1, len(down) + 1)} | {()})
     return contexts
 
 
