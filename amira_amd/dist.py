@@ -84,8 +84,9 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     return everything.contiguous(), total
 
 
-def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
-    """Collective: call on every rank with its own engine (reads already set)."""
+def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1, always_exchange=False):
+    """Collective: call on every rank with its own engine (reads already set).  At world size 1 the records
+    do not travel (always_exchange=True sends them through the collectives anyway: tests of the plumbing)."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", engine.device)
@@ -116,7 +117,7 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1):
                 except PeerFailed:
                     pass
             raise
-        if world == 1:  # nothing to exchange: the rank's own records are all there are
+        if world == 1 and not always_exchange:  # nothing to exchange: the rank's own records are all there are
             n = sum(arg) if op == "a2a" else arg
             reply = (buf, n)
             continue

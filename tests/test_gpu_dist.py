@@ -161,7 +161,7 @@ def test_dist_build_over_rccl_world1():
         reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
         vocab, toks, offs, _ = tokenize(reads)
         ref = Engine(0); ref.set_reads(toks, offs, vocab.two_v); ref.build(5)
-        eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v); dist_build(eng, 5)
+        eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v); dist_build(eng, 5, always_exchange=True)
         assert_same_graph(graph_state(eng), graph_state(ref))
         assert np.array_equal(eng.read_nodes()[0], ref.read_nodes()[0])
         eng.close(); ref.close()
