@@ -1330,13 +1330,31 @@ class GeneMerGraph(BubblePopping):
             starts = np.concatenate([c[1] for c in chosen])
             which = np.concatenate([np.zeros(len(chosen[0][0]), np.int8), np.ones(len(chosen[1][0]), np.int8)])
             order = np.argsort(rows, kind="stable")   # read order == dict order of _reads
+            ro, so, wo = rows[order], starts[order], which[order]
+            rids = [self._read_ids[r] for r in ro.tolist()]
+            if rids:
+                path_reads.setdefault(named, set()).update(rids)
+            pos = self._genePositions
+            if (fw_idx and rids and hasattr(self._reads, "tokens") and hasattr(pos, "gene_start")
+                    and not pos._cache and self._gs is not None):
+                # tokenised containers: the genes and positions of all chosen reads come out of the flat arrays
+                # at once (one entry per read and allele, appended in read order as the loop below does)
+                V = max(self._vocab.V, 1)
+                want = self._vocab.rank[geneOfInterest]
+                base = self._read_off[ro] + so
+                for g, allele in fw_idx.items():
+                    t = base + np.where(wo == 1, len(fwd) - g - 1, g)
+                    tok = self._tokens[t].astype(np.int64)
+                    assert bool(np.all(np.where(tok >= V, tok - V, V - 1 - tok) == want))
+                    entries = [f"{rid}_{s_}_{e_}" for rid, s_, e_ in zip(rids, self._gs[t].tolist(), self._ge[t].tolist())]
+                    gene_clusters[allele].extend(entries)
+                    read_tracking[allele].update(entries)
+                continue
             # (single genes / positions of a read: tokenised containers answer without decoding the read)
             gene_at = getattr(self._reads, "gene_at", None) or (lambda rid, i: self._reads[rid][i])
-            pos_at = getattr(self._genePositions, "pos_at", None) or (lambda rid, i: self._genePositions[rid][i])
-            for r, start, w in zip(rows[order].tolist(), starts[order].tolist(), which[order].tolist()):
+            pos_at = getattr(pos, "pos_at", None) or (lambda rid, i: pos[rid][i])
+            for read_id, start, w in zip(rids, so.tolist(), wo.tolist()):
                 idx = rv_idx if w else fw_idx
-                read_id = self._read_ids[r]
-                path_reads.setdefault(named, set()).add(read_id)
                 for gene_index in idx:
                     assert gene_at(read_id, start + gene_index)[1:] == geneOfInterest
                     s_, e_ = pos_at(read_id, start + gene_index)
@@ -1408,30 +1426,45 @@ class GeneMerGraph(BubblePopping):
 
     def _node_tree_from_device_ids(self, reads_with_gene):
         """construct_suffix_tree({r: readNodes[r]}) (path_finding_utils.py:79-85) without interning the
-        256-bit node hashes item by item: the search codes are the DEVICE node ids of the per-window
-        array (None = -2), the sequences stay lists of hashes.  Entry order as the reference builds it:
-        the reads in the given order, then '<read>_reverse' for every read with more than one distinct node."""
-        if not hasattr(Tree, "from_codes"):
+        256-bit node hashes item by item and without a Python loop over the reads: the search codes are the
+        DEVICE node ids of the per-window array (None = -2) gathered for all reads at once, the sequences
+        (lists of hashes, what suffixes are cut from) are the view's cached read lists.  Entry order
+        as the reference builds it: the reads in the given order, then '<read>_reverse' for every read with
+        more than one distinct node."""
+        if not hasattr(Tree, "from_flat"):
             return None   # the external suffix_tree package is in use
         v = self._v()
         tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
-        index, read_nodes = self._read_index, v.readNodes
-        keys, seqs, codes, late_keys, late_seqs, late_codes = [], [], [], [], [], []
-        for rid in reads_with_gene:
-            r = index[rid]
-            a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
-            ids = tok_node[a:a + n]
-            nodes = read_nodes[rid]
-            keys.append(rid)
-            seqs.append(nodes)
-            codes.append(ids)
-            if len(set(nodes)) != 1:
-                late_keys.append(rid + "_reverse")
-                late_seqs.append(nodes[::-1])
-                late_codes.append(ids[::-1])
+        index = self._read_index
+        reads_with_gene = list(reads_with_gene)
+        rows = np.fromiter((index[rid] for rid in reads_with_gene), dtype=np.int64, count=len(reads_with_gene))
+        a = offs[rows]
+        n = offs[rows + 1] - a - k + 1
+        starts = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum(n, out=starts[1:])
+        total = int(starts[-1])
+        within = np.arange(total, dtype=np.int64) - np.repeat(starts[:-1], n)
+        fwd = tok_node[np.repeat(a, n) + within].astype(np.int64)
+        if len(rows):
+            lo = np.minimum.reduceat(fwd, starts[:-1])
+            hi = np.maximum.reduceat(fwd, starts[:-1])
+            late = np.flatnonzero(lo != hi)       # more than one distinct node (ids <-> hashes, -2 <-> None)
+        else:
+            late = np.zeros(0, np.int64)
+        n_late = n[late]
+        starts_late = np.zeros(len(late) + 1, dtype=np.int64)
+        np.cumsum(n_late, out=starts_late[1:])
+        within_l = np.arange(int(starts_late[-1]), dtype=np.int64) - np.repeat(starts_late[:-1], n_late)
+        rev = fwd[np.repeat(starts[late] + n_late - 1, n_late) - within_l]
+        flat = np.concatenate([fwd, rev])
+        all_starts = np.concatenate([starts, starts_late[1:] + total])
+        keys = reads_with_gene + [reads_with_gene[i] + "_reverse" for i in late.tolist()]
+        # the sequences themselves (what suffixes are cut from): the reads' node-hash lists of the view
+        read_nodes = v.readNodes
+        seqs = [read_nodes[rid] for rid in reads_with_gene]
+        seqs += [seqs[i][::-1] for i in late.tolist()]
         to_id = v.node_of_hash
-        return Tree.from_codes(keys + late_keys, seqs + late_seqs, codes + late_codes,
-                               lambda x: -2 if x is None else to_id.get(x))
+        return Tree.from_flat(keys, seqs, flat, all_starts, lambda x: -2 if x is None else to_id.get(x))
 
     def _assign_reads_to_genes(self, listOfGenes, cores, allele_counts, mean_node_coverage):
         clustered_reads, path_reads = {}, {}

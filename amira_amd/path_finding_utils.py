@@ -67,6 +67,19 @@ class _ScanTree:
         self._code = code_of
         return self
 
+    @classmethod
+    def from_flat(cls, keys, seqs, flat, starts, code_of):
+        """as from_codes, with the codes already laid end to end (`flat`, `starts`) and `seqs` anything that
+        answers seqs[row] with the row's item list (it may build the list when asked)"""
+        import numpy as np
+        self = cls.__new__(cls)
+        self._np = np
+        self._keys, self._seqs = list(keys), seqs
+        self._starts = np.asarray(starts, dtype=np.int64)
+        self._flat = np.asarray(flat, dtype=np.int64)
+        self._code = code_of
+        return self
+
     def _codes_of(self, query):
         np = self._np
         if self._code is None:
