@@ -10,6 +10,8 @@ all-to-alls and two all-gathers in between are issued here.
 is driven either by torch.distributed (`dist_build`) or, in one process, by the loop-back
 driver `dist_build_loopback` that tests use to emulate W ranks on one GPU.
 """
+import os
+
 import torch
 
 
@@ -117,7 +119,7 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1, always_exc
                 except PeerFailed:
                     pass
             raise
-        if world == 1 and not always_exchange:  # nothing to exchange: the rank's own records are all there are
+        if world == 1 and not (always_exchange or os.environ.get("AMG_DIST_ALWAYS_EXCHANGE")):  # nothing to exchange
             n = sum(arg) if op == "a2a" else arg
             reply = (buf, n)
             continue
