@@ -55,6 +55,7 @@ def _load():
         "amg_set_positions": (C.c_int, [P, P, P, P, C.c_int]),
         "amg_set_read_lengths": (C.c_int, [P, P, C.c_int]),
         "amg_build": (C.c_int, [P, I32]),
+        "amg_build_filtered": (C.c_int, [P, C.c_int32, C.c_uint32, C.c_uint32]),
         "amg_counts": (C.c_int, [P, C.POINTER(Counts)]),
         "amg_finalize": (C.c_int, [P]),
         "amg_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),

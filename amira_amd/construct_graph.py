@@ -149,7 +149,9 @@ def _release_engine(engine):
 
 class GeneMerGraph(BubblePopping):
     # ------------------------------------------------------------------ build
-    def __init__(self, readDict, kmerSize, gene_positions=None, device=None):
+    def __init__(self, readDict, kmerSize, gene_positions=None, device=None, _filter=None):
+        """_filter = (minNodeCoverage, minEdgeCoverage): the graph comes out as GeneMerGraph(...).filter_graph(...)
+        would leave it, with the filter applied during the build (amg_build_filtered; graph_utils.build_filtered_graph)"""
         self._reads = readDict
         self._kmerSize = kmerSize
         self._minNodeCoverage = 1
@@ -193,7 +195,11 @@ class GeneMerGraph(BubblePopping):
             self._gs, self._ge = gs, ge
             self._engine.set_positions(gs, ge, None)
         try:
-            self._engine.build(kmerSize_dev)
+            if _filter is None:
+                self._engine.build(kmerSize_dev)
+            else:
+                self._minNodeCoverage, self._minEdgeCoverage = _filter
+                self._engine.build_filtered(kmerSize_dev, max(int(_filter[0]), 0), max(int(_filter[1]), 0))
         except _ffi.AmgError as err:
             if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
                 raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None

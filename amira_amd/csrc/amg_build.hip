@@ -881,7 +881,28 @@ void bs_size_tables(amg_ctx* c) {
   c->edge_slots = 1024;
 }
 
+static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov, bool* fused);
+
 extern "C" int amg_build(amg_ctx* c, int32_t k) {
+  bool fused = false;
+  return build_impl(c, k, 0, 0, &fused);
+}
+
+// GeneMerGraph.__init__ followed by filter_graph(min_node_cov, min_edge_cov) (graph_utils.py:147-149 — what every
+// cleaning iteration does with a freshly built graph).  On the exact-key path the filter is applied ON THE WAY:
+// nodes below the threshold never get an id, an array entry or an edge (an uncorrected graph is ~99 % such
+// nodes), their windows read None and their reads are queued for correction — the state a caller of
+// amg_build + amg_filter finds, except that ids number the survivors only (first-seen order among them).
+// Elsewhere (fingerprint keys, AMG_FUSED) it IS amg_build + amg_filter.
+extern "C" int amg_build_filtered(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov) {
+  bool fused = false;
+  const int r = build_impl(c, k, min_node_cov < 1 ? 1 : min_node_cov, min_edge_cov < 1 ? 1 : min_edge_cov, &fused);
+  if (r != AMG_OK || fused) return r;
+  return amg_filter(c, min_node_cov, min_edge_cov);
+}
+
+static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov, bool* fused) {
+  *fused = false;
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
   if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
@@ -915,6 +936,10 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
       r = bf_tables(c, k, &which);
       if (r == AMG_OK) r = bx_nodes_rank(c);
       if (r == AMG_OK) r = bf_finish(c);
+    } else if (exact && min_node_cov > 0 && !getenv("AMG_NO_FUSED_FILTER")) {
+      r = bx_nodes_filtered(c, k, min_node_cov, &which);
+      if (r == AMG_OK) r = bx_edges(c, &which, min_edge_cov);
+      *fused = true;
     } else if (exact) {
       r = bx_nodes(c, k, &which);
       if (r == AMG_OK) r = bx_edges(c, &which);
@@ -925,9 +950,12 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
       if (r == AMG_OK) r = bs_pairs_from_local(c);
     }
     if (r == AMG_OK) r = bs_finish_from_pairs(c);
+    if (r == AMG_OK && *fused) r = bx_flag_dead_reads(c);
     if (r == AMG_OK) {
       c->built = true;
-      c->node_hint = c->n_nodes > 256 ? c->n_nodes : 256;
+      // (a filtered build keeps only the survivors: the next table is sized by what the pass saw)
+      const int64_t seen = *fused ? c->n_local_nodes : c->n_nodes;
+      c->node_hint = seen > 256 ? seen : 256;
       return AMG_OK;
     }
     if (r != AMG_E_OVERFLOW || which == 0) return r;

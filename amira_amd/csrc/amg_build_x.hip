@@ -133,13 +133,13 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
     signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0) {
   typedef int i4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
   const int tid = threadIdx.x;
-  const long long t0 = (long long)blockIdx.x * TILE;
+  const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
   const int flip = two_v - 1;
   {
     bool bad = false;
@@ -244,6 +244,46 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
         tok_dir[t + w] = (signed char)(od >> (8 * w));
       }
   }
+}
+
+// ---- build with the coverage filter applied on the way (amg_build_filtered): claims below the threshold are
+// taken out of the claim space (first-seen words zeroed = "unclaimed", which every ranking kernel skips) before
+// anything is ranked, so only the survivors get ids, arrays, edges
+__global__ void k_x_drop_claims(const unsigned int* __restrict__ cnt, long long n, unsigned int min_cnt,
+                                unsigned int* __restrict__ first2, int* __restrict__ final_of_claim,
+                                unsigned long long* __restrict__ n_kept) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  if (c < n) {
+    keep = cnt[c] >= min_cnt && x_first_inv(first2, c) != 0u;
+    if (!keep) {
+      first2[2 * c] = 0u;
+      first2[2 * c + 1] = 0u;
+      if (final_of_claim) final_of_claim[c] = -2;  // windows of a dropped node read None (remove_node_from_reads)
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_kept, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_x_cov_from_claims(const unsigned int* __restrict__ cnt, const unsigned int* __restrict__ first2,
+                                    const int* __restrict__ final_of_claim, long long n,
+                                    unsigned int* __restrict__ node_cov) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n || x_first_inv(first2, c) == 0u) return;
+  node_cov[final_of_claim[c]] = cnt[c];
+}
+
+// reads that lost a window to the filter join _readsToCorrect (remove_node_from_reads :442-461)
+__global__ __launch_bounds__(256) void k_x_flag_dead_reads(const int* __restrict__ tok_node,
+                                                            const long long* __restrict__ read_off, long long n_reads,
+                                                            unsigned char* __restrict__ read_fix) {
+  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_reads) return;
+  const int lane = threadIdx.x & 63;
+  bool hit = false;
+  for (long long t = read_off[r] + lane; t < read_off[r + 1]; t += 64) hit = hit || (tok_node[t] == -2);
+  if (__any(hit) && lane == 0) read_fix[r] = 1;
 }
 
 // ---- ranking by first-seen without a sort.  A token
@@ -447,14 +487,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
     unsigned int probe_limit, unsigned long long* status, int* __restrict__ tok_pair, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0) {
   typedef int i4 __attribute__((ext_vector_type(4)));
   // word per window: node id | (direction -1) << 30 | last-of-read << 31, -1: no node
   constexpr unsigned int DIRBIT = 0x40000000u;
   __shared__ __attribute__((aligned(16))) int s_w[TILE + 4];
   __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
   const int tid = threadIdx.x;
-  const long long t0 = (long long)blockIdx.x * TILE;
+  const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
   const int i0 = 4 * tid;
   const long long t = t0 + i0;
   // node id of a window: -1 no node, -2 a node the merge's fused filter dropped (amg_dist.hip)
@@ -569,6 +609,19 @@ static inline unsigned int blocks_for(long long n, int per) {
 }
 
 static const unsigned int kProbeLimitX = 1024;
+
+// tiles of the head launch of a table pass (0: none).  Worth its extra launch only when many windows create a key
+// (expected keys > 1/16 of the windows): a few coverages of a genome of at most two_v / 2 genes, never more than
+// 1/16 of the tiles.
+static long long head_tiles(const amg_ctx* c, long long n_tiles, long long expected_keys) {
+  const char* e = getenv("AMG_X_HEAD_TILES");  // A/B switch
+  if (e) return atoll(e) < n_tiles ? atoll(e) : n_tiles;
+  if (expected_keys * 16 < c->n_tokens || n_tiles < 4096) return 0;
+  long long h = 4ll * c->two_v / TILE;
+  if (h < 64) h = 64;
+  if (h > n_tiles / 16) h = n_tiles / 16;
+  return h;
+}
 static const long long kRankBitmapMax = 16ll << 20;  // claims up to which the bitmap ranking is used (5.4 M: 0.38 vs 0.44 ms;
                                                     // 0.5 M: 0.09 vs 0.16 ms); the radix sort beyond (AMG_X_RANK_SORT=1 forces it)
 
@@ -669,12 +722,23 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
         else if (k == 5) kern = two ? k_nodes_v<true, 5, false> : k_nodes_v<false, 5, false>;
         else if (k == 7) kern = two ? k_nodes_v<true, 7, false> : k_nodes_v<false, 7, false>;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
-                         c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
-                         c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                         c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                         c->x_slot.as<unsigned int>(), (unsigned int)max_claims, xw2_for(max_claims, T));
+      // Claim ids follow the order in which the ~2000 concurrently running tiles create keys: with many creations
+      // per tile (a first build: one window in ten) the genome's keys, which almost every later window hits,
+      // get claims scattered over the first few hundred thousand, and whoever counts by claim (k_count_ids, one
+      // LDS range of 32 k ids per sweep) needs several sweeps.  A short head launch over the first few genome
+      // coverages creates them first: their claims are then the lowest.
+      const long long head = head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8);
+      for (int part = 0; part < 2; ++part) {
+        const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
+        if (cnt <= 0) continue;
+        hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                           c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
+                           c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
+                           c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
+                           c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
+                           c->x_slot.as<unsigned int>(), (unsigned int)max_claims, xw2_for(max_claims, T),
+                           (unsigned int)lo);
+      }
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
@@ -695,6 +759,38 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
   c->x_nspace = c->n_nodes;
   c->x_max_claims = (int64_t)max_claims;
+  return AMG_OK;
+}
+
+// node table pass, then only the nodes with coverage >= min_cov are kept: ids, arrays and coverages of the
+// survivors; x_final = -2 for the others
+int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
+  hipStream_t st = c->stream;
+  AMGCHK(bx_nodes_upsert(c, k, which));
+  const long long n = c->n_local_nodes, T = c->n_tokens;
+  stage_begin(c, "node_count");  // per claim, straight from the per-window claims (construct_node.py:33-36)
+  AMGCHK(c->x_ecnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->x_ecnt.as<unsigned int>(), 2));
+  stage_end(c);
+  stage_begin(c, "node_filter");
+  unsigned long long* kept = c->status.as<unsigned long long>() + ST_COMPACT_A;
+  HIPCHK(hipMemsetAsync(kept, 0, sizeof(unsigned long long), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), n,
+                       min_cov, c->x_first.as<unsigned int>(), c->x_final.as<int>(), kept);
+  unsigned long long D = 0;
+  {
+    FetchList l;
+    l.add(kept);
+    AMGCHK(fetch(c, l, &D));
+  }
+  stage_end(c);
+  c->n_nodes = (int64_t)D;
+  c->x_nspace = n;  // claim ids in use lie below n; the dropped ones are holes
+  AMGCHK(bx_nodes_rank(c));
+  if (n > 0 && D > 0)
+    hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(),
+                       c->x_first.as<unsigned int>(), c->x_final.as<int>(), n, c->node_cov.as<unsigned int>());
   return AMG_OK;
 }
 
@@ -736,9 +832,9 @@ int bx_nodes_rank(amg_ctx* c) {
 
 // adjacencies -> edge-class table, claims, pair arrays in first-seen order, coverages.
 // AMG_E_OVERFLOW + *which = 2: edge table full
-int bx_edges(amg_ctx* c, int* which) {
+int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov) {
   AMGCHK(bx_edges_upsert(c, which));
-  return bx_edges_rank(c);
+  return bx_edges_rank(c, min_edge_cov);
 }
 
 // the table pass alone: tok_node from x_final, edge-class claims 0 .. n_local_pairs-1
@@ -773,13 +869,19 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
                        c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
                        c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate,
                        xw2_for(max_claims, T));
-  else if (n_tiles > 0)
-    hipLaunchKernelGGL(k_edges_v, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
-                       c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
-                       c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
-                       c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), (unsigned int)max_claims,
-                       xw2_for(max_claims, T));
+  else if (n_tiles > 0) {
+    const long long head = head_tiles(c, n_tiles, D);  // (see bx_nodes_upsert: the genome's classes get the lowest claims)
+    for (int part = 0; part < 2; ++part) {
+      const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
+      if (cnt <= 0) continue;
+      hipLaunchKernelGGL(k_edges_v, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+                         c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
+                         c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
+                         c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
+                         c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), (unsigned int)max_claims,
+                         xw2_for(max_claims, T), (unsigned int)lo);
+    }
+  }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
@@ -794,19 +896,42 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   return AMG_OK;
 }
 
-// coverages, edge classes in first-seen order
-int bx_edges_rank(amg_ctx* c) {
+// coverages, edge classes in first-seen order.  min_edge_cov > 0: the build applies the coverage filter on the
+// way (bx_nodes_filtered has the node coverages already; classes below min_edge_cov are dropped before ranking)
+int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov) {
   const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
-  // node coverage (construct_node.py:33-36) from the per-window node ids
-  stage_begin(c, "node_count");
-  AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
-  stage_end(c);
+  if (min_edge_cov == 0) {
+    // node coverage (construct_node.py:33-36) from the per-window node ids
+    stage_begin(c, "node_count");
+    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
+    stage_end(c);
+  }
   // edge-class coverage per claim
   stage_begin(c, "edge_count");
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
   stage_end(c);
+  if (min_edge_cov > 1 && P > 0) {  // filter_graph's edge threshold (:531-535)
+    hipStream_t st = c->stream;
+    unsigned long long* kept = c->status.as<unsigned long long>() + ST_COMPACT_A;
+    HIPCHK(hipMemsetAsync(kept, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), P,
+                       min_edge_cov, c->x_efirst.as<unsigned int>(), (int*)nullptr, kept);
+    unsigned long long left = 0;
+    FetchList l;
+    l.add(kept);
+    AMGCHK(fetch(c, l, &left));
+    c->n_pairs = (int64_t)left;  // x_espace stays: the dropped classes are holes of the claim space
+  }
   return bx_pairs_rank(c, nullptr, nullptr);
+}
+
+// after bs_finish_from_pairs of a filtered build: the reads the filter touched
+int bx_flag_dead_reads(amg_ctx* c) {
+  if (c->n_reads > 0)
+    hipLaunchKernelGGL(k_x_flag_dead_reads, dim3(blocks_for(c->n_reads, 4)), dim3(256), 0, c->stream,
+                       c->tok_node.as<int>(), c->read_off.as<long long>(), c->n_reads, c->read_fix.as<unsigned char>());
+  return AMG_OK;
 }
 
 // edge classes in first-seen order (pair_key / pair_first / pair_cnt) from the claims' arrays;

@@ -312,9 +312,11 @@ bool bx_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
 int bx_nodes_upsert(amg_ctx* c, int k, int* which);
 int bx_nodes_rank(amg_ctx* c);
-int bx_edges(amg_ctx* c, int* which);
+int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov = 0);
+int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which);
+int bx_flag_dead_reads(amg_ctx* c);
 int bx_edges_upsert(amg_ctx* c, int* which);
-int bx_edges_rank(amg_ctx* c);
+int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov = 0);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind, const int* remap = nullptr);
 // counts of remap[claim] over per-window node claims (claim | AMG_LAST_FLAG, -1 none); the array is

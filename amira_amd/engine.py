@@ -57,6 +57,10 @@ class Engine:
     def build(self, k):
         check(_ffi.lib.amg_build(self._h, int(k)))
 
+    def build_filtered(self, k, min_node_cov, min_edge_cov):
+        """build + filter_graph(min_node_cov, min_edge_cov) with the filter applied on the way (amg.h)"""
+        check(_ffi.lib.amg_build_filtered(self._h, int(k), max(int(min_node_cov), 0), max(int(min_edge_cov), 0)))
+
     def finalize(self):
         """component ids + per-node edge lists of the built graph now (they are otherwise made on first use)"""
         check(_ffi.lib.amg_finalize(self._h))

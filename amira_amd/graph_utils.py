@@ -41,6 +41,14 @@ def _tokenized(reads, gene_positions):
     return reads_t, TokenizedPositions(reads_t.read_ids, offs, gs, ge)
 
 
+def build_filtered_graph(read_dict, kmer_size, gene_positions, min_node_coverage, min_edge_coverage=1):
+    """build_graph(...) followed by filter_graph(min_node_coverage, min_edge_coverage) — the opening of every
+    cleaning iteration (graph_utils.py:147-149) — in one device pass: an uncorrected graph is ~99 % nodes the filter
+    deletes at once, and they are never ranked, stored or joined by edges.  The graph a caller gets is the one the
+    two calls leave behind."""
+    return GeneMerGraph(read_dict, kmer_size, gene_positions, _filter=(min_node_coverage, min_edge_coverage))
+
+
 def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positions=None):
     """single-graph result (what cores=1 gives in the reference), built on the GPU."""
     reads = {r: annotatedReads[r] for r in annotatedReads}
@@ -52,8 +60,9 @@ def cleaning_sweep(reads, gene_positions, geneMer_size, fastq_content, node_min_
     """one cleaning iteration without the bubble-popping tail (graph_utils.py:145-166):
     build -> filter_graph(n, 1) -> correct_reads -> build -> remove_short_linear_paths(k)
     -> correct_reads -> build.  Returns (graph, reads, positions)."""
-    graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
-    graph.filter_graph(node_min_coverage, 1)
+    graph = build_filtered_graph({r: reads[r] for r in reads},
+                                 geneMer_size, None if gene_positions is None else {r: gene_positions[r] for r in gene_positions},
+                                 node_min_coverage, 1)
     reads, gene_positions = graph.correct_reads(fastq_content)
     graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
     graph.remove_short_linear_paths(geneMer_size)
@@ -66,14 +75,16 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
                              geneMer_size, cores, short_reads, short_read_gene_positions,
                              fastq_content, output_dir, node_min_coverage, sample_genesOfInterest,
                              min_path_coverage):
-    """same loop as the reference; the final step of every iteration
-    (correct_low_coverage_paths) raises NotImplementedError."""
+    """same loop as the reference (graph_utils.py:127-181), bubble popping included; the first build of an
+    iteration and the filter_graph that follows it run as one device pass (build_filtered_graph)."""
     prev_nodes = 0
     components_to_skip = set()
     for this_iteration in range(cleaning_iterations):
         sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
-        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
-        graph.filter_graph(node_min_coverage, 1)
+        graph = build_filtered_graph(
+            {r: new_annotatedReads[r] for r in new_annotatedReads}, geneMer_size,
+            None if new_gene_position_dict is None else {r: new_gene_position_dict[r] for r in new_gene_position_dict},
+            node_min_coverage, 1)
         new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
         graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
         if graph.get_total_number_of_nodes() == prev_nodes:

@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
+    ap.add_argument("--fused-filter", action="store_true",
+                    help="sweep: first build and filter_graph(3,1) as one device pass (amg_build_filtered), as the "
+                         "merged multi-GPU path always does; not the default so that `value` stays the sweep as the "
+                         "reference spells it")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the merged (multi-GPU) code path even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -298,6 +302,8 @@ def main():
             # first build of the sweep: filter_graph(3,1) is fused into the merge so that the
             # low-coverage nodes (90 % of an uncorrected graph) are never replicated
             dist_build(eng, k, None, *(fused_filter or (1, 1)))
+        elif fused_filter and args.fused_filter:
+            eng.build_filtered(k, *fused_filter)
         else:
             eng.build(k)
 
@@ -324,7 +330,7 @@ def main():
             stage_ms[name][1] += 1
 
     def sweep_after_first_build(record, readback=None):
-        if not merge:
+        if not (merge or args.fused_filter):
             eng.filter(3, 1)
             if record:
                 tally()
@@ -387,6 +393,25 @@ def main():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- the same sweep with its first two steps as one device pass (amg_build_filtered): reported beside `value`
+    fused_line = None
+    if w["sweep"] and world == 1 and not merge and not args.fused_filter:
+        args.fused_filter = True
+        for _ in range(max(args.warmup, 1)):
+            step(False)
+        eng.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        eng.sync()
+        df = (time.perf_counter() - t1) / args.steps
+        args.fused_filter = False
+        fused_line = {"value": n_windows / df, "unit": "gene-mers/s", "ms_per_step": df * 1e3, "steps": args.steps,
+                      "what": "the same step with build 1 and filter_graph(3,1) as ONE device pass (amg_build_filtered): "
+                              "nodes below the threshold are never ranked, stored or joined by edges; everything the "
+                              "rest of the sweep reads is identical (tests/test_gpu_filtered.py, full size in "
+                              "tests/test_gpu_fullsize.py); `value` above is the sweep as the reference spells it"}
 
     # ---- SURVEY 8(d)'s timed region: host CSR -> host graph arrays (N = 1)
     e2e = None
@@ -514,7 +539,9 @@ def main():
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": world * N * args.steps / dt,
-            "config": {"workload": w["desc"], "reads_per_gpu": N, "genes_per_read": L, "k": k,
+            "config": {"workload": w["desc"] + ("; first build and filter_graph(3,1) as one device pass (--fused-filter)"
+                                                 if (args.fused_filter and w["sweep"] and not merge) else ""),
+                       "reads_per_gpu": N, "genes_per_read": L, "k": k,
                        "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
                        "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
                        "multi_gpu": ("n/a" if not (world > 1 or merge) else
@@ -532,6 +559,8 @@ def main():
                                          "unit": "GB/s"}},
             "stages_ms_per_step": {n: round(v, 3) for n, v in stage_tot.items()},
         }
+        if fused_line is not None:
+            out["fused_first_filter"] = fused_line
         if e2e is not None:
             out["e2e"] = e2e
         out.update(cpu)

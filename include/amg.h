@@ -119,6 +119,13 @@ int amg_set_read_lengths(amg_ctx* ctx, const int64_t* read_len, int on_device);
  *      (construct_gene_mer.py:42-56), add_node (:196-212), add_node_to_read (:165-178),
  *      add_edge (:300-324), assign_component_ids (:920-927) --------------------------- */
 int amg_build(amg_ctx* ctx, int32_t k);
+/* amg_build followed by amg_filter(min_node_cov, min_edge_cov) — GeneMerGraph.__init__ + filter_graph
+ * (construct_graph.py:31-102, :523-540), the opening of every cleaning iteration (graph_utils.py:147-149) — with the
+ * filter applied on the way where the key layout allows it: nodes / edge classes below the thresholds are never
+ * ranked, stored or joined by edges.  Live nodes, live edges, coverages, list orders, masked windows and the reads
+ * queued for correction are those of the two separate calls; node / edge ids number what is present in first-seen
+ * order (with the two calls the filtered nodes keep their ids with alive = 0). */
+int amg_build_filtered(amg_ctx* ctx, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
 int amg_counts(amg_ctx* ctx, amg_counts_t* out);
 /* amg_build leaves component ids (assign_component_ids, construct_graph.py:920-927) and the per-node
  * forward / backward edge lists (construct_node.py:79-101) to the first call that needs them

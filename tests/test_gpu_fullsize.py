@@ -319,3 +319,31 @@ def test_cfg4_full_size_build_and_planted_alleles():
             assert 2000 < len(rows) < 4000                                    # ~3 000x depth per copy
             seen |= rows
     g.close()
+
+
+def test_full_size_filtered_build_equals_c_oracle():
+    """amg_build_filtered at the benchmark size: the first build of the cfg 3 sweep with filter_graph(3,1) applied on
+    the way must leave what the C oracle's build + filter leave (live nodes, edges, coverages, list orders, masked
+    windows, reads to correct) and the first correction must come out the same, genes and positions."""
+    from amira_amd import Engine
+    from helpers import compare_corrected, live_arrays
+    N = 1_000_000
+    w, vocab, toks, offs, gs, ge, rl = _cfg3_inputs(N)
+    k = w["k"]
+    eng = Engine(0)
+    orc = token_oracle.Sweep(toks, offs, vocab.two_v, gs, ge, rl)
+    try:
+        eng.set_reads(toks, offs, vocab.two_v)
+        eng.set_positions(gs, ge, rl)
+        eng.build_filtered(k, 3, 1)
+        orc.build(k)
+        orc.filter(3, 1)
+        got, want = live_arrays(eng), live_arrays(orc)
+        for key in want:
+            assert np.array_equal(got[key], want[key]), key
+        assert eng.counts()["n_nodes"] == len(want["coverage"])      # only the survivors exist
+        out = compare_corrected(eng, orc, True, "correct 1 after the filtered build")
+        assert int(out["changed"].sum()) > N // 2
+    finally:
+        eng.close()
+        orc.close()
