@@ -103,3 +103,27 @@ def test_sweep_with_filtered_first_build(case):
             if y[key] is not None:
                 assert np.array_equal(x[key], y[key]), key
     assert np.array_equal(ra, rb) and np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1], tb[1])
+
+
+@pytest.mark.parametrize("thr", [(10 ** 6, 1), (1, 10 ** 6), (0, 0)])
+def test_extreme_thresholds_and_empty_input(thr):
+    """everything dropped, every edge dropped, nothing dropped; and no reads at all"""
+    from amira_amd import Engine, tokenize
+    reads, _, _ = P.synth_inputs(3, 200, 20, 50, 0.05)
+    vocab, toks, offs, _ = tokenize(reads)
+    a, b = Engine(0), Engine(0)
+    try:
+        for e in (a, b):
+            e.set_reads(toks, offs, vocab.two_v)
+        a.build_filtered(5, *thr)
+        b.build(5)
+        b.filter(*thr)
+        _same_live(a, b, thr)
+        assert a.correct_reads() == b.correct_reads()
+        a.finalize()
+        a.set_reads(np.zeros(0, np.int32), np.zeros(1, np.int64), 2)
+        a.build_filtered(3, 3, 1)
+        assert a.counts()["n_nodes"] == 0
+    finally:
+        a.close()
+        b.close()
