@@ -483,6 +483,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
 }
 
 // ------------------------------------------------------------------ edges, four consecutive adjacencies per thread
+template <bool HEAD>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
@@ -727,7 +728,8 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
       // get claims scattered over the first few hundred thousand, and whoever counts by claim (k_count_ids, one
       // LDS range of 32 k ids per sweep) needs several sweeps.  A short head launch over the first few genome
       // coverages creates them first: their claims are then the lowest.
-      const long long head = head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8);
+      // (only the filtered build counts by node claim; the plain build counts by ranked node id)
+      const long long head = c->filtered_build ? head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8) : 0;
       for (int part = 0; part < 2; ++part) {
         const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
         if (cnt <= 0) continue;
@@ -766,7 +768,10 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
 // survivors; x_final = -2 for the others
 int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   hipStream_t st = c->stream;
-  AMGCHK(bx_nodes_upsert(c, k, which));
+  c->filtered_build = true;
+  const int r0 = bx_nodes_upsert(c, k, which);
+  c->filtered_build = false;
+  AMGCHK(r0);
   const long long n = c->n_local_nodes, T = c->n_tokens;
   stage_begin(c, "node_count");  // per claim, straight from the per-window claims (construct_node.py:33-36)
   AMGCHK(c->x_ecnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
@@ -861,7 +866,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   stage_end(c);
   const char* abl = getenv("AMG_X_ABLATE");
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
-  stage_begin(c, "edge_upsert");
+  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles, D) > 0) ? "edge_upsert_head" : "edge_upsert");
   if (n_tiles > 0 && getenv("AMG_X_OLD_PASS"))  // A/B switch: one adjacency per lane, strided (the round-1 kernel)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
@@ -874,7 +879,11 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     for (int part = 0; part < 2; ++part) {
       const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
       if (cnt <= 0) continue;
-      hipLaunchKernelGGL(k_edges_v, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+      if (part == 1 && head > 0) {  // the head launch is a stage of its own
+        stage_end(c);
+        stage_begin(c, "edge_upsert");
+      }
+      hipLaunchKernelGGL(part == 0 ? k_edges_v<true> : k_edges_v<false>, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                          c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                          c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                          c->status.as<unsigned long long>(), c->tok_pair.as<int>(),

@@ -160,6 +160,7 @@ struct amg_ctx {
   int64_t n_nodes = 0, n_pairs = 0, n_edges = 0, n_components = 0;
   int64_t node_slots = 0, edge_slots = 0, retries = 0;
   int64_t node_hint = 0;  // distinct-node estimate carried between builds
+  bool filtered_build = false;  // bx_nodes_upsert is running for amg_build_filtered (head launch: see there)
   int64_t n_local_nodes = 0, n_local_pairs = 0;  // before a multi-GPU merge
   int64_t tok_base = 0;   // global index of this shard's first token (0 on a single GPU)
   int64_t tok_total = 0;  // tokens over all shards

@@ -505,7 +505,8 @@ def main():
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
-                                                        "node_upsert", "node_rank", "edge_table_clear", "edge_upsert",
+                                                        "node_upsert", "node_rank", "node_filter", "edge_table_clear", "edge_upsert_head",
+                                                        "edge_upsert",
                                                         "edge_rank", "node_count", "edge_count", "edge_emit",
                                                         "components", "adjacency"))
         n_builds = max(stage_ms.get("graph_upsert", stage_ms.get("node_upsert", [0, 1]))[1], 1)
