@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-fused-line", action="store_true", help="skip the extra `fused_first_filter` measurement")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
     ap.add_argument("--fused-filter", action="store_true",
                     help="sweep: first build and filter_graph(3,1) as one device pass (amg_build_filtered), as the "
@@ -396,7 +397,7 @@ def main():
 
     # ---- the same sweep with its first two steps as one device pass (amg_build_filtered): reported beside `value`
     fused_line = None
-    if w["sweep"] and world == 1 and not merge and not args.fused_filter:
+    if w["sweep"] and world == 1 and not merge and not args.fused_filter and not args.no_fused_line:
         args.fused_filter = True
         for _ in range(max(args.warmup, 1)):
             step(False)

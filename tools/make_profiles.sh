@@ -6,11 +6,12 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# the profiled command is the default bench command without its host-side legs (CPU baseline, PCIe round trip)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o out -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/${tag}_sweep_bench.log 2>&1
+# the profiled command is the default bench command without its extra legs (CPU baseline, PCIe round trip, the
+# fused-filter variant): only the timed sweep itself is under the profiler
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o out -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-fused-line > $O/${tag}_sweep_bench.log 2>&1
 cp $(find $O/ks -name "*kernel_stats.csv" | head -1) $O/${tag}_sweep_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c -d $O/pmc_$c -o out -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $O/pmc_$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c -d $O/pmc_$c -o out -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-fused-line > $O/pmc_$c.log 2>&1
 done
 cd $R
 python3 tools/pmc_fetch_write.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/${tag}_sweep_pmc_summary.json
