@@ -267,6 +267,22 @@ def p_bubbles_synth(impl, name, k, min_cov):
     return _bubble_entry(g, fq, set())
 
 
+def p_bubbles_random(impl, seed, N, L, V, k, err, min_cov=3):
+    """bubble popping (correct_low_coverage_paths with its MinHash containment test) on random reads with compact
+    gene positions (60-base genes every 80 bases: nucleotide reads of a few kilobases, so that the pure-Python
+    sketch of the oracle stays fast) after filter + correction, as the cleaning loop runs it — for the
+    differential fuzzer (tools/fuzz_api.py), not a golden case"""
+    ids, sts = synth.loop_reads(seed, N, L, V, err, 0)
+    calls = synth.to_read_dict(ids, sts, synth.gene_names(V, 0))
+    pos = {r: [(80 * i, 80 * i + 59) for i in range(len(g))] for r, g in calls.items()}
+    fq = synth_fastq(calls, pos, flank=40)
+    g = impl.GeneMerGraph(calls, k, pos)
+    g.filter_graph(min_cov, 1)
+    calls, pos = g.correct_reads(fq)
+    g = impl.GeneMerGraph(calls, k, pos)
+    return _bubble_entry(g, fq, set())
+
+
 def p_iterative(impl, which):
     """the whole cleaning driver iterative_bubble_popping (graph_utils.py:127-181)"""
     if which == "real":

@@ -33,7 +33,16 @@ def run(budget, seed, max_cases=None):
     n_ok = n_fail = 0
     while time.time() < t_end and (max_cases is None or n_ok + n_fail < max_cases):
         k = int(rng.choice([3, 5, 7]))
-        if rng.random() < 0.7:
+        u = rng.random()
+        only = os.environ.get("FUZZ_ONLY")   # e.g. FUZZ_ONLY=bubbles
+        if only == "bubbles":
+            u = 0.0
+        if u < 0.15:   # bubble popping, device MinHash against the oracle's pure-Python sketch
+            k = int(rng.choice([3, 5]))
+            args = (int(rng.integers(1, 1 << 30)), int(rng.integers(80, 220)), int(rng.integers(k + 8, 36)),
+                    int(rng.choice([40, 120, 400])), k, float(rng.choice([0.02, 0.05, 0.08])))
+            proc = P.p_bubbles_random
+        elif u < 0.75:
             args = (int(rng.integers(1, 1 << 30)), int(rng.integers(100, 500)), int(rng.integers(k + 6, 45)),
                     int(rng.choice([40, 120, 400, 1500])), k, float(rng.choice([0.0, 0.02, 0.05])))
             proc = P.p_sweep
