@@ -29,3 +29,19 @@ def test_random_merged_builds_equal_unsharded():
     spec.loader.exec_module(fd)
     n_ok, n_skip, n_fail = fd.run(budget=120.0, seed=4711, max_cases=150)
     assert n_fail == 0 and n_ok > 100
+
+
+def test_random_bubble_popping_equals_oracle():
+    """tools/fuzz_api.py restricted to bubble popping (f1): correct_low_coverage_paths on random reads, the device
+    MinHash against the oracle's pure-Python sketch.  In a child interpreter with PYTHONHASHSEED=0 (the reference's
+    set-order dependence)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONHASHSEED="0", FUZZ_ONLY="bubbles")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "45", "424242"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    last = [l for l in out.stdout.splitlines() if l.startswith("fuzz_api:")]
+    assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
+    n_ok = int(last[-1].split()[1])
+    assert n_ok >= 5 and " 0 failures" in last[-1]
