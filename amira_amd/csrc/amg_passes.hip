@@ -1490,12 +1490,43 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
     const int m = __popcll(mm);
     diagonal = m <= 1;
     const int x_next = __shfl_down(x0, 1, 64), y_next = __shfl_down(yj, 1, 64);  // every lane shuffles
+    const unsigned long long eq_a = __ballot(lane < N - 1 && x0 == y_next);  // x[i] == y[i+1]
+    const unsigned long long eq_b = __ballot(lane < N - 1 && x_next == yj);  // x[i+1] == y[i]
     if (m == 2) {
       const int b = 63 - __clzll((long long)mm);               // the later mismatch, b >= 1
       const unsigned long long upto_b = (1ull << b) - 1ull;    // places 0 .. b-1
-      const unsigned long long eq_a = __ballot(lane < N - 1 && x0 == y_next);  // x[i] == y[i+1]
-      const unsigned long long eq_b = __ballot(lane < N - 1 && x_next == yj);  // x[i+1] == y[i]
       diagonal = (eq_a & upto_b) != upto_b && (eq_b & upto_b) != upto_b;
+    } else if (m == 3 || m == 4) {
+      // Three or four mismatches: the diagonal scores N - m >= N - 4, any alignment with two or more gaps per
+      // list at most N - 5, so only the alignments with ONE gap in each list can reach it.  Such an alignment
+      // runs on the diagonal up to its first gap at u, one place off it (x[i] against y[i+1], or the mirror
+      // image) up to its second gap at l, and on the diagonal again; it scores its matches - 2, + 1 when the
+      // first gap is a leading one (u = 0: the first gap of a leading run is free).  With the match indicators
+      // as bit masks (D diagonal, S shifted) its matches are prefD(u) - prefS(u) + prefS(l) + sufD(l): the best
+      // over u <= l is a prefix maximum over the lanes.  If even the best such alignment stays BELOW N - m the
+      // diagonal is the unique optimum (a tie would not do: the traceback prefers gaps).  Checked exhaustively
+      // against the reference's alignment in tests/test_nw_shortcut_cpu.py.
+      const unsigned long long dmask = ~mm & (N == 64 ? ~0ull : ((1ull << N) - 1ull));
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int prefD = __popcll(dmask & below);
+      const int sufD = lane >= 63 ? 0 : __popcll(dmask >> (lane + 1));
+      const int ID = (int)0x80000000 / 2;
+      int best = ID;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int prefS = __popcll((side == 0 ? eq_a : eq_b) & below);
+        int g = lane < N ? prefD - prefS + (lane == 0 ? 1 : 0) : ID;
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x111, 0xf, 0xf, false));  // row_shr:1
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x112, 0xf, 0xf, false));  // row_shr:2
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x114, 0xf, 0xf, false));  // row_shr:4
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x118, 0xf, 0xf, false));  // row_shr:8
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x142, 0xa, 0xf, false));  // row_bcast:15
+        g = max(g, __builtin_amdgcn_update_dpp(ID, g, 0x143, 0xc, 0xf, false));  // row_bcast:31
+        int h = lane < N ? g + prefS + sufD - 2 : ID;
+        for (int d = 32; d > 0; d >>= 1) h = max(h, __shfl_xor(h, d, 64));
+        best = max(best, h);
+      }
+      diagonal = best < N - m;
     }
     if (diagonal && lane < N) {
       const bool match = ((mm >> lane) & 1ull) == 0ull;

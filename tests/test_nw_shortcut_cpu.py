@@ -17,14 +17,27 @@ def shortcut_says_diagonal(x, y):
     if n != len(y):
         return False
     mism = [i for i in range(n) if x[i] != y[i]]
-    if len(mism) <= 1:
+    m = len(mism)
+    if m <= 1:
         return True
-    if len(mism) > 2:
+    if m == 2:
+        b = mism[1]
+        tie_a = all(x[i] == y[i + 1] for i in range(b))
+        tie_b = all(x[i + 1] == y[i] for i in range(b))
+        return not tie_a and not tie_b
+    if m > 4:
         return False
-    b = mism[1]
-    tie_a = all(x[i] == y[i + 1] for i in range(b))
-    tie_b = all(x[i + 1] == y[i] for i in range(b))
-    return not tie_a and not tie_b
+    # m = 3, 4: only the alignments with one gap in each list can reach N - m; the best of them must stay below
+    D = [1 if x[i] == y[i] else 0 for i in range(n)]
+    best = -10 ** 9
+    for S in ([1 if i + 1 < n and x[i] == y[i + 1] else 0 for i in range(n)],
+              [1 if i + 1 < n and x[i + 1] == y[i] else 0 for i in range(n)]):
+        g = -10 ** 9
+        for l in range(n):
+            pref_d, pref_s, suf_d = sum(D[:l]), sum(S[:l]), sum(D[l + 1:])
+            g = max(g, pref_d - pref_s + (1 if l == 0 else 0))
+            best = max(best, g + pref_s + suf_d - 2)
+    return best < n - m
 
 
 def reference_is_diagonal(nw, x, y):
@@ -35,8 +48,10 @@ def test_shortcut_never_contradicts_the_reference_alignment():
     from amira_oracle.graph import GeneMerGraph
     nw = GeneMerGraph.needleman_wunsch
     claimed = 0
-    for n in range(1, 7):
+    for n in range(1, 8):
         for alpha in (2, 3):
+            if n == 7 and alpha == 3:
+                continue
             for x in itertools.product(range(alpha), repeat=n):
                 for y in itertools.product(range(alpha), repeat=n):
                     if shortcut_says_diagonal(x, y):
@@ -52,7 +67,7 @@ def test_shortcut_never_contradicts_the_reference_alignment():
         x = list(y)
         if rng.random() < 0.5:   # shift a stretch by one
             x = x[1:] + [rng.randint(0, 3)]
-        for _ in range(rng.randint(0, 2)):
+        for _ in range(rng.randint(0, 4)):
             x[rng.randrange(n)] = rng.randint(0, 4)
         if shortcut_says_diagonal(x, y):
             claimed += 1
