@@ -255,11 +255,19 @@ def _rccl_worker(rank, world, port, out_dir):
     """one rank of a REAL multi-process merged build over RCCL (needs >= world GPUs on the node)"""
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
     import numpy as np
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:   # an environment in which two ranks cannot even meet is not a failure of the merge (exit code 77 = skip)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)
+        assert float(probe.item()) == world
+    except Exception as exc:  # noqa: BLE001
+        print("RCCL set-up failed:", exc, flush=True)
+        sys.exit(77)
     from amira_amd import Engine, tokenize
     from amira_amd.dist import dist_build
     reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
@@ -293,7 +301,9 @@ def test_dist_build_over_rccl_two_processes(tmp_path):
         p.start()
     for p in procs:
         p.join(timeout=300)
-        assert p.exitcode == 0
+    if any(p.exitcode == 77 for p in procs):
+        pytest.skip("the two ranks could not set RCCL up on this machine")
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
     vocab, toks, offs, _ = tokenize(reads)
     ref = Engine(0)
