@@ -301,6 +301,10 @@ def test_dist_build_over_rccl_two_processes(tmp_path):
         p.start()
     for p in procs:
         p.join(timeout=300)
+    for p in procs:   # a rank left waiting for one that gave up
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=30)
     if any(p.exitcode == 77 for p in procs):
         pytest.skip("the two ranks could not set RCCL up on this machine")
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
