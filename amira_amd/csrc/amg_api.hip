@@ -91,7 +91,7 @@ __global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long lon
 }
 
 int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out) {
-  static const bool plain = getenv("AMG_PLAIN_SYNC") != nullptr;  // A/B switch: hipMemcpyAsync + hipStreamSynchronize
+  const bool plain = getenv("AMG_PLAIN_SYNC") != nullptr;  // A/B switch: hipMemcpyAsync + hipStreamSynchronize
   if (plain) {
     for (int i = 0; i < l.n; ++i)
       HIPCHK(hipMemcpyAsync(out + i, l.p[i], sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
