@@ -416,6 +416,13 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   // one block per CU (the counters fill the LDS): four loads in flight per thread make up for
   // the low occupancy
   long long t = (long long)blockIdx.x * 1024 + threadIdx.x;
+  for (; t + 7 * stride < n; t += 8 * stride) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = GATHER ? ids[t + j * stride] : __builtin_nontemporal_load(ids + t + j * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tally(v[j], t + j * stride);
+  }
   for (; t + 3 * stride < n; t += 4 * stride) {
     const int i0 = ids[t], i1 = ids[t + stride], i2 = ids[t + 2 * stride], i3 = ids[t + 3 * stride];
     tally(i0, t);
