@@ -230,10 +230,13 @@ def get_blocks_from_subtree(sub_tree, a2, nodeAnchors):
 
 def get_all_context_options(nodes_on_reads, start, end):
     up, down = tuple(nodes_on_reads[:start]), tuple(nodes_on_reads[end + 1:])
-    # (slices of a tuple are tuples; same elements inserted in the same order as the reference's
-    # {tuple(up[-i:]) ...} | {()}, so the sets iterate alike)
-    up_options = {up[-i:] for i in range(1, len(up) + 1)} | {()}
-    down_options = {down[:i] for i in range(1, len(down) + 1)} | {()}
+    # (slices of a tuple are tuples; the elements go in one by one in the reference's order — suffixes by growing
+    # length, then the empty tuple — so that the sets iterate as the reference's do: a union with {()} would
+    # rebuild the table)
+    up_options = {up[-i:] for i in range(1, len(up) + 1)}
+    up_options.add(())
+    down_options = {down[:i] for i in range(1, len(down) + 1)}
+    down_options.add(())
     return up_options, down_options
 
 
@@ -262,14 +265,17 @@ def get_full_path_contexts(positions_of_path, contexts, reads, read_id, block_re
 
 
 def generate_contexts(block_reads, block_duplicates, reads):
-    """contexts of every block (path_finding_utils.py:150-201), with the same final state as the
-    reference's read-by-read loop at a fraction of its work:
+    """contexts of every block (path_finding_utils.py:150-215), the reference's read-by-read loop with two
+    savings that leave every set operation it performs on the surviving entries exactly as it is:
       * a read whose block is in the NON-canonical orientation replaces the block's entry by sets made from
         that read alone, so whatever earlier reads contributed is gone — only the LAST such read of a block
         and the canonical reads after it are looked at;
-      * the context sets are suffix- / prefix-closed (every update adds all suffixes of an upstream list,
-        all prefixes of a downstream list), so a list that is already in the set brings nothing new and
-        its O(L^2) options are not generated (adding present elements does not touch a set)."""
+      * the O(L^2) option sets of a read depend on its upstream / downstream node lists only, and the reads
+        through one block share a few dozen of those: the sets are made once per distinct list and handed to
+        `set.update` again (same contents, same size, same iteration order as a freshly made one — `update`
+        resizes by the size of its argument even when every element is present already, so the calls
+        themselves cannot be skipped without changing how the context sets iterate, which decides ties in the
+        clustering that follows)."""
     contexts = {}
     todo = {}  # key -> [(read_id, where, is_canonical), ...] in read order
     for read_id, block in block_reads.items():
@@ -282,23 +288,30 @@ def generate_contexts(block_reads, block_duplicates, reads):
         if len(where) == 1:
             contexts.setdefault(key, {"upstream": set(), "downstream": set()})   # dict order = first read
             todo.setdefault(key, []).append((read_id, where, canonical == block))
+    up_cache, down_cache = {}, {}
     for key, entries in todo.items():
         first = 0
         for i, (_, _, is_canonical) in enumerate(entries):
             if not is_canonical:
                 first = i
         for read_id, where, is_canonical in entries[first:]:
-            if not is_canonical:
-                get_full_path_contexts(where, contexts, reads, read_id, block_reads)
-                continue
             start, end = where[0]
             on_read = reads[read_id]
-            ups, downs = contexts[key]["upstream"], contexts[key]["downstream"]
             up, down = tuple(on_read[:start]), tuple(on_read[end + 1:])
-            if up not in ups or () not in ups:
-                ups.update({up[-i:] for i in range(1, len(up) + 1)} | {()})
-            if down not in downs or () not in downs:
-                downs.update({down[:i] for i in range(1, len(down) + 1)} | {()})
+            up_options = up_cache.get(up)
+            if up_options is None:
+                up_options = up_cache[up] = {up[-i:] for i in range(1, len(up) + 1)}
+                up_options.add(())
+            down_options = down_cache.get(down)
+            if down_options is None:
+                down_options = down_cache[down] = {down[:i] for i in range(1, len(down) + 1)}
+                down_options.add(())
+            if is_canonical:
+                contexts[key]["upstream"].update(up_options)
+                contexts[key]["downstream"].update(down_options)
+            else:  # the reference REPLACES the entry here
+                contexts[key] = {"upstream": {tuple(reversed(d)) for d in down_options},
+                                 "downstream": {tuple(reversed(u)) for u in up_options}}
     return contexts
 
 
