@@ -69,3 +69,59 @@ def test_generate_contexts_equals_the_read_by_read_loop():
         assert dup_b == dup_a
         n += 1
     assert n > 2000
+
+
+def _reads_case(rng):
+    """node lists of reads over a small 'genome' with a second locus sharing a stretch, some reversed"""
+    alphabet = rng.choice([12, 40])
+    genome = list(range(100, 100 + rng.randint(14, 40)))
+    if rng.random() < 0.6:   # a second locus sharing a stretch (copies of a gene in different contexts)
+        a = rng.randrange(2, len(genome) - 6)
+        other = [200 + i for i in range(rng.randint(3, 8))] + genome[a:a + rng.randint(2, 5)] + [300 + i for i in range(rng.randint(3, 8))]
+    else:
+        other = []
+    reads = {}
+    for i in range(rng.randint(4, 40)):
+        src = other if (other and rng.random() < 0.4) else genome
+        lo = rng.randrange(0, max(len(src) - 3, 1))
+        hi = rng.randint(lo + 1, len(src) - 1) if lo + 1 < len(src) else lo
+        nodes = src[lo:hi + 1]
+        if rng.random() < 0.5:
+            nodes = nodes[::-1]
+        reads[f"r{i:03d}"] = list(nodes)   # (no masked nodes: the reference's int() parse of a suffix would raise)
+    pool = sorted({n for v in reads.values() for n in v if n is not None})
+    anchors = set(rng.sample(pool, min(len(pool), rng.randint(2, 5))))
+    return reads, anchors
+
+
+def test_anchor_blocks_equal_the_reference_procedure():
+    """get_full_paths' first stage (suffix tree -> sub-tree per anchor -> process_anchors) in the product — through
+    the scan tree's generic calls and through its one-step `reversed_suffix_tree` — against the oracle's restatement:
+    the same full blocks in the same order with the same supporting reads"""
+    from amira_oracle import paths as ref
+    prod = _product_module()
+    rng = random.Random(424242)
+    compared = 0
+    for _ in range(1500):
+        reads, anchors = _reads_case(rng)
+        anchors_list = sorted(anchors)
+        want = {}
+        tree_r = ref.construct_suffix_tree({r: list(v) for r, v in reads.items()})
+        for a1 in anchors_list:
+            suf = ref.get_suffixes_from_initial_tree(tree_r, a1)
+            sub = ref.Tree({r: list(reversed(s)) for r, s in suf.items()})
+            ref.process_anchors(sub, anchors, a1, want, reads, tree_r, 1)
+        for fast in (False, True):
+            got = {}
+            tree_p = prod.construct_suffix_tree({r: list(v) for r, v in reads.items()})
+            for a1 in anchors_list:
+                if fast:
+                    sub = tree_p.reversed_suffix_tree(a1)
+                else:
+                    suf = prod.get_suffixes_from_initial_tree(tree_p, a1)
+                    sub = prod.Tree({r: list(reversed(s)) for r, s in suf.items()})
+                prod.process_anchors(sub, anchors, a1, got, reads, tree_p, 1)
+            assert list(got) == list(want), fast
+            assert got == want, fast
+        compared += len(want)
+    assert compared > 500
