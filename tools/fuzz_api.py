@@ -37,6 +37,8 @@ def run(budget, seed, max_cases=None):
         only = os.environ.get("FUZZ_ONLY")   # e.g. FUZZ_ONLY=bubbles
         if only == "bubbles":
             u = 0.0
+        elif only == "planted":   # read-path clustering (assign_reads_to_genes) on planted multi-copy genes
+            u = 0.99
         if u < 0.15:   # bubble popping, device MinHash against the oracle's pure-Python sketch
             k = int(rng.choice([3, 5]))
             args = (int(rng.integers(1, 1 << 30)), int(rng.integers(80, 220)), int(rng.integers(k + 8, 36)),
