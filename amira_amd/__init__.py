@@ -15,7 +15,8 @@ from .construct_graph import GeneMerGraph  # noqa: F401
 from .construct_node import Node  # noqa: F401
 from .construct_read import Read  # noqa: F401
 from .engine import Engine  # noqa: F401
-from .graph_utils import build_graph, build_multiprocessed_graph, cleaning_sweep  # noqa: F401
+from .graph_utils import (build_filtered_graph, build_graph, build_multiprocessed_graph,  # noqa: F401
+                          cleaning_sweep, iterative_bubble_popping)
 from .tokens import Vocabulary, tokenize  # noqa: F401
 
 __version__ = "0.1.0"

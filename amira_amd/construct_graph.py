@@ -4,6 +4,7 @@ Same constructor, accessors and passes as the reference class; the work is done 
 libamg.so (HIP, gfx950) through amira_amd.engine:
 
     __init__                          amg_set_reads / amg_set_positions / amg_build
+    __init__(..., _filter=(n, m))     amg_build_filtered (= __init__ + filter_graph in one device pass)
     filter_graph                      amg_filter
     remove_node & friends             amg_remove_nodes
     remove_short_linear_paths         amg_remove_short_linear_paths
