@@ -80,3 +80,38 @@ def test_token_order_equals_signed_hash_order():
         assert (1 if toks < rc else -1) == gm.get_geneMerDirection()
         canon = toks if toks < rc else rc
         assert [v.gene(t) for t in canon] == [x.as_string() for x in gm.get_canonical_geneMer()]
+
+
+# methods / functions of the reference that the pipeline never reaches (last list; the
+# multi-process merge the pipeline never uses; plots): everything else must exist under the same name
+UNREACHED = {
+    "GeneMerGraph": {"create_adjacency_matrix", "find_paths", "all_paths_for_subgraph", "get_anchors_of_interest",
+                     "extract_elements", "find_paths_between_nodes", "insert_valid_paths", "get_gene_to_node_mapping",
+                     "get_new_genes_from_alignment", "all_sublist_combinations",
+                     "mp_get_all_paths_between_junctions_in_component", "find_potential_paths", "reverse_complement",
+                     "merge_dict", "new_get_minhashes_for_paths", "find", "union", "cluster_paths", "assess_connectivity",
+                     "merge_read_clusters", "new_merge_clusters", "make_intersection_matrix",
+                     "get_node_with_highest_subthreshold_connections", "filter_nodes_by_intersection", "trim_fringe_nodes"},
+    "graph_utils": {"merge_nodes", "merge_edges", "merge_reads", "merge_graphs", "plot_node_coverages"},
+    "path_finding_utils": {"orient_nodes_on_read", "get_start_stop_indices", "get_unique_anchor_suffixes",
+                           "filter_anchor_suffixes"},
+}
+
+
+def test_python_api_surface_covers_the_reference():
+    """every method of the reference's GeneMerGraph / Node / Edge / Gene / GeneMer / Read and every function of its
+    graph_utils / path_finding_utils (names indexed in tests/golden/api_surface.json by gen_api_surface.py) exists in
+    the product under the same name, except the ones the pipeline never reaches"""
+    import json
+    import os
+    import amira_amd
+    import amira_amd.graph_utils as gu
+    import amira_amd.path_finding_utils as pf
+    surface = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_surface.json")))
+    for cls, names in surface["classes"].items():
+        have = set(dir(getattr(amira_amd, cls)))
+        missing = [n for n in names if n not in have and n not in UNREACHED.get(cls, set())]
+        assert not missing, (cls, missing)
+    for mod, obj in (("graph_utils", gu), ("path_finding_utils", pf)):
+        missing = [n for n in surface["functions"][mod] if not hasattr(obj, n) and n not in UNREACHED[mod]]
+        assert not missing, (mod, missing)
