@@ -155,7 +155,8 @@ def cpu_baseline(w, frac=0.01):
     subsample of the SAME stream, the whole step (sweep workloads: the whole sweep)."""
     # sized to ~25 s of CPU work from a 250-read pilot, at most the 1 % subsample of SURVEY 8(d)
     pilot_done, pilot_s = _cpu_sweep_or_build(w, w["N"] - 250, 250)
-    per_read = pilot_s / 250 * (6.0 if w["sweep"] else 1.0)   # a deeper sample re-threads more reads per read
+    # (a deeper sample re-threads more reads per read: measured 1.8x from the 250-read pilot to a 0.1 % sample)
+    per_read = pilot_s / 250 * (2.2 if w["sweep"] else 1.0)
     n = max(min(int(w["N"] * frac), int(25.0 / max(per_read, 1e-6))), 250)
     done, spent = _cpu_sweep_or_build(w, 0, n)
     what = "full sweep" if w["sweep"] else "build"
