@@ -428,6 +428,11 @@ CASES["drivers_nine"] = (p_drivers, ("nine",), False)
 CASES["cluster_eight_k3"] = (p_cluster_fixture, ("eight", 3, ["dfrA17"]), False)
 CASES["planted_s20250909"] = (p_planted, (20250909, 1500, 40, 1000, 5), True)
 CASES["planted_small"] = (p_planted, (5, 300, 40, 1000, 5), False)
+CASES["planted_k3"] = (p_planted, (31, 500, 30, 600, 3), False)
+CASES["planted_k7"] = (p_planted, (77, 400, 45, 800, 7), False)
+CASES["planted_dense_k5"] = (p_planted, (123, 900, 40, 500, 5), True)
+CASES["bubbles_random_k3"] = (p_bubbles_random, (4242, 150, 25, 120, 3, 0.05), False)
+CASES["bubbles_random_k5"] = (p_bubbles_random, (99, 200, 30, 120, 5, 0.05), False)
 CASES["cluster_five_k3"] = (p_cluster_fixture, ("five", 3, ["blaCTXM110NG_0489052"]), False)
 CASES["cluster_six_k3"] = (p_cluster_fixture, ("six", 3, ["blaTEM239NG_0766451"]), False)
 CASES["cluster_seven_k3"] = (p_cluster_fixture, ("seven", 3, ["blaIMI9NG_0491711"]), False)

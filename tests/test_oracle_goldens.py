@@ -24,7 +24,7 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens
 
 # the two largest cases take ~1 min each in pure Python; they run in the default CPU
 # suite only when AMG_SLOW=1 (they were green when the goldens were generated)
-HEAVY = {"fixture_one_k3", "sweep_s20250908", "bubbles_synth_nine_k3"}
+HEAVY = {"fixture_one_k3", "sweep_s20250908", "bubbles_synth_nine_k3", "planted_dense_k5"}
 
 
 def _cases():
