@@ -421,6 +421,9 @@ CASES["sweep_small_k5"] = (p_sweep, (7, 400, 30, 300, 5, 0.03), False)
 CASES["sweep_small_k3"] = (p_sweep, (11, 400, 24, 200, 3, 0.03), False)
 CASES["sweep_small_k7"] = (p_sweep, (13, 300, 40, 250, 7, 0.02), False)
 CASES["sweep_dense_k5"] = (p_sweep, (17, 800, 40, 150, 5, 0.05), False)
+CASES["sweep_r2_k5_err6"] = (p_sweep, (23, 600, 35, 120, 5, 0.06), False)
+CASES["sweep_r2_k3_err4"] = (p_sweep, (29, 500, 28, 400, 3, 0.04), False)
+CASES["sweep_r2_k7_err3"] = (p_sweep, (41, 350, 50, 90, 7, 0.03), False)
 CASES["misc_nine_k3"] = (p_misc_passes, ("nine", 3), False)
 CASES["misc_four_k5"] = (p_misc_passes, ("four", 5), False)
 CASES["drivers_eight"] = (p_drivers, ("eight",), False)
