@@ -426,6 +426,12 @@ CASES["sweep_r2_k3_err4"] = (p_sweep, (29, 500, 28, 400, 3, 0.04), False)
 CASES["sweep_r2_k7_err3"] = (p_sweep, (41, 350, 50, 90, 7, 0.03), False)
 CASES["misc_nine_k3"] = (p_misc_passes, ("nine", 3), False)
 CASES["misc_four_k5"] = (p_misc_passes, ("four", 5), False)
+CASES["misc_five_k3"] = (p_misc_passes, ("five", 3), False)
+CASES["misc_six_k5"] = (p_misc_passes, ("six", 5), False)
+CASES["misc_seven_k3"] = (p_misc_passes, ("seven", 3), False)
+CASES["drivers_five"] = (p_drivers, ("five",), False)
+CASES["read_helpers_six_k3"] = (p_read_helpers, ("six", 3), False)
+CASES["outputs_seven_k3"] = (p_outputs, ("seven", 3), False)
 CASES["drivers_eight"] = (p_drivers, ("eight",), False)
 CASES["drivers_nine"] = (p_drivers, ("nine",), False)
 CASES["cluster_eight_k3"] = (p_cluster_fixture, ("eight", 3, ["dfrA17"]), False)
