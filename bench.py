@@ -248,6 +248,43 @@ def run_cfg4(args, w, rank, world, local_rank):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as fresh child processes
+    (torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process makes any GPU call — counting the devices
+    does not initialise HIP — and hand rank 0's JSON line on as this process's own last line.  A box with fewer than
+    N GPUs fails here, loudly, instead of measuring something else."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but this machine has {have} GPU(s); refusing to report a "
+              f"{n}-GPU number from fewer devices", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode})", file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != n:
+        print(f"bench.py: the ranks reported n_gpus != {n}", file=sys.stderr, flush=True)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,9 +304,17 @@ def main():
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
+                 f"or call bench.py --gpus {args.gpus} without a launcher and it starts them itself")
 
     # CPU yardsticks first (rank 0, N = 1), before this process touches the GPU: the N-core line
     # starts worker processes
