@@ -77,16 +77,14 @@ def _load():
         "amg_minhash": (C.c_int, [P, P, P, P, I64, I32, C.c_uint64, P, P, I64, C.POINTER(I64)]),
         "amg_dist_record_bytes": (C.c_int, [I32, C.POINTER(I64), C.POINTER(I64)]),
         "amg_dist_set_filter": (C.c_int, [P, U32, U32]),
-        "amg_dist_nodes_local": (C.c_int, [P, I32, I64, I64, I32, P]),
+        "amg_dist_nodes_local": (C.c_int, [P, I32, I64, I64, I32, I32, P]),
         "amg_dist_nodes_pack": (C.c_int, [P, P]),
-        "amg_dist_nodes_reduce": (C.c_int, [P, P, I64, C.POINTER(I64)]),
-        "amg_dist_nodes_owned": (C.c_int, [P, P]),
-        "amg_dist_nodes_global": (C.c_int, [P, P, I64]),
+        "amg_dist_nodes_reduce": (C.c_int, [P, P, I64, I32, P, P, C.POINTER(I64)]),
+        "amg_dist_nodes_global": (C.c_int, [P, P, I64, I64, P]),
         "amg_dist_edges_local": (C.c_int, [P, I32, P]),
         "amg_dist_edges_pack": (C.c_int, [P, P]),
-        "amg_dist_edges_reduce": (C.c_int, [P, P, I64, C.POINTER(I64)]),
-        "amg_dist_edges_owned": (C.c_int, [P, P]),
-        "amg_dist_edges_global": (C.c_int, [P, P, I64]),
+        "amg_dist_edges_reduce": (C.c_int, [P, P, I64, I32, P, C.POINTER(I64)]),
+        "amg_dist_edges_global": (C.c_int, [P, P, I64, I64]),
         "amg_calls_load_json": (C.c_int, [C.c_char_p, C.POINTER(P)]),
         "amg_calls_counts": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64),
                                        C.POINTER(I64)]),

@@ -6,18 +6,30 @@
 // all_to_all_single / all_gather_into_tensor on the device buffers passed here), so the same
 // phases also run in a single process with a loop-back exchange (tests on one GPU):
 //
-//   amg_dist_nodes_local   local windows -> local node table; records bucketed by owner
+//   amg_dist_nodes_local   local windows -> local node table; one record per local node,
+//                          bucketed by owner = hash(key) mod world
 //   amg_dist_nodes_pack    records in destination order                     --> all-to-all
-//   amg_dist_nodes_reduce  owner side: equal keys reduced (sum count, min first-seen)
-//   amg_dist_nodes_owned   owned records                                    --> all-gather
-//   amg_dist_nodes_global  all records: global ids = rank of first-seen; local slots -> ids
-//   amg_dist_edges_local / _pack / _reduce / _owned / _global   same for the edge classes,
-//                          keyed by GLOBAL node ids; then edges, components, adjacency
+//   amg_dist_nodes_reduce  owner side: equal keys reduced through a hash table (sum count, min
+//                          first-seen); the owner's survivors                --> all-gather
+//                          and one reply per received record (its key's global first-seen, or
+//                          "dropped by the fused filter")                    --> all-to-all back
+//   amg_dist_nodes_global  global node id = rank of first-seen: a token position opens at most one
+//                          window, so the first-seen token indices of the nodes are distinct and the
+//                          rank is a prefix popcount over a bitmap of the GLOBAL token space — no sort,
+//                          no key -> id table; every rank fills the node arrays from the gathered
+//                          records and maps its own local nodes through the replies
+//   amg_dist_edges_local / _pack / _reduce / _global   the same for the edge classes, keyed by
+//                          GLOBAL node ids (no replies: nothing per adjacency needs the class id);
+//                          then edges, components, adjacency
 //
 // After amg_dist_edges_global every rank holds the global node / edge tables and its own
 // reads' node ids: filter / clip run identically everywhere, correct_reads on local reads.
 // first-seen values carry GLOBAL token indices (token_base + local index), so minima over
 // ranks reproduce the single-process insertion order exactly.
+//
+// No phase ends with a host synchronisation of its own: whatever the host needs (counts that size
+// the caller's buffers, status words) comes back through fetch(), everything else is ordered by
+// the ctx's stream — the caller issues its collectives on that same stream (amira_amd/dist.py).
 #include "amg_device.h"
 #include "amg_x.h"
 
@@ -32,9 +44,10 @@ static inline unsigned int nblk(long long n, int per) {
   return (unsigned int)(b < 1 ? 1 : b);
 }
 
-// node record: {u64 key, u64 first, u32 count, u32 k, i32 tok[k]} padded to 8 bytes
+// node record: {u64 key, u64 first, u32 count, u32 k, i32 tok[k]} padded to 8 bytes; key != 0
 static inline size_t node_rec_bytes(int k) { return (size_t)((24 + 4 * k + 7) & ~7); }
-#define EDGE_REC_BYTES 24  // {u64 key, u64 first, u32 count, u32 pad}
+#define EDGE_REC_BYTES 24  // {u64 key, u64 first, u32 count, u32 pad}; key != 0
+#define REPLY_DROPPED (~0ull)
 
 extern "C" int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes) {
   if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "bad k");
@@ -56,17 +69,12 @@ __device__ __forceinline__ unsigned int owner_of(unsigned long long key, unsigne
 
 // ------------------------------------------------------------------ phase: local nodes
 // destination of every local node (compaction list: first / slot)
-__global__ void k_dist_node_dest(const unsigned int* __restrict__ slots, long long n,
-                                 const Slot* __restrict__ tab, unsigned int world,
-                                 unsigned int* __restrict__ dest, unsigned int* __restrict__ idx,
-                                 unsigned long long* __restrict__ counts) {
+__global__ void k_dist_dest(const unsigned int* __restrict__ slots, long long n, const Slot* __restrict__ tab,
+                            unsigned int world, unsigned int* __restrict__ dest, unsigned int* __restrict__ idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  unsigned int d = owner_of(tab[slots[i]].key, world);
-  dest[i] = d;
+  dest[i] = owner_of(tab[slots[i]].key, world);
   idx[i] = (unsigned int)i;
-  (void)counts;  // per-destination counts come from the sorted array (k_dest_counts): millions of
-                 // atomics on `world` addresses would serialise
 }
 
 // counts[d] = number of entries equal to d in the ascending array dest_sorted[0..n)
@@ -85,6 +93,7 @@ __global__ void k_dest_counts(const unsigned int* __restrict__ dest_sorted, long
   counts[d] = (unsigned long long)(lower(d + 1) - lower(d));
 }
 
+// order == nullptr: the records leave in local order (one destination: nothing was sorted)
 __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long long n,
                                  const unsigned int* __restrict__ slots,
                                  const unsigned long long* __restrict__ firsts,
@@ -94,7 +103,7 @@ __global__ void k_dist_node_pack(const unsigned int* __restrict__ order, long lo
                                  int rec_bytes) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  unsigned int i = order[j];
+  unsigned int i = order ? order[j] : (unsigned int)j;
   const Slot* s = tab + slots[i];
   unsigned long long first = firsts[i];
   unsigned char* rec = out + (size_t)j * rec_bytes;
@@ -126,7 +135,7 @@ static int fetch_counts(amg_ctx* c, unsigned long long* h, int world) {
 // ------------------------------------------------------------------ exact local tables
 // When the shard qualifies (bx_fits) the LOCAL passes are those of the single-GPU exact-key
 // build (amg_build_x.hip: 16-byte slots, claim ids, dense per-claim arrays); the records that
-// travel keep the format below — the key is the same 64-bit fingerprint of the tuple, so ranks
+// travel keep the format above — the key is the same 64-bit fingerprint of the tuple, so ranks
 // on either path merge with each other.
 // fingerprint of a canonical tuple given as tokens: same value as canon_fingerprint()
 __device__ __forceinline__ unsigned long long tuple_fingerprint(const int* tok, int k, unsigned long long seed) {
@@ -151,8 +160,10 @@ __global__ void k_xd_node_keys(const Slot16* __restrict__ tab, const unsigned in
   for (int j = 0; j < k; ++j) tok[j] = x_unpack(s.w1, tag, bits, j);
   const unsigned long long key = tuple_fingerprint(tok, k, seed);
   keys[i] = key;
-  dest[i] = owner_of(key, world);
-  idx[i] = (unsigned int)i;
+  if (world > 1) {
+    dest[i] = owner_of(key, world);
+    idx[i] = (unsigned int)i;
+  }
 }
 
 __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long n,
@@ -163,7 +174,7 @@ __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long
                                int k, int bits, int two, unsigned char* __restrict__ out, int rec_bytes) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned int c = order[j];
+  const unsigned int c = order ? order[j] : (unsigned int)j;
   const unsigned long long first = ((unsigned long long)tok_base << 1) + (unsigned long long)(unsigned int)~x_first_inv(first2, c);
   unsigned char* rec = out + (size_t)j * rec_bytes;
   unsigned long long* q = reinterpret_cast<unsigned long long*>(rec);
@@ -176,28 +187,6 @@ __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;
   int* tk = reinterpret_cast<int*>(rec + 24);
   for (int x = 0; x < k; ++x) tk[x] = x_unpack(s.w1, tag, bits, x);
-}
-
-// local claim -> global node id (looked up by key); -2 when the node fell to the fused filter
-__global__ void k_xd_claims_to_global(const unsigned long long* __restrict__ keys, long long n,
-                                      const Slot* __restrict__ gtab, unsigned long long gmask,
-                                      int allow_missing, int* __restrict__ final_of_claim,
-                                      unsigned long long* status) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long key = keys[i];
-  unsigned long long s = (key >> 20) & gmask;
-  for (unsigned int probes = 0; probes < (1u << 20); ++probes) {
-    const unsigned long long cur = gtab[s].key;
-    if (cur == key) {
-      final_of_claim[i] = gtab[s].id;
-      return;
-    }
-    if (cur == 0ull) break;
-    s = (s + 1) & gmask;
-  }
-  final_of_claim[i] = -2;
-  if (!allow_missing) status[ST_OVERFLOW] = 5;  // local key missing from the global table
 }
 
 __global__ void k_xd_edge_dest(const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
@@ -216,22 +205,43 @@ __global__ void k_xd_edge_pack(const unsigned int* __restrict__ order, long long
                                unsigned char* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned int c = order[j];
+  const unsigned int c = order ? order[j] : (unsigned int)j;
   unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
   q[0] = etab[slot_by_claim[c]].w1;
   q[1] = ((unsigned long long)tok_base << 3) + (unsigned long long)(unsigned int)~x_first_inv(first2, c);
   q[2] = (unsigned long long)lcnt[c];
 }
 
+// the four arrays of a bucketing (n + 1 words each) inside dist_a
+struct Bucketing {
+  unsigned int *dest, *idx, *dest_sorted, *order;
+};
+static int bucketing(amg_ctx* c, long long n, Bucketing* b) {
+  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
+  b->dest = c->dist_a.as<unsigned int>();
+  b->idx = b->dest + (n + 1);
+  b->dest_sorted = b->idx + (n + 1);
+  b->order = b->dest_sorted + (n + 1);
+  return AMG_OK;
+}
+static const unsigned int* send_order(const amg_ctx* c, long long n) {
+  return c->world > 1 ? c->dist_a.as<unsigned int>() + 3 * (n + 1) : nullptr;
+}
+
 // per-destination send counts of n records whose destinations are in dest[]: sorts (dest, idx)
-// into (dest_sorted, order) and fills send_counts
-static int dest_counts(amg_ctx* c, long long n, int world, unsigned int* dest, unsigned int* idx,
-                       unsigned int* dest_sorted, unsigned int* order, int64_t* send_counts) {
+// into (dest_sorted, order) and fills send_counts.  One destination: nothing to sort, the records leave in local
+// order (send_order() == nullptr) and no count has to come back from the device.
+static int dest_counts(amg_ctx* c, long long n, int world, const Bucketing& b, int64_t* send_counts) {
   hipStream_t st = c->stream;
+  if (world == 1) {
+    send_counts[0] = n;
+    return AMG_OK;
+  }
+  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
   if (n > 0) {
-    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
-    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
+    AMGCHK(prim_sort_u32_u32(c, b.dest, b.dest_sorted, b.idx, b.order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, b.dest_sorted, n, (unsigned int)world,
                        c->dist_cnt.as<unsigned long long>());
   }
   std::vector<unsigned long long> h(world);
@@ -253,21 +263,21 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
   }
   const long long n = c->n_local_nodes, T = c->n_tokens;
   // local occurrence counts per claim, straight from the per-window claims
+  stage_begin(c, "node_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 2));
-  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
-  unsigned int* dest = c->dist_a.as<unsigned int>();
-  unsigned int* idx = dest + (n + 1);
-  unsigned int* dest_sorted = idx + (n + 1);
-  unsigned int* order = dest_sorted + (n + 1);
-  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
+  stage_end(c);
+  stage_begin(c, "merge_node_bucket");
+  Bucketing b;
+  AMGCHK(bucketing(c, n, &b));
   AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));  // keys per claim
   if (n > 0)
     hipLaunchKernelGGL(k_xd_node_keys, dim3(nblk(n, 256)), dim3(256), 0, st, c->node_tab.as<Slot16>(),
                        c->x_slot.as<unsigned int>(), n, k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->seed,
-                       (unsigned int)world,
-                       c->dist_first.as<unsigned long long>(), dest, idx);
-  return dest_counts(c, n, world, dest, idx, dest_sorted, order, send_counts);
+                       (unsigned int)world, c->dist_first.as<unsigned long long>(), b.dest, b.idx);
+  const int r = dest_counts(c, n, world, b, send_counts);
+  stage_end(c);
+  return r;
 }
 
 static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
@@ -281,24 +291,27 @@ static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
     c->edge_slots *= 4;
   }
   const long long n = c->n_local_pairs, T = c->n_tokens;
+  stage_begin(c, "edge_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 1));
-  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
-  unsigned int* dest = c->dist_a.as<unsigned int>();
-  unsigned int* idx = dest + (n + 1);
-  unsigned int* dest_sorted = idx + (n + 1);
-  unsigned int* order = dest_sorted + (n + 1);
-  if (n > 0)
+  stage_end(c);
+  stage_begin(c, "merge_edge_bucket");
+  Bucketing b;
+  AMGCHK(bucketing(c, n, &b));
+  if (n > 0 && world > 1)
     hipLaunchKernelGGL(k_xd_edge_dest, dim3(nblk(n, 256)), dim3(256), 0, st, c->edge_tab.as<Slot16>(),
-                       c->x_eslot.as<unsigned int>(), n, (unsigned int)world, dest, idx);
-  return dest_counts(c, n, world, dest, idx, dest_sorted, order, send_counts);
+                       c->x_eslot.as<unsigned int>(), n, (unsigned int)world, b.dest, b.idx);
+  const int r = dest_counts(c, n, world, b, send_counts);
+  stage_end(c);
+  return r;
 }
 
 extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, int64_t token_total,
-                                    int32_t world, int64_t* send_counts) {
+                                    int32_t world, int32_t attempt, int64_t* send_counts) {
   NEED_CTX(c);
   if (k < 1 || k > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
   if (world < 1 || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
+  if (attempt < 0) return amg_fail(AMG_E_ARG, "bad attempt");
   if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
   hipStream_t st = c->stream;
   stages_reset(c);
@@ -312,23 +325,26 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   c->world = world;
   c->dist_mode = true;
   // merge keys and key owners are fingerprints of this seed: every rank must use the SAME one,
-  // whatever collision retries an earlier single-GPU build on this ctx went through
+  // whatever collision retries an earlier single-GPU build on this ctx went through.  `attempt`
+  // is the caller's collective retry counter (a cross-rank fingerprint collision makes every
+  // rank come back with attempt + 1: amira_amd/dist.py)
   c->seed = kAmgSeed0;
+  for (int a = 0; a < attempt; ++a) c->seed = c->seed * 6364136223846793005ull + 1442695040888963407ull;
   c->count_inline = false;  // local occurrence counts come from bs_count_by_slot, not per-window atomics
   bs_size_tables(c);
   c->exact_keys = false;
   c->dist_x = bx_fits(c, k);
   if (c->dist_x) return nodes_local_x(c, k, world, send_counts);
-  for (int attempt = 0;; ++attempt) {
+  for (int tries = 0;; ++tries) {
     int which = 0;
     int r = bs_nodes_pass(c, k, &which);
     if (r == AMG_OK) break;
-    if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
+    if (r != AMG_E_OVERFLOW || which != 1 || tries >= 8) return r;
     ++c->retries;
     if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
     c->node_slots = c->node_slots * 4 > (1ll << 30) ? (1ll << 30) : c->node_slots * 4;
   }
-  // compaction list lives in s1 (first) / s3 (slot); destination order -> dist_order
+  // compaction list lives in s1 (first) / s3 (slot); destination order -> dist_a
   const long long n = c->n_local_nodes;
   {
     // local occurrence counts: rank the local nodes by first-seen (hot nodes get low ids),
@@ -341,13 +357,8 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
                             c->node_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
                             c->dist_lcnt.as<unsigned int>(), 0));
   }
-  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
-  unsigned int* dest = c->dist_a.as<unsigned int>();
-  unsigned int* idx = dest + (n + 1);
-  unsigned int* dest_sorted = idx + (n + 1);
-  unsigned int* order = dest_sorted + (n + 1);
-  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
-  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
+  Bucketing b;
+  AMGCHK(bucketing(c, n, &b));
   // keep the compaction list: the sort below uses the generic scratch
   AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
   AMGCHK(c->dist_slot.ensure((size_t)(n + 1) * sizeof(unsigned int)));
@@ -355,18 +366,10 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
                         hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(c->dist_slot.p, c->s3.p, (size_t)n * sizeof(unsigned int),
                         hipMemcpyDeviceToDevice, st));
-  if (n > 0) {
-    hipLaunchKernelGGL(k_dist_node_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
-                       c->dist_slot.as<unsigned int>(), n, c->node_tab.as<Slot>(), (unsigned int)world,
-                       dest, idx, c->dist_cnt.as<unsigned long long>());
-    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
-    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
-                       c->dist_cnt.as<unsigned long long>());
-  }
-  std::vector<unsigned long long> h(world);
-  AMGCHK(fetch_counts(c, h.data(), world));
-  for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
-  return AMG_OK;
+  if (n > 0 && world > 1)
+    hipLaunchKernelGGL(k_dist_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
+                       c->dist_slot.as<unsigned int>(), n, c->node_tab.as<Slot>(), (unsigned int)world, b.dest, b.idx);
+  return dest_counts(c, n, world, b, send_counts);
 }
 
 extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
@@ -374,302 +377,354 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
   const long long n = c->n_local_nodes;
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
-  unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
-  if (c->dist_x) {
+  const unsigned int* order = send_order(c, n);
+  stage_begin(c, "merge_node_pack");
+  if (c->dist_x)
     hipLaunchKernelGGL(k_xd_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                        c->dist_first.as<unsigned long long>(), c->x_first.as<unsigned int>(),
                        (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
                        c->k, c->x_bits, (long long)c->k * c->x_bits > 63 ? 1 : 0,
                        reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
-    AMGCHK(stream_wait(c));
-    return AMG_OK;
-  }
-  hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
-                     c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
-                     c->node_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(), c->tokens.as<int>(), c->k,
-                     c->two_v, (long long)c->tok_base,
-                     reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
-  AMGCHK(stream_wait(c));
+  else
+    hipLaunchKernelGGL(k_dist_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                       c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
+                       c->node_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(), c->tokens.as<int>(), c->k,
+                       c->two_v, (long long)c->tok_base,
+                       reinterpret_cast<unsigned char*>(send_buf), (int)node_rec_bytes(c->k));
+  stage_end(c);
   return AMG_OK;
 }
 
 // ------------------------------------------------------------------ phase: owner-side reduce
-// Received records are sorted by key; a run of equal keys (one record per contributing rank)
-// collapses to: sum of counts, min first-seen, tokens of the min-first record.  Records of a
-// run must carry the same canonical tuple, otherwise two tuples share a fingerprint.
-__global__ void k_rec_keys(const unsigned char* __restrict__ recs, long long n, int rec_bytes,
-                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = *reinterpret_cast<const unsigned long long*>(recs + (size_t)i * rec_bytes);
-  idx[i] = (unsigned int)i;
+// Records of one key arrive from every rank that saw it.  They meet in an open-addressing table
+// keyed by the record key: count = sum of the local counts, first-seen = the minimum (atomicMax
+// of the complement); the record that carries the minimum is the key's representative (first-seen
+// values of different ranks differ: they are global token indices) and is what the owner hands
+// on.  Every other record's canonical tuple must equal the representative's, otherwise two tuples
+// share a fingerprint.  Records that all come from ONE rank are distinct keys already: no table.
+__device__ __forceinline__ bool edge_key_self_loop(unsigned long long key) {
+  const unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
+  const unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
+  return lo == hi;
 }
 
-// head[i] = 1 for the first record of a run of equal keys whose reduced coverage reaches
-// min_cov (edge classes that are self-loops count twice)
-__global__ void k_run_heads(const unsigned char* __restrict__ recs, int rec_bytes, int is_edge,
-                            const unsigned long long* __restrict__ keys_sorted,
-                            const unsigned int* __restrict__ idx_sorted, long long n,
-                            unsigned int min_cov, unsigned int* __restrict__ head) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned int h = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1u : 0u;
-  if (h && min_cov > 1) {
-    const unsigned long long key = keys_sorted[i];
-    unsigned long long total = 0;
-    for (long long j = i; j < n && keys_sorted[j] == key; ++j)
-      total += *reinterpret_cast<const unsigned int*>(recs + (size_t)idx_sorted[j] * rec_bytes + 16);
-    if (is_edge) {
-      unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
-      unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
-      if (lo == hi) total *= 2;
+__global__ void k_own_upsert(const unsigned char* __restrict__ recs, long long n, int rec_bytes, Slot* tab,
+                             unsigned long long mask, unsigned int* __restrict__ recslot,
+                             unsigned long long* status) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned char* r = recs + (size_t)j * rec_bytes;
+  const unsigned long long key = *reinterpret_cast<const unsigned long long*>(r);
+  const unsigned long long first = *reinterpret_cast<const unsigned long long*>(r + 8);
+  const unsigned int cnt = *reinterpret_cast<const unsigned int*>(r + 16);
+  const long long slot = table_upsert(tab, mask, key, mix64(key), first, 1u << 16, false, status + ST_OVERFLOW);
+  if (slot < 0) {
+    status[ST_OVERFLOW] = 6;
+    recslot[j] = 0u;
+    return;
+  }
+  atomicAdd(&tab[slot].count, cnt);
+  recslot[j] = (unsigned int)slot;
+}
+
+// flag[j] = record j is the representative of a key that reaches min_cov (edge classes that are
+// self-loops count twice)
+template <bool MULTI>
+__global__ void k_own_flag(const unsigned char* __restrict__ recs, long long n, int rec_bytes, int is_edge,
+                           unsigned int min_cov, Slot* tab, const unsigned int* __restrict__ recslot,
+                           unsigned int* __restrict__ flag) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned char* r = recs + (size_t)j * rec_bytes;
+  const unsigned long long key = *reinterpret_cast<const unsigned long long*>(r);
+  const unsigned long long first = *reinterpret_cast<const unsigned long long*>(r + 8);
+  unsigned long long total = *reinterpret_cast<const unsigned int*>(r + 16);
+  bool rep = true;
+  if (MULTI) {
+    Slot* s = tab + recslot[j];
+    total = s->count;
+    rep = ~s->first_inv == first;
+    if (rep) s->id = (int)j;  // one writer per slot
+  }
+  if (is_edge && edge_key_self_loop(key)) total *= 2;
+  flag[j] = (rep && total >= min_cov) ? 1u : 0u;
+}
+
+template <bool MULTI>
+__global__ void k_own_emit(const unsigned char* __restrict__ recs, long long n, int rec_bytes, int tok_words,
+                           int is_edge, unsigned int min_cov, const Slot* __restrict__ tab,
+                           const unsigned int* __restrict__ recslot, const unsigned int* __restrict__ flag,
+                           const long long* __restrict__ pos, unsigned char* __restrict__ owned,
+                           unsigned long long* __restrict__ replies, unsigned long long* status) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned char* r = recs + (size_t)j * rec_bytes;
+  const unsigned long long key = *reinterpret_cast<const unsigned long long*>(r);
+  unsigned long long gfirst = *reinterpret_cast<const unsigned long long*>(r + 8);
+  unsigned long long total = *reinterpret_cast<const unsigned int*>(r + 16);
+  if (MULTI) {
+    const Slot* s = tab + recslot[j];
+    total = s->count;
+    gfirst = ~s->first_inv;
+    if (tok_words > 0 && s->id != (int)j) {  // exact tuple check against the representative
+      const int* t0 = reinterpret_cast<const int*>(recs + (size_t)s->id * rec_bytes + 24);
+      const int* t1 = reinterpret_cast<const int*>(r + 24);
+      for (int x = 0; x < tok_words; ++x)
+        if (t1[x] != t0[x]) status[ST_COLLISION] = 1;
     }
-    if (total < min_cov) h = 0;
   }
-  head[i] = h;
+  const unsigned long long cov = (is_edge && edge_key_self_loop(key)) ? total * 2 : total;
+  if (replies) replies[j] = cov >= min_cov ? gfirst : REPLY_DROPPED;
+  if (flag[j]) {
+    unsigned char* o = owned + (size_t)pos[j] * rec_bytes;
+    for (int x = 0; x < rec_bytes; x += 8)
+      *reinterpret_cast<unsigned long long*>(o + x) = *reinterpret_cast<const unsigned long long*>(r + x);
+    *reinterpret_cast<unsigned int*>(o + 16) = (unsigned int)total;
+  }
 }
 
-__global__ void k_reduce_runs(const unsigned char* __restrict__ recs, int rec_bytes, int tok_words,
-                              const unsigned long long* __restrict__ keys_sorted,
-                              const unsigned int* __restrict__ idx_sorted,
-                              const unsigned int* __restrict__ head, const long long* __restrict__ pos,
-                              long long n, unsigned char* __restrict__ out, unsigned long long* status) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  const unsigned long long key = keys_sorted[i];
-  unsigned long long best_first = ~0ull, total = 0;
-  long long best = -1;
-  for (long long j = i; j < n && keys_sorted[j] == key; ++j) {
-    const unsigned char* r = recs + (size_t)idx_sorted[j] * rec_bytes;
-    unsigned long long f = *reinterpret_cast<const unsigned long long*>(r + 8);
-    total += *reinterpret_cast<const unsigned int*>(r + 16);
-    if (f < best_first) {
-      best_first = f;
-      best = j;
-    }
-  }
-  const unsigned char* b = recs + (size_t)idx_sorted[best] * rec_bytes;
-  // exact tuple check across the run (fingerprint collision between ranks)
-  for (long long j = i; j < n && keys_sorted[j] == key; ++j) {
-    const int* t1 = reinterpret_cast<const int*>(recs + (size_t)idx_sorted[j] * rec_bytes + 24);
-    const int* t0 = reinterpret_cast<const int*>(b + 24);
-    for (int x = 0; x < tok_words; ++x)
-      if (t1[x] != t0[x]) status[ST_COLLISION] = 1;
-  }
-  unsigned char* o = out + (size_t)pos[i] * rec_bytes;
-  for (int x = 0; x < rec_bytes; x += 8)
-    *reinterpret_cast<unsigned long long*>(o + x) = *reinterpret_cast<const unsigned long long*>(b + x);
-  *reinterpret_cast<unsigned long long*>(o + 8) = best_first;
-  *reinterpret_cast<unsigned int*>(o + 16) = (unsigned int)total;
-}
-
-static int reduce_records(amg_ctx* c, const void* recv, long long n, int rec_bytes, int tok_words,
-                          unsigned int min_cov, DevBuf& owned, int64_t* n_owned) {
+// owned_out: room for n records; replies_out (nodes): n words
+static int reduce_records(amg_ctx* c, const void* recv, long long n, int n_sources, int rec_bytes, int tok_words,
+                          unsigned int min_cov, void* owned_out, unsigned long long* replies_out, int64_t* n_owned) {
   hipStream_t st = c->stream;
   *n_owned = 0;
   if (n == 0) return AMG_OK;
-  AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
-  AMGCHK(c->s2.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
+  if (!recv || !owned_out) return amg_fail(AMG_E_ARG, "null record buffer");
+  const bool multi = n_sources > 1;
+  const int is_edge = tok_words == 0 ? 1 : 0;
   AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-  AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-  AMGCHK(c->s5.ensure((size_t)(n + 2) * (sizeof(unsigned int) + sizeof(long long))));
+  AMGCHK(c->s4.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(n + 2) * sizeof(long long)));
   const unsigned char* recs = reinterpret_cast<const unsigned char*>(recv);
-  hipLaunchKernelGGL(k_rec_keys, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes,
-                     c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
-  AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
-                           c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, 64));
+  unsigned int* recslot = c->s3.as<unsigned int>();
+  unsigned int* flag = c->s4.as<unsigned int>();
   long long* pos = c->s5.as<long long>();
-  unsigned int* head = reinterpret_cast<unsigned int*>(pos + (n + 2));
-  hipLaunchKernelGGL(k_run_heads, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rec_bytes, tok_words == 0 ? 1 : 0,
-                     c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), n, min_cov, head);
-  HIPCHK(hipMemsetAsync(head + n, 0, sizeof(unsigned int), st));
-  AMGCHK(prim_exscan_u32_to_i64(c, head, pos, (size_t)n + 1));
-  long long total = 0;
+  unsigned long long* status = c->status.as<unsigned long long>();
+  uint64_t slots = 0;
+  {
+    ClearList cl;
+    cl.add(flag + n, sizeof(unsigned int));
+    cl.add(status + ST_OVERFLOW, sizeof(unsigned long long));
+    cl.add(status + ST_COLLISION, sizeof(unsigned long long));
+    if (multi) {
+      slots = pow2_at_least((uint64_t)n * 2 + 16);
+      AMGCHK(c->dist_gtab.ensure((size_t)slots * sizeof(Slot)));
+      cl.add(c->dist_gtab.p, (size_t)slots * sizeof(Slot));
+    }
+    AMGCHK(clear_many(c, cl));
+  }
+  Slot* tab = c->dist_gtab.as<Slot>();
+  if (multi) {
+    hipLaunchKernelGGL(k_own_upsert, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes, tab,
+                       (unsigned long long)(slots - 1), recslot, status);
+    hipLaunchKernelGGL(k_own_flag<true>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes, is_edge, min_cov,
+                       tab, recslot, flag);
+  } else {
+    hipLaunchKernelGGL(k_own_flag<false>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes, is_edge, min_cov,
+                       tab, recslot, flag);
+  }
+  AMGCHK(prim_exscan_u32_to_i64(c, flag, pos, (size_t)n + 1));
+  if (multi)
+    hipLaunchKernelGGL(k_own_emit<true>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes, tok_words, is_edge,
+                       min_cov, tab, recslot, flag, pos, reinterpret_cast<unsigned char*>(owned_out), replies_out, status);
+  else
+    hipLaunchKernelGGL(k_own_emit<false>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rec_bytes, tok_words, is_edge,
+                       min_cov, tab, recslot, flag, pos, reinterpret_cast<unsigned char*>(owned_out), replies_out, status);
+  unsigned long long h[3] = {0, 0, 0};
   {
     FetchList l;
     l.add(pos + n);
-    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&total)));
+    l.add(status + ST_COLLISION);
+    l.add(status + ST_OVERFLOW);
+    AMGCHK(fetch(c, l, h));
   }
-  AMGCHK(owned.ensure((size_t)(total + 1) * rec_bytes));
-  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COLLISION, 0, sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(k_reduce_runs, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rec_bytes, tok_words,
-                     c->s2.as<unsigned long long>(), c->s4.as<unsigned int>(), head, pos, n,
-                     owned.as<unsigned char>(), c->status.as<unsigned long long>());
-  unsigned long long coll = 0;
-  {
-    FetchList l;
-    l.add(c->status.as<unsigned long long>() + ST_COLLISION);
-    AMGCHK(fetch(c, l, &coll));
-  }
-  if (coll) return amg_fail(AMG_E_OVERFLOW, "fingerprint collision across ranks: rebuild with another seed");
-  *n_owned = total;
+  if (h[2]) return amg_fail(AMG_E_DIST, "owner table full (code %llu)", h[2]);
+  if (h[1]) return amg_fail(AMG_E_COLLISION, "fingerprint collision across ranks: the merged build is repeated with the next seed");
+  *n_owned = (int64_t)h[0];
   return AMG_OK;
 }
 
-extern "C" int amg_dist_nodes_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
+extern "C" int amg_dist_nodes_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int32_t n_sources,
+                                     void* owned_out, void* replies_out, int64_t* n_owned) {
   NEED_CTX(c);
-  if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
-  int r = reduce_records(c, recv_buf, n_recv, (int)node_rec_bytes(c->k), c->k, c->dist_min_node,
-                         c->dist_owned, n_owned);
+  if (!n_owned || n_recv < 0 || (n_recv > 0 && !replies_out)) return amg_fail(AMG_E_ARG, "bad arguments");
+  stage_begin(c, "merge_node_reduce");
+  const int r = reduce_records(c, recv_buf, n_recv, n_sources, (int)node_rec_bytes(c->k), c->k, c->dist_min_node,
+                               owned_out, reinterpret_cast<unsigned long long*>(replies_out), n_owned);
+  stage_end(c);
   c->n_owned = *n_owned;
   return r;
 }
 
-extern "C" int amg_dist_nodes_owned(amg_ctx* c, void* out) {
-  NEED_CTX(c);
-  if (c->n_owned > 0) {
-    if (!out) return amg_fail(AMG_E_ARG, "null out");
-    HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * node_rec_bytes(c->k),
-                          hipMemcpyDeviceToDevice, c->stream));
-    AMGCHK(stream_wait(c));
+// ------------------------------------------------------------------ phase: global ids
+// rank of a first-seen value among all of them = number of set bits before its token in a bitmap
+// over the GLOBAL token space (one bit per record).  Many records: one byte per token first, set
+// with plain stores and folded into the bitmap words by the pass that counts them (scattered
+// atomicOr runs at the memory-side atomic rate); few records (a filtered graph over a long token
+// stream): atomicOr on the words directly, nothing token-sized but the words to clear.
+__global__ void k_d_setflags(const unsigned char* __restrict__ recs, long long n_slots, int rec_bytes, int shift,
+                             unsigned char* __restrict__ flags, unsigned int* __restrict__ bits) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const unsigned char* r = recs + (size_t)i * rec_bytes;
+  if (*reinterpret_cast<const unsigned long long*>(r) == 0ull) return;  // padding of the all-gather
+  const unsigned long long t = *reinterpret_cast<const unsigned long long*>(r + 8) >> shift;
+  if (flags)
+    flags[t] = 1;
+  else
+    atomicOr(bits + (t >> 5), 1u << (t & 31));
+}
+
+__global__ void k_d_fold_words(const unsigned char* __restrict__ flags, long long n_words,
+                               unsigned int* __restrict__ bits, unsigned int* __restrict__ cnt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words) return;
+  unsigned int w;
+  if (flags) {
+    const uint4* p = reinterpret_cast<const uint4*>(flags + 32 * i);
+    const uint4 a = p[0], b = p[1];
+    auto nib = [](unsigned int x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };
+    w = nib(a.x) | (nib(a.y) << 4) | (nib(a.z) << 8) | (nib(a.w) << 12) | (nib(b.x) << 16) | (nib(b.y) << 20) |
+        (nib(b.z) << 24) | (nib(b.w) << 28);
+    bits[i] = w;
+  } else {
+    w = bits[i];
   }
-  return AMG_OK;
+  cnt[i] = (unsigned int)__popc(w);
 }
 
-// ------------------------------------------------------------------ phase: global node ids
-__global__ void k_rec_firsts(const unsigned char* __restrict__ recs, long long n, int rec_bytes,
-                             unsigned long long* __restrict__ firsts, unsigned int* __restrict__ idx) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  firsts[i] = *reinterpret_cast<const unsigned long long*>(recs + (size_t)i * rec_bytes + 8);
-  idx[i] = (unsigned int)i;
+__device__ __forceinline__ long long d_rank_of(unsigned long long t, const unsigned int* __restrict__ bits,
+                                               const long long* __restrict__ prefix) {
+  const unsigned int w = bits[t >> 5];
+  return prefix[t >> 5] + (long long)__popc(w & ((1u << (t & 31)) - 1u));
 }
 
-// node arrays in global id order + key -> id table
-__global__ void k_global_nodes(const unsigned char* __restrict__ recs, int rec_bytes, int k,
-                               const unsigned int* __restrict__ idx_sorted, long long n,
-                               Slot* __restrict__ gtab, unsigned long long gmask,
+// bitmap (s1) + exclusive prefix of the word popcounts (s5; s5[words] = number of set bits) over the
+// global token space from the first-seen values of n_slots gathered records, n_total of them real
+static int d_rank_bitmap(amg_ctx* c, const unsigned char* recs, long long n_slots, long long n_total, int rec_bytes,
+                         int shift) {
+  hipStream_t st = c->stream;
+  const long long words = ((c->tok_total > 0 ? c->tok_total : 1) >> 5) + 2;
+  AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
+  AMGCHK(c->s2.ensure((size_t)(words + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(words + 2) * sizeof(long long)));
+  const bool bytes = n_total * 64 > c->tok_total;
+  unsigned char* flags = nullptr;
+  ClearList cl;
+  if (bytes) {
+    AMGCHK(c->s0.ensure((size_t)words * 32 + 64));
+    flags = c->s0.as<unsigned char>();
+    cl.add(flags, (size_t)words * 32);
+  } else {
+    cl.add(c->s1.p, (size_t)words * sizeof(unsigned int));
+  }
+  cl.add(c->s2.as<unsigned int>() + words, sizeof(unsigned int));
+  AMGCHK(clear_many(c, cl));
+  if (n_slots > 0)
+    hipLaunchKernelGGL(k_d_setflags, dim3(nblk(n_slots, 256)), dim3(256), 0, st, recs, n_slots, rec_bytes, shift,
+                       flags, c->s1.as<unsigned int>());
+  hipLaunchKernelGGL(k_d_fold_words, dim3(nblk(words, 256)), dim3(256), 0, st, flags, words, c->s1.as<unsigned int>(),
+                     c->s2.as<unsigned int>());
+  return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words + 1);
+}
+
+// node arrays in global id order, straight from the gathered records
+__global__ void k_global_nodes(const unsigned char* __restrict__ recs, long long n_slots, int rec_bytes, int k,
+                               const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
                                int* __restrict__ node_tokens, unsigned int* __restrict__ node_cov,
-                               long long* __restrict__ node_first, unsigned char* __restrict__ node_alive,
-                               unsigned long long* status) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned char* r = recs + (size_t)idx_sorted[i] * rec_bytes;
-  const unsigned long long key = *reinterpret_cast<const unsigned long long*>(r);
-  node_first[i] = (long long)*reinterpret_cast<const unsigned long long*>(r + 8);
+                               long long* __restrict__ node_first, unsigned char* __restrict__ node_alive) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots) return;
+  const unsigned char* r = recs + (size_t)j * rec_bytes;
+  if (*reinterpret_cast<const unsigned long long*>(r) == 0ull) return;
+  const unsigned long long first = *reinterpret_cast<const unsigned long long*>(r + 8);
+  const long long i = d_rank_of(first >> 1, bits, prefix);
+  node_first[i] = (long long)first;
   node_cov[i] = *reinterpret_cast<const unsigned int*>(r + 16);
   node_alive[i] = 1;
   const int* tk = reinterpret_cast<const int*>(r + 24);
   for (int x = 0; x < k; ++x) node_tokens[i * k + x] = tk[x];
-  // insert key -> id (keys are unique after the owner-side reduce)
-  unsigned long long s = (key >> 20) & gmask;
-  for (unsigned int probes = 0;; ++probes) {
-    unsigned long long cur = atomicCAS(&gtab[s].key, 0ull, key);
-    if (cur == 0ull) {
-      gtab[s].id = (int)i;
-      return;
-    }
-    if (cur == key || probes > 1u << 20) {
-      status[ST_OVERFLOW] = 4;  // duplicate key after reduce: cannot happen
-      return;
-    }
-    s = (s + 1) & gmask;
+}
+
+// local node (record j of what this rank sent) -> global node id through its owner's reply; -2
+// when the node fell to the fused filter (its windows then read None)
+__global__ void k_replies_to_claims(const unsigned long long* __restrict__ replies, long long n,
+                                    const unsigned int* __restrict__ order, const unsigned int* __restrict__ bits,
+                                    const long long* __restrict__ prefix, int* __restrict__ final_of_claim) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long g = replies[j];
+  final_of_claim[order ? order[j] : (unsigned int)j] = g == REPLY_DROPPED ? -2 : (int)d_rank_of(g >> 1, bits, prefix);
+}
+
+__global__ void k_replies_to_slots(const unsigned long long* __restrict__ replies, long long n,
+                                   const unsigned int* __restrict__ order, const unsigned int* __restrict__ bits,
+                                   const long long* __restrict__ prefix, const unsigned int* __restrict__ slots,
+                                   Slot* __restrict__ ltab, const int* __restrict__ node_tokens, int k, int packed) {
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long g = replies[j];
+  Slot* s = ltab + slots[order ? order[j] : (unsigned int)j];
+  const int gid = g == REPLY_DROPPED ? -2 : (int)d_rank_of(g >> 1, bits, prefix);
+  if (!packed) {
+    s->id = gid;
+  } else if (gid >= 0) {
+    slot_pack(s, gid, node_tokens + (long long)gid * k, k);
+  } else {
+    int none[AMG_MAX_K] = {0};
+    slot_pack(s, -2, none, k);
   }
 }
 
-// local table slot -> global node id (looked up by key)
-__global__ void k_local_to_global(Slot* __restrict__ ltab, unsigned long long n_slots,
-                                  const Slot* __restrict__ gtab, unsigned long long gmask,
-                                  const int* __restrict__ node_tokens, int k, int packed, int allow_missing,
-                                  unsigned long long* status) {
-  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_slots) return;
-  const unsigned long long key = ltab[i].key;
-  if (key == 0ull) return;
-  unsigned long long s = (key >> 20) & gmask;
-  for (unsigned int probes = 0; probes < (1u << 20); ++probes) {
-    unsigned long long cur = gtab[s].key;
-    if (cur == key) {
-      const int gid = gtab[s].id;
-      if (packed)
-        slot_pack(ltab + i, gid, node_tokens + (long long)gid * k, k);
-      else
-        ltab[i].id = gid;
-      return;
-    }
-    if (cur == 0ull) break;
-    s = (s + 1) & gmask;
-  }
-  if (allow_missing) {
-    // the node did not reach the fused coverage threshold: its windows become None (-2)
-    if (packed) {
-      int none[AMG_MAX_K] = {0};
-      slot_pack(ltab + i, -2, none, k);
-    } else {
-      ltab[i].id = -2;
-    }
-    return;
-  }
-  status[ST_OVERFLOW] = 5;  // local key missing from the global table
-}
-
-extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_t n_total) {
+// all_records: n_slots record slots as the all-gather delivered them (equal-size contributions:
+// the unused tail of a rank's part is zero), n_total of them real; my_replies: one word per record
+// this rank sent, in the order it sent them
+extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_t n_slots, int64_t n_total,
+                                     const void* my_replies) {
   NEED_CTX(c);
   hipStream_t st = c->stream;
   const long long n = n_total;
   const int rb = (int)node_rec_bytes(c->k);
-  c->packed_nodes = (c->two_v <= 65536 && c->k <= AMG_PACK_MAX_K);
+  if (n_slots < n || n < 0) return amg_fail(AMG_E_ARG, "bad record counts");
+  if (n > 0 && !all_records) return amg_fail(AMG_E_ARG, "null records");
+  if (c->n_local_nodes > 0 && !my_replies) return amg_fail(AMG_E_ARG, "null replies");
+  stage_begin(c, "merge_node_global");
+  c->packed_nodes = !c->dist_x && (c->two_v <= 65536 && c->k <= AMG_PACK_MAX_K);
   c->n_nodes = n;
   AMGCHK(bs_alloc_nodes(c, n));
-  uint64_t gslots = pow2_at_least((uint64_t)n * 2 + 16);
-  AMGCHK(c->dist_gtab.ensure((size_t)gslots * sizeof(Slot)));
-  HIPCHK(hipMemsetAsync(c->dist_gtab.p, 0, (size_t)gslots * sizeof(Slot), st));
-  HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_OVERFLOW, 0, sizeof(unsigned long long), st));
-  if (n > 0) {
-    if (!all_records) return amg_fail(AMG_E_ARG, "null records");
-    AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
-    AMGCHK(c->s2.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
-    AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-    AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-    const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
-    hipLaunchKernelGGL(k_rec_firsts, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, rb,
-                       c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
-    int first_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 2 + 2) + 1;
-    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->s2.as<unsigned long long>(),
-                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, first_bits));
-    hipLaunchKernelGGL(k_global_nodes, dim3(nblk(n, 256)), dim3(256), 0, st, recs, rb, c->k,
-                       c->s4.as<unsigned int>(), n, c->dist_gtab.as<Slot>(), (unsigned long long)(gslots - 1),
-                       c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
-                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>(),
-                       c->status.as<unsigned long long>());
-  }
-  if (c->dist_x) {
-    c->packed_nodes = false;
-    if (c->n_local_nodes > 0)
-      hipLaunchKernelGGL(k_xd_claims_to_global, dim3(nblk(c->n_local_nodes, 256)), dim3(256), 0, st,
-                         c->dist_first.as<unsigned long long>(), (long long)c->n_local_nodes,
-                         c->dist_gtab.as<Slot>(), (unsigned long long)(gslots - 1),
-                         c->dist_min_node > 1 ? 1 : 0, c->x_final.as<int>(), c->status.as<unsigned long long>());
-  } else
-  hipLaunchKernelGGL(k_local_to_global, dim3(nblk(c->node_slots, 256)), dim3(256), 0, st,
-                     c->node_tab.as<Slot>(), (unsigned long long)c->node_slots, c->dist_gtab.as<Slot>(),
-                     (unsigned long long)(gslots - 1), c->node_tokens.as<int>(), c->k,
-                     c->packed_nodes ? 1 : 0, c->dist_min_node > 1 ? 1 : 0,
-                     c->status.as<unsigned long long>());
-  unsigned long long ov = 0;
+  const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
+  AMGCHK(d_rank_bitmap(c, recs, n_slots, n, rb, 1));
+  const unsigned int* bits = c->s1.as<unsigned int>();
+  const long long* prefix = c->s5.as<long long>();
+  if (n_slots > 0)
+    hipLaunchKernelGGL(k_global_nodes, dim3(nblk(n_slots, 256)), dim3(256), 0, st, recs, (long long)n_slots, rb, c->k,
+                       bits, prefix, c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+  const long long nl = c->n_local_nodes;
+  const unsigned long long* rep = reinterpret_cast<const unsigned long long*>(my_replies);
+  if (nl > 0 && c->dist_x)
+    hipLaunchKernelGGL(k_replies_to_claims, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c, nl), bits,
+                       prefix, c->x_final.as<int>());
+  else if (nl > 0)
+    hipLaunchKernelGGL(k_replies_to_slots, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c, nl), bits,
+                       prefix, c->dist_slot.as<unsigned int>(), c->node_tab.as<Slot>(), c->node_tokens.as<int>(), c->k,
+                       c->packed_nodes ? 1 : 0);
+  // distinct first-seen values <=> as many bits as records
+  const long long words = ((c->tok_total > 0 ? c->tok_total : 1) >> 5) + 2;
+  unsigned long long set = 0;
   {
     FetchList l;
-    l.add(c->status.as<unsigned long long>() + ST_OVERFLOW);
-    AMGCHK(fetch(c, l, &ov));
+    l.add(prefix + words);
+    AMGCHK(fetch(c, l, &set));
   }
-  if (ov) return amg_fail(AMG_E_DIST, "global node table inconsistent (code %llu)", ov);
+  stage_end(c);
+  if ((long long)set != n)
+    return amg_fail(AMG_E_DIST, "global node table inconsistent: %lld records, %llu distinct first-seen positions", n, set);
   return AMG_OK;
 }
 
 // ------------------------------------------------------------------ phase: edges
-__global__ void k_dist_edge_dest(const unsigned int* __restrict__ slots, long long n,
-                                 const Slot* __restrict__ tab, unsigned int world,
-                                 unsigned int* __restrict__ dest, unsigned int* __restrict__ idx,
-                                 unsigned long long* __restrict__ counts) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned int d = owner_of(tab[slots[i]].key, world);
-  dest[i] = d;
-  idx[i] = (unsigned int)i;
-  (void)counts;
-}
-
 __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long long n,
                                  const unsigned int* __restrict__ slots,
                                  const unsigned long long* __restrict__ firsts,
@@ -677,7 +732,7 @@ __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long lo
                                  unsigned char* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  unsigned int i = order[j];
+  unsigned int i = order ? order[j] : (unsigned int)j;
   const Slot* s = tab + slots[i];
   unsigned long long* q = reinterpret_cast<unsigned long long*>(out + (size_t)j * EDGE_REC_BYTES);
   q[0] = s->key;
@@ -687,7 +742,7 @@ __global__ void k_dist_edge_pack(const unsigned int* __restrict__ order, long lo
 
 extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_counts) {
   NEED_CTX(c);
-  if (world < 1 || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
+  if (world < 1 || world != c->world || !send_counts) return amg_fail(AMG_E_ARG, "bad world / send_counts");
   hipStream_t st = c->stream;
   if (c->dist_x) return edges_local_x(c, world, send_counts);
   for (int attempt = 0;; ++attempt) {
@@ -695,7 +750,8 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
     int r = bs_edges_pass(c, &which);
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 2 || attempt >= 8) {
-      if (which == 3) return amg_fail(AMG_E_OVERFLOW, "fingerprint collision: rebuild with another seed");
+      if (which == 3)
+        return amg_fail(AMG_E_COLLISION, "fingerprint collision: the merged build is repeated with the next seed");
       return r;
     }
     ++c->retries;
@@ -711,30 +767,18 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
                             c->edge_tab.as<Slot>(), c->s4.as<unsigned int>(), n,
                             c->dist_lcnt.as<unsigned int>(), 1));
   }
-  AMGCHK(c->dist_a.ensure((size_t)(n + 1) * sizeof(unsigned int) * 4 + 64));
-  unsigned int* dest = c->dist_a.as<unsigned int>();
-  unsigned int* idx = dest + (n + 1);
-  unsigned int* dest_sorted = idx + (n + 1);
-  unsigned int* order = dest_sorted + (n + 1);
-  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
+  Bucketing b;
+  AMGCHK(bucketing(c, n, &b));
   AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
   AMGCHK(c->dist_slot.ensure((size_t)(n + 1) * sizeof(unsigned int)));
   HIPCHK(hipMemcpyAsync(c->dist_first.p, c->s1.p, (size_t)n * sizeof(unsigned long long),
                         hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(c->dist_slot.p, c->s3.p, (size_t)n * sizeof(unsigned int),
                         hipMemcpyDeviceToDevice, st));
-  if (n > 0) {
-    hipLaunchKernelGGL(k_dist_edge_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
-                       c->dist_slot.as<unsigned int>(), n, c->edge_tab.as<Slot>(), (unsigned int)world,
-                       dest, idx, c->dist_cnt.as<unsigned long long>());
-    AMGCHK(prim_sort_u32_u32(c, dest, dest_sorted, idx, order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
-    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, dest_sorted, n, (unsigned int)world,
-                       c->dist_cnt.as<unsigned long long>());
-  }
-  std::vector<unsigned long long> h(world);
-  AMGCHK(fetch_counts(c, h.data(), world));
-  for (int i = 0; i < world; ++i) send_counts[i] = (int64_t)h[i];
-  return AMG_OK;
+  if (n > 0 && world > 1)
+    hipLaunchKernelGGL(k_dist_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
+                       c->dist_slot.as<unsigned int>(), n, c->edge_tab.as<Slot>(), (unsigned int)world, b.dest, b.idx);
+  return dest_counts(c, n, world, b, send_counts);
 }
 
 extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
@@ -742,40 +786,32 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
   const long long n = c->n_local_pairs;
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
-  unsigned int* order = c->dist_a.as<unsigned int>() + 3 * (n + 1);
-  if (c->dist_x) {
+  const unsigned int* order = send_order(c, n);
+  stage_begin(c, "merge_edge_pack");
+  if (c->dist_x)
     hipLaunchKernelGGL(k_xd_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
                        c->edge_tab.as<Slot16>(), c->x_eslot.as<unsigned int>(), c->x_efirst.as<unsigned int>(),
                        (long long)c->tok_base,
                        c->dist_lcnt.as<unsigned int>(), reinterpret_cast<unsigned char*>(send_buf));
-    AMGCHK(stream_wait(c));
-    return AMG_OK;
-  }
-  hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
-                     c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
-                     c->edge_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(),
-                     reinterpret_cast<unsigned char*>(send_buf));
-  AMGCHK(stream_wait(c));
+  else
+    hipLaunchKernelGGL(k_dist_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
+                       c->dist_slot.as<unsigned int>(), c->dist_first.as<unsigned long long>(),
+                       c->edge_tab.as<Slot>(), c->dist_lcnt.as<unsigned int>(),
+                       reinterpret_cast<unsigned char*>(send_buf));
+  stage_end(c);
   return AMG_OK;
 }
 
-extern "C" int amg_dist_edges_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int64_t* n_owned) {
+extern "C" int amg_dist_edges_reduce(amg_ctx* c, const void* recv_buf, int64_t n_recv, int32_t n_sources,
+                                     void* owned_out, int64_t* n_owned) {
   NEED_CTX(c);
-  if (!n_owned || (n_recv > 0 && !recv_buf)) return amg_fail(AMG_E_ARG, "bad arguments");
-  int r = reduce_records(c, recv_buf, n_recv, EDGE_REC_BYTES, 0, c->dist_min_edge, c->dist_owned, n_owned);
+  if (!n_owned || n_recv < 0) return amg_fail(AMG_E_ARG, "bad arguments");
+  stage_begin(c, "merge_edge_reduce");
+  const int r = reduce_records(c, recv_buf, n_recv, n_sources, EDGE_REC_BYTES, 0, c->dist_min_edge, owned_out,
+                               nullptr, n_owned);
+  stage_end(c);
   c->n_owned = *n_owned;
   return r;
-}
-
-extern "C" int amg_dist_edges_owned(amg_ctx* c, void* out) {
-  NEED_CTX(c);
-  if (c->n_owned > 0) {
-    if (!out) return amg_fail(AMG_E_ARG, "null out");
-    HIPCHK(hipMemcpyAsync(out, c->dist_owned.p, (size_t)c->n_owned * EDGE_REC_BYTES,
-                          hipMemcpyDeviceToDevice, c->stream));
-    AMGCHK(stream_wait(c));
-  }
-  return AMG_OK;
 }
 
 __global__ __launch_bounds__(256) void k_flag_dead_reads(const int* __restrict__ tok_node,
@@ -789,44 +825,51 @@ __global__ __launch_bounds__(256) void k_flag_dead_reads(const int* __restrict__
   if (__any(hit) && lane == 0) read_fix[r] = 1;
 }
 
-__global__ void k_global_pairs(const unsigned char* __restrict__ recs, const unsigned int* __restrict__ idx_sorted,
-                               long long n, unsigned long long* __restrict__ pkey,
+// edge classes in first-seen order (the input of the edge emission), straight from the gathered records
+__global__ void k_global_pairs(const unsigned char* __restrict__ recs, long long n_slots,
+                               const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
+                               unsigned long long* __restrict__ pkey, unsigned long long* __restrict__ pfirst,
                                unsigned int* __restrict__ pcnt) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long* q =
-      reinterpret_cast<const unsigned long long*>(recs + (size_t)idx_sorted[i] * EDGE_REC_BYTES);
+  long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots) return;
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(recs + (size_t)j * EDGE_REC_BYTES);
+  if (q[0] == 0ull) return;
+  const long long i = d_rank_of(q[1] >> 3, bits, prefix);
   pkey[i] = q[0];
+  pfirst[i] = q[1];
   pcnt[i] = (unsigned int)q[2];
 }
 
-extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_t n_total) {
+extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_t n_slots, int64_t n_total) {
   NEED_CTX(c);
   hipStream_t st = c->stream;
   const long long n = n_total;
+  if (n_slots < n || n < 0) return amg_fail(AMG_E_ARG, "bad record counts");
+  if (n > 0 && !all_records) return amg_fail(AMG_E_ARG, "null records");
+  stage_begin(c, "merge_edge_global");
   c->n_pairs = n;
   AMGCHK(bs_alloc_pairs(c, n));
-  if (n > 0) {
-    if (!all_records) return amg_fail(AMG_E_ARG, "null records");
-    AMGCHK(c->s1.ensure((size_t)(n + 1) * sizeof(unsigned long long)));
-    AMGCHK(c->s3.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-    AMGCHK(c->s4.ensure((size_t)(n + 1) * sizeof(unsigned int)));
-    const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
-    hipLaunchKernelGGL(k_rec_firsts, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, EDGE_REC_BYTES,
-                       c->s1.as<unsigned long long>(), c->s3.as<unsigned int>());
-    int efirst_bits = ilog2_ceil((uint64_t)(c->tok_total > 0 ? c->tok_total : 1) * 8 + 8) + 1;
-    AMGCHK(prim_sort_u64_u32(c, c->s1.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
-                             c->s3.as<unsigned int>(), c->s4.as<unsigned int>(), (size_t)n, efirst_bits));
-    hipLaunchKernelGGL(k_global_pairs, dim3(nblk(n, 256)), dim3(256), 0, st, recs, c->s4.as<unsigned int>(), n,
-                       c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+  const unsigned char* recs = reinterpret_cast<const unsigned char*>(all_records);
+  AMGCHK(d_rank_bitmap(c, recs, n_slots, n, EDGE_REC_BYTES, 3));
+  if (n_slots > 0)
+    hipLaunchKernelGGL(k_global_pairs, dim3(nblk(n_slots, 256)), dim3(256), 0, st, recs, (long long)n_slots,
+                       c->s1.as<unsigned int>(), c->s5.as<long long>(), c->pair_key.as<unsigned long long>(),
+                       c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>());
+  const long long words = ((c->tok_total > 0 ? c->tok_total : 1) >> 5) + 2;
+  unsigned long long set = 0;
+  {
+    FetchList l;
+    l.add(c->s5.as<long long>() + words);
+    AMGCHK(fetch(c, l, &set));
   }
+  stage_end(c);
+  if ((long long)set != n)
+    return amg_fail(AMG_E_DIST, "global edge table inconsistent: %lld records, %llu distinct first-seen positions", n, set);
   AMGCHK(bs_finish_from_pairs(c));
-  if (c->dist_min_node > 1 && c->n_reads > 0) {
+  if (c->dist_min_node > 1 && c->n_reads > 0)
     // fused filter: reads that lost a node join _readsToCorrect (remove_node_from_reads :442-461)
     hipLaunchKernelGGL(k_flag_dead_reads, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, c->tok_node.as<int>(),
                        c->read_off.as<long long>(), c->n_reads, c->read_fix.as<unsigned char>());
-    AMGCHK(stream_wait(c));
-  }
   c->dist_min_node = c->dist_min_edge = 1;
   c->built = true;
   c->node_hint = c->n_local_nodes > 256 ? c->n_local_nodes : 256;

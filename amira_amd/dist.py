@@ -3,8 +3,18 @@
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).  Every rank holds
 a contiguous shard of the reads in its Engine; `dist_build` produces on every rank the
 single-graph result (the graph GeneMerGraph would build from ALL reads) plus the node ids of
-the rank's own reads.  The device work is the ten `amg_dist_*` phases of libamg; the two
-all-to-alls and two all-gathers in between are issued here.
+the rank's own reads.  The device work is the eight `amg_dist_*` phases of libamg (include/amg.h);
+the collectives between them are issued here, ON THE ENGINE'S OWN STREAM, so device phases and
+collectives are ordered by the stream and the host only waits where it needs a number (the record
+counts that size the next buffer):
+
+    nodes   local -> pack ==all-to-all==> reduce ==all-gather of the survivors==>
+                                                 ==all-to-all back (one reply per record)==> global
+    edges   local -> pack ==all-to-all==> reduce ==all-gather==> global
+
+An owner reduces the records of its keys and answers every record with the key's global first-seen
+value; global node id = rank of first-seen = a prefix count over a bitmap of the global token space,
+which every rank computes from the gathered survivors — no rank sorts or hashes the global table.
 
 `steps()` is written as a generator that yields each exchange, so the same phase sequence
 is driven either by torch.distributed (`dist_build`) or, in one process, by the loop-back
@@ -14,40 +24,63 @@ import os
 
 import torch
 
+from ._ffi import AmgError
 
-def steps(engine, k, world, rank, token_base, token_total, min_node_cov=1, min_edge_cov=1):
+REPLY_BYTES = 8
+E_COLLISION = -8          # include/amg.h AMG_E_COLLISION: every rank repeats the build with the next seed
+MAX_ATTEMPTS = 4
+
+
+def steps(engine, k, world, rank, token_base, token_total, min_node_cov=1, min_edge_cov=1, attempt=0):
     """min_node_cov / min_edge_cov > 1 fuse filter_graph into the merge (amg_dist_set_filter).
-       yield ("a2a", send_tensor, send_counts, rec_bytes) -> (recv_tensor, n_recv)
-       yield ("ag", owned_tensor, n_owned, rec_bytes)      -> (all_tensor, n_total)"""
+       yield ("a2a", send, send_counts, rec_bytes)            -> (recv, recv_counts)
+       yield ("ag", owned, n_owned, rec_bytes)                -> (all_slots, n_slots, n_total)
+       yield ("back", replies, recv_counts, send_counts)      -> my_replies (one int64 per record sent)"""
     node_bytes, edge_bytes = engine.dist_record_bytes(k)
     dev = torch.device("cuda", engine.device)
     engine.dist_set_filter(min_node_cov, min_edge_cov)
     for what, rec_bytes in (("nodes", node_bytes), ("edges", edge_bytes)):
         if what == "nodes":
-            send_counts = engine.dist_nodes_local(k, token_base, token_total, world)
+            send_counts = engine.dist_nodes_local(k, token_base, token_total, world, attempt)
         else:
             send_counts = engine.dist_edges_local(world)
         send = torch.empty(max(sum(send_counts), 1) * rec_bytes, dtype=torch.uint8, device=dev)
         engine.dist_pack(what, send.data_ptr())
-        recv, n_recv = yield ("a2a", send, send_counts, rec_bytes)
-        n_owned = engine.dist_reduce(what, recv.data_ptr(), n_recv)
-        owned = torch.empty(max(n_owned, 1) * rec_bytes, dtype=torch.uint8, device=dev)
-        engine.dist_owned(what, owned.data_ptr())
-        everything, n_total = yield ("ag", owned, n_owned, rec_bytes)
-        engine.dist_global(what, everything.data_ptr(), n_total)
+        recv, recv_counts = yield ("a2a", send, send_counts, rec_bytes)
+        n_recv = sum(recv_counts)
+        n_sources = sum(1 for c in recv_counts if c > 0)
+        owned = torch.empty(max(n_recv, 1) * rec_bytes, dtype=torch.uint8, device=dev)
+        replies = None
+        if what == "nodes":
+            replies = torch.empty(max(n_recv, 1), dtype=torch.int64, device=dev)
+            n_owned = engine.dist_reduce(what, recv.data_ptr(), n_recv, n_sources, owned.data_ptr(), replies.data_ptr())
+        else:
+            n_owned = engine.dist_reduce(what, recv.data_ptr(), n_recv, n_sources, owned.data_ptr())
+        everything, n_slots, n_total = yield ("ag", owned, n_owned, rec_bytes)
+        if what == "nodes":
+            mine = yield ("back", replies, recv_counts, send_counts)
+            engine.dist_global(what, everything.data_ptr(), n_slots, n_total, mine.data_ptr())
+        else:
+            engine.dist_global(what, everything.data_ptr(), n_slots, n_total)
 
 
 class PeerFailed(RuntimeError):
-    """a rank's device phase failed (table overflow, fingerprint collision, bad input): the build is off on every rank"""
+    """a rank's device phase failed (table overflow, fingerprint collision, bad input): the build is off on every
+    rank.  codes[r] < 0 for the ranks that failed: -1 an error, -2 a merge-key collision (retry with the next seed)"""
 
-    def __init__(self, ranks):
+    def __init__(self, ranks, codes=None):
         super().__init__(f"merged build abandoned: device phase failed on rank(s) {ranks}")
         self.ranks = ranks
+        self.codes = codes or {r: -1 for r in ranks}
+
+    @property
+    def retry(self):
+        return bool(self.codes) and all(c == -2 for c in self.codes.values())
 
 
 def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     """variable-size all-to-all of whole records (works on device tensors with RCCL and on CPU
-    tensors with gloo): returns (recv tensor, number of records received)."""
+    tensors with gloo): returns (recv tensor, records received from every rank)."""
     import torch.distributed as dist
     dev = buf.device
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
@@ -55,17 +88,21 @@ def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.tolist()
     if min(recv_counts, default=0) < 0 or min(send_counts, default=0) < 0:   # see dist_build
-        raise PeerFailed([r for r, n in enumerate(recv_counts) if n < 0])
+        bad = {r: n for r, n in enumerate(recv_counts) if n < 0}
+        raise PeerFailed(sorted(bad), bad)
     n_send, n_recv = sum(send_counts), sum(recv_counts)
     recv = torch.empty(max(n_recv, 1) * rec_bytes, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(recv[: n_recv * rec_bytes], buf[: n_send * rec_bytes],
                            [n * rec_bytes for n in recv_counts], [n * rec_bytes for n in send_counts],
                            group=group)
-    return recv, n_recv
+    return recv, recv_counts
 
 
 def exchange_ag(buf, n_owned, rec_bytes, group=None):
-    """variable-size all-gather of whole records: returns (all records in rank order, total)."""
+    """variable-size all-gather of whole records as ONE equal-size all-gather: every rank contributes m = the largest
+    count, its unused tail zeroed (a record's first 8 bytes are never zero, so the consumer skips the padding; owners
+    are chosen by hash, so the counts are nearly equal and the padding is small).
+    Returns (world * m record slots, world * m, total records)."""
     import torch.distributed as dist
     dev = buf.device
     world = dist.get_world_size(group)
@@ -74,57 +111,103 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     dist.all_gather_into_tensor(allno, no, group=group)
     counts = allno.tolist()
     if min(counts) < 0:   # see dist_build
-        raise PeerFailed([r for r, n in enumerate(counts) if n < 0])
-    m = max(max(counts), 1)  # equal-size contributions: pad to the largest, compact afterwards
-    padded = torch.zeros(m * rec_bytes, dtype=torch.uint8, device=dev)
-    padded[: n_owned * rec_bytes] = buf[: n_owned * rec_bytes]
+        bad = {r: n for r, n in enumerate(counts) if n < 0}
+        raise PeerFailed(sorted(bad), bad)
+    m = max(max(counts), 1)
+    if n_owned == m and buf.numel() >= m * rec_bytes:
+        padded = buf[: m * rec_bytes]
+    else:
+        padded = torch.zeros(m * rec_bytes, dtype=torch.uint8, device=dev)
+        padded[: n_owned * rec_bytes] = buf[: n_owned * rec_bytes]
     out = torch.empty(world * m * rec_bytes, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, padded, group=group)
-    parts = [out[r * m * rec_bytes: r * m * rec_bytes + counts[r] * rec_bytes] for r in range(world)]
-    total = sum(counts)
-    everything = torch.cat(parts) if total else torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
-    return everything.contiguous(), total
+    return out, world * m, sum(counts)
+
+
+def exchange_back(replies, recv_counts, send_counts, group=None):
+    """the first all-to-all in reverse: one int64 per record goes back to the rank that sent the record"""
+    import torch.distributed as dist
+    n_send, n_recv = sum(send_counts), sum(recv_counts)
+    mine = torch.empty(max(n_send, 1), dtype=torch.int64, device=replies.device)
+    dist.all_to_all_single(mine[:n_send], replies[:n_recv], list(send_counts), list(recv_counts), group=group)
+    return mine
+
+
+def engine_stream(engine):
+    """the engine's own HIP stream as a torch stream: tensors made and collectives issued under
+    `torch.cuda.stream(engine_stream(e))` are ordered with the engine's kernels by the stream itself"""
+    return torch.cuda.ExternalStream(engine.stream(), device=torch.device("cuda", engine.device))
 
 
 def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1, always_exchange=False):
     """Collective: call on every rank with its own engine (reads already set).  At world size 1 the records
-    do not travel (always_exchange=True sends them through the collectives anyway: tests of the plumbing)."""
+    do not travel (always_exchange=True sends them through the collectives anyway: tests of the plumbing).
+    A merge-key collision between two gene-mers (AMG_E_COLLISION on the rank that owns the key) makes every
+    rank repeat the build with the next fingerprint seed."""
+    for attempt in range(MAX_ATTEMPTS):
+        try:
+            with torch.cuda.stream(engine_stream(engine)):
+                return _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchange, attempt)
+        except PeerFailed as e:
+            if not e.retry or attempt + 1 == MAX_ATTEMPTS:
+                raise
+        except AmgError as e:
+            if e.code != E_COLLISION or attempt + 1 == MAX_ATTEMPTS:
+                raise
+
+
+def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchange, attempt):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", engine.device)
-    n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)
-    gathered = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered, n_local, group=group)
-    tokens = gathered.tolist()
-    gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens), min_node_cov, min_edge_cov)
+    exchange = world > 1 or always_exchange or bool(os.environ.get("AMG_DIST_ALWAYS_EXCHANGE"))
+    if world > 1:
+        n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)
+        gathered = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, n_local, group=group)
+        tokens = gathered.tolist()
+    else:
+        tokens = [engine.sizes()[1]]
+    gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens), min_node_cov, min_edge_cov, attempt)
     reply = None
-    expected = iter(("a2a", "ag", "a2a", "ag"))
+    # the collectives in the order every rank issues them; the ones that open with a count exchange can carry a failure
+    expected = iter(("a2a", "ag", "back", "a2a", "ag"))
     while True:
         nxt = next(expected, None)
         try:
-            op, buf, arg, rec_bytes = gen.send(reply)
+            req = gen.send(reply)
         except StopIteration:
             return
-        except Exception:
+        except Exception as err:
             # A failing device phase must not leave the other ranks waiting in the collective they enter next:
             # take part in its count exchange with negative counts — every rank (this one included) then sees
-            # them and leaves before any data moves — and re-raise the local error.
-            if world > 1 and nxt is not None:
+            # them and leaves before any data moves — and re-raise the local error.  (-2: a merge-key collision,
+            # after which every rank retries with the next seed.)  No device phase runs between "ag" and "back".
+            if world > 1 and nxt in ("a2a", "ag"):
+                code = -2 if isinstance(err, AmgError) and err.code == E_COLLISION else -1
                 dummy = torch.zeros(1, dtype=torch.uint8, device=dev)
                 try:
                     if nxt == "a2a":
-                        exchange_a2a(dummy, [-1] * world, 1, group)
+                        exchange_a2a(dummy, [code] * world, 1, group)
                     else:
-                        exchange_ag(dummy, -1, 1, group)
+                        exchange_ag(dummy, code, 1, group)
                 except PeerFailed:
                     pass
             raise
-        if world == 1 and not (always_exchange or os.environ.get("AMG_DIST_ALWAYS_EXCHANGE")):  # nothing to exchange
-            n = sum(arg) if op == "a2a" else arg
-            reply = (buf, n)
-            continue
-        reply = (exchange_a2a if op == "a2a" else exchange_ag)(buf, arg, rec_bytes, group)
-        torch.cuda.current_stream(dev).synchronize()
+        op = req[0]
+        if not exchange:   # one rank: nothing travels
+            if op == "a2a":
+                reply = (req[1], list(req[2]))
+            elif op == "ag":
+                reply = (req[1], req[2], req[2])
+            else:
+                reply = req[1]
+        elif op == "a2a":
+            reply = exchange_a2a(req[1], req[2], req[3], group)
+        elif op == "ag":
+            reply = exchange_ag(req[1], req[2], req[3], group)
+        else:
+            reply = exchange_back(req[1], req[2], req[3], group)
 
 
 def dist_build_loopback(engines, k, min_node_cov=1, min_edge_cov=1):
@@ -132,7 +215,16 @@ def dist_build_loopback(engines, k, min_node_cov=1, min_edge_cov=1):
     plain tensor copies, the device phases are exactly those of dist_build."""
     world = len(engines)
     tokens = [e.sizes()[1] for e in engines]
-    gens = [steps(e, k, world, r, sum(tokens[:r]), sum(tokens), min_node_cov, min_edge_cov)
+    for attempt in range(MAX_ATTEMPTS):
+        try:
+            return _loopback_once(engines, k, world, tokens, min_node_cov, min_edge_cov, attempt)
+        except AmgError as e:
+            if e.code != E_COLLISION or attempt + 1 == MAX_ATTEMPTS:
+                raise
+
+
+def _loopback_once(engines, k, world, tokens, min_node_cov, min_edge_cov, attempt):
+    gens = [steps(e, k, world, r, sum(tokens[:r]), sum(tokens), min_node_cov, min_edge_cov, attempt)
             for r, e in enumerate(engines)]
     replies = [None] * world
     while True:
@@ -145,21 +237,38 @@ def dist_build_loopback(engines, k, min_node_cov=1, min_edge_cov=1):
         if all(q is None for q in reqs):
             return
         assert all(q is not None for q in reqs), "ranks fell out of step"
-        op, rec_bytes = reqs[0][0], reqs[0][3]
+        torch.cuda.synchronize()   # the engines' phases run on their own streams, the copies below on torch's
+        op = reqs[0][0]
+        dev = reqs[0][1].device
         if op == "a2a":
+            rec_bytes = reqs[0][3]
             for dst in range(world):
-                parts, n = [], 0
+                parts, counts = [], []
                 for src in range(world):
-                    _, buf, counts, _ = reqs[src]
-                    off = sum(counts[:dst]) * rec_bytes
-                    parts.append(buf[off: off + counts[dst] * rec_bytes])
-                    n += counts[dst]
-                recv = torch.cat(parts) if n else torch.empty(rec_bytes, dtype=torch.uint8, device=parts[0].device)
-                replies[dst] = (recv.contiguous(), n)
-        else:
-            parts = [q[1][: q[2] * rec_bytes] for q in reqs]
+                    _, buf, sc, _ = reqs[src]
+                    off = sum(sc[:dst]) * rec_bytes
+                    parts.append(buf[off: off + sc[dst] * rec_bytes])
+                    counts.append(sc[dst])
+                recv = torch.cat(parts) if sum(counts) else torch.empty(rec_bytes, dtype=torch.uint8, device=dev)
+                replies[dst] = (recv.contiguous(), counts)
+        elif op == "ag":
+            rec_bytes = reqs[0][3]
+            m = max(max(q[2] for q in reqs), 1)
+            out = torch.zeros(world * m * rec_bytes, dtype=torch.uint8, device=dev)
+            for r, q in enumerate(reqs):
+                out[r * m * rec_bytes: (r * m + q[2]) * rec_bytes] = q[1][: q[2] * rec_bytes]
             n = sum(q[2] for q in reqs)
             for dst in range(world):
-                everything = torch.cat(parts) if n else torch.empty(rec_bytes, dtype=torch.uint8, device=parts[0].device)
-                replies[dst] = (everything.contiguous(), n)
+                replies[dst] = (out, world * m, n)
+        else:   # "back": rank dst gets, from every owner src, the replies to the records it sent there
+            for dst in range(world):
+                parts = []
+                for src in range(world):
+                    _, rep, recv_counts, _ = reqs[src]
+                    off = sum(recv_counts[:dst])
+                    parts.append(rep[off: off + recv_counts[dst]])
+                mine = torch.cat(parts) if parts else torch.empty(1, dtype=torch.int64, device=dev)
+                if mine.numel() == 0:
+                    mine = torch.empty(1, dtype=torch.int64, device=dev)
+                replies[dst] = mine.contiguous()
         torch.cuda.synchronize()

@@ -252,10 +252,10 @@ class Engine:
     def dist_set_filter(self, min_node_cov, min_edge_cov):
         check(_ffi.lib.amg_dist_set_filter(self._h, int(min_node_cov), int(min_edge_cov)))
 
-    def dist_nodes_local(self, k, token_base, token_total, world):
+    def dist_nodes_local(self, k, token_base, token_total, world, attempt=0):
         counts = np.zeros(world, np.int64)
         check(_ffi.lib.amg_dist_nodes_local(self._h, int(k), int(token_base), int(token_total),
-                                            int(world), ptr(counts)))
+                                            int(world), int(attempt), ptr(counts)))
         return counts.tolist()
 
     def dist_edges_local(self, world):
@@ -263,19 +263,23 @@ class Engine:
         check(_ffi.lib.amg_dist_edges_local(self._h, int(world), ptr(counts)))
         return counts.tolist()
 
-    def _dist_call(self, name, *args):
-        check(getattr(_ffi.lib, name)(self._h, *args))
-
     def dist_pack(self, what, dev_ptr):
-        self._dist_call(f"amg_dist_{what}_pack", C.c_void_p(dev_ptr))
+        check(getattr(_ffi.lib, f"amg_dist_{what}_pack")(self._h, C.c_void_p(dev_ptr)))
 
-    def dist_reduce(self, what, dev_ptr, n_recv):
+    def dist_reduce(self, what, recv_ptr, n_recv, n_sources, owned_ptr, replies_ptr=None):
+        """owner side; returns the number of records written to owned_ptr (nodes also fill replies_ptr)"""
         n = C.c_int64(0)
-        self._dist_call(f"amg_dist_{what}_reduce", C.c_void_p(dev_ptr), int(n_recv), C.byref(n))
+        if what == "nodes":
+            check(_ffi.lib.amg_dist_nodes_reduce(self._h, C.c_void_p(recv_ptr), int(n_recv), int(n_sources),
+                                                 C.c_void_p(owned_ptr), C.c_void_p(replies_ptr), C.byref(n)))
+        else:
+            check(_ffi.lib.amg_dist_edges_reduce(self._h, C.c_void_p(recv_ptr), int(n_recv), int(n_sources),
+                                                 C.c_void_p(owned_ptr), C.byref(n)))
         return n.value
 
-    def dist_owned(self, what, dev_ptr):
-        self._dist_call(f"amg_dist_{what}_owned", C.c_void_p(dev_ptr))
-
-    def dist_global(self, what, dev_ptr, n_total):
-        self._dist_call(f"amg_dist_{what}_global", C.c_void_p(dev_ptr), int(n_total))
+    def dist_global(self, what, all_ptr, n_slots, n_total, replies_ptr=None):
+        if what == "nodes":
+            check(_ffi.lib.amg_dist_nodes_global(self._h, C.c_void_p(all_ptr), int(n_slots), int(n_total),
+                                                 C.c_void_p(replies_ptr)))
+        else:
+            check(_ffi.lib.amg_dist_edges_global(self._h, C.c_void_p(all_ptr), int(n_slots), int(n_total)))

@@ -53,7 +53,9 @@ enum {
                          /* (construct_gene_mer.py:23-25) -> AssertionError in Python  */
   AMG_E_OVERFLOW = -5,   /* internal table overflow that retries could not resolve     */
   AMG_E_NOMEM = -6,
-  AMG_E_DIST = -7        /* multi-GPU merge inconsistency                              */
+  AMG_E_DIST = -7,       /* multi-GPU merge inconsistency                              */
+  AMG_E_COLLISION = -8   /* merged build: two gene-mers share a 64-bit merge key; every rank
+                            repeats the build with attempt + 1 (amg_dist_nodes_local)    */
 };
 
 #define AMG_MAX_K 16
@@ -220,8 +222,15 @@ int amg_minhash(amg_ctx* ctx, const uint8_t* bases, const int64_t* seg_off, cons
  *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
  *      Every rank holds a contiguous shard of the reads.  The library runs the device phases;
  *      the CALLER moves the record buffers between ranks with RCCL (torch.distributed
- *      all_to_all_single / all_gather on the device pointers below), see amira_amd/dist.py.
- *      All buffers here are DEVICE pointers.  Record sizes: amg_dist_record_bytes. ------- */
+ *      all_to_all_single / all_gather_into_tensor on the device pointers below, issued on
+ *      amg_stream(ctx) so that nothing but the count read-backs waits on the host), see
+ *      amira_amd/dist.py.  All buffers here are DEVICE pointers the caller allocates; the phases
+ *      are asynchronous on the ctx's stream.  Record sizes: amg_dist_record_bytes; a record's
+ *      first 8 bytes (its merge key) are never zero, so zeroed padding can be told from records.
+ *
+ *      nodes:  local -> pack ==all-to-all==> reduce ==all-gather (survivors) + all-to-all back
+ *              (replies)==> global          edges: local -> pack ==all-to-all==> reduce
+ *              ==all-gather==> global ------------------------------------------------------- */
 int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes);
 /* Optional: fuse filter_graph(min_node_cov, min_edge_cov) (construct_graph.py:523-540) into
  * the NEXT merged build.  Owners then keep only nodes / edge classes that reach the thresholds,
@@ -232,24 +241,35 @@ int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes);
  * graph.  Thresholds reset to (1, 1) = keep everything after the build. */
 int amg_dist_set_filter(amg_ctx* ctx, uint32_t min_node_cov, uint32_t min_edge_cov);
 /* local node table of this shard; token_base = global index of the shard's first token,
- * token_total = tokens over all shards; send_counts[world] = records per destination rank */
+ * token_total = tokens over all shards; send_counts[world] = records per destination rank
+ * (owner = hash of the merge key mod world).  attempt = the ranks' common retry counter: 0, and
+ * + 1 on EVERY rank after any of them returned AMG_E_COLLISION (it selects the fingerprint seed
+ * of the merge keys, which all ranks must share). */
 int amg_dist_nodes_local(amg_ctx* ctx, int32_t k, int64_t token_base, int64_t token_total,
-                         int32_t world, int64_t* send_counts);
+                         int32_t world, int32_t attempt, int64_t* send_counts);
 int amg_dist_nodes_pack(amg_ctx* ctx, void* send_buf);              /* destination order   */
-/* after the all-to-all: reduce the received records (sum count, min first-seen) */
-int amg_dist_nodes_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int64_t* n_owned);
-int amg_dist_nodes_owned(amg_ctx* ctx, void* out_buf);              /* n_owned records     */
-/* after the all-gather of every rank's owned records: global node ids (rank of first-seen),
- * global node arrays on this rank, local windows mapped to global ids */
-int amg_dist_nodes_global(amg_ctx* ctx, const void* all_records, int64_t n_total);
-/* same five phases for the edge classes (keyed by global node ids); the last call also emits
- * the directed edges, components and adjacency lists, after which the ctx behaves as after
- * amg_build (global graph, local reads) */
+/* after the all-to-all: the n_recv records this rank owns the keys of, n_sources = ranks that
+ * contributed any (records of ONE rank are distinct keys: no reduction needed).  Equal keys are
+ * reduced (sum count, min first-seen); owned_out (room for n_recv records) receives the *n_owned
+ * reduced records that reach the fused filter's threshold — what this rank contributes to the
+ * all-gather; replies_out[n_recv] (8 bytes each) = for every received record, in the order
+ * received, its key's global first-seen value or ~0 when the filter dropped the key — what goes
+ * back to the senders (all-to-all with the split sizes of the first one swapped) */
+int amg_dist_nodes_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int32_t n_sources,
+                          void* owned_out, void* replies_out, int64_t* n_owned);
+/* after the all-gather and the reply exchange: all_records = n_slots record slots (equal-size
+ * contributions, unused tails zeroed) holding n_total records; my_replies = one 8-byte reply per
+ * record this rank sent, in send order.  Global node id = rank of first-seen (a prefix count over a
+ * bitmap of the global token space); global node arrays on this rank, local windows -> global ids */
+int amg_dist_nodes_global(amg_ctx* ctx, const void* all_records, int64_t n_slots, int64_t n_total,
+                          const void* my_replies);
+/* the same for the edge classes (keyed by global node ids; no replies); the last call also emits
+ * the directed edges, after which the ctx behaves as after amg_build (global graph, local reads) */
 int amg_dist_edges_local(amg_ctx* ctx, int32_t world, int64_t* send_counts);
 int amg_dist_edges_pack(amg_ctx* ctx, void* send_buf);
-int amg_dist_edges_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int64_t* n_owned);
-int amg_dist_edges_owned(amg_ctx* ctx, void* out_buf);
-int amg_dist_edges_global(amg_ctx* ctx, const void* all_records, int64_t n_total);
+int amg_dist_edges_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int32_t n_sources,
+                          void* owned_out, int64_t* n_owned);
+int amg_dist_edges_global(amg_ctx* ctx, const void* all_records, int64_t n_slots, int64_t n_total);
 
 /* ---- native front-end / write-back (host code, no GPU needed):
  *      gene-call JSON {"read": ["+geneA", "-geneB", ...]} as dumped / reloaded by the reference

@@ -34,12 +34,21 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from amira_amd.dist import exchange_a2a, exchange_ag
+    from amira_amd.dist import exchange_back
     counts, data = _payload(rank, world)
-    recv, n = exchange_a2a(torch.from_numpy(data.copy()), counts, REC)
+    recv, recv_counts = exchange_a2a(torch.from_numpy(data.copy()), counts, REC)
+    n = sum(recv_counts)
     owned = torch.from_numpy(data[: (rank + 2) * REC].copy()) if len(data) >= (rank + 2) * REC else torch.zeros(0, dtype=torch.uint8)
     n_owned = len(owned) // REC
-    everything, total = exchange_ag(owned if n_owned else torch.zeros(REC, dtype=torch.uint8), n_owned, REC)
-    q.put((rank, recv[: n * REC].numpy().copy(), n, everything[: total * REC].numpy().copy(), total, n_owned))
+    slots, n_slots, total = exchange_ag(owned if n_owned else torch.zeros(REC, dtype=torch.uint8), n_owned, REC)
+    # the padded all-gather: world equal parts of n_slots / world record slots, zero tails
+    m = n_slots // world
+    parts = slots.numpy().reshape(world, m * REC)
+    # one reply per received record travels back to its sender: reply = 1000 * owner + index at the owner
+    replies = torch.arange(max(n, 1), dtype=torch.int64) + 1000 * rank
+    mine = exchange_back(replies, recv_counts, counts)
+    q.put((rank, recv[: n * REC].numpy().copy(), n, parts.copy(), total, n_owned, recv_counts,
+           mine[: sum(counts)].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,8 +63,8 @@ def test_exchange_world2_gloo():
         p.start()
     got = {}
     for _ in range(world):
-        r, recv, n, everything, total, n_owned = q.get(timeout=120)
-        got[r] = (recv, n, everything, total, n_owned)
+        r, recv, n, parts, total, n_owned, recv_counts, mine = q.get(timeout=120)
+        got[r] = (recv, n, parts, total, n_owned, recv_counts, mine)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -72,7 +81,18 @@ def test_exchange_world2_gloo():
     owned = [payload[r][1][: got[r][4] * REC] for r in range(world)]
     for r in range(world):
         assert got[r][3] == sum(got[x][4] for x in range(world))
-        assert np.array_equal(got[r][2], np.concatenate(owned))
+        for x in range(world):   # rank x's part: its records, then zeros
+            part = got[r][2][x]
+            assert np.array_equal(part[: len(owned[x])], owned[x])
+            assert not part[len(owned[x]):].any()
+    # replies: rank r sent counts[d] records to owner d, which received them after those of the ranks below r
+    for r in range(world):
+        counts = payload[r][0]
+        want = []
+        for d in range(world):
+            before = sum(got[d][5][:r])
+            want += [1000 * d + before + i for i in range(counts[d])]
+        assert got[r][6].tolist() == want
 
 
 def _failing_worker(rank, world, port, q):

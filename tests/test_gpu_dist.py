@@ -84,6 +84,48 @@ def test_sharded_build_equals_unsharded(world, case):
         e.close()
 
 
+@pytest.mark.parametrize("thr", [None, (3, 1)])
+def test_rank_without_reads(thr):
+    """a rank that holds no reads at all (and one that holds a single short read) takes part in every exchange and
+    ends with the whole graph"""
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    k = 5
+    vocab, toks, offs, _ = tokenize(reads)
+    R = len(offs) - 1
+    bounds = [0, 0, R // 2, R // 2, R]          # ranks 0 and 2 are empty
+    ref = Engine(0)
+    ref.set_reads(toks, offs, vocab.two_v)
+    ref.build(k)
+    if thr:
+        ref.filter(*thr)
+    engines = []
+    for r in range(len(bounds) - 1):
+        lo, hi = bounds[r], bounds[r + 1]
+        e = Engine(0)
+        e.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
+        engines.append(e)
+    dist_build_loopback(engines, k, *(thr or (1, 1)))
+    if thr:
+        want = live_state(ref)
+        for r, e in enumerate(engines):
+            got = live_state(e)
+            lo, hi = bounds[r], bounds[r + 1]
+            for key in ("tokens", "coverage", "first_dir", "src", "tgt", "sdir", "tdir", "ecov"):
+                assert np.array_equal(got[key], want[key]), key
+            assert np.array_equal(got["tok_node"], want["tok_node"][offs[lo]:offs[hi]])
+            assert np.array_equal(got["to_correct"], want["to_correct"][lo:hi])
+    else:
+        want = graph_state(ref)
+        want_node = ref.read_nodes()[0]
+        for r, e in enumerate(engines):
+            assert_same_graph(graph_state(e), want)
+            assert np.array_equal(e.read_nodes()[0], want_node[offs[bounds[r]]:offs[bounds[r + 1]]])
+    for e in engines + [ref]:
+        e.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_sweep_equals_unsharded(world):
     """build -> filter -> correct -> build -> clip -> correct -> build with every build merged
@@ -251,7 +293,7 @@ def test_sharded_sweep_with_fused_first_filter():
         e.close()
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, out_dir, empty_rank=None):
     """one rank of a REAL multi-process merged build over RCCL (needs >= world GPUs on the node)"""
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -272,7 +314,7 @@ def _rccl_worker(rank, world, port, out_dir):
     from amira_amd.dist import dist_build
     reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
     vocab, toks, offs, _ = tokenize(reads)
-    t, o, lo, hi = make_shards(toks, offs, world)[rank]
+    t, o, lo, hi = _rccl_shards(toks, offs, world, empty_rank)[rank]
     eng = Engine(rank)
     eng.set_reads(t, o, vocab.two_v)
     dist_build(eng, 5)
@@ -284,7 +326,19 @@ def _rccl_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_dist_build_over_rccl_two_processes(tmp_path):
+def _rccl_shards(toks, offs, world, empty_rank):
+    """shards of the two-process test; empty_rank: that rank holds no reads, the others share them"""
+    if empty_rank is None:
+        return make_shards(toks, offs, world)
+    rest = make_shards(toks, offs, world - 1)
+    R = len(offs) - 1
+    edge = 0 if empty_rank == 0 else rest[empty_rank - 1][3]
+    rest.insert(empty_rank, (toks[:0], offs[:1] - offs[0], edge, edge))
+    return rest
+
+
+@pytest.mark.parametrize("empty_rank", [None, 1])
+def test_dist_build_over_rccl_two_processes(tmp_path, empty_rank):
     """two processes, two GPUs, RCCL all-to-all / all-gather between them: every rank must end with the graph the
     unsharded engine builds (skipped on a single-GPU box; the driver's multi-GPU tier runs it)"""
     import socket
@@ -296,7 +350,7 @@ def test_dist_build_over_rccl_two_processes(tmp_path):
     world = 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, str(tmp_path), empty_rank)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -315,10 +369,10 @@ def test_dist_build_over_rccl_two_processes(tmp_path):
     ref.build(5)
     want = graph_state(ref)
     ref_nodes = ref.read_nodes()[0]
-    bounds = shard_bounds(len(offs) - 1, world)
+    shards = _rccl_shards(toks, offs, world, empty_rank)
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         for key in want:
             assert np.array_equal(got[key], want[key]), (r, key)
-        assert np.array_equal(got["tok_node"], ref_nodes[offs[bounds[r]]:offs[bounds[r + 1]]])
+        assert np.array_equal(got["tok_node"], ref_nodes[offs[shards[r][2]]:offs[shards[r][3]]])
     ref.close()
