@@ -93,6 +93,7 @@ def _load():
         "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
         "amg_calls_free": (C.c_int, [P]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+        "amg_set_timing": (C.c_int, [P, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here == header / library mismatch

@@ -56,6 +56,13 @@ extern "C" int amg_last_timings(amg_ctx* c, const char** names, float* ms, int c
   return n;
 }
 
+extern "C" int amg_set_timing(amg_ctx* c, int on) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  c->timing = on != 0;
+  if (!c->timing) stages_reset(c);
+  return AMG_OK;
+}
+
 // ------------------------------------------------------------------ clear_many
 struct ClearArgs {
   void* p[8];

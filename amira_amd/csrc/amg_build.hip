@@ -413,24 +413,49 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
       if (tail_all) atomicAdd(&out[id], 1u);
     }
   };
-  // one block per CU (the counters fill the LDS): four loads in flight per thread make up for
-  // the low occupancy
-  long long t = (long long)blockIdx.x * 1024 + threadIdx.x;
-  for (; t + 7 * stride < n; t += 8 * stride) {
-    int v[8];
+  // one block per CU (the counters fill the LDS), so the bytes in flight have to come from the threads themselves:
+  // 16-byte loads, four of them in flight per thread (64 MB chip-wide; with 4-byte loads the sweep ran at 2.2 TB/s)
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  const long long n4 = ((reinterpret_cast<uintptr_t>(ids) & 15) == 0) ? (n >> 2) : 0;
+  i4* ids4 = reinterpret_cast<i4*>(ids);
+  long long q = (long long)blockIdx.x * 1024 + threadIdx.x;
+  auto tally4 = [&](i4 x, long long qi) {
+    if (GATHER) {
+      i4 y;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = GATHER ? ids[t + j * stride] : __builtin_nontemporal_load(ids + t + j * stride);
+      for (int j = 0; j < 4; ++j) {
+        int id = x[j];
+        if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);
+        y[j] = id < 0 ? -1 : (remap ? remap[id] : tab[id].id);
+      }
+      ids4[qi] = y;
+      x = y;
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tally(v[j], t + j * stride);
+    for (int j = 0; j < 4; ++j) {
+      int id = x[j];
+      if (!GATHER && strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);
+      if (id < 0) continue;
+      const long long rel = (long long)id - lo;
+      if (rel < 0) continue;
+      if (rel < HOT_IDS) {
+        atomicAdd(&s_cnt[rel], 1u);
+      } else {
+        ++beyond;
+        if (tail_all) atomicAdd(&out[id], 1u);
+      }
+    }
+  };
+  for (; q + 3 * stride < n4; q += 4 * stride) {
+    i4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = GATHER ? ids4[q + j * stride] : __builtin_nontemporal_load(ids4 + q + j * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tally4(v[j], q + j * stride);
   }
-  for (; t + 3 * stride < n; t += 4 * stride) {
-    const int i0 = ids[t], i1 = ids[t + stride], i2 = ids[t + 2 * stride], i3 = ids[t + 3 * stride];
-    tally(i0, t);
-    tally(i1, t + stride);
-    tally(i2, t + 2 * stride);
-    tally(i3, t + 3 * stride);
-  }
-  for (; t < n; t += stride) tally(ids[t], t);
+  for (; q < n4; q += stride) tally4(GATHER ? ids4[q] : __builtin_nontemporal_load(ids4 + q), q);
+  // what the 16-byte chunks leave (at most three ids; everything when the array is not 16-byte aligned)
+  for (long long t = 4 * n4 + (long long)blockIdx.x * 1024 + threadIdx.x; t < n; t += stride) tally(ids[t], t);
   for (int d = 32; d > 0; d >>= 1) beyond += __shfl_down(beyond, d, 64);
   if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
   if (tail_all && blockIdx.x == 0 && threadIdx.x == 0) state[COUNT_MAX_SWEEPS + sweep] = 1ull;
@@ -454,20 +479,31 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   ClearList cl;
   cl.add(out, (size_t)(n_ids + 1) * sizeof(unsigned int));
   const bool fresh = !c->cnt_state.p || c->cnt_hint_reset;
-  AMGCHK(c->cnt_state.ensure((2 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
+  // per kind (nodes / edge classes) a block of 2 * COUNT_MAX_SWEEPS state words; the two hints after both blocks
+  AMGCHK(c->cnt_state.ensure((4 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
+  if (fresh) c->cnt_sweeps[0] = c->cnt_sweeps[1] = COUNT_MAX_SWEEPS;
   c->cnt_hint_reset = false;
-  unsigned long long* state = c->cnt_state.as<unsigned long long>();
-  unsigned long long* hint = state + 2 * COUNT_MAX_SWEEPS + 2 * ((kind == 1 || kind == 3) ? 1 : 0);
+  const int kslot = (kind == 1 || kind == 3) ? 1 : 0;
+  unsigned long long* state = c->cnt_state.as<unsigned long long>() + kslot * 2 * COUNT_MAX_SWEEPS;
+  unsigned long long* hint = c->cnt_state.as<unsigned long long>() + 4 * COUNT_MAX_SWEEPS + 2 * kslot;
   const int strip = kind >= 2 ? 1 : 0;
-  cl.add(state, (fresh ? 2 * COUNT_MAX_SWEEPS + 4 : 2 * COUNT_MAX_SWEEPS) * sizeof(unsigned long long));
+  cl.add(state, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long));
+  if (fresh) cl.add(c->cnt_state.as<unsigned long long>() + 4 * COUNT_MAX_SWEEPS, 4 * sizeof(unsigned long long));
   AMGCHK(clear_many(c, cl));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
   if (ranges > COUNT_MAX_SWEEPS) ranges = COUNT_MAX_SWEEPS;
+  // no more sweeps than the previous count of this kind made use of (count_learn): the last one launched finishes
+  // with global atomics whatever is left, so too few sweeps cost time, never counts
+  if (ranges > c->cnt_sweeps[kslot]) ranges = c->cnt_sweeps[kslot];
   // every block flushes up to HOT_IDS counters with global atomics at the end of a sweep: give a
   // block at least twice that many ids to count (small inputs: fewer blocks, not a shorter sweep)
   long long want_blocks = (n + 2 * HOT_IDS - 1) / (2 * HOT_IDS);
   unsigned int blocks = (unsigned int)(want_blocks < 1 ? 1 : (want_blocks < 256 ? want_blocks : 256));
+  if (const char* e = getenv("AMG_COUNT_BLOCKS")) {  // A/B switch
+    const unsigned int b = (unsigned int)atoi(e);
+    if (b >= 1 && b < blocks) blocks = b;
+  }
   for (long long r = 0; r < ranges; ++r) {
     const long long lo = r * HOT_IDS;
     const int last = (r == ranges - 1) ? 1 : 0;
@@ -777,12 +813,23 @@ int bs_finish_from_pairs(amg_ctx* c) {
                        c->edge_tdir.as<signed char>(), c->edge_cov.as<unsigned int>(),
                        c->edge_alive.as<unsigned char>());
   }
-  {  // the build's final synchronisation
+  {  // the build's final synchronisation; the done flags of its counting sweeps ride along
     FetchList l;
     l.add(P > 0 ? static_cast<const void*>(base + P) : c->status.p);
-    unsigned long long v = 0;
-    AMGCHK(fetch(c, l, &v));
-    if (P > 0) total = (long long)v;
+    const bool learn = c->cnt_state.p && !c->cnt_hint_reset;
+    if (learn)
+      for (int s = 0; s < 2; ++s)
+        l.add_words(c->cnt_state.as<unsigned long long>() + s * 2 * COUNT_MAX_SWEEPS + COUNT_MAX_SWEEPS, COUNT_MAX_SWEEPS);
+    unsigned long long v[1 + 2 * COUNT_MAX_SWEEPS] = {0};
+    AMGCHK(fetch(c, l, v));
+    if (P > 0) total = (long long)v[0];
+    if (learn)
+      for (int s = 0; s < 2; ++s) {
+        int used = COUNT_MAX_SWEEPS;
+        for (int q = COUNT_MAX_SWEEPS - 1; q >= 0; --q)
+          if (v[1 + s * COUNT_MAX_SWEEPS + q]) used = q + 1;
+        c->cnt_sweeps[s] = used;
+      }
   }
   c->n_edges = total;
   stage_end(c);

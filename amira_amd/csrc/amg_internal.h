@@ -247,6 +247,7 @@ struct amg_ctx {
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
   DevBuf cnt_state;    // counting sweeps: per-sweep left-over counts and done flags + the hints
   bool cnt_hint_reset = false;
+  int cnt_sweeps[2] = {4, 4};  // sweeps the last node / edge-class count made use of (count_ids launches no more)
 
   std::vector<StageTime> stages;
   bool timing = true;

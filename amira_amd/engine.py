@@ -88,6 +88,10 @@ class Engine:
     def stream(self):
         return _ffi.lib.amg_stream(self._h)
 
+    def set_timing(self, on):
+        """per-stage HIP-event timing (two events per stage, ~5 us of stream idle each): on by default"""
+        check(_ffi.lib.amg_set_timing(self._h, 1 if on else 0))
+
     def timings(self):
         names = (C.c_char_p * 64)()
         ms = (C.c_float * 64)()

@@ -294,6 +294,10 @@ int amg_calls_free(amg_calls* calls);
 /* ---- per-stage device time of the last call, for bench.py ------------------------- */
 /* names[i] points at static strings; returns the number of stages (<= cap). */
 int amg_last_timings(amg_ctx* ctx, const char** names, float* ms, int cap);
+/* Stage timing brackets every stage with two HIP events (~5 us of stream idle each, ~90 per cleaning
+ * sweep): on by default (AMG_TIMING=0 in the environment turns it off), switched per ctx here.  With it
+ * off amg_last_timings returns 0 stages. */
+int amg_set_timing(amg_ctx* ctx, int on);
 
 #ifdef __cplusplus
 }
