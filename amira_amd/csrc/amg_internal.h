@@ -243,6 +243,14 @@ struct amg_ctx {
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
   DevBuf nw_big;       // global scratch of the general position carry-over kernel (long reads)
   DevBuf gap_rec;      // per gapped read: the record k_corr_gapped_fast starts from
+  // path memo of the re-threading (amg_passes.hip: k_gap_queries / k_gap_dfs)
+  DevBuf gm_mask;      // uint64[n_reads]   live-window mask per read (k_corr_classify)
+  DevBuf gm_tab;       // uint64[slots]     question table: (start node, direction, end node)
+  DevBuf gm_res;       // int4  [slots]     per question {pool offset, ints, paths}
+  DevBuf gm_list;      // int32 [questions] occupied slots
+  DevBuf gm_q;         // int32 [gapped reads x GF_MAXGAP] question slot per None run
+  DevBuf gm_pool;      // int32 path records
+  DevBuf gm_ctr;       // uint64[4]         {questions listed, pool ints used}
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
   DevBuf cnt_state;    // counting sweeps: per-sweep left-over counts and done flags + the hints

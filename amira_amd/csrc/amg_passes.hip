@@ -535,6 +535,8 @@ struct CorrArgs {
   // per read
   unsigned int* gflag;            // 1: the read is re-threaded (RC_GAPPED)
   unsigned long long* max_bound;  // largest `bound` of a re-threaded read
+  unsigned long long* lmask;      // live-window mask of a flagged read with <= 64 windows (0 otherwise)
+  unsigned long long* n_runs;     // None runs over all re-threaded reads: 16 partial sums, 16 words apart
   unsigned char* cls;
   int* r_start;
   int* r_end;
@@ -646,7 +648,6 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
       live = li;
     }
   }
-  if (!have) return;
   const long long L = n + a.k - 1;
   unsigned char cls;
   int start = 0, end = -1;
@@ -671,20 +672,27 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
       bound = b1 > (unsigned int)L ? b1 : (unsigned int)L;  // may fall back to the original genes
     }
   }
-  a.cls[r] = cls;
-  a.r_start[r] = start;
-  a.r_end[r] = end;
-  a.bound[r] = bound;    // temp space: only re-threaded reads are staged
-  a.new_len[r] = len_out;
-  a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
-  // largest staging bound of a re-threaded read: one atomic per wave, and only when it raises a plain (possibly
-  // stale, never too large) read of the maximum
-  unsigned int mb = cls == RC_GAPPED ? bound : 0u;
+  if (have) {
+    a.cls[r] = cls;
+    a.r_start[r] = start;
+    a.r_end[r] = end;
+    a.bound[r] = bound;    // temp space: only re-threaded reads are staged
+    a.new_len[r] = len_out;
+    a.gflag[r] = cls == RC_GAPPED ? 1u : 0u;  // list of re-threaded reads (scan input)
+    a.lmask[r] = (cls == RC_GAPPED && n <= 64) ? lv : 0ull;
+  }
+  // largest staging bound of a re-threaded read and the number of None runs: one atomic per wave each (the maximum
+  // only when it raises a plain — possibly stale, never too large — read of it); lanes past the last read hold zeros
+  unsigned int mb = (have && cls == RC_GAPPED) ? bound : 0u;
+  unsigned int nr = (have && cls == RC_GAPPED) ? runs : 0u;
   for (int d = 32; d > 0; d >>= 1) {
     const unsigned int o = (unsigned int)__shfl_xor((int)mb, d, 64);
     mb = mb > o ? mb : o;
+    nr += (unsigned int)__shfl_xor((int)nr, d, 64);
   }
   if (lane == 0 && (unsigned long long)mb > *a.max_bound) atomicMax(a.max_bound, (unsigned long long)mb);
+  // (16 counter words 128 bytes apart: one word takes ~90 atomics per microsecond, a wave per 64 reads asks more)
+  if (lane == 0 && nr) atomicAdd(a.n_runs + 16 * (blockIdx.x & 15), (unsigned long long)nr);
 }
 
 // ---- gapped reads
@@ -786,6 +794,8 @@ struct GapIter {
 struct __attribute__((aligned(16))) GapRec {
   int r, L0, start, end;
   long long t0, dst;
+  unsigned long long mask;  // live windows of a read with <= 64 windows (k_corr_classify), 0 otherwise
+  long long pad;
 };
 
 struct GapArgs {
@@ -803,6 +813,11 @@ struct GapArgs {
   unsigned char* final_cls;
   unsigned char* need_slow;  // per gapped read: 1 = the wave-per-read fast kernel gave up
   int ablate;                // timing experiments (AMG_GAP_ABLATE): 1 stop before the DFS, 2 stop after it
+  // path memo (k_gap_queries / k_gap_dfs): the same (start node, direction, end node) question is asked by every read
+  // that lost the same stretch of the genome — about nine times each at 3 000x depth — and answered once
+  const int* gq;             // per gapped read GF_MAXGAP query slots in run order; [0] < 0: no memo for this read
+  const int4* qres;          // per query slot {pool offset, ints, paths, -}; ints < 0: the answer did not fit
+  const int* qpool;          // [run = 0, len, nodes, dirs] records in DFS order
 };
 
 // build candidate `combo` (mixed radix over the gaps' path choices) into (out_node, out_dir);
@@ -1074,6 +1089,118 @@ __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distan
   return overflow ? -1 : n_paths;
 }
 
+// ---- path memo.  k_gap_queries: one LANE per re-threaded read walks the read's None runs on its live-window mask
+// (k_corr_classify kept it), looks up the three node words of each run and enters the question (start node, start
+// direction, end node) into an open-addressing table; the slot index is the question's id, the lane that created
+// the slot lists it.  k_gap_dfs answers every listed question once (the wave-cooperative search below, result copied
+// to a global pool); k_corr_gapped_fast copies answers instead of searching.  Reads with more than 64 windows or
+// more than GF_MAXGAP runs take no part (gq[0] = -1: they search for themselves, as before).
+#define GM_INLINE 64
+__device__ __forceinline__ unsigned long long gap_query_key(int s, int sdir, int e) {
+  return (1ull << 63) | ((unsigned long long)(unsigned int)s << 32) | ((unsigned long long)(unsigned int)e << 1) |
+         (sdir == 1 ? 1ull : 0ull);
+}
+
+__global__ __launch_bounds__(256) void k_gap_queries(const GapRec* __restrict__ rec, long long n_gapped, int k,
+                                                      const int* __restrict__ tok_node,
+                                                      const signed char* __restrict__ tok_dir,
+                                                      unsigned long long* qtab, unsigned int qmask,
+                                                      unsigned long long* ctr /*[0] questions listed*/,
+                                                      int* __restrict__ qlist, int* __restrict__ gq,
+                                                      unsigned long long* status) {
+  // the questions this workgroup creates are collected in LDS and listed with ONE atomicAdd (a counter word takes
+  // ~90 returning atomics per microsecond; there are ~100 k questions)
+  __shared__ int s_list[256 * GF_MAXGAP];
+  __shared__ unsigned int s_n;
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi < n_gapped) {
+    const GapRec q = rec[gi];
+    int* my = gq + gi * GF_MAXGAP;
+    const int nwin = q.L0 - k + 1;
+    const unsigned long long lv = q.mask;
+    // a None run ends at window i when i is not live and i + 1 is, first <= i < last (k_corr_classify's `runs`)
+    const int first = q.start, last = q.end;
+    const unsigned long long inside =
+        (last >= 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << (first & 63)) - 1ull);
+    unsigned long long ends = ~lv & inside & (lv >> 1);
+    if (nwin > 64 || lv == 0ull || __popcll(ends) > GF_MAXGAP) {
+      my[0] = -1;
+    } else {
+      int j = 0;
+      while (ends) {
+        const int i = __ffsll((long long)ends) - 1;
+        ends &= ends - 1ull;
+        const int ps = 63 - __clzll((long long)(lv & ((1ull << i) - 1ull)));  // the live window before the run
+        const int pe = i + 1;
+        const unsigned long long key = gap_query_key(tok_node[q.t0 + ps], (int)tok_dir[q.t0 + ps], tok_node[q.t0 + pe]);
+        unsigned int idx = (unsigned int)mix64(key) & qmask;
+        int slot = -1;
+        for (unsigned int probes = 0; probes <= qmask; ++probes) {
+          unsigned long long cur = qtab[idx];  // plain: a stale view can only show "empty", which the CAS settles
+          if (cur == 0ull) {
+            cur = atomicCAS(qtab + idx, 0ull, key);
+            if (cur == 0ull) {
+              s_list[atomicAdd(&s_n, 1u)] = (int)idx;
+              cur = key;
+            }
+          }
+          if (cur == key) {
+            slot = (int)idx;
+            break;
+          }
+          idx = (idx + 1) & qmask;
+        }
+        if (slot < 0) status[ST_OVERFLOW] = 7;  // the table holds two slots per run: cannot fill up
+        my[j++] = slot;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int n = s_n;
+  if (n == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(ctr, (unsigned long long)n);
+  __syncthreads();
+  for (unsigned int i = threadIdx.x; i < n; i += 256) qlist[s_base + i] = s_list[i];
+}
+
+__global__ __launch_bounds__(64, 8) void k_gap_dfs(GView g, const int* __restrict__ qlist, long long n_queries,
+                                                    const unsigned long long* __restrict__ qtab,
+                                                    unsigned long long* pool_used, unsigned long long pool_cap,
+                                                    int* __restrict__ qpool, int4* __restrict__ qres) {
+  __shared__ int s_pool[GF_POOL];
+  __shared__ int s_used;
+  const long long qi = blockIdx.x;
+  if (qi >= n_queries) return;
+  const int lane = threadIdx.x;
+  const int slot = qlist[qi];
+  const unsigned long long key = qtab[slot];
+  const int s = (int)((key >> 32) & 0x7fffffffull), e = (int)((key >> 1) & 0x7fffffffull);
+  const int sdir = (key & 1ull) ? 1 : -1;
+  if (lane == 0) s_used = 0;
+  wave_sync();
+  const int np = dfs_paths_wave(g, s, sdir, e, 2 * g.k, 0, s_pool, &s_used, lane);
+  wave_sync();
+  const int used = s_used;
+  int4 res = make_int4(0, -1, 0, 0);
+  if (np >= 0) {
+    // an answer of up to GM_INLINE ints lives in the question's own stretch of the pool (a few paths of ~7 nodes: nearly
+    // all of them); longer ones take space behind those stretches, one atomicAdd each
+    unsigned long long off = (unsigned long long)qi * GM_INLINE;
+    if (used > GM_INLINE) {
+      if (lane == 0) off = (unsigned long long)n_queries * GM_INLINE + atomicAdd(pool_used, (unsigned long long)used);
+      off = (unsigned long long)bcast_i64((long long)off, 0);
+    }
+    if (off + (unsigned long long)used <= pool_cap) {
+      for (int i = lane; i < used; i += 64) qpool[off + i] = s_pool[i];
+      res = make_int4((int)off, used, np, 0);
+    }
+  }
+  if (lane == 0) qres[slot] = res;
+}
+
 // GF_WPB reads (waves) per workgroup.  The LDS of a workgroup is held until its LAST wave is done
 // and reads differ a lot in work (runs, paths): with four waves per workgroup the kernel ran at
 // half its occupancy limit waiting for stragglers (2.05 ms; 1.83 ms with two, 1.80 ms with one).
@@ -1113,6 +1240,8 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
     Dr[i] = a.tok_dir[t0 + i];
   }
   for (int i = lane; i < L0; i += 64) TK[i] = a.tokens[t0 + i];
+  // the read's question slots in the path memo ([0] < 0: none; entries past its runs are not initialised)
+  const int myslot = (A.gq && lane < GF_MAXGAP) ? A.gq[gi * GF_MAXGAP + lane] : -1;
   if (lane == 0) s_used[wv] = 0;
   wave_sync();
   // ---- None runs in [start, end] (identify_path_terminals), in read order
@@ -1139,14 +1268,45 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
   }
   wave_sync();
   if (AMG_EXPERIMENTS && A.ablate == 1) return;
-  // ---- one wave-cooperative DFS per run, runs in read order
+  // ---- the paths of every run, runs in read order: copied from the memo when the read's questions were entered
+  // there (k_gap_queries) — lane q looks run q up, then all copies are in flight together — otherwise one
+  // wave-cooperative DFS per run
+  const bool memo = __builtin_amdgcn_readfirstlane(myslot) >= 0;
   bool bad = false;
-  for (int q = 0; q < n_gaps && !bad; ++q) {
-    const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
-    const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane,
-                                  (AMG_EXPERIMENTS && A.ablate == 3) ? A.status + 8 : nullptr);
-    if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
-    bad = np < 0;
+  if (memo) {
+    int4 res = make_int4(0, 0, 0, 0);
+    if (lane < n_gaps) res = A.qres[myslot];
+    const int len = res.y > 0 ? res.y : 0;
+    int at = len;  // inclusive prefix over the runs (lanes < n_gaps <= 16)
+#pragma unroll
+    for (int d = 1; d < GF_MAXGAP; d <<= 1) {
+      const int o = __shfl_up(at, d, 64);
+      if (lane >= d) at += o;
+    }
+    const int total = __shfl(at, n_gaps - 1, 64);
+    at -= len;
+    bad = __any(res.y < 0) || total > GF_POOL;
+    if (!bad) {
+      for (int q = 0; q < n_gaps; ++q) {
+        const int src = __shfl(res.x, q, 64), ln = __shfl(len, q, 64), dst0 = __shfl(at, q, 64);
+        for (int i = lane; i < ln; i += 64) POOL[dst0 + i] = A.qpool[src + i];
+      }
+      wave_sync();
+      if (lane < n_gaps) {
+        for (int o = at; o < at + len; o += 2 + 2 * POOL[o + 1]) POOL[o] = lane;  // the records' run field
+        GAP[3 * lane + 2] = res.z;
+      }
+      if (lane == 0) s_used[wv] = total;
+      wave_sync();
+    }
+  } else {
+    for (int q = 0; q < n_gaps && !bad; ++q) {
+      const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
+      const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane,
+                                    (AMG_EXPERIMENTS && A.ablate == 3) ? A.status + 8 : nullptr);
+      if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
+      bad = np < 0;
+    }
   }
   if (bad) {
     if (lane == 0) A.need_slow[gi] = 1;
@@ -1744,7 +1904,8 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
 __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const long long* __restrict__ pos,
                                  long long n_reads, int* __restrict__ out, const long long* __restrict__ read_off,
                                  const int* __restrict__ r_start, const int* __restrict__ r_end,
-                                 const long long* __restrict__ tmp_off, GapRec* __restrict__ rec) {
+                                 const long long* __restrict__ tmp_off, const unsigned long long* __restrict__ lmask,
+                                 GapRec* __restrict__ rec) {
   long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads || !flag[r]) return;
   const long long gi = pos[r];
@@ -1757,6 +1918,8 @@ __global__ void k_scatter_gapped(const unsigned int* __restrict__ flag, const lo
   q.start = r_start[r];
   q.end = r_end[r];
   q.dst = tmp_off[r];
+  q.mask = lmask[r];
+  q.pad = 0;
   rec[gi] = q;
 }
 
@@ -1887,14 +2050,20 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
 
   stage_begin(c, "correct_classify");
   unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
+  AMGCHK(c->gm_mask.ensure(per_read * sizeof(unsigned long long)));
+  AMGCHK(c->gm_ctr.ensure((256 + 16) * sizeof(unsigned long long)));
+  unsigned long long* n_runs_d = c->gm_ctr.as<unsigned long long>() + 16;  // [16 x 16 words]; [0..16) belong to the memo
   {
     ClearList cl;
     cl.add(bound, per_read * sizeof(unsigned int) * 3);
     cl.add(mx, sizeof(unsigned long long));
+    cl.add(n_runs_d, 256 * sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
   }
   a.gflag = flag;
   a.max_bound = mx;
+  a.lmask = c->gm_mask.as<unsigned long long>();
+  a.n_runs = n_runs_d;
   if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * CLS_READS)), dim3(256), 0, st, a);  // also new_len, flag, max
   AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
   long long tmp_total = 0;
@@ -1902,17 +2071,19 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
 
   // list of gapped reads
   AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
-  long long n_gapped = 0;
+  long long n_gapped = 0, total_runs = 0;
   {
     FetchList l;
     l.add(tmp_off + R);
     l.add(mx);
     l.add(new_idx + R);
-    unsigned long long v[3];
+    for (int i = 0; i < 16; ++i) l.add(n_runs_d + 16 * i);
+    unsigned long long v[3 + 16];
     AMGCHK(fetch(c, l, v));
     tmp_total = (long long)v[0];
     max_bound = v[1];
     n_gapped = (long long)v[2];
+    for (int i = 0; i < 16; ++i) total_runs += (long long)v[3 + i];
   }
   stage_end(c);
 
@@ -1932,7 +2103,49 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     AMGCHK(glist.ensure((size_t)(n_gapped + 1) * sizeof(int)));
     AMGCHK(c->gap_rec.ensure((size_t)(n_gapped + 1) * sizeof(GapRec)));
     hipLaunchKernelGGL(k_scatter_gapped, dim3(nblk(R, 256)), dim3(256), 0, st, flag, new_idx, R,
-                       glist.as<int>(), a.read_off, r_start, r_end, tmp_off, c->gap_rec.as<GapRec>());
+                       glist.as<int>(), a.read_off, r_start, r_end, tmp_off, a.lmask, c->gap_rec.as<GapRec>());
+    // ---- path memo: every distinct (start, direction, end) question of the None runs is answered once
+    const int* gq = nullptr;
+    {
+      const char* nm = getenv("AMG_NO_GAP_MEMO");  // A/B switch
+      if (total_runs > 0 && !(nm && nm[0] == '1')) {
+        const uint64_t qslots = pow2_at_least((uint64_t)total_runs * 2 + 16);
+        AMGCHK(c->gm_tab.ensure((size_t)qslots * sizeof(unsigned long long)));
+        AMGCHK(c->gm_res.ensure((size_t)qslots * sizeof(int4)));
+        AMGCHK(c->gm_list.ensure((size_t)(total_runs + 1) * sizeof(int)));
+        AMGCHK(c->gm_q.ensure((size_t)(n_gapped + 1) * GF_MAXGAP * sizeof(int)));
+        {
+          ClearList cl;
+          cl.add(c->gm_tab.p, (size_t)qslots * sizeof(unsigned long long));
+          cl.add(c->gm_ctr.p, 16 * sizeof(unsigned long long));
+          cl.add(c->status.as<unsigned long long>() + ST_OVERFLOW, sizeof(unsigned long long));
+          AMGCHK(clear_many(c, cl));
+        }
+        hipLaunchKernelGGL(k_gap_queries, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->gap_rec.as<GapRec>(), n_gapped,
+                           c->k, a.tok_node, a.tok_dir, c->gm_tab.as<unsigned long long>(), (unsigned int)(qslots - 1),
+                           c->gm_ctr.as<unsigned long long>(), c->gm_list.as<int>(), c->gm_q.as<int>(),
+                           c->status.as<unsigned long long>());
+        unsigned long long v[2] = {0, 0};
+        {
+          FetchList l;
+          l.add(c->gm_ctr.p);
+          l.add(c->status.as<unsigned long long>() + ST_OVERFLOW);
+          AMGCHK(fetch(c, l, v));
+        }
+        if (v[1]) return amg_fail(AMG_E_HIP, "correct_reads: path memo table full");
+        const long long n_queries = (long long)v[0];
+        // answers average ~20 ints; one that does not find room sends its reads to the general kernel
+        const unsigned long long qcap = (unsigned long long)n_queries * (GM_INLINE + 32ull) + 4096ull;
+        if (qcap <= 0x7fffffffull) {  // (pool offsets are ints)
+        AMGCHK(c->gm_pool.ensure((size_t)qcap * sizeof(int)));
+        if (n_queries > 0)
+          hipLaunchKernelGGL(k_gap_dfs, dim3((unsigned int)n_queries), dim3(64), 0, st, make_view(c), c->gm_list.as<int>(),
+                             n_queries, c->gm_tab.as<unsigned long long>(), c->gm_ctr.as<unsigned long long>() + 1, qcap,
+                             c->gm_pool.as<int>(), c->gm_res.as<int4>());
+        gq = c->gm_q.as<int>();
+        }
+      }
+    }
     const unsigned int threads_total = 64u * 2048u;
     unsigned int cand_stride = (unsigned int)(2 * max_bound + (max_bound + 3) / 4 + c->k + 16);
     DevBuf& cand = c->c_gstart;  // free until the pack step
@@ -1960,6 +2173,9 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       G.cand_stride = cand_stride;
       G.final_cls = final_cls;
       G.need_slow = need_slow;
+      G.gq = gq;
+      G.qres = c->gm_res.as<int4>();
+      G.qpool = c->gm_pool.as<int>();
       {
         const char* ga = getenv("AMG_GAP_ABLATE");
         G.ablate = (AMG_EXPERIMENTS && ga) ? atoi(ga) : 0;
