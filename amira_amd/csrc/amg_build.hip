@@ -300,20 +300,6 @@ __global__ void k_row_offsets(const unsigned int* __restrict__ keys, long long n
 // node that only LOOKED like a root fails and returns the truth, and a path-halving store can
 // at worst undo some compression.  (With agent-scope loads and atomicMin halving every step was
 // a fabric transaction: 0.8 ms for 6.3 M pairs.)
-__device__ __forceinline__ int uf_ld(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // plain load, never hoisted
-}
-__device__ __forceinline__ int uf_find(int* parent, int x) {
-  int p = uf_ld(parent + x);
-  while (p != x) {
-    const int g = uf_ld(parent + p);
-    if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // halving
-    x = p;
-    p = g;
-  }
-  return x;
-}
-
 __global__ void k_uf_init(int* parent, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) parent[i] = (int)i;
@@ -585,7 +571,7 @@ int bs_read_stats(amg_ctx* c, int k, const ClearList* also) {
     AMGCHK(clear_many(c, cl));
   }
   if (R > 0)
-    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_read_stats, dim3(blocks_for(R, 256) < 512u ? blocks_for(R, 256) : 512u), dim3(256), 0, st,
                        c->read_off.as<long long>(), R, T, k, c->status.as<unsigned long long>(),
                        c->bnd_bits.as<unsigned int>());
   stage_end(c);
@@ -844,6 +830,7 @@ int bs_finish_from_pairs(amg_ctx* c) {
 // removed since: the reference labels once, in __init__)
 int ensure_components(amg_ctx* c) {
   if (c->comp_valid) return AMG_OK;
+  if (c->comp_from_claims) return bx_components_from_claims(c);  // a filtered build: the UNFILTERED graph's labels
   hipStream_t st = c->stream;
   const long long P = c->n_pairs, D = c->n_nodes;
   stage_begin(c, "components");
@@ -970,6 +957,7 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   c->tok_base = 0;
   c->tok_total = c->n_tokens;
   c->dist_mode = false;
+  c->comp_from_claims = false;
   {
     // test hook: the first AMG_TEST_WEAK_FP attempts use a 12-bit fingerprint, which is
     // certain to collide; the exact verification must catch it and the retry must succeed

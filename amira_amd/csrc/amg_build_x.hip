@@ -251,10 +251,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
 // anything is ranked, so only the survivors get ids, arrays, edges
 __global__ void k_x_drop_claims(const unsigned int* __restrict__ cnt, long long n, unsigned int min_cnt,
                                 unsigned int* __restrict__ first2, int* __restrict__ final_of_claim,
-                                unsigned long long* __restrict__ n_kept) {
+                                unsigned long long* __restrict__ n_kept, unsigned int* __restrict__ first_all) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool keep = false;
   if (c < n) {
+    if (first_all) first_all[c] = x_first_inv(first2, c);  // component labels are those of the UNFILTERED graph
     keep = cnt[c] >= min_cnt && x_first_inv(first2, c) != 0u;
     if (!keep) {
       first2[2 * c] = 0u;
@@ -400,6 +401,74 @@ __global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
   const Slot16 s = tab[slot_by_claim[c]];
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys keep the creator's first-seen there
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, bits, j);
+}
+
+// ------------------------------------------------------------------ components of a filtered build
+// The reference labels components once, in __init__, on the graph of ALL nodes (construct_graph.py:101-102,
+// :911-927) and keeps the labels through filter_graph.  A filtered build never makes the nodes and edges
+// below the threshold, so the labels are made in CLAIM space instead, from what the node pass left behind:
+// every window's claim (tok_slot) — two consecutive windows of a read are an edge of the unfiltered graph —
+// and every claim's first-seen value (saved by k_x_drop_claims).  Union-find over the claims; component id =
+// 1 + rank of the component's earliest first-seen among the components (= DFS discovery order over _nodes).
+__global__ void k_xc_init(int* parent, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) parent[i] = (int)i;
+}
+
+__global__ void k_xc_union(const int* __restrict__ tok_claim, long long n_tokens, int* parent) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t + 1 >= n_tokens) return;
+  const int raw = tok_claim[t];
+  if (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) return;
+  const int nxt = tok_claim[t + 1];
+  if (nxt == -1) return;
+  int a = (int)((unsigned int)raw & ~AMG_LAST_FLAG), b = (int)((unsigned int)nxt & ~AMG_LAST_FLAG);
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) break;
+    if (a > b) { int x = a; a = b; b = x; }
+    const int old = atomicCAS(parent + b, b, a);  // hook the larger root under the smaller
+    if (old == b) break;
+    b = old;
+  }
+}
+
+__global__ void k_xc_flatten(int* parent, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) parent[i] = uf_find(parent, (int)i);  // only thread i writes entry i; roots keep parent == self
+}
+
+__device__ __forceinline__ int xc_root(const int* __restrict__ parent, long long c) {
+  int r = parent[c];
+  while (parent[r] != r) r = parent[r];  // entries of non-roots may still name an intermediate ancestor
+  return r;
+}
+
+// best2[2 r] = the largest complemented first-seen (= the earliest) among the claims of root r; roots counted
+__global__ void k_xc_best(const int* __restrict__ parent, const unsigned int* __restrict__ first_all, long long n,
+                          unsigned int* __restrict__ best2, unsigned long long* __restrict__ n_roots) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool root = false;
+  if (c < n && first_all[c] != 0u) {
+    const int r = xc_root(parent, c);
+    root = r == (int)c;
+    atomicMax(best2 + 2ll * r, first_all[c]);
+  }
+  const unsigned long long m = __ballot(root);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_roots, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_xc_label(const int* __restrict__ parent, const unsigned int* __restrict__ first_all, long long n,
+                           const unsigned int* __restrict__ best2, const unsigned int* __restrict__ bits,
+                           const long long* __restrict__ prefix, const int* __restrict__ final_of_claim,
+                           int* __restrict__ node_comp) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n || first_all[c] == 0u) return;
+  const int node = final_of_claim[c];
+  if (node < 0) return;  // the filter dropped this node
+  const unsigned int first = ~best2[2ll * xc_root(parent, c)];
+  node_comp[node] = (int)x_rank_of(first >> 1, bits, prefix) + 1;
 }
 
 // ------------------------------------------------------------------ edges
@@ -778,11 +847,14 @@ int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->x_ecnt.as<unsigned int>(), 2));
   stage_end(c);
   stage_begin(c, "node_filter");
+  AMGCHK(c->x_first_all.ensure((size_t)(n + 2) * sizeof(unsigned int)));
+  c->comp_from_claims = true;
   unsigned long long* kept = c->status.as<unsigned long long>() + ST_COMPACT_A;
   HIPCHK(hipMemsetAsync(kept, 0, sizeof(unsigned long long), st));
   if (n > 0)
     hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), n,
-                       min_cov, c->x_first.as<unsigned int>(), c->x_final.as<int>(), kept);
+                       min_cov, c->x_first.as<unsigned int>(), c->x_final.as<int>(), kept,
+                       c->x_first_all.as<unsigned int>());
   unsigned long long D = 0;
   {
     FetchList l;
@@ -925,7 +997,7 @@ int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov) {
     unsigned long long* kept = c->status.as<unsigned long long>() + ST_COMPACT_A;
     HIPCHK(hipMemsetAsync(kept, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), P,
-                       min_edge_cov, c->x_efirst.as<unsigned int>(), (int*)nullptr, kept);
+                       min_edge_cov, c->x_efirst.as<unsigned int>(), (int*)nullptr, kept, (unsigned int*)nullptr);
     unsigned long long left = 0;
     FetchList l;
     l.add(kept);
@@ -977,5 +1049,42 @@ int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal) {
                        c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(), final_of_claim);
   }
   stage_end(c);
+  return AMG_OK;
+}
+
+// component ids of a filtered build (see k_xc_*)
+int bx_components_from_claims(amg_ctx* c) {
+  hipStream_t st = c->stream;
+  const long long S = c->x_nspace, T = c->n_tokens, D = c->n_nodes;
+  stage_begin(c, "components");
+  AMGCHK(c->node_comp.ensure((size_t)(D + 1) * sizeof(int)));
+  AMGCHK(c->s3.ensure((size_t)(S + 2) * sizeof(int)));
+  AMGCHK(c->s4.ensure((size_t)(2 * S + 4) * sizeof(unsigned int)));
+  int* parent = c->s3.as<int>();
+  unsigned int* best2 = c->s4.as<unsigned int>();
+  unsigned long long* n_roots = c->status.as<unsigned long long>() + ST_COMPACT_A;
+  long long ncomp = 0;
+  if (S > 0) {
+    ClearList cl;
+    cl.add(best2, (size_t)(2 * S + 2) * sizeof(unsigned int));
+    cl.add(n_roots, sizeof(unsigned long long));
+    AMGCHK(clear_many(c, cl));
+    hipLaunchKernelGGL(k_xc_init, dim3(blocks_for(S, 256)), dim3(256), 0, st, parent, S);
+    if (T > 1)
+      hipLaunchKernelGGL(k_xc_union, dim3(blocks_for(T, 256)), dim3(256), 0, st, c->tok_slot.as<int>(), T, parent);
+    hipLaunchKernelGGL(k_xc_flatten, dim3(blocks_for(S, 256)), dim3(256), 0, st, parent, S);
+    hipLaunchKernelGGL(k_xc_best, dim3(blocks_for(S, 256)), dim3(256), 0, st, parent, c->x_first_all.as<unsigned int>(), S,
+                       best2, n_roots);
+    AMGCHK(x_rank_bitmap(c, best2, S, 1));  // non-roots keep {0, 0}: skipped like unclaimed ids
+    hipLaunchKernelGGL(k_xc_label, dim3(blocks_for(S, 256)), dim3(256), 0, st, parent, c->x_first_all.as<unsigned int>(), S,
+                       best2, c->s1.as<unsigned int>(), c->s5.as<long long>(), c->x_final.as<int>(),
+                       c->node_comp.as<int>());
+    FetchList l;
+    l.add(n_roots);
+    AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&ncomp)));
+  }
+  stage_end(c);
+  c->n_components = ncomp;
+  c->comp_valid = true;
   return AMG_OK;
 }

@@ -149,3 +149,20 @@ __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigne
                                                          unsigned int* s_wave /*[4]*/) {
   return block_exscan<4>(v, total, s_wave);
 }
+
+// ------------------------------------------------------------------ union-find helpers (components)
+__device__ __forceinline__ int uf_ld(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // plain load, never hoisted
+}
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+  int p = uf_ld(parent + x);
+  while (p != x) {
+    const int g = uf_ld(parent + p);
+    if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // halving
+    x = p;
+    p = g;
+  }
+  return x;
+}
+
+

@@ -220,12 +220,14 @@ struct amg_ctx {
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
   DevBuf f_ctrs;             // fused table pass: per-shard claim counters
   DevBuf x_efinal;           // int32 [edge claims] claim id -> edge-class id
+  DevBuf x_first_all;        // uint32[claims] filtered build: ~first_seen of EVERY claim (k_x_drop_claims zeroes x_first)
+  bool comp_from_claims = false;  // filtered build: component ids come from the claims (bx_components_from_claims)
 
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
   int64_t n_owned = 0;
   uint32_t dist_min_node = 1, dist_min_edge = 1;  // fused filter of the next merged build
-  DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_owned, dist_gtab, dist_lcnt;
+  DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_gtab, dist_lcnt;
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
   bool match_valid = false;
@@ -240,6 +242,9 @@ struct amg_ctx {
   unsigned long long* mail_dev = nullptr;
   unsigned long long mail_ticket = 0;
   DevBuf sort_tmp;     // rocPRIM temp storage
+  DevBuf scan_state;   // amg_scan.hip: ticket counter + one status word per tile
+  unsigned long long scan_tickets = 0;  // tiles all scans so far have used
+  unsigned int scan_epoch = 0;
   DevBuf s0, s1, s2, s3, s4, s5;  // general scratch arrays
   DevBuf nw_big;       // global scratch of the general position carry-over kernel (long reads)
   DevBuf gap_rec;      // per gapped read: the record k_corr_gapped_fast starts from
@@ -335,6 +340,7 @@ int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long
                     int edges);
 int bx_bits(const amg_ctx* c, int k);
 int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal);
+int bx_components_from_claims(amg_ctx* c);
 bool bf_applicable(const amg_ctx* c, int k);
 int bf_tables(amg_ctx* c, int k, int* which);
 int bf_finish(amg_ctx* c);

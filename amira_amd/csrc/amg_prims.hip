@@ -1,5 +1,5 @@
-// amg_prims.hip — library primitives (radix sort, scan) behind a narrow interface.
-// rocPRIM does the generic sorting / scanning of SMALL arrays (distinct nodes, edge
+// amg_prims.hip — library primitives (radix sort) behind a narrow interface (prefix sums: amg_scan.hip).
+// rocPRIM does the generic sorting of SMALL arrays (distinct nodes, edge
 // classes); every gene-mer-sized kernel (window extraction, hashing, table upsert,
 // compaction, masking, threading, matching) is hand-written in amg_build.hip /
 // amg_passes.hip.  Kept in its own translation unit because it dominates compile time.
@@ -41,26 +41,5 @@ int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
   if (end_bit > 32) end_bit = 32;
   return with_temp(c, [&](void* tmp, size_t& bytes) {
     return rocprim::radix_sort_pairs<SortCfg>(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream);
-  });
-}
-
-int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n) {
-  if (n == 0) return AMG_OK;
-  return with_temp(c, [&](void* tmp, size_t& bytes) {
-    return rocprim::exclusive_scan(tmp, bytes, in, out, 0ll, n, rocprim::plus<long long>(),
-                                   c->stream);
-  });
-}
-
-struct U32ToI64 {
-  __host__ __device__ long long operator()(unsigned int v) const { return (long long)v; }
-};
-
-int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n) {
-  if (n == 0) return AMG_OK;
-  auto it = rocprim::make_transform_iterator(in, U32ToI64());
-  return with_temp(c, [&](void* tmp, size_t& bytes) {
-    return rocprim::exclusive_scan(tmp, bytes, it, out, 0ll, n, rocprim::plus<long long>(),
-                                   c->stream);
   });
 }

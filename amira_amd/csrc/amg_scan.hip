@@ -1,0 +1,141 @@
+// amg_scan.hip — exclusive prefix sums in ONE launch (decoupled look-back, hand-written for wave64).
+//
+// The passes scan short arrays all the time (flags -> positions, counts -> offsets: ~25 scans per cleaning
+// sweep over 0.5 - 6 M elements).  A library scan is two launches (state initialisation + scan) through a
+// generic dispatch layer; here a scan is one kernel and needs no initialisation launch:
+//   * a workgroup takes its tile number from a counter that only ever grows (tile = ticket - the number of
+//     tiles all earlier scans used: the host keeps that sum), so tiles start in order and a tile never waits for
+//     one that has not started;
+//   * a tile publishes {state, epoch, value} as ONE 64-bit word with a relaxed agent-scope store — value and
+//     flag travel together, so no fence is needed (a release fence writes the XCD's L2 back) — first its own
+//     sum (state 1), then its inclusive prefix (state 2); the status words are never cleared: a word whose
+//     epoch is not the current scan's is simply "not there yet" (the buffer is zeroed when the 14-bit epoch wraps);
+//   * the first wave of a tile looks back 64 predecessors at a time until it meets an inclusive prefix.
+// Values are sums of non-negative counts below 2^48.
+#include "amg_device.h"
+
+#define SC_THREADS 256
+#define SC_ROWS 16                       // rows of 64 per wave: a wave scans 1024 consecutive elements
+#define SC_TILE (SC_THREADS * SC_ROWS)   // 4096 elements per workgroup
+#define SC_VAL_MASK ((1ull << 48) - 1ull)
+
+__device__ __forceinline__ unsigned long long sc_word(unsigned int state, unsigned int epoch, unsigned long long v) {
+  return ((unsigned long long)state << 62) | ((unsigned long long)(epoch & 0x3fffu) << 48) | (v & SC_VAL_MASK);
+}
+
+template <class In>
+__global__ __launch_bounds__(SC_THREADS) void k_exscan(const In* __restrict__ in, long long* __restrict__ out,
+                                                        long long n, unsigned long long* counter,
+                                                        unsigned long long ticket_base, unsigned long long* status,
+                                                        unsigned int epoch) {
+  __shared__ unsigned long long s_wave[SC_THREADS / 64];
+  __shared__ unsigned long long s_excl;
+  __shared__ unsigned int s_tile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = (unsigned int)(atomicAdd(counter, 1ull) - ticket_base);
+  __syncthreads();
+  const long long tile = s_tile;
+  const long long w0 = tile * SC_TILE + (long long)wave * (64 * SC_ROWS);
+  // ---- the wave's 1024 elements as 16 coalesced rows; inclusive scan of every row, rows chained
+  unsigned long long x[SC_ROWS], inc[SC_ROWS];
+#pragma unroll
+  for (int r = 0; r < SC_ROWS; ++r) {
+    const long long i = w0 + r * 64 + lane;
+    x[r] = i < n ? (unsigned long long)in[i] : 0ull;
+  }
+  unsigned long long row_off = 0;
+#pragma unroll
+  for (int r = 0; r < SC_ROWS; ++r) {
+    unsigned long long v = x[r];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(v, d, 64);
+      if (lane >= d) v += o;
+    }
+    inc[r] = v + row_off;
+    row_off += __shfl(v, 63, 64);
+  }
+  if (lane == 0) s_wave[wave] = row_off;  // the wave's sum
+  __syncthreads();
+  unsigned long long wave_excl = 0, tile_sum = 0;
+#pragma unroll
+  for (int w = 0; w < SC_THREADS / 64; ++w) {
+    const unsigned long long s = s_wave[w];
+    wave_excl += w < wave ? s : 0ull;
+    tile_sum += s;
+  }
+  // ---- look-back (first wave): sum of everything before this tile
+  if (wave == 0) {
+    unsigned long long excl = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(status, sc_word(2u, epoch, tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(status + tile, sc_word(1u, epoch, tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (long long look = tile - 1;; look -= 64) {
+        const long long idx = look - lane;
+        unsigned int state = 2u;  // before the first tile: an inclusive prefix of 0
+        unsigned long long val = 0;
+        if (idx >= 0) {
+          unsigned long long w;
+          do {  // the tile at idx has started (tickets are taken in order) and publishes without waiting for anybody
+            w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((unsigned int)((w >> 48) & 0x3fffu) != (epoch & 0x3fffu) || (w >> 62) == 0ull);
+          state = (unsigned int)(w >> 62);
+          val = w & SC_VAL_MASK;
+        }
+        const unsigned long long full = __ballot(state == 2u);
+        // lanes up to the nearest inclusive prefix count; nothing further back does
+        const int stop = full ? __ffsll((long long)full) - 1 : 63;
+        unsigned long long part = lane <= stop ? val : 0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        excl += part;
+        if (full) break;
+      }
+      if (lane == 0)
+        __hip_atomic_store(status + tile, sc_word(2u, epoch, excl + tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_excl = excl;
+  }
+  __syncthreads();
+  const unsigned long long base = s_excl + wave_excl;
+#pragma unroll
+  for (int r = 0; r < SC_ROWS; ++r) {
+    const long long i = w0 + r * 64 + lane;
+    if (i < n) out[i] = (long long)(base + inc[r] - x[r]);
+  }
+}
+
+template <class In>
+static int exscan(amg_ctx* c, const In* in, long long* out, size_t n) {
+  if (n == 0) return AMG_OK;
+  const unsigned long long tiles = (n + SC_TILE - 1) / SC_TILE;
+  // [0] the ticket counter, [8 ...] one status word per tile
+  const size_t need = (size_t)(tiles + 8) * sizeof(unsigned long long);
+  if (need > c->scan_state.cap || c->scan_epoch >= 0x3fffu) {
+    if (need > c->scan_state.cap) {
+      AMGCHK(c->scan_state.ensure(need * 2));
+      c->scan_tickets = 0;
+      HIPCHK(hipMemsetAsync(c->scan_state.p, 0, c->scan_state.cap, c->stream));
+    } else {  // the epoch wraps: forget every old status word (the ticket counter keeps counting)
+      HIPCHK(hipMemsetAsync(c->scan_state.as<unsigned long long>() + 8, 0,
+                            c->scan_state.cap - 8 * sizeof(unsigned long long), c->stream));
+    }
+    c->scan_epoch = 0;
+  }
+  const unsigned int epoch = ++c->scan_epoch;
+  unsigned long long* st = c->scan_state.as<unsigned long long>();
+  hipLaunchKernelGGL(k_exscan<In>, dim3((unsigned int)tiles), dim3(SC_THREADS), 0, c->stream, in, out, (long long)n, st,
+                     c->scan_tickets, st + 8, epoch);
+  c->scan_tickets += tiles;
+  return AMG_OK;
+}
+
+int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n) {
+  return exscan<unsigned int>(c, in, out, n);
+}
+
+int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n) {
+  return exscan<long long>(c, in, out, n);
+}

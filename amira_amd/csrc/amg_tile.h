@@ -13,9 +13,11 @@
 static __global__ void k_read_stats(const long long* __restrict__ read_off, long long n_reads, long long n_tokens,
                                     int k, unsigned long long* status, unsigned int* __restrict__ bnd_bits) {
   __shared__ unsigned long long s_w[4], s_s[4];
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride: a few hundred workgroups whatever the number of reads — each ends with one atomicAdd per counter,
+  // and a single counter word takes only ~90 atomics per microsecond (one workgroup per 256 reads spent 40 of the
+  // kernel's 50 us queueing there)
   unsigned long long w = 0, sh = 0;
-  if (r < n_reads) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (long long)gridDim.x * blockDim.x) {
     const long long beg = read_off[r], end = read_off[r + 1];
     // the CSR may be caller-owned device memory nobody has looked at yet: offsets must start at 0,
     // never decrease and end at the token count before anything is indexed with them
@@ -26,9 +28,9 @@ static __global__ void k_read_stats(const long long* __restrict__ read_off, long
     } else {
       const long long len = end - beg;
       if (len >= k)
-        w = (unsigned long long)(len - k + 1);
+        w += (unsigned long long)(len - k + 1);
       else
-        sh = 1;
+        sh += 1;
       atomicOr(&bnd_bits[end >> 5], 1u << (end & 31));
     }
   }

@@ -1,5 +1,6 @@
 """Graph drivers — drop-in for the hot-path part of amira/graph_utils.py (reference v0.11.0):
-build_graph (:12-14), build_multiprocessed_graph (:105-124), the cleaning loop of
+build_graph (:12-14), merge_nodes / merge_edges / merge_reads / merge_graphs (:17-102),
+build_multiprocessed_graph (:105-124), the cleaning loop of
 iterative_bubble_popping (:127-181), choose_kmer_size (:258-296) and
 get_overall_mean_node_coverages (:299-313).
 
@@ -54,6 +55,40 @@ def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positio
     reads = {r: annotatedReads[r] for r in annotatedReads}
     positions = None if gene_positions is None else {r: gene_positions[r] for r in gene_positions}
     return build_graph(reads, geneMer_size, positions)
+
+
+def merge_graphs(sub_graphs):
+    """graph_utils.py:94-102: one graph from the sub-graphs of a read-sharded build.  The reference replays every
+    sub-graph's windows into the first one object by object (merge_nodes :17-50) and then patches edges in
+    (merge_edges :53-76, which doubles the coverage of every shared edge instead of adding the other side's: SURVEY
+    section 5).  Here the merged graph is BUILT: the sub-graphs' reads, in sub-graph order — the order in which the
+    reference's merge meets them — go through one device build, which is the single-graph result (what the
+    reference's own pipeline always uses: it passes cores = 1).  Across GPUs the same result comes from
+    amira_amd.dist.dist_build (read shards + key-owner table merge over RCCL)."""
+    first = sub_graphs[0]
+    reads, positions = {}, ({} if first.get_gene_positions() is not None else None)
+    for g in sub_graphs:
+        for r in g.get_reads():
+            reads[r] = g.get_reads()[r]
+            if positions is not None and g.get_gene_positions() is not None:
+                positions[r] = g.get_gene_positions()[r]
+    return GeneMerGraph(reads, first.get_kmerSize(), positions)
+
+
+def merge_nodes(sub_graphs, fastq_data=None):
+    """graph_utils.py:17-50.  Returns the merged graph like the reference; it is complete already (edges, reads and
+    component ids included: see merge_graphs), so merge_edges / merge_reads have nothing left to do."""
+    return merge_graphs(sub_graphs)
+
+
+def merge_edges(sub_graphs, reference_graph):
+    """graph_utils.py:53-76: nothing to do on a graph merge_nodes / merge_graphs returned (edges are part of the build)"""
+    return None
+
+
+def merge_reads(sub_graphs, reference_graph):
+    """graph_utils.py:78-91: nothing to do on a graph merge_nodes / merge_graphs returned (it was built from all reads)"""
+    return None
 
 
 def cleaning_sweep(reads, gene_positions, geneMer_size, fastq_content, node_min_coverage=3):

@@ -125,8 +125,11 @@ int amg_build(amg_ctx* ctx, int32_t k);
  * (construct_graph.py:31-102, :523-540), the opening of every cleaning iteration (graph_utils.py:147-149) — with the
  * filter applied on the way where the key layout allows it: nodes / edge classes below the thresholds are never
  * ranked, stored or joined by edges.  Live nodes, live edges, coverages, list orders, masked windows and the reads
- * queued for correction are those of the two separate calls; node / edge ids number what is present in first-seen
- * order (with the two calls the filtered nodes keep their ids with alive = 0). */
+ * queued for correction are those of the two separate calls, and so are the COMPONENT ids: the reference labels
+ * components once, in __init__, on the graph of all nodes (construct_graph.py:101-102) and keeps the labels through
+ * filter_graph; the one-pass build makes the same labels from the per-window claims of its node pass (on first use).
+ * Node / edge ids number what is present, in first-seen order (with the two calls the filtered nodes keep their ids
+ * with alive = 0). */
 int amg_build_filtered(amg_ctx* ctx, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
 int amg_counts(amg_ctx* ctx, amg_counts_t* out);
 /* amg_build leaves component ids (assign_component_ids, construct_graph.py:920-927) and the per-node

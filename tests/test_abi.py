@@ -92,7 +92,7 @@ UNREACHED = {
                      "merge_dict", "new_get_minhashes_for_paths", "find", "union", "cluster_paths", "assess_connectivity",
                      "merge_read_clusters", "new_merge_clusters", "make_intersection_matrix",
                      "get_node_with_highest_subthreshold_connections", "filter_nodes_by_intersection", "trim_fringe_nodes"},
-    "graph_utils": {"merge_nodes", "merge_edges", "merge_reads", "merge_graphs", "plot_node_coverages"},
+    "graph_utils": {"plot_node_coverages"},
     "path_finding_utils": {"orient_nodes_on_read", "get_start_stop_indices", "get_unique_anchor_suffixes",
                            "filter_anchor_suffixes"},
 }

@@ -86,3 +86,34 @@ def test_empty_and_degenerate_graphs():
     assert g.get_nodes() == {} and g.get_short_read_annotations() == {"a": [], "b": ["+x"]}
     assert g.components() == [] and g.correct_reads({}) == ({}, {})
     assert g.filter_graph(3, 1) is g and g.get_total_number_of_reads() == 2
+
+
+def test_merge_graphs_is_the_single_graph_build():
+    """graph_utils.merge_nodes / merge_edges / merge_reads / merge_graphs (reference :17-102): the merged graph of two
+    read shards equals the graph built from their reads in sub-graph order, and build_multiprocessed_graph gives the
+    cores = 1 result whatever `cores` says (the reference's own merge doubles shared edge coverages: SURVEY section 5)"""
+    import procedures as P
+    from amira_amd import graph_utils as gu
+    reads, pos = P.fixture("nine")
+    ids = list(reads)
+    shards = [{r: reads[r] for r in ids[i::2]} for i in range(2)]
+    pshards = [{r: pos[r] for r in ids[i::2]} for i in range(2)]
+    subs = [gu.build_graph(shards[i], 3, pshards[i]) for i in range(2)]
+    merged = gu.merge_graphs(subs)
+    order = list(shards[0]) + list(shards[1])
+    want = gu.build_graph({r: reads[r] for r in order}, 3, {r: pos[r] for r in order})
+
+    def state(g):
+        return ([(h, n.get_node_coverage(), n.get_component(), list(n.get_reads())) for h, n in g.get_nodes().items()],
+                [(h, e.get_edge_coverage()) for h, e in g.get_edges().items()],
+                {r: list(v) for r, v in g.get_readNodes().items()})
+
+    assert state(merged) == state(want)
+    again = gu.merge_nodes(subs)
+    assert gu.merge_edges(subs, again) is None and gu.merge_reads(subs, again) is None
+    assert state(again) == state(want)
+    one = gu.build_multiprocessed_graph(reads, 3, 1, pos)
+    two = gu.build_multiprocessed_graph(reads, 3, 2, pos)
+    assert state(one) == state(two)
+    for g in subs + [merged, want, again, one, two]:
+        g.close()

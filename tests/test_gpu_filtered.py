@@ -57,6 +57,10 @@ def test_build_filtered_equals_build_then_filter(case, thr, key_mode, monkeypatc
         assert ca["n_live_nodes"] == cb["n_live_nodes"] and ca["n_live_edges"] == cb["n_live_edges"]
         if key_mode == "exact":
             assert ca["n_nodes"] == cb["n_live_nodes"]          # only the survivors exist
+        # component ids are the UNFILTERED graph's (the reference labels once, in __init__, construct_graph.py:101-102)
+        na_, nb_ = a.nodes(), b.nodes()
+        assert np.array_equal(na_["component"][na_["alive"] != 0], nb_["component"][nb_["alive"] != 0])
+        assert a.counts()["n_components"] == b.counts()["n_components"]
         # what follows sees no difference: correction, rebuild
         na, nb = a.correct_reads(), b.correct_reads()
         assert na == nb
@@ -124,6 +128,32 @@ def test_extreme_thresholds_and_empty_input(thr):
         a.set_reads(np.zeros(0, np.int32), np.zeros(1, np.int64), 2)
         a.build_filtered(3, 3, 1)
         assert a.counts()["n_nodes"] == 0
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("thr", [(3, 1), (2, 2)])
+@pytest.mark.parametrize("case", CASES)
+def test_component_passes_after_build_filtered(case, thr):
+    """what reads the component labels — remove_short_linear_paths' whole-component guard (:702-713) and
+    remove_low_coverage_components (:950-958) — gives the same graph after the one-pass build + filter"""
+    from amira_amd import Engine
+    reads, pos, fq, k, vocab, toks, offs, ids = _inputs(case)
+    a, b = Engine(0), Engine(0)
+    try:
+        for e in (a, b):
+            e.set_reads(toks, offs, vocab.two_v)
+        a.build_filtered(k, *thr)
+        b.build(k)
+        b.filter(*thr)
+        live_b = np.cumsum(b.nodes()["alive"] != 0) - 1
+        ra, rb = a.remove_short_linear_paths(k), b.remove_short_linear_paths(k)
+        assert sorted(ra.tolist()) == sorted(live_b[rb].tolist())
+        _same_live(a, b, "after tip clipping")
+        a.remove_low_coverage_components(5)
+        b.remove_low_coverage_components(5)
+        _same_live(a, b, "after the component filter")
     finally:
         a.close()
         b.close()

@@ -34,7 +34,6 @@ Engine.dist_nodes_local = timed("nodes_local", Engine.dist_nodes_local)
 Engine.dist_edges_local = timed("edges_local", Engine.dist_edges_local)
 Engine.dist_pack = timed("pack", Engine.dist_pack)
 Engine.dist_reduce = timed("reduce", Engine.dist_reduce)
-Engine.dist_owned = timed("owned", Engine.dist_owned)
 Engine.dist_global = timed("global", Engine.dist_global)
 t = time.perf_counter(); dist_build_loopback(engines, 5, 3, 1); torch.cuda.synchronize(); tot = time.perf_counter() - t
 print("fused per-rank phase ms:", {k: round(v * 1e3 / W, 2) for k, v in acc.items()}, "total/rank", round(tot * 1e3 / W, 1))

@@ -18,7 +18,7 @@ def timed(name, fn):
         acc[name + (":" + str(a[0]) if name in ("pack", "reduce", "owned", "global") else "")] += time.perf_counter() - t
         return r
     return wrap
-for n in ("dist_nodes_local", "dist_edges_local", "dist_pack", "dist_reduce", "dist_owned", "dist_global"):
+for n in ("dist_nodes_local", "dist_edges_local", "dist_pack", "dist_reduce", "dist_global"):
     setattr(Engine, n, timed(n[5:], getattr(Engine, n)))
 eng = Engine(0)
 for it in range(3):

@@ -24,7 +24,7 @@ def timed(name, fn):
         acc[name] += time.perf_counter() - t
         return r
     return wrap
-for m in ("dist_nodes_local", "dist_edges_local", "dist_pack", "dist_reduce", "dist_owned", "dist_global",
+for m in ("dist_nodes_local", "dist_edges_local", "dist_pack", "dist_reduce", "dist_global",
           "correct_reads", "adopt_corrected", "remove_short_linear_paths", "set_reads_device", "set_positions_device"):
     setattr(Engine, m, timed(m, getattr(Engine, m)))
 D.exchange_a2a = timed("exchange_a2a", D.exchange_a2a); D.exchange_ag = timed("exchange_ag", D.exchange_ag)
