@@ -178,7 +178,8 @@ class GeneMerGraph(BubblePopping):
         self._engine.set_reads(toks, offs, self._vocab.two_v)
         self._tokens = toks
         self._gs = self._ge = None
-        if gene_positions is not None and hasattr(gene_positions, "gene_start"):  # io.TokenizedPositions
+        if (gene_positions is not None and hasattr(gene_positions, "gene_start")
+                and getattr(gene_positions, "_moved", None) is None):  # io.TokenizedPositions as it was made
             self._gs = np.ascontiguousarray(gene_positions.gene_start, np.int64)
             self._ge = np.ascontiguousarray(gene_positions.gene_end, np.int64)
             assert len(self._gs) == int(offs[-1]) == len(self._ge), "positions do not match the gene calls"
@@ -664,9 +665,13 @@ class GeneMerGraph(BubblePopping):
             if ids:
                 protect = np.zeros(self._engine.counts()["n_nodes"], np.uint8)
                 protect[ids] = 1
-        v = self._v()
+        v = self._view   # the object view is NOT made for this: the hashes of the removed nodes come from their tokens
+        tokens = None if v is not None else self._engine.nodes()["tokens"]
         removed = self._engine.remove_short_linear_paths(int(min_length), protect)
-        hashes = [v.node_hash[i] for i in removed.tolist()]
+        if v is not None:
+            hashes = [v.node_hash[i] for i in removed.tolist()]
+        else:
+            hashes = [self._hash_of_tokens(tokens[i].tolist()) for i in removed.tolist()]
         if len(hashes):
             self._invalidate()
         return hashes
@@ -714,7 +719,9 @@ class GeneMerGraph(BubblePopping):
         self._device_pass("correct_reads")
         eng, vocab = self._engine, self._vocab
         have_pos = bool(self._genePositions)
-        if have_pos:
+        if have_pos and hasattr(fastq_data, "lengths_array"):   # amira_amd.io.ReadLengths: no per-read loop
+            eng.set_read_lengths(fastq_data.lengths_array(self._read_ids, getattr(self._reads, "source_rows", None)))
+        elif have_pos:
             flags = eng.reads_to_correct()
             lengths = np.zeros(len(self._read_ids), np.int64)
             for r in np.nonzero(flags)[0].tolist():
@@ -725,6 +732,8 @@ class GeneMerGraph(BubblePopping):
             eng.set_read_lengths(lengths)
         n_reads, n_tokens = eng.correct_reads()
         out = eng.corrected(n_reads, n_tokens, have_pos)
+        if self._tokenized_io(have_pos):
+            return self._corrected_as_arrays(out, have_pos)
         offs, toks = out["read_offsets"].tolist(), out["tokens"]
         corrected_genes, corrected_gene_positions = {}, {}
         for i, (orig, changed) in enumerate(zip(out["orig_read"].tolist(), out["changed"].tolist())):
@@ -740,6 +749,38 @@ class GeneMerGraph(BubblePopping):
             if have_pos:
                 corrected_gene_positions[read_id] = self._genePositions[read_id]
         return corrected_genes, corrected_gene_positions
+
+    def _tokenized_io(self, have_pos):
+        """the caller handed the reads (and positions) over as arrays (amira_amd.io.TokenizedReads /
+        TokenizedPositions): corrections go back the same way, with no per-read Python work"""
+        from .io import TokenizedPositions, TokenizedReads
+        return isinstance(self._reads, TokenizedReads) and (not have_pos or isinstance(self._genePositions,
+                                                                                         TokenizedPositions))
+
+    def _corrected_as_arrays(self, out, have_pos):
+        """correct_reads' result for array inputs: the corrected calls as a TokenizedReads over the device's output
+        arrays, their positions as a TokenizedPositions; reads the correction changed are redirected to their new
+        positions in the caller's mapping (the reference updates gene_positions in place, :1282-1284, :1328)"""
+        from .io import TokenizedPositions, TokenizedReads
+        orig = out["orig_read"]
+        ids_arr = self._read_ids_array()
+        ids = ids_arr[orig].tolist()
+        offs = out["read_offsets"]
+        src = getattr(self._reads, "source_rows", None)
+        reads = TokenizedReads(self._vocab, out["tokens"], offs, ids,
+                               source_rows=orig.astype(np.int64) if src is None else src[orig])
+        if not have_pos:
+            return reads, {}
+        positions = TokenizedPositions(ids, offs, out["gene_start"], out["gene_end"])
+        changed = np.flatnonzero(out["changed"])
+        if len(changed):
+            self._genePositions.replace_rows(orig[changed], positions, changed)
+        return reads, positions
+
+    def _read_ids_array(self):
+        if getattr(self, "_read_ids_arr", None) is None:
+            self._read_ids_arr = np.asarray(self._read_ids, dtype=object)
+        return self._read_ids_arr
 
     def correct_single_read(self, read_id, readNodes, fastq_data):
         """host twin of one read of the device correction (:1136-1151), for callers that correct a

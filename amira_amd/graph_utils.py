@@ -29,7 +29,7 @@ def _tokenized(reads, gene_positions):
         reads_t = reads
     else:
         reads_t = TokenizedReads(*tokenize(reads))
-    if gene_positions is None or hasattr(gene_positions, "gene_start"):
+    if gene_positions is None or (hasattr(gene_positions, "gene_start") and getattr(gene_positions, "_moved", None) is None):
         return reads_t, gene_positions
     offs, n = reads_t.read_offsets, int(reads_t.read_offsets[-1])
     gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
@@ -42,6 +42,17 @@ def _tokenized(reads, gene_positions):
     return reads_t, TokenizedPositions(reads_t.read_ids, offs, gs, ge)
 
 
+def _own(mapping):
+    """the graph's own copy of a {read: ...} mapping, as the reference's drivers make one (.copy(), dict
+    comprehensions); array-backed mappings (amira_amd.io.TokenizedReads / TokenizedPositions) keep their arrays —
+    copying them item by item would decode a million reads into lists only to tokenise them again"""
+    if mapping is None or hasattr(mapping, "tokens"):
+        return mapping
+    if hasattr(mapping, "gene_start"):
+        return mapping.copy()   # shares the arrays; correct_reads redirects changed reads in the COPY, as it would
+    return {r: mapping[r] for r in mapping}
+
+
 def build_filtered_graph(read_dict, kmer_size, gene_positions, min_node_coverage, min_edge_coverage=1):
     """build_graph(...) followed by filter_graph(min_node_coverage, min_edge_coverage) — the opening of every
     cleaning iteration (graph_utils.py:147-149) — in one device pass: an uncorrected graph is ~99 % nodes the filter
@@ -52,9 +63,7 @@ def build_filtered_graph(read_dict, kmer_size, gene_positions, min_node_coverage
 
 def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positions=None):
     """single-graph result (what cores=1 gives in the reference), built on the GPU."""
-    reads = {r: annotatedReads[r] for r in annotatedReads}
-    positions = None if gene_positions is None else {r: gene_positions[r] for r in gene_positions}
-    return build_graph(reads, geneMer_size, positions)
+    return build_graph(_own(annotatedReads), geneMer_size, _own(gene_positions))
 
 
 def merge_graphs(sub_graphs):
@@ -95,9 +104,7 @@ def cleaning_sweep(reads, gene_positions, geneMer_size, fastq_content, node_min_
     """one cleaning iteration without the bubble-popping tail (graph_utils.py:145-166):
     build -> filter_graph(n, 1) -> correct_reads -> build -> remove_short_linear_paths(k)
     -> correct_reads -> build.  Returns (graph, reads, positions)."""
-    graph = build_filtered_graph({r: reads[r] for r in reads},
-                                 geneMer_size, None if gene_positions is None else {r: gene_positions[r] for r in gene_positions},
-                                 node_min_coverage, 1)
+    graph = build_filtered_graph(_own(reads), geneMer_size, _own(gene_positions), node_min_coverage, 1)
     reads, gene_positions = graph.correct_reads(fastq_content)
     graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
     graph.remove_short_linear_paths(geneMer_size)
@@ -116,10 +123,8 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
     components_to_skip = set()
     for this_iteration in range(cleaning_iterations):
         sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
-        graph = build_filtered_graph(
-            {r: new_annotatedReads[r] for r in new_annotatedReads}, geneMer_size,
-            None if new_gene_position_dict is None else {r: new_gene_position_dict[r] for r in new_gene_position_dict},
-            node_min_coverage, 1)
+        graph = build_filtered_graph(_own(new_annotatedReads), geneMer_size, _own(new_gene_position_dict),
+                                     node_min_coverage, 1)
         new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
         graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
         if graph.get_total_number_of_nodes() == prev_nodes:

@@ -16,8 +16,11 @@ from .tokens import Vocabulary
 class TokenizedReads(Mapping):
     """{read id: ["+geneA", ...]} backed by CSR token arrays (lists are decoded on access)."""
 
-    def __init__(self, vocab, tokens, read_offsets, read_ids):
+    def __init__(self, vocab, tokens, read_offsets, read_ids, source_rows=None):
         self.vocab, self.tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
+        # where these reads sat in the read list they descend from (correct_reads drops reads and keeps the order):
+        # lets array-backed side tables (ReadLengths) follow without a lookup per read; None = they are that list
+        self.source_rows = source_rows
         self._index = None   # built on the first lookup by name (a million reads: ~0.2 s)
         self._cache = {}
 
@@ -66,6 +69,7 @@ class TokenizedPositions(Mapping):
         self.gene_start, self.gene_end = gene_start, gene_end
         self._index = None
         self._cache = {}
+        self._moved = None   # (row -> row of another TokenizedPositions or -1, that other mapping): replace_rows
 
     def _idx(self):
         if self._index is None:
@@ -76,15 +80,43 @@ class TokenizedPositions(Mapping):
         got = self._cache.get(read_id)
         if got is None:
             i = self._idx()[read_id]
-            a, b = int(self.read_offsets[i]), int(self.read_offsets[i + 1])
-            got = self._cache[read_id] = list(zip(self.gene_start[a:b].tolist(), self.gene_end[a:b].tolist()))
+            src, j = self, i
+            if self._moved is not None and self._moved[0][i] >= 0:   # replaced wholesale by a correction
+                src, j = self._moved[1], int(self._moved[0][i])
+            a, b = int(src.read_offsets[j]), int(src.read_offsets[j + 1])
+            got = self._cache[read_id] = list(zip(src.gene_start[a:b].tolist(), src.gene_end[a:b].tolist()))
         return got
+
+    def copy(self):
+        """the caller's own copy (the arrays are shared — they are never written — the redirections are not)"""
+        c = TokenizedPositions(self.read_ids, self.read_offsets, self.gene_start, self.gene_end)
+        c._index = self._index
+        c._cache = dict(self._cache)
+        if self._moved is not None:
+            c._moved = (self._moved[0].copy(), self._moved[1])
+        return c
+
+    def replace_rows(self, rows, other, other_rows):
+        """the positions of reads `rows` (indices into read_ids) are from now on rows `other_rows` of the
+        TokenizedPositions `other` — what GeneMerGraph.correct_reads does to the caller's gene positions for every
+        read it changed (construct_graph.py:1282-1284, :1328), for a million reads at once"""
+        if self._moved is not None and self._moved[1] is not other:   # a second correction on the same mapping
+            for i in np.flatnonzero(self._moved[0] >= 0).tolist():
+                self[self.read_ids[i]]       # pin what the first one left (rare: the drivers rebuild in between)
+            self._moved = None
+        if self._moved is None:
+            self._moved = (np.full(len(self.read_ids), -1, np.int64), other)
+        self._moved[0][rows] = other_rows
+        for i in np.asarray(rows).tolist() if len(self._cache) else ():
+            self._cache.pop(self.read_ids[i], None)
 
     def pos_at(self, read_id, i):
         """self[read_id][i] without building the read's list of pairs"""
         got = self._cache.get(read_id)
         if got is not None:
             return got[i]
+        if self._moved is not None:
+            return self[read_id][i]
         r = self._idx()[read_id]
         a, b = int(self.read_offsets[r]), int(self.read_offsets[r + 1])
         if i < 0:
@@ -105,6 +137,56 @@ class TokenizedPositions(Mapping):
 
     def __contains__(self, read_id):
         return read_id in self._idx()
+
+
+class _Sized:
+    """stands in for a read's nucleotide string where only its length is asked for"""
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+class ReadLengths(Mapping):
+    """{read id: {"sequence": <something with the read's length>}} backed by one int64 array — the only thing
+    correct_reads wants from the FASTQ dict (len(fastq[read]["sequence"]), construct_graph.py:1685).
+    GeneMerGraph.correct_reads takes the whole array at once (lengths_array) instead of a million lookups."""
+
+    def __init__(self, read_ids, lengths):
+        self.read_ids, self.lengths = read_ids, np.ascontiguousarray(lengths, np.int64)
+        self._index = None
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {r: i for i, r in enumerate(self.read_ids)}
+        return self._index
+
+    def __getitem__(self, read_id):
+        return {"sequence": _Sized(int(self.lengths[self._idx()[read_id]]))}
+
+    def __iter__(self):
+        return iter(self.read_ids)
+
+    def __len__(self):
+        return len(self.read_ids)
+
+    def lengths_array(self, read_ids, rows_hint=None):
+        """lengths of `read_ids` in that order (0 for a read this mapping does not know); rows_hint: where the
+        caller believes these reads sit in this mapping (TokenizedReads.source_rows), checked at both ends"""
+        if (rows_hint is not None and len(rows_hint) == len(read_ids) and len(read_ids) > 0
+                and int(rows_hint[-1]) < len(self.read_ids) and self.read_ids[int(rows_hint[0])] == read_ids[0]
+                and self.read_ids[int(rows_hint[-1])] == read_ids[-1]):
+            return self.lengths[rows_hint]
+        if read_ids is self.read_ids or (len(read_ids) == len(self.read_ids) and len(read_ids) > 0 and
+                                         read_ids[0] == self.read_ids[0] and read_ids[-1] == self.read_ids[-1]
+                                         and read_ids == self.read_ids):
+            return self.lengths
+        idx = self._idx()
+        rows = np.fromiter((idx.get(r, -1) for r in read_ids), dtype=np.int64, count=len(read_ids))
+        return np.where(rows >= 0, self.lengths[np.maximum(rows, 0)], 0)
 
 
 def _split(buf):

@@ -248,6 +248,53 @@ def run_cfg4(args, w, rank, world, local_rank):
     return out
 
 
+def run_api_e2e(w, vocab, toks, offs, k, n_windows, steps=2):
+    """graph_utils.cleaning_sweep's call sequence on the workload's stream through the Python drop-in: GeneMerGraph(...)
+    [+ filter_graph fused], correct_reads, GeneMerGraph, remove_short_linear_paths, correct_reads, GeneMerGraph — host
+    arrays in (TokenizedReads / TokenizedPositions / ReadLengths), array-backed mappings out, every build and every
+    correction crossing PCIe (1.2 GB each way)."""
+    from amira_amd import graph_utils as gu, synth
+    from amira_amd.io import ReadLengths, TokenizedPositions, TokenizedReads
+    N, L = w["N"], w["L"]
+    ids = synth.read_names(0, N)
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    ge = gs + 899
+    lengths = ReadLengths(ids, np.full(N, L * 1000 + 100, np.int64))
+    stages = {}
+
+    def timed(name, fn):
+        t = time.perf_counter()
+        r = fn()
+        stages[name] = stages.get(name, 0.0) + time.perf_counter() - t
+        return r
+
+    def sweep():
+        reads, pos = TokenizedReads(vocab, toks, offs, ids), TokenizedPositions(ids, offs, gs, ge)
+        g = timed("build_filtered_graph", lambda: gu.build_filtered_graph(reads, k, pos, 3, 1))
+        r1, p1 = timed("correct_reads", lambda: g.correct_reads(lengths))
+        g2 = timed("build_graph", lambda: gu.build_multiprocessed_graph(r1, k, 1, p1))
+        timed("remove_short_linear_paths", lambda: g2.remove_short_linear_paths(k))
+        r2, p2 = timed("correct_reads", lambda: g2.correct_reads(lengths))
+        g3 = timed("build_graph", lambda: gu.build_multiprocessed_graph(r2, k, 1, p2))
+        n = g3.get_total_number_of_nodes()
+        for x in (g, g2, g3):
+            x.close()
+        return n, len(r2)
+
+    sweep()
+    stages.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nodes, reads_left = sweep()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": n_windows / dt, "unit": "gene-mers/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "final_nodes": nodes, "reads_left": reads_left,
+            "stages_ms_per_step": {n: round(v * 1e3 / steps, 1) for n, v in stages.items()},
+            "what": "graph_utils.cleaning_sweep's calls through amira_amd.GeneMerGraph with array-backed mappings "
+                    "(amira_amd.io.TokenizedReads / TokenizedPositions / ReadLengths) in and out; host arrays cross PCIe "
+                    "at every build and every correction"}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as fresh child processes
     (torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process makes any GPU call — counting the devices
@@ -293,6 +340,7 @@ def main():
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the extra `cfg4` object (read-path clustering) of the default line")
     ap.add_argument("--no-fused-line", action="store_true", help="skip the extra `fused_first_filter` measurement")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: independent shards, no table merge")
     ap.add_argument("--fused-filter", action="store_true",
@@ -531,6 +579,12 @@ def main():
                          + (" and of the corrected calls with their positions" if w["sweep"] else "")
                          + "; position upload overlapped with the first build on a second stream"}
 
+    # ---- the same sweep through the reference-shaped Python API (amira_amd.graph_utils / GeneMerGraph), inputs as
+    # array-backed mappings (amira_amd.io): what a caller of the drop-in pays per cleaning iteration, PCIe included
+    api_e2e = None
+    if w["sweep"] and world == 1 and not merge and not args.no_e2e:
+        api_e2e = run_api_e2e(w, vocab, toks, offs, k, n_windows)
+
     out = None
     if rank == 0:
         stage_avg = {n: v[0] / v[1] for n, v in stage_ms.items()}     # ms per launch
@@ -629,8 +683,18 @@ def main():
             out["fused_first_filter"] = fused_line
         if e2e is not None:
             out["e2e"] = e2e
+        if api_e2e is not None:
+            out["api_e2e"] = api_e2e
         out.update(cpu)
-    eng.close()
+    # ---- BASELINE configs[3] beside it: build + read-path clustering through the Python API (its own engine)
+    if rank == 0 and world == 1 and not merge and w["sweep"] and not args.no_cfg4 and not args.no_e2e:
+        eng.close()
+        eng = None
+        c4 = run_cfg4(argparse.Namespace(steps=2, warmup=1), WORKLOADS["cfg4"], 0, 1, local_rank)
+        out["cfg4"] = {key: c4[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "reads_per_s",
+                                                 "config", "stages_s_per_step")}
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
     if rank == 0:
