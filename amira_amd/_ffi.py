@@ -57,6 +57,7 @@ def _load():
         "amg_build": (C.c_int, [P, I32]),
         "amg_build_filtered": (C.c_int, [P, C.c_int32, C.c_uint32, C.c_uint32]),
         "amg_counts": (C.c_int, [P, C.POINTER(Counts)]),
+        "amg_build_multi": (C.c_int, [C.POINTER(P), C.POINTER(I32), I32]),
         "amg_finalize": (C.c_int, [P]),
         "amg_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
         "amg_graph_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I32)]),

@@ -153,6 +153,71 @@ class GeneMerGraph(BubblePopping):
     def __init__(self, readDict, kmerSize, gene_positions=None, device=None, _filter=None):
         """_filter = (minNodeCoverage, minEdgeCoverage): the graph comes out as GeneMerGraph(...).filter_graph(...)
         would leave it, with the filter applied during the build (amg_build_filtered; graph_utils.build_filtered_graph)"""
+        self._init_fields(readDict, kmerSize, gene_positions, device)
+        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):  # amira_amd.io.TokenizedReads
+            self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
+                                                       readDict.read_offsets, list(readDict.read_ids))
+        else:
+            self._vocab, toks, offs, self._read_ids = tokenize(readDict)
+        self._read_off = offs
+        self._tokens = toks
+        self._engine.set_reads(toks, offs, self._vocab.two_v)
+        self._host_positions(gene_positions)
+        self._upload_positions()
+        try:
+            if _filter is None:
+                self._engine.build(self._kmer_for_device())
+            else:
+                self._minNodeCoverage, self._minEdgeCoverage = _filter
+                self._engine.build_filtered(self._kmer_for_device(), max(int(_filter[0]), 0), max(int(_filter[1]), 0))
+        except _ffi.AmgError as err:
+            if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
+                raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None
+            raise
+        self._note_short_reads()
+
+    @classmethod
+    def build_many(cls, readDict, kmerSizes, gene_positions=None, device=None):
+        """[GeneMerGraph(readDict, k, gene_positions) for k in kmerSizes] — the seven graphs of choose_kmer_size
+        (graph_utils.py:258-296) — with the reads tokenised and uploaded once and the token stream read twice in
+        all instead of twice per k (amg_build_multi).  Graph i owns its own engine; the graphs after the first read
+        the first one's device arrays and keep it alive."""
+        kmerSizes = list(kmerSizes)
+        first = cls.__new__(cls)
+        first._init_fields(readDict, kmerSizes[0], gene_positions, device)
+        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):
+            first._vocab, toks, offs, first._read_ids = (readDict.vocab, readDict.tokens, readDict.read_offsets,
+                                                         list(readDict.read_ids))
+        else:
+            first._vocab, toks, offs, first._read_ids = tokenize(readDict)
+        first._read_off, first._tokens = offs, toks
+        first._engine.set_reads(toks, offs, first._vocab.two_v)
+        first._host_positions(gene_positions)
+        first._upload_positions()
+        graphs = [first]
+        for k in kmerSizes[1:]:
+            g = cls.__new__(cls)
+            g._init_fields(readDict, k, gene_positions, device)
+            g._vocab, g._read_ids, g._read_off, g._tokens = first._vocab, first._read_ids, first._read_off, first._tokens
+            g._read_index_ = first._read_index_
+            g._gs, g._ge = first._gs, first._ge
+            g._positions_pending = g._gs is not None   # uploaded when a correction asks for them
+            g._reads_owner = first
+            first._borrowers += 1
+            graphs.append(g)
+        try:
+            Engine.build_multi([g._engine for g in graphs], [g._kmer_for_device() for g in graphs])
+        except _ffi.AmgError as err:
+            for g in graphs:
+                g.close()
+            if err.code == _ffi.E_PALINDROME:
+                raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None
+            raise
+        for g in graphs:
+            g._note_short_reads()
+        return graphs
+
+    def _init_fields(self, readDict, kmerSize, gene_positions, device):
         self._reads = readDict
         self._kmerSize = kmerSize
         self._minNodeCoverage = 1
@@ -162,28 +227,27 @@ class GeneMerGraph(BubblePopping):
         self._host_edits = False   # add_node / add_edge / remove_edge ... changed the host view
         self._extra_to_correct = set()
         self._gene_cache = {}
+        self._read_index_ = None
+        self._gs = self._ge = None
+        self._positions_pending = False
+        self._reads_owner = None   # build_many: the graph whose engine holds the reads this one's engine borrows
+        self._borrowers = 0        # build_many: graphs that borrow this one's reads
+        self._close_pending = False
         dev = int(os.environ.get("AMG_DEVICE", "0")) if device is None else int(device)
         self._engine = _acquire_engine(dev)
-        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):  # amira_amd.io.TokenizedReads
-            self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
-                                                       readDict.read_offsets, list(readDict.read_ids))
-        else:
-            self._vocab, toks, offs, self._read_ids = tokenize(readDict)
-        self._read_off = offs
-        self._read_index_ = None
-        if kmerSize < 1 and len(toks) == 0:
-            kmerSize_dev = 1  # GeneMerGraph({}, 0) is legal in the reference: nothing to build
-        else:
-            kmerSize_dev = kmerSize
-        self._engine.set_reads(toks, offs, self._vocab.two_v)
-        self._tokens = toks
-        self._gs = self._ge = None
+
+    def _kmer_for_device(self):
+        # GeneMerGraph({}, 0) is legal in the reference: nothing to build
+        return 1 if (self._kmerSize < 1 and len(self._tokens) == 0) else self._kmerSize
+
+    def _host_positions(self, gene_positions):
+        """flat int64 (start, end) per gene, aligned with the tokens"""
+        offs = self._read_off
         if (gene_positions is not None and hasattr(gene_positions, "gene_start")
                 and getattr(gene_positions, "_moved", None) is None):  # io.TokenizedPositions as it was made
             self._gs = np.ascontiguousarray(gene_positions.gene_start, np.int64)
             self._ge = np.ascontiguousarray(gene_positions.gene_end, np.int64)
             assert len(self._gs) == int(offs[-1]) == len(self._ge), "positions do not match the gene calls"
-            self._engine.set_positions(self._gs, self._ge, None)
         elif gene_positions:
             n = int(offs[-1])
             gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
@@ -195,19 +259,16 @@ class GeneMerGraph(BubblePopping):
                     gs[a:b] = [x[0] for x in p[: b - a]]
                     ge[a:b] = [x[1] for x in p[: b - a]]
             self._gs, self._ge = gs, ge
-            self._engine.set_positions(gs, ge, None)
-        try:
-            if _filter is None:
-                self._engine.build(kmerSize_dev)
-            else:
-                self._minNodeCoverage, self._minEdgeCoverage = _filter
-                self._engine.build_filtered(kmerSize_dev, max(int(_filter[0]), 0), max(int(_filter[1]), 0))
-        except _ffi.AmgError as err:
-            if err.code == _ffi.E_PALINDROME:  # construct_gene_mer.py:23-25
-                raise AssertionError("Gene-mer and reverse complement gene-mer are identical") from None
-            raise
-        short = np.flatnonzero(np.diff(offs) < kmerSize).tolist() if len(offs) > 1 else []
-        self._shortReads = {self._read_ids[r]: readDict[self._read_ids[r]] for r in short}   # :53-55
+
+    def _upload_positions(self):
+        if self._gs is not None:
+            self._engine.set_positions(self._gs, self._ge, None)
+        self._positions_pending = False
+
+    def _note_short_reads(self):
+        offs = self._read_off
+        short = np.flatnonzero(np.diff(offs) < self._kmerSize).tolist() if len(offs) > 1 else []
+        self._shortReads = {self._read_ids[r]: self._reads[self._read_ids[r]] for r in short}   # :53-55
 
     @property
     def _read_index(self):
@@ -217,9 +278,17 @@ class GeneMerGraph(BubblePopping):
 
     def close(self):
         """hand the device engine back (the graph can no longer be queried); also done when the object dies"""
-        engine, self._engine = getattr(self, "_engine", None), None
         self._view = None
+        owner, self._reads_owner = getattr(self, "_reads_owner", None), None
+        if getattr(self, "_borrowers", 0) > 0:   # graphs of build_many still read this one's device arrays
+            self._close_pending = True
+            return
+        engine, self._engine = getattr(self, "_engine", None), None
         _release_engine(engine)
+        if owner is not None:
+            owner._borrowers -= 1
+            if owner._borrowers == 0 and getattr(owner, "_close_pending", False):
+                owner.close()
 
     def __del__(self):
         try:
@@ -719,6 +788,8 @@ class GeneMerGraph(BubblePopping):
         self._device_pass("correct_reads")
         eng, vocab = self._engine, self._vocab
         have_pos = bool(self._genePositions)
+        if self._positions_pending:   # a graph of build_many: its engine has not seen the positions yet
+            self._upload_positions()
         if have_pos and hasattr(fastq_data, "lengths_array"):   # amira_amd.io.ReadLengths: no per-read loop
             eng.set_read_lengths(fastq_data.lengths_array(self._read_ids, getattr(self._reads, "source_rows", None)))
         elif have_pos:

@@ -1014,3 +1014,350 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   }
   return amg_fail(AMG_E_OVERFLOW, "build did not converge after 12 attempts");
 }
+
+// ------------------------------------------------------------------ several k in one pass over the tokens
+// choose_kmer_size (graph_utils.py:258-296) builds the graph of the SAME reads for k = 3, 5, ..., 15.  amg_build_multi
+// makes those graphs with TWO reads of the token stream instead of two per k: a tile of tokens is staged in LDS once
+// and the node pass of every k runs from it (each k into its own table), and likewise the edge pass of every k (whose
+// exact check of the fingerprints needs the tokens again).  Everything per graph — ranking, counting, emission — is
+// the single-graph code on that graph's own ctx.  Fingerprint keys throughout (k up to 16 does not fit the exact slots).
+#define MULTI_MAX 8
+struct MultiNodeJob {
+  Slot* tab;
+  unsigned long long mask, seed, fp_mask;
+  int* tok_slot;
+  signed char* tok_dir;
+  unsigned long long* status;
+  int k;
+};
+struct MultiNodeJobs {
+  MultiNodeJob j[MULTI_MAX];
+  int n, kmax;
+};
+
+// tokens t0 .. t0 + TILE + kmax - 1 and the tile's slice of the read-end bitmap into LDS (one read of the stream for
+// all jobs); a token outside [0, two_v) is reported to every job
+template <class Jobs>
+__device__ __forceinline__ void multi_stage(const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits,
+                                            long long n_tokens, int kmax, long long t0, int two_v, int* s_tok,
+                                            unsigned int* s_bits, const Jobs& jobs) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < TILE + kmax; i += TILE_THREADS) {
+    const long long t = t0 + i;
+    const int v = t < n_tokens ? __builtin_nontemporal_load(tokens + t) : 0;
+    bad = bad || (unsigned int)v >= (unsigned int)two_v;
+    s_tok[i] = v;
+  }
+  if (bad)
+    for (int q = 0; q < jobs.n; ++q) jobs.j[q].status[ST_BADINPUT] = 2;
+  if (threadIdx.x < TILE_BIT_WORDS) s_bits[threadIdx.x] = bnd_bits[(t0 >> 5) + threadIdx.x];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_node_upsert_multi(const int* __restrict__ tokens,
+                                                                     const unsigned int* __restrict__ bnd_bits,
+                                                                     long long n_tokens, int two_v, unsigned int probe_limit,
+                                                                     MultiNodeJobs jobs) {
+  __shared__ int s_tok[TILE + AMG_MAX_K];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
+  const long long t0 = (long long)blockIdx.x * TILE;
+  multi_stage(tokens, bnd_bits, n_tokens, jobs.kmax, t0, two_v, s_tok, s_bits, jobs);
+  const int flip = two_v - 1;
+  for (int q = 0; q < jobs.n; ++q) {
+    const MultiNodeJob& J = jobs.j[q];
+    const int k = J.k;
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) {
+      const int i = threadIdx.x + it * TILE_THREADS;
+      const long long t = t0 + i;
+      if (t >= n_tokens) continue;
+      bool inside, is_last;
+      tile_window(s_bits, i, k, inside, is_last);
+      int out_slot = -1;
+      signed char out_dir = 0;
+      if ((t + k <= n_tokens) && inside) {
+        LdsView w{s_tok + i};
+        const int dir = canon_dir(w, k, flip);
+        if (dir == 0) {
+          J.status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+        } else {
+          unsigned long long fp = canon_fingerprint(w, k, flip, dir, J.seed) & J.fp_mask;
+          fp = fp ? fp : 1ull;
+          const unsigned long long first = ((unsigned long long)t << 1) | (dir < 0 ? 1ull : 0ull);
+          const long long slot = table_upsert(J.tab, J.mask, fp, fp >> 20, first, probe_limit, false, J.status + ST_OVERFLOW);
+          if (slot < 0) {
+            J.status[ST_OVERFLOW] = 1;
+          } else {
+            out_slot = (int)((unsigned int)slot | (is_last ? AMG_LAST_FLAG : 0u));
+            out_dir = (signed char)dir;
+          }
+        }
+      }
+      J.tok_slot[t] = out_slot;
+      J.tok_dir[t] = out_dir;
+    }
+  }
+}
+
+struct MultiEdgeJob {
+  const Slot* node_tab;
+  const int* node_tokens;
+  const int* tok_slot;
+  const signed char* tok_dir;
+  int* tok_node;
+  Slot* edge_tab;
+  unsigned long long edge_mask;
+  unsigned long long* status;
+  int* tok_pair;
+  int k, packed;
+};
+struct MultiEdgeJobs {
+  MultiEdgeJob j[MULTI_MAX];
+  int n, kmax;
+  unsigned long long* status_of(int q) const { return j[q].status; }
+};
+
+// k_edges for several k from one staged tile of tokens (the exact verification reads the tile in LDS)
+__global__ __launch_bounds__(TILE_THREADS) void k_edges_multi(const int* __restrict__ tokens,
+                                                               const unsigned int* __restrict__ bnd_bits,
+                                                               long long n_tokens, int two_v, unsigned int probe_limit,
+                                                               MultiEdgeJobs jobs) {
+  __shared__ int s_tok[TILE + AMG_MAX_K];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
+  __shared__ int s_id[TILE + 1];
+  __shared__ int s_raw[TILE + 1];
+  __shared__ signed char s_dir[TILE + 1];
+  const long long t0 = (long long)blockIdx.x * TILE;
+  multi_stage(tokens, bnd_bits, n_tokens, jobs.kmax, t0, two_v, s_tok, s_bits, jobs);
+  const int flip = two_v - 1;
+  for (int q = 0; q < jobs.n; ++q) {
+    const MultiEdgeJob& J = jobs.j[q];
+    const int k = J.k;
+    __syncthreads();  // the previous job is done with s_id / s_raw / s_dir
+    for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
+      const long long t = t0 + i;
+      int raw = -1;
+      signed char d = 0;
+      if (t < n_tokens) {
+        raw = J.tok_slot[t];
+        d = J.tok_dir[t];
+      }
+      int id = -1;
+      if (raw != -1) {
+        const int* nt = nullptr;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (J.packed) {
+          const uint4* rec = reinterpret_cast<const uint4*>(J.node_tab + ((unsigned int)raw & ~AMG_LAST_FLAG));
+          lo = rec[0];
+          hi = rec[1];
+          id = (int)hi.y;
+        } else {
+          id = J.node_tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
+          nt = J.node_tokens + (long long)id * k;
+        }
+        if (i < TILE && id >= 0) {  // exact check: the window's canonical tuple must equal the node's
+          bool same = true;
+          for (int x = 0; x < k; ++x) {
+            const int c = d > 0 ? s_tok[i + x] : flip - s_tok[i + k - 1 - x];
+            same = same && (J.packed ? (unsigned int)c == packed_tok(lo, hi, x) : c == nt[x]);
+          }
+          if (!same) J.status[ST_COLLISION] = 1;
+        }
+      }
+      s_id[i] = id;
+      s_raw[i] = raw;
+      s_dir[i] = d;
+      if (i < TILE && t < n_tokens) J.tok_node[t] = id;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) {
+      const int i = threadIdx.x + it * TILE_THREADS;
+      if (t0 + i >= n_tokens) continue;
+      const int raw = s_raw[i];
+      int out = -1;
+      if (raw != -1 && !((unsigned int)raw & AMG_LAST_FLAG) && s_id[i] >= 0 && s_id[i + 1] >= 0) {
+        const unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
+        const int dA = s_dir[i], dB = s_dir[i + 1];
+        const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
+        const unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
+        const unsigned long long key = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
+        const unsigned long long orient = (a == lo ? 1ull : 0ull) | (dA > 0 ? 2ull : 0ull) | (dB > 0 ? 4ull : 0ull);
+        const unsigned long long first = ((unsigned long long)(t0 + i) << 3) | orient;
+        const long long slot = table_upsert(J.edge_tab, J.edge_mask, key, mix64(key), first, probe_limit, false);
+        if (slot < 0) J.status[ST_OVERFLOW] = 2;
+        out = (int)slot;
+      }
+      J.tok_pair[t0 + i] = out;
+    }
+  }
+}
+
+// state of a ctx at the start of a build (what build_impl sets)
+static void multi_begin(amg_ctx* c, int k) {
+  stages_reset(c);
+  c->built = false;
+  c->have_corrected = false;
+  c->match_valid = false;
+  c->k = k;
+  c->retries = 0;
+  c->tok_base = 0;
+  c->tok_total = c->n_tokens;
+  c->dist_mode = false;
+  c->comp_from_claims = false;
+  c->weak_fp_builds = 0;
+  c->count_inline = false;
+  c->exact_keys = false;
+  c->dist_x = false;
+  bs_size_tables(c);
+}
+
+extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t n) {
+  if (!ctxs || !ks || n < 1 || n > MULTI_MAX) return amg_fail(AMG_E_ARG, "amg_build_multi: 1 .. %d graphs", MULTI_MAX);
+  amg_ctx* c0 = ctxs[0];
+  if (!c0 || c0->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads on the first ctx first");
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return amg_fail(AMG_E_ARG, "null ctx");
+    if (ctxs[i]->device != c0->device) return amg_fail(AMG_E_ARG, "amg_build_multi: one device");
+    if (ks[i] < 1 || ks[i] > AMG_MAX_K) return amg_fail(AMG_E_ARG, "k must be in [1, %d]", AMG_MAX_K);
+    for (int j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) return amg_fail(AMG_E_ARG, "amg_build_multi: one ctx per graph");
+  }
+  HIPCHK(hipSetDevice(c0->device));
+  HIPCHK(hipStreamSynchronize(c0->stream));
+  const long long T = c0->n_tokens, R = c0->n_reads;
+  // the other graphs read the first ctx's token arrays (borrowed: nothing is copied) and, for the length of this
+  // call, work on its stream
+  std::vector<hipStream_t> own(n);
+  for (int i = 0; i < n; ++i) {
+    amg_ctx* c = ctxs[i];
+    own[i] = c->stream;
+    if (i == 0) continue;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tokens.borrow(c0->tokens.p, (size_t)T * sizeof(int32_t));
+    c->read_off.borrow(c0->read_off.p, (size_t)(R + 1) * sizeof(int64_t));
+    c->n_reads = R;
+    c->n_tokens = T;
+    c->two_v = c0->two_v;
+    c->have_pos = c->have_read_len = false;
+    c->node_hint = 0;
+    c->cnt_hint_reset = true;
+    c->stream = c0->stream;
+  }
+  struct Restore {
+    amg_ctx* const* ctxs;
+    std::vector<hipStream_t>& own;
+    int n;
+    ~Restore() {
+      for (int i = 0; i < n; ++i) ctxs[i]->stream = own[i];
+    }
+  } restore{ctxs, own, n};
+  hipStream_t st = c0->stream;
+  const long long n_tiles = (T + TILE - 1) / TILE;
+  int kmax = 1;
+  for (int i = 0; i < n; ++i) kmax = ks[i] > kmax ? ks[i] : kmax;
+  std::vector<char> alone(n, 0);  // graphs that have to be built by themselves (a table overflowed, a fingerprint collided)
+  unsigned long long hs[ST_WORDS];
+
+  // ---- node pass of every k from one staged tile
+  MultiNodeJobs nj;
+  nj.n = n;
+  nj.kmax = kmax;
+  for (int i = 0; i < n; ++i) {
+    amg_ctx* c = ctxs[i];
+    multi_begin(c, ks[i]);
+    HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+    AMGCHK(bs_read_stats(c, ks[i]));
+    AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
+    AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
+    AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
+    AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot)));
+    HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot), st));
+    nj.j[i] = MultiNodeJob{c->node_tab.as<Slot>(), (unsigned long long)(c->node_slots - 1), c->seed, ~0ull,
+                           c->tok_slot.as<int>(), c->tok_dir.as<signed char>(), c->status.as<unsigned long long>(), ks[i]};
+  }
+  stage_begin(c0, "node_upsert");
+  if (n_tiles > 0)
+    hipLaunchKernelGGL(k_node_upsert_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
+                       c0->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, nj);
+  stage_end(c0);
+  for (int i = 0; i < n; ++i) {
+    amg_ctx* c = ctxs[i];
+    size_t max_nodes = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
+    AMGCHK(c->s1.ensure(max_nodes * sizeof(unsigned long long)));
+    AMGCHK(c->s2.ensure(max_nodes * sizeof(unsigned long long)));
+    AMGCHK(c->s3.ensure(max_nodes * sizeof(unsigned int)));
+    AMGCHK(c->s4.ensure(max_nodes * sizeof(unsigned int)));
+    hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->node_slots, 2048)), dim3(256), 0, st, c->node_tab.as<Slot>(),
+                       (unsigned long long)c->node_slots, c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
+                       c->status.as<unsigned long long>() + ST_COMPACT_A);
+    AMGCHK(read_status(c, hs));
+    if (hs[ST_BADINPUT])
+      return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
+                                                      : "a token lies outside [0, two_v)");
+    if (hs[ST_PALINDROME])
+      return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
+    if (hs[ST_OVERFLOW]) {
+      alone[i] = 1;
+      continue;
+    }
+    c->n_windows = (int64_t)hs[ST_N_WINDOWS];
+    c->n_short = (int64_t)hs[ST_N_SHORT];
+    c->n_local_nodes = (int64_t)hs[ST_COMPACT_A];
+    AMGCHK(bs_nodes_rank_local(c));
+  }
+
+  // ---- edge pass of every k from one staged tile
+  MultiEdgeJobs ej;
+  ej.n = 0;
+  ej.kmax = kmax;
+  std::vector<int> in_pass;
+  for (int i = 0; i < n; ++i) {
+    if (alone[i]) continue;
+    amg_ctx* c = ctxs[i];
+    const long long D = c->n_nodes;
+    if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
+    AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
+    AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
+    HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot), st));
+    HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_OVERFLOW, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COMPACT_B, 0, sizeof(unsigned long long), st));
+    ej.j[ej.n++] = MultiEdgeJob{c->node_tab.as<Slot>(), c->node_tokens.as<int>(), c->tok_slot.as<int>(),
+                                c->tok_dir.as<signed char>(), c->tok_node.as<int>(), c->edge_tab.as<Slot>(),
+                                (unsigned long long)(c->edge_slots - 1), c->status.as<unsigned long long>(),
+                                c->tok_pair.as<int>(), ks[i], c->packed_nodes ? 1 : 0};
+    in_pass.push_back(i);
+  }
+  stage_begin(c0, "edge_upsert");
+  if (n_tiles > 0 && ej.n > 0)
+    hipLaunchKernelGGL(k_edges_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
+                       c0->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, ej);
+  stage_end(c0);
+  for (int i : in_pass) {
+    amg_ctx* c = ctxs[i];
+    size_t max_pairs = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+    AMGCHK(c->s1.ensure(max_pairs * sizeof(unsigned long long)));
+    AMGCHK(c->s2.ensure(max_pairs * sizeof(unsigned long long)));
+    AMGCHK(c->s3.ensure(max_pairs * sizeof(unsigned int)));
+    AMGCHK(c->s4.ensure(max_pairs * sizeof(unsigned int)));
+    hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->edge_slots, 2048)), dim3(256), 0, st, c->edge_tab.as<Slot>(),
+                       (unsigned long long)c->edge_slots, c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
+                       c->status.as<unsigned long long>() + ST_COMPACT_B);
+    AMGCHK(read_status(c, hs));
+    if (hs[ST_COLLISION] || hs[ST_OVERFLOW]) {
+      alone[i] = 1;
+      continue;
+    }
+    c->n_local_pairs = (int64_t)hs[ST_COMPACT_B];
+    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, c->n_nodes, c->node_cov.as<unsigned int>(), 0));
+    AMGCHK(bs_pairs_from_local(c));
+    AMGCHK(bs_finish_from_pairs(c));
+    c->built = true;
+    c->node_hint = c->n_nodes > 256 ? c->n_nodes : 256;
+  }
+  // ---- the graphs the shared passes could not finish: by themselves, with amg_build's own retries
+  for (int i = 0; i < n; ++i)
+    if (alone[i]) AMGCHK(amg_build(ctxs[i], ks[i]));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}

@@ -61,6 +61,16 @@ class Engine:
         """build + filter_graph(min_node_cov, min_edge_cov) with the filter applied on the way (amg.h)"""
         check(_ffi.lib.amg_build_filtered(self._h, int(k), max(int(min_node_cov), 0), max(int(min_edge_cov), 0)))
 
+    @staticmethod
+    def build_multi(engines, ks):
+        """the graphs of engines[0]'s reads for every k of ks, graph i on engines[i], with two passes over the tokens in
+        all (amg_build_multi); the other engines borrow engines[0]'s read arrays: keep it alive and unchanged"""
+        n = len(engines)
+        assert n == len(ks) and n >= 1
+        handles = (C.c_void_p * n)(*[e._h for e in engines])
+        arr = (C.c_int32 * n)(*[int(k) for k in ks])
+        check(_ffi.lib.amg_build_multi(handles, arr, n))
+
     def finalize(self):
         """component ids + per-node edge lists of the built graph now (they are otherwise made on first use)"""
         check(_ffi.lib.amg_finalize(self._h))

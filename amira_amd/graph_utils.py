@@ -151,11 +151,12 @@ def choose_kmer_size(overall_mean_node_coverage, new_annotatedReads, cores, new_
     AMR nodes have >= 2k-1 genes (graph_utils.py:258-296)."""
     geneMer_size = 3
     if overall_mean_node_coverage >= 20:
-        # the seven builds see the same reads: gene names are hashed and ranked, reads and positions
-        # flattened ONCE; every build then hands the same arrays to the (pooled) engine
+        # the seven graphs see the same reads: gene names are hashed and ranked, reads and positions flattened and
+        # uploaded ONCE, and the seven builds share two passes over the token stream (GeneMerGraph.build_many ->
+        # amg_build_multi) instead of making two each
         reads_t, pos_t = _tokenized(new_annotatedReads, new_gene_position_dict)
-        for k in range(3, 16, 2):
-            graph = build_graph(reads_t, k, pos_t)
+        graphs = GeneMerGraph.build_many(reads_t, list(range(3, 16, 2)), pos_t)
+        for k, graph in zip(range(3, 16, 2), graphs):
             amr = {n.__hash__() for g in sample_genesOfInterest for n in graph.get_nodes_containing(g)}
 
             def is_component_valid(component):
@@ -170,6 +171,8 @@ def choose_kmer_size(overall_mean_node_coverage, new_annotatedReads, cores, new_
                 geneMer_size = k
             else:
                 break
+        for graph in reversed(graphs):
+            graph.close()
     return geneMer_size
 
 

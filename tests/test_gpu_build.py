@@ -143,3 +143,64 @@ def test_match_patterns_against_brute_force(eng):
                     if p and row[i:i + len(p)] == p]
             got = list(zip(hr[off[j]:off[j + 1]].tolist(), hp[off[j]:off[j + 1]].tolist()))
             assert got == want, (which, j)
+
+
+@pytest.mark.parametrize("case", [("fixture", "nine"), ("fixture", "five"), ("synth", 13, 300, 40, 250, 0.02),
+                                  ("ragged",)])
+def test_build_multi_equals_single_builds(case):
+    """amg_build_multi (choose_kmer_size's seven graphs, graph_utils.py:258-296, from two passes over the tokens):
+    graph i must be exactly what amg_build(k_i) gives — nodes, edges, coverages, adjacency, components, window ids"""
+    from amira_amd import Engine, tokenize
+    from test_gpu_dist import assert_same_graph, graph_state
+    if case[0] == "fixture":
+        reads, _ = P.fixture(case[1])
+    elif case[0] == "synth":
+        reads, _, _ = P.synth_inputs(*case[1:])
+    else:
+        reads = {"e0": [], "s1": ["+a"], "x": ["+a", "-b", "+c"], "y": ["-c", "+b", "-a", "+d", "+e", "-f", "+a", "-b", "+c"],
+                 "z": ["+a", "-b", "+c", "+d", "+e", "-f", "+g", "+h", "+i", "-j", "+k", "+l", "-m", "+n", "+o", "+p", "-q"]}
+    vocab, toks, offs, _ = tokenize(reads)
+    ks = list(range(3, 16, 2))
+    engines = [Engine(0) for _ in ks]
+    single = Engine(0)
+    try:
+        engines[0].set_reads(toks, offs, vocab.two_v)
+        Engine.build_multi(engines, ks)
+        single.set_reads(toks, offs, vocab.two_v)
+        for e, k in zip(engines, ks):
+            single.build(k)
+            assert_same_graph(graph_state(e), graph_state(single))
+            assert np.array_equal(e.read_nodes()[0], single.read_nodes()[0])
+            assert np.array_equal(e.read_nodes()[1], single.read_nodes()[1])
+            ca, cb = e.counts(), single.counts()
+            for key in ("n_nodes", "n_edges", "n_windows", "n_short_reads", "n_components"):
+                assert ca[key] == cb[key], (k, key)
+    finally:
+        for e in engines + [single]:
+            e.close()
+
+
+def test_build_many_graphs_equal_separate_graphs():
+    """GeneMerGraph.build_many == [GeneMerGraph(reads, k, positions) for k in ...] through the object API, including a
+    correction on one of the later graphs (its engine gets the positions only then)"""
+    from amira_amd import GeneMerGraph
+    reads, pos, fq = P.synth_inputs(17, 400, 30, 100, 0.04)
+    many = GeneMerGraph.build_many(dict(reads), [3, 5, 7], {r: list(v) for r, v in pos.items()})
+    for g, k in zip(many, (3, 5, 7)):
+        one = GeneMerGraph(dict(reads), k, {r: list(v) for r, v in pos.items()})
+        assert list(g.get_nodes()) == list(one.get_nodes()) and list(g.get_edges()) == list(one.get_edges())
+        assert [n.get_node_coverage() for n in g.all_nodes()] == [n.get_node_coverage() for n in one.all_nodes()]
+        assert g.components() == one.components()
+        assert {r: list(v) for r, v in g.get_readNodePositions().items()} == \
+               {r: list(v) for r, v in one.get_readNodePositions().items()}
+        assert g.get_short_read_annotations() == one.get_short_read_annotations()
+        if k == 5:
+            g.filter_graph(3, 1)
+            one.filter_graph(3, 1)
+            assert g.correct_reads(fq) == one.correct_reads(fq)
+        one.close()
+    many[0].close()          # the first graph's engine is only handed back when the graphs that read its arrays are closed
+    assert many[0]._engine is not None
+    many[1].close()
+    many[2].close()
+    assert many[0]._engine is None
