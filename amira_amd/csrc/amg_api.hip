@@ -98,6 +98,7 @@ __global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long lon
 }
 
 int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out) {
+  if (l.overflow) return amg_fail(AMG_E_ARG, "fetch: more than %d words in one list", FETCH_MAX);
   const bool plain = getenv("AMG_PLAIN_SYNC") != nullptr;  // A/B switch: hipMemcpyAsync + hipStreamSynchronize
   if (plain) {
     for (int i = 0; i < l.n; ++i)
@@ -139,6 +140,7 @@ int fetch_status(amg_ctx* c, unsigned long long* out) {
 }
 
 int clear_many(amg_ctx* c, const ClearList& l) {
+  if (l.overflow) return amg_fail(AMG_E_ARG, "clear_many: more than %d ranges in one list", CLEAR_MAX);
   if (l.n == 0) return AMG_OK;
   ClearArgs a;
   unsigned long long most = 0;

@@ -276,12 +276,18 @@ int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, s
 
 // one launch that zeroes up to 8 device ranges (a hipMemsetAsync is a kernel launch of its own: ~5 us
 // each, and a build issued ~40 of them); sizes are rounded up to 4 bytes — pad the allocations
+#define CLEAR_MAX 8
 struct ClearList {
-  void* p[8];
-  unsigned long long bytes[8];
+  void* p[CLEAR_MAX];
+  unsigned long long bytes[CLEAR_MAX];
   int n = 0;
+  bool overflow = false;  // more than CLEAR_MAX ranges were added: clear_many refuses the list
   void add(void* ptr, size_t b) {
     if (b == 0) return;
+    if (n >= CLEAR_MAX) {
+      overflow = true;
+      return;
+    }
     p[n] = ptr;
     bytes[n] = (unsigned long long)((b + 3) & ~(size_t)3);
     ++n;
@@ -296,10 +302,17 @@ int clear_many(amg_ctx* c, const ClearList& l);
 struct FetchList {
   const unsigned long long* p[FETCH_MAX];
   int n = 0;
-  void add(const void* q) { if (n < FETCH_MAX) p[n++] = static_cast<const unsigned long long*>(q); }
+  bool overflow = false;  // more than FETCH_MAX words were asked for: fetch refuses the list
+  void add(const void* q) {
+    if (n < FETCH_MAX)
+      p[n++] = static_cast<const unsigned long long*>(q);
+    else
+      overflow = true;
+  }
   void add_words(const void* q, int words) { for (int i = 0; i < words; ++i) add(static_cast<const unsigned long long*>(q) + i); }
 };
 int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out);
+static_assert(ST_WORDS <= FETCH_MAX, "fetch_status reads the status words in one list");
 int fetch_status(amg_ctx* c, unsigned long long* out /*[ST_WORDS]*/);
 int stream_wait(amg_ctx* c);  // hipStreamSynchronize at the latency of fetch()
 

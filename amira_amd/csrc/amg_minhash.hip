@@ -146,11 +146,13 @@ extern "C" int amg_minhash(amg_ctx* c, const uint8_t* bases, const int64_t* seg_
   if (n_bases == 0) return AMG_OK;
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  // sourmash: max_hash = 2^64 - 1 for scaled 1, int(round(2^64 / scaled)) in double arithmetic otherwise
+  // sourmash (>= 4, Rust core: max_hash_for_scaled): 2^64 - 1 for scaled 1, otherwise (u64::MAX as f64 / scaled as
+  // f64) as u64 — a truncation.  (The old Python helper rounded; the two agree whenever the quotient is >= 2^53,
+  // i.e. for scaled <= 2048, which covers the reference's 1 and 10.)
   unsigned long long max_hash = ~0ull;
   if (scaled == 0) return amg_fail(AMG_E_ARG, "scaled must be >= 1");
   if (scaled > 1) {
-    const double q = rint(18446744073709551616.0 / (double)scaled);  // round half to even, as Python's round()
+    const double q = 18446744073709551616.0 / (double)scaled;   // u64::MAX as f64 == 2^64
     max_hash = q >= 18446744073709551615.0 ? ~0ull : (unsigned long long)q;
   }
   // upper bound of the output: every k-mer start (scaled == 1) or a generous share of them

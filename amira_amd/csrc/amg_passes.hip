@@ -2369,10 +2369,40 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   // borrowed genes / offsets / lengths go back to their owner: the corrected set lives in our own
   // allocations.  The position arrays stay where they are (borrowed or not): corrected reads point
   // into them and into the pool of produced positions.
+  // The pool of produced positions only grows while corrections follow each other without a new
+  // amg_set_positions.  Once it holds more than twice the live genes the corrected set's positions are gathered
+  // into flat arrays of our own, which become the new "caller's arrays" (borrowed ones go back to their owner
+  // here, earlier than the contract promises), and the pool starts empty again.
+  bool compacted = false;
+  if (c->have_pos && c->c_tokens > 0) {
+    long long slack = 1ll << 20;
+    if (const char* e = getenv("AMG_POS_COMPACT_MIN")) slack = atoll(e);  // test hook
+    if (c->c_pos1_used > 2 * c->c_tokens + slack) {
+      HIPCHK(hipSetDevice(c->device));
+      AMGCHK(c->c_gstart.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+      AMGCHK(c->c_gend.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+      CorrArgs a;
+      memset(&a, 0, sizeof(a));
+      fill_pos_args(c, a);
+      hipLaunchKernelGGL(k_gather_positions, dim3(nblk(c->c_reads, 4)), dim3(256), 0, c->stream, a,
+                         c->c_read_off.as<long long>(), c->c_pos_off.as<long long>(), (long long)c->c_reads,
+                         c->c_gstart.as<long long>(), c->c_gend.as<long long>());
+      HIPCHK(hipStreamSynchronize(c->stream));  // the borrowed arrays are read for the last time
+      c->gene_start.unborrow();
+      c->gene_end.unborrow();
+      std::swap(c->gene_start, c->c_gstart);
+      std::swap(c->gene_end, c->c_gend);
+      compacted = true;
+    }
+  }
   for (DevBuf* b : {&c->tokens, &c->read_off, &c->read_len}) b->unborrow();
   std::swap(c->tokens, c->c_tokens_buf);
   std::swap(c->read_off, c->c_read_off);
-  if (c->have_pos) {
+  if (c->have_pos && compacted) {
+    c->pos_identity = true;
+    c->pos_n0 = c->c_tokens;
+    c->pos1_used = c->c_pos1_used = 0;
+  } else if (c->have_pos) {
     std::swap(c->pos_off, c->c_pos_off);
     c->pos_identity = false;
     c->pos1_used = c->c_pos1_used;

@@ -242,13 +242,19 @@ class Engine:
             return out
         sets = np.ascontiguousarray(set_ids, dtype=np.int32)
         n = C.c_int64(0)
-        check(_ffi.lib.amg_minhash(self._h, ptr(bases), ptr(offs), ptr(sets), len(blobs), int(ksize), int(scaled),
-                                   None, None, 0, C.byref(n)))
+        # one pass: room for every k-mer start when all hashes are kept (scaled 1), for four times the expected share
+        # otherwise; hashed a second time only if that was not enough
+        cap = len(bases) if int(scaled) <= 1 else min(len(bases), 4 * len(bases) // int(scaled) + 1024)
+        while True:
+            o_set, o_hash = np.empty(cap, np.int32), np.empty(cap, np.uint64)
+            check(_ffi.lib.amg_minhash(self._h, ptr(bases), ptr(offs), ptr(sets), len(blobs), int(ksize), int(scaled),
+                                       ptr(o_set), ptr(o_hash), cap, C.byref(n)))
+            if n.value <= cap:
+                break
+            cap = n.value
         if n.value == 0:
             return out
-        o_set, o_hash = np.empty(n.value, np.int32), np.empty(n.value, np.uint64)
-        check(_ffi.lib.amg_minhash(self._h, ptr(bases), ptr(offs), ptr(sets), len(blobs), int(ksize), int(scaled),
-                                   ptr(o_set), ptr(o_hash), n.value, C.byref(n)))
+        o_set, o_hash = o_set[: n.value], o_hash[: n.value]
         order = np.lexsort((o_hash, o_set))
         o_set, o_hash = o_set[order], o_hash[order]
         cuts = np.flatnonzero(np.diff(o_set)) + 1

@@ -93,8 +93,10 @@ void* amg_stream(amg_ctx* ctx);
 /* ---- input: replaces the readDict / gene_positions arguments of
  *      GeneMerGraph.__init__ (construct_graph.py:31) ------------------------------- */
 /* on_device: 0 = host pointers (copied H2D); 1 = device pointers on ctx's device (copied D2D);
- * 2 = device pointers BORROWED without a copy: the caller keeps the memory alive and unchanged
- * until the next amg_set_* call for that array or amg_adopt_corrected; it is never written.
+ * 2 = device pointers BORROWED without a copy: the caller keeps the memory alive and unchanged — reads
+ * (tokens, read_offsets, read lengths) until the next amg_set_reads / amg_set_read_lengths or amg_adopt_corrected,
+ * POSITIONS until the next amg_set_positions / amg_set_reads (see there: longer than in releases before round 2,
+ * where amg_adopt_corrected let go of them too); borrowed memory is never written.
  * Stream contract for on_device != 0: the library reads the arrays on ITS OWN stream (amg_stream),
  * which is not ordered against the stream that produced them — the caller synchronises its
  * producer stream (or device) before the call.

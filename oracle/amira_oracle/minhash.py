@@ -10,7 +10,7 @@ its PUBLISHED algorithm is restated here (sourmash 4.8 `KmerMinHash`, DNA):
     complement;
   * hash = first 64 bits of MurmurHash3_x64_128(k-mer bytes, seed 42);
   * with `scaled = S` the sketch keeps every hash <= max_hash, max_hash = 2^64 - 1 for S = 1 and
-    int(round(2^64 / S)) (float arithmetic, as sourmash does it) otherwise; `n = 0`: no size bound.
+    int(2^64 / S) (float division, truncated, as sourmash's Rust core does it) otherwise; `n = 0`: no size bound.
 PARITY: pinned by reference-held test vectors only — tests/test_gene_mer_graph.py:5154-5155
 (containments 0.9105839416058394 / 0.9091323161011159 on tests/test_1.fastq.gz) and :4528-4607
 (assess_connectivity thresholds) — see tests/test_minhash_cpu.py.
@@ -87,7 +87,9 @@ def max_hash_for_scaled(scaled):
         return 0
     if scaled == 1:
         return M64
-    return int(round(2 ** 64 / scaled, 0))
+    # sourmash >= 4 (Rust core, max_hash_for_scaled): (u64::MAX as f64 / scaled as f64) as u64 — a truncation; the
+    # older Python helper rounded: equal whenever the quotient is >= 2^53 (scaled <= 2048: the reference's 1 and 10)
+    return min(int(float(2 ** 64) / float(scaled)), M64)
 
 
 class MinHash:
