@@ -67,6 +67,7 @@ extern "C" int amg_set_timing(amg_ctx* c, int on) {
 struct ClearArgs {
   void* p[8];
   unsigned long long words[8];  // 4-byte words per range
+  unsigned int fill[8];         // the word each range is filled with
   int n;
 };
 __global__ __launch_bounds__(256) void k_clear_many(ClearArgs a) {
@@ -74,16 +75,17 @@ __global__ __launch_bounds__(256) void k_clear_many(ClearArgs a) {
   for (int r = 0; r < a.n; ++r) {
     unsigned int* p = reinterpret_cast<unsigned int*>(a.p[r]);
     const unsigned long long w = a.words[r];
+    const unsigned int f = a.fill[r];
     // 16-byte stores over the aligned middle, words at the ragged ends
     const unsigned long long head = ((16u - ((unsigned long long)(uintptr_t)p & 15u)) & 15u) >> 2;
     const unsigned long long h = head < w ? head : w;
     const unsigned long long quads = (w - h) >> 2;
     uint4* q = reinterpret_cast<uint4*>(p + h);
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < quads; i += stride)
-      q[i] = make_uint4(0u, 0u, 0u, 0u);
+      q[i] = make_uint4(f, f, f, f);
     if (blockIdx.x == 0) {
-      for (unsigned long long i = threadIdx.x; i < h; i += 256) p[i] = 0u;
-      for (unsigned long long i = h + quads * 4 + threadIdx.x; i < w; i += 256) p[i] = 0u;
+      for (unsigned long long i = threadIdx.x; i < h; i += 256) p[i] = f;
+      for (unsigned long long i = h + quads * 4 + threadIdx.x; i < w; i += 256) p[i] = f;
     }
   }
 }
@@ -148,6 +150,7 @@ int clear_many(amg_ctx* c, const ClearList& l) {
   for (int i = 0; i < l.n; ++i) {
     a.p[i] = l.p[i];
     a.words[i] = l.bytes[i] >> 2;
+    a.fill[i] = l.fill[i];
     most = a.words[i] > most ? a.words[i] : most;
   }
   unsigned long long blocks = (most / 4 + 256 * 8 - 1) / (256 * 8);  // ~8 quads per thread at the largest range
@@ -198,7 +201,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_cnt, &c->ladj_pos, &c->ladj_keys, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp, &c->scan_state,   &c->s0, &c->s1, &c->s2, &c->s3,
-                   &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->gm_mask, &c->gm_tab, &c->gm_res, &c->gm_list, &c->gm_q, &c->gm_pool, &c->gm_ctr, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->f_ctrs, &c->x_efinal, &c->x_first_all, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
+                   &c->s4, &c->s5, &c->cnt_state, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->gm_mask, &c->gm_tab, &c->gm_res, &c->gm_list, &c->gm_q, &c->gm_pool, &c->gm_ctr, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->x_ncnt, &c->f_ctrs, &c->x_efinal, &c->x_first_all, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
   for (DevBuf* b : all) b->release();
   if (c->mail_host) (void)hipHostFree(c->mail_host);
   (void)hipStreamDestroy(c->stream);

@@ -383,13 +383,19 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   __syncthreads();
   const long long stride = (long long)gridDim.x * 1024;
   unsigned int beyond = 0;
+  // strip: 1 = claims as the table pass wrote them (flags in the top bits), 2 = and the occurrence that created a
+  // key is not counted (every counter started at 1: count_ids)
   auto tally = [&](int id, long long t) {
-    if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);  // claims with the last-window flag
+    bool made = false;
+    if (strip && id != -1) {
+      made = strip == 2 && ((unsigned int)id & AMG_MADE_FLAG) != 0u;
+      id = (int)((unsigned int)id & ~AMG_FLAG_MASK);
+    }
     if (GATHER) {
       id = id < 0 ? -1 : (remap ? remap[id] : tab[id].id);
       ids[t] = id;
     }
-    if (id < 0) return;
+    if (id < 0 || made) return;
     const long long rel = (long long)id - lo;
     if (rel < 0) return;
     if (rel < HOT_IDS) {
@@ -406,12 +412,18 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   i4* ids4 = reinterpret_cast<i4*>(ids);
   long long q = (long long)blockIdx.x * 1024 + threadIdx.x;
   auto tally4 = [&](i4 x, long long qi) {
+    unsigned int mades = 0;
+    if (strip == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (x[j] != -1 && ((unsigned int)x[j] & AMG_MADE_FLAG)) mades |= 1u << j;
+    }
     if (GATHER) {
       i4 y;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int id = x[j];
-        if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);
+        if (strip && id != -1) id = (int)((unsigned int)id & ~AMG_FLAG_MASK);
         y[j] = id < 0 ? -1 : (remap ? remap[id] : tab[id].id);
       }
       ids4[qi] = y;
@@ -420,8 +432,8 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int id = x[j];
-      if (!GATHER && strip && id != -1) id = (int)((unsigned int)id & ~AMG_LAST_FLAG);
-      if (id < 0) continue;
+      if (!GATHER && strip && id != -1) id = (int)((unsigned int)id & ~AMG_FLAG_MASK);
+      if (id < 0 || (mades & (1u << j))) continue;
       const long long rel = (long long)id - lo;
       if (rel < 0) continue;
       if (rel < HOT_IDS) {
@@ -452,8 +464,9 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   }
 }
 
-// counts[id] += occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes,
-// 2 / 3 node / edge-class claims as the table pass wrote them (id | AMG_LAST_FLAG on the last window of a read)
+// counts[id] = occurrences of id in ids[0..n); n_ids distinct ids; kind: 0 nodes, 1 edge classes,
+// 2 / 3 node / edge-class claims as a table pass wrote them (flag bits on top), 4 / 5 the same with the creating
+// occurrence marked (AMG_MADE_FLAG: the exact-key passes)
 int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long long n_ids, unsigned int* out,
                     int edges) {
   return count_ids(c, claims, n, nullptr, n_ids, out, edges ? 3 : 2, remap);
@@ -462,17 +475,20 @@ int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind, const int* remap) {
   hipStream_t st = c->stream;
+  // kinds 4 / 5: the ids carry AMG_MADE_FLAG on the occurrence that created their key — exactly one per id — so every
+  // counter starts at 1 and the sweeps leave those occurrences out: an id seen once costs nothing
+  const bool made = kind >= 4;
   ClearList cl;
-  cl.add(out, (size_t)(n_ids + 1) * sizeof(unsigned int));
+  cl.add(out, (size_t)(n_ids + 1) * sizeof(unsigned int), made ? 1u : 0u);
   const bool fresh = !c->cnt_state.p || c->cnt_hint_reset;
   // per kind (nodes / edge classes) a block of 2 * COUNT_MAX_SWEEPS state words; the two hints after both blocks
   AMGCHK(c->cnt_state.ensure((4 * COUNT_MAX_SWEEPS + 4) * sizeof(unsigned long long)));
   if (fresh) c->cnt_sweeps[0] = c->cnt_sweeps[1] = COUNT_MAX_SWEEPS;
   c->cnt_hint_reset = false;
-  const int kslot = (kind == 1 || kind == 3) ? 1 : 0;
+  const int kslot = (kind == 1 || kind == 3 || kind == 5) ? 1 : 0;
   unsigned long long* state = c->cnt_state.as<unsigned long long>() + kslot * 2 * COUNT_MAX_SWEEPS;
   unsigned long long* hint = c->cnt_state.as<unsigned long long>() + 4 * COUNT_MAX_SWEEPS + 2 * kslot;
-  const int strip = kind >= 2 ? 1 : 0;
+  const int strip = made ? 2 : (kind >= 2 ? 1 : 0);
   cl.add(state, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long));
   if (fresh) cl.add(c->cnt_state.as<unsigned long long>() + 4 * COUNT_MAX_SWEEPS, 4 * sizeof(unsigned long long));
   AMGCHK(clear_many(c, cl));

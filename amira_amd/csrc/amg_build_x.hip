@@ -115,7 +115,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
     if (t >= n_tokens) continue;
     int out = -1;
-    if (slot[it] >= 0) out = (int)((id1[it] - 1u) | ((last & (1u << it)) ? AMG_LAST_FLAG : 0u));
+    if (slot[it] >= 0)
+      out = (int)((id1[it] - 1u) | ((last & (1u << it)) ? AMG_LAST_FLAG : 0u) | ((created & (1u << it)) ? AMG_MADE_FLAG : 0u));
     __builtin_nontemporal_store(out, tok_claim + t);
     __builtin_nontemporal_store(slot[it] >= 0 ? (signed char)dirs[it] : (signed char)0, tok_dir + t);
   }
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
   const int i0 = 4 * tid;
   unsigned int id1[TILE_ITEMS];
   unsigned int last = 0, ndir = 0, valid = 0;  // per window: last of its read; direction -1; has a node
+  unsigned int made = 0;                       // per window: it created its node's key
   {
     unsigned long long w1[TILE_ITEMS];
     unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS];
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
       if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
     }
     f_table_phase<TWO, 1, false>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2,
-                                 slot_by_claim, status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave);
+                                 slot_by_claim, status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave,
+                                 &made);
   }
   i4 oc;
   unsigned int od = 0;
@@ -227,7 +230,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
     int o[TILE_ITEMS];
 #pragma unroll
     for (int w = 0; w < TILE_ITEMS; ++w) {
-      o[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u)) : -1;
+      o[w] = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
+                            ((made & (1u << w)) ? AMG_MADE_FLAG : 0u))
+                    : -1;
       od |= (id1[w] ? ((ndir & (1u << w)) ? 0xffu : 1u) : 0u) << (8 * w);
     }
     oc = i4{o[0], o[1], o[2], o[3]};
@@ -422,7 +427,7 @@ __global__ void k_xc_union(const int* __restrict__ tok_claim, long long n_tokens
   if (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) return;
   const int nxt = tok_claim[t + 1];
   if (nxt == -1) return;
-  int a = (int)((unsigned int)raw & ~AMG_LAST_FLAG), b = (int)((unsigned int)nxt & ~AMG_LAST_FLAG);
+  int a = (int)((unsigned int)raw & ~AMG_FLAG_MASK), b = (int)((unsigned int)nxt & ~AMG_FLAG_MASK);
   while (true) {
     a = uf_find(parent, a);
     b = uf_find(parent, b);
@@ -494,8 +499,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
       d = __builtin_nontemporal_load(tok_dir + t);
     }
     int id = -1;
-    if (raw != -1) id = (ablate & 64) ? (int)((unsigned int)raw & ~AMG_LAST_FLAG)  // timing experiment
-                                      : final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG];
+    if (raw != -1) id = (ablate & 64) ? (int)((unsigned int)raw & ~AMG_FLAG_MASK)  // timing experiment
+                                      : final_of_claim[(unsigned int)raw & ~AMG_FLAG_MASK];
     s_id[i] = id;
     s_dir[i] = d;
     s_last[i] = (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) ? 1 : 0;
@@ -547,7 +552,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     const long long t = t0 + threadIdx.x + it * TILE_THREADS;
-    if (t < n_tokens) __builtin_nontemporal_store(slot[it] >= 0 ? (int)(id1[it] - 1u) : -1, tok_pair + t);
+    if (t < n_tokens)
+      __builtin_nontemporal_store(slot[it] >= 0 ? (int)((id1[it] - 1u) | ((created & (1u << it)) ? AMG_MADE_FLAG : 0u)) : -1,
+                                  tok_pair + t);
   }
 }
 
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
   const int i0 = 4 * tid;
   const long long t = t0 + i0;
   // node id of a window: -1 no node, -2 a node the merge's fused filter dropped (amg_dist.hip)
-  auto node_of = [&](int raw) { return raw == -1 ? -1 : final_of_claim[(unsigned int)raw & ~AMG_LAST_FLAG]; };
+  auto node_of = [&](int raw) { return raw == -1 ? -1 : final_of_claim[(unsigned int)raw & ~AMG_FLAG_MASK]; };
   auto word = [&](int raw, int id, unsigned int d) {  // d: the direction byte
     if (id < 0) return -1;
     return (int)((unsigned int)id | ((unsigned int)raw & AMG_LAST_FLAG) | ((d & 0x80u) ? DIRBIT : 0u));
@@ -642,9 +649,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
 #endif
     valid |= 1u << w;
   }
+  unsigned int made = 0;
   f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
-                                 slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave);
-  const i4 op = {(int)id1[0] - 1, (int)id1[1] - 1, (int)id1[2] - 1, (int)id1[3] - 1};
+                                 slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave,
+                                 &made);
+  i4 op;
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w)
+    op[w] = id1[w] ? (int)((id1[w] - 1u) | ((made & (1u << w)) ? AMG_MADE_FLAG : 0u)) : -1;
   if (t + TILE_ITEMS <= n_tokens) {
     __builtin_nontemporal_store(op, reinterpret_cast<i4*>(tok_pair + t));
   } else {
@@ -797,8 +809,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
       // get claims scattered over the first few hundred thousand, and whoever counts by claim (k_count_ids, one
       // LDS range of 32 k ids per sweep) needs several sweeps.  A short head launch over the first few genome
       // coverages creates them first: their claims are then the lowest.
-      // (only the filtered build counts by node claim; the plain build counts by ranked node id)
-      const long long head = c->filtered_build ? head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8) : 0;
+      const long long head = head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8);
       for (int part = 0; part < 2; ++part) {
         const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
         if (cnt <= 0) continue;
@@ -844,7 +855,7 @@ int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   const long long n = c->n_local_nodes, T = c->n_tokens;
   stage_begin(c, "node_count");  // per claim, straight from the per-window claims (construct_node.py:33-36)
   AMGCHK(c->x_ecnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->x_ecnt.as<unsigned int>(), 2));
+  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->x_ecnt.as<unsigned int>(), 4));
   stage_end(c);
   stage_begin(c, "node_filter");
   AMGCHK(c->x_first_all.ensure((size_t)(n + 2) * sizeof(unsigned int)));
@@ -982,15 +993,23 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
 int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov) {
   const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
   if (min_edge_cov == 0) {
-    // node coverage (construct_node.py:33-36) from the per-window node ids
+    // node coverage (construct_node.py:33-36): occurrences per CLAIM from the node pass's per-window claims — the
+    // occurrence that created a key is marked there, so the keys seen once (most of an uncorrected graph) cost
+    // nothing — then one store per claim into the node's counter
     stage_begin(c, "node_count");
-    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, D, c->node_cov.as<unsigned int>(), 0));
+    const long long S = c->x_nspace;
+    AMGCHK(c->x_ncnt.ensure((size_t)(S + 2) * sizeof(unsigned int)));
+    AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, S, c->x_ncnt.as<unsigned int>(), 4));
+    if (S > 0 && D > 0)
+      hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(S, 256)), dim3(256), 0, c->stream,
+                         c->x_ncnt.as<unsigned int>(), c->x_first.as<unsigned int>(), c->x_final.as<int>(), S,
+                         c->node_cov.as<unsigned int>());
     stage_end(c);
   }
   // edge-class coverage per claim
   stage_begin(c, "edge_count");
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 1));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 5));
   stage_end(c);
   if (min_edge_cov > 1 && P > 0) {  // filter_graph's edge threshold (:531-535)
     hipStream_t st = c->stream;

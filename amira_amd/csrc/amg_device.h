@@ -4,6 +4,11 @@
 
 #define AMG_WAVE 64
 #define AMG_LAST_FLAG 0x80000000u
+// per-window claims of the exact-key table passes: bit 30 marks the occurrence that CREATED the key.  Every key
+// has exactly one, so occurrence counters start at 1 and the counting sweeps skip the marked occurrences: the
+// millions of keys seen once (the error gene-mers of an uncorrected read set) then cost no atomic at all
+#define AMG_MADE_FLAG 0x40000000u
+#define AMG_FLAG_MASK (AMG_LAST_FLAG | AMG_MADE_FLAG)
 
 // relaxed, agent-scope accessors: L1-bypassing loads, coherent with the device-scope
 // atomics that mutate the tables (MI355X_MICROARCH.md, "Inter-workgroup visibility").

@@ -265,7 +265,7 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
   // local occurrence counts per claim, straight from the per-window claims
   stage_begin(c, "node_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 2));
+  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 4));
   stage_end(c);
   stage_begin(c, "merge_node_bucket");
   Bucketing b;
@@ -293,7 +293,7 @@ static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
   const long long n = c->n_local_pairs, T = c->n_tokens;
   stage_begin(c, "edge_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 1));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 5));
   stage_end(c);
   stage_begin(c, "merge_edge_bucket");
   Bucketing b;

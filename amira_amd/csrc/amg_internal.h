@@ -218,6 +218,7 @@ struct amg_ctx {
   DevBuf x_final;            // int32 [claims]  claim id -> node id
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
+  DevBuf x_ncnt;             // uint32[node claims] occurrences (plain build: scattered into node_cov)
   DevBuf f_ctrs;             // fused table pass: per-shard claim counters
   DevBuf x_efinal;           // int32 [edge claims] claim id -> edge-class id
   DevBuf x_first_all;        // uint32[claims] filtered build: ~first_seen of EVERY claim (k_x_drop_claims zeroes x_first)
@@ -282,7 +283,8 @@ struct ClearList {
   unsigned long long bytes[CLEAR_MAX];
   int n = 0;
   bool overflow = false;  // more than CLEAR_MAX ranges were added: clear_many refuses the list
-  void add(void* ptr, size_t b) {
+  unsigned int fill[CLEAR_MAX];  // 32-bit word the range is filled with (0: cleared)
+  void add(void* ptr, size_t b, unsigned int value = 0u) {
     if (b == 0) return;
     if (n >= CLEAR_MAX) {
       overflow = true;
@@ -290,6 +292,7 @@ struct ClearList {
     }
     p[n] = ptr;
     bytes[n] = (unsigned long long)((b + 3) & ~(size_t)3);
+    fill[n] = value;
     ++n;
   }
 };

@@ -318,7 +318,8 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                                               unsigned int* __restrict__ slot_by_claim,
                                               unsigned long long* ctr, unsigned int shard, unsigned int cap,
                                               unsigned int probe_limit, unsigned long long* status, int which,
-                                              unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr) {
+                                              unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr,
+                                              unsigned int* made = nullptr) {
   auto tpos = [&](int it) { return tbase + (unsigned int)it; };
   auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
@@ -370,6 +371,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
       }
     if (made) created |= 1u << it;
   }
+  if (made) *made = created;
   // ---- claim ids of the wave's creators
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
