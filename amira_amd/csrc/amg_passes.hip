@@ -163,26 +163,93 @@ __global__ void k_live_keys(const unsigned char* __restrict__ e_alive, const int
   vals[o] = (unsigned int)e;
 }
 
-__global__ void k_live_ent(const unsigned int* __restrict__ edge_of, const int* __restrict__ e_tgt,
-                           const signed char* __restrict__ e_tdir, long long n_live, int2* __restrict__ lent) {
+// Rows from the dense list of live edges WITHOUT a sort (a library radix sort of a few ten thousand pairs is a
+// dozen launches).  The live edges of a row are few (one side of one node), so:
+//   k_lr_count   every live edge adds 1 to its row's counter                          (rows zeroed before)
+//   k_lr_alloc   every live edge takes a ticket of its row; ticket 0 reserves the row's stretch of the entry
+//                array — stretches are handed out per workgroup with ONE atomicAdd (their order is irrelevant)
+//   k_lr_fill    every live edge drops its edge id into its row's stretch at its ticket (any order)
+//   k_lr_finish  the ticket-0 edge of a row sorts the row's ids ascending (= list order of the reference: edge ids
+//                follow insertion order) and writes the entries {target, direction} and the row record; rows longer
+//                than LR_SMALL are left to k_lr_long, a workgroup per long row (hub nodes)
+#define LR_SMALL 32
+__global__ void k_lr_count(const unsigned int* __restrict__ keys, long long n_live, int4* __restrict__ lrows) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_live) return;
-  const unsigned int e = edge_of[i];
-  lent[i] = make_int2(e_tgt[e], (int)e_tdir[e]);
+  if (i < n_live) atomicAdd(&lrows[keys[i]].y, 1);
 }
 
-// one row record per run of equal keys (rows without a live edge keep the zero record of the memset:
-// every reader tests the count first); runs are short — the live edges of one side of one node
-__global__ void k_live_rows(const unsigned int* __restrict__ keys, const int2* __restrict__ lent, long long n_live,
-                            int4* __restrict__ lrows) {
+__global__ __launch_bounds__(256) void k_lr_alloc(const unsigned int* __restrict__ keys, long long n_live,
+                                                  int4* __restrict__ lrows, unsigned int* __restrict__ tick,
+                                                  unsigned long long* pool) {
+  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned long long s_base;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_live) return;
+  unsigned int t = 1, cnt = 0, key = 0;
+  if (i < n_live) {
+    key = keys[i];
+    t = (unsigned int)atomicAdd(&lrows[key].z, 1);
+    tick[i] = t;
+    if (t == 0) cnt = (unsigned int)lrows[key].y;  // final: k_lr_count is a launch of its own
+  }
+  unsigned int total;
+  const unsigned int off = block_exscan_256(cnt, &total, s_wave);
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(pool, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  if (i < n_live && t == 0) lrows[key].x = (int)(s_base + off);
+}
+
+__global__ void k_lr_fill(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ edge_of,
+                          const unsigned int* __restrict__ tick, long long n_live, const int4* __restrict__ lrows,
+                          unsigned int* __restrict__ tmp) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_live) tmp[lrows[keys[i]].x + tick[i]] = edge_of[i];
+}
+
+__global__ void k_lr_finish(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ tick, long long n_live,
+                            const unsigned int* __restrict__ tmp, const int* __restrict__ e_tgt,
+                            const signed char* __restrict__ e_tdir, int4* __restrict__ lrows, int2* __restrict__ lent,
+                            unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_live || tick[i] != 0u) return;
   const unsigned int key = keys[i];
-  if (i > 0 && keys[i - 1] == key) return;
-  long long j = i + 1;
-  while (j < n_live && keys[j] == key) ++j;
-  const int2 first = lent[i];
-  lrows[key] = make_int4((int)i, (int)(j - i), first.x, first.y);
+  const int off = lrows[key].x, cnt = lrows[key].y;
+  if (cnt > LR_SMALL) {
+    long_rows[atomicAdd(n_long, 1ull)] = key;
+    return;
+  }
+  unsigned int e[LR_SMALL];
+  for (int j = 0; j < cnt; ++j) {  // insertion sort in registers / scratch: rows hold a handful of edges
+    const unsigned int x = tmp[off + j];
+    int p = j;
+    while (p > 0 && e[p - 1] > x) {
+      e[p] = e[p - 1];
+      --p;
+    }
+    e[p] = x;
+  }
+  for (int j = 0; j < cnt; ++j) lent[off + j] = make_int2(e_tgt[e[j]], (int)e_tdir[e[j]]);
+  lrows[key] = make_int4(off, cnt, e_tgt[e[0]], (int)e_tdir[e[0]]);
+}
+
+// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids
+__global__ __launch_bounds__(256) void k_lr_long(const unsigned int* __restrict__ long_rows,
+                                                 const unsigned long long* __restrict__ n_long,
+                                                 const unsigned int* __restrict__ tmp, const int* __restrict__ e_tgt,
+                                                 const signed char* __restrict__ e_tdir, int4* __restrict__ lrows,
+                                                 int2* __restrict__ lent) {
+  const unsigned long long n = *n_long;
+  for (unsigned long long r = blockIdx.x; r < n; r += gridDim.x) {
+    const unsigned int key = long_rows[r];
+    const int off = lrows[key].x, cnt = lrows[key].y;
+    __syncthreads();  // (the row record is rewritten below: everybody has read it)
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const unsigned int x = tmp[off + j];
+      int rank = 0;
+      for (int q = 0; q < cnt; ++q) rank += tmp[off + q] < x ? 1 : 0;
+      lent[off + rank] = make_int2(e_tgt[x], (int)e_tdir[x]);
+      if (rank == 0) lrows[key] = make_int4(off, cnt, e_tgt[x], (int)e_tdir[x]);
+    }
+  }
 }
 
 // forward/backward edge lists with the removed edges squeezed out: the walkers below then
@@ -193,9 +260,15 @@ static int ensure_live_adj(amg_ctx* c) {
   hipStream_t st = c->stream;
   const long long rows = 2 * c->n_nodes, E = c->n_edges;
   AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
-  HIPCHK(hipMemsetAsync(c->ladj_rows.p, 0, (size_t)(rows + 2) * sizeof(int4), st));
   AMGCHK(c->ladj_cnt.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->ladj_pos.ensure((size_t)(E + 2) * sizeof(long long)));
+  unsigned long long* ctr = c->status.as<unsigned long long>() + ST_COMPACT_A;  // [0] entries handed out, [1] long rows
+  {
+    ClearList cl;
+    cl.add(c->ladj_rows.p, (size_t)(rows + 2) * sizeof(int4));
+    cl.add(ctr, 2 * sizeof(unsigned long long));
+    AMGCHK(clear_many(c, cl));
+  }
   hipLaunchKernelGGL(k_live_flags, dim3(nblk(E + 1, 256)), dim3(256), 0, st, c->edge_alive.as<unsigned char>(), E,
                      c->ladj_cnt.as<unsigned int>());
   AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_pos.as<long long>(), (size_t)E + 1));
@@ -206,22 +279,26 @@ static int ensure_live_adj(amg_ctx* c) {
     AMGCHK(fetch(c, l, reinterpret_cast<unsigned long long*>(&total)));
   }
   AMGCHK(c->ladj.ensure((size_t)(total + 1) * sizeof(int2)));
-  AMGCHK(c->ladj_keys.ensure(4 * (size_t)(total + 2) * sizeof(unsigned int)));
-  unsigned int* k_in = c->ladj_keys.as<unsigned int>();
-  unsigned int* v_in = k_in + (total + 2);
-  unsigned int* k_out = v_in + (total + 2);
-  unsigned int* v_out = k_out + (total + 2);
+  AMGCHK(c->ladj_keys.ensure(5 * (size_t)(total + 2) * sizeof(unsigned int)));
+  unsigned int* keys = c->ladj_keys.as<unsigned int>();
+  unsigned int* edge_of = keys + (total + 2);
+  unsigned int* tick = edge_of + (total + 2);
+  unsigned int* tmp = tick + (total + 2);
+  unsigned int* long_rows = tmp + (total + 2);
   if (total > 0) {
     hipLaunchKernelGGL(k_live_keys, dim3(nblk(E, 256)), dim3(256), 0, st, c->edge_alive.as<unsigned char>(),
-                       c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), c->ladj_pos.as<long long>(), E, k_in,
-                       v_in);
-    AMGCHK(prim_sort_u32_u32(c, k_in, k_out, v_in, v_out, (size_t)total, ilog2_ceil((uint64_t)rows + 2) + 1));
-    hipLaunchKernelGGL(k_live_ent, dim3(nblk(total, 256)), dim3(256), 0, st, v_out, c->edge_tgt.as<int>(),
-                       c->edge_tdir.as<signed char>(), total, c->ladj.as<int2>());
+                       c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), c->ladj_pos.as<long long>(), E, keys,
+                       edge_of);
+    hipLaunchKernelGGL(k_lr_count, dim3(nblk(total, 256)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>());
+    hipLaunchKernelGGL(k_lr_alloc, dim3(nblk(total, 256)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>(), tick,
+                       ctr);
+    hipLaunchKernelGGL(k_lr_fill, dim3(nblk(total, 256)), dim3(256), 0, st, keys, edge_of, tick, total,
+                       c->ladj_rows.as<int4>(), tmp);
+    hipLaunchKernelGGL(k_lr_finish, dim3(nblk(total, 256)), dim3(256), 0, st, keys, tick, total, tmp, c->edge_tgt.as<int>(),
+                       c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>(), long_rows, ctr + 1);
+    hipLaunchKernelGGL(k_lr_long, dim3(64), dim3(256), 0, st, long_rows, ctr + 1, tmp, c->edge_tgt.as<int>(),
+                       c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>());
   }
-  if (total > 0)
-    hipLaunchKernelGGL(k_live_rows, dim3(nblk(total, 256)), dim3(256), 0, st, k_out, c->ladj.as<int2>(), total,
-                       c->ladj_rows.as<int4>());
   c->ladj_valid = true;
   return AMG_OK;
 }
