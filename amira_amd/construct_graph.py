@@ -763,6 +763,8 @@ class GeneMerGraph(BubblePopping):
 
     def remove_junk_reads(self, error_rate):
         """split reads by their fraction of masked nodes; Python round() (:1398-1420)."""
+        if not self._host_edits:
+            return self._remove_junk_reads_arrays(error_rate)
         new_reads, new_positions, rejected_reads, rejected_read_positions = {}, {}, {}, {}
         for read_id, nodes in self.get_readNodes().items():
             allowed = round(len(nodes) * (1 - error_rate))
@@ -774,6 +776,28 @@ class GeneMerGraph(BubblePopping):
                 rejected_reads[read_id] = self._reads[read_id]
                 rejected_read_positions[read_id] = self._genePositions[read_id]
         return new_reads, new_positions, rejected_reads, rejected_read_positions
+
+    def _remove_junk_reads_arrays(self, error_rate):
+        """remove_junk_reads from the device's per-window node ids: masked windows per read by one segmented sum, the
+        reference's round() (half to even, in double arithmetic) by numpy's rint of the same product"""
+        tok_node, _ = self._engine.read_nodes()
+        offs, k = self._read_off, self._kmerSize
+        n_win = np.maximum(np.diff(offs) - k + 1, 0) if len(offs) > 1 else np.zeros(0, np.int64)
+        rows = np.flatnonzero(n_win > 0)            # the reads get_readNodes() lists, in read order
+        masked_tok = (tok_node == -2).astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(masked_tok)])
+        masked = csum[offs[rows] + n_win[rows]] - csum[offs[rows]]
+        allowed = np.rint(n_win[rows].astype(np.float64) * (1 - error_rate))
+        ok = masked <= allowed
+        keep_rows, drop_rows = rows[ok], rows[~ok]
+        if self._tokenized_io(self._genePositions is not None) and self._genePositions is not None:
+            return (self._reads.subset(keep_rows), self._genePositions.subset(keep_rows),
+                    self._reads.subset(drop_rows), self._genePositions.subset(drop_rows))
+        ids, reads, pos = self._read_ids, self._reads, self._genePositions
+        keep = [ids[i] for i in keep_rows.tolist()]
+        drop = [ids[i] for i in drop_rows.tolist()]
+        return ({r: reads[r] for r in keep}, {r: pos[r] for r in keep},
+                {r: reads[r] for r in drop}, {r: pos[r] for r in drop})
 
     def get_valid_reads_only(self):
         fix = self.get_reads_to_correct()

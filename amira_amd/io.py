@@ -13,6 +13,16 @@ from ._ffi import check, ptr
 from .tokens import Vocabulary
 
 
+def _gather_rows(offsets, rows):
+    """(flat element indices, new offsets) of the CSR rows `rows`, in that order"""
+    rows = np.asarray(rows, dtype=np.int64)
+    n = offsets[rows + 1] - offsets[rows]
+    new_off = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum(n, out=new_off[1:])
+    idx = np.repeat(offsets[rows] - new_off[:-1], n) + np.arange(int(new_off[-1]), dtype=np.int64)
+    return idx, new_off
+
+
 class TokenizedReads(Mapping):
     """{read id: ["+geneA", ...]} backed by CSR token arrays (lists are decoded on access)."""
 
@@ -36,6 +46,14 @@ class TokenizedReads(Mapping):
             got = self._cache[read_id] = self.vocab.decode(
                 self.tokens[self.read_offsets[i]:self.read_offsets[i + 1]])
         return got
+
+    def subset(self, rows):
+        """the reads at `rows` (indices into read_ids), in that order, as a TokenizedReads of their own"""
+        rows = np.asarray(rows, dtype=np.int64)
+        idx, new_off = _gather_rows(self.read_offsets, rows)
+        ids = np.asarray(self.read_ids, dtype=object)[rows].tolist()
+        src = rows if self.source_rows is None else self.source_rows[rows]
+        return TokenizedReads(self.vocab, self.tokens[idx], new_off, ids, source_rows=src)
 
     def gene_at(self, read_id, i):
         """self[read_id][i] without decoding the rest of the read"""
@@ -86,6 +104,21 @@ class TokenizedPositions(Mapping):
             a, b = int(src.read_offsets[j]), int(src.read_offsets[j + 1])
             got = self._cache[read_id] = list(zip(src.gene_start[a:b].tolist(), src.gene_end[a:b].tolist()))
         return got
+
+    def subset(self, rows):
+        """the positions of the reads at `rows`, in that order, as a TokenizedPositions of their own"""
+        rows = np.asarray(rows, dtype=np.int64)
+        if self._moved is not None or self._cache:   # redirected / hand-set reads: row by row
+            ids = [self.read_ids[i] for i in rows.tolist()]
+            per = [self[r] for r in ids]
+            new_off = np.zeros(len(ids) + 1, np.int64)
+            np.cumsum([len(p) for p in per], out=new_off[1:])
+            gs = np.fromiter((x[0] for p in per for x in p), dtype=np.int64, count=int(new_off[-1]))
+            ge = np.fromiter((x[1] for p in per for x in p), dtype=np.int64, count=int(new_off[-1]))
+            return TokenizedPositions(ids, new_off, gs, ge)
+        idx, new_off = _gather_rows(self.read_offsets, rows)
+        ids = np.asarray(self.read_ids, dtype=object)[rows].tolist()
+        return TokenizedPositions(ids, new_off, self.gene_start[idx], self.gene_end[idx])
 
     def copy(self):
         """the caller's own copy (the arrays are shared — they are never written — the redirections are not)"""

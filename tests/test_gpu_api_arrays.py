@@ -81,3 +81,28 @@ def test_correct_reads_updates_the_positions_it_was_given():
         assert rt[r] == rd[r] and [tuple(x) for x in pt[r]] == [tuple(x) for x in pd[r]]
     gd.close()
     gt.close()
+
+
+@pytest.mark.parametrize("rate", [0.8, 0.5, 0.25])
+def test_remove_junk_reads_on_arrays_equals_dicts(rate):
+    """remove_junk_reads (:1398-1420) from the device's per-window ids — dict inputs and array-backed inputs — against
+    the per-read loop over the object view (which a host edit switches back on)"""
+    from amira_amd import GeneMerGraph
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    pos_d = {r: list(v) for r, v in pos.items()}
+    treads, tpos, _ = _tokenized(reads, pos, fq)
+    gd, gt, gl = GeneMerGraph(dict(reads), 5, pos_d), GeneMerGraph(treads, 5, tpos), GeneMerGraph(dict(reads), 5, pos_d)
+    for g in (gd, gt, gl):
+        g.filter_graph(3, 1)
+    gl.get_readNodes()
+    gl._host_edits = True            # the reference-shaped loop
+    want = gl.remove_junk_reads(rate)
+    assert len(want[0]) > 0 and len(want[2]) > 0
+    for got in (gd.remove_junk_reads(rate), gt.remove_junk_reads(rate)):
+        for a, b in zip(got, want):
+            assert list(a) == list(b)
+            for r in b:
+                assert [tuple(x) if isinstance(x, (list, tuple)) else x for x in a[r]] == \
+                       [tuple(x) if isinstance(x, (list, tuple)) else x for x in b[r]]
+    for g in (gd, gt, gl):
+        g.close()
