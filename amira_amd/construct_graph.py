@@ -120,12 +120,64 @@ class _GraphNode(Node):
     def listOfReads(self, value):
         self._reads_list = value
 
+    # the forward / backward edge-hash lists are made (and their edges hashed) the first time they are looked at:
+    # read-path clustering asks for the neighbours of a few hundred nodes of tens of thousands
+    def _lazy_edges(self, forward_maker, backward_maker):
+        self._fw_maker, self._bw_maker = forward_maker, backward_maker
+        self._fw = self._bw = None
+
+    @property
+    def forwardEdgeHashes(self):
+        if self._fw is None:
+            self._fw = self._fw_maker()
+        return self._fw
+
+    @forwardEdgeHashes.setter
+    def forwardEdgeHashes(self, value):
+        self._fw = value
+
+    @property
+    def backwardEdgeHashes(self):
+        if self._bw is None:
+            self._bw = self._bw_maker()
+        return self._bw
+
+    @backwardEdgeHashes.setter
+    def backwardEdgeHashes(self, value):
+        self._bw = value
+
 
 class _View:
-    """Reference-shaped object view of the device graph (see module docstring)."""
+    """Reference-shaped object view of the device graph (see module docstring).  Nodes are made at once; Edge
+    objects (two sha256 each) when somebody looks at them: one by one through a node's edge lists, all of them —
+    in the reference's insertion order — the first time the edge dict itself is asked for."""
 
-    __slots__ = ("nodes", "edges", "readNodes", "readNodeDirections", "readNodePositions",
-                 "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
+    __slots__ = ("nodes", "_edges", "_edges_complete", "_edge_obj", "_make_edge", "_n_edges", "readNodes",
+                 "readNodeDirections", "readNodePositions", "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
+
+    def edge_hash_of(self, e):
+        h = self.edge_hash[e]
+        if h is None:
+            edge = self._edge_obj[e] = self._make_edge(e)
+            h = self.edge_hash[e] = edge.__hash__()
+            self._edges[h] = edge
+        return h
+
+    @property
+    def edges(self):
+        if not self._edges_complete:
+            alive = self.arrays["edges"]["alive"]
+            ordered = {}
+            for e in range(self._n_edges):
+                if alive[e]:
+                    h = self.edge_hash_of(e)
+                    ordered[h] = self._edge_obj[e]
+            self._edges, self._edges_complete = ordered, True
+        return self._edges
+
+    def edge_by_hash(self, h):
+        got = self._edges.get(h)
+        return got if got is not None else self.edges[h]
 
 
 # Engines (a HIP stream + grow-only device buffers each) are pooled per device: the reference's
@@ -332,7 +384,8 @@ class GeneMerGraph(BubblePopping):
         adj_off, adj_edge = eng.node_adj()
         nr_off, nr_idx = eng.node_reads()
         v = _View()
-        v.arrays = {"nodes": nodes, "edges": edges, "tok_node": tok_node, "tok_dir": tok_dir}
+        v.arrays = {"nodes": nodes, "edges": edges, "tok_node": tok_node, "tok_dir": tok_dir,
+                    "node_reads_off": nr_off, "node_reads": nr_idx}
         D, E = len(nodes["coverage"]), len(edges["coverage"])
         v.alive = nodes["alive"]
         v.node_hash = [None] * D
@@ -356,25 +409,28 @@ class GeneMerGraph(BubblePopping):
             node_obj[i] = node
         v.node_of_hash = {h: n._amg_id for h, n in v.nodes.items()}
         v.edge_hash = [None] * E
-        v.edges = {}
-        for e in range(E):
-            if not edges["alive"][e]:
-                continue
-            edge = Edge(node_obj[edges["src"][e]], node_obj[edges["tgt"][e]],
-                        int(edges["sdir"][e]), int(edges["tdir"][e]))
-            edge.edgeCoverage = int(edges["coverage"][e])
+        v._edge_obj = [None] * E
+        v._edges, v._edges_complete, v._n_edges = {}, False, E
+        e_src, e_tgt, e_sdir, e_tdir, e_cov, e_alive = (edges["src"], edges["tgt"], edges["sdir"], edges["tdir"],
+                                                         edges["coverage"], edges["alive"])
+
+        def make_edge(e):
+            edge = Edge(node_obj[e_src[e]], node_obj[e_tgt[e]], int(e_sdir[e]), int(e_tdir[e]))
+            edge.edgeCoverage = int(e_cov[e])
             edge._amg_id = e
-            h = edge.__hash__()
-            v.edge_hash[e] = h
-            v.edges[h] = edge
+            return edge
+
+        v._make_edge = make_edge
+
+        def edge_list(lo, hi):
+            return lambda: [v.edge_hash_of(e) for e in adj_edge[lo:hi].tolist() if e_alive[e]]
+
+        off_l = adj_off.tolist()
         for i in range(D):
             node = node_obj[i]
             if node is None:
                 continue
-            node.forwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i]:adj_off[2 * i + 1]].tolist()
-                                      if edges["alive"][e]]
-            node.backwardEdgeHashes = [v.edge_hash[e] for e in adj_edge[adj_off[2 * i + 1]:adj_off[2 * i + 2]].tolist()
-                                       if edges["alive"][e]]
+            node._lazy_edges(edge_list(off_l[2 * i], off_l[2 * i + 1]), edge_list(off_l[2 * i + 1], off_l[2 * i + 2]))
         offs, nh = self._read_off, v.node_hash
 
         def window_ids(r):
@@ -482,7 +538,7 @@ class GeneMerGraph(BubblePopping):
         return self.get_nodes()[h]
 
     def get_edge_by_hash(self, edgeHash):
-        return self.get_edges()[edgeHash]
+        return self._v().edge_by_hash(edgeHash)
 
     def get_total_number_of_nodes(self):
         return self._engine.counts()["n_live_nodes"]
@@ -1263,9 +1319,75 @@ class GeneMerGraph(BubblePopping):
     def is_sublist(self, long_list, sub_list):
         return _is_sublist(long_list, sub_list)
 
+    def _amr_occurrence_stats(self, AMRNodes):
+        """What the read loop of get_AMR_anchors (:2644-2676) finds out about every AMR node, from the device's
+        per-window node ids in one numpy pass: {hash: (stopped at an anchor occurrence, all(singletons), flags)}.
+        A node's reads are listed in read order and its positions on a read ascend, so the loop meets the node's
+        occurrences in ascending token order; every occurrence is, independently of the node, one of: the only window
+        of its read (stop, flag True), a terminal window (flag True), an interior window with a non-AMR neighbour
+        (anchor, stop), an interior window between AMR nodes (flag False)."""
+        v = self._v()
+        tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
+        nr_off, nr_idx = v.arrays["node_reads_off"], v.arrays["node_reads"]
+        ids = [v.node_of_hash[h] for h in AMRNodes]
+        D = len(v.alive)
+        is_amr = np.zeros(D + 1, bool)            # [D]: windows without a node (None)
+        is_amr[ids] = True
+        rows = np.unique(np.concatenate([nr_idx[nr_off[i]:nr_off[i + 1]] for i in ids])) if ids else np.zeros(0, np.int64)
+        rows = rows.astype(np.int64)
+        a = offs[rows]
+        n = offs[rows + 1] - a - k + 1
+        starts = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(n, out=starts[1:])
+        total = int(starts[-1])
+        within = np.arange(total, dtype=np.int64) - np.repeat(starts[:-1], n)
+        flat = tok_node[np.repeat(a, n) + within].astype(np.int64)
+        amr = is_amr[np.where(flat >= 0, flat, D)]
+        n_of = np.repeat(n, n)
+        first, last = within == 0, within == n_of - 1
+        left = np.concatenate([[False], amr[:-1]])
+        right = np.concatenate([amr[1:], [False]])
+        # 0 flag False, 1 flag True (terminal), 2 anchor (stop), 3 single-window read (flag True, stop)
+        kind = np.where(n_of == 1, 3, np.where(first | last, 1, np.where(~left | ~right, 2, 0)))
+        out = {}
+        for h, i in zip(AMRNodes, ids):
+            occ = kind[np.flatnonzero(flat == i)]
+            stops = np.flatnonzero(occ >= 2)
+            cut = int(stops[0]) if len(stops) else len(occ)
+            flags = (occ[:cut] == 1).tolist()
+            is_anchor = cut < len(occ) and occ[cut] == 2
+            if cut < len(occ) and occ[cut] == 3:
+                flags.append(True)
+            singleton_all = len(occ) == 0 or occ[0] == 3
+            out[h] = (bool(is_anchor), bool(singleton_all), flags)
+        return out
+
     def get_AMR_anchors(self, AMRNodes):
         """anchor selection (:2629-2691), including the reference's use of FORWARD neighbours
         for both sides of the first test."""
+        if not self._host_edits:
+            AMRNodes = list(AMRNodes)
+            amr_set = set(AMRNodes)
+            stats = self._amr_occurrence_stats(AMRNodes)
+            anchors = set()
+            for h in AMRNodes:                      # the same add() sequence as the loop below
+                node = self.get_node_by_hash(h)
+                forward = self.get_forward_neighbors(node)
+                if len([n for n in forward if n.__hash__() != h]) == 0:
+                    anchors.add(h)
+                is_anchor, singleton_all, flags = stats[h]
+                if is_anchor:
+                    anchors.add(h)
+                if singleton_all or all(flags):
+                    fw_amr = [n for n in forward if n.__hash__() in amr_set]
+                    bw_amr = [n for n in self.get_backward_neighbors(node) if n.__hash__() in amr_set]
+                    if len(bw_amr) == 0 or len(fw_amr) == 0:
+                        anchors.add(h)
+            for h in AMRNodes:
+                flags = stats[h][2]
+                if flags and flags.count(True) / len(flags) > 0.3:
+                    anchors.add(h)
+            return anchors
         readNodes = self.get_readNodes()
         anchors, terminals = set(), {}
         per_read = {}  # read -> (AMR flag per node of the read, positions of every AMR node on it): a read is
