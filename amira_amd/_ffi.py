@@ -74,6 +74,7 @@ def _load():
         "amg_correct_reads": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
         "amg_get_corrected": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_adopt_corrected": (C.c_int, [P]),
+        "amg_set_reads_from_corrected": (C.c_int, [P, P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),
         "amg_minhash": (C.c_int, [P, P, P, P, I64, I32, C.c_uint64, P, P, I64, C.POINTER(I64)]),
         "amg_dist_record_bytes": (C.c_int, [I32, C.POINTER(I64), C.POINTER(I64)]),

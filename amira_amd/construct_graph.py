@@ -48,6 +48,7 @@ from .path_finding_utils import (
     is_sublist as _is_sublist,
     process_anchors,
 )
+from .io import TokenizedPositions, TokenizedReads
 from .tokens import tokenize
 
 sys.setrecursionlimit(50000)  # construct_graph.py:27
@@ -206,16 +207,28 @@ class GeneMerGraph(BubblePopping):
         """_filter = (minNodeCoverage, minEdgeCoverage): the graph comes out as GeneMerGraph(...).filter_graph(...)
         would leave it, with the filter applied during the build (amg_build_filtered; graph_utils.build_filtered_graph)"""
         self._init_fields(readDict, kmerSize, gene_positions, device)
-        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):  # amira_amd.io.TokenizedReads
-            self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
-                                                       readDict.read_offsets, list(readDict.read_ids))
+        on_device = readDict.device_source() if isinstance(readDict, TokenizedReads) else None
+        if on_device is not None and on_device.engine().device == self._engine.device:
+            # the output of a correct_reads that never left the GPU: taken over device to device, positions included
+            # when they come from the same correction (amira_amd.io.DeviceCorrected)
+            ids = readDict.read_ids
+            self._vocab, self._read_off, self._read_ids = readDict.vocab, readDict.read_offsets, (ids if isinstance(ids, list) else list(ids))
+            self._engine.set_reads_from_corrected(on_device.engine())
+            same = isinstance(gene_positions, TokenizedPositions) and gene_positions.device_source() is on_device
+            if not same:
+                self._host_positions(gene_positions)
+                self._upload_positions()
         else:
-            self._vocab, toks, offs, self._read_ids = tokenize(readDict)
-        self._read_off = offs
-        self._tokens = toks
-        self._engine.set_reads(toks, offs, self._vocab.two_v)
-        self._host_positions(gene_positions)
-        self._upload_positions()
+            if isinstance(readDict, TokenizedReads):
+                self._vocab, toks, offs, self._read_ids = (readDict.vocab, readDict.tokens,
+                                                           readDict.read_offsets, list(readDict.read_ids))
+            else:
+                self._vocab, toks, offs, self._read_ids = tokenize(readDict)
+            self._read_off = offs
+            self._tokens_val = toks
+            self._engine.set_reads(toks, offs, self._vocab.two_v)
+            self._host_positions(gene_positions)
+            self._upload_positions()
         try:
             if _filter is None:
                 self._engine.build(self._kmer_for_device())
@@ -237,12 +250,12 @@ class GeneMerGraph(BubblePopping):
         kmerSizes = list(kmerSizes)
         first = cls.__new__(cls)
         first._init_fields(readDict, kmerSizes[0], gene_positions, device)
-        if hasattr(readDict, "tokens") and hasattr(readDict, "read_offsets"):
+        if isinstance(readDict, TokenizedReads):
             first._vocab, toks, offs, first._read_ids = (readDict.vocab, readDict.tokens, readDict.read_offsets,
                                                          list(readDict.read_ids))
         else:
             first._vocab, toks, offs, first._read_ids = tokenize(readDict)
-        first._read_off, first._tokens = offs, toks
+        first._read_off, first._tokens_val = offs, toks
         first._engine.set_reads(toks, offs, first._vocab.two_v)
         first._host_positions(gene_positions)
         first._upload_positions()
@@ -250,10 +263,10 @@ class GeneMerGraph(BubblePopping):
         for k in kmerSizes[1:]:
             g = cls.__new__(cls)
             g._init_fields(readDict, k, gene_positions, device)
-            g._vocab, g._read_ids, g._read_off, g._tokens = first._vocab, first._read_ids, first._read_off, first._tokens
+            g._vocab, g._read_ids, g._read_off, g._tokens_val = first._vocab, first._read_ids, first._read_off, toks
             g._read_index_ = first._read_index_
-            g._gs, g._ge = first._gs, first._ge
-            g._positions_pending = g._gs is not None   # uploaded when a correction asks for them
+            g._gs_val, g._ge_val = first._gs, first._ge
+            g._positions_pending = g._gs_val is not None   # uploaded when a correction asks for them
             g._reads_owner = first
             first._borrowers += 1
             graphs.append(g)
@@ -280,7 +293,8 @@ class GeneMerGraph(BubblePopping):
         self._extra_to_correct = set()
         self._gene_cache = {}
         self._read_index_ = None
-        self._gs = self._ge = None
+        self._tokens_val = self._gs_val = self._ge_val = None   # host copies: see the properties below
+        self._leases = weakref.WeakSet()   # outputs of correct_reads that still live in this graph's engine
         self._positions_pending = False
         self._reads_owner = None   # build_many: the graph whose engine holds the reads this one's engine borrows
         self._borrowers = 0        # build_many: graphs that borrow this one's reads
@@ -290,16 +304,39 @@ class GeneMerGraph(BubblePopping):
 
     def _kmer_for_device(self):
         # GeneMerGraph({}, 0) is legal in the reference: nothing to build
-        return 1 if (self._kmerSize < 1 and len(self._tokens) == 0) else self._kmerSize
+        return 1 if (self._kmerSize < 1 and int(self._read_off[-1]) == 0) else self._kmerSize
+
+    # host copies of the genes and their positions: made at once when the caller handed dicts or host arrays over, on
+    # first use when the reads came straight from another graph's correction on the device
+    @property
+    def _tokens(self):
+        if self._tokens_val is None:
+            self._tokens_val = self._reads.tokens
+        return self._tokens_val
+
+    def _positions_from_mapping(self):
+        if self._gs_val is None and isinstance(self._genePositions, TokenizedPositions) \
+                and self._genePositions._moved is None and self._genePositions._gs is not None:
+            self._gs_val = np.ascontiguousarray(self._genePositions.gene_start, np.int64)
+            self._ge_val = np.ascontiguousarray(self._genePositions.gene_end, np.int64)
+
+    @property
+    def _gs(self):
+        self._positions_from_mapping()
+        return self._gs_val
+
+    @property
+    def _ge(self):
+        self._positions_from_mapping()
+        return self._ge_val
 
     def _host_positions(self, gene_positions):
         """flat int64 (start, end) per gene, aligned with the tokens"""
         offs = self._read_off
-        if (gene_positions is not None and hasattr(gene_positions, "gene_start")
-                and getattr(gene_positions, "_moved", None) is None):  # io.TokenizedPositions as it was made
-            self._gs = np.ascontiguousarray(gene_positions.gene_start, np.int64)
-            self._ge = np.ascontiguousarray(gene_positions.gene_end, np.int64)
-            assert len(self._gs) == int(offs[-1]) == len(self._ge), "positions do not match the gene calls"
+        if isinstance(gene_positions, TokenizedPositions) and gene_positions._moved is None:  # as it was made
+            self._gs_val = np.ascontiguousarray(gene_positions.gene_start, np.int64)
+            self._ge_val = np.ascontiguousarray(gene_positions.gene_end, np.int64)
+            assert len(self._gs_val) == int(offs[-1]) == len(self._ge_val), "positions do not match the gene calls"
         elif gene_positions:
             n = int(offs[-1])
             gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
@@ -310,11 +347,11 @@ class GeneMerGraph(BubblePopping):
                     # Read.get_geneMers indexes positions[i] / positions[i + k - 1] (construct_read.py:48-52)
                     gs[a:b] = [x[0] for x in p[: b - a]]
                     ge[a:b] = [x[1] for x in p[: b - a]]
-            self._gs, self._ge = gs, ge
+            self._gs_val, self._ge_val = gs, ge
 
     def _upload_positions(self):
-        if self._gs is not None:
-            self._engine.set_positions(self._gs, self._ge, None)
+        if self._gs_val is not None:
+            self._engine.set_positions(self._gs_val, self._ge_val, None)
         self._positions_pending = False
 
     def _note_short_reads(self):
@@ -331,6 +368,9 @@ class GeneMerGraph(BubblePopping):
     def close(self):
         """hand the device engine back (the graph can no longer be queried); also done when the object dies"""
         self._view = None
+        if len(getattr(self, "_leases", ())) > 0:   # a correct_reads output still lives in this engine's buffers: the
+            self._close_pending = True              # engine goes back when it has been fetched or dropped
+            return
         owner, self._reads_owner = getattr(self, "_reads_owner", None), None
         if getattr(self, "_borrowers", 0) > 0:   # graphs of build_many still read this one's device arrays
             self._close_pending = True
@@ -341,6 +381,11 @@ class GeneMerGraph(BubblePopping):
             owner._borrowers -= 1
             if owner._borrowers == 0 and getattr(owner, "_close_pending", False):
                 owner.close()
+
+    def _lease_done(self, lease):
+        self._leases.discard(lease)
+        if self._close_pending and len(self._leases) == 0:
+            self.close()
 
     def __del__(self):
         try:
@@ -881,10 +926,12 @@ class GeneMerGraph(BubblePopping):
                 except (KeyError, TypeError, IndexError):
                     lengths[r] = 0
             eng.set_read_lengths(lengths)
+        for lease in list(self._leases):   # an earlier correction's output still on the device: about to be overwritten
+            lease.fetch()
         n_reads, n_tokens = eng.correct_reads()
-        out = eng.corrected(n_reads, n_tokens, have_pos)
         if self._tokenized_io(have_pos):
-            return self._corrected_as_arrays(out, have_pos)
+            return self._corrected_as_arrays(eng.corrected_index(n_reads), n_reads, n_tokens, have_pos)
+        out = eng.corrected(n_reads, n_tokens, have_pos)
         offs, toks = out["read_offsets"].tolist(), out["tokens"]
         corrected_genes, corrected_gene_positions = {}, {}
         for i, (orig, changed) in enumerate(zip(out["orig_read"].tolist(), out["changed"].tolist())):
@@ -904,25 +951,27 @@ class GeneMerGraph(BubblePopping):
     def _tokenized_io(self, have_pos):
         """the caller handed the reads (and positions) over as arrays (amira_amd.io.TokenizedReads /
         TokenizedPositions): corrections go back the same way, with no per-read Python work"""
-        from .io import TokenizedPositions, TokenizedReads
         return isinstance(self._reads, TokenizedReads) and (not have_pos or isinstance(self._genePositions,
                                                                                          TokenizedPositions))
 
-    def _corrected_as_arrays(self, out, have_pos):
-        """correct_reads' result for array inputs: the corrected calls as a TokenizedReads over the device's output
-        arrays, their positions as a TokenizedPositions; reads the correction changed are redirected to their new
-        positions in the caller's mapping (the reference updates gene_positions in place, :1282-1284, :1328)"""
-        from .io import TokenizedPositions, TokenizedReads
+    def _corrected_as_arrays(self, out, n_reads, n_tokens, have_pos):
+        """correct_reads' result for array inputs: the corrected calls as a TokenizedReads, their positions as a
+        TokenizedPositions — both over a DeviceCorrected: the genes and positions stay on the device until somebody
+        reads them on the host, and a GeneMerGraph built from the two takes them over device to device.  Reads the
+        correction changed are redirected to their new positions in the caller's mapping (the reference updates
+        gene_positions in place, :1282-1284, :1328)"""
+        from .io import DeviceCorrected
         orig = out["orig_read"]
         ids_arr = self._read_ids_array()
         ids = ids_arr[orig].tolist()
         offs = out["read_offsets"]
         src = getattr(self._reads, "source_rows", None)
-        reads = TokenizedReads(self._vocab, out["tokens"], offs, ids,
+        on_device = DeviceCorrected(self, n_reads, n_tokens, have_pos)
+        reads = TokenizedReads(self._vocab, on_device, offs, ids,
                                source_rows=orig.astype(np.int64) if src is None else src[orig])
         if not have_pos:
             return reads, {}
-        positions = TokenizedPositions(ids, offs, out["gene_start"], out["gene_end"])
+        positions = TokenizedPositions(ids, offs, on_device, on_device)
         changed = np.flatnonzero(out["changed"])
         if len(changed):
             self._genePositions.replace_rows(orig[changed], positions, changed)
@@ -1600,7 +1649,7 @@ class GeneMerGraph(BubblePopping):
             if rids:
                 path_reads.setdefault(named, set()).update(rids)
             pos = self._genePositions
-            if (fw_idx and rids and hasattr(self._reads, "tokens") and hasattr(pos, "gene_start")
+            if (fw_idx and rids and isinstance(self._reads, TokenizedReads) and isinstance(pos, TokenizedPositions)
                     and not pos._cache and self._gs is not None):
                 # tokenised containers: the genes and positions of all chosen reads come out of the flat arrays
                 # at once (one entry per read and allele, appended in read order as the loop below does)

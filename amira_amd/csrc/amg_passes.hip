@@ -2493,3 +2493,53 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   return AMG_OK;
 }
 
+// The corrected set of `src` becomes the read set of `dst`, device to device: what the reference does between
+// correct_reads and the next GeneMerGraph(...) (graph_utils.py:147-150, :165) without the reads leaving the GPU.
+// Positions are gathered into flat arrays of dst's own (pool 0, identity offsets); src keeps its corrected set.
+extern "C" int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src) {
+  if (!dst || !src) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!src->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads on the source ctx first");
+  if (dst == src) return amg_adopt_corrected(src);
+  if (dst->device != src->device) return amg_fail(AMG_E_ARG, "amg_set_reads_from_corrected: one device");
+  HIPCHK(hipSetDevice(dst->device));
+  HIPCHK(hipStreamSynchronize(src->stream));
+  hipStream_t st = dst->stream;
+  const long long R = src->c_reads, T = src->c_tokens;
+  AMGCHK(dst->tokens.ensure((size_t)T * sizeof(int32_t) + 64));
+  AMGCHK(dst->read_off.ensure((size_t)(R + 1) * sizeof(int64_t) + 64));
+  if (T > 0) HIPCHK(hipMemcpyAsync(dst->tokens.p, src->c_tokens_buf.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(dst->read_off.p, src->c_read_off.p, (size_t)(R + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+  dst->n_reads = R;
+  dst->n_tokens = T;
+  dst->two_v = src->two_v;
+  dst->have_pos = dst->have_read_len = false;
+  if (src->have_pos) {
+    AMGCHK(dst->gene_start.ensure((size_t)(T + 64) * sizeof(long long)));
+    AMGCHK(dst->gene_end.ensure((size_t)(T + 64) * sizeof(long long)));
+    if (R > 0 && T > 0) {
+      CorrArgs a;
+      memset(&a, 0, sizeof(a));
+      fill_pos_args(src, a);
+      hipLaunchKernelGGL(k_gather_positions, dim3(nblk(R, 4)), dim3(256), 0, st, a, src->c_read_off.as<long long>(),
+                         src->c_pos_off.as<long long>(), R, dst->gene_start.as<long long>(),
+                         dst->gene_end.as<long long>());
+    }
+    dst->have_pos = true;
+    dst->pos_identity = true;
+    dst->pos_n0 = T;
+    dst->pos1_used = dst->c_pos1_used = 0;
+  }
+  if (src->have_read_len) {
+    AMGCHK(dst->read_len.ensure((size_t)(R + 1) * sizeof(long long) + 64));
+    if (R > 0)
+      HIPCHK(hipMemcpyAsync(dst->read_len.p, src->c_read_len.p, (size_t)R * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    dst->have_read_len = true;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  dst->built = false;
+  dst->have_corrected = false;
+  dst->match_valid = false;
+  dst->node_hint = 0;
+  dst->cnt_hint_reset = true;
+  return AMG_OK;
+}

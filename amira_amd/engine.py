@@ -206,8 +206,21 @@ class Engine:
         out["gene_start"], out["gene_end"] = gs, ge
         return out
 
+    def corrected_index(self, n_reads):
+        """the small arrays of a corrected set only: read offsets, the read each one was, whether it changed"""
+        out = {"read_offsets": np.empty(n_reads + 1, np.int64), "orig_read": np.empty(n_reads, np.int32),
+               "changed": np.empty(n_reads, np.uint8)}
+        check(_ffi.lib.amg_get_corrected(self._h, None, ptr(out["read_offsets"]), ptr(out["orig_read"]),
+                                         ptr(out["changed"]), None, None))
+        return out
+
     def adopt_corrected(self):
         check(_ffi.lib.amg_adopt_corrected(self._h))
+
+    def set_reads_from_corrected(self, src):
+        """this engine's read set := the corrected set of engine `src` (genes, offsets, positions, read lengths),
+        device to device"""
+        check(_ffi.lib.amg_set_reads_from_corrected(self._h, src._h))
 
     # ---- K6: batched exact sub-list search
     def match_patterns(self, which, patterns):

@@ -25,11 +25,11 @@ def _tokenized(reads, gene_positions):
     """(TokenizedReads, TokenizedPositions or None) of a {read: genes} / {read: [(start, end)]} pair"""
     from .io import TokenizedPositions, TokenizedReads
     from .tokens import tokenize
-    if hasattr(reads, "tokens") and hasattr(reads, "read_offsets"):
+    if isinstance(reads, TokenizedReads):
         reads_t = reads
     else:
         reads_t = TokenizedReads(*tokenize(reads))
-    if gene_positions is None or (hasattr(gene_positions, "gene_start") and getattr(gene_positions, "_moved", None) is None):
+    if gene_positions is None or (isinstance(gene_positions, TokenizedPositions) and gene_positions._moved is None):
         return reads_t, gene_positions
     offs, n = reads_t.read_offsets, int(reads_t.read_offsets[-1])
     gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
@@ -46,9 +46,10 @@ def _own(mapping):
     """the graph's own copy of a {read: ...} mapping, as the reference's drivers make one (.copy(), dict
     comprehensions); array-backed mappings (amira_amd.io.TokenizedReads / TokenizedPositions) keep their arrays —
     copying them item by item would decode a million reads into lists only to tokenise them again"""
-    if mapping is None or hasattr(mapping, "tokens"):
+    from .io import TokenizedPositions, TokenizedReads
+    if mapping is None or isinstance(mapping, TokenizedReads):
         return mapping
-    if hasattr(mapping, "gene_start"):
+    if isinstance(mapping, TokenizedPositions):
         return mapping.copy()   # shares the arrays; correct_reads redirects changed reads in the COPY, as it would
     return {r: mapping[r] for r in mapping}
 

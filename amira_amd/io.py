@@ -13,6 +13,40 @@ from ._ffi import check, ptr
 from .tokens import Vocabulary
 
 
+class DeviceCorrected:
+    """What one GeneMerGraph.correct_reads produced, still on the device: the corrected genes and their positions
+    (240 MB + 960 MB for a million 60-gene reads).  The array-backed mappings correct_reads hands back point here;
+    the arrays cross PCIe only if somebody looks at them on the host — a GeneMerGraph built from those mappings takes
+    them over device to device (amg_set_reads_from_corrected).  Holds the graph (and with it the engine whose buffers
+    these are) until it is fetched or dropped."""
+
+    def __init__(self, graph, n_reads, n_tokens, have_pos):
+        self._graph, self._shape, self._arrays = graph, (n_reads, n_tokens, have_pos), None
+        graph._leases.add(self)
+
+    def engine(self):
+        """the engine that still holds the set (None once it has been fetched)"""
+        return self._graph._engine if self._graph is not None else None
+
+    def fetch(self):
+        if self._arrays is None:
+            out = self._graph._engine.corrected(*self._shape)
+            self._arrays = {"tokens": out["tokens"], "gene_start": out["gene_start"], "gene_end": out["gene_end"]}
+            self._done()
+        return self._arrays
+
+    def _done(self):
+        graph, self._graph = self._graph, None
+        if graph is not None:
+            graph._lease_done(self)
+
+    def __del__(self):
+        try:
+            self._done()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def _gather_rows(offsets, rows):
     """(flat element indices, new offsets) of the CSR rows `rows`, in that order"""
     rows = np.asarray(rows, dtype=np.int64)
@@ -27,12 +61,24 @@ class TokenizedReads(Mapping):
     """{read id: ["+geneA", ...]} backed by CSR token arrays (lists are decoded on access)."""
 
     def __init__(self, vocab, tokens, read_offsets, read_ids, source_rows=None):
-        self.vocab, self.tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
+        # tokens: an int32 array, or a DeviceCorrected (the genes are still on the device: see the property)
+        self.vocab, self._tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
         # where these reads sat in the read list they descend from (correct_reads drops reads and keeps the order):
         # lets array-backed side tables (ReadLengths) follow without a lookup per read; None = they are that list
         self.source_rows = source_rows
         self._index = None   # built on the first lookup by name (a million reads: ~0.2 s)
         self._cache = {}
+
+    @property
+    def tokens(self):
+        if isinstance(self._tokens, DeviceCorrected):
+            self._tokens = self._tokens.fetch()["tokens"]
+        return self._tokens
+
+    def device_source(self):
+        """the DeviceCorrected these genes still live in, if nobody has asked for them on the host yet"""
+        t = self._tokens
+        return t if isinstance(t, DeviceCorrected) and t.engine() is not None else None
 
     def _idx(self):
         if self._index is None:
@@ -83,11 +129,31 @@ class TokenizedPositions(Mapping):
     TokenizedReads; GeneMerGraph hands the arrays to the device as they are (no per-read loop)."""
 
     def __init__(self, read_ids, read_offsets, gene_start, gene_end):
+        # gene_start / gene_end: int64 arrays, or one DeviceCorrected for both (still on the device)
         self.read_ids, self.read_offsets = read_ids, read_offsets
-        self.gene_start, self.gene_end = gene_start, gene_end
+        self._gs, self._ge = gene_start, gene_end
         self._index = None
         self._cache = {}
         self._moved = None   # (row -> row of another TokenizedPositions or -1, that other mapping): replace_rows
+
+    def _from_device(self):
+        if isinstance(self._gs, DeviceCorrected):
+            got = self._gs.fetch()
+            self._gs, self._ge = got["gene_start"], got["gene_end"]
+
+    @property
+    def gene_start(self):
+        self._from_device()
+        return self._gs
+
+    @property
+    def gene_end(self):
+        self._from_device()
+        return self._ge
+
+    def device_source(self):
+        g = self._gs
+        return g if isinstance(g, DeviceCorrected) and g.engine() is not None and self._moved is None and not self._cache else None
 
     def _idx(self):
         if self._index is None:
@@ -122,7 +188,7 @@ class TokenizedPositions(Mapping):
 
     def copy(self):
         """the caller's own copy (the arrays are shared — they are never written — the redirections are not)"""
-        c = TokenizedPositions(self.read_ids, self.read_offsets, self.gene_start, self.gene_end)
+        c = TokenizedPositions(self.read_ids, self.read_offsets, self._gs, self._ge)
         c._index = self._index
         c._cache = dict(self._cache)
         if self._moved is not None:

@@ -204,6 +204,11 @@ int amg_get_corrected(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets,
 /* the corrected read set becomes the current read set (device resident; the next
  * amg_build runs on it) — the rebuild of graph_utils.py:147-150,165 */
 int amg_adopt_corrected(amg_ctx* ctx);
+/* the corrected set of `src` (after amg_correct_reads there) becomes the read set of `dst` — genes, read offsets, read
+ * lengths and the positions, gathered into flat arrays of dst's own — device to device: correct_reads followed by the
+ * next GeneMerGraph(...) (graph_utils.py:147-150, :165) without the reads leaving the GPU.  src keeps its corrected
+ * set; dst == src is amg_adopt_corrected.  Same device; synchronous. */
+int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src);
 
 /* ---- read-path clustering support: batched exact sub-list search
  *      (is_sublist / find_sublist_indices, construct_graph.py:1957-1966,2117-2123;

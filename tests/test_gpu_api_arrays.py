@@ -106,3 +106,38 @@ def test_remove_junk_reads_on_arrays_equals_dicts(rate):
                        [tuple(x) if isinstance(x, (list, tuple)) else x for x in b[r]]
     for g in (gd, gt, gl):
         g.close()
+
+
+def test_corrected_reads_go_to_the_next_graph_on_the_device():
+    """the output of correct_reads on array-backed inputs stays on the device (amira_amd.io.DeviceCorrected): the next
+    GeneMerGraph takes it over device to device, the host arrays appear only when somebody reads them, and the engine
+    that holds them is handed back only then"""
+    from amira_amd import GeneMerGraph
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    pos_d = {r: list(v) for r, v in pos.items()}
+    treads, tpos, tlen = _tokenized(reads, pos, fq)
+    gd, gt = GeneMerGraph(dict(reads), 5, pos_d), GeneMerGraph(treads, 5, tpos)
+    gd.filter_graph(3, 1)
+    gt.filter_graph(3, 1)
+    rd, pd = gd.correct_reads(fq)
+    rt, pt = gt.correct_reads(tlen)
+    assert rt.device_source() is not None and pt.device_source() is rt.device_source()
+    gt.close()
+    assert gt._engine is not None                     # still holds the corrected set
+    g2d, g2t = GeneMerGraph(rd, 5, pd), GeneMerGraph(rt, 5, pt)
+    assert rt.device_source() is not None             # nothing crossed PCIe for the rebuild
+    assert list(g2t.get_nodes()) == list(g2d.get_nodes())
+    assert [(h, e.get_edge_coverage()) for h, e in g2t.get_edges().items()] == \
+           [(h, e.get_edge_coverage()) for h, e in g2d.get_edges().items()]
+    assert {r: list(v) for r, v in g2t.get_readNodePositions().items()} == \
+           {r: list(v) for r, v in g2d.get_readNodePositions().items()}   # reads the host positions: fetched now
+    g2t.remove_short_linear_paths(5)
+    g2d.remove_short_linear_paths(5)
+    r2d, p2d = g2d.correct_reads(fq)
+    r2t, p2t = g2t.correct_reads(tlen)
+    assert list(r2t) == list(r2d)
+    for r in r2d:
+        assert r2t[r] == r2d[r] and [tuple(x) for x in p2t[r]] == [tuple(x) for x in p2d[r]]
+    assert rt.device_source() is None and gt._engine is None   # fetched -> the first graph's engine went back
+    for g in (gd, g2d, g2t):
+        g.close()
