@@ -78,6 +78,34 @@ class PeerFailed(RuntimeError):
         return bool(self.codes) and all(c == -2 for c in self.codes.values())
 
 
+def _host_staged(group):
+    """gloo moves CPU tensors: device buffers are staged through the host around its collectives — the whole driver
+    (count exchanges, padded all-gather, reply trip, failure hand-shake) then runs between processes without RCCL,
+    e.g. two ranks sharing one GPU in a test; the production transport is backend "nccl" (= RCCL), device to device"""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
+def _a2a_single(out, inp, out_splits, in_splits, group):
+    import torch.distributed as dist
+    if _host_staged(group) and out.is_cuda:
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather(out, inp, group):
+    import torch.distributed as dist
+    if _host_staged(group) and out.is_cuda:
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     """variable-size all-to-all of whole records (works on device tensors with RCCL and on CPU
     tensors with gloo): returns (recv tensor, records received from every rank)."""
@@ -85,16 +113,15 @@ def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     dev = buf.device
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
+    _a2a_single(rc, sc, None, None, group)
     recv_counts = rc.tolist()
     if min(recv_counts, default=0) < 0 or min(send_counts, default=0) < 0:   # see dist_build
         bad = {r: n for r, n in enumerate(recv_counts) if n < 0}
         raise PeerFailed(sorted(bad), bad)
     n_send, n_recv = sum(send_counts), sum(recv_counts)
     recv = torch.empty(max(n_recv, 1) * rec_bytes, dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(recv[: n_recv * rec_bytes], buf[: n_send * rec_bytes],
-                           [n * rec_bytes for n in recv_counts], [n * rec_bytes for n in send_counts],
-                           group=group)
+    _a2a_single(recv[: n_recv * rec_bytes], buf[: n_send * rec_bytes],
+                [n * rec_bytes for n in recv_counts], [n * rec_bytes for n in send_counts], group)
     return recv, recv_counts
 
 
@@ -108,7 +135,7 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     world = dist.get_world_size(group)
     no = torch.tensor([n_owned], dtype=torch.int64, device=dev)
     allno = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allno, no, group=group)
+    _all_gather(allno, no, group)
     counts = allno.tolist()
     if min(counts) < 0:   # see dist_build
         bad = {r: n for r, n in enumerate(counts) if n < 0}
@@ -120,7 +147,7 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
         padded = torch.zeros(m * rec_bytes, dtype=torch.uint8, device=dev)
         padded[: n_owned * rec_bytes] = buf[: n_owned * rec_bytes]
     out = torch.empty(world * m * rec_bytes, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    _all_gather(out, padded, group)
     return out, world * m, sum(counts)
 
 
@@ -129,7 +156,7 @@ def exchange_back(replies, recv_counts, send_counts, group=None):
     import torch.distributed as dist
     n_send, n_recv = sum(send_counts), sum(recv_counts)
     mine = torch.empty(max(n_send, 1), dtype=torch.int64, device=replies.device)
-    dist.all_to_all_single(mine[:n_send], replies[:n_recv], list(send_counts), list(recv_counts), group=group)
+    _a2a_single(mine[:n_send], replies[:n_recv], list(send_counts), list(recv_counts), group)
     return mine
 
 
@@ -164,7 +191,7 @@ def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchan
     if world > 1:
         n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)
         gathered = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered, n_local, group=group)
+        _all_gather(gathered, n_local, group)
         tokens = gathered.tolist()
     else:
         tokens = [engine.sizes()[1]]

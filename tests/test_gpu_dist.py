@@ -376,3 +376,118 @@ def test_dist_build_over_rccl_two_processes(tmp_path, empty_rank):
             assert np.array_equal(got[key], want[key]), (r, key)
         assert np.array_equal(got["tok_node"], ref_nodes[offs[shards[r][2]]:offs[shards[r][3]]])
     ref.close()
+
+
+def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep):
+    """one rank of a multi-PROCESS merged build whose ranks share ONE GPU: torch.distributed over gloo (the record
+    buffers are staged through the host around the collectives, amira_amd/dist.py) — everything of the N > 1 driver
+    except the RCCL transport: count exchanges, padded all-gather, reply trip, the order of the collectives"""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    t, o, lo, hi = _rccl_shards(toks, offs, world, empty_rank)[rank]
+    eng = Engine(0)
+    eng.set_reads(t, o, vocab.two_v)
+    out = {}
+    if not sweep:
+        dist_build(eng, 5)
+        out = graph_state(eng)
+        out["tok_node"] = eng.read_nodes()[0]
+    else:
+        gs, ge = flat_positions(read_ids, reads, pos)
+        rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+        eng.set_positions(gs[offs[lo]:offs[hi]], ge[offs[lo]:offs[hi]], rl[lo:hi])
+        dist_build(eng, 5, None, 3, 1)                       # first build with filter_graph(3, 1) fused into the merge
+        c1 = eng.corrected(*eng.correct_reads(), True)
+        eng.adopt_corrected()
+        dist_build(eng, 5)
+        removed = eng.remove_short_linear_paths(5)
+        c2 = eng.corrected(*eng.correct_reads(), True)
+        eng.adopt_corrected()
+        dist_build(eng, 5)
+        out = graph_state(eng)
+        for i, c in enumerate((c1, c2)):
+            for key in ("tokens", "gene_start", "gene_end", "changed"):
+                out[f"c{i}_{key}"] = c[key]
+            out[f"c{i}_len"] = np.diff(c["read_offsets"])
+        out["removed"] = np.sort(removed)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_gloo(tmp_path, world, empty_rank, sweep):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, str(tmp_path), empty_rank, sweep)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=30)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+@pytest.mark.parametrize("world,empty_rank", [(2, None), (3, 1)])
+def test_dist_build_between_processes_sharing_the_gpu(tmp_path, world, empty_rank, key_mode):
+    """the torch.distributed driver between real processes (gloo, one GPU shared): every rank ends with the unsharded graph"""
+    from amira_amd import Engine, tokenize
+    got = _run_gloo(tmp_path, world, empty_rank, sweep=False)
+    reads, _, _ = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, _ = tokenize(reads)
+    ref = Engine(0)
+    ref.set_reads(toks, offs, vocab.two_v)
+    ref.build(5)
+    want = graph_state(ref)
+    ref_nodes = ref.read_nodes()[0]
+    shards = _rccl_shards(toks, offs, world, empty_rank)
+    for r in range(world):
+        for key in want:
+            assert np.array_equal(got[r][key], want[key]), (r, key)
+        assert np.array_equal(got[r]["tok_node"], ref_nodes[offs[shards[r][2]]:offs[shards[r][3]]])
+    ref.close()
+
+
+def test_dist_sweep_between_processes_sharing_the_gpu(tmp_path, key_mode):
+    """the bench's N > 1 sweep (fused first filter, every build merged) between two real processes over gloo: final
+    graph on every rank and the concatenated corrected reads equal the single-GPU sweep"""
+    from amira_amd import Engine, tokenize
+    world = 2
+    got = _run_gloo(tmp_path, world, None, sweep=True)
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+    e = Engine(0)
+    e.set_reads(toks, offs, vocab.two_v)
+    e.set_positions(gs, ge, rl)
+    e.build(5); e.filter(3, 1)
+    c1 = e.corrected(*e.correct_reads(), True); e.adopt_corrected()
+    e.build(5); removed = np.sort(e.remove_short_linear_paths(5))
+    c2 = e.corrected(*e.correct_reads(), True); e.adopt_corrected()
+    e.build(5)
+    want = graph_state(e)
+    for r in range(world):
+        for key in want:
+            assert np.array_equal(got[r][key], want[key]), (r, key)
+        assert np.array_equal(got[r]["removed"], removed)
+    for i, c in enumerate((c1, c2)):
+        for key in ("tokens", "gene_start", "gene_end", "changed"):
+            assert np.array_equal(np.concatenate([got[r][f"c{i}_{key}"] for r in range(world)]), c[key]), (i, key)
+        assert np.array_equal(np.concatenate([got[r][f"c{i}_len"] for r in range(world)]), np.diff(c["read_offsets"]))
+    e.close()
