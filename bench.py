@@ -425,7 +425,7 @@ def launch_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("AMG_SHARE_GPU") != "1":   # (AMG_SHARE_GPU=1 + AMG_DIST_BACKEND=gloo: functional test)
         print(f"bench.py: --gpus {n} requested but this machine has {have} GPU(s); refusing to report a "
               f"{n}-GPU number from fewer devices", file=sys.stderr, flush=True)
         return 2
@@ -499,6 +499,9 @@ def main():
         return
 
     import torch
+    shared_gpu = os.environ.get("AMG_SHARE_GPU") == "1" and torch.cuda.device_count() < world
+    if shared_gpu:   # functional test of the N > 1 path on a box with fewer GPUs (backend gloo): never a scaling figure
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_merge:
@@ -507,8 +510,11 @@ def main():
             os.environ.pop("NCCL_DEBUG")  # the RCCL version banner goes to stdout at exit, after the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("AMG_DIST_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" only for functional tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from amira_amd import Engine
     from amira_amd.dist import dist_build
     merge = (world > 1 or args.force_merge) and not args.no_merge
@@ -790,6 +796,7 @@ def main():
                        "reads_per_gpu": N, "genes_per_read": L, "k": k,
                        "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
                        "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
+                       "shared_gpu_functional_test_only": True if shared_gpu else None,
                        "multi_gpu": ("n/a" if not (world > 1 or merge) else
                                      "read shards + key-owner table merge per build (RCCL all-to-all + all-gather)"
                                      if merge else "independent read shards, no table merge")},
