@@ -933,6 +933,9 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   const long long n_tiles = (T + TILE - 1) / TILE;
   unsigned long long hs[ST_WORDS];
   if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
+  if (const char* e = getenv("AMG_EDGE_SLOTS_LOG2")) {  // A/B switch (first builds only: D large)
+    if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
+  }
   const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
   AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
