@@ -1,0 +1,60 @@
+"""Host logic of the array-backed mappings (amira_amd.io) that stand in for the reference's {read: genes} /
+{read: [(start, end)]} / FASTQ dicts: lookups, subsets, the redirection of corrected reads, read lengths."""
+import numpy as np
+
+from amira_amd.io import ReadLengths, TokenizedPositions, TokenizedReads, _gather_rows
+from amira_amd.tokens import Vocabulary
+
+
+def _mappings():
+    names = [f"g{i}" for i in range(6)]
+    vocab = Vocabulary(names)
+    reads = {"a": ["+g0", "-g1"], "b": ["+g2"], "c": [], "d": ["-g3", "+g4", "+g5", "-g0"]}
+    ids = list(reads)
+    toks = np.asarray([vocab._tok[g] for r in ids for g in reads[r]], np.int32)
+    offs = np.concatenate([[0], np.cumsum([len(reads[r]) for r in ids])]).astype(np.int64)
+    gs = np.arange(len(toks), dtype=np.int64) * 100
+    ge = gs + 50
+    return reads, ids, TokenizedReads(vocab, toks, offs, ids), TokenizedPositions(ids, offs, gs, ge)
+
+
+def test_lookups_and_subsets():
+    reads, ids, tr, tp = _mappings()
+    assert list(tr) == ids and len(tr) == 4 and "c" in tr and "x" not in tr
+    for r in ids:
+        assert tr[r] == reads[r]
+    assert tr.gene_at("d", -1) == "-g0" and tr.gene_at("a", 0) == "+g0"
+    assert tp["d"] == [(300, 350), (400, 450), (500, 550), (600, 650)] and tp["c"] == []
+    assert tp.pos_at("d", 1) == (400, 450)
+    idx, off = _gather_rows(tr.read_offsets, [3, 0])
+    assert idx.tolist() == [3, 4, 5, 6, 0, 1] and off.tolist() == [0, 4, 6]
+    sub = tr.subset([3, 1])
+    assert list(sub) == ["d", "b"] and sub["d"] == reads["d"] and sub["b"] == reads["b"]
+    assert sub.source_rows.tolist() == [3, 1] and sub.subset([1]).source_rows.tolist() == [1]
+    psub = tp.subset([3, 1])
+    assert list(psub) == ["d", "b"] and psub["d"] == tp["d"] and psub["b"] == [(200, 250)]
+
+
+def test_redirected_positions_and_copies():
+    _, ids, tr, tp = _mappings()
+    other = TokenizedPositions(["d", "a"], np.array([0, 2, 3]), np.array([7, 8, 9]), np.array([17, 18, 19]))
+    mine = tp.copy()                       # what a driver works on: the caller's mapping stays as it was
+    mine.replace_rows(np.array([3, 0]), other, np.array([0, 1]))
+    assert mine["d"] == [(7, 17), (8, 18)] and mine["a"] == [(9, 19)] and mine["b"] == [(200, 250)]
+    assert mine.pos_at("d", 1) == (8, 18)
+    assert tp["d"] == [(300, 350), (400, 450), (500, 550), (600, 650)] and tp["a"] == [(0, 50), (100, 150)]
+    assert mine.subset([3, 1])["d"] == [(7, 17), (8, 18)]     # subsets follow the redirection
+    again = mine.copy()
+    assert again["d"] == [(7, 17), (8, 18)]
+    mine["b"] = [(1, 2)]                   # hand-set positions (bubble popping replaces a read's list)
+    assert mine["b"] == [(1, 2)] and again["b"] == [(200, 250)]
+
+
+def test_read_lengths():
+    ids = ["a", "b", "c"]
+    rl = ReadLengths(ids, [5, 6, 7])
+    assert len(rl["b"]["sequence"]) == 6 and list(rl) == ids
+    assert rl.lengths_array(ids) is rl.lengths
+    assert rl.lengths_array(["c", "x", "a"]).tolist() == [7, 0, 5]
+    assert rl.lengths_array(["c", "a"], rows_hint=np.array([2, 0])).tolist() == [7, 5]
+    assert rl.lengths_array(["c", "a"], rows_hint=np.array([1, 0])).tolist() == [7, 5]   # a wrong hint is not trusted
