@@ -148,14 +148,101 @@ class _GraphNode(Node):
         self._bw = value
 
 
+class _HashToId:
+    """{node hash: device node id} over the nodes of a view; hashes the view has not made yet are settled by making
+    every node (see _View)."""
+
+    __slots__ = ("_view",)
+
+    def __init__(self, view):
+        self._view = view
+
+    def get(self, h, default=None):
+        v = self._view
+        i = v._id_of.get(h)
+        if i is None and not v._nodes_complete:
+            v.nodes   # (makes them all)
+            i = v._id_of.get(h)
+        return default if i is None else i
+
+    def __getitem__(self, h):
+        i = self.get(h)
+        if i is None:
+            raise KeyError(h)
+        return i
+
+    def __contains__(self, h):
+        return self.get(h) is not None
+
+
 class _View:
-    """Reference-shaped object view of the device graph (see module docstring).  Nodes are made at once; Edge
-    objects (two sha256 each) when somebody looks at them: one by one through a node's edge lists, all of them —
-    in the reference's insertion order — the first time the edge dict itself is asked for."""
+    """Reference-shaped object view of the device graph (see module docstring).  Node objects (a sha256 and a dozen
+    small objects each) and Edge objects (two sha256 each) are made when somebody looks at them — read-path
+    clustering touches the few thousand nodes its genes' reads run through, of tens of thousands: one by one through
+    node_at / hash_at / node_by_hash and a node's edge lists, all of them — in the reference's insertion order — the
+    first time the node / edge dict itself is asked for."""
 
-    __slots__ = ("nodes", "_edges", "_edges_complete", "_edge_obj", "_make_edge", "_n_edges", "readNodes",
-                 "readNodeDirections", "readNodePositions", "node_hash", "edge_hash", "node_of_hash", "alive", "arrays")
+    __slots__ = ("_nodes", "_nodes_complete", "_node_obj", "_make_node", "_id_of", "node_of_hash",
+                 "_edges", "_edges_complete", "_edge_obj", "_make_edge", "_n_edges", "readNodes",
+                 "readNodeDirections", "readNodePositions", "node_hash", "edge_hash", "alive", "arrays",
+                 "_nh_table")
 
+    # ---- nodes
+    def node_at(self, i):
+        """the node with device id i (None: removed)"""
+        if self._nodes_complete:
+            h = self.node_hash[i]
+            return None if h is None else self._nodes[h]
+        node = self._node_obj[i]
+        return node if node is not None else self._make_node(i)
+
+    def hash_at(self, i):
+        h = self.node_hash[i]
+        if h is None and not self._nodes_complete and self._make_node(i) is not None:
+            h = self.node_hash[i]
+        return h
+
+    def ensure_hashes(self, ids):
+        """node_hash[i] filled in for every id >= 0 of `ids` (an iterable of ints)"""
+        if self._nodes_complete:
+            return
+        nh, make = self.node_hash, self._make_node
+        for i in ids:
+            if i >= 0 and nh[i] is None:
+                make(i)
+
+    @property
+    def nodes(self):
+        if not self._nodes_complete:
+            ordered = {}
+            for i in range(len(self.node_hash)):
+                node = self.node_at(i)
+                if node is not None:
+                    ordered[self.node_hash[i]] = node
+            self._nodes, self._nodes_complete = ordered, True
+        return self._nodes
+
+    def node_by_hash(self, h, default=None):
+        got = self._nodes.get(h)
+        if got is None and not self._nodes_complete:
+            got = self.nodes.get(h)
+        return default if got is None else got
+
+    def node_hash_table(self, ids=None):
+        """node hashes as an object array indexed by device node id, two None entries at the end (ids -2 and -1:
+        a window without a node); with `ids` (an int array) only those entries are promised"""
+        if not self._nodes_complete:
+            if ids is None:
+                self.nodes
+            else:
+                self.ensure_hashes(np.unique(ids).tolist())
+        if self._nh_table is None:
+            t = np.empty(len(self.node_hash) + 2, dtype=object)
+            t[:len(self.node_hash)] = self.node_hash
+            self._nh_table = t
+        return self._nh_table
+
+    # ---- edges
     def edge_hash_of(self, e):
         h = self.edge_hash[e]
         if h is None:
@@ -362,7 +449,11 @@ class GeneMerGraph(BubblePopping):
     @property
     def _read_index(self):
         if self._read_index_ is None:
-            self._read_index_ = {r: i for i, r in enumerate(self._read_ids)}
+            src = self._reads
+            if isinstance(src, TokenizedReads) and len(src.read_ids) == len(self._read_ids):
+                self._read_index_ = src._idx()   # the mapping's own name -> row table (same reads, same order)
+            else:
+                self._read_index_ = dict(zip(self._read_ids, range(len(self._read_ids))))
         return self._read_index_
 
     def close(self):
@@ -429,53 +520,66 @@ class GeneMerGraph(BubblePopping):
         adj_off, adj_edge = eng.node_adj()
         nr_off, nr_idx = eng.node_reads()
         v = _View()
+        v._nh_table = None
         v.arrays = {"nodes": nodes, "edges": edges, "tok_node": tok_node, "tok_dir": tok_dir,
                     "node_reads_off": nr_off, "node_reads": nr_idx}
         D, E = len(nodes["coverage"]), len(edges["coverage"])
-        v.alive = nodes["alive"]
+        v.alive = n_alive = nodes["alive"]
         v.node_hash = [None] * D
-        v.nodes = {}
-        node_obj = [None] * D
+        v._node_obj = [None] * D
+        v._nodes, v._nodes_complete, v._id_of = {}, False, {}
+        v.node_of_hash = _HashToId(v)
         read_ids = self._read_ids
-        for i in range(D):
-            if not nodes["alive"][i]:
-                continue
-            toks = nodes["tokens"][i].tolist()
-            canon = [self._gene_obj(t) for t in toks]
-            rc = [self._gene_obj(vocab.flip(t)) for t in reversed(toks)]
-            h = self._hash_of_tokens(toks)
-            node = _GraphNode(GeneMer._from_parts(canon, rc, int(nodes["first_dir"][i]), h))
-            node.nodeCoverage = int(nodes["coverage"][i])
-            node._component_ID = int(nodes["component"][i])
-            node._lazy(lambda a=int(nr_off[i]), b=int(nr_off[i + 1]): [read_ids[r] for r in nr_idx[a:b].tolist()])
-            node._amg_id = i
-            v.node_hash[i] = h
-            v.nodes[h] = node
-            node_obj[i] = node
-        v.node_of_hash = {h: n._amg_id for h, n in v.nodes.items()}
+        n_tokens, n_cov, n_comp, n_fdir = nodes["tokens"], nodes["coverage"], nodes["component"], nodes["first_dir"]
         v.edge_hash = [None] * E
         v._edge_obj = [None] * E
         v._edges, v._edges_complete, v._n_edges = {}, False, E
         e_src, e_tgt, e_sdir, e_tdir, e_cov, e_alive = (edges["src"], edges["tgt"], edges["sdir"], edges["tdir"],
                                                          edges["coverage"], edges["alive"])
 
+        def edge_list(lo, hi):
+            return lambda: [v.edge_hash_of(e) for e in adj_edge[lo:hi].tolist() if e_alive[e]]
+
+        # (nothing below may hold `self`: the view must not keep its graph alive)
+        gene_cache, gene_name, flip, signed_hash = self._gene_cache, vocab.gene, vocab.flip, vocab.signed_hash
+
+        def gene_obj(t):
+            g = gene_cache.get(t)
+            if g is None:
+                g = gene_cache[t] = Gene(gene_name(t))
+            return g
+
+        def make_node(i):
+            if not n_alive[i]:
+                return None
+            toks = n_tokens[i].tolist()
+            canon = [gene_obj(t) for t in toks]
+            rc = [gene_obj(flip(t)) for t in reversed(toks)]
+            h = hashlib_hash(tuple([signed_hash(t) for t in toks]))
+            node = _GraphNode(GeneMer._from_parts(canon, rc, int(n_fdir[i]), h))
+            node.nodeCoverage = int(n_cov[i])
+            node._component_ID = int(n_comp[i])
+            node._lazy(lambda a=int(nr_off[i]), b=int(nr_off[i + 1]): [read_ids[r] for r in nr_idx[a:b].tolist()])
+            node._amg_id = i
+            lo, mid, hi = int(adj_off[2 * i]), int(adj_off[2 * i + 1]), int(adj_off[2 * i + 2])
+            node._lazy_edges(edge_list(lo, mid), edge_list(mid, hi))
+            v.node_hash[i] = h
+            v._node_obj[i] = node
+            v._nodes[h] = node
+            v._id_of[h] = i
+            if v._nh_table is not None:
+                v._nh_table[i] = h
+            return node
+
+        v._make_node = make_node
+
         def make_edge(e):
-            edge = Edge(node_obj[e_src[e]], node_obj[e_tgt[e]], int(e_sdir[e]), int(e_tdir[e]))
+            edge = Edge(v.node_at(int(e_src[e])), v.node_at(int(e_tgt[e])), int(e_sdir[e]), int(e_tdir[e]))
             edge.edgeCoverage = int(e_cov[e])
             edge._amg_id = e
             return edge
 
         v._make_edge = make_edge
-
-        def edge_list(lo, hi):
-            return lambda: [v.edge_hash_of(e) for e in adj_edge[lo:hi].tolist() if e_alive[e]]
-
-        off_l = adj_off.tolist()
-        for i in range(D):
-            node = node_obj[i]
-            if node is None:
-                continue
-            node._lazy_edges(edge_list(off_l[2 * i], off_l[2 * i + 1]), edge_list(off_l[2 * i + 1], off_l[2 * i + 2]))
         offs, nh = self._read_off, v.node_hash
 
         def window_ids(r):
@@ -484,6 +588,7 @@ class GeneMerGraph(BubblePopping):
 
         def make_nodes(r):
             _, _, ids = window_ids(r)
+            v.ensure_hashes(ids)
             return [nh[x] if x >= 0 else None for x in ids]
 
         def make_dirs(r):
@@ -571,16 +676,20 @@ class GeneMerGraph(BubblePopping):
         return reads
 
     def get_nodes_containing_read(self, readId):
-        nodes = self.get_nodes()
-        return [nodes[h] for h in self.get_readNodes()[readId] if h in nodes]
+        v = self._v()
+        found = [v.node_by_hash(h) for h in self.get_readNodes()[readId] if h is not None]
+        return [n for n in found if n is not None]
 
     def get_node_by_hash(self, nodeHash):
-        return self.get_nodes()[nodeHash]
+        node = self._v().node_by_hash(nodeHash)
+        if node is None:
+            raise KeyError(nodeHash)
+        return node
 
     def get_node(self, geneMer):
-        h = geneMer.__hash__()
-        assert h in self.get_nodes(), "This gene-mer is not in the graph"
-        return self.get_nodes()[h]
+        node = self._v().node_by_hash(geneMer.__hash__())
+        assert node is not None, "This gene-mer is not in the graph"
+        return node
 
     def get_edge_by_hash(self, edgeHash):
         return self._v().edge_by_hash(edgeHash)
@@ -601,7 +710,7 @@ class GeneMerGraph(BubblePopping):
         assert isinstance(geneOfInterest, str), "Gene of interest is the wrong type"
         v = self._v()
         ids = self._node_ids_containing([geneOfInterest])
-        return [v.nodes[v.node_hash[i]] for i in ids]
+        return [v.node_at(i) for i in ids]
 
     def _node_ids_containing(self, genes):
         v = self._v()
@@ -839,7 +948,7 @@ class GeneMerGraph(BubblePopping):
         tokens = None if v is not None else self._engine.nodes()["tokens"]
         removed = self._engine.remove_short_linear_paths(int(min_length), protect)
         if v is not None:
-            hashes = [v.node_hash[i] for i in removed.tolist()]
+            hashes = [v.hash_at(i) for i in removed.tolist()]
         else:
             hashes = [self._hash_of_tokens(tokens[i].tolist()) for i in removed.tolist()]
         if len(hashes):
@@ -1353,12 +1462,12 @@ class GeneMerGraph(BubblePopping):
         return out
 
     def collect_reads_in_path(self, path):
-        nodes = self.get_nodes()
+        v = self._v()
         reads = set()
         for h in list(path):
-            if h in nodes:
-                for r in nodes[h].get_reads():
-                    reads.add(r)
+            node = v.node_by_hash(h)
+            if node is not None:
+                reads.update(node.get_reads())   # (a list: added one by one, as the reference's loop does)
         return reads
 
     # ------------------------------------------------------------------ read-path clustering
@@ -1539,10 +1648,15 @@ class GeneMerGraph(BubblePopping):
         uniq = list(dict.fromkeys(combs))
         hits = self._match_gene_lists([list(c) for c in uniq] +
                                       [self.reverse_list_of_genes(list(c)) for c in uniq])
-        in_subset = np.zeros(len(self._read_ids) + 1, bool)   # reads that count (by row)
-        index = self._read_index
-        rows = [index.get(rid) for rid in gene_call_subset]
-        in_subset[[r for r in rows if r is not None]] = True
+        memo = getattr(self, "_subset_rows_memo", None)   # (the blocks of one gene come with the same subset)
+        if memo is not None and memo[0] is gene_call_subset and memo[1] == len(gene_call_subset):
+            in_subset = memo[2]
+        else:
+            in_subset = np.zeros(len(self._read_ids) + 1, bool)   # reads that count (by row)
+            index = self._read_index
+            rows = [index.get(rid) for rid in gene_call_subset]
+            in_subset[[r for r in rows if r is not None]] = True
+            self._subset_rows_memo = (gene_call_subset, len(gene_call_subset), in_subset)
         support = {}
         for j, comb in enumerate(uniq):
             reads = np.union1d(hits[j][0], hits[j + len(uniq)][0])
@@ -1564,8 +1678,16 @@ class GeneMerGraph(BubblePopping):
                 sub_tree = Tree({r: list(reversed(s)) for r, s in suffixes.items()})
             process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, node_tree, threshold)
         gene_blocks = {}
+        spelled = {}   # block -> its gene list (the graph does not change in here; the lists are only read)
+
+        def genes_of(f):
+            got = spelled.get(f)
+            if got is None:
+                got = spelled[f] = self.get_genes_in_unitig(list(f))
+            return got
+
         for f in full_blocks:
-            options = self.get_all_sublists(self.get_genes_in_unitig(f), gene_call_subset, threshold,
+            options = self.get_all_sublists(genes_of(f), gene_call_subset, threshold,
                                             geneOfInterest, cores)
             if len(options) > 0:
                 gene_blocks[f] = options
@@ -1583,7 +1705,7 @@ class GeneMerGraph(BubblePopping):
                 for f2 in filtered_blocks:
                     if f1 == f2:
                         continue
-                    other = self.get_genes_in_unitig(list(f2))
+                    other = genes_of(f2)
                     if _is_sublist(other, fwd) or _is_sublist(other, rev):
                         shared = True
                         break
@@ -1758,7 +1880,7 @@ class GeneMerGraph(BubblePopping):
         np.cumsum(n, out=starts[1:])
         total = int(starts[-1])
         within = np.arange(total, dtype=np.int64) - np.repeat(starts[:-1], n)
-        fwd = tok_node[np.repeat(a, n) + within].astype(np.int64)
+        fwd = tok_node[np.repeat(a, n) + within]
         if len(rows):
             lo = np.minimum.reduceat(fwd, starts[:-1])
             hi = np.maximum.reduceat(fwd, starts[:-1])
@@ -1773,9 +1895,14 @@ class GeneMerGraph(BubblePopping):
         flat = np.concatenate([fwd, rev])
         all_starts = np.concatenate([starts, starts_late[1:] + total])
         keys = reads_with_gene + [reads_with_gene[i] + "_reverse" for i in late.tolist()]
-        # the sequences themselves (what suffixes are cut from): the reads' node-hash lists of the view
-        read_nodes = v.readNodes
-        seqs = [read_nodes[rid] for rid in reads_with_gene]
+        # the sequences themselves (what suffixes are cut from): the reads' node-hash lists, cut out of ONE gather of
+        # the hashes by device id (ids -2 / -1 land on the two None entries at the end of the table)
+        hashes = v.node_hash_table(fwd)[fwd].tolist()
+        cuts = starts.tolist()
+        seqs = [hashes[cuts[i]:cuts[i + 1]] for i in range(len(rows))]
+        cache = v.readNodes._cache   # the block search asks the view for the same reads' lists next
+        for rid, lst in zip(reads_with_gene, seqs):
+            cache.setdefault(rid, lst)
         seqs += [seqs[i][::-1] for i in late.tolist()]
         to_id = v.node_of_hash
         return Tree.from_flat(keys, seqs, flat, all_starts, lambda x: -2 if x is None else to_id.get(x))
@@ -1805,4 +1932,5 @@ class GeneMerGraph(BubblePopping):
                 by_component.setdefault(self.get_node_by_hash(h).get_component(), set()).add(h)
             self.collect_component_missed_genes(by_component, clustered_reads, allele_counts,
                                                 geneOfInterest, path_reads)
+        self._subset_rows_memo = None
         return clustered_reads, path_reads

@@ -778,6 +778,13 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
 
   const char* abl = getenv("AMG_X_ABLATE");  // timing experiments (tools/ablate_probe.py): the build fails
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 63) : 0;
+#ifdef AMG_EXP_CTR
+  {
+    void* p = nullptr;
+    hipGetSymbolAddress(&p, HIP_SYMBOL(g_exp_ctr));
+    hipMemsetAsync(p, 0, 64 * 16 * 8, st);
+  }
+#endif
   stage_begin(c, "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
@@ -826,6 +833,9 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
+#ifdef AMG_EXP_CTR
+  if ((AMG_EXP_CTR) == 1 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
+#endif
   if (hs[ST_BADINPUT])
     return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
                                                     : "a token lies outside [0, two_v)");
@@ -941,6 +951,13 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
+#ifdef AMG_EXP_CTR
+  {
+    void* p = nullptr;
+    hipGetSymbolAddress(&p, HIP_SYMBOL(g_exp_ctr));
+    hipMemsetAsync(p, 0, 64 * 16 * 8, st);
+  }
+#endif
   stage_begin(c, "edge_table_clear");
   {
     ClearList cl;
@@ -980,6 +997,9 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
+#ifdef AMG_EXP_CTR
+  if ((AMG_EXP_CTR) == 2 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
+#endif
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");
   if (hs[ST_OVERFLOW]) {
     *which = 2;

@@ -301,6 +301,9 @@ __device__ __forceinline__ int f_canon_pack16(const int* a, int flip, unsigned l
 // The creators of a wave are counted with ballots and served by one atomicAdd of the wave:
 // no LDS, no workgroup barrier.
 #define F_SHARDS 64
+#ifdef AMG_EXP_CTR
+static __device__ unsigned long long g_exp_ctr[64 * 16];
+#endif
 #define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
 
 template <class T>
@@ -403,6 +406,21 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
       total += cnt;
     }
     if (total) {  // workgroup-uniform
+#ifdef AMG_EXP_CTR  // timing experiment (tools/ctr_probe.sh): is the single claim counter what a first build waits for?
+      // AMG_EXP_CTR: 1 node pass, 2 edge pass; AMG_EXP_MODE 1: a second returning atomic on the same word,
+      // 2: 64 counters with disjoint claim ranges (the counts the host reads are garbage: the build stops after the pass)
+      if ((AMG_EXP_CTR) == which) {
+        if (threadIdx.x == 0) {
+          if ((AMG_EXP_MODE) == 1) {
+            const unsigned int z = (unsigned int)atomicAdd(ctr, 0ull);
+            s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total) + (z & 0x80000000u);
+          } else {
+            const unsigned int sh = blockIdx.x & 63u;
+            s_wave[TILE_THREADS / 64] = sh * (cap >> 6) + (unsigned int)atomicAdd(g_exp_ctr + sh * 16u, (unsigned long long)total);
+          }
+        }
+      } else
+#endif
       if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total);
       __syncthreads();
       base = s_wave[TILE_THREADS / 64] + before;

@@ -82,7 +82,7 @@ class TokenizedReads(Mapping):
 
     def _idx(self):
         if self._index is None:
-            self._index = {r: i for i, r in enumerate(self.read_ids)}
+            self._index = dict(zip(self.read_ids, range(len(self.read_ids))))
         return self._index
 
     def __getitem__(self, read_id):
@@ -157,7 +157,7 @@ class TokenizedPositions(Mapping):
 
     def _idx(self):
         if self._index is None:
-            self._index = {r: i for i, r in enumerate(self.read_ids)}
+            self._index = dict(zip(self.read_ids, range(len(self.read_ids))))
         return self._index
 
     def __getitem__(self, read_id):
@@ -260,7 +260,7 @@ class ReadLengths(Mapping):
 
     def _idx(self):
         if self._index is None:
-            self._index = {r: i for i, r in enumerate(self.read_ids)}
+            self._index = dict(zip(self.read_ids, range(len(self.read_ids))))
         return self._index
 
     def __getitem__(self, read_id):

@@ -23,6 +23,26 @@ class _Suffix:
         return " ".join([str(x) for x in self.items] + ["$"])
 
 
+class _ReversedSuffixes:
+    """sequence j = parent[rows[j]][first[j]:] back to front, made when asked for; suffix(j, i) = that sequence from
+    its item i on, as ONE slice of the parent's list"""
+
+    __slots__ = ("_parent", "_rows", "_first")
+
+    def __init__(self, parent, rows, first):
+        self._parent, self._rows, self._first = parent, rows, first
+
+    def __len__(self):
+        return len(self._rows)
+
+    def suffix(self, j, i):
+        seq, p = self._parent[self._rows[j]], self._first[j]
+        return seq[len(seq) - 1 - i:p - 1:-1] if p else seq[len(seq) - 1 - i::-1]
+
+    def __getitem__(self, j):
+        return self.suffix(j, 0)
+
+
 class _ScanTree:
     """Exact sub-list search over a {key: sequence} mapping with the call shape of suffix_tree.Tree
     (`Tree(dict)`, `find_all(seq) -> [(key, suffix from the match start)]`, hits in key order then
@@ -76,7 +96,7 @@ class _ScanTree:
         self._np = np
         self._keys, self._seqs = list(keys), seqs
         self._starts = np.asarray(starts, dtype=np.int64)
-        self._flat = np.asarray(flat, dtype=np.int64)
+        self._flat = np.asarray(flat)   # any integer type (the device's 32-bit ids: half the bytes per scan)
         self._code = code_of
         return self
 
@@ -101,7 +121,7 @@ class _ScanTree:
         sub._np, sub._code = np, self._code
         if codes is None or len(self._flat) == 0:
             sub._keys, sub._seqs = [], []
-            sub._starts, sub._flat = np.zeros(1, np.int64), np.zeros(0, np.int64)
+            sub._starts, sub._flat = np.zeros(1, np.int64), np.zeros(0, self._flat.dtype)
             return sub
         at = np.flatnonzero(self._flat == codes[0])
         row = np.searchsorted(self._starts, at, side="right") - 1
@@ -109,12 +129,15 @@ class _ScanTree:
         at, row = at[first], row[first]
         ends = self._starts[row + 1]
         sub._keys = [self._keys[r] for r in row.tolist()]
-        sub._seqs = [self._seqs[r][a - s:][::-1] for r, a, s in zip(row.tolist(), at.tolist(), self._starts[row].tolist())]
-        pieces = [self._flat[a:e][::-1] for a, e in zip(at.tolist(), ends.tolist())]
-        starts = np.zeros(len(pieces) + 1, dtype=np.int64)
-        np.cumsum(ends - at, out=starts[1:])
+        # the item lists of the sub-tree are cut out of this tree's lists when a hit asks for them
+        sub._seqs = _ReversedSuffixes(self._seqs, row.tolist(), (at - self._starts[row]).tolist())
+        lens = ends - at
+        starts = np.zeros(len(at) + 1, dtype=np.int64)
+        np.cumsum(lens, out=starts[1:])
         sub._starts = starts
-        sub._flat = np.concatenate(pieces) if pieces else np.zeros(0, np.int64)
+        # codes of all suffixes back to front in one gather
+        within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], lens)
+        sub._flat = self._flat[np.repeat(ends - 1, lens) - within]
         return sub
 
     def find_all(self, query):
@@ -139,7 +162,11 @@ class _ScanTree:
             keep = flat[at + j] == codes[j]
             at, row = at[keep], row[keep]
         begin = (at - starts[row]).tolist()
-        return [(self._keys[r], _Suffix(self._seqs[r][i:])) for r, i in zip(row.tolist(), begin)]
+        keys, seqs = self._keys, self._seqs
+        if isinstance(seqs, _ReversedSuffixes):
+            cut = seqs.suffix
+            return [(keys[r], _Suffix(cut(r, i))) for r, i in zip(row.tolist(), begin)]
+        return [(keys[r], _Suffix(seqs[r][i:])) for r, i in zip(row.tolist(), begin)]
 
 
 Tree = _ExternalTree or _ScanTree
@@ -147,7 +174,7 @@ Tree = _ExternalTree or _ScanTree
 
 def _suffix_ints(path):
     if isinstance(path, _Suffix):  # our own tree: no need to print and re-parse the suffix
-        return None if path.items[0] is None else list(path.items)
+        return None if path.items[0] is None else path.items   # (a list of its own: find_all cuts one per hit)
     parts = str(path).split(" ")
     if parts[0] == "None":
         return None
@@ -165,7 +192,20 @@ def is_sublist(long_list, sub_list):
 
 def find_sublist_indices(main_list, sublist):
     m = len(sublist)
-    return [(i, i + m - 1) for i in range(len(main_list) - m + 1) if main_list[i:i + m] == sublist]
+    if m == 0:
+        return [(i, i - 1) for i in range(len(main_list) + 1)]
+    # candidates = where the first item occurs (list.index scans at C speed), then one slice compare each
+    found, first, i, last = [], sublist[0], -1, len(main_list) - m
+    try:
+        while True:
+            i = main_list.index(first, i + 1)
+            if i > last:
+                break
+            if main_list[i:i + m] == sublist:
+                found.append((i, i + m - 1))
+    except ValueError:
+        pass
+    return found
 
 
 def _greedy_clusters(adjacent_paths, fits):
