@@ -558,13 +558,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
   }
 }
 
-// ------------------------------------------------------------------ edges, four consecutive adjacencies per thread
-template <bool HEAD>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
+// ------------------------------------------------------------------ edges, four adjacencies per thread
+// HOME = 0: a thread's four adjacencies are consecutive (one LDS read of its neighbours' words, one 16-byte store of its
+// results), every class lives where its key hashes to.
+// HOME > 0 (`home_n` slots in front of the hashed ones): node ids are first-seen ranks, so nine adjacencies in ten join
+// ids n and n + 1 — their class lives in slot n, addressed directly (a second class of the same two nodes, or any other
+// pair, goes to the hashed slots behind), and a thread's adjacencies lie 256 windows apart so that the 64 lanes of a
+// probe instruction look at 64 consecutive windows: consecutive ids, eight slots to a 128-byte line instead of one
+// line per lane (the passes are bound by the line requests of their probes).
+template <bool HEAD, bool HOME>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
     unsigned int probe_limit, unsigned long long* status, int* __restrict__ tok_pair, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n) {
   typedef int i4 __attribute__((ext_vector_type(4)));
   // word per window: node id | (direction -1) << 30 | last-of-read << 31, -1: no node
   constexpr unsigned int DIRBIT = 0x40000000u;
@@ -621,20 +628,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     s_w[TILE] = wn;
   }
   __syncthreads();
-  cw[TILE_ITEMS] = s_w[i0 + TILE_ITEMS];
+  if constexpr (!HOME) cw[TILE_ITEMS] = s_w[i0 + TILE_ITEMS];
 
   // adjacency (A, dA) -> (B, dB) of windows t and t + 1 of one read (create_edges :246-262); class key =
   // (smaller id, larger id, dA * dB), first-seen = (token << 3) | orientation
   unsigned long long key[TILE_ITEMS];
   unsigned int idx[TILE_ITEMS], etag[TILE_ITEMS], id1[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
-  unsigned int valid = 0, orient3 = 0;
+  unsigned int valid = 0, orient3 = 0, homed = 0;
 #pragma unroll
   for (int w = 0; w < TILE_ITEMS; ++w) {
     key[w] = 0;
     idx[w] = 0;
     etag[w] = 0;
-    const int A = cw[w], B = cw[w + 1];
+    const int A = HOME ? s_w[w * TILE_THREADS + tid] : cw[w], B = HOME ? s_w[w * TILE_THREADS + tid + 1] : cw[w + 1];
     if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
     const unsigned int a = (unsigned int)A & (DIRBIT - 1u), b = (unsigned int)B & (DIRBIT - 1u);
     const bool negA = ((unsigned int)A & DIRBIT) != 0u, negB = ((unsigned int)B & DIRBIT) != 0u;
@@ -643,26 +650,46 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
     const unsigned int orient = (a == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
     orient3 |= orient << (3 * w);
-    idx[w] = (unsigned int)mix64(key[w]) & emask;
+    if (HOME && hi == lo + 1u && lo < home_n) {
+      idx[w] = lo;
+      homed |= 1u << w;
+    } else {
+      idx[w] = (HOME ? home_n : 0u) + ((unsigned int)mix64(key[w]) & emask);
+    }
 #ifndef AMG_ABLATE_NOPROBE
     v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
 #endif
     valid |= 1u << w;
   }
   unsigned int made = 0;
-  f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
-                                 slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave,
-                                 &made);
-  i4 op;
+  if constexpr (HOME)
+    f_table_phase<false, 3, false, TILE_THREADS>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid, orient3, xf,
+                                                 first2, slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit,
+                                                 status, 2, id1, s_wave, &made, homed, home_n);
+  else
+    f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
+                                   slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave,
+                                   &made);
+  if constexpr (HOME) {
 #pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w)
-    op[w] = id1[w] ? (int)((id1[w] - 1u) | ((made & (1u << w)) ? AMG_MADE_FLAG : 0u)) : -1;
-  if (t + TILE_ITEMS <= n_tokens) {
-    __builtin_nontemporal_store(op, reinterpret_cast<i4*>(tok_pair + t));
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      const long long tw = t0 + w * TILE_THREADS + tid;
+      if (tw < n_tokens)
+        __builtin_nontemporal_store(id1[w] ? (int)((id1[w] - 1u) | ((made & (1u << w)) ? AMG_MADE_FLAG : 0u)) : -1,
+                                    tok_pair + tw);
+    }
   } else {
+    i4 op;
 #pragma unroll
     for (int w = 0; w < TILE_ITEMS; ++w)
-      if (t + w < n_tokens) tok_pair[t + w] = op[w];
+      op[w] = id1[w] ? (int)((id1[w] - 1u) | ((made & (1u << w)) ? AMG_MADE_FLAG : 0u)) : -1;
+    if (t + TILE_ITEMS <= n_tokens) {
+      __builtin_nontemporal_store(op, reinterpret_cast<i4*>(tok_pair + t));
+    } else {
+#pragma unroll
+      for (int w = 0; w < TILE_ITEMS; ++w)
+        if (t + w < n_tokens) tok_pair[t + w] = op[w];
+    }
   }
 }
 
@@ -947,8 +974,12 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
   }
   const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
+  // home slots (k_edges_v<.., true>): one per node id in front of the hashed slots; AMG_EDGE_HOME=0: none (A/B switch)
+  const char* eh = getenv("AMG_EDGE_HOME");
+  const long long home_n = (getenv("AMG_X_OLD_PASS") || (eh && atoi(eh) == 0)) ? 0 : ((D + 7) & ~7ll);
+  const size_t tab_slots = (size_t)c->edge_slots + (size_t)home_n;
   AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
-  AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot16)));
+  AMGCHK(c->edge_tab.ensure(tab_slots * sizeof(Slot16)));
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
 #ifdef AMG_EXP_CTR
@@ -961,7 +992,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   stage_begin(c, "edge_table_clear");
   {
     ClearList cl;
-    cl.add(c->edge_tab.p, (size_t)c->edge_slots * sizeof(Slot16));
+    cl.add(c->edge_tab.p, tab_slots * sizeof(Slot16));
     cl.add(c->x_efirst.p, 2 * max_claims * sizeof(unsigned int));
     cl.add(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 2 * sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
@@ -986,12 +1017,14 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
         stage_end(c);
         stage_begin(c, "edge_upsert");
       }
-      hipLaunchKernelGGL(part == 0 ? k_edges_v<true> : k_edges_v<false>, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
+      auto kern = home_n ? (part == 0 ? k_edges_v<true, true> : k_edges_v<false, true>)
+                         : (part == 0 ? k_edges_v<true, false> : k_edges_v<false, false>);
+      hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                          c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                          c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                          c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
                          c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), (unsigned int)max_claims,
-                         xw2_for(max_claims, T), (unsigned int)lo);
+                         xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n);
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline

@@ -106,7 +106,9 @@ __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
                                               unsigned long long w1, unsigned int tag,
                                               unsigned int idx, ulonglong2 v,
                                               unsigned int limit, const unsigned long long* abort_flag,
-                                              unsigned long long& w2v, bool& created) {
+                                              unsigned long long& w2v, bool& created, unsigned int off = 0u) {
+  // off: the hashed slots are tab[off .. off + mask] (slots below `off` are addressed directly: home slots of the
+  // edge pass, probed with limit 0 — taken, found or given up after that one slot)
   created = false;
   w2v = 0;
   unsigned int probes = 0;
@@ -161,7 +163,7 @@ __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
     if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
       return -1;
     ++probes;
-    idx = (idx + 1) & mask;
+    idx = off + ((idx - off + 1u) & mask);
     v = *reinterpret_cast<const ulonglong2*>(tab + idx);
   }
 }
@@ -311,7 +313,10 @@ __device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
   return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3];
 }
 
-template <bool TWO, int FSH, bool SHARDED>
+// STRIDE: window `it` of a thread starts STRIDE tokens after window it - 1.  homed / off: items whose idx[] is a
+// HOME slot (a directly addressed slot below `off`: taken, found, or — when another key sits there — given up for the
+// key's hashed slot in tab[off .. off + mask]); one-word keys only.
+template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1>
 __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
                                               const unsigned long long (&w1)[TILE_ITEMS],
                                               const unsigned int (&tag)[TILE_ITEMS],
@@ -322,8 +327,9 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                                               unsigned long long* ctr, unsigned int shard, unsigned int cap,
                                               unsigned int probe_limit, unsigned long long* status, int which,
                                               unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr,
-                                              unsigned int* made = nullptr) {
-  auto tpos = [&](int it) { return tbase + (unsigned int)it; };
+                                              unsigned int* made = nullptr, unsigned int homed = 0u,
+                                              unsigned int off = 0u) {
+  auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
   auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
   int slot[TILE_ITEMS];
@@ -358,9 +364,16 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     // (the slot is loaded again rather than picked out of v[]: a register array indexed at run time
     // lives in scratch memory)
     const unsigned int ix = f_pick(idx, it);
-    const int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
-                                 *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit,
-                                 status + ST_OVERFLOW, w2v, made);
+    const bool home = (homed >> it) & 1u;
+    int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
+                           *reinterpret_cast<const ulonglong2*>(tab + ix), home ? 0u : probe_limit,
+                           status + ST_OVERFLOW, w2v, made, off);
+    if (!TWO && sl < 0 && home) {  // another class lives in the home slot: this one goes where its key hashes to
+      const unsigned int ix2 = off + ((unsigned int)mix64(f_pick(w1, it)) & mask);
+      sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix2,
+                         *reinterpret_cast<const ulonglong2*>(tab + ix2), probe_limit, status + ST_OVERFLOW, w2v, made,
+                         off);
+    }
     if (sl < 0) {
       status[ST_OVERFLOW] = (unsigned long long)which;
       valid &= ~(1u << it);
