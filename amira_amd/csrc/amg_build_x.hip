@@ -969,15 +969,18 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   const long long T = c->n_tokens, D = c->n_nodes;
   const long long n_tiles = (T + TILE - 1) / TILE;
   unsigned long long hs[ST_WORDS];
-  if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
-  if (const char* e = getenv("AMG_EDGE_SLOTS_LOG2")) {  // A/B switch (first builds only: D large)
-    if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
-  }
-  const size_t max_claims = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
   // home slots (k_edges_v<.., true>): one per node id in front of the hashed slots; AMG_EDGE_HOME=0: none (A/B switch)
   const char* eh = getenv("AMG_EDGE_HOME");
   const long long home_n = (getenv("AMG_X_OLD_PASS") || (eh && atoi(eh) == 0)) ? 0 : ((D + 7) & ~7ll);
+  // hashed slots: with home slots only the classes that do not join ids n and n + 1 (one in ten on gene-call reads)
+  // need one — sized for a quarter of the nodes; an input that needs more overflows once and is rebuilt 4x larger
+  const int64_t want_slots = (int64_t)slots_for((uint64_t)(home_n ? D / 4 + 1 : D));
+  if (c->edge_slots < want_slots) c->edge_slots = want_slots;
+  if (const char* e = getenv("AMG_EDGE_SLOTS_LOG2")) {  // A/B switch (first builds only: D large)
+    if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
+  }
   const size_t tab_slots = (size_t)c->edge_slots + (size_t)home_n;
+  const size_t max_claims = (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
   AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure(tab_slots * sizeof(Slot16)));
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
