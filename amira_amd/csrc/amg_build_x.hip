@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
 // probed: nearly every window of a rebuild) is straight-line code.  Streams are non-temporal so that the L2s keep
 // the table's hot lines (tools/ubench/pass_bench.hip: a pass of this shape is bound by the line requests of its
 // probes, 0.2 ms per 56 M, plus its streams; whatever else it does has to hide behind those).
-template <bool TWO, int K, bool B16>
+template <bool TWO, int K, bool B16, bool HEAD = false>  // HEAD: the short launch over the first tiles (a symbol of its own, as k_edges_v's)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
@@ -815,7 +815,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
     hipMemsetAsync(p, 0, 64 * 16 * 8, st);
   }
 #endif
-  stage_begin(c, "node_upsert");
+  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles, 0) > 0) ? "node_upsert_head" : "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
     if (getenv("AMG_X_OLD_PASS")) {  // A/B switch: one window per lane, strided (the round-1 kernel)
@@ -834,12 +834,16 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
     } else {
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
       auto kern = two ? k_nodes_v<true, 0, false> : k_nodes_v<false, 0, false>;
+      auto kern_head = two ? k_nodes_v<true, 0, false, true> : k_nodes_v<false, 0, false, true>;
       if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
-        if (b16 && k == 3) kern = k_nodes_v<false, 3, true>;
-        else if (b16 && k == 5) kern = k_nodes_v<true, 5, true>;
-        else if (k == 3) kern = two ? k_nodes_v<true, 3, false> : k_nodes_v<false, 3, false>;
-        else if (k == 5) kern = two ? k_nodes_v<true, 5, false> : k_nodes_v<false, 5, false>;
-        else if (k == 7) kern = two ? k_nodes_v<true, 7, false> : k_nodes_v<false, 7, false>;
+        if (b16 && k == 3) kern = k_nodes_v<false, 3, true>, kern_head = k_nodes_v<false, 3, true, true>;
+        else if (b16 && k == 5) kern = k_nodes_v<true, 5, true>, kern_head = k_nodes_v<true, 5, true, true>;
+        else if (k == 3) kern = two ? k_nodes_v<true, 3, false> : k_nodes_v<false, 3, false>,
+                         kern_head = two ? k_nodes_v<true, 3, false, true> : k_nodes_v<false, 3, false, true>;
+        else if (k == 5) kern = two ? k_nodes_v<true, 5, false> : k_nodes_v<false, 5, false>,
+                         kern_head = two ? k_nodes_v<true, 5, false, true> : k_nodes_v<false, 5, false, true>;
+        else if (k == 7) kern = two ? k_nodes_v<true, 7, false> : k_nodes_v<false, 7, false>,
+                         kern_head = two ? k_nodes_v<true, 7, false, true> : k_nodes_v<false, 7, false, true>;
       }
       // Claim ids follow the order in which the ~2000 concurrently running tiles create keys: with many creations
       // per tile (a first build: one window in ten) the genome's keys, which almost every later window hits,
@@ -850,7 +854,11 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
       for (int part = 0; part < 2; ++part) {
         const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
         if (cnt <= 0) continue;
-        hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+        if (part == 1 && head > 0) {  // the head launch is a stage of its own
+          stage_end(c);
+          stage_begin(c, "node_upsert");
+        }
+        hipLaunchKernelGGL(part == 0 ? kern_head : kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
                            c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
                            c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                            c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),

@@ -740,7 +740,7 @@ def main():
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
-                                                        "node_upsert", "node_rank", "node_filter", "edge_table_clear", "edge_upsert_head",
+                                                        "node_upsert_head", "node_upsert", "node_rank", "node_filter", "edge_table_clear", "edge_upsert_head",
                                                         "edge_upsert",
                                                         "edge_rank", "node_count", "edge_count", "edge_emit",
                                                         "components", "adjacency"))
@@ -748,7 +748,7 @@ def main():
         survey_b = 4.0 * L / (L - k + 1) + 5 + (4 * k + 8) + 20.0 * (L - k) / (L - k + 1)
         # both table passes together: their algorithmic bytes over their time (per step)
         table_passes = None
-        tp = [x for x in ("node_upsert", "edge_upsert", "edge_upsert_head", "graph_upsert") if x in stage_tot]
+        tp = [x for x in ("node_upsert", "node_upsert_head", "edge_upsert", "edge_upsert_head", "graph_upsert") if x in stage_tot]
         if tp:
             tp_bytes = sum((cands.get(x) or 0.0) * stage_ms[x][1] for x in tp)
             tp_ms = sum(stage_tot[x] for x in tp)
@@ -772,7 +772,10 @@ def main():
         if w["sweep"] and world == 1 and pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
-                row = next(r for r in pmc["kernels"] if r["kernel"].split("<")[0] == kernel_of[dom])
+                # (the short head launch of a table pass is a template instance of its own: the main launch is the
+                # instance that moves the most)
+                row = max((r for r in pmc["kernels"] if r["kernel"].split("<")[0] == kernel_of[dom]),
+                          key=lambda r: r.get("FETCH_SIZE_KB_mean", 0) + r.get("WRITE_SIZE_KB_mean", 0))
                 n = min(len(row["FETCH_SIZE_KB_per_launch"]), len(row["WRITE_SIZE_KB_per_launch"]))
                 # gfx950: FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane loads at 64 bytes (MI355X_MICROARCH.md,
                 # HBM): every load of the table passes is such a load (token stream, slot probes), so the read side is
