@@ -26,7 +26,7 @@ import os
 import statistics
 import sys
 import weakref
-from collections.abc import Mapping
+from collections.abc import Mapping, Sequence
 from itertools import product
 
 import numpy as np
@@ -38,7 +38,7 @@ from .construct_gene import Gene, convert_int_strand_to_string, hashlib_hash
 from .construct_gene_mer import GeneMer
 from .construct_node import Node
 from .construct_read import Read  # noqa: F401  (re-exported like the reference)
-from .engine import Engine
+from .engine import Engine, _ENGINE_POOL, acquire_engine as _acquire_engine, release_engine as _release_engine  # noqa: F401
 from .path_finding_utils import (
     Tree,
     construct_suffix_tree,
@@ -102,6 +102,35 @@ class _LazyReadLists(Mapping):
 
     def __contains__(self, rid):
         return rid in self._cache or self._row(rid) is not None
+
+
+class _LazyHashes(Sequence):
+    """node hashes of the rows of a token matrix, computed on first use (a list from then on)"""
+
+    def __init__(self, token_rows, vocab):
+        self._rows, self._vocab, self._made = token_rows, vocab, None
+
+    def _list(self):
+        if self._made is None:
+            signed = self._vocab.signed_hash
+            self._made = [hashlib_hash(tuple([signed(t) for t in row])) for row in self._rows.tolist()]
+            self._rows = None
+        return self._made
+
+    def __len__(self):
+        return len(self._rows) if self._made is None else len(self._made)
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+    def __iter__(self):
+        return iter(self._list())
+
+    def __eq__(self, other):
+        return self._list() == (other._list() if isinstance(other, _LazyHashes) else other)
+
+    def __repr__(self):
+        return repr(self._list())
 
 
 class _GraphNode(Node):
@@ -268,26 +297,6 @@ class _View:
         return got if got is not None else self.edges[h]
 
 
-# Engines (a HIP stream + grow-only device buffers each) are pooled per device: the reference's
-# drivers build graph after graph (three per cleaning iteration, seven in choose_kmer_size), and an
-# engine that has already sized its buffers for the read set makes the next build allocation-free.
-_ENGINE_POOL = {}
-
-
-def _acquire_engine(device):
-    free = _ENGINE_POOL.setdefault(device, [])
-    while free:
-        engine = free.pop()
-        if engine._h:   # (an engine finalised by the cycle collector together with its graph is closed)
-            return engine
-    return Engine(device)
-
-
-def _release_engine(engine):
-    if engine is not None and engine._h:
-        _ENGINE_POOL.setdefault(engine.device, []).append(engine)
-
-
 class GeneMerGraph(BubblePopping):
     # ------------------------------------------------------------------ build
     def __init__(self, readDict, kmerSize, gene_positions=None, device=None, _filter=None):
@@ -381,7 +390,6 @@ class GeneMerGraph(BubblePopping):
         self._gene_cache = {}
         self._read_index_ = None
         self._tokens_val = self._gs_val = self._ge_val = None   # host copies: see the properties below
-        self._leases = weakref.WeakSet()   # outputs of correct_reads that still live in this graph's engine
         self._positions_pending = False
         self._reads_owner = None   # build_many: the graph whose engine holds the reads this one's engine borrows
         self._borrowers = 0        # build_many: graphs that borrow this one's reads
@@ -459,24 +467,16 @@ class GeneMerGraph(BubblePopping):
     def close(self):
         """hand the device engine back (the graph can no longer be queried); also done when the object dies"""
         self._view = None
-        if len(getattr(self, "_leases", ())) > 0:   # a correct_reads output still lives in this engine's buffers: the
-            self._close_pending = True              # engine goes back when it has been fetched or dropped
-            return
         owner, self._reads_owner = getattr(self, "_reads_owner", None), None
         if getattr(self, "_borrowers", 0) > 0:   # graphs of build_many still read this one's device arrays
             self._close_pending = True
             return
         engine, self._engine = getattr(self, "_engine", None), None
-        _release_engine(engine)
+        _release_engine(engine)   # (pooled once no correct_reads output lives in its buffers any more)
         if owner is not None:
             owner._borrowers -= 1
             if owner._borrowers == 0 and getattr(owner, "_close_pending", False):
                 owner.close()
-
-    def _lease_done(self, lease):
-        self._leases.discard(lease)
-        if self._close_pending and len(self._leases) == 0:
-            self.close()
 
     def __del__(self):
         try:
@@ -949,6 +949,10 @@ class GeneMerGraph(BubblePopping):
         removed = self._engine.remove_short_linear_paths(int(min_length), protect)
         if v is not None:
             hashes = [v.hash_at(i) for i in removed.tolist()]
+        elif isinstance(self._reads, TokenizedReads):
+            # array-backed inputs (the drivers, which ignore the result): the hashes — a sha256 per removed node, tens
+            # of thousands of them in a first sweep — are made when somebody looks at them
+            hashes = _LazyHashes(tokens[removed], self._vocab)
         else:
             hashes = [self._hash_of_tokens(tokens[i].tolist()) for i in removed.tolist()]
         if len(hashes):
@@ -1035,7 +1039,7 @@ class GeneMerGraph(BubblePopping):
                 except (KeyError, TypeError, IndexError):
                     lengths[r] = 0
             eng.set_read_lengths(lengths)
-        for lease in list(self._leases):   # an earlier correction's output still on the device: about to be overwritten
+        for lease in list(eng._leases):   # an earlier correction's output still on the device: about to be overwritten
             lease.fetch()
         n_reads, n_tokens = eng.correct_reads()
         if self._tokenized_io(have_pos):
@@ -1071,11 +1075,13 @@ class GeneMerGraph(BubblePopping):
         gene_positions in place, :1282-1284, :1328)"""
         from .io import DeviceCorrected
         orig = out["orig_read"]
-        ids_arr = self._read_ids_array()
-        ids = ids_arr[orig].tolist()
+        if len(orig) == len(self._read_ids):   # nothing dropped (the order is kept): the very same reads
+            ids = self._read_ids
+        else:
+            ids = self._read_ids_array()[orig].tolist()
         offs = out["read_offsets"]
         src = getattr(self._reads, "source_rows", None)
-        on_device = DeviceCorrected(self, n_reads, n_tokens, have_pos)
+        on_device = DeviceCorrected(self._engine, n_reads, n_tokens, have_pos)
         reads = TokenizedReads(self._vocab, on_device, offs, ids,
                                source_rows=orig.astype(np.int64) if src is None else src[orig])
         if not have_pos:

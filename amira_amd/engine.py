@@ -2,6 +2,7 @@
 This is the layer bench.py times; amira_amd.construct_graph builds the reference's
 object API on top of it."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -14,6 +15,10 @@ class Engine:
         self._h = C.c_void_p()
         check(_ffi.lib.amg_create(int(device), C.byref(self._h)))
         self.device = device
+        # outputs of a correct_reads that still live in this engine's buffers (amira_amd.io.DeviceCorrected): while
+        # there are any, the engine stays out of the pool
+        self._leases = weakref.WeakSet()
+        self._pool_when_free = False
 
     def close(self):
         if self._h:
@@ -316,3 +321,36 @@ class Engine:
                                                  C.c_void_p(replies_ptr)))
         else:
             check(_ffi.lib.amg_dist_edges_global(self._h, C.c_void_p(all_ptr), int(n_slots), int(n_total)))
+
+
+# Engines (a HIP stream + grow-only device buffers each) are pooled per device: the reference's drivers build graph
+# after graph (three per cleaning iteration, seven in choose_kmer_size), and an engine that has already sized its
+# buffers for the read set makes the next build allocation-free.
+_ENGINE_POOL = {}
+
+
+def acquire_engine(device):
+    free = _ENGINE_POOL.setdefault(device, [])
+    while free:
+        engine = free.pop()
+        if engine._h:
+            return engine
+    return Engine(device)
+
+
+def release_engine(engine):
+    """back to the pool — at once, or, while the output of a correct_reads still lives in its buffers, when the last
+    such output has been fetched or dropped (lease_done)"""
+    if engine is None or not engine._h:
+        return
+    if len(engine._leases) > 0:
+        engine._pool_when_free = True
+        return
+    engine._pool_when_free = False
+    _ENGINE_POOL.setdefault(engine.device, []).append(engine)
+
+
+def lease_done(engine, lease):
+    engine._leases.discard(lease)
+    if engine._pool_when_free and len(engine._leases) == 0:
+        release_engine(engine)

@@ -17,28 +17,30 @@ class DeviceCorrected:
     """What one GeneMerGraph.correct_reads produced, still on the device: the corrected genes and their positions
     (240 MB + 960 MB for a million 60-gene reads).  The array-backed mappings correct_reads hands back point here;
     the arrays cross PCIe only if somebody looks at them on the host — a GeneMerGraph built from those mappings takes
-    them over device to device (amg_set_reads_from_corrected).  Holds the graph (and with it the engine whose buffers
-    these are) until it is fetched or dropped."""
+    them over device to device (amg_set_reads_from_corrected).  Holds the ENGINE whose buffers these are — not the
+    graph, whose own gene positions point back here (a cycle would leave graph and engine to the cyclic collector) —
+    and keeps it out of the engine pool until the set has been fetched or dropped."""
 
-    def __init__(self, graph, n_reads, n_tokens, have_pos):
-        self._graph, self._shape, self._arrays = graph, (n_reads, n_tokens, have_pos), None
-        graph._leases.add(self)
+    def __init__(self, engine, n_reads, n_tokens, have_pos):
+        self._engine, self._shape, self._arrays = engine, (n_reads, n_tokens, have_pos), None
+        engine._leases.add(self)
 
     def engine(self):
         """the engine that still holds the set (None once it has been fetched)"""
-        return self._graph._engine if self._graph is not None else None
+        return self._engine
 
     def fetch(self):
         if self._arrays is None:
-            out = self._graph._engine.corrected(*self._shape)
+            out = self._engine.corrected(*self._shape)
             self._arrays = {"tokens": out["tokens"], "gene_start": out["gene_start"], "gene_end": out["gene_end"]}
             self._done()
         return self._arrays
 
     def _done(self):
-        graph, self._graph = self._graph, None
-        if graph is not None:
-            graph._lease_done(self)
+        engine, self._engine = self._engine, None
+        if engine is not None:
+            from .engine import lease_done
+            lease_done(engine, self)
 
     def __del__(self):
         try:

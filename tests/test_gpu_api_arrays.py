@@ -111,7 +111,7 @@ def test_remove_junk_reads_on_arrays_equals_dicts(rate):
 def test_corrected_reads_go_to_the_next_graph_on_the_device():
     """the output of correct_reads on array-backed inputs stays on the device (amira_amd.io.DeviceCorrected): the next
     GeneMerGraph takes it over device to device, the host arrays appear only when somebody reads them, and the engine
-    that holds them is handed back only then"""
+    that holds them goes back to the pool only then; nothing of this hangs in a reference cycle"""
     from amira_amd import GeneMerGraph
     reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
     pos_d = {r: list(v) for r, v in pos.items()}
@@ -122,8 +122,11 @@ def test_corrected_reads_go_to_the_next_graph_on_the_device():
     rd, pd = gd.correct_reads(fq)
     rt, pt = gt.correct_reads(tlen)
     assert rt.device_source() is not None and pt.device_source() is rt.device_source()
+    from amira_amd.engine import _ENGINE_POOL
+    held = rt.device_source().engine()
     gt.close()
-    assert gt._engine is not None                     # still holds the corrected set
+    # the graph has let go of its engine, the corrected set keeps it alive and out of the pool
+    assert gt._engine is None and held._h and all(held is not e for e in _ENGINE_POOL.get(held.device, []))
     g2d, g2t = GeneMerGraph(rd, 5, pd), GeneMerGraph(rt, 5, pt)
     assert rt.device_source() is not None             # nothing crossed PCIe for the rebuild
     assert list(g2t.get_nodes()) == list(g2d.get_nodes())
@@ -131,13 +134,19 @@ def test_corrected_reads_go_to_the_next_graph_on_the_device():
            [(h, e.get_edge_coverage()) for h, e in g2d.get_edges().items()]
     assert {r: list(v) for r, v in g2t.get_readNodePositions().items()} == \
            {r: list(v) for r, v in g2d.get_readNodePositions().items()}   # reads the host positions: fetched now
-    g2t.remove_short_linear_paths(5)
-    g2d.remove_short_linear_paths(5)
+    clipped_t, clipped_d = g2t.remove_short_linear_paths(5), g2d.remove_short_linear_paths(5)
+    assert isinstance(clipped_d, list) and len(clipped_t) == len(clipped_d) > 0
+    assert list(clipped_t) == clipped_d and clipped_t == clipped_d   # (array inputs: the hashes are made when looked at)
     r2d, p2d = g2d.correct_reads(fq)
     r2t, p2t = g2t.correct_reads(tlen)
     assert list(r2t) == list(r2d)
     for r in r2d:
         assert r2t[r] == r2d[r] and [tuple(x) for x in p2t[r]] == [tuple(x) for x in p2d[r]]
-    assert rt.device_source() is None and gt._engine is None   # fetched -> the first graph's engine went back
+    # fetched -> the first graph's engine went back (the second graph has taken it from the pool or it waits there)
+    assert rt.device_source() is None and len(held._leases) == 0 and not held._pool_when_free
     for g in (gd, g2d, g2t):
         g.close()
+    import weakref
+    probe = weakref.ref(g2t)
+    del g2t, g2d, gd, gt, r2t, p2t, rt, pt, g
+    assert probe() is None   # freed by reference counting: a graph in a cycle would take its engine to the collector
