@@ -724,10 +724,9 @@ static const unsigned int kProbeLimitX = 1024;
 // included: the keys that almost every later window hits then hold the lowest claims in stream order, which is what
 // the counting sweeps and the rank bitmaps like (measured on the cleaning sweep: 8.8 -> 8.5 ms against head launches
 // for first builds only; 48 / 64 / 96 / 128 / 156 / 256 / 512 tiles: 9.27 / 9.02 / 8.69 / 8.62 / 8.46 / 8.70 / 8.84 ms).
-static long long head_tiles(const amg_ctx* c, long long n_tiles, long long expected_keys) {
+static long long head_tiles(const amg_ctx* c, long long n_tiles) {
   const char* e = getenv("AMG_X_HEAD_TILES");  // A/B switch
   if (e) return atoll(e) < n_tiles ? atoll(e) : n_tiles;
-  (void)expected_keys;
   if (n_tiles < 4096) return 0;
   long long h = 4ll * c->two_v / TILE;
   if (h < 64) h = 64;
@@ -815,7 +814,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
     hipMemsetAsync(p, 0, 64 * 16 * 8, st);
   }
 #endif
-  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles, 0) > 0) ? "node_upsert_head" : "node_upsert");
+  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles) > 0) ? "node_upsert_head" : "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
     if (getenv("AMG_X_OLD_PASS")) {  // A/B switch: one window per lane, strided (the round-1 kernel)
@@ -850,7 +849,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
       // get claims scattered over the first few hundred thousand, and whoever counts by claim (k_count_ids, one
       // LDS range of 32 k ids per sweep) needs several sweeps.  A short head launch over the first few genome
       // coverages creates them first: their claims are then the lowest.
-      const long long head = head_tiles(c, n_tiles, c->node_hint > 0 ? c->node_hint : T / 8);
+      const long long head = head_tiles(c, n_tiles);
       for (int part = 0; part < 2; ++part) {
         const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
         if (cnt <= 0) continue;
@@ -1014,7 +1013,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
   stage_end(c);
   const char* abl = getenv("AMG_X_ABLATE");
   const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
-  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles, D) > 0) ? "edge_upsert_head" : "edge_upsert");
+  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles) > 0) ? "edge_upsert_head" : "edge_upsert");
   if (n_tiles > 0 && getenv("AMG_X_OLD_PASS"))  // A/B switch: one adjacency per lane, strided (the round-1 kernel)
     hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                        c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
@@ -1023,7 +1022,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
                        c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate,
                        xw2_for(max_claims, T));
   else if (n_tiles > 0) {
-    const long long head = head_tiles(c, n_tiles, D);  // (see bx_nodes_upsert: the genome's classes get the lowest claims)
+    const long long head = head_tiles(c, n_tiles);  // (see bx_nodes_upsert: the genome's classes get the lowest claims)
     for (int part = 0; part < 2; ++part) {
       const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
       if (cnt <= 0) continue;
