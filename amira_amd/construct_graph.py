@@ -159,7 +159,7 @@ class _GraphNode(Node):
     @property
     def forwardEdgeHashes(self):
         if self._fw is None:
-            self._fw = self._fw_maker()
+            self._fw = self._fw_maker() if self._fw_maker else []   # (no maker: the graph was closed)
         return self._fw
 
     @forwardEdgeHashes.setter
@@ -169,7 +169,7 @@ class _GraphNode(Node):
     @property
     def backwardEdgeHashes(self):
         if self._bw is None:
-            self._bw = self._bw_maker()
+            self._bw = self._bw_maker() if self._bw_maker else []
         return self._bw
 
     @backwardEdgeHashes.setter
@@ -215,6 +215,16 @@ class _View:
                  "_edges", "_edges_complete", "_edge_obj", "_make_edge", "_n_edges", "readNodes",
                  "readNodeDirections", "readNodePositions", "node_hash", "edge_hash", "alive", "arrays",
                  "_nh_table")
+
+    def dispose(self):
+        """cut the view's own reference cycles (its makers close over it) so that it is freed the moment its graph lets
+        go of it, not when the cyclic collector next walks the heap; called when the graph is closed"""
+        self._make_node = self._make_edge = self.node_of_hash = None
+        self.readNodes = self.readNodeDirections = self.readNodePositions = None
+        for node in self._node_obj:
+            if node is not None:
+                node._reads_maker = node._fw_maker = node._bw_maker = None
+        self._node_obj, self._edge_obj = [], []
 
     # ---- nodes
     def node_at(self, i):
@@ -466,7 +476,9 @@ class GeneMerGraph(BubblePopping):
 
     def close(self):
         """hand the device engine back (the graph can no longer be queried); also done when the object dies"""
-        self._view = None
+        view, self._view = getattr(self, "_view", None), None
+        if view is not None:
+            view.dispose()
         owner, self._reads_owner = getattr(self, "_reads_owner", None), None
         if getattr(self, "_borrowers", 0) > 0:   # graphs of build_many still read this one's device arrays
             self._close_pending = True
