@@ -1923,6 +1923,7 @@ class GeneMerGraph(BubblePopping):
             cache.setdefault(rid, lst)
         seqs += [seqs[i][::-1] for i in late.tolist()]
         to_id = v.node_of_hash
+        self._tree_rows = rows
         return Tree.from_flat(keys, seqs, flat, all_starts, lambda x: -2 if x is None else to_id.get(x))
 
     def _assign_reads_to_genes(self, listOfGenes, cores, allele_counts, mean_node_coverage):
@@ -1940,6 +1941,15 @@ class GeneMerGraph(BubblePopping):
             # keys are enough and no read is decoded into strings)
             gene_call_subset = dict.fromkeys(reads_with_gene)
             gene_call_subset.update(dict.fromkeys([r + "_reverse" for r in reads_with_gene]))
+            known = getattr(self, "_tree_rows", None)
+            if (known is not None and len(known) == len(reads_with_gene) and isinstance(self._reads, TokenizedReads)
+                    and not self._reads.any_name_ends_with("_reverse")):
+                # which rows count for get_all_sublists: the rows of these reads, already known from the tree (the
+                # "<read>_reverse" keys name no read of their own)
+                in_subset = np.zeros(len(self._read_ids) + 1, bool)
+                in_subset[known] = True
+                self._subset_rows_memo = (gene_call_subset, len(gene_call_subset), in_subset)
+            self._tree_rows = None
             paths, coverages = self.get_paths_for_gene(node_tree, gene_call_subset, hashes,
                                                        mean_node_coverage / 20, geneOfInterest, cores)
             alleles, path_reads = self.split_into_subpaths(geneOfInterest, paths, coverages, path_reads,

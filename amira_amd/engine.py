@@ -161,11 +161,11 @@ class Engine:
     def node_reads(self):
         D = self.graph_sizes()[0]
         off = np.empty(D + 1, np.int64)
-        check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), None))
-        idx = np.empty(int(off[-1]) if D else 0, np.int32)
-        if len(idx):
-            check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), ptr(idx)))
-        return off, idx
+        # one call: the list cannot be longer than the windows of the read set (the pages of the buffer that are never
+        # written are never touched); the two-call spelling of the C ABI builds the lists twice
+        idx = np.empty(max(self.sizes()[1], 1), np.int32)
+        check(_ffi.lib.amg_get_node_reads(self._h, ptr(off), ptr(idx)))
+        return off, idx[:int(off[-1]) if D else 0]
 
     def reads_to_correct(self):
         f = np.empty(self.sizes()[0], np.uint8)

@@ -87,6 +87,14 @@ class TokenizedReads(Mapping):
             self._index = dict(zip(self.read_ids, range(len(self.read_ids))))
         return self._index
 
+    def any_name_ends_with(self, suffix):
+        """is there a read whose name ends with `suffix`?  (asked once per mapping: read-path clustering names the
+        reverse complement of read r "r_reverse", and a read really called that would count twice)"""
+        memo = self.__dict__.setdefault("_suffix_memo", {})
+        if suffix not in memo:
+            memo[suffix] = any(r.endswith(suffix) for r in self.read_ids)
+        return memo[suffix]
+
     def __getitem__(self, read_id):
         got = self._cache.get(read_id)
         if got is None:
