@@ -140,33 +140,60 @@ class _ScanTree:
         sub._flat = self._flat[np.repeat(ends - 1, lens) - within]
         return sub
 
-    def find_all(self, query):
+    def _hits(self, query):
+        """(positions in the code array, rows) of the occurrences of `query`, in key order then position"""
         np = self._np
-        query = list(query)
         m = len(query)
         if m == 0 or len(self._flat) == 0:
-            return []
+            return None
         codes = self._codes_of(query)
         if codes is None:   # an item no sequence holds
-            return []
+            return None
         flat, starts = self._flat, self._starts
         at = np.flatnonzero(flat == codes[0])
         if len(at) == 0:
-            return []
+            return None
         row = np.searchsorted(starts, at, side="right") - 1
         ok = at + m <= starts[row + 1]          # the match must end inside its own sequence
         at, row = at[ok], row[ok]
         for j in range(1, m):
             if len(at) == 0:
-                return []
+                return None
             keep = flat[at + j] == codes[j]
             at, row = at[keep], row[keep]
-        begin = (at - starts[row]).tolist()
+        return at, row
+
+    def find_all(self, query):
+        hits = self._hits(list(query))
+        if hits is None:
+            return []
+        at, row = hits
+        begin = (at - self._starts[row]).tolist()
         keys, seqs = self._keys, self._seqs
         if isinstance(seqs, _ReversedSuffixes):
             cut = seqs.suffix
             return [(keys[r], _Suffix(cut(r, i))) for r, i in zip(row.tolist(), begin)]
         return [(keys[r], _Suffix(seqs[r][i:])) for r, i in zip(row.tolist(), begin)]
+
+    def find_all_coded(self, query):
+        """find_all for callers that see the same suffix over and over (thousands of reads run through one block):
+        (keys, codes, items_of) — per hit its key and the integer codes of its suffix as bytes (equal codes <=> equal
+        items), and items_of(j), which cuts the item list of hit j only when asked"""
+        hits = self._hits(list(query))
+        if hits is None:
+            return [], [], None
+        at, row = hits
+        starts, flat = self._starts, self._flat
+        rows = row.tolist()
+        begin = (at - starts[row]).tolist()
+        codes = [flat[a:e].tobytes() for a, e in zip(at.tolist(), starts[row + 1].tolist())]
+        keys, seqs = self._keys, self._seqs
+        if isinstance(seqs, _ReversedSuffixes):
+            cut = seqs.suffix
+            items_of = lambda j: cut(rows[j], begin[j])   # noqa: E731
+        else:
+            items_of = lambda j: seqs[rows[j]][begin[j]:]   # noqa: E731
+        return [keys[r] for r in rows], codes, items_of
 
 
 Tree = _ExternalTree or _ScanTree
@@ -256,6 +283,31 @@ def get_suffixes_from_initial_tree(tree, a1):
 
 def get_blocks_from_subtree(sub_tree, a2, nodeAnchors):
     block_reads, block_duplicates = {}, {}
+    coded = getattr(sub_tree, "find_all_coded", None)
+    if coded is not None:
+        # the same block comes from thousands of reads: its list, its reversal and its canonical tuple are made for
+        # the first of them and SHARED by the rest (nobody writes to a block list) — which assignment happens for
+        # which read, and in which order the dicts are filled, stays as in the loop below
+        keys, codes, items_of = coded([a2])
+        seen = {}   # codes of a suffix -> its block (the suffix back to front), None: the suffix starts with None
+        for j, read_id in enumerate(keys):
+            cb = codes[j]
+            if cb in seen:
+                block = seen[cb]
+            else:
+                nodes = items_of(j)
+                if nodes[0] is None:
+                    block = seen[cb] = None
+                else:
+                    assert nodes[0] in nodeAnchors and nodes[-1] in nodeAnchors
+                    block = seen[cb] = nodes[::-1]
+                    block_duplicates[tuple(sorted([nodes, block])[0])] = False
+            if block is None:
+                continue
+            if "_reverse" not in read_id:
+                if read_id not in block_reads or len(block) > len(block_reads[read_id]):
+                    block_reads[read_id] = block
+        return block_reads, block_duplicates
     for read_id, path in sub_tree.find_all([a2]):
         nodes = _suffix_ints(path)
         if nodes is None:
@@ -318,16 +370,22 @@ def generate_contexts(block_reads, block_duplicates, reads):
         clustering that follows)."""
     contexts = {}
     todo = {}  # key -> [(read_id, where, is_canonical), ...] in read order
-    for read_id, block in block_reads.items():
+    per_block = {}   # id(block list) -> [key, is_canonical, its todo list]: the reads through one block share ONE list
+    for read_id, block in block_reads.items():   # (get_blocks_from_subtree), so canonical form and key are made once
         on_read = reads[read_id]
         where = find_sublist_indices(on_read, block)
         assert len(where) > 0
-        canonical = get_canonical_representation(block)
-        key = tuple(canonical)
+        rec = per_block.get(id(block))
+        if rec is None:
+            canonical = get_canonical_representation(block)
+            rec = per_block[id(block)] = [tuple(canonical), canonical == block, None]
+        key = rec[0]
         update_duplicates(block_duplicates, key, where)
         if len(where) == 1:
-            contexts.setdefault(key, {"upstream": set(), "downstream": set()})   # dict order = first read
-            todo.setdefault(key, []).append((read_id, where, canonical == block))
+            if rec[2] is None:
+                contexts.setdefault(key, {"upstream": set(), "downstream": set()})   # dict order = first read
+                rec[2] = todo.setdefault(key, [])
+            rec[2].append((read_id, where, rec[1]))
     up_cache, down_cache = {}, {}
     for key, entries in todo.items():
         first = 0
