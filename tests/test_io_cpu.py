@@ -58,3 +58,13 @@ def test_read_lengths():
     assert rl.lengths_array(["c", "x", "a"]).tolist() == [7, 0, 5]
     assert rl.lengths_array(["c", "a"], rows_hint=np.array([2, 0])).tolist() == [7, 5]
     assert rl.lengths_array(["c", "a"], rows_hint=np.array([1, 0])).tolist() == [7, 5]   # a wrong hint is not trusted
+
+
+def test_names_ending_with_a_suffix():
+    _, ids, tr, _ = _mappings()
+    assert not tr.any_name_ends_with("_reverse")
+    vocab = tr.vocab
+    other = TokenizedReads(vocab, np.zeros(0, np.int32), np.zeros(4, np.int64), ["a", "b_reverse", "c"])
+    assert other.any_name_ends_with("_reverse") and not other.any_name_ends_with("_reversed")
+    inner = TokenizedReads(vocab, np.zeros(0, np.int32), np.zeros(3, np.int64), ["a_reverse_b", "c"])
+    assert not inner.any_name_ends_with("_reverse")
