@@ -213,7 +213,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
         continue;
       }
       idx[w] = (unsigned int)mix64(w1[w] ^ ((unsigned long long)tag[w] * 0x9E3779B97F4A7C15ull)) & mask;
-#ifndef AMG_ABLATE_NOPROBE
+#if defined(AMG_ABLATE_PREDICT)
+      // timing experiment (tools/predict_probe.sh): what would the pass cost if the windows after a thread's first
+      // found their key through a dense, id-ordered array (lanes 4 entries apart, a thread's entries adjacent)
+      // instead of a hashed slot?  Windows 1..3 load from consecutive slots and "find" their key; no graph.
+      v[w] = *reinterpret_cast<const ulonglong2*>(tab + (w == 0 ? idx[w] : (((unsigned int)(t0 + i0) + (unsigned int)w) & 0xffffu)));
+#elif !defined(AMG_ABLATE_NOPROBE)
       v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
 #endif
       if (dir < 0) ndir |= 1u << w;

@@ -345,6 +345,10 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     if (!(valid & (1u << it))) continue;
 #ifdef AMG_ABLATE_NOPROBE  // timing experiment (tools/noprobe_probe.sh): every window "finds" its key; no graph
     const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx[it] & 1023ull));
+#elif defined(AMG_ABLATE_PREDICT)  // (tools/predict_probe.sh) windows 1..3 of a node-pass thread "find" theirs; the load is consumed
+    const unsigned long long c1 = (it == 0 || which != 1) ? v[it].x : w1[it],
+                             c2 = (it == 0 || which != 1) ? v[it].y
+                                                          : (((unsigned long long)tag[it] << 32) | (1ull + ((idx[it] ^ v[it].x ^ v[it].y) & 1023ull)));
 #else
     const unsigned long long c1 = v[it].x, c2 = v[it].y;
 #endif
