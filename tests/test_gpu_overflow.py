@@ -86,3 +86,30 @@ def test_malformed_device_csr_is_refused(monkeypatch, key_mode, damage):
         assert eng.counts()["n_nodes"] > 0
     finally:
         eng.close()
+
+
+def test_hashed_edge_region_overflow_is_rebuilt():
+    """The edge table keeps the class joining node ids n and n + 1 in slot n and sizes its HASHED region for the rest
+    to a quarter of the nodes.  A dense graph over a tiny vocabulary (a few thousand nodes, tens of thousands of edge
+    classes, hardly any of them between consecutive ids) overflows that region: the build must grow it and still
+    equal the sequential C oracle."""
+    import token_oracle
+    from amira_amd import Engine
+    from helpers import compare_engine_to_sweep
+    rng = np.random.default_rng(11)
+    V, L, N, k = 10, 30, 20000, 3
+    genes = rng.integers(0, V, (N, L))
+    strands = rng.integers(0, 2, (N, L))
+    toks = np.where(strands == 1, V + genes, V - 1 - genes).astype(np.int32).ravel()
+    offs = np.arange(0, (N + 1) * L, L, dtype=np.int64)
+    eng, orc = Engine(0), token_oracle.Sweep(toks, offs, 2 * V)
+    try:
+        eng.set_reads(toks, offs, 2 * V)
+        eng.build(k)   # (an odd k has no palindromes)
+        orc.build(k)
+        c = eng.counts()
+        assert c["n_edges"] > 8 * c["n_nodes"] and c["build_retries"] >= 1
+        compare_engine_to_sweep(eng, orc, "dense graph")
+    finally:
+        eng.close()
+        orc.close()
