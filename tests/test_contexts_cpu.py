@@ -125,3 +125,41 @@ def test_anchor_blocks_equal_the_reference_procedure():
             assert got == want, fast
         compared += len(want)
     assert compared > 500
+
+
+def test_blocks_from_coded_hits_equal_the_plain_loop():
+    """get_blocks_from_subtree over find_all_coded (one shared block list per distinct suffix, found again through the
+    integer codes) against the hit-by-hit loop over find_all: same block per read, same duplicates dict, same orders;
+    and generate_contexts gives the same contexts whether the reads of a block share its list or not"""
+    import random
+    from amira_amd import path_finding_utils as pf
+
+    class Plain(pf._ScanTree):
+        find_all_coded = None   # hides the coded search: get_blocks_from_subtree takes the plain loop
+
+    rng = random.Random(5)
+    big = [10 ** 40 + i for i in range(7)]
+    for _ in range(300):
+        reads = {}
+        for i in range(rng.randint(1, 9)):
+            seq = [rng.choice(big + [None]) for _ in range(rng.randint(1, 10))]
+            reads[f"r{i}"] = seq
+        data = dict(reads)
+        data.update({r + "_reverse": s[::-1] for r, s in reads.items() if len(set(s)) > 1})
+        a1, a2 = rng.choice(big), rng.choice(big)
+        if a1 == a2:
+            continue
+        anchors = [x for x in big]
+        got_tree, want_tree = pf._ScanTree(data), Plain(data)
+        sub_got, sub_want = got_tree.reversed_suffix_tree(a1), want_tree.reversed_suffix_tree(a1)
+        sub_want.__class__ = Plain
+        got = pf.get_blocks_from_subtree(sub_got, a2, anchors)
+        want = pf.get_blocks_from_subtree(sub_want, a2, anchors)
+        assert list(got[0].items()) == list(want[0].items()) and list(got[1].items()) == list(want[1].items())
+        lists = {r: list(s) for r, s in data.items()}
+        c_got = pf.generate_contexts(got[0], dict(got[1]), lists)
+        c_want = pf.generate_contexts(want[0], dict(want[1]), lists)
+        assert list(c_got) == list(c_want)
+        for key in c_want:
+            for side in ("upstream", "downstream"):
+                assert list(c_got[key][side]) == list(c_want[key][side])   # same elements in the same iteration order
