@@ -221,8 +221,8 @@ class _View:
         go of it, not when the cyclic collector next walks the heap; called when the graph is closed"""
         self._make_node = self._make_edge = self.node_of_hash = None
         self.readNodes = self.readNodeDirections = self.readNodePositions = None
-        for node in self._node_obj:
-            if node is not None:
+        for node in self._nodes.values():   # (the nodes made so far)
+            if isinstance(node, _GraphNode):
                 node._reads_maker = node._fw_maker = node._bw_maker = None
         self._node_obj, self._edge_obj = [], []
 
