@@ -424,6 +424,10 @@ CASES["sweep_dense_k5"] = (p_sweep, (17, 800, 40, 150, 5, 0.05), False)
 CASES["sweep_r2_k5_err6"] = (p_sweep, (23, 600, 35, 120, 5, 0.06), False)
 CASES["sweep_r2_k3_err4"] = (p_sweep, (29, 500, 28, 400, 3, 0.04), False)
 CASES["sweep_r2_k7_err3"] = (p_sweep, (41, 350, 50, 90, 7, 0.03), False)
+# round 3 (home slots of the edge pass): small genomes read many times over — loop closures, repeats of short
+# gene-mers and errors give many adjacencies that do NOT join consecutive node ids
+CASES["sweep_r3_k3_v40"] = (p_sweep, (53, 500, 30, 40, 3, 0.04), False)
+CASES["sweep_r3_k5_v60"] = (p_sweep, (59, 400, 45, 60, 5, 0.05), False)
 CASES["misc_nine_k3"] = (p_misc_passes, ("nine", 3), False)
 CASES["misc_four_k5"] = (p_misc_passes, ("four", 5), False)
 CASES["misc_five_k3"] = (p_misc_passes, ("five", 3), False)
