@@ -68,3 +68,38 @@ def test_names_ending_with_a_suffix():
     assert other.any_name_ends_with("_reverse") and not other.any_name_ends_with("_reversed")
     inner = TokenizedReads(vocab, np.zeros(0, np.int32), np.zeros(3, np.int64), ["a_reverse_b", "c"])
     assert not inner.any_name_ends_with("_reverse")
+
+
+def test_engine_leases_and_pool():
+    """an engine whose buffers still hold the output of a correct_reads stays out of the pool until the last such output
+    has been fetched or dropped (amira_amd.engine.release_engine / lease_done; no device needed for the bookkeeping)"""
+    import weakref
+    from amira_amd import engine as E
+    from amira_amd.io import DeviceCorrected
+
+    class FakeEngine:
+        def __init__(self):
+            self._h, self.device = True, 97
+            self._leases, self._pool_when_free = weakref.WeakSet(), False
+            self.fetched = 0
+
+        def corrected(self, n_reads, n_tokens, have_pos):
+            self.fetched += 1
+            z = np.zeros(n_tokens, np.int64)
+            return {"tokens": z.astype(np.int32), "gene_start": z, "gene_end": z}
+
+    pool = E._ENGINE_POOL.setdefault(97, [])
+    del pool[:]
+    eng = FakeEngine()
+    a, b = DeviceCorrected(eng, 2, 5, True), DeviceCorrected(eng, 2, 5, True)
+    E.release_engine(eng)                       # the graph lets go: two outputs still live in the buffers
+    assert pool == [] and eng._pool_when_free
+    assert a.fetch()["tokens"].shape == (5,) and a.engine() is None and eng.fetched == 1
+    a.fetch()
+    assert eng.fetched == 1 and pool == []      # fetched once; the other output still holds the engine
+    del b                                       # dropped without being read
+    assert pool == [eng] and not eng._pool_when_free
+    assert E.acquire_engine(97) is eng and pool == []
+    E.release_engine(eng)                       # no leases: back at once
+    assert pool == [eng]
+    del pool[:]
