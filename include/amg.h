@@ -73,7 +73,7 @@ typedef struct amg_counts_t {
   int64_t n_live_edges;
   int64_t n_reads_to_correct;
   int64_t node_table_slots;
-  int64_t edge_table_slots;
+  int64_t edge_table_slots;  /* hashed slots (exact keys: one directly addressed slot per node id on top)   */
   int64_t build_retries;  /* table growth / fingerprint-collision rebuilds             */
   int32_t k;
   int32_t two_v;
