@@ -98,3 +98,20 @@ def test_block_generator_matches_read_ranges_and_loop_generator_known_answer():
     assert len(reads) == 50 and all(len(v) == 40 for v in reads.values())
     assert synth.positions_for(reads)["r0000000"][1] == [1000, 1899]
     assert synth.fake_fastq_lengths(reads)["r0000000"] == 40100
+
+
+def test_lazy_clip_hashes_behave_like_the_list():
+    """remove_short_linear_paths with array-backed inputs returns its node hashes as a sequence that computes them when
+    looked at: length without hashing, then list semantics (iteration, indexing, equality, sorted)"""
+    import numpy as np
+    from amira_amd.construct_gene import hashlib_hash
+    from amira_amd.construct_graph import _LazyHashes
+    from amira_amd.tokens import Vocabulary
+    vocab = Vocabulary([f"g{i}" for i in range(9)])
+    rows = np.array([[9, 10, 11], [8, 7, 6], [12, 3, 14]], np.int32)
+    want = [hashlib_hash(tuple(vocab.signed_hash(int(t)) for t in row)) for row in rows]
+    lazy = _LazyHashes(rows, vocab)
+    assert len(lazy) == 3 and lazy._made is None          # nothing hashed yet
+    assert list(lazy) == want and lazy[1] == want[1] and lazy == want and sorted(lazy) == sorted(want)
+    assert want[2] in lazy and lazy == _LazyHashes(rows.copy(), vocab)
+    assert len(_LazyHashes(rows[:0], vocab)) == 0 and list(_LazyHashes(rows[:0], vocab)) == []
