@@ -133,6 +133,11 @@ class _LazyHashes(Sequence):
         return repr(self._list())
 
 
+def _graph_closed():
+    raise RuntimeError("this Node's lists were never looked at while its GeneMerGraph was open, and the graph has been "
+                       "closed (its device arrays are gone); read them before close() or keep the graph")
+
+
 class _GraphNode(Node):
     """Node view whose read list is cut out of the device's node->reads CSR on first use."""
 
@@ -159,7 +164,7 @@ class _GraphNode(Node):
     @property
     def forwardEdgeHashes(self):
         if self._fw is None:
-            self._fw = self._fw_maker() if self._fw_maker else []   # (no maker: the graph was closed)
+            self._fw = self._fw_maker() if self._fw_maker else []   # (no maker: a node made by hand, add_node)
         return self._fw
 
     @forwardEdgeHashes.setter
@@ -223,7 +228,9 @@ class _View:
         self.readNodes = self.readNodeDirections = self.readNodePositions = None
         for node in self._nodes.values():   # (the nodes made so far)
             if isinstance(node, _GraphNode):
-                node._reads_maker = node._fw_maker = node._bw_maker = None
+                # lists that were looked at stay as they are; the others can no longer be made: say so instead of
+                # answering with an empty list
+                node._reads_maker = node._fw_maker = node._bw_maker = _graph_closed
         self._node_obj, self._edge_obj = [], []
 
     # ---- nodes
@@ -506,6 +513,15 @@ class GeneMerGraph(BubblePopping):
     def _invalidate(self):
         self._view = None
 
+    def _settle_leases(self):
+        """What an earlier correct_reads of this graph left on the device (amira_amd.io.DeviceCorrected: the lazy
+        mappings it handed back) is brought to the host before a pass that changes the graph: every such pass
+        invalidates the engine's corrected set (amg_filter, amg_remove_nodes, amg_remove_short_linear_paths,
+        amg_remove_low_coverage_components, amg_correct_reads), and the mappings must keep answering afterwards as
+        the reference's dicts do."""
+        for lease in list(self._engine._leases):
+            lease.fetch()
+
     def _device_pass(self, what):
         """The incremental mutators of the reference class (add_node, add_edge, remove_edge,
         remove_node_from_reads, ... — used by its unit tests and its multi-process merge) edit the
@@ -513,6 +529,7 @@ class GeneMerGraph(BubblePopping):
         if self._host_edits:
             raise RuntimeError(f"{what}: this graph was edited through add_node / add_edge / remove_edge on the "
                                "host; build a GeneMerGraph from reads to run device passes")
+        self._settle_leases()
 
     def _gene_obj(self, token):
         g = self._gene_cache.get(token)
@@ -911,11 +928,14 @@ class GeneMerGraph(BubblePopping):
                     self.remove_edge(e)
             del self.get_nodes()[h]
             return
-        self._engine.remove_nodes([self._node_id(h)])
+        i = self._node_id(h)
+        self._settle_leases()
+        self._engine.remove_nodes([i])
         self._invalidate()
 
     def _remove_node_ids(self, ids):
         if len(ids):
+            self._settle_leases()
             self._engine.remove_nodes(np.asarray(ids, dtype=np.int32))
             self._invalidate()
 
@@ -947,8 +967,10 @@ class GeneMerGraph(BubblePopping):
         self._engine.remove_low_coverage_components(max(int(min_component_coverage), 0))
         self._invalidate()
 
-    def remove_short_linear_paths(self, min_length, sample_genesOfInterest={}):
-        """tip clipping on the device (:679-720); returns the hashes of the removed nodes."""
+    def remove_short_linear_paths(self, min_length, sample_genesOfInterest={}, _lazy_hashes=False):
+        """tip clipping on the device (:679-720); returns the hashes of the removed nodes (a list, as the reference
+        does; _lazy_hashes: the drivers of graph_utils, which ignore the result, ask for a Sequence whose hashes are
+        only made when somebody looks at them)."""
         self._device_pass("remove_short_linear_paths")
         protect = None
         if sample_genesOfInterest:
@@ -961,9 +983,9 @@ class GeneMerGraph(BubblePopping):
         removed = self._engine.remove_short_linear_paths(int(min_length), protect)
         if v is not None:
             hashes = [v.hash_at(i) for i in removed.tolist()]
-        elif isinstance(self._reads, TokenizedReads):
-            # array-backed inputs (the drivers, which ignore the result): the hashes — a sha256 per removed node, tens
-            # of thousands of them in a first sweep — are made when somebody looks at them
+        elif _lazy_hashes:
+            # (the drivers, which ignore the result): the hashes — a sha256 per removed node, tens of thousands of
+            # them in a first sweep — are made when somebody looks at them
             hashes = _LazyHashes(tokens[removed], self._vocab)
         else:
             hashes = [self._hash_of_tokens(tokens[i].tolist()) for i in removed.tolist()]
@@ -1041,7 +1063,8 @@ class GeneMerGraph(BubblePopping):
         if self._positions_pending:   # a graph of build_many: its engine has not seen the positions yet
             self._upload_positions()
         if have_pos and hasattr(fastq_data, "lengths_array"):   # amira_amd.io.ReadLengths: no per-read loop
-            eng.set_read_lengths(fastq_data.lengths_array(self._read_ids, getattr(self._reads, "source_rows", None)))
+            eng.set_read_lengths(fastq_data.lengths_array(self._read_ids, getattr(self._reads, "source_rows", None),
+                                                          getattr(self._reads, "source_ids", None)))
         elif have_pos:
             flags = eng.reads_to_correct()
             lengths = np.zeros(len(self._read_ids), np.int64)
@@ -1051,9 +1074,7 @@ class GeneMerGraph(BubblePopping):
                 except (KeyError, TypeError, IndexError):
                     lengths[r] = 0
             eng.set_read_lengths(lengths)
-        for lease in list(eng._leases):   # an earlier correction's output still on the device: about to be overwritten
-            lease.fetch()
-        n_reads, n_tokens = eng.correct_reads()
+        n_reads, n_tokens = eng.correct_reads()   # (an earlier correction's output was fetched by _device_pass)
         if self._tokenized_io(have_pos):
             return self._corrected_as_arrays(eng.corrected_index(n_reads), n_reads, n_tokens, have_pos)
         out = eng.corrected(n_reads, n_tokens, have_pos)
@@ -1095,7 +1116,8 @@ class GeneMerGraph(BubblePopping):
         src = getattr(self._reads, "source_rows", None)
         on_device = DeviceCorrected(self._engine, n_reads, n_tokens, have_pos)
         reads = TokenizedReads(self._vocab, on_device, offs, ids,
-                               source_rows=orig.astype(np.int64) if src is None else src[orig])
+                               source_rows=orig.astype(np.int64) if src is None else src[orig],
+                               source_ids=self._reads.read_ids if src is None else self._reads.source_ids)
         if not have_pos:
             return reads, {}
         positions = TokenizedPositions(ids, offs, on_device, on_device)
@@ -1790,7 +1812,7 @@ class GeneMerGraph(BubblePopping):
                 path_reads.setdefault(named, set()).update(rids)
             pos = self._genePositions
             if (fw_idx and rids and isinstance(self._reads, TokenizedReads) and isinstance(pos, TokenizedPositions)
-                    and not pos._cache and self._gs is not None):
+                    and not pos._cache and pos._moved is None and self._gs is not None):
                 # tokenised containers: the genes and positions of all chosen reads come out of the flat arrays
                 # at once (one entry per read and allele, appended in read order as the loop below does)
                 V = max(self._vocab.V, 1)

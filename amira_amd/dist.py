@@ -218,8 +218,13 @@ def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchan
                         exchange_a2a(dummy, [code] * world, 1, group)
                     else:
                         exchange_ag(dummy, code, 1, group)
-                except PeerFailed:
-                    pass
+                except PeerFailed as seen:
+                    # What every rank saw in this hand-shake decides what every rank does next: retry only when ALL
+                    # the failures were collisions.  A local collision next to another rank's fatal error must not
+                    # send this rank into a retry that nobody else joins (it would wait in the next all-gather for
+                    # ever): the peers' verdict replaces the local one.
+                    if code == -2 and not seen.retry:
+                        raise seen from err
             raise
         op = req[0]
         if not exchange:   # one rank: nothing travels

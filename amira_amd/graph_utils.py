@@ -108,7 +108,7 @@ def cleaning_sweep(reads, gene_positions, geneMer_size, fastq_content, node_min_
     graph = build_filtered_graph(_own(reads), geneMer_size, _own(gene_positions), node_min_coverage, 1)
     reads, gene_positions = graph.correct_reads(fastq_content)
     graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
-    graph.remove_short_linear_paths(geneMer_size)
+    graph.remove_short_linear_paths(geneMer_size, _lazy_hashes=True)
     reads, gene_positions = graph.correct_reads(fastq_content)
     graph = build_multiprocessed_graph(reads, geneMer_size, 1, gene_positions)
     return graph, reads, gene_positions
@@ -135,7 +135,7 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
         sys.stderr.write("\n\tAmira: removing dead ends\n")
         short_reads.update(graph.get_short_read_annotations())
         short_read_gene_positions.update(graph.get_short_read_gene_positions())
-        graph.remove_short_linear_paths(geneMer_size)
+        graph.remove_short_linear_paths(geneMer_size, _lazy_hashes=True)
         new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
         graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
         short_reads.update(graph.get_short_read_annotations())

@@ -62,12 +62,14 @@ def _gather_rows(offsets, rows):
 class TokenizedReads(Mapping):
     """{read id: ["+geneA", ...]} backed by CSR token arrays (lists are decoded on access)."""
 
-    def __init__(self, vocab, tokens, read_offsets, read_ids, source_rows=None):
+    def __init__(self, vocab, tokens, read_offsets, read_ids, source_rows=None, source_ids=None):
         # tokens: an int32 array, or a DeviceCorrected (the genes are still on the device: see the property)
         self.vocab, self._tokens, self.read_offsets, self.read_ids = vocab, tokens, read_offsets, read_ids
         # where these reads sat in the read list they descend from (correct_reads drops reads and keeps the order):
-        # lets array-backed side tables (ReadLengths) follow without a lookup per read; None = they are that list
+        # lets array-backed side tables (ReadLengths) follow without a lookup per read; None = they are that list.
+        # source_ids: that list itself (the object), so that a side table can tell whether the rows are ITS rows
         self.source_rows = source_rows
+        self.source_ids = source_ids if source_rows is not None else None
         self._index = None   # built on the first lookup by name (a million reads: ~0.2 s)
         self._cache = {}
 
@@ -111,7 +113,8 @@ class TokenizedReads(Mapping):
         idx, new_off = _gather_rows(self.read_offsets, rows)
         ids = np.asarray(self.read_ids, dtype=object)[rows].tolist()
         src = rows if self.source_rows is None else self.source_rows[rows]
-        return TokenizedReads(self.vocab, self.tokens[idx], new_off, ids, source_rows=src)
+        return TokenizedReads(self.vocab, self.tokens[idx], new_off, ids, source_rows=src,
+                              source_ids=self.read_ids if self.source_rows is None else self.source_ids)
 
     def gene_at(self, read_id, i):
         """self[read_id][i] without decoding the rest of the read"""
@@ -284,16 +287,25 @@ class ReadLengths(Mapping):
     def __len__(self):
         return len(self.read_ids)
 
-    def lengths_array(self, read_ids, rows_hint=None):
-        """lengths of `read_ids` in that order (0 for a read this mapping does not know); rows_hint: where the
-        caller believes these reads sit in this mapping (TokenizedReads.source_rows), checked at both ends"""
-        if (rows_hint is not None and len(rows_hint) == len(read_ids) and len(read_ids) > 0
-                and int(rows_hint[-1]) < len(self.read_ids) and self.read_ids[int(rows_hint[0])] == read_ids[0]
-                and self.read_ids[int(rows_hint[-1])] == read_ids[-1]):
-            return self.lengths[rows_hint]
-        if read_ids is self.read_ids or (len(read_ids) == len(self.read_ids) and len(read_ids) > 0 and
-                                         read_ids[0] == self.read_ids[0] and read_ids[-1] == self.read_ids[-1]
-                                         and read_ids == self.read_ids):
+    def lengths_array(self, read_ids, rows_hint=None, hint_ids=None):
+        """lengths of `read_ids` in that order (0 for a read this mapping does not know).  rows_hint: where the
+        caller believes these reads sit in the read list `hint_ids` (TokenizedReads.source_rows / source_ids).  The
+        hint is taken as it is when that list IS this mapping's list (same object) and the rows are in range;
+        otherwise only after every row has been checked against the names."""
+        if read_ids is self.read_ids:
+            return self.lengths
+        if rows_hint is not None and len(rows_hint) == len(read_ids) and len(read_ids) > 0:
+            rows = np.asarray(rows_hint, dtype=np.int64)
+            if int(rows.min()) >= 0 and int(rows.max()) < len(self.read_ids):
+                if hint_ids is not None and hint_ids is self.read_ids:
+                    return self.lengths[rows]
+                mine = self.__dict__.get("_ids_arr")
+                if mine is None:
+                    mine = self._ids_arr = np.asarray(self.read_ids, dtype=object)
+                if np.array_equal(mine[rows], np.asarray(read_ids, dtype=object)):
+                    return self.lengths[rows]
+        if len(read_ids) == len(self.read_ids) and len(read_ids) > 0 and read_ids[0] == self.read_ids[0] \
+                and read_ids[-1] == self.read_ids[-1] and read_ids == self.read_ids:
             return self.lengths
         idx = self._idx()
         rows = np.fromiter((idx.get(r, -1) for r in read_ids), dtype=np.int64, count=len(read_ids))

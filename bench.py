@@ -415,7 +415,7 @@ def run_api_e2e(w, vocab, toks, offs, k, n_windows, steps=5):
         g = timed("build_filtered_graph", lambda: gu.build_filtered_graph(reads, k, pos, 3, 1))
         r1, p1 = timed("correct_reads", lambda: g.correct_reads(lengths))
         g2 = timed("build_graph", lambda: gu.build_multiprocessed_graph(r1, k, 1, p1))
-        timed("remove_short_linear_paths", lambda: g2.remove_short_linear_paths(k))
+        timed("remove_short_linear_paths", lambda: g2.remove_short_linear_paths(k, _lazy_hashes=True))
         r2, p2 = timed("correct_reads", lambda: g2.correct_reads(lengths))
         g3 = timed("build_graph", lambda: gu.build_multiprocessed_graph(r2, k, 1, p2))
         n = g3.get_total_number_of_nodes()

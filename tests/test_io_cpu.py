@@ -58,6 +58,23 @@ def test_read_lengths():
     assert rl.lengths_array(["c", "x", "a"]).tolist() == [7, 0, 5]
     assert rl.lengths_array(["c", "a"], rows_hint=np.array([2, 0])).tolist() == [7, 5]
     assert rl.lengths_array(["c", "a"], rows_hint=np.array([1, 0])).tolist() == [7, 5]   # a wrong hint is not trusted
+    # a hint that is right at both ends and wrong in the middle (the same reads in another order) is not trusted either
+    rl5 = ReadLengths(["a", "b", "c", "d", "e"], [1, 2, 3, 4, 5])
+    assert rl5.lengths_array(["a", "c", "b", "e"], rows_hint=np.array([0, 1, 2, 4])).tolist() == [1, 3, 2, 5]
+    # rows of ANOTHER list, out of range here at the front (a subset's rows need not ascend): no IndexError
+    assert rl5.lengths_array(["e", "a"], rows_hint=np.array([9, 0])).tolist() == [5, 1]
+    assert rl5.lengths_array(["e", "a"], rows_hint=np.array([-1, 0])).tolist() == [5, 1]
+    # the identity token: rows into this very list are taken as they are
+    assert rl5.lengths_array(["d", "b"], rows_hint=np.array([3, 1]), hint_ids=rl5.read_ids).tolist() == [4, 2]
+    assert rl5.lengths_array(["d", "b"], rows_hint=np.array([3, 1]), hint_ids=["a", "b", "c", "d", "e"]).tolist() == [4, 2]
+
+
+def test_source_ids_follow_subsets():
+    _, ids, tr, _ = _mappings()
+    assert tr.source_rows is None and tr.source_ids is None
+    sub = tr.subset([3, 1])
+    assert sub.source_ids is tr.read_ids
+    assert sub.subset([1]).source_ids is tr.read_ids and sub.subset([1]).source_rows.tolist() == [1]
 
 
 def test_names_ending_with_a_suffix():
