@@ -68,6 +68,7 @@ def _load():
         "amg_get_node_reads": (C.c_int, [P, P, P]),
         "amg_filter": (C.c_int, [P, U32, U32]),
         "amg_remove_nodes": (C.c_int, [P, P, I64]),
+        "amg_remove_edges": (C.c_int, [P, P, I64]),
         "amg_remove_short_linear_paths": (C.c_int, [P, I32, P, C.POINTER(I64), P]),
         "amg_remove_low_coverage_components": (C.c_int, [P, U32]),
         "amg_get_reads_to_correct": (C.c_int, [P, P]),

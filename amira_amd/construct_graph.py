@@ -346,6 +346,7 @@ class GeneMerGraph(BubblePopping):
             if _filter is None:
                 self._engine.build(self._kmer_for_device())
             else:
+                self._build_filter = (int(_filter[0]), int(_filter[1]))
                 self._minNodeCoverage, self._minEdgeCoverage = _filter
                 self._engine.build_filtered(self._kmer_for_device(), max(int(_filter[0]), 0), max(int(_filter[1]), 0))
         except _ffi.AmgError as err:
@@ -403,6 +404,8 @@ class GeneMerGraph(BubblePopping):
         self._genePositions = gene_positions
         self._view = None
         self._host_edits = False   # add_node / add_edge / remove_edge ... changed the host view
+        self._pass_log = []        # device passes applied since the build, in order (replayed by __setstate__)
+        self._build_filter = None  # _filter of the build
         self._extra_to_correct = set()
         self._gene_cache = {}
         self._read_index_ = None
@@ -502,6 +505,45 @@ class GeneMerGraph(BubblePopping):
             self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+    # ------------------------------------------------------------------ pickling (graph_utils.py:108-122: loky workers
+    # hand whole GeneMerGraph objects back to the parent)
+    def __getstate__(self):
+        """What travels is what the graph was made FROM — the reads and positions (array-backed mappings fetch what
+        still lives on the device), the gene-mer size, the filter of a filtered build — and the device passes
+        applied since, in order.  The device arrays themselves stay behind: every pass is deterministic, so the
+        receiving process builds the graph on its own GPU and replays the passes (__setstate__)."""
+        if self._host_edits:
+            raise TypeError("a GeneMerGraph edited by hand (add_node / add_edge / ...) lives in host objects of this "
+                            "process only and cannot be pickled")
+        for obj in (self._reads, self._genePositions):
+            if isinstance(obj, TokenizedReads):
+                obj.tokens          # noqa: B018  (fetches a DeviceCorrected)
+            elif isinstance(obj, TokenizedPositions):
+                obj.gene_start      # noqa: B018
+        return {"reads": self._reads, "k": self._kmerSize, "positions": self._genePositions,
+                "filter": self._build_filter, "passes": list(self._pass_log),
+                "min_cov": (self._minNodeCoverage, self._minEdgeCoverage), "device": self._engine.device,
+                "extra_to_correct": set(self._extra_to_correct)}
+
+    def __setstate__(self, state):
+        self.__init__(state["reads"], state["k"], state["positions"], device=state.get("device"),
+                      _filter=state["filter"])
+        eng = self._engine
+        for what, arg in state["passes"]:
+            if what == "filter":
+                eng.filter(*arg)
+            elif what == "remove_nodes":
+                eng.remove_nodes(arg)
+            elif what == "remove_edges":
+                eng.remove_edges(arg)
+            elif what == "remove_low_coverage_components":
+                eng.remove_low_coverage_components(arg)
+            elif what == "remove_short_linear_paths":
+                eng.remove_short_linear_paths(*arg)
+        self._pass_log = list(state["passes"])
+        self._minNodeCoverage, self._minEdgeCoverage = state["min_cov"]
+        self._extra_to_correct = set(state["extra_to_correct"])
 
     def __enter__(self):
         return self
@@ -827,11 +869,19 @@ class GeneMerGraph(BubblePopping):
         del self._v().edges[edgeHash]
 
     def remove_edge(self, edgeHash):
-        """drop an edge from the graph and from its source node's list; unknown hashes are ignored (:409-428)"""
+        """drop an edge from the graph and from its source node's list; unknown hashes are ignored (:409-428).
+        On a graph that has not been edited by hand the edge is removed ON THE DEVICE (amg_remove_edges), so that
+        device passes keep working afterwards, as filter_graph does after remove_edge in the reference."""
         edges = self._v().edges
         if edgeHash not in edges:
             return
         edge = edges[edgeHash]
+        if not self._host_edits and getattr(edge, "_amg_id", None) is not None:
+            self._settle_leases()
+            self._engine.remove_edges([edge._amg_id])
+            self._pass_log.append(("remove_edges", [int(edge._amg_id)]))
+            self._invalidate()
+            return
         source = edge.get_sourceNode()
         if edge.get_sourceNodeDirection() == 1:
             source.remove_forward_edge_hash(edgeHash)
@@ -931,12 +981,14 @@ class GeneMerGraph(BubblePopping):
         i = self._node_id(h)
         self._settle_leases()
         self._engine.remove_nodes([i])
+        self._pass_log.append(("remove_nodes", [int(i)]))
         self._invalidate()
 
     def _remove_node_ids(self, ids):
         if len(ids):
             self._settle_leases()
             self._engine.remove_nodes(np.asarray(ids, dtype=np.int32))
+            self._pass_log.append(("remove_nodes", np.asarray(ids, dtype=np.int32)))
             self._invalidate()
 
     def list_nodes_to_remove(self, minNodeCoverage):
@@ -959,12 +1011,14 @@ class GeneMerGraph(BubblePopping):
         self.set_minNodeCoverage(minNodeCoverage)
         self.set_minEdgeCoverage(minEdgeCoverage)
         self._engine.filter(max(int(minNodeCoverage), 0), max(int(minEdgeCoverage), 0))
+        self._pass_log.append(("filter", (max(int(minNodeCoverage), 0), max(int(minEdgeCoverage), 0))))
         self._invalidate()
         return self
 
     def remove_low_coverage_components(self, min_component_coverage):
         self._device_pass("remove_low_coverage_components")
         self._engine.remove_low_coverage_components(max(int(min_component_coverage), 0))
+        self._pass_log.append(("remove_low_coverage_components", max(int(min_component_coverage), 0)))
         self._invalidate()
 
     def remove_short_linear_paths(self, min_length, sample_genesOfInterest={}, _lazy_hashes=False):
@@ -981,6 +1035,7 @@ class GeneMerGraph(BubblePopping):
         v = self._view   # the object view is NOT made for this: the hashes of the removed nodes come from their tokens
         tokens = None if v is not None else self._engine.nodes()["tokens"]
         removed = self._engine.remove_short_linear_paths(int(min_length), protect)
+        self._pass_log.append(("remove_short_linear_paths", (int(min_length), protect)))
         if v is not None:
             hashes = [v.hash_at(i) for i in removed.tolist()]
         elif _lazy_hashes:

@@ -256,6 +256,125 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
   }
 }
 
+// ------------------------------------------------------------------ nodes, minimiser buckets
+// k_nodes_v is bound by the 128-byte line requests of its probes (one hashed slot = one line per window, DESIGN.md
+// section 4).  Consecutive windows of a read share k - 1 genes, so a key function that consecutive windows mostly
+// AGREE on turns neighbouring probes into requests for the same line: the gene of a window with the smallest rank
+// (its minimiser; ranks follow sha256 order, i.e. they are a random permutation of the genes) is shared by about
+// (k + 1) / 2 consecutive windows.  The table gets a BUCKET REGION in front of its hashed slots: one 128-byte line
+// (8 slots) per gene rank.  A gene-mer lives in the line of its minimiser, starting at slot p0 = the position of
+// that gene in the tuple read along the gene's own strand: the up to k gene-mers of a genome that share a
+// minimiser g hold g at k different positions, so every one of them sits in its FIRST slot (p0 is a function of
+// the canonical tuple alone: the key decides where it lives, whatever the orientation of the read).  Whatever
+// does not find room within AMG_BUCKET_PROBES slots of its line (error gene-mers, genes in many copies) goes to its
+// hashed slot as before.  A thread's four windows lie 256 apart, so the 64 lanes of one probe instruction look at
+// 64 consecutive windows: ~64 * 2 / (k + 1) distinct lines instead of 64.
+#ifndef AMG_BUCKET_PROBES
+#define AMG_BUCKET_PROBES 3
+#endif
+template <bool TWO, int K, bool B16, bool HEAD = false>
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
+    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int two_v,
+    int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
+    signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n) {
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
+  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
+  const int tid = threadIdx.x;
+  const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  const int flip = two_v - 1, V = two_v >> 1;
+  {
+    bool bad = false;
+    if (t0 + TILE <= n_tokens && (reinterpret_cast<uintptr_t>(tokens) & 15) == 0) {  // (a borrowed array may sit anywhere)
+      const i4 x = __builtin_nontemporal_load(reinterpret_cast<const i4*>(tokens + t0) + tid);
+      bad = (unsigned int)x.x >= (unsigned int)two_v || (unsigned int)x.y >= (unsigned int)two_v ||
+            (unsigned int)x.z >= (unsigned int)two_v || (unsigned int)x.w >= (unsigned int)two_v;
+      reinterpret_cast<i4*>(s_tok)[tid] = x;
+    } else {
+      for (int i = tid; i < TILE; i += TILE_THREADS) {
+        const long long t = t0 + i;
+        const int x = t < n_tokens ? tokens[t] : 0;
+        bad = bad || (unsigned int)x >= (unsigned int)two_v;
+        s_tok[i] = x;
+      }
+    }
+    if (tid < K + 3) {  // the k - 1 tokens the last windows reach into
+      const long long t = t0 + TILE + tid;
+      const int x = t < n_tokens ? tokens[t] : 0;
+      bad = bad || (unsigned int)x >= (unsigned int)two_v;
+      s_tok[TILE + tid] = x;
+    }
+    if (bad) status[ST_BADINPUT] = 2;  // a token outside [0, two_v) would alias another tuple
+    if (tid < TILE_BIT_WORDS) s_bits[tid] = bnd_bits[(t0 >> 5) + tid];
+  }
+  __syncthreads();
+  unsigned int id1[TILE_ITEMS];
+  unsigned int last = 0, ndir = 0, valid = 0;  // per window: last of its read; direction -1; has a node
+  unsigned int made = 0;                       // per window: it created its node's key
+  {
+    unsigned long long w1[TILE_ITEMS];
+    unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS];
+    ulonglong2 v[TILE_ITEMS];
+#pragma unroll
+    for (int w = 0; w < TILE_ITEMS; ++w) {
+      w1[w] = 0;
+      tag[w] = 0;
+      idx[w] = 0;
+      const int i = w * TILE_THREADS + tid;
+      const long long t = t0 + i;
+      // no read ends at the positions t + 1 .. t + k - 1; one that ends right after the window makes it the last of its read
+      const unsigned int b = tile_bits(s_bits, i + 1, K);
+      if (!((t + K <= n_tokens) && (b & ((1u << (K - 1)) - 1u)) == 0u)) continue;
+      int a[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) a[j] = s_tok[i + j];
+      int dir;
+      if constexpr (B16)
+        dir = f_canon_pack16<K, TWO>(a, flip, w1[w], tag[w]);
+      else
+        dir = x_canon_pack<K, TWO>(a, flip, bits, w1[w], tag[w]);
+      if (dir == 0) {
+        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
+        continue;
+      }
+      // minimiser of the CANONICAL tuple (first occurrence of the smallest gene rank) and where it sits along its own strand
+      int best = 0x7fffffff, bj = 0;
+      bool plus = true;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int c = dir > 0 ? a[j] : flip - a[K - 1 - j];
+        const bool p = c >= V;
+        const int r = p ? c - V : V - 1 - c;
+        if (r < best) {
+          best = r;
+          bj = j;
+          plus = p;
+        }
+      }
+      idx[w] = (unsigned int)best * 8u + (unsigned int)((plus ? bj : K - 1 - bj) & 7);
+      v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
+      if (dir < 0) ndir |= 1u << w;
+      valid |= 1u << w;
+      if ((b >> (K - 1)) & 1u) last |= 1u << w;
+    }
+    f_table_phase<TWO, 1, false, TILE_THREADS, AMG_BUCKET_PROBES>(
+        tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir, xf, first2, slot_by_claim,
+        status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n);
+  }
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w) {
+    const long long t = t0 + w * TILE_THREADS + tid;
+    if (t >= n_tokens) continue;
+    const int o = id1[w] ? (int)((id1[w] - 1u) | ((last & (1u << w)) ? AMG_LAST_FLAG : 0u) |
+                                 ((made & (1u << w)) ? AMG_MADE_FLAG : 0u))
+                         : -1;
+    __builtin_nontemporal_store(o, tok_claim + t);
+    __builtin_nontemporal_store(id1[w] ? ((ndir & (1u << w)) ? (signed char)-1 : (signed char)1) : (signed char)0, tok_dir + t);
+  }
+}
+
 // ---- build with the coverage filter applied on the way (amg_build_filtered): claims below the threshold are
 // taken out of the claim space (first-seen words zeroed = "unclaimed", which every ranking kernel skips) before
 // anything is ranked, so only the survivors get ids, arrays, edges
@@ -793,11 +912,18 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   c->x_bits = bx_bits(c, k);
   const long long n_tiles = (T + TILE - 1) / TILE;
 
-  const size_t max_claims = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
+  // bucket region of the node table (k_nodes_m): one 8-slot line per gene rank in front of the hashed slots, for the
+  // gene-mer sizes that have a compile-time kernel; AMG_NODE_BUCKETS=0: hashed slots only (k_nodes_v; A/B switch)
+  const char* nb = getenv("AMG_NODE_BUCKETS");
+  const bool buckets = !(nb && atoi(nb) == 0) && !getenv("AMG_X_OLD_PASS") && !getenv("AMG_X_GENERIC_K") &&
+                       (k == 3 || k == 5 || k == 7) && n_tiles > 0;
+  const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
+  const size_t tab_slots = (size_t)c->node_slots + home_n;
+  const size_t max_claims = (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
   AMGCHK(c->tok_slot.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_node.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_dir.ensure((size_t)(T + 8)));
-  AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot16)));
+  AMGCHK(c->node_tab.ensure(tab_slots * sizeof(Slot16)));
   AMGCHK(c->x_first.ensure(2 * max_claims * sizeof(unsigned int)));  // {raised by others, creator's} per claim
   AMGCHK(c->x_slot.ensure(max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_final.ensure(max_claims * sizeof(int)));
@@ -805,7 +931,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   {  // status words, table, first-seen words and the read-end bitmap are zeroed by ONE launch
     ClearList cl;
     cl.add(c->status.p, ST_WORDS * sizeof(unsigned long long));
-    cl.add(c->node_tab.p, (size_t)c->node_slots * sizeof(Slot16));
+    cl.add(c->node_tab.p, tab_slots * sizeof(Slot16));
     cl.add(c->x_first.p, 2 * max_claims * sizeof(unsigned int));
     AMGCHK(bs_read_stats(c, k, &cl));
   }
@@ -835,6 +961,33 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                          c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                          c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
                          c->x_slot.as<unsigned int>(), ablate, xw2_for(max_claims, T));
+    } else if (buckets) {
+      const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
+      auto kern = k_nodes_m<false, 3, false>;
+      auto kern_head = k_nodes_m<false, 3, false, true>;
+      if (b16 && k == 3) kern = k_nodes_m<false, 3, true>, kern_head = k_nodes_m<false, 3, true, true>;
+      else if (b16 && k == 5) kern = k_nodes_m<true, 5, true>, kern_head = k_nodes_m<true, 5, true, true>;
+      else if (k == 3) kern = two ? k_nodes_m<true, 3, false> : k_nodes_m<false, 3, false>,
+                       kern_head = two ? k_nodes_m<true, 3, false, true> : k_nodes_m<false, 3, false, true>;
+      else if (k == 5) kern = two ? k_nodes_m<true, 5, false> : k_nodes_m<false, 5, false>,
+                       kern_head = two ? k_nodes_m<true, 5, false, true> : k_nodes_m<false, 5, false, true>;
+      else kern = two ? k_nodes_m<true, 7, false> : k_nodes_m<false, 7, false>,
+           kern_head = two ? k_nodes_m<true, 7, false, true> : k_nodes_m<false, 7, false, true>;
+      const long long head = head_tiles(c, n_tiles);  // (see below: the genome's keys get the lowest claims — and the first slots of their lines)
+      for (int part = 0; part < 2; ++part) {
+        const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
+        if (cnt <= 0) continue;
+        if (part == 1 && head > 0) {  // the head launch is a stage of its own
+          stage_end(c);
+          stage_begin(c, "node_upsert");
+        }
+        hipLaunchKernelGGL(part == 0 ? kern_head : kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
+                           c->bnd_bits.as<unsigned int>(), T, c->two_v, c->x_bits, c->node_tab.as<Slot16>(),
+                           (unsigned int)(c->node_slots - 1), kProbeLimitX, c->tok_slot.as<int>(),
+                           c->tok_dir.as<signed char>(), c->status.as<unsigned long long>(),
+                           c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), (unsigned int)max_claims,
+                           xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n);
+      }
     } else {
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
       auto kern = two ? k_nodes_v<true, 0, false> : k_nodes_v<false, 0, false>;

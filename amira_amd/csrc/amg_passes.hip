@@ -335,6 +335,24 @@ __device__ __forceinline__ int lin_step(const GView& g, int n, bool use_forward,
   return ((deg == 1 || deg == 2) && *tgt != n) ? 2 : 1;
 }
 
+// ------------------------------------------------------------------ remove_edge (:409-428)
+// one DIRECTED edge per listed id leaves the graph (and its source node's forward / backward list); its reverse
+// twin stays, as in the reference, until it is removed by its own call
+extern "C" int amg_remove_edges(amg_ctx* c, const int32_t* edge_ids, int64_t n) {
+  NEED_BUILT(c);
+  if (n < 0 || (n > 0 && !edge_ids)) return amg_fail(AMG_E_ARG, "bad edge list");
+  if (n == 0) return AMG_OK;
+  AMGCHK(c->s0.ensure((size_t)n * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(c->s0.p, edge_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_kill_listed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->s0.as<int>(), (long long)n,
+                     c->n_edges, c->edge_alive.as<unsigned char>());
+  c->ladj_valid = false;
+  c->match_valid = false;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->have_corrected = false;
+  return AMG_OK;
+}
+
 // ------------------------------------------------------------------ remove_short_linear_paths (:679-720)
 #define CLIP_MAX 64
 __global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double thr,

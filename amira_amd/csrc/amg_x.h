@@ -101,7 +101,10 @@ __device__ __forceinline__ int x_canon_pack(const int* w, int flip, int bits, un
 // whichever thread needs it first; that thread owns the slot ("created").
 // Returns the slot or -1; w2v = the slot's second word as seen (low 32 bits zero: the claim id
 // is not published yet).
-template <bool TWO>
+// BUCKET: the slots probed are those of ONE 128-byte line (8 slots), starting at idx and wrapping inside the line —
+// the bucket region of the node table (k_nodes_m), probed `limit` + 1 slots deep, after which the key goes to its
+// hashed slot.
+template <bool TWO, bool BUCKET = false>
 __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
                                               unsigned long long w1, unsigned int tag,
                                               unsigned int idx, ulonglong2 v,
@@ -163,7 +166,7 @@ __device__ __forceinline__ int x_upsert(Slot16* tab, unsigned int mask,
     if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag))
       return -1;
     ++probes;
-    idx = off + ((idx - off + 1u) & mask);
+    idx = BUCKET ? ((idx & ~7u) | ((idx + 1u) & 7u)) : off + ((idx - off + 1u) & mask);
     v = *reinterpret_cast<const ulonglong2*>(tab + idx);
   }
 }
@@ -316,7 +319,9 @@ __device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
 // STRIDE: window `it` of a thread starts STRIDE tokens after window it - 1.  homed / off: items whose idx[] is a
 // HOME slot (a directly addressed slot below `off`: taken, found, or — when another key sits there — given up for the
 // key's hashed slot in tab[off .. off + mask]); one-word keys only.
-template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1>
+// HOME_PROBES: slots of its line a homed item looks at before it goes to its hashed slot (1: the home slot alone —
+// the edge pass; > 1: a bucket line of the node table, k_nodes_m).
+template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1, int HOME_PROBES = 1>
 __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
                                               const unsigned long long (&w1)[TILE_ITEMS],
                                               const unsigned int (&tag)[TILE_ITEMS],
@@ -369,11 +374,17 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     // lives in scratch memory)
     const unsigned int ix = f_pick(idx, it);
     const bool home = (homed >> it) & 1u;
-    int sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
-                           *reinterpret_cast<const ulonglong2*>(tab + ix), home ? 0u : probe_limit,
-                           status + ST_OVERFLOW, w2v, made, off);
-    if (!TWO && sl < 0 && home) {  // another class lives in the home slot: this one goes where its key hashes to
-      const unsigned int ix2 = off + ((unsigned int)mix64(f_pick(w1, it)) & mask);
+    int sl;
+    if (home)
+      sl = x_upsert<TWO, (HOME_PROBES > 1)>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
+                                            *reinterpret_cast<const ulonglong2*>(tab + ix), (unsigned int)(HOME_PROBES - 1),
+                                            status + ST_OVERFLOW, w2v, made, off);
+    else
+      sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix,
+                         *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit, status + ST_OVERFLOW, w2v, made, off);
+    if (sl < 0 && home) {  // other keys live in the home slot(s): this one goes where its key hashes to
+      const unsigned int ix2 =
+          off + ((unsigned int)mix64(f_pick(w1, it) ^ (TWO ? (unsigned long long)f_pick(tag, it) * 0x9E3779B97F4A7C15ull : 0ull)) & mask);
       sl = x_upsert<TWO>(tab, mask, f_pick(w1, it), f_pick(tag, it), ix2,
                          *reinterpret_cast<const ulonglong2*>(tab + ix2), probe_limit, status + ST_OVERFLOW, w2v, made,
                          off);

@@ -180,6 +180,10 @@ class Engine:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         check(_ffi.lib.amg_remove_nodes(self._h, ptr(ids), len(ids)))
 
+    def remove_edges(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(_ffi.lib.amg_remove_edges(self._h, ptr(ids), len(ids)))
+
     def remove_short_linear_paths(self, min_length, protect=None):
         D = self.graph_sizes()[0]
         n = C.c_int64(0)

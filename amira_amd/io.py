@@ -36,6 +36,10 @@ class DeviceCorrected:
             self._done()
         return self._arrays
 
+    def __reduce__(self):
+        """pickled as what it holds: the arrays, fetched (a device buffer does not travel)"""
+        return (_fetched, (self.fetch(), self._shape))
+
     def _done(self):
         engine, self._engine = self._engine, None
         if engine is not None:
@@ -47,6 +51,17 @@ class DeviceCorrected:
             self._done()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+
+class _Fetched(DeviceCorrected):
+    """a DeviceCorrected after its trip through pickle: the arrays only, no engine"""
+
+    def __init__(self, arrays, shape):   # noqa: super().__init__ not called: there is no engine to lease
+        self._engine, self._shape, self._arrays = None, shape, arrays
+
+
+def _fetched(arrays, shape):
+    return _Fetched(arrays, shape)
 
 
 def _gather_rows(offsets, rows):

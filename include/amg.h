@@ -181,6 +181,9 @@ int amg_get_node_reads(amg_ctx* ctx, int64_t* offsets, int32_t* read_idx);
 int amg_filter(amg_ctx* ctx, uint32_t min_node_cov, uint32_t min_edge_cov);
 /* remove_node for each listed node (construct_graph.py:463-484) */
 int amg_remove_nodes(amg_ctx* ctx, const int32_t* node_ids, int64_t n);
+/* remove_edge for each listed DIRECTED edge (construct_graph.py:409-428): the edge leaves the graph and its source
+ * node's forward / backward list; its reverse twin is an edge of its own */
+int amg_remove_edges(amg_ctx* ctx, const int32_t* edge_ids, int64_t n);
 /* remove_short_linear_paths(min_length) (construct_graph.py:679-720); protect[n] != 0
  * keeps node n (the AMR_nodes exemption); removed_ids may be NULL. */
 int amg_remove_short_linear_paths(amg_ctx* ctx, int32_t min_length, const uint8_t* protect,

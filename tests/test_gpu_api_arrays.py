@@ -151,3 +151,42 @@ def test_corrected_reads_go_to_the_next_graph_on_the_device():
     probe = weakref.ref(g2t)
     del g2t, g2d, gd, gt, r2t, p2t, rt, pt, g
     assert probe() is None   # freed by reference counting: a graph in a cycle would take its engine to the collector
+
+
+def test_mappings_of_a_correction_survive_later_passes():
+    """correct_reads on array inputs hands back mappings whose arrays still live on the device; a pass that changes
+    the graph afterwards (it invalidates the engine's corrected set) must not take them away: the reference's dicts
+    keep answering whatever happens to the graph later"""
+    from amira_amd import GeneMerGraph
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    pos_d = {r: list(v) for r, v in pos.items()}
+    treads, tpos, tlen = _tokenized(reads, pos, fq)
+    gd, gt = GeneMerGraph(dict(reads), 5, pos_d), GeneMerGraph(treads, 5, tpos)
+    gd.filter_graph(3, 1)
+    gt.filter_graph(3, 1)
+    rd, pd = gd.correct_reads(fq)
+    rt, pt = gt.correct_reads(tlen)
+    assert rt.device_source() is not None
+    gt.remove_short_linear_paths(5)               # settles the lease first
+    gd.remove_short_linear_paths(5)
+    assert rt.device_source() is None
+    some = list(rd)[:50]
+    for r in some:
+        assert rt[r] == rd[r] and [tuple(x) for x in pt[r]] == [tuple(x) for x in pd[r]]
+    # ... and the same through filter_graph / remove_node / remove_low_coverage_components
+    for mutate in (lambda g: g.filter_graph(4, 2), lambda g: g.remove_node(next(iter(g.get_nodes().values()))),
+                   lambda g: g.remove_low_coverage_components(5)):
+        r2t, p2t = gt.correct_reads(tlen)
+        r2d, p2d = gd.correct_reads(fq)
+        mutate(gt)
+        mutate(gd)
+        assert list(r2t) == list(r2d)
+        for r in list(r2d)[:50]:
+            assert r2t[r] == r2d[r] and [tuple(x) for x in p2t[r]] == [tuple(x) for x in p2d[r]]
+        g3 = GeneMerGraph(r2t, 5, p2t)           # (host arrays by now)
+        g3d = GeneMerGraph(r2d, 5, p2d)
+        assert list(g3.get_nodes()) == list(g3d.get_nodes())
+        g3.close()
+        g3d.close()
+    gd.close()
+    gt.close()

@@ -117,3 +117,68 @@ def test_merge_graphs_is_the_single_graph_build():
     assert state(one) == state(two)
     for g in subs + [merged, want, again, one, two]:
         g.close()
+
+
+def test_pickle_round_trip():
+    """graph_utils.py:108-122: loky workers return whole GeneMerGraph objects; the state that travels is what the graph
+    was made from plus the device passes applied since, replayed on the receiving side's own engine"""
+    import pickle
+    p, o = _pair("nine", 5)
+    q = pickle.loads(pickle.dumps(p))
+    assert D.dump_graph(q) == D.dump_graph(o) == D.dump_graph(p)
+    for g in (p, o):
+        g.filter_graph(3, 1)
+        g.remove_node(g.get_node_by_hash(list(g.get_nodes())[7]))
+        g.remove_short_linear_paths(5)
+    blob = pickle.dumps(p)
+    p.close()                         # the copy owes nothing to the original's engine
+    q2 = pickle.loads(blob)
+    assert D.dump_graph(q2) == D.dump_graph(o)
+    assert q2.get_reads_to_correct() == o.get_reads_to_correct()
+    assert (q2.get_minNodeCoverage(), q2.get_minEdgeCoverage()) == (o.get_minNodeCoverage(), o.get_minEdgeCoverage())
+    fq = P.FakeFastq({r: 10 ** 6 for r in o.get_reads()})
+    qg, qp = q2.correct_reads(fq)
+    og, op = o.correct_reads(fq)
+    assert D.dump_corrected(qg, qp) == D.dump_corrected(og, op)
+    # array-backed mappings whose arrays still live on the device travel as arrays
+    import numpy as np
+    from amira_amd import GeneMerGraph, tokenize
+    from amira_amd.io import ReadLengths, TokenizedPositions, TokenizedReads
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, ids = tokenize(reads)
+    gs = np.concatenate([[x[0] for x in pos[r]] for r in ids]).astype(np.int64)
+    ge = np.concatenate([[x[1] for x in pos[r]] for r in ids]).astype(np.int64)
+    g = GeneMerGraph(TokenizedReads(vocab, toks, offs, ids), 5, TokenizedPositions(ids, offs, gs, ge), _filter=(3, 1))
+    rt, pt = g.correct_reads(ReadLengths(ids, np.asarray([len(fq[r]["sequence"]) for r in ids], np.int64)))
+    g2 = GeneMerGraph(rt, 5, pt)
+    assert rt.device_source() is not None
+    g3 = pickle.loads(pickle.dumps(g2))
+    assert list(g3.get_nodes()) == list(g2.get_nodes())
+    assert {r: list(v) for r, v in g3.get_readNodes().items()} == {r: list(v) for r, v in g2.get_readNodes().items()}
+    back = pickle.loads(pickle.dumps(g))      # a filtered build keeps its filter
+    assert list(back.get_nodes()) == list(g.get_nodes()) and back.get_reads_to_correct() == g.get_reads_to_correct()
+    for x in (q, q2, o, g, g2, g3, back):
+        x.close()
+
+
+def test_remove_edge_then_device_passes():
+    """remove_edge followed by filter_graph works in the reference (construct_graph.py:409-428, 523-540): on a graph
+    nobody has edited by hand the edge is removed on the device and device passes carry on"""
+    p, o = _pair("eight", 3)
+    doomed = list(o.get_edges())[3:40:5]
+    for h in doomed:
+        p.remove_edge(h)
+        o.remove_edge(h)
+    p.remove_edge(12345)              # unknown hashes are ignored
+    assert not p._host_edits
+    assert D.dump_graph(p) == D.dump_graph(o)
+    p.filter_graph(3, 2)
+    o.filter_graph(3, 2)
+    assert D.dump_graph(p) == D.dump_graph(o)
+    assert sorted(p.remove_short_linear_paths(3)) == sorted(o.remove_short_linear_paths(3))
+    assert D.dump_graph(p) == D.dump_graph(o)
+    fq = P.FakeFastq({r: 10 ** 6 for r in o.get_reads()})
+    pg, pp = p.correct_reads(fq)
+    og, op = o.correct_reads(fq)
+    assert D.dump_corrected(pg, pp) == D.dump_corrected(og, op)
+    p.close()
