@@ -95,6 +95,12 @@ def _load():
         "amg_calls_load_positions_json": (C.c_int, [P, C.c_char_p, P, P]),
         "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
         "amg_calls_free": (C.c_int, [P]),
+        "amg_cluster_full_blocks": (C.c_int, [P, P, I64, P, P, I32, P, I64, I64, C.POINTER(P)]),
+        "amg_cluster_blocks_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
+        "amg_cluster_blocks_get": (C.c_int, [P, P, P]),
+        "amg_cluster_blocks_free": (C.c_int, [P]),
+        "amg_py_tuple_hash": (I64, [P, I64]),
+        "amg_pyset_script": (C.c_int, [P, I64, P, I32, P, P]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
         "amg_set_timing": (C.c_int, [P, C.c_int]),
     }

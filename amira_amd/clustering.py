@@ -1,0 +1,95 @@
+"""Read-path clustering, block search: the glue between GeneMerGraph.assign_reads_to_genes and
+amg_cluster_full_blocks (amira_amd/csrc/amg_cluster.hip, host C++ behind the C ABI).
+
+The reference (path_finding_utils.py:88-247) finds, for every ordered pair of anchor nodes, the blocks between
+them on the reads, collects what lies upstream / downstream of each block in Python sets of tuples of 256-bit node
+hashes, clusters those contexts and keeps the full blocks some read really holds.  The native code does the same on
+the device's node ids; what it must get right beyond the arithmetic is the ORDER in which those Python sets
+iterate, because that order becomes the order of the full blocks and, in the end, the numbering of the alleles.  It
+reproduces CPython's set and tuple hash for that, and `emulation_ok()` checks the reproduction against the running
+interpreter before it is relied on: on an interpreter whose sets behave differently the pure-Python block search
+(amira_amd.path_finding_utils) stays in charge.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+
+_OK = None
+
+
+def emulation_ok():
+    """do CPython's own sets iterate as the native emulation predicts?  (a few hundred random operations on sets of
+    tuples of big ints / None, once per process, ~2 ms)"""
+    global _OK
+    if _OK is None:
+        try:
+            _OK = _self_check()
+        except Exception:  # noqa: BLE001 - a missing symbol or anything else: the Python path stays in charge
+            _OK = False
+    return _OK
+
+
+def _self_check():
+    rng = random.Random(20250908)
+    base = tuple(rng.getrandbits(256) - (1 << 255) for _ in range(60))
+    keys = [base[-i:] for i in range(1, 61)] + [base[:i] for i in range(1, 60)] + [()]
+    keys += [tuple(rng.choice(base + (None,)) for _ in range(rng.randrange(1, 9))) for _ in range(300)]
+    keys = list(dict.fromkeys(keys))
+    key_hash = np.asarray([hash(k) for k in keys], np.int64)
+    for k in keys[:40]:
+        lanes = np.asarray([hash(x) for x in k], np.int64)
+        if _ffi.lib.amg_py_tuple_hash(ptr(lanes) if len(lanes) else None, len(lanes)) != hash(k):
+            return False
+    n_sets = 4
+    real = [set() for _ in range(n_sets)]
+    ops = []
+    for _ in range(1500):
+        r, a = rng.random(), rng.randrange(n_sets)
+        if r < 0.75:
+            b = rng.randrange(len(keys))
+            real[a].add(keys[b])
+            ops.append((0, a, b))
+        elif r < 0.93:
+            b = rng.randrange(n_sets)
+            real[a].update(real[b])
+            ops.append((1, a, b))
+        elif r < 0.95:
+            real[a] = set()
+            ops.append((2, a, 0))
+        else:
+            b = rng.randrange(n_sets)
+            real[a] = {k for k in real[b]}
+            ops.append((3, a, b))
+    ops = np.ascontiguousarray(np.asarray(ops, np.int32))
+    out_keys = np.empty(len(keys) * n_sets, np.int32)
+    out_off = np.empty(n_sets + 1, np.int64)
+    check(_ffi.lib.amg_pyset_script(ptr(ops), len(ops), ptr(key_hash), n_sets, ptr(out_keys), ptr(out_off)))
+    index = {k: i for i, k in enumerate(keys)}
+    return all(out_keys[out_off[s]:out_off[s + 1]].tolist() == [index[k] for k in real[s]] for s in range(n_sets))
+
+
+def full_block_ids(seq, seq_off, anchor_ids, anchor_rank, py_hash, none_hash):
+    """-> list of int32 arrays: the keys of full_blocks in insertion order, as device node ids (-2 = None)"""
+    seq = np.ascontiguousarray(seq, np.int32)
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    anchors = np.ascontiguousarray(anchor_ids, np.int32)
+    ranks = np.ascontiguousarray(anchor_rank, np.int32)
+    py_hash = np.ascontiguousarray(py_hash, np.int64)
+    h = C.c_void_p()
+    check(_ffi.lib.amg_cluster_full_blocks(ptr(seq) if len(seq) else None, ptr(seq_off), len(seq_off) - 1,
+                                           ptr(anchors) if len(anchors) else None, ptr(ranks) if len(ranks) else None,
+                                           len(anchors), ptr(py_hash), len(py_hash), int(none_hash), C.byref(h)))
+    try:
+        nb, ni = C.c_int64(0), C.c_int64(0)
+        check(_ffi.lib.amg_cluster_blocks_sizes(h, C.byref(nb), C.byref(ni)))
+        off = np.empty(nb.value + 1, np.int64)
+        ids = np.empty(max(ni.value, 1), np.int32)
+        check(_ffi.lib.amg_cluster_blocks_get(h, ptr(off), ptr(ids)))
+    finally:
+        _ffi.lib.amg_cluster_blocks_free(h)
+    cuts = off.tolist()
+    return [ids[cuts[i]:cuts[i + 1]] for i in range(nb.value)]

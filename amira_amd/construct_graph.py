@@ -32,6 +32,7 @@ from itertools import product
 import numpy as np
 
 from . import _ffi
+from . import clustering as _clustering
 from .bubble_popping import BubblePopping
 from .construct_edge import Edge
 from .construct_gene import Gene, convert_int_strand_to_string, hashlib_hash
@@ -312,6 +313,17 @@ class _View:
     def edge_by_hash(self, h):
         got = self._edges.get(h)
         return got if got is not None else self.edges[h]
+
+
+class _SubsetRows:
+    """stands in for the {read: genes} subset handed to get_all_sublists where only its size is looked at"""
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
 
 
 class GeneMerGraph(BubblePopping):
@@ -1772,6 +1784,11 @@ class GeneMerGraph(BubblePopping):
                 suffixes = get_suffixes_from_initial_tree(node_tree, a1)
                 sub_tree = Tree({r: list(reversed(s)) for r, s in suffixes.items()})
             process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, node_tree, threshold)
+        return self._paths_from_full_blocks(full_blocks, gene_call_subset, threshold, geneOfInterest, cores)
+
+    def _paths_from_full_blocks(self, full_blocks, gene_call_subset, threshold, geneOfInterest, cores):
+        """the second half of get_full_paths (:2738-2782): gene paths of the full blocks, block filter, the
+        differentiating path of every kept block"""
         gene_blocks = {}
         spelled = {}   # block -> its gene list (the graph does not change in here; the lists are only read)
 
@@ -2003,11 +2020,85 @@ class GeneMerGraph(BubblePopping):
         self._tree_rows = rows
         return Tree.from_flat(keys, seqs, flat, all_starts, lambda x: -2 if x is None else to_id.get(x))
 
+    def _reads_on_nodes(self, node_ids):
+        """collect_reads_in_path (:1497-1504) for nodes given by device id, with the rows of the reads: the SET of read
+        names is made by the same update() calls, node by node — the order in which it iterates later is the order of
+        the reference's set — and the rows come out of the node -> reads lists themselves, not out of a name -> row
+        table of the whole read set"""
+        v = self._v()
+        nr_off, nr_idx = v.arrays["node_reads_off"], v.arrays["node_reads"]
+        names_of = self._read_ids_array()
+        reads, row_of = set(), {}
+        for i in node_ids:
+            if not v.alive[i]:
+                continue
+            rows = nr_idx[nr_off[i]:nr_off[i + 1]]
+            names = names_of[rows].tolist()
+            reads.update(names)
+            row_of.update(zip(names, rows.tolist()))
+        return reads, np.fromiter((row_of[r] for r in reads), dtype=np.int64, count=len(reads))
+
+    def _cluster_gene_native(self, geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
+                             path_reads):
+        """one gene of assign_reads_to_genes (:2896-2937) with the block search in native code
+        (amira_amd.clustering / amg_cluster_full_blocks): the reads, their node lists and the blocks stay integer
+        arrays; node hashes are made for the nodes these reads run through, objects for the few nodes and edges the
+        anchor selection and the unitig spelling look at."""
+        v = self._v()
+        node_ids = self._node_ids_containing([geneOfInterest])
+        hashes = [v.hash_at(i) for i in node_ids]
+        reads_with_gene, rows = self._reads_on_nodes(node_ids)
+        threshold = mean_node_coverage / 20
+        anchors = self.get_AMR_anchors(hashes)
+        # the reads' node lists, laid end to end
+        tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
+        a = offs[rows]
+        n = offs[rows + 1] - a - k + 1
+        starts = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum(n, out=starts[1:])
+        within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], n)
+        seq = tok_node[np.repeat(a, n) + within]
+        uniq = np.unique(seq)
+        uniq = uniq[uniq >= 0]
+        nh = v.node_hash_table(uniq)
+        memo = getattr(self, "_py_hash_memo", None)
+        if memo is None or memo[0] is not v:
+            memo = self._py_hash_memo = (v, np.zeros(len(v.alive), np.int64), np.zeros(len(v.alive), bool))
+        py_hash, known = memo[1], memo[2]
+        new = uniq[~known[uniq]]
+        if len(new):
+            py_hash[new] = [hash(h) for h in nh[new].tolist()]
+            known[new] = True
+        anchor_list = list(anchors)                       # the set's iteration order, as `for a1 in nodeAnchors` meets it
+        by_hash = {h: i for i, h in enumerate(sorted(anchor_list))}
+        anchor_ids = [v.node_of_hash[h] for h in anchor_list]
+        blocks = _clustering.full_block_ids(seq, starts, anchor_ids, [by_hash[h] for h in anchor_list], py_hash,
+                                            hash(None))
+        full_blocks = {tuple(nh[b].tolist()): True for b in blocks}
+        in_subset = np.zeros(len(self._read_ids) + 1, bool)
+        in_subset[rows] = True
+        subset = _SubsetRows(2 * len(rows))   # (reads and their "_reverse" twins: get_all_sublists only asks which rows count)
+        self._subset_rows_memo = (subset, len(subset), in_subset)
+        paths, seen, coverages = self._paths_from_full_blocks(full_blocks, subset, threshold, geneOfInterest, cores)
+        self.get_singleton_paths(seen, anchors, paths, coverages)
+        alleles, _ = self.split_into_subpaths(geneOfInterest, paths, coverages, path_reads, mean_node_coverage)
+        self.assign_final_alleles_to_components(alleles, clustered_reads, allele_counts, geneOfInterest)
+        by_component = {}
+        for h in hashes:
+            by_component.setdefault(self.get_node_by_hash(h).get_component(), set()).add(h)
+        self.collect_component_missed_genes(by_component, clustered_reads, allele_counts, geneOfInterest, path_reads)
+
     def _assign_reads_to_genes(self, listOfGenes, cores, allele_counts, mean_node_coverage):
         clustered_reads, path_reads = {}, {}
         if mean_node_coverage is None:
             mean_node_coverage = self.get_mean_node_coverage()
+        native = (not self._host_edits and hasattr(Tree, "from_flat") and isinstance(self._reads, TokenizedReads)
+                  and not os.environ.get("AMG_CLUSTER_PYTHON") and _clustering.emulation_ok())
         for geneOfInterest in listOfGenes:
+            if native and not self._reads.any_name_ends_with("_reverse"):
+                self._cluster_gene_native(geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
+                                          path_reads)
+                continue
             hashes = [n.__hash__() for n in self.get_nodes_containing(geneOfInterest)]
             reads_with_gene = self.collect_reads_in_path(hashes)
             node_tree = None if self._host_edits else self._node_tree_from_device_ids(reads_with_gene)

@@ -354,7 +354,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
         }
       }
       idx[w] = (unsigned int)best * 8u + (unsigned int)((plus ? bj : K - 1 - bj) & 7);
+#ifndef AMG_ABLATE_NOPROBE
       v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
+#endif
       if (dir < 0) ndir |= 1u << w;
       valid |= 1u << w;
       if ((b >> (K - 1)) & 1u) last |= 1u << w;
@@ -363,6 +365,21 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
         tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir, xf, first2, slot_by_claim,
         status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n);
   }
+#ifdef AMG_M_DIR_LDS
+  // directions leave as one 4-byte store per thread: bytes through LDS (the token tile is no longer needed)
+  __syncthreads();
+  signed char* s_dir = reinterpret_cast<signed char*>(s_tok);
+#pragma unroll
+  for (int w = 0; w < TILE_ITEMS; ++w)
+    s_dir[w * TILE_THREADS + tid] = id1[w] ? ((ndir & (1u << w)) ? (signed char)-1 : (signed char)1) : (signed char)0;
+  __syncthreads();
+  if (t0 + 4 * tid + 4 <= n_tokens) {
+    __builtin_nontemporal_store(reinterpret_cast<const unsigned int*>(s_dir)[tid], reinterpret_cast<unsigned int*>(tok_dir + t0) + tid);
+  } else {
+    for (int j = 0; j < 4; ++j)
+      if (t0 + 4 * tid + j < n_tokens) tok_dir[t0 + 4 * tid + j] = s_dir[4 * tid + j];
+  }
+#endif
 #pragma unroll
   for (int w = 0; w < TILE_ITEMS; ++w) {
     const long long t = t0 + w * TILE_THREADS + tid;
@@ -371,7 +388,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
                                  ((made & (1u << w)) ? AMG_MADE_FLAG : 0u))
                          : -1;
     __builtin_nontemporal_store(o, tok_claim + t);
+#ifndef AMG_M_DIR_LDS
     __builtin_nontemporal_store(id1[w] ? ((ndir & (1u << w)) ? (signed char)-1 : (signed char)1) : (signed char)0, tok_dir + t);
+#endif
   }
 }
 

@@ -311,6 +311,31 @@ int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t*
                          const char* read_ids);
 int amg_calls_free(amg_calls* calls);
 
+/* ---- read-path clustering, block search (host code; construct_graph.py:2725-2749 get_full_paths and
+ *      path_finding_utils.py:88-247 process_anchors / get_blocks_from_subtree / generate_contexts /
+ *      generate_full_paths / cluster_*_adjacent_paths / update_full_blocks) --------------------------
+ * For one gene of interest: the keys of `full_blocks` in the reference's insertion order, as tuples of DEVICE
+ * NODE IDS (-2 = None).  seq / seq_off: per-window node ids of the reads that hold the gene, reads in the
+ * iteration order of the reference's set of read names; anchors: node ids in the iteration order of the
+ * reference's anchor set; anchor_rank[i]: rank of anchor i's node hash among the anchors; py_hash[id]:
+ * Python's hash() of node id's 256-bit hash for every id in seq; none_hash: hash(None).  The reference's
+ * containers are Python sets of tuples whose iteration order decides the order of the result: CPython's set
+ * and tuple hash are reproduced (amg_pyset_script / amg_py_tuple_hash expose the emulation to the check that
+ * amira_amd/clustering.py runs against the interpreter's own sets before relying on it). */
+typedef struct amg_blocks amg_blocks;
+int amg_cluster_full_blocks(const int32_t* seq, const int64_t* seq_off, int64_t n_reads,
+                            const int32_t* anchors, const int32_t* anchor_rank, int32_t n_anchors,
+                            const int64_t* py_hash, int64_t n_nodes, int64_t none_hash, amg_blocks** out);
+int amg_cluster_blocks_sizes(const amg_blocks* blocks, int64_t* n_blocks, int64_t* n_ids);
+int amg_cluster_blocks_get(const amg_blocks* blocks, int64_t* block_off, int32_t* block_ids);
+int amg_cluster_blocks_free(amg_blocks* blocks);
+int64_t amg_py_tuple_hash(const int64_t* item_hashes, int64_t n);
+/* ops: n_ops (op, a, b) triples over n_sets sets — 0: sets[a].add(key b); 1: sets[a].update(sets[b]);
+ * 2: sets[a] = set(); 3: sets[a] = {k for k in sets[b]}.  key_hash[k] = hash of key k.  Out: every set's
+ * iteration order (out_off[n_sets + 1], out_keys). */
+int amg_pyset_script(const int32_t* ops, int64_t n_ops, const int64_t* key_hash, int32_t n_sets,
+                     int32_t* out_keys, int64_t* out_off);
+
 /* ---- per-stage device time of the last call, for bench.py ------------------------- */
 /* names[i] points at static strings; returns the number of stages (<= cap). */
 int amg_last_timings(amg_ctx* ctx, const char** names, float* ms, int cap);
