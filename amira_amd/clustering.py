@@ -37,7 +37,7 @@ def _self_check():
     rng = random.Random(20250908)
     base = tuple(rng.getrandbits(256) - (1 << 255) for _ in range(60))
     keys = [base[-i:] for i in range(1, 61)] + [base[:i] for i in range(1, 60)] + [()]
-    keys += [tuple(rng.choice(base + (None,)) for _ in range(rng.randrange(1, 9))) for _ in range(300)]
+    keys += [tuple(rng.choice(base + (None,)) for _ in range(rng.randrange(1, 9))) for _ in range(120)]
     keys = list(dict.fromkeys(keys))
     key_hash = np.asarray([hash(k) for k in keys], np.int64)
     for k in keys[:40]:
@@ -47,7 +47,7 @@ def _self_check():
     n_sets = 4
     real = [set() for _ in range(n_sets)]
     ops = []
-    for _ in range(1500):
+    for _ in range(500):
         r, a = rng.random(), rng.randrange(n_sets)
         if r < 0.75:
             b = rng.randrange(len(keys))
@@ -93,3 +93,15 @@ def full_block_ids(seq, seq_off, anchor_ids, anchor_rank, py_hash, none_hash):
         _ffi.lib.amg_cluster_blocks_free(h)
     cuts = off.tolist()
     return [ids[cuts[i]:cuts[i + 1]] for i in range(nb.value)]
+
+
+def anchor_stats(seq, seq_off, read_order, amr_ids, n_nodes):
+    """-> int32 array [n_amr, 4]: {stopped at an anchor occurrence, all(singletons), flags, True flags} per AMR node"""
+    seq = np.ascontiguousarray(seq, np.int32)
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    order = None if read_order is None else np.ascontiguousarray(read_order, np.int64)
+    amr = np.ascontiguousarray(amr_ids, np.int32)
+    out = np.zeros((len(amr), 4), np.int32)
+    check(_ffi.lib.amg_cluster_anchor_stats(ptr(seq) if len(seq) else None, ptr(seq_off), len(seq_off) - 1, ptr(order),
+                                            ptr(amr) if len(amr) else None, len(amr), int(n_nodes), ptr(out)))
+    return out

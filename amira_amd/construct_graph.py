@@ -66,7 +66,9 @@ class _LazyReadLists(Mapping):
         self._extra = []       # reads added through add_node_to_read
 
     def _row(self, rid):
-        r = self._g._read_index.get(rid)
+        r = self._g._known_rows.get(rid)      # reads the clustering has met already (no name -> row table of ALL reads)
+        if r is None:
+            r = self._g._read_index.get(rid)
         if r is None:
             return None
         off = self._g._read_off
@@ -220,12 +222,12 @@ class _View:
     __slots__ = ("_nodes", "_nodes_complete", "_node_obj", "_make_node", "_id_of", "node_of_hash",
                  "_edges", "_edges_complete", "_edge_obj", "_make_edge", "_n_edges", "readNodes",
                  "readNodeDirections", "readNodePositions", "node_hash", "edge_hash", "alive", "arrays",
-                 "_nh_table")
+                 "_nh_table", "_hash_node")
 
     def dispose(self):
         """cut the view's own reference cycles (its makers close over it) so that it is freed the moment its graph lets
         go of it, not when the cyclic collector next walks the heap; called when the graph is closed"""
-        self._make_node = self._make_edge = self.node_of_hash = None
+        self._make_node = self._make_edge = self.node_of_hash = self._hash_node = None
         self.readNodes = self.readNodeDirections = self.readNodePositions = None
         for node in self._nodes.values():   # (the nodes made so far)
             if isinstance(node, _GraphNode):
@@ -245,18 +247,19 @@ class _View:
 
     def hash_at(self, i):
         h = self.node_hash[i]
-        if h is None and not self._nodes_complete and self._make_node(i) is not None:
-            h = self.node_hash[i]
+        if h is None and not self._nodes_complete:
+            h = self._hash_node(i)
         return h
 
     def ensure_hashes(self, ids):
-        """node_hash[i] filled in for every id >= 0 of `ids` (an iterable of ints)"""
+        """node_hash[i] filled in for every id >= 0 of `ids` (an iterable of ints) — the hash alone (one sha256 of the
+        node's tokens); the Node object with its genes is made when somebody asks for the node itself"""
         if self._nodes_complete:
             return
-        nh, make = self.node_hash, self._make_node
+        nh, hash_node = self.node_hash, self._hash_node
         for i in ids:
             if i >= 0 and nh[i] is None:
-                make(i)
+                hash_node(i)
 
     @property
     def nodes(self):
@@ -272,7 +275,8 @@ class _View:
     def node_by_hash(self, h, default=None):
         got = self._nodes.get(h)
         if got is None and not self._nodes_complete:
-            got = self.nodes.get(h)
+            i = self._id_of.get(h)          # hashed already (ensure_hashes), object not made yet
+            got = self.node_at(i) if i is not None else self.nodes.get(h)
         return default if got is None else got
 
     def node_hash_table(self, ids=None):
@@ -416,6 +420,7 @@ class GeneMerGraph(BubblePopping):
         self._genePositions = gene_positions
         self._view = None
         self._host_edits = False   # add_node / add_edge / remove_edge ... changed the host view
+        self._known_rows = {}      # read name -> row for the reads the native clustering has looked at
         self._pass_log = []        # device passes applied since the build, in order (replayed by __setstate__)
         self._build_filter = None  # _filter of the build
         self._extra_to_correct = set()
@@ -533,14 +538,31 @@ class GeneMerGraph(BubblePopping):
                 obj.tokens          # noqa: B018  (fetches a DeviceCorrected)
             elif isinstance(obj, TokenizedPositions):
                 obj.gene_start      # noqa: B018
-        return {"reads": self._reads, "k": self._kmerSize, "positions": self._genePositions,
+        # the positions the graph was BUILT with: correct_reads replaces the positions of the reads it changes in the
+        # caller's mapping (:1282-1284, :1328) while the graph keeps its reads, so the mapping as it is now may no
+        # longer match them; the flat arrays made at construction do
+        gs, ge = self._gs_val, self._ge_val
+        if gs is None and isinstance(self._genePositions, TokenizedPositions):
+            self._genePositions._from_device()
+            gs, ge = self._genePositions._gs, self._genePositions._ge
+        return {"reads": self._reads, "k": self._kmerSize, "positions": self._genePositions, "built_with": (gs, ge),
                 "filter": self._build_filter, "passes": list(self._pass_log),
                 "min_cov": (self._minNodeCoverage, self._minEdgeCoverage), "device": self._engine.device,
                 "extra_to_correct": set(self._extra_to_correct)}
 
     def __setstate__(self, state):
-        self.__init__(state["reads"], state["k"], state["positions"], device=state.get("device"),
-                      _filter=state["filter"])
+        gs, ge = state["built_with"]
+        reads = state["reads"]
+        built_with = None
+        if gs is not None:
+            ids = reads.read_ids if isinstance(reads, TokenizedReads) else list(reads)
+            offs = reads.read_offsets if isinstance(reads, TokenizedReads) else None
+            if offs is None:
+                offs = np.zeros(len(ids) + 1, np.int64)
+                np.cumsum([len(reads[r]) for r in ids], out=offs[1:])
+            built_with = TokenizedPositions(ids, offs, gs, ge)
+        self.__init__(reads, state["k"], built_with, device=state.get("device"), _filter=state["filter"])
+        self._genePositions = state["positions"]
         eng = self._engine
         for what, arg in state["passes"]:
             if what == "filter":
@@ -632,13 +654,26 @@ class GeneMerGraph(BubblePopping):
                 g = gene_cache[t] = Gene(gene_name(t))
             return g
 
+        def hash_node(i):
+            if not n_alive[i]:
+                return None
+            h = v.node_hash[i] = hashlib_hash(tuple([signed_hash(t) for t in n_tokens[i].tolist()]))
+            v._id_of[h] = i
+            if v._nh_table is not None:
+                v._nh_table[i] = h
+            return h
+
+        v._hash_node = hash_node
+
         def make_node(i):
             if not n_alive[i]:
                 return None
             toks = n_tokens[i].tolist()
             canon = [gene_obj(t) for t in toks]
             rc = [gene_obj(flip(t)) for t in reversed(toks)]
-            h = hashlib_hash(tuple([signed_hash(t) for t in toks]))
+            h = v.node_hash[i]
+            if h is None:
+                h = hashlib_hash(tuple([signed_hash(t) for t in toks]))
             node = _GraphNode(GeneMer._from_parts(canon, rc, int(n_fdir[i]), h))
             node.nodeCoverage = int(n_cov[i])
             node._component_ID = int(n_comp[i])
@@ -1627,30 +1662,33 @@ class GeneMerGraph(BubblePopping):
             out[h] = (bool(is_anchor), bool(singleton_all), flags)
         return out
 
-    def get_AMR_anchors(self, AMRNodes):
+    def get_AMR_anchors(self, AMRNodes, _stats=None):
         """anchor selection (:2629-2691), including the reference's use of FORWARD neighbours
-        for both sides of the first test."""
+        for both sides of the first test.  _stats: {hash: (stopped at an anchor occurrence, all(singletons), number of
+        terminal flags, number of True ones)} when the caller has walked the reads already (native clustering)."""
         if not self._host_edits:
             AMRNodes = list(AMRNodes)
             amr_set = set(AMRNodes)
-            stats = self._amr_occurrence_stats(AMRNodes)
+            if _stats is None:
+                _stats = {h: (a, s_, len(f), f.count(True))
+                          for h, (a, s_, f) in self._amr_occurrence_stats(AMRNodes).items()}
             anchors = set()
             for h in AMRNodes:                      # the same add() sequence as the loop below
                 node = self.get_node_by_hash(h)
                 forward = self.get_forward_neighbors(node)
                 if len([n for n in forward if n.__hash__() != h]) == 0:
                     anchors.add(h)
-                is_anchor, singleton_all, flags = stats[h]
+                is_anchor, singleton_all, n_flags, n_true = _stats[h]
                 if is_anchor:
                     anchors.add(h)
-                if singleton_all or all(flags):
+                if singleton_all or n_true == n_flags:
                     fw_amr = [n for n in forward if n.__hash__() in amr_set]
                     bw_amr = [n for n in self.get_backward_neighbors(node) if n.__hash__() in amr_set]
                     if len(bw_amr) == 0 or len(fw_amr) == 0:
                         anchors.add(h)
             for h in AMRNodes:
-                flags = stats[h][2]
-                if flags and flags.count(True) / len(flags) > 0.3:
+                n_flags, n_true = _stats[h][2], _stats[h][3]
+                if n_flags and n_true / n_flags > 0.3:
                     anchors.add(h)
             return anchors
         readNodes = self.get_readNodes()
@@ -1744,6 +1782,14 @@ class GeneMerGraph(BubblePopping):
         complements) are matched against all reads in one device call.  A read supports a
         window if the window occurs in it in either orientation; reads without nodes (< k
         genes) are not in gene_call_subset and do not count."""
+        combs, uniq = self._sublist_windows(lst, geneOfInterest)
+        hits = self._match_gene_lists([list(c) for c in uniq] +
+                                      [self.reverse_list_of_genes(list(c)) for c in uniq])
+        return self._sublists_from_hits(combs, uniq, hits[:len(uniq)], hits[len(uniq):], gene_call_subset, threshold)
+
+    def _sublist_windows(self, lst, geneOfInterest):
+        """the windows of a block's gene path that hold every copy of the gene, in the reference's order (:296-310),
+        and the distinct ones among them"""
         plus, minus = f"+{geneOfInterest}", f"-{geneOfInterest}"
         wanted = lst.count(plus) + lst.count(minus)
         combs = []
@@ -1752,9 +1798,9 @@ class GeneMerGraph(BubblePopping):
                 comb = tuple(lst[start:start + i])
                 if comb.count(plus) + comb.count(minus) == wanted:
                     combs.append(comb)
-        uniq = list(dict.fromkeys(combs))
-        hits = self._match_gene_lists([list(c) for c in uniq] +
-                                      [self.reverse_list_of_genes(list(c)) for c in uniq])
+        return combs, list(dict.fromkeys(combs))
+
+    def _sublists_from_hits(self, combs, uniq, fwd_hits, rev_hits, gene_call_subset, threshold):
         memo = getattr(self, "_subset_rows_memo", None)   # (the blocks of one gene come with the same subset)
         if memo is not None and memo[0] is gene_call_subset and memo[1] == len(gene_call_subset):
             in_subset = memo[2]
@@ -1766,7 +1812,7 @@ class GeneMerGraph(BubblePopping):
             self._subset_rows_memo = (gene_call_subset, len(gene_call_subset), in_subset)
         support = {}
         for j, comb in enumerate(uniq):
-            reads = np.union1d(hits[j][0], hits[j + len(uniq)][0])
+            reads = np.union1d(fwd_hits[j][0], rev_hits[j][0])
             support[comb] = int(in_subset[reads].sum())
         sublists = {}
         for comb in combs:
@@ -1798,9 +1844,15 @@ class GeneMerGraph(BubblePopping):
                 got = spelled[f] = self.get_genes_in_unitig(list(f))
             return got
 
-        for f in full_blocks:
-            options = self.get_all_sublists(genes_of(f), gene_call_subset, threshold,
-                                            geneOfInterest, cores)
+        # the windows of ALL blocks go to the device in one batch (the reference asks block by block, :2741-2746)
+        plans = [(f,) + self._sublist_windows(genes_of(f), geneOfInterest) for f in full_blocks]
+        fwd_lists = [list(c) for _, _, uniq in plans for c in uniq]
+        hits = self._match_gene_lists(fwd_lists + [self.reverse_list_of_genes(x) for x in fwd_lists]) if fwd_lists else []
+        at, n_all = 0, len(fwd_lists)
+        for f, combs, uniq in plans:
+            options = self._sublists_from_hits(combs, uniq, hits[at:at + len(uniq)],
+                                               hits[n_all + at:n_all + at + len(uniq)], gene_call_subset, threshold)
+            at += len(uniq)
             if len(options) > 0:
                 gene_blocks[f] = options
         filtered_blocks = filter_blocks({f: full_blocks[f] for f in gene_blocks})
@@ -2036,6 +2088,7 @@ class GeneMerGraph(BubblePopping):
             names = names_of[rows].tolist()
             reads.update(names)
             row_of.update(zip(names, rows.tolist()))
+        self._known_rows.update(row_of)
         return reads, np.fromiter((row_of[r] for r in reads), dtype=np.int64, count=len(reads))
 
     def _cluster_gene_native(self, geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
@@ -2049,7 +2102,6 @@ class GeneMerGraph(BubblePopping):
         hashes = [v.hash_at(i) for i in node_ids]
         reads_with_gene, rows = self._reads_on_nodes(node_ids)
         threshold = mean_node_coverage / 20
-        anchors = self.get_AMR_anchors(hashes)
         # the reads' node lists, laid end to end
         tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
         a = offs[rows]
@@ -2058,6 +2110,9 @@ class GeneMerGraph(BubblePopping):
         np.cumsum(n, out=starts[1:])
         within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], n)
         seq = tok_node[np.repeat(a, n) + within]
+        st = _clustering.anchor_stats(seq, starts, np.argsort(rows, kind="stable"), node_ids, len(v.alive))
+        anchors = self.get_AMR_anchors(hashes, _stats={h: (bool(x[0]), bool(x[1]), int(x[2]), int(x[3]))
+                                                       for h, x in zip(hashes, st.tolist())})
         uniq = np.unique(seq)
         uniq = uniq[uniq >= 0]
         nh = v.node_hash_table(uniq)

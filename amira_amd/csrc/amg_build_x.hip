@@ -266,11 +266,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
 // that gene in the tuple read along the gene's own strand: the up to k gene-mers of a genome that share a
 // minimiser g hold g at k different positions, so every one of them sits in its FIRST slot (p0 is a function of
 // the canonical tuple alone: the key decides where it lives, whatever the orientation of the read).  Whatever
-// does not find room within AMG_BUCKET_PROBES slots of its line (error gene-mers, genes in many copies) goes to its
+// does not find its slot free or its own (AMG_BUCKET_PROBES = 1 slot looked at; error gene-mers, genes in many copies) goes to its
 // hashed slot as before.  A thread's four windows lie 256 apart, so the 64 lanes of one probe instruction look at
 // 64 consecutive windows: ~64 * 2 / (k + 1) distinct lines instead of 64.
 #ifndef AMG_BUCKET_PROBES
-#define AMG_BUCKET_PROBES 3
+#define AMG_BUCKET_PROBES 1  // measured on cfg 3 (first build / rebuild, ms): 1: 0.92 / 0.35, 2: 0.97 / 0.36, 3: 1.00 / 0.37, 8: 1.16 / 0.43
 #endif
 template <bool TWO, int K, bool B16, bool HEAD = false>
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(

@@ -516,6 +516,64 @@ extern "C" int amg_cluster_full_blocks(const int32_t* seq, const int64_t* seq_of
   return AMG_OK;
 }
 
+// What the read loop of get_AMR_anchors (construct_graph.py:2644-2676) finds out about every AMR node, from the node ids
+// of the windows of the reads that hold the gene.  The loop walks a node's reads in read order and its positions on
+// a read in ascending order, i.e. the node's occurrences in ascending token order; every occurrence is one of: the
+// only window of its read (flag True, stop), a terminal window (flag True), an interior window with a non-AMR
+// neighbour (anchor, stop), an interior window between AMR nodes (flag False).  read_order: the reads of seq in
+// ascending order of their rows in the read set (seq itself follows the iteration order of a Python set).
+// out[4 i ..]: {stopped at an anchor occurrence, all(singletons), number of flags, number of True flags} of amr_ids[i].
+extern "C" int amg_cluster_anchor_stats(const int32_t* seq, const int64_t* seq_off, int64_t n_reads,
+                                        const int64_t* read_order, const int32_t* amr_ids, int32_t n_amr,
+                                        int64_t n_nodes, int32_t* out) {
+  if (!seq_off || !out || (n_amr > 0 && !amr_ids) || n_reads < 0) return amg_fail(AMG_E_ARG, "amg_cluster_anchor_stats: bad argument");
+  std::vector<int32_t> slot((size_t)(n_nodes > 0 ? n_nodes : 1), -1);
+  for (int i = 0; i < n_amr; ++i) {
+    if (amr_ids[i] < 0 || amr_ids[i] >= n_nodes) return amg_fail(AMG_E_ARG, "amg_cluster_anchor_stats: node id out of range");
+    slot[amr_ids[i]] = i;
+  }
+  struct St {
+    bool stopped = false, anchor = false, any = false, first_single = false;
+    int32_t flags = 0, yes = 0;
+  };
+  std::vector<St> st((size_t)n_amr);
+  auto amr = [&](int32_t v) { return v >= 0 && v < n_nodes && slot[v] >= 0; };
+  for (int64_t x = 0; x < n_reads; ++x) {
+    const int64_t r = read_order ? read_order[x] : x;
+    if (r < 0 || r >= n_reads) return amg_fail(AMG_E_ARG, "amg_cluster_anchor_stats: bad read order");
+    const int32_t* s = seq + seq_off[r];
+    const int64_t n = seq_off[r + 1] - seq_off[r];
+    for (int64_t i = 0; i < n; ++i) {
+      if (!amr(s[i])) continue;
+      St& a = st[slot[s[i]]];
+      const int kind = n == 1 ? 3 : (i == 0 || i == n - 1) ? 1 : (!amr(s[i - 1]) || !amr(s[i + 1])) ? 2 : 0;
+      if (!a.any) {
+        a.any = true;
+        a.first_single = kind == 3;
+      }
+      if (a.stopped) continue;
+      if (kind >= 2) {
+        a.stopped = true;
+        if (kind == 2) a.anchor = true;
+        else {
+          ++a.flags;
+          ++a.yes;
+        }
+      } else {
+        ++a.flags;
+        a.yes += kind == 1;
+      }
+    }
+  }
+  for (int i = 0; i < n_amr; ++i) {
+    out[4 * i] = st[i].anchor ? 1 : 0;
+    out[4 * i + 1] = (!st[i].any || st[i].first_single) ? 1 : 0;
+    out[4 * i + 2] = st[i].flags;
+    out[4 * i + 3] = st[i].yes;
+  }
+  return AMG_OK;
+}
+
 extern "C" int amg_cluster_blocks_sizes(const amg_blocks* b, int64_t* n_blocks, int64_t* n_ids) {
   if (!b || !n_blocks || !n_ids) return amg_fail(AMG_E_ARG, "amg_cluster_blocks_sizes: null argument");
   *n_blocks = (int64_t)b->res.off.size() - 1;

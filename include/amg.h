@@ -326,6 +326,11 @@ typedef struct amg_blocks amg_blocks;
 int amg_cluster_full_blocks(const int32_t* seq, const int64_t* seq_off, int64_t n_reads,
                             const int32_t* anchors, const int32_t* anchor_rank, int32_t n_anchors,
                             const int64_t* py_hash, int64_t n_nodes, int64_t none_hash, amg_blocks** out);
+/* the read loop of get_AMR_anchors (construct_graph.py:2644-2676) over the same seq / seq_off: per AMR node
+ * out[4 i ..] = {stopped at an anchor occurrence, all(singletons), flags, True flags}; read_order: the reads of seq
+ * in ascending order of their rows in the read set (NULL: seq is in that order already) */
+int amg_cluster_anchor_stats(const int32_t* seq, const int64_t* seq_off, int64_t n_reads, const int64_t* read_order,
+                             const int32_t* amr_ids, int32_t n_amr, int64_t n_nodes, int32_t* out);
 int amg_cluster_blocks_sizes(const amg_blocks* blocks, int64_t* n_blocks, int64_t* n_ids);
 int amg_cluster_blocks_get(const amg_blocks* blocks, int64_t* block_off, int32_t* block_ids);
 int amg_cluster_blocks_free(amg_blocks* blocks);

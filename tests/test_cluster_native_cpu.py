@@ -105,3 +105,55 @@ def test_native_blocks_equal_the_python_block_search_with_masked_nodes():
         assert got == list(want)
         compared += len(want)
     assert compared > 2000
+
+
+def test_native_anchor_stats_equal_the_reference_read_loop():
+    """amg_cluster_anchor_stats against the read loop of get_AMR_anchors (construct_graph.py:2644-2676) written out
+    per node: reads in read order, positions ascending, stop at a single-window read or at an interior occurrence
+    with a non-AMR neighbour"""
+    from amira_amd import clustering
+    rng = random.Random(99)
+    for _ in range(400):
+        n_nodes = rng.randint(3, 30)
+        reads = []
+        for _ in range(rng.randint(1, 40)):
+            n = rng.choice([1, 1, 2, 3, 5, 9, 20])
+            reads.append([rng.choice([-2] + list(range(n_nodes))) for _ in range(n)])
+        amr = rng.sample(range(n_nodes), rng.randint(1, min(6, n_nodes)))
+        amr_set = set(amr)
+        want = []
+        for h in amr:
+            flags, singletons, is_anchor = [], [], False
+            for on_read in reads:
+                if h not in on_read:
+                    continue
+                if len(on_read) == 1 and on_read[0] == h:
+                    singletons.append(True)
+                    flags.append(True)
+                    break
+                singletons.append(False)
+                for idx, x in enumerate(on_read):
+                    if x != h:
+                        continue
+                    if idx == 0 or idx == len(on_read) - 1:
+                        flags.append(True)
+                        continue
+                    if on_read[idx - 1] not in amr_set or on_read[idx + 1] not in amr_set:
+                        is_anchor = True
+                        break
+                    flags.append(False)
+                if is_anchor:
+                    break
+            # all(singletons) as the vectorised product code states it: no occurrence at all, or the first is a
+            # single-window read (then the loop stopped there)
+            want.append([int(is_anchor), int(all(singletons)), len(flags), flags.count(True)])
+        # the reads reach the native code in another order (a Python set's), with the permutation back to read order
+        perm = list(range(len(reads)))
+        rng.shuffle(perm)
+        shuffled = [reads[i] for i in perm]
+        order = np.argsort(np.asarray(perm), kind="stable")
+        seq = np.asarray([x for r in shuffled for x in r], np.int32)
+        off = np.zeros(len(shuffled) + 1, np.int64)
+        np.cumsum([len(r) for r in shuffled], out=off[1:])
+        got = clustering.anchor_stats(seq, off, order, amr, n_nodes)
+        assert got.tolist() == want
