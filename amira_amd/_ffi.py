@@ -53,6 +53,7 @@ def _load():
         "amg_stream": (P, [P]),
         "amg_set_reads": (C.c_int, [P, P, P, I64, I32, C.c_int]),
         "amg_set_positions": (C.c_int, [P, P, P, P, C.c_int]),
+        "amg_set_positions32": (C.c_int, [P, P, P, P, C.c_int]),
         "amg_set_read_lengths": (C.c_int, [P, P, C.c_int]),
         "amg_build": (C.c_int, [P, I32]),
         "amg_build_filtered": (C.c_int, [P, C.c_int32, C.c_uint32, C.c_uint32]),
@@ -74,6 +75,7 @@ def _load():
         "amg_get_reads_to_correct": (C.c_int, [P, P]),
         "amg_correct_reads": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
         "amg_get_corrected": (C.c_int, [P, P, P, P, P, P, P]),
+        "amg_get_corrected32": (C.c_int, [P, P, P, P, P, P, P, P, C.POINTER(I64)]),
         "amg_adopt_corrected": (C.c_int, [P]),
         "amg_set_reads_from_corrected": (C.c_int, [P, P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),

@@ -185,6 +185,22 @@ class _GraphNode(Node):
         self._bw = value
 
 
+class _LazyArrays(dict):
+    """the device arrays of a view by name; an array that is big and rarely wanted is fetched by its maker the first
+    time it is asked for (a maker returns {name: array} for everything it fetched)"""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.makers = {}
+
+    def __missing__(self, key):
+        maker = self.makers.get(key)
+        if maker is None:
+            raise KeyError(key)
+        self.update(maker())
+        return dict.__getitem__(self, key)
+
+
 class _HashToId:
     """{node hash: device node id} over the nodes of a view; hashes the view has not made yet are settled by making
     every node (see _View)."""
@@ -228,6 +244,8 @@ class _View:
         """cut the view's own reference cycles (its makers close over it) so that it is freed the moment its graph lets
         go of it, not when the cyclic collector next walks the heap; called when the graph is closed"""
         self._make_node = self._make_edge = self.node_of_hash = self._hash_node = None
+        if isinstance(self.arrays, _LazyArrays):
+            self.arrays.makers.clear()   # (they hold the engine)
         self.readNodes = self.readNodeDirections = self.readNodePositions = None
         for node in self._nodes.values():   # (the nodes made so far)
             if isinstance(node, _GraphNode):
@@ -621,13 +639,16 @@ class GeneMerGraph(BubblePopping):
             return self._view
         eng, vocab, k = self._engine, self._vocab, self._kmerSize
         nodes, edges = eng.nodes(), eng.edges()
-        tok_node, tok_dir = eng.read_nodes()
+        tok_node = eng.read_node_ids()
         adj_off, adj_edge = eng.node_adj()
-        nr_off, nr_idx = eng.node_reads()
         v = _View()
         v._nh_table = None
-        v.arrays = {"nodes": nodes, "edges": edges, "tok_node": tok_node, "tok_dir": tok_dir,
-                    "node_reads_off": nr_off, "node_reads": nr_idx}
+        # the window directions (60 MB per million reads) and the node -> reads lists (computed on the device for ALL
+        # nodes, 4 bytes per window) are fetched when somebody asks for them: read-path clustering needs neither
+        arrays = v.arrays = _LazyArrays({"nodes": nodes, "edges": edges, "tok_node": tok_node})
+        arrays.makers["tok_dir"] = lambda: {"tok_dir": eng.read_dirs()}
+        arrays.makers["node_reads_off"] = arrays.makers["node_reads"] = \
+            lambda: dict(zip(("node_reads_off", "node_reads"), eng.node_reads()))
         D, E = len(nodes["coverage"]), len(edges["coverage"])
         v.alive = n_alive = nodes["alive"]
         v.node_hash = [None] * D
@@ -677,7 +698,8 @@ class GeneMerGraph(BubblePopping):
             node = _GraphNode(GeneMer._from_parts(canon, rc, int(n_fdir[i]), h))
             node.nodeCoverage = int(n_cov[i])
             node._component_ID = int(n_comp[i])
-            node._lazy(lambda a=int(nr_off[i]), b=int(nr_off[i + 1]): [read_ids[r] for r in nr_idx[a:b].tolist()])
+            node._lazy(lambda i=i: [read_ids[r] for r in
+                                    arrays["node_reads"][arrays["node_reads_off"][i]:arrays["node_reads_off"][i + 1]].tolist()])
             node._amg_id = i
             lo, mid, hi = int(adj_off[2 * i]), int(adj_off[2 * i + 1]), int(adj_off[2 * i + 2])
             node._lazy_edges(edge_list(lo, mid), edge_list(mid, hi))
@@ -711,7 +733,7 @@ class GeneMerGraph(BubblePopping):
 
         def make_dirs(r):
             a, n, ids = window_ids(r)
-            return [d if x >= 0 else None for d, x in zip(tok_dir[a:a + n].tolist(), ids)]
+            return [d if x >= 0 else None for d, x in zip(arrays["tok_dir"][a:a + n].tolist(), ids)]
 
         gs_all, ge_all = self._gs, self._ge
 
@@ -2072,24 +2094,38 @@ class GeneMerGraph(BubblePopping):
         self._tree_rows = rows
         return Tree.from_flat(keys, seqs, flat, all_starts, lambda x: -2 if x is None else to_id.get(x))
 
+    def _any_read_name_ends_with(self, suffix):
+        if isinstance(self._reads, TokenizedReads):
+            return self._reads.any_name_ends_with(suffix)
+        memo = self.__dict__.setdefault("_suffix_memo", {})
+        if suffix not in memo:
+            memo[suffix] = any(r.endswith(suffix) for r in self._read_ids)
+        return memo[suffix]
+
     def _reads_on_nodes(self, node_ids):
         """collect_reads_in_path (:1497-1504) for nodes given by device id, with the rows of the reads: the SET of read
         names is made by the same update() calls, node by node — the order in which it iterates later is the order of
         the reference's set — and the rows come out of the node -> reads lists themselves, not out of a name -> row
         table of the whole read set"""
         v = self._v()
-        nr_off, nr_idx = v.arrays["node_reads_off"], v.arrays["node_reads"]
         names_of = self._read_ids_array()
-        reads, row_of = set(), {}
-        for i in node_ids:
-            if not v.alive[i]:
-                continue
-            rows = nr_idx[nr_off[i]:nr_off[i + 1]]
+        node_ids = [i for i in node_ids if v.alive[i]]
+        # the reads of these few nodes by one batched device search over the per-window node ids (k_match with
+        # one-node patterns: hits ordered by node, read, position) — not the node -> reads lists of every node
+        off, hit_read, _ = self._engine.match_patterns(1, [[i] for i in node_ids])
+        off = off.tolist()
+        reads, all_names, all_rows = set(), [], []
+        for j in range(len(node_ids)):
+            rows = hit_read[off[j]:off[j + 1]]
+            if len(rows) > 1:
+                rows = rows[np.concatenate([[True], rows[1:] != rows[:-1]])]   # a read once per node, in read order
             names = names_of[rows].tolist()
             reads.update(names)
-            row_of.update(zip(names, rows.tolist()))
+            all_names += names
+            all_rows += rows.tolist()
+        row_of = dict(zip(all_names, all_rows))
         self._known_rows.update(row_of)
-        return reads, np.fromiter((row_of[r] for r in reads), dtype=np.int64, count=len(reads))
+        return reads, np.asarray(list(map(row_of.__getitem__, reads)), dtype=np.int64)
 
     def _cluster_gene_native(self, geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
                              path_reads):
@@ -2147,10 +2183,12 @@ class GeneMerGraph(BubblePopping):
         clustered_reads, path_reads = {}, {}
         if mean_node_coverage is None:
             mean_node_coverage = self.get_mean_node_coverage()
-        native = (not self._host_edits and hasattr(Tree, "from_flat") and isinstance(self._reads, TokenizedReads)
-                  and not os.environ.get("AMG_CLUSTER_PYTHON") and _clustering.emulation_ok())
+        # (a read really called "<name>_reverse" would collide with the reference's name for a reversed read: the
+        # Python block search, which carries the names around as the reference does, keeps such inputs)
+        native = (not self._host_edits and hasattr(Tree, "from_flat") and not os.environ.get("AMG_CLUSTER_PYTHON")
+                  and _clustering.emulation_ok() and not self._any_read_name_ends_with("_reverse"))
         for geneOfInterest in listOfGenes:
-            if native and not self._reads.any_name_ends_with("_reverse"):
+            if native:
                 self._cluster_gene_native(geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
                                           path_reads)
                 continue

@@ -276,6 +276,7 @@ extern "C" int amg_set_positions(amg_ctx* c, const int64_t* gene_start, const in
   AMGCHK(copy_in(c, c->gene_end, gene_end, (size_t)c->n_tokens * sizeof(int64_t), on_device));
   c->have_pos = true;
   c->pos_identity = true;
+  c->pos0_own = false;
   c->pos_n0 = c->n_tokens;
   c->pos1_used = c->c_pos1_used = 0;
   c->have_corrected = false;

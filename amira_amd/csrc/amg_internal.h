@@ -204,6 +204,7 @@ struct amg_ctx {
 
   // ---- corrected read set (output of amg_correct_reads)
   bool have_corrected = false;
+  bool pos0_own = false;  // pool 0 of the positions is the engine's own compaction, not the caller's arrays any more
   int64_t c_reads = 0, c_tokens = 0;
   DevBuf c_tokens_buf, c_read_off, c_orig, c_changed, c_gstart, c_gend, c_read_len;
 

@@ -2458,6 +2458,162 @@ extern "C" int amg_get_corrected(amg_ctx* c, int32_t* tokens, int64_t* read_offs
   return AMG_OK;
 }
 
+// ---- 32-bit positions at the boundary.  Read coordinates fit 32 bits; the position arrays are four fifths of what a
+// cleaning sweep moves over PCIe (16 of 20 bytes per gene).  amg_set_positions32 takes them as int32 (widened on the
+// device into the engine's own arrays); amg_get_corrected32 hands back, for every corrected read, WHERE its positions
+// are — a slice of the caller's own arrays for a read that was left alone or only trimmed, new values (int32, laid end
+// to end) only for the reads whose positions the carry-over produced.
+__global__ void k_widen_pos(const int* __restrict__ s32, const int* __restrict__ e32, long long n,
+                            long long* __restrict__ s64, long long* __restrict__ e64) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    s64[i] = (long long)s32[i];
+    e64[i] = (long long)e32[i];
+  }
+}
+
+extern "C" int amg_set_positions32(amg_ctx* c, const int32_t* gene_start, const int32_t* gene_end,
+                                   const int64_t* read_len, int on_device) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
+  if (!gene_start || !gene_end) return amg_fail(AMG_E_ARG, "null positions");
+  if (on_device != 0 && on_device != 1) return amg_fail(AMG_E_ARG, "amg_set_positions32: on_device is 0 or 1 (the arrays are widened, never borrowed)");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const long long T = c->n_tokens;
+  const int* d_s = gene_start;
+  const int* d_e = gene_end;
+  if (!on_device) {  // staged in the buffers the read-back of a correction uses (free until then)
+    AMGCHK(c->c_gstart.ensure((size_t)(T + 64) * sizeof(long long)));
+    AMGCHK(c->c_gend.ensure((size_t)(T + 64) * sizeof(long long)));
+    if (T > 0) {
+      HIPCHK(hipMemcpyAsync(c->c_gstart.p, gene_start, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->c_gend.p, gene_end, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    d_s = c->c_gstart.as<int>();
+    d_e = c->c_gend.as<int>();
+  }
+  c->gene_start.unborrow();
+  c->gene_end.unborrow();
+  AMGCHK(c->gene_start.ensure((size_t)(T + 64) * sizeof(long long)));
+  AMGCHK(c->gene_end.ensure((size_t)(T + 64) * sizeof(long long)));
+  if (T > 0)
+    hipLaunchKernelGGL(k_widen_pos, dim3(nblk(T, 1024) < 4096u ? nblk(T, 1024) : 4096u), dim3(256), 0, st, d_s, d_e, T,
+                       c->gene_start.as<long long>(), c->gene_end.as<long long>());
+  c->have_pos = true;
+  c->pos_identity = true;
+  c->pos0_own = false;
+  c->pos_n0 = T;
+  c->pos1_used = c->c_pos1_used = 0;
+  c->have_corrected = false;
+  c->have_read_len = false;
+  if (read_len) {
+    c->read_len.unborrow();
+    AMGCHK(c->read_len.ensure((size_t)c->n_reads * sizeof(int64_t) + 64));
+    if (c->n_reads > 0)
+      HIPCHK(hipMemcpyAsync(c->read_len.p, read_len, (size_t)c->n_reads * sizeof(int64_t),
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    c->have_read_len = true;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
+// per corrected read: number of positions the carry-over produced for it (0: its positions are a slice of the caller's)
+// (own: indices below it are the CALLER's arrays — 0 once amg_adopt_corrected has compacted the pools into arrays of
+// the engine's own, after which every read's positions travel)
+__global__ void k_new_pos_len(const long long* __restrict__ c_off, const long long* __restrict__ c_posoff, long long own,
+                              long long c_reads, long long* __restrict__ len) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < c_reads) len[q] = c_posoff[q] >= own ? c_off[q + 1] - c_off[q] : 0;
+}
+
+__global__ __launch_bounds__(256) void k_gather_new_positions32(CorrArgs a, const long long* __restrict__ c_off,
+                                                                const long long* __restrict__ c_posoff, long long c_reads,
+                                                                const long long* __restrict__ new_off,
+                                                                long long* __restrict__ pos_src, int* __restrict__ o_gs,
+                                                                int* __restrict__ o_ge, unsigned long long* too_wide,
+                                                                long long own) {
+  const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= c_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = c_posoff[q];
+  if (off < own) {
+    if (lane == 0) pos_src[q] = off;
+    return;
+  }
+  const long long n = c_off[q + 1] - c_off[q], at = new_off[q];
+  if (lane == 0) pos_src[q] = -1 - at;
+  const long long *gs, *ge;
+  pos_base(a, off, gs, ge);
+  bool wide = false;
+  for (long long i = lane; i < n; i += 64) {
+    const long long s = gs[i], e = ge[i];
+    wide = wide || s != (long long)(int)s || e != (long long)(int)e;
+    o_gs[at + i] = (int)s;
+    o_ge[at + i] = (int)e;
+  }
+  if (wide) *too_wide = 1ull;
+}
+
+extern "C" int amg_get_corrected32(amg_ctx* c, int32_t* tokens, int64_t* read_offsets, int32_t* orig_read,
+                                   uint8_t* changed, int64_t* pos_src, int32_t* new_start, int32_t* new_end,
+                                   int64_t* n_new) {
+  if (!c) return amg_fail(AMG_E_ARG, "null ctx");
+  if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
+  if (!pos_src || !n_new) return amg_fail(AMG_E_ARG, "amg_get_corrected32: pos_src and n_new are required");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const long long R = c->c_reads;
+  *n_new = 0;
+  auto get = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (!dst || !bytes) return AMG_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    return AMG_OK;
+  };
+  AMGCHK(get(tokens, c->c_tokens_buf.p, (size_t)c->c_tokens * sizeof(int32_t)));
+  AMGCHK(get(read_offsets, c->c_read_off.p, (size_t)(R + 1) * sizeof(int64_t)));
+  AMGCHK(get(orig_read, c->c_orig.p, (size_t)R * sizeof(int32_t)));
+  AMGCHK(get(changed, c->c_changed.p, (size_t)R));
+  if (!c->have_pos || R == 0) {
+    HIPCHK(hipStreamSynchronize(st));
+    return c->have_pos ? AMG_OK : amg_fail(AMG_E_STATE, "amg_get_corrected32: no positions were set");
+  }
+  // lengths -> offsets of the new positions (s1: lengths + their prefix, s2: pos_src), then one gather
+  AMGCHK(c->s1.ensure((size_t)(2 * R + 4) * sizeof(long long)));
+  AMGCHK(c->s2.ensure((size_t)(R + 2) * sizeof(long long)));
+  AMGCHK(c->c_gstart.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+  AMGCHK(c->c_gend.ensure((size_t)(c->c_tokens + 64) * sizeof(long long)));
+  long long* len = c->s1.as<long long>();
+  long long* off = len + (R + 2);
+  CorrArgs a;
+  memset(&a, 0, sizeof(a));
+  fill_pos_args(c, a);
+  unsigned long long* flag = c->status.as<unsigned long long>() + ST_MISC;
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(len + R, 0, sizeof(long long), st));
+  const long long own = c->pos0_own ? 0 : a.n0;
+  hipLaunchKernelGGL(k_new_pos_len, dim3(nblk(R, 256)), dim3(256), 0, st, c->c_read_off.as<long long>(),
+                     c->c_pos_off.as<long long>(), own, R, len);
+  AMGCHK(prim_exscan_i64(c, len, off, (size_t)R + 1));
+  hipLaunchKernelGGL(k_gather_new_positions32, dim3(nblk(R, 4)), dim3(256), 0, st, a, c->c_read_off.as<long long>(),
+                     c->c_pos_off.as<long long>(), R, off, c->s2.as<long long>(), c->c_gstart.as<int>(),
+                     c->c_gend.as<int>(), flag, own);
+  unsigned long long h[2] = {0, 0};
+  {
+    FetchList l;
+    l.add(off + R);
+    l.add(flag);
+    AMGCHK(fetch(c, l, h));
+  }
+  if (h[1]) return amg_fail(AMG_E_ARG, "amg_get_corrected32: a position does not fit 32 bits (amg_get_corrected returns 64-bit positions)");
+  *n_new = (int64_t)h[0];
+  AMGCHK(get(pos_src, c->s2.p, (size_t)R * sizeof(int64_t)));
+  AMGCHK(get(new_start, c->c_gstart.p, (size_t)h[0] * sizeof(int32_t)));
+  AMGCHK(get(new_end, c->c_gend.p, (size_t)h[0] * sizeof(int32_t)));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
 extern "C" int amg_adopt_corrected(amg_ctx* c) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
@@ -2488,6 +2644,7 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
       std::swap(c->gene_start, c->c_gstart);
       std::swap(c->gene_end, c->c_gend);
       compacted = true;
+      c->pos0_own = true;  // pool 0 is no longer what the caller handed over (amg_get_corrected32)
     }
   }
   for (DevBuf* b : {&c->tokens, &c->read_off, &c->read_len}) b->unborrow();
@@ -2543,6 +2700,7 @@ extern "C" int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src) {
                          dst->gene_end.as<long long>());
     }
     dst->have_pos = true;
+    dst->pos0_own = true;  // gathered here: not arrays any caller holds
     dst->pos_identity = true;
     dst->pos_n0 = T;
     dst->pos1_used = dst->c_pos1_used = 0;

@@ -45,10 +45,20 @@ class Engine:
                                      int(n_reads), int(two_v), 2 if borrow else 1))
 
     def set_positions(self, gene_start, gene_end, read_len=None):
+        """int32 arrays travel as they are (amg_set_positions32: half the bytes over PCIe), anything else as int64"""
+        rl = None if read_len is None else np.ascontiguousarray(read_len, dtype=np.int64)
+        if getattr(gene_start, "dtype", None) == np.int32 and getattr(gene_end, "dtype", None) == np.int32:
+            gs, ge = np.ascontiguousarray(gene_start), np.ascontiguousarray(gene_end)
+            check(_ffi.lib.amg_set_positions32(self._h, ptr(gs), ptr(ge), ptr(rl), 0))
+            return
         gs = np.ascontiguousarray(gene_start, dtype=np.int64)
         ge = np.ascontiguousarray(gene_end, dtype=np.int64)
-        rl = None if read_len is None else np.ascontiguousarray(read_len, dtype=np.int64)
         check(_ffi.lib.amg_set_positions(self._h, ptr(gs), ptr(ge), ptr(rl), 0))
+
+    def set_positions32_device(self, gs_ptr, ge_ptr, rl_ptr):
+        """int32 position arrays already on the device (copied and widened: the caller's arrays are free afterwards)"""
+        check(_ffi.lib.amg_set_positions32(self._h, C.c_void_p(gs_ptr), C.c_void_p(ge_ptr),
+                                           C.c_void_p(rl_ptr) if rl_ptr else None, 1))
 
     def set_read_lengths(self, read_len):
         rl = np.ascontiguousarray(read_len, dtype=np.int64)
@@ -152,6 +162,20 @@ class Engine:
         check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), ptr(d)))
         return node, d
 
+    def read_node_ids(self, buf=None):
+        """the node id per window alone (the directions stay on the device)"""
+        T = self.sizes()[1]
+        node = self._take(buf, "tok_node", (T,), np.int32)
+        check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), None))
+        return node
+
+    def read_dirs(self, buf=None):
+        """the gene-mer direction per window alone"""
+        T = self.sizes()[1]
+        d = self._take(buf, "tok_dir", (T,), np.int8)
+        check(_ffi.lib.amg_get_read_nodes(self._h, None, ptr(d)))
+        return d
+
     def node_adj(self):
         D, E, _ = self.graph_sizes()
         off, ids = np.empty(2 * D + 1, np.int64), np.empty(E, np.int32)
@@ -213,6 +237,22 @@ class Engine:
         check(_ffi.lib.amg_get_corrected(self._h, ptr(out["tokens"]), ptr(out["read_offsets"]),
                                          ptr(out["orig_read"]), ptr(out["changed"]), ptr(gs), ptr(ge)))
         out["gene_start"], out["gene_end"] = gs, ge
+        return out
+
+    def corrected32(self, n_reads, n_tokens, buf=None):
+        """the corrected set with 32-bit positions, only the NEW ones moved (amg_get_corrected32): pos_src[i] >= 0 — read
+        i's positions are the caller's own arrays from that index on; < 0 — new_start / new_end from -1 - pos_src[i] on"""
+        out = {"tokens": self._take(buf, "c_tokens", (n_tokens,), np.int32),
+               "read_offsets": self._take(buf, "c_read_offsets", (n_reads + 1,), np.int64),
+               "orig_read": self._take(buf, "c_orig_read", (n_reads,), np.int32),
+               "changed": self._take(buf, "c_changed", (n_reads,), np.uint8),
+               "pos_src": self._take(buf, "c_pos_src", (n_reads,), np.int64)}
+        ns = self._take(buf, "c_new_start", (n_tokens,), np.int32)
+        ne = self._take(buf, "c_new_end", (n_tokens,), np.int32)
+        n = C.c_int64(0)
+        check(_ffi.lib.amg_get_corrected32(self._h, ptr(out["tokens"]), ptr(out["read_offsets"]), ptr(out["orig_read"]),
+                                           ptr(out["changed"]), ptr(out["pos_src"]), ptr(ns), ptr(ne), C.byref(n)))
+        out["new_start"], out["new_end"] = ns[: n.value], ne[: n.value]
         return out
 
     def corrected_index(self, n_reads):

@@ -113,6 +113,10 @@ int amg_set_reads(amg_ctx* ctx, const int32_t* tokens, const int64_t* read_offse
  * reads keep pointing at the positions of their unchanged genes instead of copying them. */
 int amg_set_positions(amg_ctx* ctx, const int64_t* gene_start, const int64_t* gene_end,
                       const int64_t* read_len, int on_device);
+/* the same from 32-bit position arrays (read coordinates fit; half the bytes over PCIe): widened on the device into
+ * the engine's own arrays — on_device 0 (host) or 1 (device), never borrowed; read_len stays 64-bit */
+int amg_set_positions32(amg_ctx* ctx, const int32_t* gene_start, const int32_t* gene_end,
+                        const int64_t* read_len, int on_device);
 
 /* per-read sequence length only (len(fastq[read]["sequence"]), construct_graph.py:1685);
  * may be called any time before amg_correct_reads */
@@ -204,6 +208,15 @@ int amg_correct_reads(amg_ctx* ctx, int64_t* n_out_reads, int64_t* n_out_tokens)
 int amg_get_corrected(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets,
                       int32_t* orig_read, uint8_t* changed, int64_t* gene_start,
                       int64_t* gene_end);
+/* The same with 32-bit positions and no byte moved that the caller already has.  pos_src[i] >= 0: the positions of
+ * corrected read i are the caller's own (the arrays handed to amg_set_positions / amg_set_positions32) from index
+ * pos_src[i] on — a read left alone or only trimmed; pos_src[i] < 0: they are new_start / new_end from index
+ * -1 - pos_src[i] on (what the position carry-over produced, construct_graph.py:1314-1328, 1669-1691).
+ * new_start / new_end: room for the corrected genes (n_out_tokens); *n_new entries are written.  A position beyond
+ * 32 bits is an error (amg_get_corrected returns 64-bit positions). */
+int amg_get_corrected32(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets, int32_t* orig_read,
+                        uint8_t* changed, int64_t* pos_src, int32_t* new_start, int32_t* new_end,
+                        int64_t* n_new);
 /* the corrected read set becomes the current read set (device resident; the next
  * amg_build runs on it) — the rebuild of graph_utils.py:147-150,165 */
 int amg_adopt_corrected(amg_ctx* ctx);

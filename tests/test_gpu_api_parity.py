@@ -157,7 +157,7 @@ def test_pickle_round_trip():
     assert {r: list(v) for r, v in g3.get_readNodes().items()} == {r: list(v) for r, v in g2.get_readNodes().items()}
     back = pickle.loads(pickle.dumps(g))      # a filtered build keeps its filter
     assert list(back.get_nodes()) == list(g.get_nodes()) and back.get_reads_to_correct() == g.get_reads_to_correct()
-    for x in (q, q2, o, g, g2, g3, back):
+    for x in (q, q2, g, g2, g3, back):
         x.close()
 
 

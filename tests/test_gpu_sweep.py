@@ -204,3 +204,63 @@ def test_sweep_general_kernels(eng, monkeypatch, env):
     run_sweep(eng, reads, pos, fq, 5)
     reads, pos, fq = P.synth_inputs(13, 300, 40, 250, 0.02)
     run_sweep(eng, reads, pos, fq, 7)
+
+
+@pytest.mark.parametrize("seed,N,L,V,k,err", [(7, 400, 30, 300, 5, 0.03), (17, 800, 40, 150, 5, 0.05)])
+def test_positions_32_bit_at_the_boundary(seed, N, L, V, k, err):
+    """amg_set_positions32 / amg_get_corrected32: int32 positions in, and out only the positions the carry-over
+    produced — everything else named as a slice of the caller's own arrays; after TWO corrections (the second one's
+    input positions live partly in the engine's pool) the reconstruction equals the 64-bit read-back"""
+    from amira_amd import Engine, tokenize
+    reads, pos, fq = P.synth_inputs(seed, N, L, V, err)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64)
+    wide, narrow = Engine(0), Engine(0)
+    try:
+        for e, (s_, e_) in ((wide, (gs, ge)), (narrow, (gs.astype(np.int32), ge.astype(np.int32)))):
+            e.set_reads(toks, offs, vocab.two_v)
+            e.set_positions(s_, e_, rl)
+            e.build(k)
+            e.filter(3, 1)
+        for stage in range(2):
+            nw, nn = wide.correct_reads(), narrow.correct_reads()
+            assert nw == nn
+            want = wide.corrected(*nw, True)
+            got = narrow.corrected32(*nn)
+            for key in ("tokens", "read_offsets", "orig_read", "changed"):
+                assert np.array_equal(got[key], want[key]), key
+            o = got["read_offsets"]
+            n_own = 0
+            for i in range(nn[0]):
+                a, b = int(o[i]), int(o[i + 1])
+                src = int(got["pos_src"][i])
+                if src >= 0:      # a slice of the arrays this engine was given
+                    s_, e_ = gs[src:src + b - a], ge[src:src + b - a]
+                    n_own += 1
+                else:
+                    at = -1 - src
+                    s_, e_ = got["new_start"][at:at + b - a], got["new_end"][at:at + b - a]
+                assert np.array_equal(s_, want["gene_start"][a:b]) and np.array_equal(e_, want["gene_end"][a:b]), (stage, i)
+            assert 0 < n_own < nn[0]
+            if stage == 0:
+                for e in (wide, narrow):
+                    e.adopt_corrected()
+                    e.build(k)
+                    e.remove_short_linear_paths(k)
+        # a position beyond 32 bits on the way out is refused, not truncated
+        big = Engine(0)
+        try:
+            big.set_reads(toks, offs, vocab.two_v)
+            big.set_positions(gs + (1 << 33), ge + (1 << 33), rl + (1 << 34))
+            big.build(k)
+            big.filter(3, 1)
+            n = big.correct_reads()
+            with pytest.raises(Exception, match="32 bits"):
+                big.corrected32(*n)
+            assert big.corrected(*n, True)["gene_start"].max() > (1 << 33)
+        finally:
+            big.close()
+    finally:
+        wide.close()
+        narrow.close()
