@@ -96,6 +96,7 @@ def _load():
         "amg_calls_get": (C.c_int, [P, P, P, P, P, P]),
         "amg_calls_load_positions_json": (C.c_int, [P, C.c_char_p, P, P]),
         "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
+        "amg_calls_write_positions_json": (C.c_int, [C.c_char_p, P, P, P, I64, P]),
         "amg_calls_free": (C.c_int, [P]),
         "amg_cluster_full_blocks": (C.c_int, [P, P, I64, P, P, I32, P, I64, I64, C.POINTER(P)]),
         "amg_cluster_anchor_stats": (C.c_int, [P, P, I64, P, P, I32, I64, P]),

@@ -14,11 +14,19 @@
 // Checked bit for bit against the Python path in tests/test_calls_cpu.py (no GPU needed).
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <ctime>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "amg_internal.h"
 
@@ -241,6 +249,22 @@ struct Interner {
     slots.swap(bigger);
     mask = m;
   }
+  void reserve(size_t n_items, size_t n_bytes) {  // room for n_items names of n_bytes in all without growing
+    size_t want = slots.size();
+    while (want < n_items * 2 + 2) want *= 4;
+    if (want != slots.size()) {
+      slots.assign(want, -1);
+      mask = want - 1;
+      for (size_t id = 0; id < off.size(); ++id) {
+        size_t s = hash(&arena[off[id]], len[id]) & mask;
+        while (slots[s] >= 0) s = (s + 1) & mask;
+        slots[s] = (int32_t)id;
+      }
+    }
+    arena.reserve(n_bytes);
+    off.reserve(n_items);
+    len.reserve(n_items);
+  }
   int32_t intern(const char* b, size_t n) { return intern_h(b, n, hash(b, n)); }
   int32_t intern_h(const char* b, size_t n, uint64_t h) {
     size_t s = h & mask;
@@ -270,17 +294,79 @@ struct Interner {
   std::string name(size_t id) const { return std::string(&arena[off[id]], len[id]); }
 };
 
-bool slurp(const char* path, std::string& out, std::string& err) {
-  FILE* f = fopen(path, "rb");
-  if (!f) { err = std::string("cannot open ") + path; return false; }
-  fseek(f, 0, SEEK_END);
-  long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out.resize((size_t)n);
-  size_t got = n ? fread(&out[0], 1, (size_t)n, f) : 0;
-  fclose(f);
-  if ((long)got != n) { err = "short read"; return false; }
-  return true;
+int worker_count(size_t bytes);
+
+// the file in memory, read by several threads at once (each its own stretch, pread): a gigabyte of gene calls is in
+// memory in a fraction of a second, and — unlike a file mapping, whose first touch of every page is a fault served
+// one at a time in sandboxed kernels — the parsers then run on ordinary memory
+struct FileView {
+  const char* data = nullptr;
+  size_t size = 0;
+  std::unique_ptr<char[]> owned;   // (not a vector: no zero fill of a gigabyte that is about to be overwritten)
+  bool open(const char* path, std::string& err) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { err = std::string("cannot open ") + path; return false; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { ::close(fd); err = std::string("cannot stat ") + path; return false; }
+    size = (size_t)st.st_size;
+    owned.reset(new char[size + 1]);
+    data = owned.get();
+    const int workers = size ? worker_count(size) : 0;
+    std::vector<int> bad((size_t)std::max(workers, 1), 0);
+    std::vector<std::thread> th;
+    for (int w = 0; w < workers; ++w)
+      th.emplace_back([&, w] {
+        size_t at = size / (size_t)workers * (size_t)w;
+        const size_t end = w + 1 == workers ? size : size / (size_t)workers * (size_t)(w + 1);
+        while (at < end) {
+          const ssize_t n = pread(fd, owned.get() + at, end - at, (off_t)at);
+          if (n <= 0) { bad[(size_t)w] = 1; return; }
+          at += (size_t)n;
+        }
+      });
+    for (auto& t : th) t.join();
+    ::close(fd);
+    for (int b : bad)
+      if (b) { err = std::string("short read of ") + path; return false; }
+    return true;
+  }
+};
+
+int worker_count(size_t bytes) {
+  if (const char* e = getenv("AMG_CALLS_THREADS")) return std::max(1, atoi(e));
+  unsigned hw = std::thread::hardware_concurrency();
+  int n = (int)std::min<unsigned>(hw ? hw : 1, 32);
+  const int by_size = (int)(bytes >> 22) + 1;  // at least 4 MB of text per thread
+  return std::max(1, std::min(n, by_size));
+}
+
+// Cut the body of a {"key": [...], "key": [...]} object into `want` pieces at entry boundaries, found by their bytes as
+// json.dumps writes them: `], "` — the bracket that closes one entry's list, the comma, the quote that opens the next
+// key.  Inside a JSON string a quote is always escaped, so these four bytes can only MISLEAD when a string ends with
+// `], ` right before its closing quote; every piece is then parsed on its own terms and must consume exactly its bytes —
+// a cut in the wrong place fails that parse and the caller falls back to the single-threaded path.  A file written
+// with other separators simply yields one piece.  Pieces: [begin, end) with begin at a key's opening quote.
+std::vector<std::pair<const char*, const char*>> split_entries(const char* b, const char* e, int want) {
+  std::vector<std::pair<const char*, const char*>> out;
+  const char* at = b;
+  const size_t total = (size_t)(e - b);
+  for (int i = 1; i < want && at < e; ++i) {
+    const char* nominal = b + total / want * i;
+    if (nominal <= at) continue;
+    const char* q = nominal;
+    const char* cut = nullptr;
+    while (q + 4 <= e) {
+      q = static_cast<const char*>(memchr(q, ']', (size_t)(e - q - 3)));
+      if (!q) break;
+      if (q[1] == ',' && q[2] == ' ' && q[3] == '"') { cut = q; break; }
+      ++q;
+    }
+    if (!cut) break;
+    out.emplace_back(at, cut + 1);
+    at = cut + 3;
+  }
+  out.emplace_back(at, e);
+  return out;
 }
 }  // namespace
 
@@ -297,105 +383,202 @@ extern "C" int amg_calls_free(amg_calls* c) {
   return AMG_OK;
 }
 
+namespace {
+// what one thread makes of its piece of the file
+struct CallsPart {
+  Interner ids;                 // read ids of the piece, in file order
+  std::vector<int64_t> n_genes; // per read
+  Interner genes;               // gene names, local first-seen ids
+  std::vector<int32_t> gid;     // per gene occurrence: LOCAL name id
+  std::vector<int8_t> strand;
+  std::string error;            // non-empty: the piece did not parse
+  long long error_at = 0;
+};
+
+// entries `"read": ["+gene", ...]` separated by commas, up to the end of the reader's range (which must be reached)
+bool parse_call_entries(Reader& r, CallsPart& part, const char* file_begin) {
+  std::string key, owned, fixed;
+  auto fail = [&](const char* what) {
+    part.error = std::string(what) + (r.err.empty() ? "" : (": " + r.err));
+    part.error_at = (long long)(r.p - file_begin);
+    return false;
+  };
+  r.ws();
+  if (r.p >= r.end) return true;
+  do {
+    const char *kb, *ke;
+    if (!r.str_view(&kb, &ke, &key)) return fail("read id");
+    {
+      // json.load keeps the LAST value of a duplicated key at the FIRST key's position;
+      // gene-call files never repeat a read id, so this is rejected rather than emulated
+      const size_t before = part.ids.size();
+      const int32_t rid = part.ids.intern(kb, (size_t)(ke - kb));
+      if ((size_t)rid != before) return fail("duplicate read id");
+    }
+    if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
+    const size_t first_gene = part.gid.size();
+    if (!r.lit(']')) {
+      do {
+        // one pass over the gene string: closing quote, escapes, blanks and the hash of the name
+        // (construct_gene.py:49-65: strand = first char, name = rest with ' ' -> '_')
+        r.ws();
+        if (r.p >= r.end || *r.p != '"') { r.err = "expected string"; return fail("gene"); }
+        const char* gb = r.p + 1;
+        const char* q = gb;
+        uint64_t hsh = 1469598103934665603ull;
+        bool blank = true, has_space = false, plain = true;
+        if (q < r.end && *q != '"' && *q != '\\') { blank = blank && *q == ' '; ++q; }  // strand char: not hashed
+        while (q < r.end && *q != '"') {
+          const char ch = *q;
+          if (ch == '\\') { plain = false; break; }
+          if (ch == ' ') has_space = true; else blank = false;
+          hsh = (hsh ^ (unsigned char)(ch == ' ' ? '_' : ch)) * 1099511628211ull;
+          ++q;
+        }
+        const char* ge;
+        int32_t id;
+        if (plain && q < r.end) {
+          ge = q;
+          r.p = q + 1;
+          if (blank) return fail("Gene information is missing");
+          if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
+          if (ge - gb < 2) return fail("Gene name information missing for a gene");
+          hsh ^= hsh >> 29;
+          if (!has_space) {
+            id = part.genes.intern_h(gb + 1, (size_t)(ge - gb - 1), hsh);
+          } else {
+            fixed.assign(gb + 1, ge);
+            std::replace(fixed.begin(), fixed.end(), ' ', '_');
+            id = part.genes.intern_h(fixed.data(), fixed.size(), hsh);
+          }
+        } else {  // escapes (or a truncated file): the general string reader
+          if (!r.str(owned)) return fail("gene");
+          gb = owned.data();
+          ge = gb + owned.size();
+          blank = true;
+          has_space = false;
+          for (const char* t = gb; t < ge; ++t) {
+            if (*t == ' ') has_space = true; else blank = false;
+          }
+          if (blank) return fail("Gene information is missing");
+          if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
+          if (ge - gb < 2) return fail("Gene name information missing for a gene");
+          fixed.assign(gb + 1, ge);
+          std::replace(fixed.begin(), fixed.end(), ' ', '_');
+          id = part.genes.intern(fixed.data(), fixed.size());
+        }
+        part.gid.push_back(id);
+        part.strand.push_back(*gb == '+' ? 1 : -1);
+      } while (r.lit(','));
+      if (!r.lit(']')) return fail("expected ']'");
+    }
+    part.n_genes.push_back((int64_t)(part.gid.size() - first_gene));
+  } while (r.lit(','));
+  r.ws();
+  if (r.p != r.end) return fail("expected ',' or the end of the object");
+  return true;
+}
+
+template <class F>
+void run_parts(size_t n, F f) {
+  if (n <= 1) {
+    if (n == 1) f(0);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(n);
+  for (size_t i = 0; i < n; ++i) th.emplace_back([&f, i] { f(i); });
+  for (auto& t : th) t.join();
+}
+}  // namespace
+
 extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
   if (!path || !out) return amg_fail(AMG_E_ARG, "null argument");
   *out = nullptr;
-  std::string text, err;
-  if (!slurp(path, text, err)) return amg_fail(AMG_E_ARG, "%s", err.c_str());
-  Reader r{text.data(), text.data() + text.size(), ""};
-  amg_calls* c = new amg_calls();
+  FileView file;
+  std::string err;
+  if (!file.open(path, err)) return amg_fail(AMG_E_ARG, "%s", err.c_str());
   const bool timing = getenv("AMG_CALLS_TIMING") != nullptr;
   clock_t t_start = clock();
-  Interner genes;               // name -> first-seen id
-  std::vector<int32_t> gid;     // per gene occurrence: first-seen name id
-  std::vector<int8_t> strand;   // per gene occurrence
-  gid.reserve(text.size() / 8);
-  strand.reserve(text.size() / 8);
-  auto fail = [&](const char* what) {
-    std::string m = std::string(what) + (r.err.empty() ? "" : (": " + r.err));
-    delete c;
-    return amg_fail(AMG_E_ARG, "%s: %s (offset %lld)", path, m.c_str(), (long long)(r.p - text.data()));
-  };
-  if (!r.lit('{')) return fail("expected an object of read -> gene list");
-  std::string key, owned, fixed;
-  if (!r.lit('}')) {
-    do {
-      const char *kb, *ke;
-      if (!r.str_view(&kb, &ke, &key)) return fail("read id");
-      {
-        // json.load keeps the LAST value of a duplicated key at the FIRST key's position;
-        // gene-call files never repeat a read id, so this is rejected rather than emulated
-        const size_t before = c->read_ids.size();
-        const int32_t rid = c->read_ids.intern(kb, (size_t)(ke - kb));
-        if ((size_t)rid != before) return fail("duplicate read id");
-      }
-      if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
-      if (!r.lit(']')) {
-        do {
-          // one pass over the gene string: closing quote, escapes, blanks and the hash of the name
-          // (construct_gene.py:49-65: strand = first char, name = rest with ' ' -> '_')
-          r.ws();
-          if (r.p >= r.end || *r.p != '"') { r.err = "expected string"; return fail("gene"); }
-          const char* gb = r.p + 1;
-          const char* q = gb;
-          uint64_t hsh = 1469598103934665603ull;
-          bool blank = true, has_space = false, plain = true;
-          if (q < r.end && *q != '"' && *q != '\\') { blank = blank && *q == ' '; ++q; }  // strand char: not hashed
-          while (q < r.end && *q != '"') {
-            const char ch = *q;
-            if (ch == '\\') { plain = false; break; }
-            if (ch == ' ') has_space = true; else blank = false;
-            hsh = (hsh ^ (unsigned char)(ch == ' ' ? '_' : ch)) * 1099511628211ull;
-            ++q;
-          }
-          const char* ge;
-          int32_t id;
-          if (plain && q < r.end) {
-            ge = q;
-            r.p = q + 1;
-            if (blank) return fail("Gene information is missing");
-            if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
-            if (ge - gb < 2) return fail("Gene name information missing for a gene");
-            hsh ^= hsh >> 29;
-            if (!has_space) {
-              id = genes.intern_h(gb + 1, (size_t)(ge - gb - 1), hsh);
-            } else {
-              fixed.assign(gb + 1, ge);
-              std::replace(fixed.begin(), fixed.end(), ' ', '_');
-              id = genes.intern_h(fixed.data(), fixed.size(), hsh);
-            }
-          } else {  // escapes (or a truncated file): the general string reader
-            if (!r.str(owned)) return fail("gene");
-            gb = owned.data();
-            ge = gb + owned.size();
-            blank = true;
-            has_space = false;
-            for (const char* t = gb; t < ge; ++t) {
-              if (*t == ' ') has_space = true; else blank = false;
-            }
-            if (blank) return fail("Gene information is missing");
-            if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
-            if (ge - gb < 2) return fail("Gene name information missing for a gene");
-            fixed.assign(gb + 1, ge);
-            std::replace(fixed.begin(), fixed.end(), ' ', '_');
-            id = genes.intern(fixed.data(), fixed.size());
-          }
-          gid.push_back(id);
-          strand.push_back(*gb == '+' ? 1 : -1);
-        } while (r.lit(','));
-        if (!r.lit(']')) return fail("expected ']'");
-      }
-      c->read_off.push_back((int64_t)gid.size());
-    } while (r.lit(','));
-    if (!r.lit('}')) return fail("expected '}'");
+  const auto w_start = std::chrono::steady_clock::now();
+  auto wall = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - w_start).count(); };
+  const char* fb = file.data;
+  const char* fe = file.data + file.size;
+  // the body between the outer braces
+  Reader outer{fb, fe, ""};
+  if (!outer.lit('{')) return amg_fail(AMG_E_ARG, "%s: expected an object of read -> gene list (offset %lld)", path, (long long)(outer.p - fb));
+  const char* body_b = outer.p;
+  const char* body_e = fe;
+  while (body_e > body_b && (body_e[-1] == ' ' || body_e[-1] == '\n' || body_e[-1] == '\t' || body_e[-1] == '\r')) --body_e;
+  if (body_e <= body_b || body_e[-1] != '}') return amg_fail(AMG_E_ARG, "%s: expected '}' (offset %lld)", path, (long long)(body_e - fb));
+  --body_e;
+  // ---- the pieces, one thread each; a piece that does not parse on its own terms sends everything down the
+  // single-threaded path (whose error message, if the file is really malformed, names the true offset)
+  std::vector<CallsPart> parts;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int want = attempt == 0 ? worker_count((size_t)(body_e - body_b)) : 1;
+    auto pieces = split_entries(body_b, body_e, want);
+    parts.clear();
+    parts.resize(pieces.size());
+    run_parts(pieces.size(), [&](size_t i) {
+      Reader r{pieces[i].first, pieces[i].second, ""};
+      parts[i].gid.reserve((size_t)(pieces[i].second - pieces[i].first) / 8);
+      parts[i].strand.reserve((size_t)(pieces[i].second - pieces[i].first) / 8);
+      parse_call_entries(r, parts[i], fb);
+    });
+    bool ok = true;
+    for (auto& p : parts) ok = ok && p.error.empty();
+    if (ok) break;
+    if (pieces.size() == 1) {
+      for (auto& p : parts)
+        if (!p.error.empty()) return amg_fail(AMG_E_ARG, "%s: %s (offset %lld)", path, p.error.c_str(), p.error_at);
+    }
   }
-  if (timing) fprintf(stderr, "parse %.3fs\n", (double)(clock() - t_start) / CLOCKS_PER_SEC);
-  // ---- hash every distinct name once, rank by hash, tokens
+  if (timing) fprintf(stderr, "parse %.3fs cpu %.3fs wall, %zu piece(s)\n", (double)(clock() - t_start) / CLOCKS_PER_SEC, wall(), parts.size());
+  amg_calls* c = new amg_calls();
+  // ---- read ids in file order (one table for the whole file: a read id must not repeat), read offsets
+  {
+    size_t n_ids = 0, id_bytes = 0;
+    for (auto& p : parts) {
+      n_ids += p.ids.size();
+      id_bytes += p.ids.arena.size();
+    }
+    c->read_ids.reserve(n_ids, id_bytes);
+    c->read_off.reserve(n_ids + 1);
+  }
+  if (timing) fprintf(stderr, "  ids reserved %.3fs wall\n", wall());
+  for (auto& p : parts) {
+    for (size_t i = 0; i < p.ids.size(); ++i) {
+      const size_t before = c->read_ids.size();
+      const int32_t rid = c->read_ids.intern(&p.ids.arena[p.ids.off[i]], p.ids.len[i]);
+      if ((size_t)rid != before) {
+        const std::string name = p.ids.name(i);
+        delete c;
+        return amg_fail(AMG_E_ARG, "%s: duplicate read id %s", path, name.c_str());
+      }
+      c->read_off.push_back(c->read_off.back() + p.n_genes[i]);
+    }
+  }
+  if (timing) fprintf(stderr, "  ids merged %.3fs wall\n", wall());
+  // ---- gene names of all pieces -> one table; hash every distinct name once, rank by hash
+  Interner genes;
+  std::vector<std::vector<int32_t>> to_global(parts.size());
+  for (size_t k = 0; k < parts.size(); ++k) {
+    auto& p = parts[k];
+    to_global[k].resize(p.genes.size());
+    for (size_t i = 0; i < p.genes.size(); ++i)
+      to_global[k][i] = genes.intern(&p.genes.arena[p.genes.off[i]], p.genes.len[i]);
+  }
   std::vector<std::string> names_seen(genes.off.size());
   for (size_t i = 0; i < names_seen.size(); ++i) names_seen[i] = genes.name(i);
   const size_t V = names_seen.size();
   std::vector<uint8_t> h(V * 32);
-  for (size_t i = 0; i < V; ++i) gene_hash(names_seen[i], &h[i * 32]);
+  {
+    const size_t workers = (size_t)std::max(1, std::min(worker_count(V * 4096), (int)((V + 255) / 256)));
+    run_parts(workers, [&](size_t w) {
+      for (size_t i = w; i < V; i += workers) gene_hash(names_seen[i], &h[i * 32]);
+    });
+  }
   std::vector<int32_t> order(V);
   for (size_t i = 0; i < V; ++i) order[i] = (int32_t)i;
   std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
@@ -410,11 +593,22 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
     c->names[rnk] = names_seen[order[rnk]];
     memcpy(&c->hashes[rnk * 32], &h[(size_t)order[rnk] * 32], 32);
   }
+  if (timing) fprintf(stderr, "  genes ranked %.3fs wall\n", wall());
+  // ---- tokens, every piece into its own stretch
   const int32_t Vp = (int32_t)(V ? V : 1);
-  c->tokens.resize(gid.size());
-  for (size_t i = 0; i < gid.size(); ++i)
-    c->tokens[i] = strand[i] > 0 ? Vp + rank[gid[i]] : Vp - 1 - rank[gid[i]];
-  if (timing) fprintf(stderr, "total %.3fs\n", (double)(clock() - t_start) / CLOCKS_PER_SEC);
+  std::vector<size_t> base(parts.size() + 1, 0);
+  for (size_t k = 0; k < parts.size(); ++k) base[k + 1] = base[k] + parts[k].gid.size();
+  c->tokens.resize(base.back());
+  run_parts(parts.size(), [&](size_t k) {
+    const auto& p = parts[k];
+    int32_t* dst = c->tokens.data() + base[k];
+    const int32_t* g2 = to_global[k].data();
+    for (size_t i = 0; i < p.gid.size(); ++i) {
+      const int32_t r = rank[g2[p.gid[i]]];
+      dst[i] = p.strand[i] > 0 ? Vp + r : Vp - 1 - r;
+    }
+  });
+  if (timing) fprintf(stderr, "total %.3fs cpu %.3fs wall\n", (double)(clock() - t_start) / CLOCKS_PER_SEC, wall());
   *out = c;
   return AMG_OK;
 }
@@ -452,91 +646,213 @@ extern "C" int amg_calls_get(amg_calls* c, int32_t* tokens, int64_t* read_offset
 
 // gene positions {"read": [[s, e], ...]} laid out in the read order of `c`; reads missing from
 // the file, or with a different number of entries than genes, are an error
+namespace {
+struct PosPart {
+  std::string error;
+  long long error_at = 0;
+};
+
+bool parse_position_entries(Reader& r, const amg_calls* c, int64_t* gene_start, int64_t* gene_end, char* seen,
+                            PosPart& part, const char* file_begin) {
+  std::string key;
+  auto fail = [&](const char* what) {
+    part.error = std::string(what) + (r.err.empty() ? "" : (": " + r.err));
+    part.error_at = (long long)(r.p - file_begin);
+    return false;
+  };
+  r.ws();
+  if (r.p >= r.end) return true;
+  do {
+    const char *kb, *ke;
+    if (!r.str_view(&kb, &ke, &key)) return fail("read id");
+    const int32_t rid = c->read_ids.find(kb, (size_t)(ke - kb));  // -1: a read that has no gene calls
+    if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
+    int64_t at = rid < 0 ? -1 : c->read_off[rid];
+    int64_t lim = rid < 0 ? -1 : c->read_off[rid + 1];
+    if (!r.lit(']')) {
+      do {
+        long long s, e;
+        if (!r.lit('[') || !r.integer(&s) || !r.lit(',') || !r.integer(&e) || !r.lit(']'))
+          return fail("expected [start, end]");
+        if (at >= 0) {
+          if (at >= lim) return fail("more positions than genes for a read");
+          gene_start[at] = s;
+          gene_end[at] = e;
+          ++at;
+        }
+      } while (r.lit(','));
+      if (!r.lit(']')) return fail("expected ']'");
+    }
+    if (rid >= 0) {
+      if (at != lim) return fail("fewer positions than genes for a read");
+      seen[rid] = 1;
+    }
+  } while (r.lit(','));
+  r.ws();
+  if (r.p != r.end) return fail("expected ',' or the end of the object");
+  return true;
+}
+}  // namespace
+
 extern "C" int amg_calls_load_positions_json(amg_calls* c, const char* path, int64_t* gene_start,
                                              int64_t* gene_end) {
   if (!c || !path || !gene_start || !gene_end) return amg_fail(AMG_E_ARG, "null argument");
-  std::string text, err;
-  if (!slurp(path, text, err)) return amg_fail(AMG_E_ARG, "%s", err.c_str());
-  Reader r{text.data(), text.data() + text.size(), ""};
+  FileView file;
+  std::string err;
+  if (!file.open(path, err)) return amg_fail(AMG_E_ARG, "%s", err.c_str());
+  const char* fb = file.data;
+  const char* fe = file.data + file.size;
+  Reader outer{fb, fe, ""};
+  if (!outer.lit('{')) return amg_fail(AMG_E_ARG, "%s: expected an object of read -> positions (offset %lld)", path, (long long)(outer.p - fb));
+  const char* body_b = outer.p;
+  const char* body_e = fe;
+  while (body_e > body_b && (body_e[-1] == ' ' || body_e[-1] == '\n' || body_e[-1] == '\t' || body_e[-1] == '\r')) --body_e;
+  if (body_e <= body_b || body_e[-1] != '}') return amg_fail(AMG_E_ARG, "%s: expected '}' (offset %lld)", path, (long long)(body_e - fb));
+  --body_e;
   std::vector<char> seen(c->read_ids.size(), 0);
-  auto fail = [&](const char* what) {
-    return amg_fail(AMG_E_ARG, "%s: %s%s%s (offset %lld)", path, what, r.err.empty() ? "" : ": ",
-                    r.err.c_str(), (long long)(r.p - text.data()));
-  };
-  if (!r.lit('{')) return fail("expected an object of read -> positions");
-  std::string key;
-  if (!r.lit('}')) {
-    do {
-      const char *kb, *ke;
-      if (!r.str_view(&kb, &ke, &key)) return fail("read id");
-      const int32_t rid = c->read_ids.find(kb, (size_t)(ke - kb));  // -1: a read that has no gene calls
-      if (!r.lit(':') || !r.lit('[')) return fail("expected ': ['");
-      int64_t at = rid < 0 ? -1 : c->read_off[rid];
-      int64_t lim = rid < 0 ? -1 : c->read_off[rid + 1];
-      if (!r.lit(']')) {
-        do {
-          long long s, e;
-          if (!r.lit('[') || !r.integer(&s) || !r.lit(',') || !r.integer(&e) || !r.lit(']'))
-            return fail("expected [start, end]");
-          if (at >= 0) {
-            if (at >= lim) return fail("more positions than genes for a read");
-            gene_start[at] = s;
-            gene_end[at] = e;
-            ++at;
-          }
-        } while (r.lit(','));
-        if (!r.lit(']')) return fail("expected ']'");
-      }
-      if (rid >= 0) {
-        if (at != lim) return fail("fewer positions than genes for a read");
-        seen[rid] = 1;
-      }
-    } while (r.lit(','));
-    if (!r.lit('}')) return fail("expected '}'");
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int want = attempt == 0 ? worker_count((size_t)(body_e - body_b)) : 1;
+    auto pieces = split_entries(body_b, body_e, want);
+    std::vector<PosPart> parts(pieces.size());
+    run_parts(pieces.size(), [&](size_t i) {
+      Reader r{pieces[i].first, pieces[i].second, ""};
+      parse_position_entries(r, c, gene_start, gene_end, seen.data(), parts[i], fb);
+    });
+    bool ok = true;
+    for (auto& p : parts) ok = ok && p.error.empty();
+    if (ok) break;
+    if (pieces.size() == 1)
+      return amg_fail(AMG_E_ARG, "%s: %s (offset %lld)", path, parts[0].error.c_str(), parts[0].error_at);
+    std::fill(seen.begin(), seen.end(), 0);
   }
   for (size_t i = 0; i < seen.size(); ++i)
     if (!seen[i] && c->read_off[i + 1] > c->read_off[i]) return amg_fail(AMG_E_ARG, "%s: no positions for read %s", path, c->read_ids.name(i).c_str());
   return AMG_OK;
 }
 
-static void json_string(FILE* f, const char* s) {
-  fputc('"', f);
-  for (const unsigned char* p = reinterpret_cast<const unsigned char*>(s); *p; ++p) {
-    if (*p == '"' || *p == '\\') { fputc('\\', f); fputc(*p, f); }
-    else if (*p < 0x20) fprintf(f, "\\u%04x", *p);
-    else fputc(*p, f);
+static void json_string(std::string& out, const char* s, size_t n) {
+  out.push_back('"');
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char ch = (unsigned char)s[i];
+    if (ch == '"' || ch == '\\') { out.push_back('\\'); out.push_back((char)ch); }
+    else if (ch < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", ch); out += b; }
+    else out.push_back((char)ch);
   }
-  fputc('"', f);
+  out.push_back('"');
 }
 
 // write-back: corrected CSR -> {"read": ["+gene", ...]} (json.dumps separators ', ' and ': ',
-// ensure_ascii=False) — result_utils.py:1260-1264
+// ensure_ascii=False) — result_utils.py:1260-1264.  The text of a stretch of reads is made by one thread each, the
+// stretches are written in order.
 extern "C" int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t* read_offsets,
                                     int64_t n_reads, const char* gene_names, int64_t n_genes,
                                     const char* read_ids) {
   if (!path || !read_offsets || !gene_names || !read_ids) return amg_fail(AMG_E_ARG, "null argument");
   std::vector<const char*> name(n_genes);
+  std::vector<uint32_t> name_len(n_genes);
   const char* p = gene_names;
-  for (int64_t i = 0; i < n_genes; ++i) { name[i] = p; p += strlen(p) + 1; }
+  for (int64_t i = 0; i < n_genes; ++i) { name[i] = p; name_len[i] = (uint32_t)strlen(p); p += name_len[i] + 1; }
+  std::vector<const char*> rid((size_t)n_reads + 1);
+  p = read_ids;
+  for (int64_t r = 0; r < n_reads; ++r) { rid[r] = p; p += strlen(p) + 1; }
+  rid[n_reads] = p;
   FILE* f = fopen(path, "wb");
   if (!f) return amg_fail(AMG_E_ARG, "cannot write %s", path);
   const int64_t V = n_genes ? n_genes : 1;
-  fputc('{', f);
-  const char* rid = read_ids;
-  for (int64_t r = 0; r < n_reads; ++r) {
-    if (r) fputs(", ", f);
-    json_string(f, rid);
-    rid += strlen(rid) + 1;
-    fputs(": [", f);
-    for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
-      if (t > read_offsets[r]) fputs(", ", f);
-      int32_t tok = tokens[t];
-      std::string g = tok >= V ? std::string("+") + name[tok - V] : std::string("-") + name[V - 1 - tok];
-      json_string(f, g.c_str());
-    }
-    fputc(']', f);
+  const int64_t T = n_reads > 0 ? read_offsets[n_reads] : 0;
+  const size_t workers = (size_t)std::max<int64_t>(1, std::min<int64_t>(worker_count((size_t)T * 10 + 1), n_reads));
+  std::vector<std::string> text(workers);
+  // batches of stretches, so that the text in memory stays bounded for very large files
+  const int64_t per_batch = std::max<int64_t>((int64_t)workers * 65536, 1);
+  bool ok = fputc('{', f) != EOF;
+  for (int64_t lo = 0; lo < n_reads && ok; lo += per_batch) {
+    const int64_t hi = std::min(n_reads, lo + per_batch);
+    run_parts(workers, [&](size_t w) {
+      std::string& o = text[w];
+      o.clear();
+      const int64_t a = lo + (hi - lo) * (int64_t)w / (int64_t)workers, b = lo + (hi - lo) * (int64_t)(w + 1) / (int64_t)workers;
+      o.reserve((size_t)(read_offsets[b] - read_offsets[a]) * 12 + (size_t)(b - a) * 24 + 16);
+      for (int64_t r = a; r < b; ++r) {
+        if (r) o += ", ";
+        json_string(o, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
+        o += ": [";
+        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
+          if (t > read_offsets[r]) o += ", ";
+          const int32_t tok = tokens[t];
+          const bool plus = tok >= V;
+          const int64_t g = plus ? tok - V : V - 1 - tok;
+          o.push_back('"');
+          o.push_back(plus ? '+' : '-');
+          // (the name's own quotes / backslashes / control characters are escaped as json.dumps does)
+          const char* nm = name[g];
+          const uint32_t nl = name_len[g];
+          bool plain = true;
+          for (uint32_t i = 0; i < nl; ++i) plain = plain && (unsigned char)nm[i] >= 0x20 && nm[i] != '"' && nm[i] != '\\';
+          if (plain) {
+            o.append(nm, nl);
+            o.push_back('"');
+          } else {
+            o.pop_back();
+            o.pop_back();
+            std::string g2(1, plus ? '+' : '-');
+            g2.append(nm, nl);
+            json_string(o, g2.data(), g2.size());
+          }
+        }
+        o.push_back(']');
+      }
+    });
+    for (size_t w = 0; w < workers && ok; ++w)
+      ok = text[w].empty() || fwrite(text[w].data(), 1, text[w].size(), f) == text[w].size();
   }
-  fputc('}', f);
-  fclose(f);
+  ok = ok && fputc('}', f) != EOF;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return amg_fail(AMG_E_ARG, "short write to %s", path);
+  return AMG_OK;
+}
+
+// positions write-back: {"read": [[start, end], ...]} as json.dumps(gene_position_dict) writes it
+// (result_utils.py:1260-1264, second file)
+extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
+                                              const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
+  if (!path || !read_offsets || !read_ids || ((!gene_start || !gene_end) && n_reads > 0 && read_offsets[n_reads] > 0))
+    return amg_fail(AMG_E_ARG, "null argument");
+  std::vector<const char*> rid((size_t)n_reads + 1);
+  const char* p = read_ids;
+  for (int64_t r = 0; r < n_reads; ++r) { rid[r] = p; p += strlen(p) + 1; }
+  rid[n_reads] = p;
+  FILE* f = fopen(path, "wb");
+  if (!f) return amg_fail(AMG_E_ARG, "cannot write %s", path);
+  const int64_t T = n_reads > 0 ? read_offsets[n_reads] : 0;
+  const size_t workers = (size_t)std::max<int64_t>(1, std::min<int64_t>(worker_count((size_t)T * 16 + 1), n_reads));
+  std::vector<std::string> text(workers);
+  const int64_t per_batch = std::max<int64_t>((int64_t)workers * 65536, 1);
+  bool ok = fputc('{', f) != EOF;
+  for (int64_t lo = 0; lo < n_reads && ok; lo += per_batch) {
+    const int64_t hi = std::min(n_reads, lo + per_batch);
+    run_parts(workers, [&](size_t w) {
+      std::string& o = text[w];
+      o.clear();
+      const int64_t a = lo + (hi - lo) * (int64_t)w / (int64_t)workers, b = lo + (hi - lo) * (int64_t)(w + 1) / (int64_t)workers;
+      o.reserve((size_t)(read_offsets[b] - read_offsets[a]) * 20 + (size_t)(b - a) * 24 + 16);
+      char num[48];
+      for (int64_t r = a; r < b; ++r) {
+        if (r) o += ", ";
+        json_string(o, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
+        o += ": [";
+        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
+          const int n = snprintf(num, sizeof(num), t > read_offsets[r] ? ", [%lld, %lld]" : "[%lld, %lld]",
+                                 (long long)gene_start[t], (long long)gene_end[t]);
+          o.append(num, (size_t)n);
+        }
+        o.push_back(']');
+      }
+    });
+    for (size_t w = 0; w < workers && ok; ++w)
+      ok = text[w].empty() || fwrite(text[w].data(), 1, text[w].size(), f) == text[w].size();
+  }
+  ok = ok && fputc('}', f) != EOF;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return amg_fail(AMG_E_ARG, "short write to %s", path);
   return AMG_OK;
 }

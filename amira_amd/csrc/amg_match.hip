@@ -108,6 +108,7 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
     return AMG_OK;
   }
   c->match_valid = false;
+  stages_reset(c);
   if (n_pat >= (1ll << PAT_BITS)) return amg_fail(AMG_E_ARG, "at most %d patterns per call", (1 << PAT_BITS) - 1);
   if (c->n_reads >= (1ll << READ_BITS)) return amg_fail(AMG_E_ARG, "too many reads for amg_match_patterns");
   const long long n_sym = pat_offsets[n_pat];
@@ -152,7 +153,9 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
   A.cap = 0;
   // ---- pass 1: count, pass 2: fill
   HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
+  stage_begin(c, "match_count");  // (the stage is the kernel alone: bench.py prices it against the HBM roofline)
   if (c->n_reads > 0) hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+  stage_end(c);
   unsigned long long total = 0;
   HIPCHK(hipMemcpyAsync(&total, A.counter, sizeof(total), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -167,7 +170,9 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
     A.hits = keys;
     A.cap = total;
     HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
+    stage_begin(c, "match_fill");
     hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+    stage_end(c);
     // sort by (pattern, read, position); the values of the pair sort are not needed
     AMGCHK(c->s2.ensure((size_t)(total + 1) * sizeof(unsigned int) * 2 + (size_t)(n_pat + 2) * sizeof(unsigned int) * 4));
     // NB: s2 may have been reallocated — bucket arrays are no longer needed after pass 2

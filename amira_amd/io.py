@@ -365,3 +365,12 @@ def write_gene_calls(path, vocab, tokens, read_offsets, read_ids):
     ids = ("\0".join(read_ids) + "\0").encode("utf-8") if len(read_ids) else b""
     check(_ffi.lib.amg_calls_write_json(str(path).encode(), ptr(tokens), ptr(read_offsets), len(read_ids),
                                         names, len(vocab.names), ids))
+
+
+def write_gene_positions(path, gene_start, gene_end, read_offsets, read_ids):
+    """flat positions -> {"read": [[start, end], ...]} JSON (the second file of result_utils.py:1260-1264)"""
+    gs = np.ascontiguousarray(gene_start, np.int64)
+    ge = np.ascontiguousarray(gene_end, np.int64)
+    read_offsets = np.ascontiguousarray(read_offsets, np.int64)
+    ids = ("\0".join(read_ids) + "\0").encode("utf-8") if len(read_ids) else b""
+    check(_ffi.lib.amg_calls_write_positions_json(str(path).encode(), ptr(gs), ptr(ge), ptr(read_offsets), len(read_ids), ids))

@@ -224,6 +224,56 @@ def cpu_baseline_ncore(w, per_worker=2500, max_workers=64):
                       f"(upper bound of graph_utils.py:105-124), wall {wall:.1f} s incl. process start-up"}
 
 
+def cpu_baseline_cfg4(w, budget_s=10.0):
+    """BASELINE configs[3] on one host core with the pure-Python oracle (the reference's cost model): build AND
+    assign_reads_to_genes on the first reads of the same stream, sized to ~budget_s of CPU work from a pilot."""
+    import threading
+    synth, GeneMerGraph, driver, values = _oracle()
+    L, k, n_amr = w["L"], w["k"], w["n_amr"]
+    genes = [f"amr{j}" for j in range(n_amr)]
+    box = {}
+
+    def once(n):
+        ids, sts = synth.block_reads(w["seed"], 0, n, L, w["V"], w["err"], n_amr=n_amr)
+        reads = synth.to_read_dict(ids, sts, synth.gene_names(w["V"], n_amr), first=0)
+        pos = synth.positions_for(reads)
+        t0 = time.perf_counter()
+        g = GeneMerGraph(reads, k, pos)
+        t1 = time.perf_counter()
+        clustered, _ = g.assign_reads_to_genes(genes, 1, {}, None)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, sum(len(d) for comp in clustered.values() for d in comp.values())
+
+    def run():
+        try:
+            sys.setrecursionlimit(2_000_000)
+            values.CACHE_HASHES = False
+            b, c_, _ = once(200)
+            n = max(200, min(int(w["N"] * 0.01), int(budget_s / max((b + c_) / 200, 1e-6))))
+            box["out"] = (n,) + once(n)
+        except BaseException as err:  # noqa: BLE001
+            box["err"] = err
+        finally:
+            values.CACHE_HASHES = True
+
+    old = threading.stack_size(1 << 30)   # (the reference labels components by recursive depth-first search)
+    try:
+        t = threading.Thread(target=run)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(old)
+    if "err" in box:
+        raise box["err"]
+    n, build_s, cluster_s, alleles = box["out"]
+    return {"value": n * (L - k + 1) / (build_s + cluster_s), "unit": "gene-mers/s", "cores": 1, "kind": "port",
+            "build_s": round(build_s, 2), "assign_reads_to_genes_s": round(cluster_s, 2), "alleles_found": alleles,
+            "sample": f"the first {n} reads ({100.0 * n / w['N']:.2g} %) of the same stream, GeneMerGraph(...) + "
+                      f"assign_reads_to_genes for the {n_amr} planted genes, pure-Python oracle (the reference's cost model); "
+                      f"the depth is {n / w['N']:.2g}x the workload's, so most planted copies are seen by a handful of reads "
+                      "or none: the clustering of the full workload is far more work per read than this sample's"}
+
+
 # ---------------------------------------------------------------------------------------------
 def run_cfg4(args, w, rank, world, local_rank):
     """BASELINE configs[3]: build + read-path clustering through amira_amd.GeneMerGraph (the reference's
@@ -244,13 +294,35 @@ def run_cfg4(args, w, rank, world, local_rank):
     n_windows = N * (L - k + 1)
     stage = {"build_s": [], "cluster_s": [], "device_build_ms": []}
     info = {}
+    dev_stages = {}   # device stage -> [ms, launches] of the instrumented step (HIP events on the engine's stream)
+
+    def note(engine):
+        for name, ms in engine.timings():
+            e = dev_stages.setdefault(name, [0.0, 0])
+            e[0] += ms
+            e[1] += 1
 
     def step(record):
+        from amira_amd import Engine
         t0 = time.perf_counter()
         g = GeneMerGraph(reads, k, positions)
         t1 = time.perf_counter()
         dev_ms = sum(m for _, m in g._engine.timings()) if record else 0.0
-        clustered, path_reads = g.assign_reads_to_genes(genes, 1, {}, None)
+        plain_match = Engine.match_patterns
+        if record:   # the device searches of the clustering (k_match), call by call
+            note(g._engine)
+
+            def timed_match(self, which, patterns):
+                out = plain_match(self, which, patterns)
+                note(self)
+                return out
+            Engine.match_patterns = timed_match
+        g._engine.set_timing(bool(record))
+        try:
+            clustered, path_reads = g.assign_reads_to_genes(genes, 1, {}, None)
+        finally:
+            Engine.match_patterns = plain_match
+            g._engine.set_timing(True)
         t2 = time.perf_counter()
         if record:
             stage["build_s"].append(t1 - t0)
@@ -284,6 +356,33 @@ def run_cfg4(args, w, rank, world, local_rank):
                               "assign_reads_to_genes": round(float(np.mean(stage["cluster_s"])), 4)},
         "roofline": None,
     }
+    # the device side of the step: the build's table passes and the batched sub-list searches of the clustering
+    # (k_match: every pass reads the gene calls of all reads once — SURVEY 8(d)'s B_cluster term, 4 L bytes per read
+    # and pass); the dominant one is priced against the HBM roofline, the rest listed
+    T = N * L
+    algo = {"match_count": 4.0 * T, "match_fill": 4.0 * T,
+            "node_upsert": stage_bytes("node_upsert", k, L, n_windows, N, 0),
+            "edge_upsert": stage_bytes("edge_upsert", k, L, n_windows, N, 0)}
+    priced = {s_: v for s_, v in dev_stages.items() if s_ in algo and v[1] > 0}
+    if priced:
+        groups = {"k_match": ["match_count", "match_fill"], "k_nodes_m": ["node_upsert"], "k_edges_v": ["edge_upsert"]}
+        per = {}
+        for kern, names in groups.items():
+            ms = sum(priced[n_][0] for n_ in names if n_ in priced)
+            launches = sum(priced[n_][1] for n_ in names if n_ in priced)
+            if launches:
+                per[kern] = {"ms_per_step": round(ms, 3), "launches_per_step": launches,
+                             "avg_launch_ms": ms / launches, "algorithmic_bytes_per_launch": algo[names[0]],
+                             "achieved_GBs": algo[names[0]] / (ms / launches * 1e-3) / 1e9}
+        dom = max(per, key=lambda kern: per[kern]["ms_per_step"])
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": per[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": per[dom]["algorithmic_bytes_per_launch"],
+                           "avg_launch_ms": per[dom]["avg_launch_ms"], "launches_per_step": per[dom]["launches_per_step"],
+                           "device_ms_per_step": round(sum(v[0] for v in dev_stages.values()), 3),
+                           "kernels": per,
+                           "note": "the step is host-bound: the device works for device_ms_per_step of ms_per_step; "
+                                   "k_match passes read the gene calls of ALL reads per call (4 L bytes per read)"}
     return out
 
 
@@ -302,7 +401,7 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
     pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
     pinned = lambda n, dt_: torch.empty(n, dtype=dt_).pin_memory().numpy()
     h_toks, h_offs = pin(toks), pin(offs)
-    h_gs = pin(np.tile(np.arange(L, dtype=np.int64) * 1000, N))
+    h_gs = pin(np.tile(np.arange(L, dtype=np.int32) * 1000, N))   # read coordinates fit 32 bits (amg_set_positions32)
     h_ge = pin(h_gs.numpy() + 899)
     h_rl = pin(np.full(N, L * 1000 + 100, np.int64))
     cap_t, cap_r = T + T // 8 + 1024, N + 1024
@@ -314,8 +413,8 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
             self.eng.set_timing(False)
             self.d_toks = torch.empty(T, dtype=torch.int32, device=dev)
             self.d_offs = torch.empty(N + 1, dtype=torch.int64, device=dev)
-            self.d_gs = torch.empty(T, dtype=torch.int64, device=dev)
-            self.d_ge = torch.empty(T, dtype=torch.int64, device=dev)
+            self.d_gs = torch.empty(T, dtype=torch.int32, device=dev)
+            self.d_ge = torch.empty(T, dtype=torch.int32, device=dev)
             self.d_rl = torch.empty(N, dtype=torch.int64, device=dev)
             self.side = torch.cuda.Stream(device=dev)
             self.ev_reads, self.ev_pos = torch.cuda.Event(), torch.cuda.Event()
@@ -328,7 +427,8 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
                         "tok_node": pinned(cap_t, torch.int32), "tok_dir": pinned(cap_t, torch.int8),
                         "c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
-                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)}
+                        "c_pos_src": pinned(cap_r, torch.int64),
+                        "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32)}
 
         def step(self):
             eng = self.eng
@@ -344,14 +444,14 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
             eng.set_reads_device(self.d_toks.data_ptr(), self.d_offs.data_ptr(), N, vocab.two_v, borrow=True)
             eng.build(k)
             self.ev_pos.synchronize()
-            eng.set_positions_device(self.d_gs.data_ptr(), self.d_ge.data_ptr(), self.d_rl.data_ptr(), borrow=True)
+            eng.set_positions32_device(self.d_gs.data_ptr(), self.d_ge.data_ptr(), self.d_rl.data_ptr())
             eng.filter(3, 1)
             eng.correct_reads()
             eng.adopt_corrected()
             eng.build(k)
             eng.remove_short_linear_paths(k)
             n_out = eng.correct_reads()
-            eng.corrected(*n_out, True, buf=self.buf)
+            eng.corrected32(*n_out, buf=self.buf)
             eng.adopt_corrected()
             eng.build(k)
             eng.nodes(self.buf)
@@ -453,6 +553,118 @@ def run_api_e2e(w, vocab, toks, offs, k, n_windows, steps=5):
                     "uploads its host arrays"}
 
 
+def run_front_end(w, vocab, toks, offs, k, n_windows):
+    """SURVEY 8 row f2 at the workload's size: gene-call JSON + gene-position JSON -> CSR arrays (amg_calls_load_json /
+    amg_calls_load_positions_json: the file read and parsed in pieces by the host's cores, one sha256 per distinct gene)
+    and CSR -> JSON (amg_calls_write_json / amg_calls_write_positions_json), then `json_e2e`: both files in ->
+    graph_utils.cleaning_sweep through the array-backed API -> corrected calls and positions out as JSON."""
+    import tempfile
+    from amira_amd import graph_utils as gu, synth
+    from amira_amd.io import (ReadLengths, TokenizedPositions, load_gene_calls, write_gene_calls, write_gene_positions)
+    N, L = w["N"], w["L"]
+    ids = synth.read_names(0, N)
+    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    ge = gs + 899
+    out = {"reads": N, "host_threads": os.cpu_count()}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        cj, pj, cj2, pj2 = (os.path.join(d, n) for n in ("calls.json", "positions.json", "corrected.json", "corrected_positions.json"))
+
+        def timed(fn):
+            t = time.perf_counter()
+            r = fn()
+            return r, time.perf_counter() - t
+
+        _, t_wc = timed(lambda: write_gene_calls(cj, vocab, toks, offs, ids))
+        _, t_wp = timed(lambda: write_gene_positions(pj, gs, ge, offs, ids))
+        sz_c, sz_p = os.path.getsize(cj), os.path.getsize(pj)
+        cold = []
+        for rep in range(2):   # (the first call of a process pays for the page faults of a gigabyte of fresh heap)
+            (reads, lgs, lge), t_l = timed(lambda: load_gene_calls(cj, pj))
+            cold.append(t_l)
+        assert np.array_equal(reads.tokens, toks) and np.array_equal(lgs, gs)
+        _, t_lc = timed(lambda: load_gene_calls(cj))
+        out.update({
+            "calls_json_bytes": sz_c, "positions_json_bytes": sz_p,
+            "load_calls_s": round(t_lc, 3), "load_calls_GBs": round(sz_c / t_lc / 1e9, 3),
+            "load_calls_and_positions_s": round(cold[1], 3),
+            "load_calls_and_positions_GBs": round((sz_c + sz_p) / cold[1] / 1e9, 3),
+            "load_calls_and_positions_first_call_s": round(cold[0], 3),
+            "load_gene_mers_per_s": n_windows / cold[1],
+            "write_calls_s": round(t_wc, 3), "write_calls_GBs": round(sz_c / t_wc / 1e9, 3),
+            "write_positions_s": round(t_wp, 3), "write_positions_GBs": round(sz_p / t_wp / 1e9, 3)})
+        lengths = ReadLengths(reads.read_ids, np.full(N, L * 1000 + 100, np.int64))
+
+        def whole():
+            r, s_, e_ = load_gene_calls(cj, pj)
+            g, r2, p2 = gu.cleaning_sweep(r, TokenizedPositions(r.read_ids, r.read_offsets, s_, e_), k,
+                                          ReadLengths(r.read_ids, lengths.lengths), 3)
+            write_gene_calls(cj2, r2.vocab, r2.tokens, r2.read_offsets, r2.read_ids)
+            write_gene_positions(pj2, p2.gene_start, p2.gene_end, p2.read_offsets, p2.read_ids)
+            n = g.get_total_number_of_nodes()
+            g.close()
+            return n
+
+        whole()
+        nodes, t_all = timed(whole)
+        out["json_e2e"] = {"value": n_windows / t_all, "unit": "gene-mers/s", "s_per_step": round(t_all, 3),
+                           "final_nodes": nodes,
+                           "what": "gene calls + positions JSON in -> graph_utils.cleaning_sweep (array-backed API, device "
+                                   "sweep) -> corrected calls + positions JSON out, second of two runs"}
+    return out
+
+
+def run_multi_k(w, vocab, toks, offs, local_rank):
+    """SURVEY 8 row f3 (graph_utils.py:258-296 choose_kmer_size): the seven graphs k = 3, 5, ..., 15 of the workload's
+    reads as ONE amg_build_multi call (two passes over the tokens for all seven, fingerprint keys) against seven
+    amg_build calls (two passes each; exact keys where the tuple fits 94 bits), and the hybrid — plain builds for the
+    k that take exact keys, one multi call for the rest."""
+    from amira_amd import Engine
+    ks = list(range(3, 16, 2))
+    engines = [Engine(local_rank) for _ in ks]
+    try:
+        for e in engines:
+            e.set_reads(toks, offs, vocab.two_v)
+            e.set_timing(False)
+
+        def sync():
+            for e in engines:
+                e.sync()
+
+        def timed(fn, reps=3):
+            fn()
+            sync()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync()
+            return (time.perf_counter() - t) / reps * 1e3
+
+        many = timed(lambda: Engine.build_multi(engines, ks))
+        nodes_multi = [e.counts()["n_nodes"] for e in engines]
+        singles = [timed(lambda i=i: engines[i].build(ks[i])) for i in range(len(ks))]
+        nodes_single = [e.counts()["n_nodes"] for e in engines]
+        exact = [i for i in range(len(ks)) if engines[i].counts()["exact_keys"]]
+        rest = [i for i in range(len(ks)) if i not in exact]
+
+        def hybrid():
+            for i in exact:
+                engines[i].build(ks[i])
+            if rest:
+                Engine.build_multi([engines[i] for i in rest], [ks[i] for i in rest])
+
+        hyb = timed(hybrid)
+        T = len(toks)
+        return {"ks": ks, "build_many_ms": round(many, 3), "seven_builds_ms": round(sum(singles), 3),
+                "single_build_ms": [round(x, 3) for x in singles], "hybrid_ms": round(hyb, 3),
+                "exact_key_ks": [ks[i] for i in exact], "nodes": nodes_single,
+                "same_graph_sizes": nodes_single == nodes_multi,
+                "token_bytes_read": {"build_many": 2 * 4 * T, "seven_builds": 14 * 4 * T,
+                                     "hybrid": (2 * len(exact) + (2 if rest else 0)) * 4 * T}}
+    finally:
+        for e in engines:
+            e.close()
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` with no launcher around it: start one rank per GPU as fresh child processes
     (torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process makes any GPU call — counting the devices
@@ -525,12 +737,18 @@ def main():
     # CPU yardsticks first (rank 0, N = 1), before this process touches the GPU: the N-core line
     # starts worker processes
     cpu = {}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "cfg4":
         cpu["cpu_baseline"] = cpu_baseline_c(w)
         cpu["cpu_baseline_python"] = cpu_baseline(w)
         cpu["cpu_baseline_ncore"] = cpu_baseline_ncore(w)
 
+    cpu4 = None
+    if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cfg3-sweep" and not args.no_cfg4
+            and not args.no_e2e):
+        cpu4 = cpu_baseline_cfg4(WORKLOADS["cfg4"])
     if args.workload == "cfg4":
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = {"cpu_baseline": cpu_baseline_cfg4(w)}
         out = run_cfg4(args, w, rank, world, local_rank)
         out.update(cpu)
         print(json.dumps(out), flush=True)
@@ -589,7 +807,7 @@ def main():
             stage_ms[name][0] += ms
             stage_ms[name][1] += 1
 
-    def sweep_after_first_build(record, readback=None):
+    def sweep_after_first_build(record, readback=None, moved=None):
         if not (merge or args.fused_filter):
             eng.filter(3, 1)
             if record:
@@ -609,8 +827,12 @@ def main():
         n_out = eng.correct_reads()
         if record:
             tally()
-        if readback is not None:   # the corrected calls + positions the reference hands on (graph_utils.py:165)
-            eng.corrected(*n_out, True, buf=readback)
+        if readback is not None:   # the corrected calls + positions the reference hands on (graph_utils.py:165):
+            # 32-bit positions, and only those the correction PRODUCED — an untouched or trimmed read's positions are a
+            # slice of the arrays the caller already has (amg_get_corrected32)
+            got = eng.corrected32(*n_out, buf=readback)
+            if moved is not None:
+                moved["new_positions"] = len(got["new_start"])
         eng.adopt_corrected()
         build()
         if record:
@@ -683,10 +905,15 @@ def main():
         h_toks, h_offs = pin(toks), pin(offs)
         T = len(toks)
         h_gs = h_ge = h_rl = None
+        d_gs32 = d_ge32 = None
         if w["sweep"]:
-            h_gs = pin(np.tile(np.arange(L, dtype=np.int64) * 1000, N))
+            # positions cross the boundary as int32 (amg_set_positions32 / amg_get_corrected32): read coordinates fit,
+            # and they are 16 of the 20 bytes per gene the region moves each way
+            h_gs = pin(np.tile(np.arange(L, dtype=np.int32) * 1000, N))
             h_ge = pin(h_gs.numpy() + 899)
             h_rl = pin(np.full(N, L * 1000 + 100, np.int64))
+            d_gs32 = torch.empty(T, dtype=torch.int32, device=dev)
+            d_ge32 = torch.empty(T, dtype=torch.int32, device=dev)
         cap_t, cap_r = T + T // 8 + 1024, N + 1024
         cap_d, cap_e = max(counts["n_nodes"] * 2, T // 8) + 1024, max(counts["n_edges"] * 2, T // 4) + 1024
         pinned = lambda n, dt_: torch.empty(n, dtype=dt_).pin_memory().numpy()
@@ -700,8 +927,10 @@ def main():
         if w["sweep"]:
             buf.update({"c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
-                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)})
+                        "c_pos_src": pinned(cap_r, torch.int64),
+                        "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32)})
         side = torch.cuda.Stream(device=dev)
+        moved = {}
         ev_reads, ev_pos = torch.cuda.Event(), torch.cuda.Event()
 
         def e2e_step():
@@ -709,9 +938,9 @@ def main():
                 d_toks.copy_(h_toks, non_blocking=True)
                 d_offs.copy_(h_offs, non_blocking=True)
                 ev_reads.record(side)
-                if w["sweep"]:   # 4x the bytes of the genes: uploaded while the first build runs
-                    d_gs.copy_(h_gs, non_blocking=True)
-                    d_ge.copy_(h_ge, non_blocking=True)
+                if w["sweep"]:   # twice the bytes of the genes: uploaded while the first build runs
+                    d_gs32.copy_(h_gs, non_blocking=True)
+                    d_ge32.copy_(h_ge, non_blocking=True)
                     d_rl.copy_(h_rl, non_blocking=True)
                     ev_pos.record(side)
             ev_reads.synchronize()
@@ -719,8 +948,8 @@ def main():
             build()
             if w["sweep"]:
                 ev_pos.synchronize()
-                eng.set_positions_device(d_gs.data_ptr(), d_ge.data_ptr(), d_rl.data_ptr(), borrow=True)
-                sweep_after_first_build(False, readback=buf)
+                eng.set_positions32_device(d_gs32.data_ptr(), d_ge32.data_ptr(), d_rl.data_ptr())
+                sweep_after_first_build(False, readback=buf, moved=moved)
             eng.nodes(buf)
             eng.edges(buf)
             eng.read_nodes(buf)
@@ -733,15 +962,17 @@ def main():
             e2e_step()
         torch.cuda.synchronize()
         de = (time.perf_counter() - t0) / n_e2e
-        h2d = T * 4 + (N + 1) * 8 + (T * 16 + N * 8 if w["sweep"] else 0)
+        h2d = T * 4 + (N + 1) * 8 + (T * 8 + N * 8 if w["sweep"] else 0)
         c_fin = eng.counts()
         d2h = (c_fin["n_nodes"] * (4 * k + 4 + 8 + 1 + 4 + 1) + c_fin["n_edges"] * 14 + c_fin["n_tokens"] * 5
-               + (c_fin["n_tokens"] * 20 + c_fin["n_reads"] * 13 if w["sweep"] else 0))
+               + (c_fin["n_tokens"] * 4 + c_fin["n_reads"] * 21 + moved.get("new_positions", 0) * 8 if w["sweep"] else 0))
         e2e = {"value": n_windows / de, "unit": "gene-mers/s", "ms_per_step": de * 1e3, "steps": n_e2e,
+               "timed_region": "SURVEY 8(d): host CSR arrays -> host graph arrays, H2D and D2H inside the clock",
                "h2d_bytes": int(h2d), "d2h_bytes": int(d2h),
-               "region": "pinned host CSR (genes, offsets, gene positions, read lengths) -> H2D -> the step -> D2H of the "
-                         "final graph (node + edge arrays, node id and direction per window)"
-                         + (" and of the corrected calls with their positions" if w["sweep"] else "")
+               "region": "pinned host CSR (genes, offsets, gene positions as int32, read lengths) -> H2D -> the step -> D2H "
+                         "of the final graph (node + edge arrays, node id and direction per window)"
+                         + (" and of the corrected calls with the positions the correction produced (int32; the other "
+                            "reads' positions are slices of the caller's own arrays, named by offset)" if w["sweep"] else "")
                          + "; position upload overlapped with the first build on a second stream"}
 
     if e2e is not None and w["sweep"]:
@@ -757,6 +988,19 @@ def main():
     if w["sweep"] and world == 1 and not merge and not args.no_e2e:
         api_e2e = run_api_e2e(w, vocab, toks, offs, k, n_windows)
 
+    front_end = multi_k = None
+    if w["sweep"] and world == 1 and not merge and not args.no_e2e and rank == 0:
+        for name, fn in (("front_end", lambda: run_front_end(w, vocab, toks, offs, k, n_windows)),
+                         ("multi_k", lambda: run_multi_k(w, vocab, toks, offs, local_rank))):
+            try:
+                got = fn()
+            except Exception as err:  # noqa: BLE001  (extra figures: never cost the line)
+                got = {"error": repr(err)}
+            if name == "front_end":
+                front_end = got
+            else:
+                multi_k = got
+
     out = None
     if rank == 0:
         stage_avg = {n: v[0] / v[1] for n, v in stage_ms.items()}     # ms per launch
@@ -771,8 +1015,9 @@ def main():
                           "achieved_GBs": round(cands[s] / (stage_avg[s] * 1e-3) / 1e9, 1)} for s in ranked[:4]}
         exact = bool(counts.get("exact_keys"))
         old_pass = bool(os.environ.get("AMG_X_OLD_PASS"))
+        buckets = os.environ.get("AMG_NODE_BUCKETS", "1") != "0" and k in (3, 5, 7) and not os.environ.get("AMG_X_GENERIC_K")
         kernel_of = {"graph_upsert": "k_graph_x",
-                     "node_upsert": ("k_nodes_x" if old_pass else "k_nodes_v") if exact else "k_node_upsert",
+                     "node_upsert": ("k_nodes_x" if old_pass else "k_nodes_m" if buckets else "k_nodes_v") if exact else "k_node_upsert",
                      "edge_upsert": ("k_edges_x" if old_pass else "k_edges_v") if exact else "k_edges",
                      "node_count": "k_count_ids",
                      "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
@@ -834,6 +1079,8 @@ def main():
             "reads_per_s": world * N * args.steps / dt,
             "config": {"workload": w["desc"] + ("; first build and filter_graph(3,1) as one device pass (--fused-filter)"
                                                  if (args.fused_filter and w["sweep"] and not merge) else ""),
+                       "timed_region": "device-resident: inputs in HBM when the clock starts, nothing read back "
+                                       "(`e2e` is SURVEY 8(d)'s host-to-host region)",
                        "reads_per_gpu": N, "genes_per_read": L, "k": k,
                        "vocab": w["V"], "error_rate": w["err"], "gene_mers_per_gpu": n_windows,
                        "final_nodes": counts["n_nodes"], "final_edges": counts["n_edges"],
@@ -861,6 +1108,10 @@ def main():
             out["e2e"] = e2e
         if api_e2e is not None:
             out["api_e2e"] = api_e2e
+        if front_end is not None:
+            out["front_end"] = front_end
+        if multi_k is not None:
+            out["multi_k"] = multi_k
         out.update(cpu)
     # ---- BASELINE configs[3] beside it: build + read-path clustering through the Python API (its own engine)
     if rank == 0 and world == 1 and not merge and w["sweep"] and not args.no_cfg4 and not args.no_e2e:
@@ -868,7 +1119,9 @@ def main():
         eng = None
         c4 = run_cfg4(argparse.Namespace(steps=2, warmup=1), WORKLOADS["cfg4"], 0, 1, local_rank)
         out["cfg4"] = {key: c4[key] for key in ("metric", "value", "unit", "ms_per_step", "steps", "reads_per_s",
-                                                 "config", "stages_s_per_step")}
+                                                 "config", "stages_s_per_step", "roofline")}
+        if cpu4 is not None:
+            out["cfg4"]["cpu_baseline"] = cpu4
     if eng is not None:
         eng.close()
     if dist is not None:

@@ -322,6 +322,9 @@ int amg_calls_load_positions_json(amg_calls* calls, const char* path, int64_t* g
 int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t* read_offsets,
                          int64_t n_reads, const char* gene_names, int64_t n_genes,
                          const char* read_ids);
+/* {"read": [[start, end], ...]} as json.dumps(gene_position_dict) writes it (result_utils.py:1260-1264, second file) */
+int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
+                                   const int64_t* read_offsets, int64_t n_reads, const char* read_ids);
 int amg_calls_free(amg_calls* calls);
 
 /* ---- read-path clustering, block search (host code; construct_graph.py:2725-2749 get_full_paths and

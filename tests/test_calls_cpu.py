@@ -34,6 +34,11 @@ def test_native_loader_equals_python_tokenizer(tmp_path, fixture):
     out = str(tmp_path / "back.json")
     write_gene_calls(out, reads.vocab, reads.tokens, reads.read_offsets, reads.read_ids)
     assert json.load(open(out)) == calls                       # write-back round trip
+    from amira_amd.io import write_gene_positions
+    out_p = str(tmp_path / "back_pos.json")
+    write_gene_positions(out_p, gs, ge, reads.read_offsets, reads.read_ids)
+    # byte for byte what the reference's json.dumps(gene_position_dict) writes (result_utils.py:1260-1264)
+    assert open(out_p).read() == json.dumps({r: [list(x) for x in pos[r]] for r in read_ids})
 
 
 def test_gene_syntax_and_escapes(tmp_path):
@@ -52,3 +57,50 @@ def test_gene_syntax_and_escapes(tmp_path):
             load_gene_calls(_write(tmp_path, "bad.json", bad))
     with pytest.raises(_ffi.AmgError):
         load_gene_calls(str(tmp_path / "missing.json"))
+
+
+def test_loader_and_writer_in_pieces(tmp_path, monkeypatch):
+    """the file is cut at entry boundaries and parsed / written by several threads (AMG_CALLS_THREADS forces pieces on
+    a small file): same result as one thread; a read id that ENDS with the bytes the cut looks for makes a piece fail
+    on its own terms and the file goes down the single-threaded path — same result again; a malformed file is still
+    reported with its offset"""
+    from amira_amd import _ffi
+    from amira_amd.io import load_gene_calls, write_gene_calls
+    import random
+    rng = random.Random(7)
+    genes = [f"g{i}" for i in range(40)] + ["two words", "café", 'q"uote', "back\\slash"]
+    calls, pos = {}, {}
+    for i in range(700):
+        n = rng.choice([0, 1, 3, 8, 30])
+        calls[f"read_{i:04d}"] = [rng.choice("+-") + rng.choice(genes) for _ in range(n)]
+        pos[f"read_{i:04d}"] = [[j * 100, j * 100 + rng.randint(1, 90)] for j in range(n)]
+    tricky = dict(calls)
+    tricky['odd], '] = ["+g1", "-g2"]                 # json.dumps writes ... "odd], ": ["+g1" ...: the cut pattern inside a key
+    tricky_pos = dict(pos)
+    tricky_pos['odd], '] = [[1, 2], [3, 4]]
+    for data, positions in ((calls, pos), (tricky, tricky_pos)):
+        cj, pj = _write(tmp_path, "c.json", data), _write(tmp_path, "p.json", positions)
+        monkeypatch.setenv("AMG_CALLS_THREADS", "1")
+        one, gs1, ge1 = load_gene_calls(cj, pj)
+        for threads in ("2", "5", "16"):
+            monkeypatch.setenv("AMG_CALLS_THREADS", threads)
+            many, gs, ge = load_gene_calls(cj, pj)
+            assert many.read_ids == one.read_ids == list(data) and many.vocab.names == one.vocab.names
+            assert many.vocab.hashes == one.vocab.hashes
+            assert np.array_equal(many.tokens, one.tokens) and np.array_equal(many.read_offsets, one.read_offsets)
+            assert np.array_equal(gs, gs1) and np.array_equal(ge, ge1)
+            out = str(tmp_path / f"back{threads}.json")
+            write_gene_calls(out, many.vocab, many.tokens, many.read_offsets, many.read_ids)
+            want = {r: [g[0] + g[1:].replace(" ", "_") for g in v] for r, v in data.items()}   # (construct_gene.py:57)
+            assert json.load(open(out)) == want
+    monkeypatch.setenv("AMG_CALLS_THREADS", "4")
+    text = json.dumps(calls)
+    cut = text.index('"read_0400"')
+    bad = tmp_path / "bad.json"
+    bad.write_text(text[:cut] + '"read_0400": ["gene_without_strand"], ' + text[cut:])
+    with pytest.raises(_ffi.AmgError, match="Strand information missing"):
+        load_gene_calls(str(bad))
+    dup = tmp_path / "dup.json"
+    dup.write_text(text[:-1] + ', "read_0003": ["+g1"]}')
+    with pytest.raises(_ffi.AmgError, match="duplicate read id"):
+        load_gene_calls(str(dup))
