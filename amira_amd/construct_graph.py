@@ -438,6 +438,7 @@ class GeneMerGraph(BubblePopping):
         self._genePositions = gene_positions
         self._view = None
         self._host_edits = False   # add_node / add_edge / remove_edge ... changed the host view
+        self._lone_edges = set()   # directed edges removed one at a time (remove_edge) on the device
         self._known_rows = {}      # read name -> row for the reads the native clustering has looked at
         self._pass_log = []        # device passes applied since the build, in order (replayed by __setstate__)
         self._build_filter = None  # _filter of the build
@@ -566,7 +567,7 @@ class GeneMerGraph(BubblePopping):
         return {"reads": self._reads, "k": self._kmerSize, "positions": self._genePositions, "built_with": (gs, ge),
                 "filter": self._build_filter, "passes": list(self._pass_log),
                 "min_cov": (self._minNodeCoverage, self._minEdgeCoverage), "device": self._engine.device,
-                "extra_to_correct": set(self._extra_to_correct)}
+                "extra_to_correct": set(self._extra_to_correct), "lone_edges": set(self._lone_edges)}
 
     def __setstate__(self, state):
         gs, ge = state["built_with"]
@@ -596,6 +597,7 @@ class GeneMerGraph(BubblePopping):
         self._pass_log = list(state["passes"])
         self._minNodeCoverage, self._minEdgeCoverage = state["min_cov"]
         self._extra_to_correct = set(state["extra_to_correct"])
+        self._lone_edges = set(state.get("lone_edges", ()))
 
     def __enter__(self):
         return self
@@ -949,6 +951,10 @@ class GeneMerGraph(BubblePopping):
             self._settle_leases()
             self._engine.remove_edges([edge._amg_id])
             self._pass_log.append(("remove_edges", [int(edge._amg_id)]))
+            # (source id, target id, source direction, target direction): tip clipping wants to know whether the twin
+            # of every edge removed one at a time is gone as well
+            self._lone_edges.add((edge.get_sourceNode()._amg_id, edge.get_targetNode()._amg_id,
+                                  edge.get_sourceNodeDirection(), edge.get_targetNodeDirection()))
             self._invalidate()
             return
         source = edge.get_sourceNode()
@@ -1095,6 +1101,12 @@ class GeneMerGraph(BubblePopping):
         does; _lazy_hashes: the drivers of graph_utils, which ignore the result, ask for a Sequence whose hashes are
         only made when somebody looks at them)."""
         self._device_pass("remove_short_linear_paths")
+        if any((t, s_, -td, -sd) not in self._lone_edges for (s_, t, sd, td) in self._lone_edges):
+            # the walk of the device kernel takes an adjacency from either end; the reference's, on a graph where
+            # remove_edge took ONE direction of an adjacency away, depends on which end it comes from
+            raise RuntimeError("remove_short_linear_paths: remove_edge has removed one direction of an adjacency and "
+                               "left its twin; remove the twin (the edge target -> source with both directions "
+                               "negated) as well, as filter_graph and remove_node do")
         protect = None
         if sample_genesOfInterest:
             ids = self._node_ids_containing(list(sample_genesOfInterest))

@@ -1274,12 +1274,30 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
   for (int i = 0; i < n; ++i) kmax = ks[i] > kmax ? ks[i] : kmax;
   std::vector<char> alone(n, 0);  // graphs that have to be built by themselves (a table overflowed, a fingerprint collided)
   unsigned long long hs[ST_WORDS];
+  // The gene-mer sizes whose tuple fits the exact-key slots (k = 3 always, k = 5 up to 2^18 genes) are built by
+  // themselves with the exact-key kernels: measured on cfg 3 (bench.py `multi_k`), the seven graphs k = 3 .. 15 take
+  // 58 ms through the shared fingerprint passes, 54 ms as seven plain builds and 52 ms this way — the table work of a
+  // pass, not the reading of the tokens, is what a build costs.  AMG_MULTI_ALL=1: everything through the shared passes.
+  {
+    const char* all = getenv("AMG_MULTI_ALL");
+    if (!(all && atoi(all) != 0))
+      for (int i = 0; i < n; ++i) {
+        ctxs[i]->weak_fp_builds = 0;
+        ctxs[i]->dist_mode = false;
+        ctxs[i]->count_inline = false;
+        if (bx_applicable(ctxs[i], ks[i])) alone[i] = 1;
+      }
+  }
+  std::vector<int> shared;  // the graphs of the shared passes
+  for (int i = 0; i < n; ++i)
+    if (!alone[i]) shared.push_back(i);
 
   // ---- node pass of every k from one staged tile
   MultiNodeJobs nj;
-  nj.n = n;
+  nj.n = (int)shared.size();
   nj.kmax = kmax;
-  for (int i = 0; i < n; ++i) {
+  for (int q = 0; q < (int)shared.size(); ++q) {
+    const int i = shared[q];
     amg_ctx* c = ctxs[i];
     multi_begin(c, ks[i]);
     HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
@@ -1289,15 +1307,17 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
     AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
     AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot)));
     HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot), st));
-    nj.j[i] = MultiNodeJob{c->node_tab.as<Slot>(), (unsigned long long)(c->node_slots - 1), c->seed, ~0ull,
+    nj.j[q] = MultiNodeJob{c->node_tab.as<Slot>(), (unsigned long long)(c->node_slots - 1), c->seed, ~0ull,
                            c->tok_slot.as<int>(), c->tok_dir.as<signed char>(), c->status.as<unsigned long long>(), ks[i]};
   }
+  // (the read-end bitmap the shared passes stage belongs to the first graph OF THE SHARED PASSES)
+  amg_ctx* cs = shared.empty() ? c0 : ctxs[shared[0]];
   stage_begin(c0, "node_upsert");
-  if (n_tiles > 0)
+  if (n_tiles > 0 && nj.n > 0)
     hipLaunchKernelGGL(k_node_upsert_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
-                       c0->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, nj);
+                       cs->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, nj);
   stage_end(c0);
-  for (int i = 0; i < n; ++i) {
+  for (int i : shared) {
     amg_ctx* c = ctxs[i];
     size_t max_nodes = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
     AMGCHK(c->s1.ensure(max_nodes * sizeof(unsigned long long)));
@@ -1328,7 +1348,7 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
   ej.n = 0;
   ej.kmax = kmax;
   std::vector<int> in_pass;
-  for (int i = 0; i < n; ++i) {
+  for (int i : shared) {
     if (alone[i]) continue;
     amg_ctx* c = ctxs[i];
     const long long D = c->n_nodes;
@@ -1347,7 +1367,7 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
   stage_begin(c0, "edge_upsert");
   if (n_tiles > 0 && ej.n > 0)
     hipLaunchKernelGGL(k_edges_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
-                       c0->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, ej);
+                       cs->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, ej);
   stage_end(c0);
   for (int i : in_pass) {
     amg_ctx* c = ctxs[i];

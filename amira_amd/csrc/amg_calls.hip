@@ -835,15 +835,27 @@ extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* g
       o.clear();
       const int64_t a = lo + (hi - lo) * (int64_t)w / (int64_t)workers, b = lo + (hi - lo) * (int64_t)(w + 1) / (int64_t)workers;
       o.reserve((size_t)(read_offsets[b] - read_offsets[a]) * 20 + (size_t)(b - a) * 24 + 16);
-      char num[48];
+      auto put = [&o](long long v) {  // decimal digits without the detour through a format string
+        char buf[24];
+        int n = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do {
+          buf[n++] = (char)('0' + u % 10);
+          u /= 10;
+        } while (u);
+        if (v < 0) o.push_back('-');
+        while (n) o.push_back(buf[--n]);
+      };
       for (int64_t r = a; r < b; ++r) {
         if (r) o += ", ";
         json_string(o, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
         o += ": [";
         for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
-          const int n = snprintf(num, sizeof(num), t > read_offsets[r] ? ", [%lld, %lld]" : "[%lld, %lld]",
-                                 (long long)gene_start[t], (long long)gene_end[t]);
-          o.append(num, (size_t)n);
+          o += t > read_offsets[r] ? ", [" : "[";
+          put((long long)gene_start[t]);
+          o += ", ";
+          put((long long)gene_end[t]);
+          o.push_back(']');
         }
         o.push_back(']');
       }

@@ -31,13 +31,18 @@ E_COLLISION = -8          # include/amg.h AMG_E_COLLISION: every rank repeats th
 MAX_ATTEMPTS = 4
 
 
+def _dev(engine):
+    """where an engine's buffers live (engine.device None: a host-side stand-in, tests of the driver without a GPU)"""
+    return torch.device("cpu") if engine.device is None else torch.device("cuda", engine.device)
+
+
 def steps(engine, k, world, rank, token_base, token_total, min_node_cov=1, min_edge_cov=1, attempt=0):
     """min_node_cov / min_edge_cov > 1 fuse filter_graph into the merge (amg_dist_set_filter).
        yield ("a2a", send, send_counts, rec_bytes)            -> (recv, recv_counts)
        yield ("ag", owned, n_owned, rec_bytes)                -> (all_slots, n_slots, n_total)
        yield ("back", replies, recv_counts, send_counts)      -> my_replies (one int64 per record sent)"""
     node_bytes, edge_bytes = engine.dist_record_bytes(k)
-    dev = torch.device("cuda", engine.device)
+    dev = _dev(engine)
     engine.dist_set_filter(min_node_cov, min_edge_cov)
     for what, rec_bytes in (("nodes", node_bytes), ("edges", edge_bytes)):
         if what == "nodes":
@@ -171,9 +176,10 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1, always_exc
     do not travel (always_exchange=True sends them through the collectives anyway: tests of the plumbing).
     A merge-key collision between two gene-mers (AMG_E_COLLISION on the rank that owns the key) makes every
     rank repeat the build with the next fingerprint seed."""
+    import contextlib
     for attempt in range(MAX_ATTEMPTS):
         try:
-            with torch.cuda.stream(engine_stream(engine)):
+            with (contextlib.nullcontext() if engine.device is None else torch.cuda.stream(engine_stream(engine))):
                 return _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchange, attempt)
         except PeerFailed as e:
             if not e.retry or attempt + 1 == MAX_ATTEMPTS:
@@ -186,7 +192,7 @@ def dist_build(engine, k, group=None, min_node_cov=1, min_edge_cov=1, always_exc
 def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchange, attempt):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = torch.device("cuda", engine.device)
+    dev = _dev(engine)
     exchange = world > 1 or always_exchange or bool(os.environ.get("AMG_DIST_ALWAYS_EXCHANGE"))
     if world > 1:
         n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)

@@ -151,19 +151,19 @@ def _cpu_worker(args):
     return _cpu_sweep_or_build(w, first, n)
 
 
-def cpu_baseline(w, frac=0.01):
+def cpu_baseline(w, frac=0.01, budget_s=12.0):
     """1 core — the reference pipeline always builds with cores=1 — on a 1 % read
     subsample of the SAME stream, the whole step (sweep workloads: the whole sweep)."""
     # sized to ~12 s of CPU work from a 250-read pilot, at most the 1 % subsample of SURVEY 8(d)
     pilot_done, pilot_s = _cpu_sweep_or_build(w, w["N"] - 250, 250)
     # (a deeper sample re-threads more reads per read: measured 1.8x from the 250-read pilot to a 0.1 % sample)
     per_read = pilot_s / 250 * (2.2 if w["sweep"] else 1.0)
-    n = max(min(int(w["N"] * frac), int(12.0 / max(per_read, 1e-6))), 250)
+    n = max(min(int(w["N"] * frac), int(budget_s / max(per_read, 1e-6))), 250)
     done, spent = _cpu_sweep_or_build(w, 0, n)
     what = "full sweep" if w["sweep"] else "build"
     return {"value": done / spent, "unit": "gene-mers/s", "cores": 1, "kind": "port",
             "sample": f"the first {n} reads ({100.0 * n / w['N']:.2g} %) of the same stream, {what}, pure-Python oracle "
-                      f"with per-call sha256+pickle (the reference's cost model), {spent:.1f} s; sized to ~12 s of CPU "
+                      f"with per-call sha256+pickle (the reference's cost model), {spent:.1f} s; sized to ~{budget_s:.0f} s of CPU "
                       f"work (the C port above carries the bounded-sample baseline the bench contract asks for) (SURVEY 8(d)'s 1 % sample would take ~{per_read * w['N'] * frac:.0f} s); "
                       f"extrapolates linearly in reads (depth is {n / w['N']:.2g}x the workload's, so fewer nodes survive "
                       f"the filter)"}

@@ -149,6 +149,27 @@ def p_drivers(impl, name):
     return entry
 
 
+def p_drivers_synth(impl, seed, N, L, V, err, keep):
+    """choose_kmer_size (graph_utils.py:258-296) where it goes BEYOND k = 5: long synthetic reads over a small genome
+    with planted multi-copy genes as the genes of interest, trimmed to ragged lengths (read i keeps keep[i % len(keep)]
+    of its L genes) so that the 80 %-of-reads-with-2k-1-genes rule stops at a chosen k: the graphs for k = 7 ... 15 of
+    the multi-k build decide the answer."""
+    reads, pos, _ = synth_inputs(seed, N, L, V, err, n_amr=4)
+    for i, r in enumerate(list(reads)):
+        n = keep[i % len(keep)]
+        reads[r], pos[r] = reads[r][:n], pos[r][:n]
+    genes = [f"amr{j}" for j in range(4)]
+    g = impl.GeneMerGraph(reads, 3, pos)
+    cov = impl.get_overall_mean_node_coverages(g)
+    entry = {"genes": genes, "mean_cov": {str(k): float(v) for k, v in cov.items()},
+             "read_lengths": sorted(set(len(v) for v in reads.values()))}
+    entry["chosen_k"] = impl.choose_kmer_size(cov[3], reads, 1, pos, genes)
+    # the graph at the chosen size and one beyond it, as the reference builds them
+    for k in (entry["chosen_k"], min(entry["chosen_k"] + 2, 15)):
+        entry[f"build_k{k}"] = D.summarise(D.dump_graph(impl.GeneMerGraph(reads, k, pos)))
+    return entry
+
+
 def p_values(impl):
     """Known-answer hashes of the value objects (pins the host-side sha256 hashing)."""
     names = ["+gene1", "-gene2", "+blaTEM-1", "-group_1234", "+g0", "+two words"]
@@ -438,6 +459,10 @@ CASES["read_helpers_six_k3"] = (p_read_helpers, ("six", 3), False)
 CASES["outputs_seven_k3"] = (p_outputs, ("seven", 3), False)
 CASES["drivers_eight"] = (p_drivers, ("eight",), False)
 CASES["drivers_nine"] = (p_drivers, ("nine",), False)
+# (lengths chosen so that >= 80 % of the reads have 2k - 1 genes up to the k wanted and fewer beyond)
+CASES["drivers_synth_k7"] = (p_drivers_synth, (41, 800, 40, 300, 0.002, [40, 36, 30, 24, 18, 14, 13, 13, 13, 10]), False)
+CASES["drivers_synth_k9"] = (p_drivers_synth, (43, 800, 44, 300, 0.002, [44, 40, 36, 30, 26, 22, 21, 21, 12, 9]), False)
+CASES["drivers_synth_k15"] = (p_drivers_synth, (47, 220, 44, 260, 0.0, [44, 40, 36, 33, 31, 30, 29, 29, 29, 12]), False)
 CASES["cluster_eight_k3"] = (p_cluster_fixture, ("eight", 3, ["dfrA17"]), False)
 CASES["planted_s20250909"] = (p_planted, (20250909, 1500, 40, 1000, 5), True)
 CASES["planted_small"] = (p_planted, (5, 300, 40, 1000, 5), False)

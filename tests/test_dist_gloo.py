@@ -135,3 +135,96 @@ def test_failed_rank_releases_its_peers_gloo():
         assert p.exitcode == 0
     assert got[0] == [("a2a", [1]), ("ag", [1])]
     assert got[1] == [("a2a", "self"), ("ag", [1])]
+
+
+class _FakeEngine:
+    """host-side stand-in for an Engine (device None): the device phases are no-ops that may fail as told, so that the
+    driver's failure hand-shake and retry logic run between real processes without a GPU"""
+    device = None
+
+    def __init__(self, fail):
+        self.fail = fail          # {attempt: error code raised by dist_nodes_local}
+        self.calls = []
+
+    @staticmethod
+    def dist_record_bytes(k):
+        return 48, 24
+
+    def sizes(self):
+        return 10, 100
+
+    def stream(self):
+        return 0
+
+    def dist_set_filter(self, a, b):
+        pass
+
+    def dist_nodes_local(self, k, base, total, world, attempt=0):
+        self.calls.append(("nodes_local", attempt))
+        code = self.fail.get(attempt)
+        if code is not None:
+            from amira_amd._ffi import AmgError
+            raise AmgError(code, "told to fail")
+        return [0] * world
+
+    def dist_edges_local(self, world):
+        return [0] * world
+
+    def dist_pack(self, what, ptr):
+        pass
+
+    def dist_reduce(self, what, recv, n_recv, n_sources, owned, replies=None):
+        return 0
+
+    def dist_global(self, what, all_ptr, n_slots, n_total, replies=None):
+        pass
+
+
+def _handshake_worker(rank, world, port, q, plan):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from amira_amd._ffi import AmgError
+    from amira_amd.dist import PeerFailed, dist_build
+    eng = _FakeEngine(plan[rank])
+    try:
+        dist_build(eng, 5)
+        got = "built"
+    except PeerFailed as e:
+        got = ("PeerFailed", sorted(e.codes.items()), e.retry)
+    except AmgError as e:
+        got = ("AmgError", e.code)
+    q.put((rank, got, [a for _, a in eng.calls]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("plan,want", [
+    # a collision on one rank, a fatal error on the other IN THE SAME PHASE: nobody retries (the colliding rank used to
+    # re-enter the build alone and wait in its first all-gather for ever), everybody raises
+    (({0: -8}, {0: -3}), {0: ("PeerFailed", [(0, -2), (1, -1)], False), 1: ("AmgError", -3)}),
+    # a collision on one rank only: every rank repeats the build with the next seed, which goes through
+    (({0: -8}, {}), {0: "built", 1: "built"}),
+    # collisions on both ranks, twice: third attempt goes through
+    (({0: -8, 1: -8}, {0: -8, 1: -8}), {0: "built", 1: "built"}),
+])
+def test_collision_hand_shake_between_processes(plan, want):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handshake_worker, args=(r, world, port, q, plan)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, res, attempts = q.get(timeout=120)     # (a hang would end here)
+        got[r] = (res, attempts)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r][0] == want[r], (r, got[r])
+    n_attempts = max(len(p) for p in plan) + 1 if all(v == "built" for v in want.values()) else 1
+    for r in range(world):
+        assert got[r][1] == list(range(n_attempts)), (r, got[r][1])
