@@ -7,6 +7,8 @@
 // the bucket of the symbol there and verifies the candidates against the read (the read slice
 // is L1/L2 resident).  Hits are packed as (pattern, read, position) keys, radix-sorted, and
 // split per pattern — i.e. ordered by pattern, then read, then position.
+#include <algorithm>
+
 #include "amg_device.h"
 
 static inline unsigned int nblk(long long n, int per) {
@@ -27,34 +29,92 @@ struct MatchArgs {
   const long long* pat_off;
   const long long* bucket_off;  // [domain + 1] -> range in bucket_pat
   const int* bucket_pat;
+  const unsigned int* has_bits;  // bit s: some pattern starts with symbol s
   long long domain;
+  int lds_words;              // words of has_bits staged in LDS (0: tested in global memory)
   unsigned long long* hits;   // nullptr: count only
   unsigned long long* counter;
   unsigned long long cap;
 };
 
+// Waves walk the reads (grid stride); each lane takes positions of the read.  Nearly every position holds a symbol
+// no pattern starts with: that is decided by one bit of a bitmap over the symbol domain staged in LDS once per
+// workgroup (5 KB for 20 000 genes) — not by two 8-byte gathers from the bucket table per gene — and the hits of a
+// read are counted first, given their places by ONE atomicAdd of the wave, and written in a second look (a single
+// counter word takes ~90 returning atomics per microsecond: one per hit made a batch with a million hits cost 10 ms).
+#define MATCH_LDS_WORDS 12288  // 48 KB: 393 216 symbols
 __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= A.n_reads) return;
+  extern __shared__ unsigned int s_has[];
+  for (int w = threadIdx.x; w < A.lds_words; w += blockDim.x) s_has[w] = A.has_bits[w];
+  __syncthreads();
+  const unsigned int* has = A.lds_words ? s_has : A.has_bits;
   const int lane = threadIdx.x & 63;
-  const long long t0 = A.read_off[r];
-  const long long len = A.read_off[r + 1] - t0 - A.tail;
-  for (long long i = lane; i < len; i += 64) {
-    const int sym = A.seq[t0 + i];
-    if (sym < 0 || sym >= A.domain) continue;
-    for (long long b = A.bucket_off[sym]; b < A.bucket_off[sym + 1]; ++b) {
-      const int p = A.bucket_pat[b];
-      const long long po = A.pat_off[p], m = A.pat_off[p + 1] - po;
-      if (i + m > len) continue;
-      bool same = true;
-      for (long long j = 1; j < m && same; ++j) same = (A.seq[t0 + i + j] == A.pat[po + j]);
-      if (!same) continue;
-      unsigned long long at = atomicAdd(A.counter, 1ull);
-      if (A.hits && at < A.cap)
-        A.hits[at] = ((unsigned long long)p << (READ_BITS + POS_BITS)) |
-                     ((unsigned long long)r << POS_BITS) | (unsigned long long)i;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  unsigned long long counted = 0;  // (count-only launches: one atomicAdd per wave at the very end)
+  for (long long r = wave0; r < A.n_reads; r += n_waves) {
+    const long long t0 = A.read_off[r];
+    const long long len = A.read_off[r + 1] - t0 - A.tail;
+    // hits of a position: patterns of the bucket of its symbol that match there; fn(pattern) per hit
+    auto scan = [&](auto fn) {
+      for (long long i = lane; i < len; i += 64) {
+        const int sym = A.seq[t0 + i];
+        if (sym < 0 || sym >= A.domain) continue;
+        if (!((has[sym >> 5] >> (sym & 31)) & 1u)) continue;
+        for (long long b = A.bucket_off[sym]; b < A.bucket_off[sym + 1]; ++b) {
+          const int p = A.bucket_pat[b];
+          const long long po = A.pat_off[p], m = A.pat_off[p + 1] - po;
+          if (i + m > len) continue;
+          bool same = true;
+          for (long long j = 1; j < m && same; ++j) same = (A.seq[t0 + i + j] == A.pat[po + j]);
+          if (same) fn(p, i);
+        }
+      }
+    };
+    unsigned int mine = 0;
+    scan([&](int, long long) { ++mine; });
+    if (!A.hits) {
+      counted += mine;
+      continue;
     }
+    // places: exclusive prefix over the lanes, one atomicAdd of the wave
+    unsigned int x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    const unsigned int total = __shfl(x, 63, 64);
+    if (total == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)total);
+    base = ((unsigned long long)(unsigned int)__shfl((int)(unsigned int)(base >> 32), 0, 64) << 32) |
+           (unsigned long long)(unsigned int)__shfl((int)(unsigned int)base, 0, 64);
+    unsigned long long at = base + (unsigned long long)(x - mine);
+    scan([&](int p, long long i) {
+      if (at < A.cap)
+        A.hits[at] = ((unsigned long long)p << (READ_BITS + POS_BITS)) | ((unsigned long long)r << POS_BITS) |
+                     (unsigned long long)i;
+      ++at;
+    });
   }
+  if (!A.hits) {
+    for (int d = 32; d > 0; d >>= 1) counted += __shfl_down(counted, d, 64);
+    if (lane == 0 && counted) atomicAdd(A.counter, counted);
+  }
+}
+
+// bit s of has_bits: hist[s] != 0 (some pattern starts with symbol s)
+__global__ void k_pat_bits(const unsigned int* __restrict__ hist, long long domain, unsigned int* __restrict__ bits,
+                           long long words) {
+  const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  unsigned int v = 0;
+  for (int b = 0; b < 32; ++b) {
+    const long long s = 32 * w + b;
+    if (s < domain && hist[s]) v |= 1u << b;
+  }
+  bits[w] = v;
 }
 
 __global__ void k_pat_first(const int* __restrict__ pat, const long long* __restrict__ pat_off,
@@ -137,6 +197,11 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
                      c->s1.as<long long>(), (long long)n_pat, domain, first, idx, c->s3.as<unsigned int>());
   AMGCHK(prim_sort_u32_u32(c, first, first_sorted, idx, idx_sorted, (size_t)n_pat,
                            ilog2_ceil((uint64_t)domain + 2) + 1));
+  // symbols that start a pattern, as a bitmap (behind the per-symbol counts in s3: they are scanned below)
+  const long long bit_words = (domain + 31) / 32 + 1;
+  AMGCHK(c->gm_mask.ensure((size_t)bit_words * sizeof(unsigned int)));
+  hipLaunchKernelGGL(k_pat_bits, dim3(nblk(bit_words, 256)), dim3(256), 0, st, c->s3.as<unsigned int>(), domain,
+                     c->gm_mask.as<unsigned int>(), bit_words);
   AMGCHK(prim_exscan_u32_to_i64(c, c->s3.as<unsigned int>(), c->s4.as<long long>(), (size_t)domain + 1));
   MatchArgs A;
   A.seq = which == 1 ? c->tok_node.as<int>() : c->tokens.as<int>();
@@ -148,13 +213,19 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
   A.bucket_off = c->s4.as<long long>();
   A.bucket_pat = reinterpret_cast<const int*>(idx_sorted);
   A.domain = domain;
+  A.has_bits = c->gm_mask.as<unsigned int>();
+  A.lds_words = bit_words <= MATCH_LDS_WORDS ? (int)bit_words : 0;
+  const size_t lds_bytes = (size_t)A.lds_words * sizeof(unsigned int);
+  // grid: enough waves to fill the device a few times over, each walking reads with a grid stride (the bitmap is staged
+  // once per workgroup)
+  const unsigned int match_blocks = (unsigned int)std::min<long long>(nblk(c->n_reads, 4), 256ll * 16);
   A.hits = nullptr;
   A.counter = c->status.as<unsigned long long>() + ST_MISC;
   A.cap = 0;
   // ---- pass 1: count, pass 2: fill
   HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
   stage_begin(c, "match_count");  // (the stage is the kernel alone: bench.py prices it against the HBM roofline)
-  if (c->n_reads > 0) hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+  if (c->n_reads > 0) hipLaunchKernelGGL(k_match, dim3(match_blocks), dim3(256), lds_bytes, st, A);
   stage_end(c);
   unsigned long long total = 0;
   HIPCHK(hipMemcpyAsync(&total, A.counter, sizeof(total), hipMemcpyDeviceToHost, st));
@@ -171,7 +242,7 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
     A.cap = total;
     HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
     stage_begin(c, "match_fill");
-    hipLaunchKernelGGL(k_match, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_match, dim3(match_blocks), dim3(256), lds_bytes, st, A);
     stage_end(c);
     // sort by (pattern, read, position); the values of the pair sort are not needed
     AMGCHK(c->s2.ensure((size_t)(total + 1) * sizeof(unsigned int) * 2 + (size_t)(n_pat + 2) * sizeof(unsigned int) * 4));
