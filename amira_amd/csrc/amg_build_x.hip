@@ -225,6 +225,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
       valid |= 1u << w;
       if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
     }
+#ifndef AMG_W2_CAS
+    if constexpr (TWO)  // the slot belongs to whoever takes w1: two memory-side operations per creation instead of three
+      f_table_phase_own<1>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2, slot_by_claim,
+                           status + ST_NODE_INSERTS, cap, probe_limit, status, 1, id1, s_wave, &made);
+    else
+#endif
     f_table_phase<TWO, 1, false>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2,
                                  slot_by_claim, status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave,
                                  &made);
@@ -361,6 +367,13 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
       valid |= 1u << w;
       if ((b >> (K - 1)) & 1u) last |= 1u << w;
     }
+#ifndef AMG_W2_CAS
+    if constexpr (TWO)
+      f_table_phase_own<1, TILE_THREADS, AMG_BUCKET_PROBES>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir,
+                                                            xf, first2, slot_by_claim, status + ST_NODE_INSERTS, cap,
+                                                            probe_limit, status, 1, id1, s_wave, &made, valid, home_n);
+    else
+#endif
     f_table_phase<TWO, 1, false, TILE_THREADS, AMG_BUCKET_PROBES>(
         tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir, xf, first2, slot_by_claim,
         status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n);

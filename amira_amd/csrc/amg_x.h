@@ -510,6 +510,269 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
   }
 }
 
+// ------------------------------------------------------------------ two-word keys, the slot owned by whoever takes w1
+// (round 4).  f_table_phase above settles a two-word key with TWO compare-and-swaps (w1, then the tag in w2) and a
+// third memory-side operation when the claim id is published: a first build makes 5.4 M keys, and those 16 M operations
+// at the rate the memory side executes them are what it costs over a rebuild.  Here the thread whose CAS takes w1 OWNS
+// the slot; the second word — tag, coarse position, claim id — arrives in ONE store when the id is published.  A slot
+// is empty, owned (w1 set, w2 zero) or published (w2 complete, never changed again): one state fewer.  A thread that
+// finds w1 equal to its own while w2 is still zero cannot tell yet whether the slot holds its key (the low 63 bits agree;
+// the tag decides): it remembers the slot and looks again AFTER its own workgroup has published this round's creations —
+// the owner publishes after its workgroup's barrier and one atomicAdd, waiting for nobody, so there is no cycle — and
+// if the tag turns out to be another key's it goes on probing in a further ROUND of the phase (workgroup-uniform loop:
+// the claim ids of a round come from a workgroup scan).  Rounds beyond the first need two keys that agree in 63 bits
+// to meet in one probe chain while one of them is unpublished: rare, but it has to be right.
+// state: 0 found (w2v complete), 1 created (this thread owns the slot), 2 pending (w1 equal, w2 not published yet)
+template <bool BUCKET>
+__device__ __forceinline__ int x_upsert_own(Slot16* tab, unsigned int mask, unsigned long long w1, unsigned int tag,
+                                            unsigned int idx, ulonglong2 v, unsigned int limit,
+                                            const unsigned long long* abort_flag, unsigned long long& w2v, int& state,
+                                            unsigned int off = 0u) {
+  state = 0;
+  w2v = 0;
+  unsigned int probes = 0;
+  while (true) {
+    Slot16* s = tab + idx;
+    unsigned long long c1 = v.x, c2 = v.y;
+    if (c1 == 0ull) {
+      c1 = atomicCAS(&s->w1, 0ull, w1);  // looks empty: the CAS returns the truth
+      if (c1 == 0ull) {
+        state = 1;
+        return (int)idx;
+      }
+      c2 = 0ull;  // (whatever the cached view said about w2 belongs to no key yet)
+    }
+    if (c1 == w1) {
+      if (c2 == 0ull) c2 = ld_u64(&s->w2);  // not published in the view we have: one look with agent scope
+      if (c2 == 0ull) {
+        state = 2;
+        return (int)idx;
+      }
+      if ((unsigned int)(c2 >> 32) == tag) {  // (a published second word is complete and final)
+        w2v = c2;
+        return (int)idx;
+      }
+    }
+    if (probes >= limit) return -1;
+    if ((probes & 63u) == 63u && *reinterpret_cast<const volatile unsigned long long*>(abort_flag)) return -1;
+    ++probes;
+    idx = BUCKET ? ((idx & ~7u) | ((idx + 1u) & 7u)) : off + ((idx - off + 1u) & mask);
+    v = *reinterpret_cast<const ulonglong2*>(tab + idx);
+  }
+}
+
+template <int FSH, int STRIDE = 1, int HOME_PROBES = 1>
+__device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask, unsigned int valid,
+                                                  const unsigned long long (&w1)[TILE_ITEMS],
+                                                  const unsigned int (&tag)[TILE_ITEMS],
+                                                  const unsigned int (&idx0)[TILE_ITEMS],
+                                                  const ulonglong2 (&v)[TILE_ITEMS], unsigned int tbase,
+                                                  unsigned int lowbits, const XW2 f, unsigned int* first2,
+                                                  unsigned int* __restrict__ slot_by_claim, unsigned long long* ctr,
+                                                  unsigned int cap, unsigned int probe_limit, unsigned long long* status,
+                                                  int which, unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave,
+                                                  unsigned int* made_out, unsigned int homed = 0u, unsigned int off = 0u) {
+  auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
+  auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int slot[TILE_ITEMS];  // where the item is: its slot once settled, the slot to go on from while it is not
+  unsigned int need = 0, at_home = homed, made_all = 0;
+  // (id1[] holds the low half of the published second word of a FOUND key until the end, claim id + 1 of a created one)
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    id1[it] = 0;
+    slot[it] = (int)idx0[it];
+    if (!(valid & (1u << it))) continue;
+#ifdef AMG_ABLATE_NOPROBE
+    const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx0[it] & 1023ull));
+#else
+    const unsigned long long c1 = v[it].x, c2 = v[it].y;
+#endif
+    // the key with its id, as the first probe load returned it: done (almost every window of a rebuild)
+    if (c1 == w1[it] && (unsigned int)(c2 >> 32) == tag[it] && (unsigned int)c2 != 0u)
+      id1[it] = (unsigned int)c2;
+    else
+      need |= 1u << it;
+  }
+  // one item through the table from slot[it] on: found / created / pending; w1 of the item passed in
+  auto upsert_item = [&](int it, unsigned long long kw, unsigned int& created, unsigned int& pending) {
+    int state;
+    unsigned long long w2v;
+    const unsigned int ix = (unsigned int)f_pick(slot, it);
+    const unsigned int tg = f_pick(tag, it);
+    int sl;
+    if ((at_home >> it) & 1u) {
+      sl = x_upsert_own<(HOME_PROBES > 1)>(tab, mask, kw, tg, ix, *reinterpret_cast<const ulonglong2*>(tab + ix),
+                                           (unsigned int)(HOME_PROBES - 1), status + ST_OVERFLOW, w2v, state, off);
+      if (sl < 0) {  // other keys live in the home slot(s): this one goes where its key hashes to
+        at_home &= ~(1u << it);
+        const unsigned int ix2 = off + ((unsigned int)mix64(kw ^ ((unsigned long long)tg * 0x9E3779B97F4A7C15ull)) & mask);
+        sl = x_upsert_own<false>(tab, mask, kw, tg, ix2, *reinterpret_cast<const ulonglong2*>(tab + ix2), probe_limit,
+                                 status + ST_OVERFLOW, w2v, state, off);
+      }
+    } else {
+      sl = x_upsert_own<false>(tab, mask, kw, tg, ix, *reinterpret_cast<const ulonglong2*>(tab + ix), probe_limit,
+                               status + ST_OVERFLOW, w2v, state, off);
+    }
+    if (sl < 0) {
+      status[ST_OVERFLOW] = (unsigned long long)which;
+      valid &= ~(1u << it);
+      state = 0;
+      w2v = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j)
+      if (j == it) {
+        slot[j] = sl;
+        id1[j] = (unsigned int)w2v;
+      }
+    if (sl >= 0 && state == 1) created |= 1u << it;
+    if (sl >= 0 && state == 2) pending |= 1u << it;
+  };
+  // claim ids of a round's creators (ballots, one atomicAdd per workgroup on the single counter) and their publication
+  auto claim_and_publish = [&](unsigned int created) {
+    unsigned int n = 0, pre[TILE_ITEMS];
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) {
+      const unsigned long long m = __ballot((created >> it) & 1u);
+      pre[it] = n + (unsigned int)__popcll(m & below);
+      n += (unsigned int)__popcll(m);
+    }
+    if (lane == 0) s_wave[wave] = n;
+    __syncthreads();
+    unsigned int before = 0, total = 0, base = 0;
+#pragma unroll
+    for (unsigned int w = 0; w < TILE_THREADS / 64; ++w) {
+      const unsigned int cnt = s_wave[w];
+      before += w < wave ? cnt : 0u;
+      total += cnt;
+    }
+    if (total) {  // workgroup-uniform
+      if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total);
+      __syncthreads();
+      base = s_wave[TILE_THREADS / 64] + before;
+    }
+    if (created) {
+#pragma unroll
+      for (int it = 0; it < TILE_ITEMS; ++it)
+        if (created & (1u << it)) {
+          unsigned int claim = base + pre[it];
+          if (claim >= cap) {  // the claim arrays are used up: the host rebuilds larger
+            status[ST_OVERFLOW] = (unsigned long long)which;
+            claim = 0;
+          }
+          first2[2u * claim + 1u] = fi(it);  // the creator's own word, plain store (others raise the other word)
+          slot_by_claim[claim] = (unsigned int)slot[it];
+          id1[it] = claim + 1u;
+          const unsigned long long pub = ((unsigned long long)tag[it] << 32) |
+                                         (unsigned long long)((tpos(it) >> f.cshift) << f.ib) | (unsigned long long)(claim + 1u);
+          __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+  };
+  // the second word of a slot that was owned but not published when this thread met it (its owner publishes without
+  // waiting for anybody, after at most its own workgroup's barrier)
+  auto published = [&](int sl) {
+    unsigned long long w = 0ull;
+    for (unsigned int spins = 0;; ++spins) {
+      w = ld_u64(&tab[sl].w2);
+      if (w != 0ull) break;
+      if (spins > (1u << 22)) {  // seconds: never expected; fail the build instead of hanging
+        status[ST_MISC] = 1ull;
+        w = ~0ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    return w;
+  };
+
+  // ---- the round every workgroup runs
+  unsigned int redo = 0;
+  {
+    unsigned int created = 0, pending = 0;
+    while (need) {
+      const int it = __ffs((int)need) - 1;
+      need &= need - 1u;
+      upsert_item(it, f_pick(w1, it), created, pending);
+    }
+    made_all = created;
+    claim_and_publish(created);
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) {
+      if (!(pending & (1u << it))) continue;
+      const unsigned long long w = published(slot[it]);
+      if ((unsigned int)(w >> 32) == tag[it])
+        id1[it] = (unsigned int)w;
+      else
+        redo |= 1u << it;  // another key with the same low 63 bits lives there
+    }
+  }
+  // ---- further rounds: only when some thread of the workgroup met a half-equal key that was not published yet
+  // (cold: what it needs beyond the round above is fetched again — the slot it stopped at holds its own w1)
+  if (__syncthreads_or(redo != 0u)) {
+    for (unsigned int round = 0;; ++round) {
+      unsigned int created = 0, pending = 0, again = 0;
+      while (redo) {
+        const int it = __ffs((int)redo) - 1;
+        redo &= redo - 1u;
+        const unsigned int sl = (unsigned int)f_pick(slot, it);
+        const unsigned long long kw = tab[sl].w1;  // == this item's w1: that is why it stopped there
+        unsigned int next;
+        if ((at_home >> it) & 1u) {
+          at_home &= ~(1u << it);
+          next = off + ((unsigned int)mix64(kw ^ ((unsigned long long)f_pick(tag, it) * 0x9E3779B97F4A7C15ull)) & mask);
+        } else {
+          next = off + ((sl - off + 1u) & mask);
+        }
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; ++j)
+          if (j == it) slot[j] = (int)next;
+        upsert_item(it, kw, created, pending);
+      }
+      made_all |= created;
+      claim_and_publish(created);
+#pragma unroll
+      for (int it = 0; it < TILE_ITEMS; ++it) {
+        if (!(pending & (1u << it))) continue;
+        const unsigned long long w = published(slot[it]);
+        if ((unsigned int)(w >> 32) == tag[it])
+          id1[it] = (unsigned int)w;
+        else
+          again |= 1u << it;
+      }
+      redo = again;
+      if (!__syncthreads_or(redo != 0u)) break;
+      if (round > 64u) {  // (a chain of 64 half-equal keys: not of this world)
+        status[ST_MISC] = 1ull;
+        break;
+      }
+    }
+  }
+  if (made_out) *made_out = made_all;
+  // ---- found keys: keep the minimum first-seen (can this window precede the creator's?  coarse positions: same or
+  // earlier bucket); id1 turns from the slot's second word into claim id + 1
+  unsigned int check = 0;
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(valid & (1u << it))) {
+      id1[it] = 0;
+      continue;
+    }
+    if (made_all & (1u << it)) continue;
+    const unsigned int lw = id1[it];
+    id1[it] = lw & ((1u << f.ib) - 1u);
+    if ((tpos(it) >> f.cshift) <= (lw >> f.ib)) check |= 1u << it;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_ITEMS; ++it) {
+    if (!(check & (1u << it))) continue;
+    const unsigned int c = id1[it] - 1u;
+    if (x_first_inv(first2, c) < fi(it)) atomicMax(first2 + 2u * c, fi(it));
+  }
+}
+
 // field widths of a two-word slot's second word for `max_claims` ids over T tokens
 static inline XW2 xw2_for(size_t max_claims, long long T) {
   XW2 f;
