@@ -178,7 +178,7 @@ extern "C" int amg_create(int device, amg_ctx** out) {
     delete c;
     return amg_fail(AMG_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
-  int r = c->status.ensure(ST_ALLOC_WORDS * sizeof(unsigned long long));
+  int r = c->status.ensure(ST_WORDS * sizeof(unsigned long long));
   if (r != AMG_OK) {
     delete c;
     return r;

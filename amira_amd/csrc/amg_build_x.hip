@@ -722,7 +722,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
 // pair, goes to the hashed slots behind), and a thread's adjacencies lie 256 windows apart so that the 64 lanes of a
 // probe instruction look at 64 consecutive windows: consecutive ids, eight slots to a 128-byte line instead of one
 // line per lane (the passes are bound by the line requests of their probes).
-template <bool HEAD, bool HOME, bool IMPL = false>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart); IMPL: a home slot's index is its class's claim id (f_table_phase)
+template <bool HEAD, bool HOME>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
@@ -819,10 +819,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
   }
   unsigned int made = 0;
   if constexpr (HOME)
-    f_table_phase<false, 3, false, TILE_THREADS, 1, IMPL>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid,
-                                                          orient3, xf, first2, slot_by_claim, status + ST_PAIR_INSERTS, 0u,
-                                                          cap, probe_limit, status, 2, id1, s_wave, &made, homed, home_n,
-                                                          status + ST_HOME_INSERTS);
+    f_table_phase<false, 3, false, TILE_THREADS>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid, orient3, xf,
+                                                 first2, slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit,
+                                                 status, 2, id1, s_wave, &made, homed, home_n);
   else
     f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
                                    slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave,
@@ -1181,11 +1180,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
   }
   const size_t tab_slots = (size_t)c->edge_slots + (size_t)home_n;
-  // implicit claims (a home slot's index is its class's claim id: k_edges_v<.., true, true>): the single-GPU builds; the
-  // merge phases of amg_dist.hip walk dense claims.  AMG_EDGE_IMPLICIT=0: ids from the counter for every class (A/B)
-  const char* ei = getenv("AMG_EDGE_IMPLICIT");
-  const bool implicit = home_n > 0 && !c->dist_mode && !(ei && atoi(ei) == 0);
-  const size_t max_claims = implicit ? tab_slots + 1 : (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
+  const size_t max_claims = (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
   AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->edge_tab.ensure(tab_slots * sizeof(Slot16)));
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
@@ -1203,7 +1198,6 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     cl.add(c->edge_tab.p, tab_slots * sizeof(Slot16));
     cl.add(c->x_efirst.p, 2 * max_claims * sizeof(unsigned int));
     cl.add(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 2 * sizeof(unsigned long long));
-    cl.add(c->status.as<unsigned long long>() + ST_HOME_INSERTS, sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
   }
   stage_end(c);
@@ -1226,9 +1220,8 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
         stage_end(c);
         stage_begin(c, "edge_upsert");
       }
-      auto kern = implicit ? (part == 0 ? k_edges_v<true, true, true> : k_edges_v<false, true, true>)
-                  : home_n ? (part == 0 ? k_edges_v<true, true> : k_edges_v<false, true>)
-                           : (part == 0 ? k_edges_v<true, false> : k_edges_v<false, false>);
+      auto kern = home_n ? (part == 0 ? k_edges_v<true, true> : k_edges_v<false, true>)
+                         : (part == 0 ? k_edges_v<true, false> : k_edges_v<false, false>);
       hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
                          c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
                          c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
@@ -1238,16 +1231,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
-  unsigned long long n_home_made = 0;
-  {
-    unsigned long long all[ST_WORDS + 1];
-    FetchList l;
-    l.add_words(c->status.p, ST_WORDS);
-    l.add(c->status.as<unsigned long long>() + ST_HOME_INSERTS);
-    AMGCHK(fetch(c, l, all));
-    memcpy(hs, all, sizeof(hs));
-    n_home_made = all[ST_WORDS];
-  }
+  AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
 #ifdef AMG_EXP_CTR
   if ((AMG_EXP_CTR) == 2 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
@@ -1257,9 +1241,8 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     *which = 2;
     return AMG_E_OVERFLOW;
   }
-  c->n_local_pairs = c->n_pairs = (int64_t)(hs[ST_PAIR_INSERTS] + (implicit ? n_home_made : 0ull));
-  // (implicit claims: home slots nobody took are holes of the claim space, which ends behind the last hashed claim)
-  c->x_espace = implicit ? (int64_t)home_n + (int64_t)hs[ST_PAIR_INSERTS] : c->n_pairs;
+  c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
+  c->x_espace = c->n_pairs;
   c->x_max_eclaims = (int64_t)max_claims;
   return AMG_OK;
 }
@@ -1284,15 +1267,14 @@ int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov) {
   }
   // edge-class coverage per claim
   stage_begin(c, "edge_count");
-  const long long ES = c->x_espace;  // claim ids in use lie below it (== P unless home slots lend their indices as claims)
-  AMGCHK(c->x_ecnt.ensure((size_t)(ES + 2) * sizeof(unsigned int)));
-  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, ES, c->x_ecnt.as<unsigned int>(), 5));
+  AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));
+  AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, P, c->x_ecnt.as<unsigned int>(), 5));
   stage_end(c);
   if (min_edge_cov > 1 && P > 0) {  // filter_graph's edge threshold (:531-535)
     hipStream_t st = c->stream;
     unsigned long long* kept = c->status.as<unsigned long long>() + ST_COMPACT_A;
     HIPCHK(hipMemsetAsync(kept, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(ES, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), ES,
+    hipLaunchKernelGGL(k_x_drop_claims, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(), P,
                        min_edge_cov, c->x_efirst.as<unsigned int>(), (int*)nullptr, kept, (unsigned int*)nullptr);
     unsigned long long left = 0;
     FetchList l;

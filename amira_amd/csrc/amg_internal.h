@@ -120,10 +120,7 @@ enum {
   ST_COMPACT_B = 8,
   ST_MISC = 9,
   ST_BADINPUT = 10,      // malformed CSR: 1 = read offsets, 2 = a token outside [0, two_v)
-  ST_WORDS = 16,
-  // counters on cache lines of their own behind the status words (the buffer holds ST_ALLOC_WORDS)
-  ST_HOME_INSERTS = 32,  // edge classes created in their home slot (their claim id is the slot index: no counter hands it out)
-  ST_ALLOC_WORDS = 48
+  ST_WORDS = 16
 };
 
 struct StageTime {

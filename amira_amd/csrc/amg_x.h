@@ -321,14 +321,7 @@ __device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
 // key's hashed slot in tab[off .. off + mask]); one-word keys only.
 // HOME_PROBES: slots of its line a homed item looks at before it goes to its hashed slot (1: the home slot alone —
 // the edge pass; > 1: a bucket line of the node table, k_nodes_m).
-// IMPL (one-word keys with home slots: the edge pass): a class that lives in its HOME slot has that slot's index as
-// its claim id.  Nothing has to be handed out and nothing published: its creation is the CAS that takes the slot and
-// nothing else at the memory side (the creator's first-seen goes into the slot's second word with a plain store; who
-// does not see it yet looks at the claim's first-seen words instead), and nobody ever waits for a home slot's id.  The
-// claims of the hashed slots start behind the home slots (off + counter), so the claim space has holes — home slots
-// nobody took — which every consumer of claims skips (first-seen words zero); the classes are counted separately
-// (home_ctr).  Two memory-side operations per creation become one for nine classes in ten.
-template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1, int HOME_PROBES = 1, bool IMPL = false>
+template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1, int HOME_PROBES = 1>
 __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
                                               const unsigned long long (&w1)[TILE_ITEMS],
                                               const unsigned int (&tag)[TILE_ITEMS],
@@ -340,8 +333,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                                               unsigned int probe_limit, unsigned long long* status, int which,
                                               unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr,
                                               unsigned int* made = nullptr, unsigned int homed = 0u,
-                                              unsigned int off = 0u, unsigned long long* home_ctr = nullptr) {
-  static_assert(!IMPL || (!TWO && !SHARDED), "implicit claims: one-word keys, one claim counter");
+                                              unsigned int off = 0u) {
   auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
   auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
@@ -366,7 +358,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     const unsigned long long c1 = v[it].x, c2 = v[it].y;
 #endif
     const bool mine = c1 == w1[it] && (!TWO || (unsigned int)(c2 >> 32) == tag[it]);
-    if (mine && ((unsigned int)c2 != 0u || (IMPL && ((homed >> it) & 1u)))) {  // (a home slot's id is its index)
+    if (mine && (unsigned int)c2 != 0u) {
       lw[it] = (unsigned int)c2;
       if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(c2 >> 32);
     } else {
@@ -414,31 +406,6 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
   // ---- claim ids of the wave's creators
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
-  unsigned int at_home = 0, born = 0;  // IMPL: items settled in a home slot (created there or found there); created there
-  if constexpr (IMPL) {
-    unsigned int n_home = 0;
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it) {
-      if ((valid & (1u << it)) && (unsigned int)slot[it] < off) at_home |= 1u << it;
-      n_home += (unsigned int)__popcll(__ballot(((created & at_home) >> it) & 1u));
-    }
-    if (lane == 0 && n_home) atomicAdd(home_ctr, (unsigned long long)n_home);  // (nobody reads the result: a count for the host)
-    born = created & at_home;
-    if (born) {
-#pragma unroll
-      for (int it = 0; it < TILE_ITEMS; ++it)
-        if (born & (1u << it)) {
-          const unsigned int claim = (unsigned int)slot[it];
-          first2[2u * claim + 1u] = fi(it);
-          slot_by_claim[claim] = claim;
-          id1[it] = claim + 1u;
-          // the creator's first-seen for the "can this window be earlier?" test of later windows: a plain store, seen
-          // by others when the line is written back (until then they check the claim's first-seen words)
-          tab[claim].w2 = ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
-        }
-    }
-    created &= ~at_home;  // what is left takes its ids from the counter, behind the home slots
-  }
   unsigned int n = 0, pre[TILE_ITEMS];
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
@@ -492,11 +459,11 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     for (int it = 0; it < TILE_ITEMS; ++it)
       if (created & (1u << it)) {
         unsigned int li = base + pre[it];
-        if (li + (IMPL ? off : 0u) >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
+        if (li >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
           status[ST_OVERFLOW] = (unsigned long long)which;
           li = 0;
         }
-        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : (IMPL ? off + li : li);
+        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : li;
         // the creator's first-seen goes to its own word with a plain store; everybody else raises the
         // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
         // has to be ordered against the publication of the id
@@ -516,15 +483,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
 #pragma unroll
   for (int it = 0; it < TILE_ITEMS; ++it) {
     if (!(valid & (1u << it)) || (created & (1u << it))) continue;
-    if (IMPL && ((born >> it) & 1u)) continue;  // created in its home slot: settled above
     unsigned long long w = (unsigned long long)lw[it] | (TWO ? 0ull : (unsigned long long)hw[TWO ? 0 : it] << 32);
-    if (IMPL && ((at_home >> it) & 1u)) {
-      // found in its home slot: the id is the slot's index; the second word, if it has arrived, only says whether
-      // this window can precede the creator's (not there yet: high half 0, the claim's first-seen words are checked)
-      id1[it] = (unsigned int)slot[it] + 1u;
-      if (fi(it) > (unsigned int)(w >> 32)) check |= 1u << it;
-      continue;
-    }
     for (unsigned int spins = 0; (unsigned int)w == 0u; ++spins) {
       w = ld_u64(&tab[slot[it]].w2);
       if ((unsigned int)w != 0u) break;
