@@ -519,9 +519,9 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
 // finds w1 equal to its own while w2 is still zero cannot tell yet whether the slot holds its key (the low 63 bits agree;
 // the tag decides): it remembers the slot and looks again AFTER its own workgroup has published this round's creations —
 // the owner publishes after its workgroup's barrier and one atomicAdd, waiting for nobody, so there is no cycle — and
-// if the tag turns out to be another key's it goes on probing in a further ROUND of the phase (workgroup-uniform loop:
-// the claim ids of a round come from a workgroup scan).  Rounds beyond the first need two keys that agree in 63 bits
-// to meet in one probe chain while one of them is unpublished: rare, but it has to be right.
+// if the tag turns out to be another key's it goes on probing by itself (a key it then creates takes its claim id with
+// an atomicAdd of its own).  That needs two keys that agree in 63 bits to meet in one probe chain while one of them
+// is unpublished: rare, but it has to be right.
 // state: 0 found (w2v complete), 1 created (this thread owns the slot), 2 pending (w1 equal, w2 not published yet)
 template <bool BUCKET>
 __device__ __forceinline__ int x_upsert_own(Slot16* tab, unsigned int mask, unsigned long long w1, unsigned int tag,
@@ -709,46 +709,81 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
         redo |= 1u << it;  // another key with the same low 63 bits lives there
     }
   }
-  // ---- further rounds: only when some thread of the workgroup met a half-equal key that was not published yet
-  // (cold: what it needs beyond the round above is fetched again — the slot it stopped at holds its own w1)
-  if (__syncthreads_or(redo != 0u)) {
-    for (unsigned int round = 0;; ++round) {
-      unsigned int created = 0, pending = 0, again = 0;
-      while (redo) {
-        const int it = __ffs((int)redo) - 1;
-        redo &= redo - 1u;
-        const unsigned int sl = (unsigned int)f_pick(slot, it);
-        const unsigned long long kw = tab[sl].w1;  // == this item's w1: that is why it stopped there
-        unsigned int next;
-        if ((at_home >> it) & 1u) {
-          at_home &= ~(1u << it);
-          next = off + ((unsigned int)mix64(kw ^ ((unsigned long long)f_pick(tag, it) * 0x9E3779B97F4A7C15ull)) & mask);
-        } else {
-          next = off + ((sl - off + 1u) & mask);
+  // ---- an item that met a half-equal key (the same low 63 bits, another tag) goes on from the next slot BY ITSELF:
+  // rare, so a key it creates takes its claim id with an atomicAdd of its own instead of the workgroup's scan — no
+  // barrier, nobody else involved.  One step per loop iteration and lane (probe a slot, or look once more at a second
+  // word that is not there yet): a lane that has just taken a slot publishes in the same iteration, so no lane of a
+  // wave ever spins waiting for another lane of the same wave.  (The slot the item stopped at holds its own w1.)
+  while (redo) {
+    const int it = __ffs((int)redo) - 1;
+    redo &= redo - 1u;
+    const unsigned int stopped = (unsigned int)f_pick(slot, it);
+    const unsigned long long kw = tab[stopped].w1;
+    const unsigned int tg = f_pick(tag, it);
+    unsigned int at;
+    if ((at_home >> it) & 1u) {
+      at_home &= ~(1u << it);
+      at = off + ((unsigned int)mix64(kw ^ ((unsigned long long)tg * 0x9E3779B97F4A7C15ull)) & mask);
+    } else {
+      at = off + ((stopped - off + 1u) & mask);
+    }
+    unsigned int got = 0, probes = 0, polls = 0;
+    bool born = false, lost = false;
+    while (true) {
+      Slot16* sp = tab + at;
+      unsigned long long c1 = sp->w1, c2 = 0ull;
+      if (c1 == 0ull) {
+        c1 = atomicCAS(&sp->w1, 0ull, kw);
+        if (c1 == 0ull) {  // taken: claim id, first-seen, publication — all in this iteration
+          unsigned int claim = (unsigned int)atomicAdd(ctr, 1ull);
+          if (claim >= cap) {
+            status[ST_OVERFLOW] = (unsigned long long)which;
+            claim = 0;
+          }
+          const unsigned int tp = tbase + (unsigned int)it * (unsigned int)STRIDE;
+          first2[2u * claim + 1u] = ~((tp << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u)));
+          slot_by_claim[claim] = at;
+          __hip_atomic_store(&sp->w2, ((unsigned long long)tg << 32) | (unsigned long long)((tp >> f.cshift) << f.ib) |
+                                          (unsigned long long)(claim + 1u),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          got = claim + 1u;
+          born = true;
+          break;
         }
-#pragma unroll
-        for (int j = 0; j < TILE_ITEMS; ++j)
-          if (j == it) slot[j] = (int)next;
-        upsert_item(it, kw, created, pending);
       }
-      made_all |= created;
-      claim_and_publish(created);
-#pragma unroll
-      for (int it = 0; it < TILE_ITEMS; ++it) {
-        if (!(pending & (1u << it))) continue;
-        const unsigned long long w = published(slot[it]);
-        if ((unsigned int)(w >> 32) == tag[it])
-          id1[it] = (unsigned int)w;
-        else
-          again |= 1u << it;
+      if (c1 == kw) {
+        c2 = ld_u64(&sp->w2);
+        if (c2 == 0ull) {  // owned, not published yet: look again in the next iteration
+          if (++polls > (1u << 22)) {
+            status[ST_MISC] = 1ull;
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        if ((unsigned int)(c2 >> 32) == tg) {
+          got = (unsigned int)c2;
+          break;
+        }
       }
-      redo = again;
-      if (!__syncthreads_or(redo != 0u)) break;
-      if (round > 64u) {  // (a chain of 64 half-equal keys: not of this world)
-        status[ST_MISC] = 1ull;
+      if (++probes > probe_limit) {
+        lost = true;
         break;
       }
+      at = off + ((at - off + 1u) & mask);
     }
+    if (lost) {
+      status[ST_OVERFLOW] = (unsigned long long)which;
+      valid &= ~(1u << it);
+    }
+    if (born) made_all |= 1u << it;
+#pragma unroll
+    for (int j = 0; j < TILE_ITEMS; ++j)
+      if (j == it) {
+        slot[j] = (int)at;
+        id1[j] = got;
+      }
   }
   if (made_out) *made_out = made_all;
   // ---- found keys: keep the minimum first-seen (can this window precede the creator's?  coarse positions: same or

@@ -204,3 +204,53 @@ def test_build_many_graphs_equal_separate_graphs():
     many[1].close()
     many[2].close()
     assert many[0]._engine is None
+
+
+@pytest.mark.parametrize("buckets", ["1", "0"])
+def test_half_equal_two_word_keys(buckets, monkeypatch):
+    """Two-word exact keys (k * bits > 63) whose first 63 bits agree and whose last gene differs: the slot belongs to
+    whoever takes the first key word, everybody else learns from the second word — published later, in one store —
+    whether the slot holds ITS key, and goes on probing if not.  Tens of thousands of such keys are created at once
+    here (short reads [A, B, C, D, X_i]: with minimiser buckets they all aim at ONE home slot), each seen two or three
+    times, forwards and as reverse complements, against the sequential C oracle."""
+    import token_oracle
+    from amira_amd import Engine
+    monkeypatch.setenv("AMG_NODE_BUCKETS", buckets)
+    V, k = 30000, 5                      # 16 bits per gene: 80-bit tuples
+    rng = np.random.default_rng(11)
+    reads = []
+    for fam in range(6):                 # six families of keys sharing their first four genes
+        head = rng.choice(V, 4, replace=False)
+        strands = rng.integers(0, 2, 5)
+        for x in rng.choice(V, 9000, replace=False):
+            genes = np.concatenate([head, [x]])
+            fwd = np.where(strands == 1, V + genes, V - 1 - genes)
+            for _ in range(int(rng.integers(2, 4))):
+                reads.append(fwd if rng.random() < 0.5 else (2 * V - 1 - fwd[::-1]))
+    # longer reads over the same families (edges between half-equal keys' nodes and ordinary ones)
+    for _ in range(3000):
+        reads.append(rng.integers(0, 2 * V, int(rng.integers(5, 12))))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    toks = np.concatenate(reads).astype(np.int32)
+    offs = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum([len(r) for r in reads], out=offs[1:])
+    eng = Engine(0)
+    try:
+        for rep in range(3):             # (creation races differ from run to run)
+            eng.set_reads(toks, offs, 2 * V)
+            eng.build(k)
+            c = eng.counts()
+            assert c["exact_keys"] == 1
+            want = token_oracle.build(toks, offs, k, 2 * V)
+            nodes, edges = eng.nodes(), eng.edges()
+            tok_node, tok_dir = eng.read_nodes()
+            assert c["n_windows"] == want["n_windows"]
+            assert np.array_equal(nodes["tokens"], want["tokens"])
+            assert np.array_equal(nodes["coverage"], want["coverage"])
+            assert np.array_equal(nodes["first_dir"], want["first_dir"])
+            for a, b in (("src", "src"), ("tgt", "tgt"), ("sdir", "sdir"), ("tdir", "tdir"), ("coverage", "ecov")):
+                assert np.array_equal(edges[a], want[b]), a
+            assert np.array_equal(tok_node, want["tok_node"]) and np.array_equal(tok_dir, want["tok_dir"])
+    finally:
+        eng.close()
