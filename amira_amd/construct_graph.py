@@ -468,8 +468,9 @@ class GeneMerGraph(BubblePopping):
     def _positions_from_mapping(self):
         if self._gs_val is None and isinstance(self._genePositions, TokenizedPositions) \
                 and self._genePositions._moved is None and self._genePositions._gs is not None:
-            self._gs_val = np.ascontiguousarray(self._genePositions.gene_start, np.int64)
-            self._ge_val = np.ascontiguousarray(self._genePositions.gene_end, np.int64)
+            keep32 = self._genePositions.gene_start.dtype == np.int32 and self._genePositions.gene_end.dtype == np.int32
+            self._gs_val = np.ascontiguousarray(self._genePositions.gene_start, np.int32 if keep32 else np.int64)
+            self._ge_val = np.ascontiguousarray(self._genePositions.gene_end, np.int32 if keep32 else np.int64)
 
     @property
     def _gs(self):
@@ -485,8 +486,10 @@ class GeneMerGraph(BubblePopping):
         """flat int64 (start, end) per gene, aligned with the tokens"""
         offs = self._read_off
         if isinstance(gene_positions, TokenizedPositions) and gene_positions._moved is None:  # as it was made
-            self._gs_val = np.ascontiguousarray(gene_positions.gene_start, np.int64)
-            self._ge_val = np.ascontiguousarray(gene_positions.gene_end, np.int64)
+            # (int32 arrays stay int32: they cross PCIe as they are, amg_set_positions32)
+            keep32 = gene_positions.gene_start.dtype == np.int32 and gene_positions.gene_end.dtype == np.int32
+            self._gs_val = np.ascontiguousarray(gene_positions.gene_start, np.int32 if keep32 else np.int64)
+            self._ge_val = np.ascontiguousarray(gene_positions.gene_end, np.int32 if keep32 else np.int64)
             assert len(self._gs_val) == int(offs[-1]) == len(self._ge_val), "positions do not match the gene calls"
         elif gene_positions:
             n = int(offs[-1])

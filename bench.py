@@ -499,7 +499,7 @@ def run_api_e2e(w, vocab, toks, offs, k, n_windows, steps=5):
     from amira_amd.io import ReadLengths, TokenizedPositions, TokenizedReads
     N, L = w["N"], w["L"]
     ids = synth.read_names(0, N)
-    gs = np.tile(np.arange(L, dtype=np.int64) * 1000, N)
+    gs = np.tile(np.arange(L, dtype=np.int32) * 1000, N)   # (read coordinates fit 32 bits: uploaded as they are)
     ge = gs + 899
     lengths = ReadLengths(ids, np.full(N, L * 1000 + 100, np.int64))
     stages = {}

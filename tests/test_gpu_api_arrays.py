@@ -190,3 +190,23 @@ def test_mappings_of_a_correction_survive_later_passes():
         g3d.close()
     gd.close()
     gt.close()
+
+
+def test_int32_positions_through_the_api():
+    """array-backed positions handed over as int32 (read coordinates fit) stay int32 on the way to the device
+    (amg_set_positions32): the sweep returns the same reads, positions and graph as with int64 arrays"""
+    from amira_amd import graph_utils as gu
+    from amira_amd.io import TokenizedPositions
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    treads, tpos, tlen = _tokenized(reads, pos, fq)
+    tpos32 = TokenizedPositions(tpos.read_ids, tpos.read_offsets, tpos.gene_start.astype(np.int32),
+                                tpos.gene_end.astype(np.int32))
+    g64, r64, p64 = gu.cleaning_sweep(treads, tpos, 5, tlen, 3)
+    g32, r32, p32 = gu.cleaning_sweep(treads, tpos32, 5, tlen, 3)
+    assert g32._gs_val is None or g32._gs_val.dtype in (np.int32, np.int64)
+    assert list(r32) == list(r64)
+    for r in r64:
+        assert r32[r] == r64[r] and [tuple(x) for x in p32[r]] == [tuple(x) for x in p64[r]], r
+    assert list(g32.get_nodes()) == list(g64.get_nodes())
+    g64.close()
+    g32.close()
