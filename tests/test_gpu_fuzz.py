@@ -45,3 +45,17 @@ def test_random_bubble_popping_equals_oracle():
     assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
     n_ok = int(last[-1].split()[1])
     assert n_ok >= 3 and " 0 failures" in last[-1]
+
+
+def test_random_two_word_keys_equal_c_oracle():
+    """tools/fuzz_twoword.py: read sets whose gene-mers need two-word exact keys, many of them agreeing in their first
+    63 bits, with and without minimiser buckets, against the sequential C oracle (the slot protocol of amg_x.h: owner by
+    the first key word, publication of the second, the lone continuation of a half-equal key)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_twoword.py"), "40", "20261003"],
+                         capture_output=True, text=True, timeout=600)
+    last = [l for l in out.stdout.splitlines() if l.startswith("fuzz_twoword:")]
+    assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(last[-1].split()[1]) >= 5 and " 0 failures" in last[-1]
