@@ -105,6 +105,7 @@ def _load():
         "amg_cluster_blocks_free": (C.c_int, [P]),
         "amg_py_tuple_hash": (I64, [P, I64]),
         "amg_pyset_script": (C.c_int, [P, I64, P, I32, P, P]),
+        "amg_fetch_words": (C.c_int, [P, P, I32, P]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
         "amg_set_timing": (C.c_int, [P, C.c_int]),
     }

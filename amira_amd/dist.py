@@ -111,7 +111,16 @@ def _all_gather(out, inp, group):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def exchange_a2a(buf, send_counts, rec_bytes, group=None):
+def _read_counts(t, read):
+    """a small int64 count tensor on the host: through the engine's pinned mailbox when the tensor lives on the
+    engine's device and the collective that filled it ran on the engine's stream (`read` = Engine.fetch_words), else
+    the framework's read-back"""
+    if read is not None and t.is_cuda and t.numel() <= 32:
+        return read(t.data_ptr(), t.numel())
+    return t.tolist()
+
+
+def exchange_a2a(buf, send_counts, rec_bytes, group=None, read=None):
     """variable-size all-to-all of whole records (works on device tensors with RCCL and on CPU
     tensors with gloo): returns (recv tensor, records received from every rank)."""
     import torch.distributed as dist
@@ -119,7 +128,7 @@ def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)
     _a2a_single(rc, sc, None, None, group)
-    recv_counts = rc.tolist()
+    recv_counts = _read_counts(rc, read)
     if min(recv_counts, default=0) < 0 or min(send_counts, default=0) < 0:   # see dist_build
         bad = {r: n for r, n in enumerate(recv_counts) if n < 0}
         raise PeerFailed(sorted(bad), bad)
@@ -130,7 +139,7 @@ def exchange_a2a(buf, send_counts, rec_bytes, group=None):
     return recv, recv_counts
 
 
-def exchange_ag(buf, n_owned, rec_bytes, group=None):
+def exchange_ag(buf, n_owned, rec_bytes, group=None, read=None):
     """variable-size all-gather of whole records as ONE equal-size all-gather: every rank contributes m = the largest
     count, its unused tail zeroed (a record's first 8 bytes are never zero, so the consumer skips the padding; owners
     are chosen by hash, so the counts are nearly equal and the padding is small).
@@ -141,7 +150,7 @@ def exchange_ag(buf, n_owned, rec_bytes, group=None):
     no = torch.tensor([n_owned], dtype=torch.int64, device=dev)
     allno = torch.empty(world, dtype=torch.int64, device=dev)
     _all_gather(allno, no, group)
-    counts = allno.tolist()
+    counts = _read_counts(allno, read)
     if min(counts) < 0:   # see dist_build
         bad = {r: n for r, n in enumerate(counts) if n < 0}
         raise PeerFailed(sorted(bad), bad)
@@ -193,12 +202,16 @@ def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchan
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = _dev(engine)
+    # counts of the exchanges come to the host through the engine's pinned mailbox when the transport is RCCL (the
+    # collectives run on the engine's stream); gloo stages through the host anyway
+    read = engine.fetch_words if (engine.device is not None and hasattr(engine, "fetch_words")
+                                  and not _host_staged(group) and not os.environ.get("AMG_DIST_PLAIN_READBACK")) else None
     exchange = world > 1 or always_exchange or bool(os.environ.get("AMG_DIST_ALWAYS_EXCHANGE"))
     if world > 1:
         n_local = torch.tensor([engine.sizes()[1]], dtype=torch.int64, device=dev)
         gathered = torch.empty(world, dtype=torch.int64, device=dev)
         _all_gather(gathered, n_local, group)
-        tokens = gathered.tolist()
+        tokens = _read_counts(gathered, read)
     else:
         tokens = [engine.sizes()[1]]
     gen = steps(engine, k, world, rank, sum(tokens[:rank]), sum(tokens), min_node_cov, min_edge_cov, attempt)
@@ -221,9 +234,9 @@ def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchan
                 dummy = torch.zeros(1, dtype=torch.uint8, device=dev)
                 try:
                     if nxt == "a2a":
-                        exchange_a2a(dummy, [code] * world, 1, group)
+                        exchange_a2a(dummy, [code] * world, 1, group, read)
                     else:
-                        exchange_ag(dummy, code, 1, group)
+                        exchange_ag(dummy, code, 1, group, read)
                 except PeerFailed as seen:
                     # What every rank saw in this hand-shake decides what every rank does next: retry only when ALL
                     # the failures were collisions.  A local collision next to another rank's fatal error must not
@@ -241,9 +254,9 @@ def _dist_build_once(engine, k, group, min_node_cov, min_edge_cov, always_exchan
             else:
                 reply = req[1]
         elif op == "a2a":
-            reply = exchange_a2a(req[1], req[2], req[3], group)
+            reply = exchange_a2a(req[1], req[2], req[3], group, read)
         elif op == "ag":
-            reply = exchange_ag(req[1], req[2], req[3], group)
+            reply = exchange_ag(req[1], req[2], req[3], group, read)
         else:
             reply = exchange_back(req[1], req[2], req[3], group)
 

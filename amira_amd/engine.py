@@ -113,6 +113,13 @@ class Engine:
     def stream(self):
         return _ffi.lib.amg_stream(self._h)
 
+    def fetch_words(self, dev_ptr, n):
+        """n (<= 32) int64 words of device memory, ordered after everything queued on the engine's stream, through the
+        engine's pinned mailbox (a few microseconds instead of a framework read-back)"""
+        out = np.empty(n, np.int64)
+        check(_ffi.lib.amg_fetch_words(self._h, C.c_void_p(dev_ptr), int(n), ptr(out)))
+        return out.tolist()
+
     def set_timing(self, on):
         """per-stage HIP-event timing (two events per stage, ~5 us of stream idle each): on by default"""
         check(_ffi.lib.amg_set_timing(self._h, 1 if on else 0))
