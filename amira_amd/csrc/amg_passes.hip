@@ -178,24 +178,39 @@ __global__ void k_lr_count(const unsigned int* __restrict__ keys, long long n_li
   if (i < n_live) atomicAdd(&lrows[keys[i]].y, 1);
 }
 
+// (LR_PER edges per thread: the pool word takes ~90 returning atomics per microsecond, and a workgroup per 256 of a
+// million live edges spent 45 of this kernel's 64 us queueing there)
+#define LR_PER 8
 __global__ __launch_bounds__(256) void k_lr_alloc(const unsigned int* __restrict__ keys, long long n_live,
                                                   int4* __restrict__ lrows, unsigned int* __restrict__ tick,
                                                   unsigned long long* pool) {
   __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int t = 1, cnt = 0, key = 0;
-  if (i < n_live) {
-    key = keys[i];
-    t = (unsigned int)atomicAdd(&lrows[key].z, 1);
-    tick[i] = t;
-    if (t == 0) cnt = (unsigned int)lrows[key].y;  // final: k_lr_count is a launch of its own
+  const long long i0 = (long long)blockIdx.x * (256 * LR_PER) + threadIdx.x;
+  unsigned int cnt[LR_PER], key[LR_PER], mine = 0;
+#pragma unroll
+  for (int j = 0; j < LR_PER; ++j) {
+    const long long i = i0 + (long long)j * 256;
+    cnt[j] = 0;
+    key[j] = 0;
+    if (i < n_live) {
+      key[j] = keys[i];
+      const unsigned int t = (unsigned int)atomicAdd(&lrows[key[j]].z, 1);
+      tick[i] = t;
+      if (t == 0) cnt[j] = (unsigned int)lrows[key[j]].y | 0x80000000u;  // final: k_lr_count is a launch of its own
+      mine += cnt[j] & 0x7fffffffu;
+    }
   }
   unsigned int total;
-  const unsigned int off = block_exscan_256(cnt, &total, s_wave);
+  unsigned int off = block_exscan_256(mine, &total, s_wave);
   if (threadIdx.x == 0) s_base = total ? atomicAdd(pool, (unsigned long long)total) : 0ull;
   __syncthreads();
-  if (i < n_live && t == 0) lrows[key].x = (int)(s_base + off);
+#pragma unroll
+  for (int j = 0; j < LR_PER; ++j)
+    if (cnt[j] & 0x80000000u) {  // this edge drew ticket 0 of its row: it places the row's stretch
+      lrows[key[j]].x = (int)(s_base + off);
+      off += cnt[j] & 0x7fffffffu;
+    }
 }
 
 __global__ void k_lr_fill(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ edge_of,
@@ -290,8 +305,8 @@ static int ensure_live_adj(amg_ctx* c) {
                        c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), c->ladj_pos.as<long long>(), E, keys,
                        edge_of);
     hipLaunchKernelGGL(k_lr_count, dim3(nblk(total, 256)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>());
-    hipLaunchKernelGGL(k_lr_alloc, dim3(nblk(total, 256)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>(), tick,
-                       ctr);
+    hipLaunchKernelGGL(k_lr_alloc, dim3(nblk(total, 256 * LR_PER)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>(),
+                       tick, ctr);
     hipLaunchKernelGGL(k_lr_fill, dim3(nblk(total, 256)), dim3(256), 0, st, keys, edge_of, tick, total,
                        c->ladj_rows.as<int4>(), tmp);
     hipLaunchKernelGGL(k_lr_finish, dim3(nblk(total, 256)), dim3(256), 0, st, keys, tick, total, tmp, c->edge_tgt.as<int>(),
