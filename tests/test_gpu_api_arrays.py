@@ -173,23 +173,31 @@ def test_mappings_of_a_correction_survive_later_passes():
     some = list(rd)[:50]
     for r in some:
         assert rt[r] == rd[r] and [tuple(x) for x in pt[r]] == [tuple(x) for x in pd[r]]
-    # ... and the same through filter_graph / remove_node / remove_low_coverage_components
+    gd.close()
+    gt.close()
+    # ... and the same through filter_graph / remove_node / remove_low_coverage_components (a fresh pair of graphs each
+    # time: the reference's correct_reads is not meant to run twice on one graph — it would align the ORIGINAL genes
+    # with positions its first run has already replaced)
     for mutate in (lambda g: g.filter_graph(4, 2), lambda g: g.remove_node(next(iter(g.get_nodes().values()))),
                    lambda g: g.remove_low_coverage_components(5)):
+        treads, tpos, tlen = _tokenized(reads, pos, fq)
+        gd, gt = GeneMerGraph(dict(reads), 5, {r: list(v) for r, v in pos.items()}), GeneMerGraph(treads, 5, tpos)
+        gd.filter_graph(3, 1)
+        gt.filter_graph(3, 1)
         r2t, p2t = gt.correct_reads(tlen)
         r2d, p2d = gd.correct_reads(fq)
+        assert r2t.device_source() is not None
         mutate(gt)
         mutate(gd)
+        assert r2t.device_source() is None
         assert list(r2t) == list(r2d)
         for r in list(r2d)[:50]:
             assert r2t[r] == r2d[r] and [tuple(x) for x in p2t[r]] == [tuple(x) for x in p2d[r]]
         g3 = GeneMerGraph(r2t, 5, p2t)           # (host arrays by now)
         g3d = GeneMerGraph(r2d, 5, p2d)
         assert list(g3.get_nodes()) == list(g3d.get_nodes())
-        g3.close()
-        g3d.close()
-    gd.close()
-    gt.close()
+        for g in (g3, g3d, gd, gt):
+            g.close()
 
 
 def test_int32_positions_through_the_api():
