@@ -52,7 +52,31 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
   const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
   unsigned long long counted = 0;  // (count-only launches: one atomicAdd per wave at the very end)
-  for (long long r = wave0; r < A.n_reads; r += n_waves) {
+  // MATCH_BATCH reads per iteration: their offsets and first 64 symbols are loaded for all of them before any is
+  // looked at (a wave that walks one read at a time is bound by the chain offsets -> symbols of that one read); a read
+  // none of whose symbols starts a pattern — nearly all of them — is done after that look
+  constexpr int MATCH_BATCH = 4;
+  for (long long rb = wave0 * MATCH_BATCH; rb < A.n_reads; rb += n_waves * MATCH_BATCH) {
+    long long bt0[MATCH_BATCH], blen[MATCH_BATCH];
+    int bsym[MATCH_BATCH];
+#pragma unroll
+    for (int q = 0; q < MATCH_BATCH; ++q) {
+      const long long r = rb + q;
+      bt0[q] = r < A.n_reads ? A.read_off[r] : 0;
+      blen[q] = r < A.n_reads ? A.read_off[r + 1] - bt0[q] - A.tail : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < MATCH_BATCH; ++q) bsym[q] = lane < blen[q] ? A.seq[bt0[q] + lane] : -1;
+    unsigned int todo = 0;
+#pragma unroll
+    for (int q = 0; q < MATCH_BATCH; ++q) {
+      const int sym = bsym[q];
+      const bool cand = sym >= 0 && sym < A.domain && ((has[sym >> 5] >> (sym & 31)) & 1u);
+      if (__any(cand) || blen[q] > 64) todo |= 1u << q;
+    }
+   for (int q = 0; q < MATCH_BATCH; ++q) {
+    if (!((todo >> q) & 1u)) continue;
+    const long long r = rb + q;
     const long long t0 = A.read_off[r];
     const long long len = A.read_off[r + 1] - t0 - A.tail;
     // hits of a position: patterns of the bucket of its symbol that match there; fn(pattern) per hit
@@ -97,6 +121,7 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
                      (unsigned long long)i;
       ++at;
     });
+   }
   }
   if (!A.hits) {
     for (int d = 32; d > 0; d >>= 1) counted += __shfl_down(counted, d, 64);
@@ -218,7 +243,7 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
   const size_t lds_bytes = (size_t)A.lds_words * sizeof(unsigned int);
   // grid: enough waves to fill the device a few times over, each walking reads with a grid stride (the bitmap is staged
   // once per workgroup)
-  const unsigned int match_blocks = (unsigned int)std::min<long long>(nblk(c->n_reads, 4), 256ll * 16);
+  const unsigned int match_blocks = (unsigned int)std::min<long long>(nblk(c->n_reads, 16), 256ll * 16);
   A.hits = nullptr;
   A.counter = c->status.as<unsigned long long>() + ST_MISC;
   A.cap = 0;
