@@ -34,12 +34,6 @@ def multi(which):
     Engine.build_multi([engines[i] for i in which], [ks[i] for i in which])
 
 
-def single(i):
-    if i:
-        engines[i].set_reads_device_from(engines[0]) if hasattr(engines[i], "set_reads_device_from") else None
-    engines[i].build(ks[i])
-
-
 # every engine its own copy of the reads for the single builds
 for e in engines[1:]:
     e.set_reads(toks, offs, vocab.two_v)
@@ -65,8 +59,6 @@ def hybrid():
         Engine.build_multi([engines[i] for i in rest], [ks[i] for i in rest])
 
 
-for i in rest[1:]:
-    pass
 out["hybrid_ms"] = round(timed(hybrid), 3)
 out["nodes"] = nodes_single
 out["same_node_counts"] = nodes_single == nodes_multi
