@@ -516,6 +516,13 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
                          (int)r, last, state, hint, out, remap ? 0 : strip, remap);
   }
+  if (getenv("AMG_COUNT_DEBUG")) {  // what every sweep left beyond its range, which one finished (synchronises: debugging only)
+    unsigned long long h[2 * COUNT_MAX_SWEEPS];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(h, state, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[amg] count kind %d: n %lld ids %lld sweeps %lld beyond %llu %llu %llu %llu done %llu %llu %llu %llu\n", kind, n,
+            n_ids, ranges, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
   return AMG_OK;
 }
 

@@ -134,13 +134,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
     signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0,
+    unsigned long long* ctrs, unsigned int head_cap) {
   typedef int i4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
   const int tid = threadIdx.x;
   const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  // claims from the shard counters (XShard); the first tiles of the stream (the head launch and a few times as many
+  // after it) share a counter of their own and take the ids below head_cap densely
+  const XShard cshard{ctrs ? ((HEAD || (blockIdx.x + tile0) * (unsigned int)TILE < head_cap) ? (int)F_SHARDS
+                                                                                              : (int)((blockIdx.x + tile0) & (F_SHARDS - 1u)))
+                           : -1,
+                      head_cap};
   const int flip = two_v - 1;
   {
     bool bad = false;
@@ -228,12 +235,13 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
 #ifndef AMG_W2_CAS
     if constexpr (TWO)  // the slot belongs to whoever takes w1: two memory-side operations per creation instead of three
       f_table_phase_own<1>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2, slot_by_claim,
-                           status + ST_NODE_INSERTS, cap, probe_limit, status, 1, id1, s_wave, &made);
+                           ctrs ? ctrs : status + ST_NODE_INSERTS, cap, probe_limit, status, 1, id1, s_wave, &made, 0u, 0u,
+                           cshard);
     else
 #endif
     f_table_phase<TWO, 1, false>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2,
-                                 slot_by_claim, status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave,
-                                 &made);
+                                 slot_by_claim, ctrs ? ctrs : status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1,
+                                 id1, s_wave, &made, 0u, 0u, 0u, 0u, cshard);
   }
   i4 oc;
   unsigned int od = 0;
@@ -283,13 +291,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int two_v,
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
     signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n,
+    unsigned long long* ctrs, unsigned int head_cap) {
   typedef int i4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
   __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
   const int tid = threadIdx.x;
   const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  // claims from the shard counters (XShard); the first tiles of the stream (the head launch and a few times as many
+  // after it) share a counter of their own and take the ids below head_cap densely
+  const XShard cshard{ctrs ? ((HEAD || (blockIdx.x + tile0) * (unsigned int)TILE < head_cap) ? (int)F_SHARDS
+                                                                                              : (int)((blockIdx.x + tile0) & (F_SHARDS - 1u)))
+                           : -1,
+                      head_cap};
   const int flip = two_v - 1, V = two_v >> 1;
   {
     bool bad = false;
@@ -370,13 +385,15 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
 #ifndef AMG_W2_CAS
     if constexpr (TWO)
       f_table_phase_own<1, TILE_THREADS, AMG_BUCKET_PROBES>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir,
-                                                            xf, first2, slot_by_claim, status + ST_NODE_INSERTS, cap,
-                                                            probe_limit, status, 1, id1, s_wave, &made, valid, home_n);
+                                                            xf, first2, slot_by_claim, ctrs ? ctrs : status + ST_NODE_INSERTS,
+                                                            cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n,
+                                                            cshard);
     else
 #endif
     f_table_phase<TWO, 1, false, TILE_THREADS, AMG_BUCKET_PROBES>(
         tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir, xf, first2, slot_by_claim,
-        status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n);
+        ctrs ? ctrs : status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n, 0u, 0u,
+        cshard);
   }
 #ifdef AMG_M_DIR_LDS
   // directions leave as one 4-byte store per thread: bytes through LDS (the token tile is no longer needed)
@@ -428,12 +445,16 @@ __global__ void k_x_drop_claims(const unsigned int* __restrict__ cnt, long long 
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_kept, (unsigned long long)__popcll(m));
 }
 
+// tagged != nullptr: claim -> node id | AMG_SINGLE_BIT where the node's coverage is 1 (what k_edges_v<.., LONE> reads)
 __global__ void k_x_cov_from_claims(const unsigned int* __restrict__ cnt, const unsigned int* __restrict__ first2,
                                     const int* __restrict__ final_of_claim, long long n,
-                                    unsigned int* __restrict__ node_cov) {
+                                    unsigned int* __restrict__ node_cov, int* __restrict__ tagged) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n || x_first_inv(first2, c) == 0u) return;
-  node_cov[final_of_claim[c]] = cnt[c];
+  if (c >= n) return;
+  const int id = final_of_claim[c];
+  const bool used = x_first_inv(first2, c) != 0u;
+  if (tagged) tagged[c] = (used && id >= 0 && cnt[c] == 1u) ? (int)((unsigned int)id | AMG_SINGLE_BIT) : id;
+  if (used) node_cov[id] = cnt[c];
 }
 
 // reads that lost a window to the filter join _readsToCorrect (remove_node_from_reads :442-461)
@@ -722,19 +743,32 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
 // pair, goes to the hashed slots behind), and a thread's adjacencies lie 256 windows apart so that the 64 lanes of a
 // probe instruction look at 64 consecutive windows: consecutive ids, eight slots to a 128-byte line instead of one
 // line per lane (the passes are bound by the line requests of their probes).
-template <bool HEAD, bool HOME>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
+// LONE (with HOME): `final_of_claim` carries AMG_SINGLE_BIT on the nodes of coverage 1 (k_x_cov_from_claims).  Every
+// adjacency of such a node lies next to its one window, so a class with a single end occurs once — or twice when
+// windows t - 1 and t + 1 of the single window t are the same node in the same direction (a period-2 stretch), which
+// the two neighbouring words show.  A class known to occur once needs no table: f_table_phase's lone items.
+template <bool HEAD, bool HOME, bool LONE = false>  // HEAD: the short launch over the first tiles (its own symbol: per-kernel statistics keep the main launch apart)
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
     const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab, unsigned int emask,
     unsigned int probe_limit, unsigned long long* status, int* __restrict__ tok_pair, unsigned int* first2,
-    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n) {
+    unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0, unsigned int home_n,
+    unsigned int lone_base, unsigned long long* ctrs, unsigned int head_cap) {
+  static_assert(!LONE || HOME, "lone classes come with the home-slot layout");
   typedef int i4 __attribute__((ext_vector_type(4)));
-  // word per window: node id | (direction -1) << 30 | last-of-read << 31, -1: no node
+  // word per window: node id | single << 29 (LONE) | (direction -1) << 30 | last-of-read << 31, -1: no node
   constexpr unsigned int DIRBIT = 0x40000000u;
+  constexpr unsigned int IDMASK = LONE ? AMG_SINGLE_BIT - 1u : DIRBIT - 1u;
   __shared__ __attribute__((aligned(16))) int s_w[TILE + 4];
   __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
   const int tid = threadIdx.x;
   const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
+  // claims from the shard counters (XShard); the first tiles of the stream (the head launch and a few times as many
+  // after it) share a counter of their own and take the ids below head_cap densely
+  const XShard cshard{ctrs ? ((HEAD || (blockIdx.x + tile0) * (unsigned int)TILE < head_cap) ? (int)F_SHARDS
+                                                                                              : (int)((blockIdx.x + tile0) & (F_SHARDS - 1u)))
+                           : -1,
+                      head_cap};
   const int i0 = 4 * tid;
   const long long t = t0 + i0;
   // node id of a window: -1 no node, -2 a node the merge's fused filter dropped (amg_dist.hip)
@@ -742,6 +776,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
   auto word = [&](int raw, int id, unsigned int d) {  // d: the direction byte
     if (id < 0) return -1;
     return (int)((unsigned int)id | ((unsigned int)raw & AMG_LAST_FLAG) | ((d & 0x80u) ? DIRBIT : 0u));
+  };
+  auto word_at = [&](long long tw) {  // a window outside the tile
+    if (tw < 0 || tw >= n_tokens) return -1;
+    const int raw = tok_claim[tw];
+    return word(raw, node_of(raw), (unsigned int)(unsigned char)tok_dir[tw]);
   };
   int cw[TILE_ITEMS + 1];
   {
@@ -762,8 +801,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     i4 ids;
 #pragma unroll
     for (int w = 0; w < TILE_ITEMS; ++w) {
-      ids[w] = node_of(x[w]);
-      cw[w] = word(x[w], ids[w], d >> (8 * w));
+      const int id = node_of(x[w]);
+      cw[w] = word(x[w], id, d >> (8 * w));
+      ids[w] = (LONE && id >= 0) ? (int)((unsigned int)id & ~AMG_SINGLE_BIT) : id;
     }
     if (t + TILE_ITEMS <= n_tokens) {
       __builtin_nontemporal_store(ids, reinterpret_cast<i4*>(tok_node + t));
@@ -774,14 +814,10 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     }
   }
   reinterpret_cast<int4*>(s_w)[tid] = make_int4(cw[0], cw[1], cw[2], cw[3]);
-  if (tid == 0) {  // the next tile's first window: right-hand neighbour of this tile's last
-    const long long tn = t0 + TILE;
-    int wn = -1;
-    if (tn < n_tokens) {
-      const int raw = tok_claim[tn];
-      wn = word(raw, node_of(raw), (unsigned int)(unsigned char)tok_dir[tn]);
-    }
-    s_w[TILE] = wn;
+  if (tid == 0) s_w[TILE] = word_at(t0 + TILE);  // the next tile's first window: right-hand neighbour of this tile's last
+  if constexpr (LONE) {                          // and the two windows the period-2 check of the tile's ends looks at
+    if (tid == 64) s_w[TILE + 1] = word_at(t0 + TILE + 1);
+    if (tid == 128) s_w[TILE + 2] = word_at(t0 - 1);
   }
   __syncthreads();
   if constexpr (!HOME) cw[TILE_ITEMS] = s_w[i0 + TILE_ITEMS];
@@ -791,7 +827,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
   unsigned long long key[TILE_ITEMS];
   unsigned int idx[TILE_ITEMS], etag[TILE_ITEMS], id1[TILE_ITEMS];
   ulonglong2 v[TILE_ITEMS];
-  unsigned int valid = 0, orient3 = 0, homed = 0;
+  unsigned int valid = 0, orient3 = 0, homed = 0, lone = 0;
 #pragma unroll
   for (int w = 0; w < TILE_ITEMS; ++w) {
     key[w] = 0;
@@ -799,13 +835,29 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     etag[w] = 0;
     const int A = HOME ? s_w[w * TILE_THREADS + tid] : cw[w], B = HOME ? s_w[w * TILE_THREADS + tid + 1] : cw[w + 1];
     if (A == -1 || ((unsigned int)A & AMG_LAST_FLAG) || B == -1) continue;
-    const unsigned int a = (unsigned int)A & (DIRBIT - 1u), b = (unsigned int)B & (DIRBIT - 1u);
+    const unsigned int a = (unsigned int)A & IDMASK, b = (unsigned int)B & IDMASK;
     const bool negA = ((unsigned int)A & DIRBIT) != 0u, negB = ((unsigned int)B & DIRBIT) != 0u;
     const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
     const unsigned long long sign = negA != negB ? 1ull : 0ull;
     key[w] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
     const unsigned int orient = (a == lo ? 1u : 0u) | (negA ? 0u : 2u) | (negB ? 0u : 4u);
     orient3 |= orient << (3 * w);
+    valid |= 1u << w;
+    if constexpr (LONE) {
+      if (((unsigned int)A | (unsigned int)B) & AMG_SINGLE_BIT) {
+        const int i = w * TILE_THREADS + tid;
+        const int Wm = i == 0 ? s_w[TILE + 2] : s_w[i - 1], Wn = s_w[i + 2];
+        // the other adjacency of a single node is the same class: same neighbour node, same direction
+        const bool dup_prev = Wm != -1 && !((unsigned int)Wm & AMG_LAST_FLAG) &&
+                              (((unsigned int)Wm ^ (unsigned int)B) & (IDMASK | DIRBIT)) == 0u;
+        const bool dup_next = !((unsigned int)B & AMG_LAST_FLAG) && Wn != -1 &&
+                              (((unsigned int)A ^ (unsigned int)Wn) & (IDMASK | DIRBIT)) == 0u;
+        if ((((unsigned int)A & AMG_SINGLE_BIT) && !dup_prev) || (((unsigned int)B & AMG_SINGLE_BIT) && !dup_next)) {
+          lone |= 1u << w;
+          continue;
+        }
+      }
+    }
     if (HOME && hi == lo + 1u && lo < home_n) {
       idx[w] = lo;
       homed |= 1u << w;
@@ -815,17 +867,21 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
 #ifndef AMG_ABLATE_NOPROBE
     v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
 #endif
-    valid |= 1u << w;
   }
+#ifdef AMG_LONE_ABL  // timing experiment (tools/edge_lone_probe.sh); the build fails after the pass
+  if (LONE && (AMG_LONE_ABL) == 1) valid &= ~lone, lone = 0u;
+  if (blockIdx.x == 0 && tid == 0) status[ST_MISC] = 1ull;
+#endif
   unsigned int made = 0;
   if constexpr (HOME)
-    f_table_phase<false, 3, false, TILE_THREADS>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid, orient3, xf,
-                                                 first2, slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit,
-                                                 status, 2, id1, s_wave, &made, homed, home_n);
+    f_table_phase<false, 3, false, TILE_THREADS, 1, LONE>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid,
+                                                          orient3, xf, first2, slot_by_claim,
+                                                          ctrs ? ctrs : status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status,
+                                                          2, id1, s_wave, &made, homed, home_n, lone, lone_base, cshard);
   else
     f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
-                                   slot_by_claim, status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2, id1, s_wave,
-                                   &made);
+                                   slot_by_claim, ctrs ? ctrs : status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2,
+                                   id1, s_wave, &made, 0u, 0u, 0u, 0u, cshard);
   if constexpr (HOME) {
 #pragma unroll
     for (int w = 0; w < TILE_ITEMS; ++w) {
@@ -865,6 +921,24 @@ __global__ void k_x_gather_pairs(const unsigned int* __restrict__ first_sorted,
   pkey[i] = key;
   pfirst[i] = (unsigned long long)first;
   pcnt[i] = cnt_by_claim[c];
+}
+
+// claims handed out by the counters of a plain pass (F_SHARDS shards + the head launch's): their sum into the count
+// word, the largest shard count into `most`
+#define X_CTRS (F_SHARDS + 1)
+__global__ void k_x_ctr_reduce(const unsigned long long* __restrict__ ctrs, unsigned long long* count,
+                               unsigned long long* most) {
+  unsigned long long v = ctrs[(size_t)threadIdx.x * F_CTR_STRIDE];
+  unsigned long long sum = v, mx = v;
+  for (int d = 32; d > 0; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    const unsigned long long o = __shfl_xor(mx, d, 64);
+    mx = mx > o ? mx : o;
+  }
+  if (threadIdx.x == 0) {
+    *count = sum + ctrs[(size_t)F_SHARDS * F_CTR_STRIDE];
+    *most = mx;
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -912,6 +986,33 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
 
 static int read_status(amg_ctx* c, unsigned long long* host) { return fetch_status(c, host); }
 
+// claims from shard counters (XShard) for the inputs that get a head launch (4 M tokens and more: below that one
+// counter serves a pass's workgroups in the time the pass takes anyway); AMG_CLAIM_SHARDS = 0 / 1: never / always
+// (A/B + test switch)
+static bool shard_claims(long long n_tiles) {
+  if (const char* e = getenv("AMG_CLAIM_SHARDS")) return atoi(e) != 0 && n_tiles > 0;
+  return n_tiles >= 4096;
+}
+// a shard's share of `bound` claims: an even split, a quarter of slack, what one workgroup creates in one go; whole chunks
+static unsigned int shard_share(long long bound) {
+  const long long even = (bound + F_SHARDS - 1) / F_SHARDS;
+  const long long share = even + even / 4 + TILE + 1;
+  return (unsigned int)((share + X_CHUNK - 1) / X_CHUNK * X_CHUNK);
+}
+// tiles at the start of the stream that take their claims densely from ONE counter: the head launch's and three times
+// as many after it.  A genome key the head launch has not seen (a dozen of 20 k on cfg 3) is created by one of the
+// next tiles; from a shard counter its claim would lie far above the ids the counting sweeps keep in LDS, and its
+// thousands of occurrences would each be a global atomic on one word (measured: 8 k such windows, +55 us per count).
+static long long dense_tiles(const amg_ctx* c, long long n_tiles) {
+  const long long d = 4 * head_tiles(c, n_tiles);
+  return d < n_tiles ? d : n_tiles;
+}
+// claim ids in use lie below this when the fullest shard handed out `most` (head_cap ids in front: the first tiles')
+static long long shard_space(unsigned long long most, long long head_cap, size_t max_claims) {
+  const long long s = head_cap + (long long)((most + X_CHUNK - 1) / X_CHUNK) * (long long)(X_CHUNK * F_SHARDS);
+  return s < (long long)max_claims ? s : (long long)max_claims;
+}
+
 bool bx_applicable(const amg_ctx* c, int k) {
   if (c->dist_mode || c->count_inline) return false;
   return bx_fits(c, k);
@@ -929,12 +1030,13 @@ bool bx_fits(const amg_ctx* c, int k) {
 
 // windows -> node table, claim ids, node ids, node arrays.  AMG_E_OVERFLOW + *which = 1: table full
 int bx_nodes(amg_ctx* c, int k, int* which) {
-  AMGCHK(bx_nodes_upsert(c, k, which));
+  AMGCHK(bx_nodes_upsert(c, k, which, true));
   return bx_nodes_rank(c);
 }
 
 // the table pass alone: claims 0 .. n_local_nodes-1 with their first-seen / slot arrays
-int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
+// sharded: claim ids may come from shard counters (then x_nspace > n_nodes: ids nobody took in between)
+int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens;
@@ -951,7 +1053,16 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                        (k == 3 || k == 5 || k == 7) && n_tiles > 0;
   const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
   const size_t tab_slots = (size_t)c->node_slots + home_n;
-  const size_t max_claims = (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
+  const long long claim_bound = ((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
+  sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
+  const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
+  const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
+  const size_t max_claims = sharded ? (size_t)head_cap + (size_t)cap * F_SHARDS + 1 : (size_t)claim_bound;
+  unsigned long long* ctrs = nullptr;
+  if (sharded) {
+    AMGCHK(c->f_ctrs.ensure(2 * X_CTRS * F_CTR_STRIDE * sizeof(unsigned long long)));
+    ctrs = c->f_ctrs.as<unsigned long long>();
+  }
   AMGCHK(c->tok_slot.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_node.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->tok_dir.ensure((size_t)(T + 8)));
@@ -965,6 +1076,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
     cl.add(c->status.p, ST_WORDS * sizeof(unsigned long long));
     cl.add(c->node_tab.p, tab_slots * sizeof(Slot16));
     cl.add(c->x_first.p, 2 * max_claims * sizeof(unsigned int));
+    if (ctrs) cl.add(ctrs, X_CTRS * F_CTR_STRIDE * sizeof(unsigned long long));
     AMGCHK(bs_read_stats(c, k, &cl));
   }
 
@@ -1017,8 +1129,8 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                            c->bnd_bits.as<unsigned int>(), T, c->two_v, c->x_bits, c->node_tab.as<Slot16>(),
                            (unsigned int)(c->node_slots - 1), kProbeLimitX, c->tok_slot.as<int>(),
                            c->tok_dir.as<signed char>(), c->status.as<unsigned long long>(),
-                           c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), (unsigned int)max_claims,
-                           xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n);
+                           c->x_first.as<unsigned int>(), c->x_slot.as<unsigned int>(), cap,
+                           xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n, ctrs, (unsigned int)head_cap);
       }
     } else {
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
@@ -1052,12 +1164,15 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
                            c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                            c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                            c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                           c->x_slot.as<unsigned int>(), (unsigned int)max_claims, xw2_for(max_claims, T),
-                           (unsigned int)lo);
+                           c->x_slot.as<unsigned int>(), cap, xw2_for(max_claims, T), (unsigned int)lo, ctrs,
+                           (unsigned int)head_cap);
       }
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
+  if (ctrs)
+    hipLaunchKernelGGL(k_x_ctr_reduce, dim3(1), dim3(64), 0, st, ctrs, c->status.as<unsigned long long>() + ST_NODE_INSERTS,
+                       c->status.as<unsigned long long>() + ST_COMPACT_A);
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
 #ifdef AMG_EXP_CTR
@@ -1076,7 +1191,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which) {
   c->n_windows = (int64_t)hs[ST_N_WINDOWS];
   c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
-  c->x_nspace = c->n_nodes;
+  c->x_nspace = ctrs ? shard_space(hs[ST_COMPACT_A], head_cap, max_claims) : c->n_nodes;
   c->x_max_claims = (int64_t)max_claims;
   return AMG_OK;
 }
@@ -1115,7 +1230,7 @@ int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   AMGCHK(bx_nodes_rank(c));
   if (n > 0 && D > 0)
     hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(),
-                       c->x_first.as<unsigned int>(), c->x_final.as<int>(), n, c->node_cov.as<unsigned int>());
+                       c->x_first.as<unsigned int>(), c->x_final.as<int>(), n, c->node_cov.as<unsigned int>(), (int*)nullptr);
   return AMG_OK;
 }
 
@@ -1158,12 +1273,43 @@ int bx_nodes_rank(amg_ctx* c) {
 // adjacencies -> edge-class table, claims, pair arrays in first-seen order, coverages.
 // AMG_E_OVERFLOW + *which = 2: edge table full
 int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov) {
-  AMGCHK(bx_edges_upsert(c, which));
-  return bx_edges_rank(c, min_edge_cov);
+  // a plain build counts its nodes BEFORE the edge pass: the nodes of coverage 1 (nine in ten of an uncorrected
+  // graph) mark the edge classes that occur once, and those need no table (k_edges_v<.., LONE>)
+  bool lone = false;
+  if (min_edge_cov == 0) {
+    const char* e = getenv("AMG_EDGE_LONE");  // A/B + test switch: 0 never, 1 whenever the kernel allows it
+    const char* eh = getenv("AMG_EDGE_HOME");
+    const bool can = !getenv("AMG_X_OLD_PASS") && !(eh && atoi(eh) == 0) && c->n_nodes > 0;
+    // worth its extra words per window where many nodes are single: more than one node per 16 windows
+    lone = can && (e ? atoi(e) != 0 : c->n_nodes * 16 > c->n_tokens);
+    AMGCHK(bx_node_count(c, lone));
+  }
+  AMGCHK(bx_edges_upsert(c, which, lone, min_edge_cov == 0));
+  return bx_edges_rank(c, min_edge_cov, min_edge_cov == 0);
+}
+
+// node coverage of a plain build (construct_node.py:33-36): occurrences per CLAIM from the node pass's per-window
+// claims — the occurrence that created a key is marked there, so the keys seen once (most of an uncorrected graph)
+// cost nothing — then one store per claim into the node's counter.  tag: x_ftag = x_final with AMG_SINGLE_BIT
+int bx_node_count(amg_ctx* c, bool tag) {
+  const long long T = c->n_tokens, D = c->n_nodes;
+  stage_begin(c, "node_count");
+  const long long S = c->x_nspace;
+  AMGCHK(c->x_ncnt.ensure((size_t)(S + 2) * sizeof(unsigned int)));
+  if (tag) AMGCHK(c->x_ftag.ensure((size_t)(S + 2) * sizeof(int)));
+  AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, S, c->x_ncnt.as<unsigned int>(), 4));
+  if (S > 0 && D > 0)
+    hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(S, 256)), dim3(256), 0, c->stream,
+                       c->x_ncnt.as<unsigned int>(), c->x_first.as<unsigned int>(), c->x_final.as<int>(), S,
+                       c->node_cov.as<unsigned int>(), tag ? c->x_ftag.as<int>() : (int*)nullptr);
+  stage_end(c);
+  return AMG_OK;
 }
 
 // the table pass alone: tok_node from x_final, edge-class claims 0 .. n_local_pairs-1
-int bx_edges_upsert(amg_ctx* c, int* which) {
+// lone: x_ftag marks the nodes of coverage 1 (bx_node_count); their classes bypass the table
+// sharded: as bx_nodes_upsert's
+int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, D = c->n_nodes;
@@ -1180,9 +1326,21 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
   }
   const size_t tab_slots = (size_t)c->edge_slots + (size_t)home_n;
-  const size_t max_claims = (size_t)((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
+  if (!home_n) lone = false;
+  // claims: at most one per table slot, plus (lone) two classes per single node, never more than the windows
+  long long claim_bound = (long long)tab_slots + (lone ? 2 * D : 0);
+  claim_bound = (claim_bound < T ? claim_bound : T) + 1;
+  sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
+  const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
+  const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
+  const size_t max_claims = sharded ? (size_t)head_cap + (size_t)cap * F_SHARDS + 1 : (size_t)claim_bound;
+  unsigned long long* ctrs = nullptr;
+  if (sharded) {
+    AMGCHK(c->f_ctrs.ensure(2 * X_CTRS * F_CTR_STRIDE * sizeof(unsigned long long)));
+    ctrs = c->f_ctrs.as<unsigned long long>() + X_CTRS * F_CTR_STRIDE;
+  }
   AMGCHK(c->tok_pair.ensure((size_t)(T + 8) * sizeof(int)));
-  AMGCHK(c->edge_tab.ensure(tab_slots * sizeof(Slot16)));
+  AMGCHK(c->edge_tab.ensure((tab_slots + (lone ? max_claims : 0)) * sizeof(Slot16)));  // (lone classes: slot = tab_slots + claim)
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
 #ifdef AMG_EXP_CTR
@@ -1198,6 +1356,7 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     cl.add(c->edge_tab.p, tab_slots * sizeof(Slot16));
     cl.add(c->x_efirst.p, 2 * max_claims * sizeof(unsigned int));
     cl.add(c->status.as<unsigned long long>() + ST_PAIR_INSERTS, 2 * sizeof(unsigned long long));
+    if (ctrs) cl.add(ctrs, X_CTRS * F_CTR_STRIDE * sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
   }
   stage_end(c);
@@ -1220,17 +1379,22 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
         stage_end(c);
         stage_begin(c, "edge_upsert");
       }
-      auto kern = home_n ? (part == 0 ? k_edges_v<true, true> : k_edges_v<false, true>)
-                         : (part == 0 ? k_edges_v<true, false> : k_edges_v<false, false>);
+      auto kern = lone     ? (part == 0 ? k_edges_v<true, true, true> : k_edges_v<false, true, true>)
+                  : home_n ? (part == 0 ? k_edges_v<true, true> : k_edges_v<false, true>)
+                           : (part == 0 ? k_edges_v<true, false> : k_edges_v<false, false>);
       hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
-                         c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
-                         c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
+                         c->tok_dir.as<signed char>(), lone ? c->x_ftag.as<int>() : c->x_final.as<int>(),
+                         c->tok_node.as<int>(), c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
                          c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                         c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), (unsigned int)max_claims,
-                         xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n);
+                         c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), cap,
+                         xw2_for(max_claims, T), (unsigned int)lo, (unsigned int)home_n, (unsigned int)tab_slots, ctrs,
+                         (unsigned int)head_cap);
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
+  if (ctrs)
+    hipLaunchKernelGGL(k_x_ctr_reduce, dim3(1), dim3(64), 0, st, ctrs, c->status.as<unsigned long long>() + ST_PAIR_INSERTS,
+                       c->status.as<unsigned long long>() + ST_COMPACT_B);
   AMGCHK(read_status(c, hs));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
 #ifdef AMG_EXP_CTR
@@ -1242,29 +1406,16 @@ int bx_edges_upsert(amg_ctx* c, int* which) {
     return AMG_E_OVERFLOW;
   }
   c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
-  c->x_espace = c->n_pairs;
+  c->x_espace = ctrs ? shard_space(hs[ST_COMPACT_B], head_cap, max_claims) : c->n_pairs;
   c->x_max_eclaims = (int64_t)max_claims;
   return AMG_OK;
 }
 
 // coverages, edge classes in first-seen order.  min_edge_cov > 0: the build applies the coverage filter on the
 // way (bx_nodes_filtered has the node coverages already; classes below min_edge_cov are dropped before ranking)
-int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov) {
-  const long long T = c->n_tokens, D = c->n_nodes, P = c->n_pairs;
-  if (min_edge_cov == 0) {
-    // node coverage (construct_node.py:33-36): occurrences per CLAIM from the node pass's per-window claims — the
-    // occurrence that created a key is marked there, so the keys seen once (most of an uncorrected graph) cost
-    // nothing — then one store per claim into the node's counter
-    stage_begin(c, "node_count");
-    const long long S = c->x_nspace;
-    AMGCHK(c->x_ncnt.ensure((size_t)(S + 2) * sizeof(unsigned int)));
-    AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, S, c->x_ncnt.as<unsigned int>(), 4));
-    if (S > 0 && D > 0)
-      hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(S, 256)), dim3(256), 0, c->stream,
-                         c->x_ncnt.as<unsigned int>(), c->x_first.as<unsigned int>(), c->x_final.as<int>(), S,
-                         c->node_cov.as<unsigned int>());
-    stage_end(c);
-  }
+int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov, bool nodes_counted) {
+  const long long T = c->n_tokens, P = c->x_espace;  // (claim ids in use lie below P)
+  if (min_edge_cov == 0 && !nodes_counted) AMGCHK(bx_node_count(c, false));
   // edge-class coverage per claim
   stage_begin(c, "edge_count");
   AMGCHK(c->x_ecnt.ensure((size_t)(P + 2) * sizeof(unsigned int)));

@@ -9,6 +9,7 @@
 // millions of keys seen once (the error gene-mers of an uncorrected read set) then cost no atomic at all
 #define AMG_MADE_FLAG 0x40000000u
 #define AMG_FLAG_MASK (AMG_LAST_FLAG | AMG_MADE_FLAG)
+#define AMG_SINGLE_BIT 0x20000000u  // on a node id handed to the edge pass: the node has coverage 1 (node ids stay below 2^29)
 
 // relaxed, agent-scope accessors: L1-bypassing loads, coherent with the device-scope
 // atomics that mutate the tables (MI355X_MICROARCH.md, "Inter-workgroup visibility").

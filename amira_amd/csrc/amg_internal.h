@@ -220,6 +220,7 @@ struct amg_ctx {
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
   DevBuf x_ncnt;             // uint32[node claims] occurrences (plain build: scattered into node_cov)
+  DevBuf x_ftag;             // int32 [node claims] x_final | AMG_SINGLE_BIT on nodes of coverage 1 (edge pass with lone classes)
   DevBuf f_ctrs;             // fused table pass: per-shard claim counters
   DevBuf x_efinal;           // int32 [edge claims] claim id -> edge-class id
   DevBuf x_first_all;        // uint32[claims] filtered build: ~first_seen of EVERY claim (k_x_drop_claims zeroes x_first)
@@ -342,13 +343,14 @@ int ensure_adjacency(amg_ctx* c);
 bool bx_applicable(const amg_ctx* c, int k);
 bool bx_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
-int bx_nodes_upsert(amg_ctx* c, int k, int* which);
+int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded = false);
 int bx_nodes_rank(amg_ctx* c);
 int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov = 0);
 int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which);
 int bx_flag_dead_reads(amg_ctx* c);
-int bx_edges_upsert(amg_ctx* c, int* which);
-int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov = 0);
+int bx_edges_upsert(amg_ctx* c, int* which, bool lone = false, bool sharded = false);
+int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov = 0, bool nodes_counted = false);
+int bx_node_count(amg_ctx* c, bool tag);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,
               unsigned int* out, int kind, const int* remap = nullptr);
 // counts of remap[claim] over per-window node claims (claim | AMG_LAST_FLAG, -1 none); the array is

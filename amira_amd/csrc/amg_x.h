@@ -311,6 +311,34 @@ static __device__ unsigned long long g_exp_ctr[64 * 16];
 #endif
 #define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
 
+// Chunked shards (the plain table passes, round 4): a WORKGROUP takes its claims from the counter of its shard
+// (tile index & 63) with one atomicAdd, as it did from the single counter — 55 k returning atomics on one word are what
+// a first-build pass waited for once its creations were cheap (0.42 of 0.72 ms in the edge pass; one word takes
+// ≈ 100 per microsecond) — and shard s owns every 64th CHUNK of X_CHUNK claim ids (a tile's worth: a workgroup's stores
+// into the per-claim arrays share lines).  The FIRST tiles of the stream — the head launch, which creates the genome's
+// keys, and a few times as many tiles after it, which create the ones it missed — share a counter of their own
+// (shard F_SHARDS) and take the ids [0, base) densely, as before: those keys hold the lowest claims, which the counting
+// sweeps rely on (spread over the shards they lay scattered over 64 k ids and the two counts of a rebuild took 0.2 ms
+// each instead of 0.07).  The shards' ids start at `base`; ids in use lie below
+// base + X_CHUNK * F_SHARDS * ceil(largest shard count / X_CHUNK); ids nobody took keep first-seen == 0.
+#define X_CHUNK 1024u
+__device__ __forceinline__ unsigned int x_chunk_claim(unsigned int li, unsigned int shard) {
+  return (li / X_CHUNK) * (X_CHUNK * F_SHARDS) + shard * X_CHUNK + (li % X_CHUNK);
+}
+// which counter a workgroup adds to and what its local index li becomes: no shards (shard < 0: one counter, claim = li),
+// the head launch's counter, a shard's
+struct XShard {
+  int shard;          // -1, 0 .. F_SHARDS - 1, F_SHARDS (head)
+  unsigned int base;  // ids of the head launch = capacity of its counter
+  __device__ __forceinline__ unsigned long long* counter(unsigned long long* ctr) const {
+    return shard >= 0 ? ctr + (unsigned int)shard * F_CTR_STRIDE : ctr;
+  }
+  __device__ __forceinline__ unsigned int limit(unsigned int cap) const { return shard == (int)F_SHARDS ? base : cap; }
+  __device__ __forceinline__ unsigned int claim(unsigned int li) const {
+    return shard < 0 || shard == (int)F_SHARDS ? li : base + x_chunk_claim(li, (unsigned int)shard);
+  }
+};
+
 template <class T>
 __device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
   return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3];
@@ -321,7 +349,11 @@ __device__ __forceinline__ T f_pick(const T (&a)[TILE_ITEMS], int w) {
 // key's hashed slot in tab[off .. off + mask]); one-word keys only.
 // HOME_PROBES: slots of its line a homed item looks at before it goes to its hashed slot (1: the home slot alone —
 // the edge pass; > 1: a bucket line of the node table, k_nodes_m).
-template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1, int HOME_PROBES = 1>
+// LONE: items of the mask `lone` are keys the caller KNOWS to occur once in the whole input (edge classes with an end
+// node of coverage 1): no probe, no compare-and-swap — they take a claim like every creator and write their slot,
+// key and id in one 16-byte store, to tab[lone_base + claim] (a region behind the table that is never probed or
+// cleared; the ranking reads the key back from there through slot_by_claim like any other).
+template <bool TWO, int FSH, bool SHARDED, int STRIDE = 1, int HOME_PROBES = 1, bool LONE = false>
 __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, unsigned int valid,
                                               const unsigned long long (&w1)[TILE_ITEMS],
                                               const unsigned int (&tag)[TILE_ITEMS],
@@ -333,7 +365,10 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                                               unsigned int probe_limit, unsigned long long* status, int which,
                                               unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr,
                                               unsigned int* made = nullptr, unsigned int homed = 0u,
-                                              unsigned int off = 0u) {
+                                              unsigned int off = 0u, unsigned int lone = 0u,
+                                              unsigned int lone_base = 0u, XShard xs = XShard{-1, 0u}) {
+  // xs.shard >= 0 (not SHARDED): ctr is the array of shard counters, cap a shard's share (XShard)
+  static_assert(!LONE || !TWO, "lone items: one-word keys");
   auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
   auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   unsigned int lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
@@ -348,6 +383,10 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     slot[it] = (int)idx[it];
     if (!TWO) hw[TWO ? 0 : it] = 0;
     if (!(valid & (1u << it))) continue;
+    if (LONE && (lone & (1u << it))) {  // v[it] was not even loaded
+      created |= 1u << it;
+      continue;
+    }
 #ifdef AMG_ABLATE_NOPROBE  // timing experiment (tools/noprobe_probe.sh): every window "finds" its key; no graph
     const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx[it] & 1023ull));
 #elif defined(AMG_ABLATE_PREDICT)  // (tools/predict_probe.sh) windows 1..3 of a node-pass thread "find" theirs; the load is consumed
@@ -449,7 +488,9 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
         }
       } else
 #endif
-      if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total);
+      if (threadIdx.x == 0)
+        s_wave[TILE_THREADS / 64] =
+            (unsigned int)atomicAdd(xs.counter(ctr), (unsigned long long)total);
       __syncthreads();
       base = s_wave[TILE_THREADS / 64] + before;
     }
@@ -459,22 +500,34 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     for (int it = 0; it < TILE_ITEMS; ++it)
       if (created & (1u << it)) {
         unsigned int li = base + pre[it];
-        if (li >= cap) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
+        if (li >= (SHARDED ? cap : xs.limit(cap))) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
           status[ST_OVERFLOW] = (unsigned long long)which;
           li = 0;
         }
-        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : li;
+        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : xs.claim(li);
         // the creator's first-seen goes to its own word with a plain store; everybody else raises the
         // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
         // has to be ordered against the publication of the id
+#if defined(AMG_LONE_ABL) && (AMG_LONE_ABL) == 2
+        if (!(LONE && (lone & (1u << it))))
+#endif
         first2[2u * claim + 1u] = fi(it);
-        slot_by_claim[claim] = (unsigned int)slot[it];
         id1[it] = claim + 1u;
         const unsigned long long pub =
             TWO ? ((unsigned long long)tag[it] << 32) | (unsigned long long)((tpos(it) >> f.cshift) << f.ib) |
                       (unsigned long long)(claim + 1u)
                 : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
-        __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LONE && (lone & (1u << it))) {
+#if !defined(AMG_LONE_ABL) || (AMG_LONE_ABL) != 2
+          slot_by_claim[claim] = lone_base + claim;
+#if !defined(AMG_LONE_ABL) || (AMG_LONE_ABL) != 3
+          *reinterpret_cast<ulonglong2*>(tab + lone_base + claim) = make_ulonglong2(w1[it], pub);
+#endif
+#endif
+        } else {
+          slot_by_claim[claim] = (unsigned int)slot[it];
+          __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
   }
   // ---- found keys: wait for an id that is still on its way (a creator publishes without waiting
@@ -571,7 +624,12 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
                                                   unsigned int* __restrict__ slot_by_claim, unsigned long long* ctr,
                                                   unsigned int cap, unsigned int probe_limit, unsigned long long* status,
                                                   int which, unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave,
-                                                  unsigned int* made_out, unsigned int homed = 0u, unsigned int off = 0u) {
+                                                  unsigned int* made_out, unsigned int homed = 0u, unsigned int off = 0u,
+                                                  XShard xs = XShard{-1, 0u}) {
+  // xs.shard >= 0: ctr is the array of shard counters, cap a shard's share (XShard)
+  unsigned long long* const myctr = xs.counter(ctr);
+  cap = xs.limit(cap);
+  auto claim_of = [&](unsigned int li) { return xs.claim(li); };
   auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
   auto fi = [&](int it) { return ~((tpos(it) << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u))); };
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -649,7 +707,7 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
       total += cnt;
     }
     if (total) {  // workgroup-uniform
-      if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total);
+      if (threadIdx.x == 0) s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(myctr, (unsigned long long)total);
       __syncthreads();
       base = s_wave[TILE_THREADS / 64] + before;
     }
@@ -657,11 +715,12 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
 #pragma unroll
       for (int it = 0; it < TILE_ITEMS; ++it)
         if (created & (1u << it)) {
-          unsigned int claim = base + pre[it];
-          if (claim >= cap) {  // the claim arrays are used up: the host rebuilds larger
+          unsigned int li = base + pre[it];
+          if (li >= cap) {  // the claim arrays are used up: the host rebuilds larger
             status[ST_OVERFLOW] = (unsigned long long)which;
-            claim = 0;
+            li = 0;
           }
+          const unsigned int claim = claim_of(li);
           first2[2u * claim + 1u] = fi(it);  // the creator's own word, plain store (others raise the other word)
           slot_by_claim[claim] = (unsigned int)slot[it];
           id1[it] = claim + 1u;
@@ -735,11 +794,12 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
       if (c1 == 0ull) {
         c1 = atomicCAS(&sp->w1, 0ull, kw);
         if (c1 == 0ull) {  // taken: claim id, first-seen, publication — all in this iteration
-          unsigned int claim = (unsigned int)atomicAdd(ctr, 1ull);
-          if (claim >= cap) {
+          unsigned int li = (unsigned int)atomicAdd(myctr, 1ull);
+          if (li >= cap) {
             status[ST_OVERFLOW] = (unsigned long long)which;
-            claim = 0;
+            li = 0;
           }
+          const unsigned int claim = claim_of(li);
           const unsigned int tp = tbase + (unsigned int)it * (unsigned int)STRIDE;
           first2[2u * claim + 1u] = ~((tp << FSH) | ((lowbits >> (it * FSH)) & ((1u << FSH) - 1u)));
           slot_by_claim[claim] = at;

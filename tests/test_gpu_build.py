@@ -206,8 +206,8 @@ def test_build_many_graphs_equal_separate_graphs():
     assert many[0]._engine is None
 
 
-@pytest.mark.parametrize("buckets", ["1", "0"])
-def test_half_equal_two_word_keys(buckets, monkeypatch):
+@pytest.mark.parametrize("buckets,shards", [("1", "0"), ("0", "0"), ("1", "1")])
+def test_half_equal_two_word_keys(buckets, shards, monkeypatch):
     """Two-word exact keys (k * bits > 63) whose first 63 bits agree and whose last gene differs: the slot belongs to
     whoever takes the first key word, everybody else learns from the second word — published later, in one store —
     whether the slot holds ITS key, and goes on probing if not.  Tens of thousands of such keys are created at once
@@ -216,6 +216,7 @@ def test_half_equal_two_word_keys(buckets, monkeypatch):
     import token_oracle
     from amira_amd import Engine
     monkeypatch.setenv("AMG_NODE_BUCKETS", buckets)
+    monkeypatch.setenv("AMG_CLAIM_SHARDS", shards)  # (1: claim ids from the 64 shard counters, as large inputs take them)
     V, k = 30000, 5                      # 16 bits per gene: 80-bit tuples
     rng = np.random.default_rng(11)
     reads = []
@@ -251,6 +252,49 @@ def test_half_equal_two_word_keys(buckets, monkeypatch):
             assert np.array_equal(nodes["first_dir"], want["first_dir"])
             for a, b in (("src", "src"), ("tgt", "tgt"), ("sdir", "sdir"), ("tdir", "tdir"), ("coverage", "ecov")):
                 assert np.array_equal(edges[a], want[b]), a
+            assert np.array_equal(tok_node, want["tok_node"]) and np.array_equal(tok_dir, want["tok_dir"])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("lone,shards", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_edge_classes_of_single_nodes(lone, shards, monkeypatch):
+    """Edge classes with an end node of coverage 1 bypass the edge table (k_edges_v<.., LONE>): they occur once — or
+    twice, when the windows either side of the single window are the same node in the same direction (a period-2
+    stretch: a b a b a b a at k = 5).  Tiny vocabularies make every such arrangement, across tile boundaries and read
+    ends, next to planted period-2 reads; against the sequential C oracle, with the shortcut forced on and off — and
+    with the claim ids of both table passes taken from one counter or from the 64 shard counters (x_chunk_claim: ids
+    nobody took in between), which large inputs use."""
+    import token_oracle
+    from amira_amd import Engine
+    monkeypatch.setenv("AMG_EDGE_LONE", lone)
+    monkeypatch.setenv("AMG_CLAIM_SHARDS", shards)
+    if lone == shards == "1":  # and with a head launch: the first tiles take their claims densely from a counter of their own
+        monkeypatch.setenv("AMG_X_HEAD_TILES", "2")
+    eng = Engine(0)
+    try:
+        for seed, V, n_reads, k in ((1, 3, 700, 5), (2, 2, 300, 5), (3, 12, 2500, 3), (4, 40, 3000, 5), (5, 6, 300, 3)):
+            rng = np.random.default_rng(seed)
+            reads = [rng.integers(0, 2 * V, int(rng.integers(1, 15))) for _ in range(n_reads)]
+            for _ in range(n_reads // 10):  # a b a b ... with strands of their own, forwards or reverse-complemented
+                a, b = rng.integers(0, 2 * V, 2)
+                r = np.where(np.arange(int(rng.integers(k + 2, k + 6))) % 2 == 0, a, b)
+                reads.append(r if rng.random() < 0.5 else 2 * V - 1 - r[::-1])
+            order = rng.permutation(len(reads))
+            reads = [reads[i] for i in order]
+            toks = np.concatenate(reads).astype(np.int32)
+            offs = np.zeros(len(reads) + 1, np.int64)
+            np.cumsum([len(r) for r in reads], out=offs[1:])
+            eng.set_reads(toks, offs, 2 * V)
+            eng.build(k)
+            want = token_oracle.build(toks, offs, k, 2 * V)
+            nodes, edges = eng.nodes(), eng.edges()
+            tok_node, tok_dir = eng.read_nodes()
+            assert (nodes["coverage"] == 1).sum() > 20, "the case has no single nodes"
+            assert np.array_equal(nodes["tokens"], want["tokens"])
+            assert np.array_equal(nodes["coverage"], want["coverage"])
+            for a, b in (("src", "src"), ("tgt", "tgt"), ("sdir", "sdir"), ("tdir", "tdir"), ("coverage", "ecov")):
+                assert np.array_equal(edges[a], want[b]), (seed, a)
             assert np.array_equal(tok_node, want["tok_node"]) and np.array_equal(tok_dir, want["tok_dir"])
     finally:
         eng.close()
