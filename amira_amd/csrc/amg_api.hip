@@ -99,12 +99,13 @@ __global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long lon
   if (i == 0) __hip_atomic_store(mail + MAIL_TICKET, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out) {
+int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out, const ClearList* filler) {
   if (l.overflow) return amg_fail(AMG_E_ARG, "fetch: more than %d words in one list", FETCH_MAX);
   const bool plain = getenv("AMG_PLAIN_SYNC") != nullptr;  // A/B switch: hipMemcpyAsync + hipStreamSynchronize
   if (plain) {
     for (int i = 0; i < l.n; ++i)
       HIPCHK(hipMemcpyAsync(out + i, l.p[i], sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (filler) AMGCHK(clear_many(c, *filler));
     HIPCHK(hipStreamSynchronize(c->stream));
     return AMG_OK;
   }
@@ -115,7 +116,8 @@ int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out) {
     for (int i = 0; i < FETCH_MAX + 8; ++i) c->mail_host[i] = 0;
   }
   const unsigned long long ticket = ++c->mail_ticket;
-  hipLaunchKernelGGL(k_fetch, dim3(1), dim3(64), 0, c->stream, l, c->mail_dev, ticket);
+  hipLaunchKernelGGL(k_fetch, dim3(1), dim3(FETCH_MAX <= 64 ? 64 : 128), 0, c->stream, l, c->mail_dev, ticket);
+  if (filler) AMGCHK(clear_many(c, *filler));
   volatile unsigned long long* t = c->mail_host + MAIL_TICKET;
   for (unsigned long long spins = 0; *t != ticket; ++spins) {
     __builtin_ia32_pause();
@@ -146,10 +148,10 @@ extern "C" int amg_fetch_words(amg_ctx* c, const void* device_words, int32_t n_w
   return fetch(c, l, reinterpret_cast<unsigned long long*>(out));
 }
 
-int fetch_status(amg_ctx* c, unsigned long long* out) {
+int fetch_status(amg_ctx* c, unsigned long long* out, const ClearList* filler) {
   FetchList l;
   l.add_words(c->status.p, ST_WORDS);
-  return fetch(c, l, out);
+  return fetch(c, l, out, filler);
 }
 
 int clear_many(amg_ctx* c, const ClearList& l) {

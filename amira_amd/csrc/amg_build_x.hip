@@ -923,23 +923,7 @@ __global__ void k_x_gather_pairs(const unsigned int* __restrict__ first_sorted,
   pcnt[i] = cnt_by_claim[c];
 }
 
-// claims handed out by the counters of a plain pass (F_SHARDS shards + the head launch's): their sum into the count
-// word, the largest shard count into `most`
-#define X_CTRS (F_SHARDS + 1)
-__global__ void k_x_ctr_reduce(const unsigned long long* __restrict__ ctrs, unsigned long long* count,
-                               unsigned long long* most) {
-  unsigned long long v = ctrs[(size_t)threadIdx.x * F_CTR_STRIDE];
-  unsigned long long sum = v, mx = v;
-  for (int d = 32; d > 0; d >>= 1) {
-    sum += __shfl_xor(sum, d, 64);
-    const unsigned long long o = __shfl_xor(mx, d, 64);
-    mx = mx > o ? mx : o;
-  }
-  if (threadIdx.x == 0) {
-    *count = sum + ctrs[(size_t)F_SHARDS * F_CTR_STRIDE];
-    *most = mx;
-  }
-}
+#define X_CTRS (F_SHARDS + 1)  // counters of a plain pass: F_SHARDS shards + the first tiles'
 
 // ------------------------------------------------------------------ host side
 static inline unsigned int blocks_for(long long n, int per) {
@@ -974,9 +958,12 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   AMGCHK(c->s2.ensure((size_t)(words + 1) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(words + 1) * sizeof(long long)));
   AMGCHK(c->s0.ensure((size_t)words * 32 + 64));
-  ClearList cl;
-  cl.add(c->s0.p, (size_t)words * 32);
-  AMGCHK(clear_many(c, cl));
+  if (c->rank_flags_clean != words) {  // (else: zeroed behind the table pass's read-back, read_status)
+    ClearList cl;
+    cl.add(c->s0.p, (size_t)words * 32);
+    AMGCHK(clear_many(c, cl));
+  }
+  c->rank_flags_clean = 0;
   hipLaunchKernelGGL(k_x_rank_setflags, dim3(blocks_for(n, 256)), dim3(256), 0, st, first2, n, shift,
                      c->s0.as<unsigned char>());
   hipLaunchKernelGGL(k_x_rank_words, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
@@ -984,7 +971,36 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
-static int read_status(amg_ctx* c, unsigned long long* host) { return fetch_status(c, host); }
+// the status words after a table pass; ctrs != nullptr: the pass took its claims from the X_CTRS counters there —
+// their sum replaces host[count_word], the fullest shard's count goes to *most.  rank_filler: the flag bytes of the
+// ranking bitmap that follows (x_rank_bitmap) are zeroed behind the read-back kernel, while the host waits
+static int read_status(amg_ctx* c, unsigned long long* host, const unsigned long long* ctrs = nullptr, int count_word = 0,
+                       unsigned long long* most = nullptr, bool rank_filler = false) {
+  FetchList l;
+  l.add_words(c->status.p, ST_WORDS);
+  if (ctrs)
+    for (int i = 0; i < X_CTRS; ++i) l.add(ctrs + (size_t)i * F_CTR_STRIDE);
+  unsigned long long v[ST_WORDS + X_CTRS];
+  ClearList fill;
+  const long long words = (c->n_tokens >> 5) + 2;
+  if (rank_filler) {
+    AMGCHK(c->s0.ensure((size_t)words * 32 + 64));
+    fill.add(c->s0.p, (size_t)words * 32);
+  }
+  AMGCHK(fetch(c, l, v, rank_filler ? &fill : nullptr));
+  if (rank_filler) c->rank_flags_clean = words;
+  for (int i = 0; i < ST_WORDS; ++i) host[i] = v[i];
+  if (ctrs) {
+    unsigned long long sum = 0, mx = 0;
+    for (int i = 0; i < X_CTRS; ++i) {
+      sum += v[ST_WORDS + i];
+      if (i < (int)F_SHARDS && v[ST_WORDS + i] > mx) mx = v[ST_WORDS + i];
+    }
+    host[count_word] = sum;
+    if (most) *most = mx;
+  }
+  return AMG_OK;
+}
 
 // claims from shard counters (XShard) for the inputs that get a head launch (4 M tokens and more: below that one
 // counter serves a pass's workgroups in the time the pass takes anyway); AMG_CLAIM_SHARDS = 0 / 1: never / always
@@ -1054,6 +1070,8 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
   const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
   const size_t tab_slots = (size_t)c->node_slots + home_n;
   const long long claim_bound = ((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
+  const bool plain = sharded;  // the caller is the plain build: ranking follows the read-back directly
+  c->rank_flags_clean = 0;
   sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
   const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
@@ -1170,10 +1188,8 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
-  if (ctrs)
-    hipLaunchKernelGGL(k_x_ctr_reduce, dim3(1), dim3(64), 0, st, ctrs, c->status.as<unsigned long long>() + ST_NODE_INSERTS,
-                       c->status.as<unsigned long long>() + ST_COMPACT_A);
-  AMGCHK(read_status(c, hs));
+  unsigned long long most = 0;
+  AMGCHK(read_status(c, hs, ctrs, ST_NODE_INSERTS, &most, plain));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
 #ifdef AMG_EXP_CTR
   if ((AMG_EXP_CTR) == 1 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
@@ -1191,7 +1207,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
   c->n_windows = (int64_t)hs[ST_N_WINDOWS];
   c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_local_nodes = c->n_nodes = (int64_t)hs[ST_NODE_INSERTS];
-  c->x_nspace = ctrs ? shard_space(hs[ST_COMPACT_A], head_cap, max_claims) : c->n_nodes;
+  c->x_nspace = ctrs ? shard_space(most, head_cap, max_claims) : c->n_nodes;
   c->x_max_claims = (int64_t)max_claims;
   return AMG_OK;
 }
@@ -1330,6 +1346,8 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
   // claims: at most one per table slot, plus (lone) two classes per single node, never more than the windows
   long long claim_bound = (long long)tab_slots + (lone ? 2 * D : 0);
   claim_bound = (claim_bound < T ? claim_bound : T) + 1;
+  const bool plain = sharded;  // the caller is the plain build: counting and ranking follow, nobody else writes s0
+  c->rank_flags_clean = 0;
   sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
   const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
@@ -1392,10 +1410,8 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
-  if (ctrs)
-    hipLaunchKernelGGL(k_x_ctr_reduce, dim3(1), dim3(64), 0, st, ctrs, c->status.as<unsigned long long>() + ST_PAIR_INSERTS,
-                       c->status.as<unsigned long long>() + ST_COMPACT_B);
-  AMGCHK(read_status(c, hs));
+  unsigned long long most = 0;
+  AMGCHK(read_status(c, hs, ctrs, ST_PAIR_INSERTS, &most, plain));
   if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
 #ifdef AMG_EXP_CTR
   if ((AMG_EXP_CTR) == 2 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
@@ -1406,7 +1422,7 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
     return AMG_E_OVERFLOW;
   }
   c->n_local_pairs = c->n_pairs = (int64_t)hs[ST_PAIR_INSERTS];
-  c->x_espace = ctrs ? shard_space(hs[ST_COMPACT_B], head_cap, max_claims) : c->n_pairs;
+  c->x_espace = ctrs ? shard_space(most, head_cap, max_claims) : c->n_pairs;
   c->x_max_eclaims = (int64_t)max_claims;
   return AMG_OK;
 }

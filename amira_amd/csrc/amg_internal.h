@@ -220,6 +220,7 @@ struct amg_ctx {
   DevBuf x_efirst, x_eslot;  // the same for edge-class claims
   DevBuf x_ecnt;             // uint32[edge claims] occurrences
   DevBuf x_ncnt;             // uint32[node claims] occurrences (plain build: scattered into node_cov)
+  int64_t rank_flags_clean = 0;  // words of the ranking bitmap's flag bytes (s0) a read-back's filler has zeroed already
   DevBuf x_ftag;             // int32 [node claims] x_final | AMG_SINGLE_BIT on nodes of coverage 1 (edge pass with lone classes)
   DevBuf f_ctrs;             // fused table pass: per-shard claim counters
   DevBuf x_efinal;           // int32 [edge claims] claim id -> edge-class id
@@ -303,7 +304,7 @@ int clear_many(amg_ctx* c, const ClearList& l);
 // Device words the host needs NOW (counts that size the next allocation, status flags): everything queued on the
 // stream before the call has finished when fetch() returns, like hipMemcpyAsync + hipStreamSynchronize, at a
 // fraction of the latency (the stream stays idle ~10 us per read-back instead of ~40).
-#define FETCH_MAX 32
+#define FETCH_MAX 96
 struct FetchList {
   const unsigned long long* p[FETCH_MAX];
   int n = 0;
@@ -316,9 +317,11 @@ struct FetchList {
   }
   void add_words(const void* q, int words) { for (int i = 0; i < words; ++i) add(static_cast<const unsigned long long*>(q) + i); }
 };
-int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out);
+// filler: ranges to zero AFTER the read-back kernel and before the host waits for it — work that does not depend on the
+// words read, queued so that the stream is not idle while the host turns the answer into the next launches
+int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out, const ClearList* filler = nullptr);
 static_assert(ST_WORDS <= FETCH_MAX, "fetch_status reads the status words in one list");
-int fetch_status(amg_ctx* c, unsigned long long* out /*[ST_WORDS]*/);
+int fetch_status(amg_ctx* c, unsigned long long* out /*[ST_WORDS]*/, const ClearList* filler = nullptr);
 int stream_wait(amg_ctx* c);  // hipStreamSynchronize at the latency of fetch()
 
 // ------------------------------------------------------------------ stage timing

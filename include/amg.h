@@ -357,7 +357,7 @@ int64_t amg_py_tuple_hash(const int64_t* item_hashes, int64_t n);
 int amg_pyset_script(const int32_t* ops, int64_t n_ops, const int64_t* key_hash, int32_t n_sets,
                      int32_t* out_keys, int64_t* out_off);
 
-/* n_words (<= 32) 64-bit words of device memory to the host, ordered after everything queued on the ctx's stream, at
+/* n_words (<= 96) 64-bit words of device memory to the host, ordered after everything queued on the ctx's stream, at
  * the latency of the ctx's pinned mailbox (~10 us): how amira_amd/dist.py reads the record counts of its exchanges */
 int amg_fetch_words(amg_ctx* ctx, const void* device_words, int32_t n_words, uint64_t* out);
 
