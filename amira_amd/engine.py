@@ -114,7 +114,7 @@ class Engine:
         return _ffi.lib.amg_stream(self._h)
 
     def fetch_words(self, dev_ptr, n):
-        """n (<= 32) int64 words of device memory, ordered after everything queued on the engine's stream, through the
+        """n (<= 96) int64 words of device memory, ordered after everything queued on the engine's stream, through the
         engine's pinned mailbox (a few microseconds instead of a framework read-back)"""
         out = np.empty(n, np.int64)
         check(_ffi.lib.amg_fetch_words(self._h, C.c_void_p(dev_ptr), int(n), ptr(out)))
