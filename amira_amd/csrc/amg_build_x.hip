@@ -1217,10 +1217,12 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
 int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   hipStream_t st = c->stream;
   c->filtered_build = true;
-  const int r0 = bx_nodes_upsert(c, k, which);
+  const int r0 = bx_nodes_upsert(c, k, which, true);
   c->filtered_build = false;
   AMGCHK(r0);
-  const long long n = c->n_local_nodes, T = c->n_tokens;
+  // claim ids in use lie below n (shard counters: with ids nobody took in between — first-seen 0, like the claims
+  // dropped here)
+  const long long n = c->x_nspace, T = c->n_tokens;
   stage_begin(c, "node_count");  // per claim, straight from the per-window claims (construct_node.py:33-36)
   AMGCHK(c->x_ecnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_slot.as<int>(), T, nullptr, n, c->x_ecnt.as<unsigned int>(), 4));
@@ -1242,7 +1244,6 @@ int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   }
   stage_end(c);
   c->n_nodes = (int64_t)D;
-  c->x_nspace = n;  // claim ids in use lie below n; the dropped ones are holes
   AMGCHK(bx_nodes_rank(c));
   if (n > 0 && D > 0)
     hipLaunchKernelGGL(k_x_cov_from_claims, dim3(blocks_for(n, 256)), dim3(256), 0, st, c->x_ecnt.as<unsigned int>(),
