@@ -322,11 +322,15 @@ __global__ void k_uf_union(const unsigned long long* __restrict__ pkey, long lon
   }
 }
 
-__global__ void k_uf_roots(int* parent, long long n, unsigned int* __restrict__ is_root) {
+// root_copy: the roots once more, for the labelling that overwrites parent[] (was a copy launch of its own);
+// is_root[n] = 0 closes the array for the scan
+__global__ void k_uf_roots(int* parent, long long n, unsigned int* __restrict__ is_root, int* __restrict__ root_copy) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) is_root[n] = 0u;
   if (i >= n) return;
   int r = uf_find(parent, (int)i);
   parent[i] = r;  // only thread i writes entry i with its final root; roots keep parent==self
+  root_copy[i] = r;
   is_root[i] = (r == (int)i) ? 1u : 0u;
 }
 
@@ -869,10 +873,8 @@ int ensure_components(amg_ctx* c) {
     if (P > 0)
       hipLaunchKernelGGL(k_uf_union, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                          c->pair_key.as<unsigned long long>(), P, parent);
-    hipLaunchKernelGGL(k_uf_roots, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D, is_root);
-    HIPCHK(hipMemsetAsync(is_root + D, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(k_uf_roots, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D, is_root, root_copy);
     AMGCHK(prim_exscan_u32_to_i64(c, is_root, c->s1.as<long long>(), (size_t)D + 1));
-    HIPCHK(hipMemcpyAsync(root_copy, parent, (size_t)D * sizeof(int), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
                        c->s1.as<long long>(), D, parent);
     FetchList l;

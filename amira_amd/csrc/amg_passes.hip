@@ -1950,6 +1950,7 @@ struct PackArgs {
   const long long* pos_new;  // per read: pool index of a re-threaded read's new positions
   long long* o_posoff;       // per corrected read: pool index of its positions
   long long* o_rl;
+  long long out_reads, out_tokens;  // the corrected CSR's last offset: o_off[out_reads] = out_tokens
 };
 
 // One wave packs 64 consecutive reads.  Lane l owns read l's record: where its genes come from (the read itself,
@@ -1964,6 +1965,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   const CorrArgs& a = A.a;
   const int lane = threadIdx.x & 63;
   const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_READS + lane;
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.o_off[A.out_reads] = A.out_tokens;
   long long dst = 0, src = 0;  // src: token index; bit 62 set = in the temp area
   int n = 0;
   if (r < a.n_reads && A.keep[r]) {
@@ -2268,7 +2270,8 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       DevBuf& pool = c->c_gend;  // free until the pack step
       AMGCHK(pool.ensure((size_t)pool_cap * sizeof(int)));
       unsigned long long* used = c->status.as<unsigned long long>() + ST_COMPACT_A;
-      HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
+      ClearList gcl;
+      gcl.add(c->status.p, ST_WORDS * sizeof(unsigned long long));
       GapArgs G;
       G.a = a;
       G.g = make_view(c);
@@ -2293,9 +2296,12 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       if (attempt == 0) {
         const char* nf = getenv("AMG_NO_FAST_GAPPED");  // debugging / A-B switch
         const bool use_fast = !(nf && nf[0] == '1');
-        HIPCHK(hipMemsetAsync(need_slow, use_fast ? 0 : 1, (size_t)n_gapped + 1, st));
+        gcl.add(need_slow, ((size_t)n_gapped + 4) & ~(size_t)3, use_fast ? 0u : 0x01010101u);  // (the buffer has 64 spare bytes)
+        AMGCHK(clear_many(c, gcl));
         if (use_fast)
           hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, GF_WPB)), dim3(64 * GF_WPB), 0, st, G);
+      } else {
+        AMGCHK(clear_many(c, gcl));  // (the status words alone)
       }
       unsigned int blocks = (unsigned int)((n_gapped + 63) / 64);
       if (blocks > 2048u) blocks = 2048u;
@@ -2428,9 +2434,13 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   Pk.pos_new = pos_new;
   Pk.o_posoff = c->have_pos ? c->c_pos_off.as<long long>() : nullptr;
   Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
-  if (R > 0) hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
-  HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
-                        hipMemcpyHostToDevice, st));
+  Pk.out_reads = out_reads;
+  Pk.out_tokens = out_tokens;
+  if (R > 0)
+    hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
+  else
+    HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
+                          hipMemcpyHostToDevice, st));
   AMGCHK(stream_wait(c));
   stage_end(c);
   c->c_reads = out_reads;
