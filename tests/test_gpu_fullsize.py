@@ -181,9 +181,19 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
             engines.append(e)
         del gs, ge
 
+        # ---- the whole stream through ONE engine's plain build (480 M tokens, 43 M nodes: claim ids from the shard
+        # counters, the edge classes of coverage-1 nodes past the edge table, at eight times the benchmark's size)
+        orc.build(k)
+        one = Engine(0)
+        try:
+            one.set_reads(toks, offs, vocab.two_v)
+            one.build(k)
+            assert one.counts()["exact_keys"] == 1
+            compare_engine_to_sweep(one, orc, "one engine, 8 M reads")
+        finally:
+            one.close()
         # ---- build 1, merged, filter_graph(3, 1) fused in == build + filter on the whole stream
         dist_build_loopback(engines, k, 3, 1)
-        orc.build(k)
         orc.filter(3, 1)
         want = live_arrays(orc)
         tok_lo = 0
