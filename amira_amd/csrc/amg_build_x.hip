@@ -760,7 +760,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
   constexpr unsigned int DIRBIT = 0x40000000u;
   constexpr unsigned int IDMASK = LONE ? AMG_SINGLE_BIT - 1u : DIRBIT - 1u;
   __shared__ __attribute__((aligned(16))) int s_w[TILE + 4];
-  __shared__ unsigned int s_wave[TILE_THREADS / 64 + 1];
+  __shared__ unsigned int s_wave[TILE_THREADS / 64 + 2];
   const int tid = threadIdx.x;
   const long long t0 = (long long)(blockIdx.x + tile0) * TILE;
   // claims from the shard counters (XShard); the first tiles of the stream (the head launch and a few times as many
@@ -877,7 +877,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     f_table_phase<false, 3, false, TILE_THREADS, 1, LONE>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid,
                                                           orient3, xf, first2, slot_by_claim,
                                                           ctrs ? ctrs : status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status,
-                                                          2, id1, s_wave, &made, homed, home_n, lone, lone_base, cshard);
+                                                          2, id1, s_wave, &made, homed, home_n, lone, lone_base, cshard,
+                                                          ctrs ? (int)((blockIdx.x + tile0) & (F_SHARDS - 1u)) : -1);
   else
     f_table_phase<false, 3, false>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + i0, orient3, xf, first2,
                                    slot_by_claim, ctrs ? ctrs : status + ST_PAIR_INSERTS, 0u, cap, probe_limit, status, 2,

@@ -366,7 +366,8 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                                               unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave = nullptr,
                                               unsigned int* made = nullptr, unsigned int homed = 0u,
                                               unsigned int off = 0u, unsigned int lone = 0u,
-                                              unsigned int lone_base = 0u, XShard xs = XShard{-1, 0u}) {
+                                              unsigned int lone_base = 0u, XShard xs = XShard{-1, 0u},
+                                              int lone_shard = -1) {
   // xs.shard >= 0 (not SHARDED): ctr is the array of shard counters, cap a shard's share (XShard)
   static_assert(!LONE || !TWO, "lone items: one-word keys");
   auto tpos = [&](int it) { return tbase + (unsigned int)it * (unsigned int)STRIDE; };
@@ -453,7 +454,57 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
     n += (unsigned int)__popcll(m);
   }
   unsigned int base = 0;
-  if constexpr (SHARDED) {
+  // LONE: the lone classes of a workgroup take the ids after its table creations — or, in the first tiles of the stream
+  // (xs = the dense counter), ids of the tile's SHARD like everywhere else: they are never counted (one occurrence, the
+  // creator's), and kept out of the dense ids those hold the genome's classes alone, within the one LDS range of the
+  // counting sweeps (with them the head's classes reached 36 k ids and the first-build edge count needed a second
+  // sweep of 0.13 ms)
+  unsigned int lbase = 0;
+  XShard lxs = xs;
+  if constexpr (LONE) {
+    unsigned int nl = 0;
+#pragma unroll
+    for (int it = 0; it < TILE_ITEMS; ++it) {  // pre[] so far ranks all creators of the wave: split it
+      const unsigned long long ml = __ballot((lone >> it) & 1u);
+      const unsigned int mine_l = nl + (unsigned int)__popcll(ml & below);
+      const unsigned int all_before_l = mine_l;  // lone creators of the wave ranked before this lane's item `it`
+      if ((lone >> it) & 1u) pre[it] = mine_l;
+      else pre[it] -= all_before_l;
+      nl += (unsigned int)__popcll(ml);
+    }
+    const unsigned int nt = n - nl;
+    const unsigned int wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = nt | (nl << 16);
+    __syncthreads();
+    unsigned int before_t = 0, before_l = 0, total_t = 0, total_l = 0;
+#pragma unroll
+    for (unsigned int w = 0; w < TILE_THREADS / 64; ++w) {
+      const unsigned int cnt = s_wave[w];
+      before_t += w < wave ? (cnt & 0xffffu) : 0u;
+      before_l += w < wave ? (cnt >> 16) : 0u;
+      total_t += cnt & 0xffffu;
+      total_l += cnt >> 16;
+    }
+    const bool split = xs.shard == (int)F_SHARDS && lone_shard >= 0;  // workgroup-uniform
+    if (split) lxs = XShard{lone_shard, xs.base};
+    if (total_t + total_l) {
+      if (threadIdx.x == 0) {
+        unsigned int bt, bl;
+        if (split) {
+          bt = total_t ? (unsigned int)atomicAdd(xs.counter(ctr), (unsigned long long)total_t) : 0u;
+          bl = total_l ? (unsigned int)atomicAdd(lxs.counter(ctr), (unsigned long long)total_l) : 0u;
+        } else {
+          bt = (unsigned int)atomicAdd(xs.counter(ctr), (unsigned long long)(total_t + total_l));
+          bl = bt + total_t;
+        }
+        s_wave[TILE_THREADS / 64] = bt;
+        s_wave[TILE_THREADS / 64 + 1] = bl;
+      }
+      __syncthreads();
+      base = s_wave[TILE_THREADS / 64] + before_t;
+      lbase = s_wave[TILE_THREADS / 64 + 1] + before_l;
+    }
+  } else if constexpr (SHARDED) {
     if (n) {  // wave-uniform
       unsigned int b = 0;
       if (lane == 0) b = (unsigned int)atomicAdd(ctr, (unsigned long long)n);
@@ -499,12 +550,13 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
 #pragma unroll
     for (int it = 0; it < TILE_ITEMS; ++it)
       if (created & (1u << it)) {
-        unsigned int li = base + pre[it];
-        if (li >= (SHARDED ? cap : xs.limit(cap))) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
+        const bool is_lone = LONE && ((lone >> it) & 1u);
+        unsigned int li = (is_lone ? lbase : base) + pre[it];
+        if (li >= (SHARDED ? cap : is_lone ? lxs.limit(cap) : xs.limit(cap))) {  // the shard's share of the claim arrays is used up: the host rebuilds larger
           status[ST_OVERFLOW] = (unsigned long long)which;
           li = 0;
         }
-        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : xs.claim(li);
+        const unsigned int claim = SHARDED ? li * F_SHARDS + shard : is_lone ? lxs.claim(li) : xs.claim(li);
         // the creator's first-seen goes to its own word with a plain store; everybody else raises the
         // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
         // has to be ordered against the publication of the id
