@@ -359,16 +359,28 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
 // this kind left behind (hint = {beyond, n}; rebuilds of a cleaning sweep look alike).
 // With GATHER the array holds table slots on entry and is rewritten to dense ids
 // (tab[slot].id) during the first sweep.
-#define HOT_IDS 32768
+// (HOT_IDS: 156 of the CU's 160 KB of LDS — the head launch of cfg 3's first build hands out 36 k claims, four
+// thousand more than the 32 k counters of rounds 1-3 held, and their windows were what a second sweep was for)
+#define HOT_IDS 39936
 #define COUNT_MAX_SWEEPS 4
+// The first sweep also LISTS the ids it finds beyond its range while they are few — every workgroup in a segment of
+// its own (COUNT_LIST_SEG ids, filled through a counter in LDS: one shared list cost 20 k returning atomics on one word,
+// 0.5 ms) — so that a count whose first sweep had no hint to finish the job itself (the first count of a read set) ends
+// with a second launch that walks the segments, microseconds, instead of a second sweep over the whole array for a few
+// thousand increments.  list: [0] a segment ran over (the list is then not used), [2 + b] ids in workgroup b's segment,
+// segments from COUNT_LIST_HEAD on.
+#define COUNT_LIST_SEG 256
+#define COUNT_MAX_BLOCKS 256
+#define COUNT_LIST_HEAD (2 + COUNT_MAX_BLOCKS)
 // state: [0..3] ids beyond the range of sweep r, [4..7] sweep r finished the job
 template <bool GATHER>
 __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long long n,
                                                     const Slot* __restrict__ tab, long long lo,
                                                     int sweep, int last, unsigned long long* state,
                                                     unsigned long long* hint, unsigned int* __restrict__ out,
-                                                    int strip, const int* __restrict__ remap) {
+                                                    int strip, const int* __restrict__ remap, unsigned int* list) {
   __shared__ unsigned int s_cnt[HOT_IDS];
+  __shared__ unsigned int s_listed;
   bool tail_all = last != 0;
   if (sweep > 0) {
     for (int q = 0; q < sweep; ++q)
@@ -379,10 +391,23 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
       hint[1] = (unsigned long long)n;
     }
     if (left == 0ull) return;
+    if (sweep == 1 && list && list[1] == 1u && list[0] == 0u) {  // everything left is in the first sweep's segments
+      const unsigned int mine = list[2 + blockIdx.x];
+      for (unsigned int i = threadIdx.x; i < mine; i += 1024u)
+        atomicAdd(&out[list[COUNT_LIST_HEAD + blockIdx.x * COUNT_LIST_SEG + i]], 1u);
+      if (blockIdx.x == 0 && threadIdx.x == 0) state[COUNT_MAX_SWEEPS + sweep] = 1ull;
+      return;
+    }
     if (left * 8ull <= (unsigned long long)n) tail_all = true;
   } else if (hint[1] != 0ull && hint[0] * 8ull <= hint[1]) {
     tail_all = true;
   }
+  const bool listing = sweep == 0 && !tail_all && list != nullptr && gridDim.x <= COUNT_MAX_BLOCKS;
+  if (threadIdx.x == 0) s_listed = 0u;  // (ordered before its first use by the barrier below)
+  auto list_id = [&](int id) {
+    const unsigned int at = atomicAdd(&s_listed, 1u);
+    if (at < (unsigned int)COUNT_LIST_SEG) list[COUNT_LIST_HEAD + blockIdx.x * COUNT_LIST_SEG + at] = (unsigned int)id;
+  };
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) s_cnt[i] = 0;
   __syncthreads();
   const long long stride = (long long)gridDim.x * 1024;
@@ -407,6 +432,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
     } else {
       ++beyond;
       if (tail_all) atomicAdd(&out[id], 1u);
+      else if (listing) list_id(id);
     }
   };
   // one block per CU (the counters fill the LDS), so the bytes in flight have to come from the threads themselves:
@@ -445,6 +471,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
       } else {
         ++beyond;
         if (tail_all) atomicAdd(&out[id], 1u);
+        else if (listing) list_id(id);
       }
     }
   };
@@ -462,6 +489,12 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   if ((threadIdx.x & 63) == 0 && beyond) atomicAdd(&state[sweep], (unsigned long long)beyond);
   if (tail_all && blockIdx.x == 0 && threadIdx.x == 0) state[COUNT_MAX_SWEEPS + sweep] = 1ull;
   __syncthreads();
+  if (listing && threadIdx.x == 0) {
+    const unsigned int got = s_listed;
+    list[2 + blockIdx.x] = got < (unsigned int)COUNT_LIST_SEG ? got : (unsigned int)COUNT_LIST_SEG;
+    if (got > (unsigned int)COUNT_LIST_SEG) list[0] = 1u;
+    if (blockIdx.x == 0) list[1] = 1u;  // "the first sweep listed"
+  }
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) {
     const unsigned int cnt = s_cnt[i];
     if (cnt) atomicAdd(&out[lo + i], cnt);
@@ -495,6 +528,9 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   const int strip = made ? 2 : (kind >= 2 ? 1 : 0);
   cl.add(state, 2 * COUNT_MAX_SWEEPS * sizeof(unsigned long long));
   if (fresh) cl.add(c->cnt_state.as<unsigned long long>() + 4 * COUNT_MAX_SWEEPS, 4 * sizeof(unsigned long long));
+  AMGCHK(c->cnt_list.ensure((size_t)(COUNT_LIST_HEAD + COUNT_MAX_BLOCKS * COUNT_LIST_SEG) * sizeof(unsigned int)));
+  unsigned int* list = c->cnt_list.as<unsigned int>();
+  cl.add(list, COUNT_LIST_HEAD * sizeof(unsigned int));
   AMGCHK(clear_many(c, cl));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
@@ -505,7 +541,7 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   // every block flushes up to HOT_IDS counters with global atomics at the end of a sweep: give a
   // block at least twice that many ids to count (small inputs: fewer blocks, not a shorter sweep)
   long long want_blocks = (n + 2 * HOT_IDS - 1) / (2 * HOT_IDS);
-  unsigned int blocks = (unsigned int)(want_blocks < 1 ? 1 : (want_blocks < 256 ? want_blocks : 256));
+  unsigned int blocks = (unsigned int)(want_blocks < 1 ? 1 : (want_blocks < COUNT_MAX_BLOCKS ? want_blocks : COUNT_MAX_BLOCKS));
   if (const char* e = getenv("AMG_COUNT_BLOCKS")) {  // A/B switch
     const unsigned int b = (unsigned int)atoi(e);
     if (b >= 1 && b < blocks) blocks = b;
@@ -515,10 +551,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
     const int last = (r == ranges - 1) ? 1 : 0;
     if ((gather_tab || remap) && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, strip, remap);
+                         (int)r, last, state, hint, out, strip, remap, list);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, remap ? 0 : strip, remap);
+                         (int)r, last, state, hint, out, remap ? 0 : strip, remap, list);
   }
   if (getenv("AMG_COUNT_DEBUG")) {  // what every sweep left beyond its range, which one finished (synchronises: debugging only)
     unsigned long long h[2 * COUNT_MAX_SWEEPS];

@@ -264,6 +264,7 @@ struct amg_ctx {
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
   DevBuf cnt_state;    // counting sweeps: per-sweep left-over counts and done flags + the hints
   bool cnt_hint_reset = false;
+  DevBuf cnt_list;     // k_count_ids: what the first sweep of a count found beyond its range, while that is little
   int cnt_sweeps[2] = {4, 4};  // sweeps the last node / edge-class count made use of (count_ids launches no more)
 
   std::vector<StageTime> stages;
