@@ -456,7 +456,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
   unsigned int base = 0;
   // LONE: the lone classes of a workgroup take the ids after its table creations — or, in the first tiles of the stream
   // (xs = the dense counter), ids of the tile's SHARD like everywhere else: they are never counted (one occurrence, the
-  // creator's), and kept out of the dense ids those hold the genome's classes alone, within the one LDS range of the
+  // creator's), and with them kept out, the dense ids hold the genome's classes alone, within the one LDS range of the
   // counting sweeps (with them the head's classes reached 36 k ids and the first-build edge count needed a second
   // sweep of 0.13 ms)
   unsigned int lbase = 0;
@@ -466,10 +466,8 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
 #pragma unroll
     for (int it = 0; it < TILE_ITEMS; ++it) {  // pre[] so far ranks all creators of the wave: split it
       const unsigned long long ml = __ballot((lone >> it) & 1u);
-      const unsigned int mine_l = nl + (unsigned int)__popcll(ml & below);
-      const unsigned int all_before_l = mine_l;  // lone creators of the wave ranked before this lane's item `it`
-      if ((lone >> it) & 1u) pre[it] = mine_l;
-      else pre[it] -= all_before_l;
+      const unsigned int lone_before = nl + (unsigned int)__popcll(ml & below);  // lone creators ranked before this item
+      pre[it] = ((lone >> it) & 1u) ? lone_before : pre[it] - lone_before;
       nl += (unsigned int)__popcll(ml);
     }
     const unsigned int nt = n - nl;
