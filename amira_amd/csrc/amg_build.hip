@@ -378,7 +378,8 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
                                                     const Slot* __restrict__ tab, long long lo,
                                                     int sweep, int last, unsigned long long* state,
                                                     unsigned long long* hint, unsigned int* __restrict__ out,
-                                                    int strip, const int* __restrict__ remap, unsigned int* list) {
+                                                    int strip, const int* __restrict__ remap, unsigned int* list,
+                                                    unsigned int seg_cap) {
   __shared__ unsigned int s_cnt[HOT_IDS];
   __shared__ unsigned int s_listed;
   bool tail_all = last != 0;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   if (threadIdx.x == 0) s_listed = 0u;  // (ordered before its first use by the barrier below)
   auto list_id = [&](int id) {
     const unsigned int at = atomicAdd(&s_listed, 1u);
-    if (at < (unsigned int)COUNT_LIST_SEG) list[COUNT_LIST_HEAD + blockIdx.x * COUNT_LIST_SEG + at] = (unsigned int)id;
+    if (at < seg_cap) list[COUNT_LIST_HEAD + blockIdx.x * COUNT_LIST_SEG + at] = (unsigned int)id;
   };
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) s_cnt[i] = 0;
   __syncthreads();
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(1024) void k_count_ids(int* __restrict__ ids, long 
   __syncthreads();
   if (listing && threadIdx.x == 0) {
     const unsigned int got = s_listed;
-    list[2 + blockIdx.x] = got < (unsigned int)COUNT_LIST_SEG ? got : (unsigned int)COUNT_LIST_SEG;
-    if (got > (unsigned int)COUNT_LIST_SEG) list[0] = 1u;
+    list[2 + blockIdx.x] = got < seg_cap ? got : seg_cap;
+    if (got > seg_cap) list[0] = 1u;
     if (blockIdx.x == 0) list[1] = 1u;  // "the first sweep listed"
   }
   for (int i = threadIdx.x; i < HOT_IDS; i += 1024) {
@@ -531,6 +532,8 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   AMGCHK(c->cnt_list.ensure((size_t)(COUNT_LIST_HEAD + COUNT_MAX_BLOCKS * COUNT_LIST_SEG) * sizeof(unsigned int)));
   unsigned int* list = c->cnt_list.as<unsigned int>();
   cl.add(list, COUNT_LIST_HEAD * sizeof(unsigned int));
+  unsigned int seg_cap = COUNT_LIST_SEG;  // AMG_COUNT_LIST_SEG: test switch (a small segment runs over: the second launch sweeps)
+  if (const char* e = getenv("AMG_COUNT_LIST_SEG")) seg_cap = (unsigned int)std::min(std::max(atoi(e), 0), COUNT_LIST_SEG);
   AMGCHK(clear_many(c, cl));
   if (n <= 0 || n_ids <= 0) return AMG_OK;
   long long ranges = (n_ids + HOT_IDS - 1) / HOT_IDS;
@@ -551,10 +554,10 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
     const int last = (r == ranges - 1) ? 1 : 0;
     if ((gather_tab || remap) && r == 0)
       hipLaunchKernelGGL(k_count_ids<true>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, strip, remap, list);
+                         (int)r, last, state, hint, out, strip, remap, list, seg_cap);
     else
       hipLaunchKernelGGL(k_count_ids<false>, dim3(blocks), dim3(1024), 0, st, ids, n, gather_tab, lo,
-                         (int)r, last, state, hint, out, remap ? 0 : strip, remap, list);
+                         (int)r, last, state, hint, out, remap ? 0 : strip, remap, list, seg_cap);
   }
   if (getenv("AMG_COUNT_DEBUG")) {  // what every sweep left beyond its range, which one finished (synchronises: debugging only)
     unsigned long long h[2 * COUNT_MAX_SWEEPS];
