@@ -771,8 +771,10 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
             li = 0;
           }
           const unsigned int claim = claim_of(li);
+#if !defined(AMG_NODE_ABL) || (AMG_NODE_ABL) != 1  // (1: timing experiment, tools/node_abl_probe.sh: the per-claim stores left out)
           first2[2u * claim + 1u] = fi(it);  // the creator's own word, plain store (others raise the other word)
           slot_by_claim[claim] = (unsigned int)slot[it];
+#endif
           id1[it] = claim + 1u;
           const unsigned long long pub = ((unsigned long long)tag[it] << 32) |
                                          (unsigned long long)((tpos(it) >> f.cshift) << f.ib) | (unsigned long long)(claim + 1u);
