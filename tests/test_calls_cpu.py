@@ -104,3 +104,35 @@ def test_loader_and_writer_in_pieces(tmp_path, monkeypatch):
     dup.write_text(text[:-1] + ', "read_0003": ["+g1"]}')
     with pytest.raises(_ffi.AmgError, match="duplicate read id"):
         load_gene_calls(str(dup))
+
+
+def test_writers_replace_a_longer_file(tmp_path, monkeypatch):
+    """the writers do not truncate on open (a replaced file keeps its cached pages) and cut the file to its new length
+    when they are done: a shorter result over a longer file leaves no tail, whatever the number of pieces; a path
+    that cannot be written is an error, not a silent nothing"""
+    from amira_amd import _ffi
+    from amira_amd.io import load_gene_calls, write_gene_calls, write_gene_positions
+    calls = {f"read_{i:03d}": [("+" if (i + j) % 3 else "-") + f"gene{(i * 7 + j) % 23}" for j in range(i % 9)]
+             for i in range(300)}
+    pos = {r: [[10 * j, 10 * j + 7] for j in range(len(v))] for r, v in calls.items()}
+    cj, pj = _write(tmp_path, "c.json", calls), _write(tmp_path, "p.json", pos)
+    reads, gs, ge = load_gene_calls(cj, pj)
+    out_c, out_p = str(tmp_path / "out_c.json"), str(tmp_path / "out_p.json")
+    for threads in ("1", "7"):
+        monkeypatch.setenv("AMG_CALLS_THREADS", threads)
+        for path in (out_c, out_p):
+            with open(path, "w") as f:
+                f.write("x" * 200_000)                       # longer than anything written below
+        write_gene_calls(out_c, reads.vocab, reads.tokens, reads.read_offsets, reads.read_ids)
+        write_gene_positions(out_p, gs, ge, reads.read_offsets, reads.read_ids)
+        assert open(out_c).read() == json.dumps(calls) and open(out_p).read() == json.dumps(pos)
+        # a handful of reads over the full files
+        few = 5
+        n_tok = int(reads.read_offsets[few])
+        write_gene_calls(out_c, reads.vocab, reads.tokens[:n_tok], reads.read_offsets[:few + 1], reads.read_ids[:few])
+        write_gene_positions(out_p, gs[:n_tok], ge[:n_tok], reads.read_offsets[:few + 1], reads.read_ids[:few])
+        assert json.load(open(out_c)) == {r: calls[r] for r in list(calls)[:few]}
+        assert json.load(open(out_p)) == {r: pos[r] for r in list(pos)[:few]}
+    with pytest.raises(_ffi.AmgError, match="cannot write"):
+        write_gene_calls(str(tmp_path / "no_such_dir" / "x.json"), reads.vocab, reads.tokens, reads.read_offsets,
+                         reads.read_ids)
