@@ -97,7 +97,10 @@ def _load():
         "amg_calls_load_positions_json": (C.c_int, [P, C.c_char_p, P, P]),
         "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
         "amg_calls_write_positions_json": (C.c_int, [C.c_char_p, P, P, P, I64, P]),
+        "amg_calls_first_use": (C.c_int, [P, I64, I32, P, I64, P]),
+        "amg_calls_has_blanks": (C.c_int, [P, C.POINTER(I32)]),
         "amg_calls_free": (C.c_int, [P]),
+        "amg_calls_trim": (C.c_int, [C.POINTER(I64)]),
         "amg_cluster_full_blocks": (C.c_int, [P, P, I64, P, P, I32, P, I64, I64, C.POINTER(P)]),
         "amg_cluster_anchor_stats": (C.c_int, [P, P, I64, P, P, I32, I64, P]),
         "amg_cluster_blocks_sizes": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -30,6 +31,83 @@
 #include <unistd.h>
 
 #include "amg_internal.h"
+
+// ------------------------------------------------------------------ big host buffers, kept between calls
+// A load or a write of a cfg-3-sized file fills one to two gigabytes of fresh heap (the file's bytes, the writers'
+// texts); freed, glibc hands blocks of that size straight back to the kernel and the next call faults every page in
+// again (every piece of a JSON -> sweep -> JSON round ran ~40 % slower inside the round than alone).  The 2 MB-aligned
+// blocks of FileView and of the writers' texts go to a small cache instead and serve the next call that asks for about
+// as much; amg_calls_trim() gives everything back to the system.
+namespace {
+const size_t kTwoMb = (size_t)2 << 20;
+struct BigCache {
+  static const int kSlots = 80;  // (two writers' 32 texts each + the file views)
+  static const size_t kMaxBytes = (size_t)8 << 30;
+  std::mutex mu;
+  void* ptr[kSlots] = {};
+  size_t bytes[kSlots] = {};
+  size_t held = 0;
+  // the smallest cached block of at least `want` bytes that is not more than twice as large; *got = its size
+  void* take(size_t want, size_t* got) {
+    std::lock_guard<std::mutex> g(mu);
+    int best = -1;
+    for (int i = 0; i < kSlots; ++i)
+      if (ptr[i] && bytes[i] >= want && bytes[i] <= 2 * want + 4 * kTwoMb && (best < 0 || bytes[i] < bytes[best])) best = i;
+    if (best < 0) return nullptr;
+    void* p = ptr[best];
+    *got = bytes[best];
+    held -= bytes[best];
+    ptr[best] = nullptr;
+    bytes[best] = 0;
+    return p;
+  }
+  bool give(void* p, size_t n) {  // false: no room, the caller frees the block
+    std::lock_guard<std::mutex> g(mu);
+    if (getenv("AMG_CALLS_NO_CACHE") || held + n > kMaxBytes) return false;
+    for (int i = 0; i < kSlots; ++i)
+      if (!ptr[i]) {
+        ptr[i] = p;
+        bytes[i] = n;
+        held += n;
+        return true;
+      }
+    return false;
+  }
+  size_t trim() {
+    std::lock_guard<std::mutex> g(mu);
+    const size_t was = held;
+    for (int i = 0; i < kSlots; ++i) {
+      if (ptr[i]) free(ptr[i]);
+      ptr[i] = nullptr;
+      bytes[i] = 0;
+    }
+    held = 0;
+    return was;
+  }
+};
+BigCache g_big;
+
+// a 2 MB-aligned block of at least `want` bytes, advised as huge pages (a gigabyte of fresh heap is 250 k page faults
+// otherwise, served under one lock while 32 threads fill it); *got = its size, which big_free wants back
+void* big_alloc(size_t want, size_t* got) {
+  const size_t whole = (want + kTwoMb - 1) & ~(kTwoMb - 1);
+  if (void* p = g_big.take(whole, got)) return p;
+  void* p = nullptr;
+  if (posix_memalign(&p, kTwoMb, whole) != 0 || !p) return nullptr;
+  madvise(p, whole, MADV_HUGEPAGE);  // (advice: ignored where transparent huge pages are off)
+  *got = whole;
+  return p;
+}
+void big_free(void* p, size_t size) {
+  if (p && !g_big.give(p, size)) free(p);
+}
+}  // namespace
+
+extern "C" int amg_calls_trim(int64_t* released_bytes) {
+  const size_t was = g_big.trim();
+  if (released_bytes) *released_bytes = (int64_t)was;
+  return AMG_OK;
+}
 
 // ------------------------------------------------------------------ SHA-256 (FIPS 180-4)
 namespace {
@@ -303,24 +381,22 @@ int worker_count(size_t bytes);
 struct FileView {
   const char* data = nullptr;
   size_t size = 0;
-  // (not a vector: no zero fill of a gigabyte that is about to be overwritten; 2 MB-aligned and advised as huge pages:
-  // a gigabyte of fresh heap is 250 k page faults otherwise, served under one lock while 32 threads fill it)
-  struct Freer { void operator()(char* p) const { free(p); } };
-  std::unique_ptr<char[], Freer> owned;
+  // (not a vector: no zero fill of a gigabyte that is about to be overwritten; a block of the big-buffer cache above)
+  char* owned = nullptr;
+  size_t owned_bytes = 0;
+  FileView() = default;
+  FileView(const FileView&) = delete;
+  FileView& operator=(const FileView&) = delete;
+  ~FileView() { big_free(owned, owned_bytes); }
   bool open(const char* path, std::string& err) {
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) { err = std::string("cannot open ") + path; return false; }
     struct stat st;
     if (fstat(fd, &st) != 0) { ::close(fd); err = std::string("cannot stat ") + path; return false; }
     size = (size_t)st.st_size;
-    {
-      void* mem = nullptr;
-      const size_t bytes = (size + 1 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-      if (posix_memalign(&mem, (size_t)2 << 20, bytes) != 0 || !mem) { ::close(fd); err = "out of memory"; return false; }
-      madvise(mem, bytes, MADV_HUGEPAGE);  // (advice: ignored where transparent huge pages are off)
-      owned.reset(static_cast<char*>(mem));
-    }
-    data = owned.get();
+    owned = static_cast<char*>(big_alloc(size + 1, &owned_bytes));
+    if (!owned) { ::close(fd); err = "out of memory"; return false; }
+    data = owned;
     const int workers = size ? worker_count(size) : 0;
     std::vector<int> bad((size_t)std::max(workers, 1), 0);
     std::vector<std::thread> th;
@@ -329,7 +405,7 @@ struct FileView {
         size_t at = size / (size_t)workers * (size_t)w;
         const size_t end = w + 1 == workers ? size : size / (size_t)workers * (size_t)(w + 1);
         while (at < end) {
-          const ssize_t n = pread(fd, owned.get() + at, end - at, (off_t)at);
+          const ssize_t n = pread(fd, owned + at, end - at, (off_t)at);
           if (n <= 0) { bad[(size_t)w] = 1; return; }
           at += (size_t)n;
         }
@@ -386,6 +462,7 @@ struct amg_calls {
   std::vector<int32_t> tokens;
   std::vector<std::string> names;  // rank order
   std::vector<uint8_t> hashes;     // 32 bytes per name, rank order
+  bool blanks = false;             // some gene name of the file held a blank
 };
 
 extern "C" int amg_calls_free(amg_calls* c) {
@@ -403,6 +480,7 @@ struct CallsPart {
   std::vector<int8_t> strand;
   std::string error;            // non-empty: the piece did not parse
   long long error_at = 0;
+  bool blanks = false;          // a gene name held a blank (stored with '_' in its place, construct_gene.py:54-56)
 };
 
 // entries `"read": ["+gene", ...]` separated by commas, up to the end of the reader's range (which must be reached)
@@ -457,6 +535,7 @@ bool parse_call_entries(Reader& r, CallsPart& part, const char* file_begin) {
           if (!has_space) {
             id = part.genes.intern_h(gb + 1, (size_t)(ge - gb - 1), hsh);
           } else {
+            part.blanks = true;
             fixed.assign(gb + 1, ge);
             std::replace(fixed.begin(), fixed.end(), ' ', '_');
             id = part.genes.intern_h(fixed.data(), fixed.size(), hsh);
@@ -473,6 +552,7 @@ bool parse_call_entries(Reader& r, CallsPart& part, const char* file_begin) {
           if (blank) return fail("Gene information is missing");
           if (*gb != '+' && *gb != '-') return fail("Strand information missing for a gene");
           if (ge - gb < 2) return fail("Gene name information missing for a gene");
+          if (has_space) part.blanks = true;
           fixed.assign(gb + 1, ge);
           std::replace(fixed.begin(), fixed.end(), ' ', '_');
           id = part.genes.intern(fixed.data(), fixed.size());
@@ -546,6 +626,7 @@ extern "C" int amg_calls_load_json(const char* path, amg_calls** out) {
   }
   if (timing) fprintf(stderr, "parse %.3fs cpu %.3fs wall, %zu piece(s)\n", (double)(clock() - t_start) / CLOCKS_PER_SEC, wall(), parts.size());
   amg_calls* c = new amg_calls();
+  for (auto& p : parts) c->blanks = c->blanks || p.blanks;
   // ---- read ids in file order (one table for the whole file: a read id must not repeat), read offsets
   {
     size_t n_ids = 0, id_bytes = 0;
@@ -637,6 +718,12 @@ extern "C" int amg_calls_counts(amg_calls* c, int64_t* n_reads, int64_t* n_token
   return AMG_OK;
 }
 
+extern "C" int amg_calls_has_blanks(amg_calls* c, int32_t* out) {
+  if (!c || !out) return amg_fail(AMG_E_ARG, "null argument");
+  *out = c->blanks ? 1 : 0;
+  return AMG_OK;
+}
+
 extern "C" int amg_calls_get(amg_calls* c, int32_t* tokens, int64_t* read_offsets, char* gene_names,
                              char* read_ids, uint8_t* gene_hashes) {
   if (!c) return amg_fail(AMG_E_ARG, "null calls");
@@ -651,6 +738,45 @@ extern "C" int amg_calls_get(amg_calls* c, int32_t* tokens, int64_t* read_offset
       read_ids += n + 1;
     }
   if (gene_hashes && !c->hashes.empty()) memcpy(gene_hashes, c->hashes.data(), c->hashes.size());
+  return AMG_OK;
+}
+
+// process_pandora_json (pre_processing.py:44-63) keeps the genes of interest that occur in the reads, collected in a
+// Python set in the order the reads first show them.  Here: for every wanted gene rank the index of the first token
+// that carries it (either strand), -1 when none does — the stream cut into stretches, one thread each.
+extern "C" int amg_calls_first_use(const int32_t* tokens, int64_t n_tokens, int32_t two_v, const int32_t* wanted_ranks,
+                                   int64_t n_wanted, int64_t* first_index) {
+  if ((n_tokens > 0 && !tokens) || (n_wanted > 0 && (!wanted_ranks || !first_index)) || two_v <= 0 || (two_v & 1))
+    return amg_fail(AMG_E_ARG, "amg_calls_first_use: bad argument");
+  const int32_t V = two_v / 2;
+  std::vector<int32_t> slot((size_t)V, -1);  // gene rank -> index into wanted_ranks
+  for (int64_t i = 0; i < n_wanted; ++i) {
+    first_index[i] = -1;
+    if (wanted_ranks[i] < 0 || wanted_ranks[i] >= V) return amg_fail(AMG_E_ARG, "amg_calls_first_use: rank outside [0, V)");
+    if (slot[(size_t)wanted_ranks[i]] < 0) slot[(size_t)wanted_ranks[i]] = (int32_t)i;
+  }
+  if (n_wanted == 0 || n_tokens == 0) return AMG_OK;
+  const size_t workers = (size_t)worker_count((size_t)n_tokens * sizeof(int32_t));
+  std::vector<std::vector<int64_t>> part(workers, std::vector<int64_t>((size_t)n_wanted, -1));
+  std::vector<int> bad(workers, 0);
+  run_parts(workers, [&](size_t w) {
+    const int64_t a = n_tokens * (int64_t)w / (int64_t)workers, b = n_tokens * (int64_t)(w + 1) / (int64_t)workers;
+    int64_t* mine = part[w].data();
+    const int32_t* sl = slot.data();
+    for (int64_t t = a; t < b; ++t) {
+      const int32_t tok = tokens[t];
+      if ((uint32_t)tok >= (uint32_t)two_v) { bad[w] = 1; return; }
+      const int32_t s = sl[tok >= V ? tok - V : V - 1 - tok];
+      if (s >= 0 && mine[s] < 0) mine[s] = t;
+    }
+  });
+  for (int b : bad)
+    if (b) return amg_fail(AMG_E_ARG, "amg_calls_first_use: a token lies outside [0, two_v)");
+  for (size_t w = 0; w < workers; ++w)
+    for (int64_t i = 0; i < n_wanted; ++i)
+      if (first_index[i] < 0 && part[w][(size_t)i] >= 0) first_index[i] = part[w][(size_t)i];
+  for (int64_t i = 0; i < n_wanted; ++i)  // a rank listed twice answers both times
+    if (first_index[i] < 0 && slot[(size_t)wanted_ranks[i]] != (int32_t)i) first_index[i] = first_index[slot[(size_t)wanted_ranks[i]]];
   return AMG_OK;
 }
 
@@ -755,19 +881,24 @@ struct HugeAlloc {
   HugeAlloc() = default;
   template <class U> HugeAlloc(const HugeAlloc<U>&) {}
   T* allocate(size_t n) {
-    const size_t bytes = n * sizeof(T), two_mb = (size_t)2 << 20;
+    const size_t bytes = n * sizeof(T);
     void* p = nullptr;
-    if (bytes >= 2 * two_mb) {
-      const size_t whole = (bytes + two_mb - 1) & ~(two_mb - 1);
-      if (posix_memalign(&p, two_mb, whole) != 0) p = nullptr;
-      if (p) madvise(p, whole, MADV_HUGEPAGE);
+    if (bytes >= 2 * kTwoMb) {
+      size_t got = 0;
+      p = big_alloc(bytes, &got);  // (a cached block may be larger than asked for; deallocate returns it at the asked size)
     } else {
       p = malloc(bytes ? bytes : 1);
     }
     if (!p) throw std::bad_alloc();
     return static_cast<T*>(p);
   }
-  void deallocate(T* p, size_t) { free(p); }
+  void deallocate(T* p, size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= 2 * kTwoMb)
+      big_free(p, (bytes + kTwoMb - 1) & ~(kTwoMb - 1));
+    else
+      free(p);
+  }
   template <class U> bool operator==(const HugeAlloc<U>&) const { return true; }
   template <class U> bool operator!=(const HugeAlloc<U>&) const { return false; }
 };

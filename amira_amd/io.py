@@ -331,16 +331,48 @@ def _split(buf):
     return [] if len(buf) == 0 else buf.tobytes()[:-1].decode("utf-8").split("\0")
 
 
-def load_gene_calls(calls_json, positions_json=None):
+class _ArrayPool:
+    """The loader's big output arrays (tokens, gene starts / ends: 0.24 + 2 x 0.48 GB for a million 60-gene reads) are
+    fresh heap on every call, and a gigabyte of fresh heap is a quarter of a million page faults.  An array the pool
+    handed out is given out again once nobody else refers to it any more (its reference count is back to the pool's
+    own: every view, slice or mapping built on it holds a reference to it, so an array somebody can still see is never
+    reused); otherwise a new one is made.  `clear()` drops the pool's arrays."""
+
+    def __init__(self, keep=6):
+        self._held, self._keep = [], keep
+
+    def empty(self, n, dtype):
+        import sys
+        dtype = np.dtype(dtype)
+        for a in self._held:
+            # 3 = the list's reference + the loop variable + getrefcount's own argument
+            if a.dtype == dtype and a.size >= n and a.size <= 2 * n + 1024 and sys.getrefcount(a) == 3:
+                return a[:n] if a.size != n else a
+        a = np.empty(n, dtype)
+        if n >= (1 << 20):
+            self._held.append(a)
+            if len(self._held) > self._keep:
+                self._held.pop(0)
+        return a
+
+    def clear(self):
+        self._held.clear()
+
+
+_pool = _ArrayPool()
+
+
+def load_gene_calls(calls_json, positions_json=None, want_blanks=False):
     """-> TokenizedReads (and, with positions_json, {read: [(start, end), ...]} as two flat
-    int64 arrays aligned with the tokens: (reads, gene_start, gene_end))."""
+    int64 arrays aligned with the tokens: (reads, gene_start, gene_end)); want_blanks adds whether some gene name of
+    the file held a blank (names are stored with '_' in its place)."""
     h = C.c_void_p()
     check(_ffi.lib.amg_calls_load_json(str(calls_json).encode(), C.byref(h)))
     try:
         n = [C.c_int64(0) for _ in range(5)]
         check(_ffi.lib.amg_calls_counts(h, *[C.byref(x) for x in n]))
         n_reads, n_tokens, n_genes, names_bytes, ids_bytes = [x.value for x in n]
-        tokens = np.empty(n_tokens, np.int32)
+        tokens = _pool.empty(n_tokens, np.int32)
         offs = np.empty(n_reads + 1, np.int64)
         names = np.empty(names_bytes, np.uint8)
         ids = np.empty(ids_bytes, np.uint8)
@@ -348,11 +380,14 @@ def load_gene_calls(calls_json, positions_json=None):
         check(_ffi.lib.amg_calls_get(h, ptr(tokens), ptr(offs), ptr(names), ptr(ids), ptr(hashes)))
         vocab = Vocabulary.from_ranked(_split(names), hashes.reshape(n_genes, 32))
         reads = TokenizedReads(vocab, tokens, offs, _split(ids))
+        blanks = C.c_int32(0)
+        if want_blanks:
+            check(_ffi.lib.amg_calls_has_blanks(h, C.byref(blanks)))
         if positions_json is None:
-            return reads
-        gs, ge = np.empty(n_tokens, np.int64), np.empty(n_tokens, np.int64)
+            return (reads, bool(blanks.value)) if want_blanks else reads
+        gs, ge = _pool.empty(n_tokens, np.int64), _pool.empty(n_tokens, np.int64)
         check(_ffi.lib.amg_calls_load_positions_json(h, str(positions_json).encode(), ptr(gs), ptr(ge)))
-        return reads, gs, ge
+        return (reads, gs, ge, bool(blanks.value)) if want_blanks else (reads, gs, ge)
     finally:
         _ffi.lib.amg_calls_free(h)
 

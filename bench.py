@@ -607,22 +607,28 @@ def run_front_end(w, vocab, toks, offs, k, n_windows):
             "write_positions_s": round(t_wp, 3), "write_positions_GBs": round(sz_p / t_wp / 1e9, 3)})
         lengths = ReadLengths(reads.read_ids, np.full(N, L * 1000 + 100, np.int64))
 
+        from amira_amd.pre_processing import process_pandora_json
+        from amira_amd.result_utils import write_pandora_gene_calls
+        wanted = [vocab.names[i] for i in range(0, vocab.V, max(vocab.V // 40, 1))] + ["not_in_the_reads"]
+
         def whole():
-            r, s_, e_ = load_gene_calls(cj, pj)
-            g, r2, p2 = gu.cleaning_sweep(r, TokenizedPositions(r.read_ids, r.read_offsets, s_, e_), k,
-                                          ReadLengths(r.read_ids, lengths.lengths), 3)
-            write_gene_calls(cj2, r2.vocab, r2.tokens, r2.read_offsets, r2.read_ids)
-            write_gene_positions(pj2, p2.gene_start, p2.gene_end, p2.read_offsets, p2.read_ids)
+            # the reference's own entry points on both sides of the sweep (pre_processing.py:44-63,
+            # result_utils.py:1260-1264): both files in, the genes of interest the reads contain, both files out
+            r, genes, p = process_pandora_json(cj, wanted, pj)
+            g, r2, p2 = gu.cleaning_sweep(r, p, k, ReadLengths(r.read_ids, lengths.lengths), 3)
+            write_pandora_gene_calls(d, p2, r2, cj2, pj2)
             n = g.get_total_number_of_nodes()
             g.close()
-            return n
+            return n, len(genes)
 
         whole()
-        nodes, t_all = timed(whole)
+        (nodes, n_genes), t_all = timed(whole)
         out["json_e2e"] = {"value": n_windows / t_all, "unit": "gene-mers/s", "s_per_step": round(t_all, 3),
-                           "final_nodes": nodes,
-                           "what": "gene calls + positions JSON in -> graph_utils.cleaning_sweep (array-backed API, device "
-                                   "sweep) -> corrected calls + positions JSON out, second of two runs"}
+                           "final_nodes": nodes, "genes_of_interest_in_reads": n_genes,
+                           "what": "process_pandora_json (gene calls + positions JSON in, genes of interest reduced to "
+                                   "those in the reads) -> graph_utils.cleaning_sweep (array-backed API, device sweep) -> "
+                                   "write_pandora_gene_calls (corrected calls + positions JSON out, the two files side by "
+                                   "side), second of two runs"}
     return out
 
 

@@ -317,6 +317,9 @@ int amg_calls_counts(amg_calls* calls, int64_t* n_reads, int64_t* n_tokens, int6
  * (names_bytes), NUL-separated read ids in file order (ids_bytes), 32-byte sha256 per gene */
 int amg_calls_get(amg_calls* calls, int32_t* tokens, int64_t* read_offsets, char* gene_names,
                   char* read_ids, uint8_t* gene_hashes);
+/* *out = 1 when some gene name of the file held a blank (names are stored with '_' in its place, construct_gene.py:54-56:
+ * a caller that compares RAW names, as pre_processing.py:54 does, then has to look at the file itself) */
+int amg_calls_has_blanks(amg_calls* calls, int32_t* out);
 int amg_calls_load_positions_json(amg_calls* calls, const char* path, int64_t* gene_start,
                                   int64_t* gene_end);
 int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t* read_offsets,
@@ -325,7 +328,15 @@ int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t*
 /* {"read": [[start, end], ...]} as json.dumps(gene_position_dict) writes it (result_utils.py:1260-1264, second file) */
 int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
                                    const int64_t* read_offsets, int64_t n_reads, const char* read_ids);
+/* pre_processing.py:44-63 (process_pandora_json keeps the genes of interest the reads contain, in the order the reads
+ * first show them): first_index[i] = index of the first token whose gene has rank wanted_ranks[i] (either strand),
+ * -1 when no token does */
+int amg_calls_first_use(const int32_t* tokens, int64_t n_tokens, int32_t two_v, const int32_t* wanted_ranks,
+                        int64_t n_wanted, int64_t* first_index);
 int amg_calls_free(amg_calls* calls);
+/* the loader and the writers keep their gigabyte-sized work buffers (file bytes, output text) for the next call
+ * instead of faulting fresh pages in every time; this gives them back to the system (released_bytes may be NULL) */
+int amg_calls_trim(int64_t* released_bytes);
 
 /* ---- read-path clustering, block search (host code; construct_graph.py:2725-2749 get_full_paths and
  *      path_finding_utils.py:88-247 process_anchors / get_blocks_from_subtree / generate_contexts /

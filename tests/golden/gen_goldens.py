@@ -26,7 +26,12 @@ from amira.construct_graph import GeneMerGraph  # noqa: E402
 from amira.graph_utils import (choose_kmer_size, get_overall_mean_node_coverages,  # noqa: E402
                                iterative_bubble_popping)
 
+from amira.pre_processing import process_pandora_json  # noqa: E402
+from amira.result_utils import write_pandora_gene_calls  # noqa: E402
+
 REFERENCE = types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
+                                  process_pandora_json=process_pandora_json,
+                                  write_pandora_gene_calls=write_pandora_gene_calls,
                                   choose_kmer_size=choose_kmer_size,
                                   get_overall_mean_node_coverages=get_overall_mean_node_coverages,
                                   iterative_bubble_popping=iterative_bubble_popping)

@@ -431,6 +431,38 @@ def p_read_helpers(impl, name, k):
             "score": [g.score("+a", "+a"), g.score("+a", "-a")]}
 
 
+def p_front_end(impl, name, blanks):
+    """the JSON front end and write-back under the reference's names: process_pandora_json (pre_processing.py:44-63)
+    on a fixture's two files with a list of genes of interest (some present, some not, one twice), then
+    write_pandora_gene_calls (result_utils.py:1260-1264) of what it returned.  blanks: one gene name of the file
+    holds a blank (the reference compares raw names, construct_gene.py:54-56 replaces blanks later)"""
+    import hashlib
+    import json
+    import tempfile
+    calls, pos = fixture(name)
+    calls = {r: list(v) for r, v in calls.items()}
+    names = sorted({g[1:] for v in calls.values() for g in v})
+    wanted = names[::5] + ["not_a_gene", names[0]] + ["absent%d" % i for i in range(3)]
+    if blanks:
+        victim = names[5]
+        calls = {r: [g[0] + victim.replace("_", " ", 1) + " x" if g[1:] == victim else g for g in v] for r, v in calls.items()}
+        wanted = wanted + [victim + " x", victim.replace("_", " ", 1) + " x"]
+    with tempfile.TemporaryDirectory() as d:
+        cj, pj, o1, o2 = (os.path.join(d, n) for n in ("calls.json", "positions.json", "out_calls.json", "out_positions.json"))
+        with open(cj, "w") as fh:
+            fh.write(json.dumps(calls))
+        with open(pj, "w") as fh:
+            fh.write(json.dumps(pos))
+        reads, genes, positions = impl.process_pandora_json(cj, wanted, pj)
+        entry = {"n_reads": len(reads), "genes_of_interest": list(genes),
+                 "reads_digest": D.digest({r: list(reads[r]) for r in reads}),
+                 "positions_digest": D.digest({r: [list(x) for x in positions[r]] for r in positions})}
+        impl.write_pandora_gene_calls(d, positions, reads, o1, o2)
+        entry["out_calls_sha256"] = hashlib.sha256(open(o1, "rb").read()).hexdigest()
+        entry["out_positions_sha256"] = hashlib.sha256(open(o2, "rb").read()).hexdigest()
+    return entry
+
+
 # name -> (procedure, args, slow?)   slow cases are skipped by `gen_goldens.py --quick`
 CASES = {"values": (p_values, (), False)}
 for _n in ("five", "six", "seven", "eight", "four", "three", "nine"):
@@ -485,3 +517,6 @@ CASES["outputs_nine_k5"] = (p_outputs, ("nine", 5), False)
 CASES["mutators"] = (p_mutators, (), False)
 CASES["read_helpers_nine_k3"] = (p_read_helpers, ("nine", 3), False)
 CASES["read_helpers_four_k5"] = (p_read_helpers, ("four", 5), False)
+CASES["front_end_five"] = (p_front_end, ("five", False), False)
+CASES["front_end_nine"] = (p_front_end, ("nine", False), False)
+CASES["front_end_six_blanks"] = (p_front_end, ("six", True), False)

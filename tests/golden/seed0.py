@@ -25,13 +25,18 @@ def _impl(kind):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from amira_oracle import Gene, GeneMer, GeneMerGraph
         from amira_oracle.driver import choose_kmer_size, get_overall_mean_node_coverages
+        from amira_oracle.front_end import process_pandora_json, write_pandora_gene_calls
     else:
         sys.path.insert(0, ROOT)
         from amira_amd import Gene, GeneMer, GeneMerGraph
         from amira_amd.graph_utils import choose_kmer_size, get_overall_mean_node_coverages
+        from amira_amd.pre_processing import process_pandora_json
+        from amira_amd.result_utils import write_pandora_gene_calls
     return types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
                                  choose_kmer_size=choose_kmer_size,
-                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages)
+                                 get_overall_mean_node_coverages=get_overall_mean_node_coverages,
+                                 process_pandora_json=process_pandora_json,
+                                 write_pandora_gene_calls=write_pandora_gene_calls)
 
 
 if __name__ == "__main__":

@@ -136,3 +136,39 @@ def test_writers_replace_a_longer_file(tmp_path, monkeypatch):
     with pytest.raises(_ffi.AmgError, match="cannot write"):
         write_gene_calls(str(tmp_path / "no_such_dir" / "x.json"), reads.vocab, reads.tokens, reads.read_offsets,
                          reads.read_ids)
+
+
+@pytest.mark.parametrize("case", ["front_end_five", "front_end_nine", "front_end_six_blanks"])
+def test_reference_named_front_end_matches_the_reference(case):
+    """process_pandora_json / write_pandora_gene_calls (pre_processing.py:44-63, result_utils.py:1260-1264) of the
+    product against goldens from the real reference: every read kept, the genes of interest the reads contain in the
+    order of the reference's list(set) (PYTHONHASHSEED=0, in a child interpreter), both files byte for byte"""
+    from seed0 import run_case_seed0
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens.json")))
+    assert run_case_seed0("product", case) == gold[case]
+
+
+def test_first_use_order_and_buffer_cache(tmp_path):
+    """the native first-use pass against a plain loop, and a second load / write served from the kept buffers"""
+    from amira_amd import pre_processing as pp
+    from amira_amd.io import load_gene_calls
+    rng = np.random.default_rng(3)
+    genes = ["g%d" % i for i in range(50)]
+    calls = {"r%d" % i: [("+" if rng.random() < 0.5 else "-") + genes[int(j)] for j in rng.integers(5, 50, int(rng.integers(0, 9)))]
+             for i in range(400)}
+    pos = {r: [[10 * i, 10 * i + 5] for i in range(len(v))] for r, v in calls.items()}
+    cj, pj = _write(tmp_path, "c.json", calls), _write(tmp_path, "p.json", pos)
+    wanted = ["g0", "g7", "g49", "g7", "nope", "g20", "g6"]
+    seen = []
+    for r in calls:
+        for g in calls[r]:
+            if g[1:] in wanted and g[1:] not in seen:
+                seen.append(g[1:])
+    reads = load_gene_calls(cj)
+    assert pp._present_in_first_use_order(reads, wanted) == seen
+    for _ in range(2):
+        reads, got, positions = pp.process_pandora_json(cj, wanted, pj)
+        assert set(got) == set(seen) and len(got) == len(seen)
+        assert {r: reads[r] for r in reads} == calls
+        assert {r: [list(x) for x in positions[r]] for r in positions} == pos
+    assert pp.trim_buffers() >= 0

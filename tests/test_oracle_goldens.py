@@ -15,11 +15,14 @@ import procedures as P
 from seed0 import run_case_seed0
 from amira_oracle import Gene, GeneMer, GeneMerGraph
 from amira_oracle.driver import choose_kmer_size, get_overall_mean_node_coverages, iterative_bubble_popping
+from amira_oracle.front_end import process_pandora_json, write_pandora_gene_calls
 
 ORACLE = types.SimpleNamespace(GeneMerGraph=GeneMerGraph, Gene=Gene, GeneMer=GeneMer,
                                choose_kmer_size=choose_kmer_size,
                                get_overall_mean_node_coverages=get_overall_mean_node_coverages,
-                               iterative_bubble_popping=iterative_bubble_popping)
+                               iterative_bubble_popping=iterative_bubble_popping,
+                               process_pandora_json=process_pandora_json,
+                               write_pandora_gene_calls=write_pandora_gene_calls)
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goldens.json")))
 
 # every case runs by default (fixture_one_k3 = BASELINE config 1: 13 s, sweep_s20250908: 23 s, planted_dense_k5: 4 s)
@@ -39,10 +42,11 @@ def test_oracle_matches_reference(name):
         pytest.skip("set AMG_SLOW=1 to run the largest oracle case (~200 s)")
     proc, args, _ = P.CASES[name]
     assert name in GOLD, "golden missing: regenerate with tests/golden/gen_goldens.py"
-    if proc in (P.p_planted, P.p_cluster_fixture) and os.environ.get("PYTHONHASHSEED") != "0":
+    if proc in (P.p_planted, P.p_cluster_fixture, P.p_front_end) and os.environ.get("PYTHONHASHSEED") != "0":
         # the reference's clustering leaks set-of-str iteration order into its result
-        # (construct_graph.py:1497-1504, :2769-2777); goldens were taken at
-        # PYTHONHASHSEED=0, so these cases re-run in a child with that seed
+        # (construct_graph.py:1497-1504, :2769-2777), and so does process_pandora_json's list(set)
+        # (pre_processing.py:61); goldens were taken at PYTHONHASHSEED=0, so these cases re-run in a child
+        # with that seed
         got = run_case_seed0("oracle", name)
     else:
         got = json.loads(json.dumps(proc(ORACLE, *args)))
