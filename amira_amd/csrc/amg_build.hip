@@ -231,17 +231,6 @@ __global__ void k_gather_pairs(const unsigned int* __restrict__ slot_sorted, lon
   pcnt[i] = s->count;
 }
 
-// width of pair i in directed edges: self-loop 1, otherwise 2
-__global__ void k_pair_width(const unsigned long long* __restrict__ pkey, long long n_pairs,
-                             unsigned int* __restrict__ width) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pairs) return;
-  unsigned long long key = pkey[i];
-  unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
-  unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
-  width[i] = lo == hi ? 1u : 2u;
-}
-
 __global__ void k_emit_edges(const unsigned long long* __restrict__ pkey,
                              const unsigned int* __restrict__ pcnt,
                              const unsigned long long* __restrict__ pfirst, long long n_pairs,
@@ -834,9 +823,7 @@ int bs_finish_from_pairs(amg_ctx* c) {
   hipStream_t st = c->stream;
   const long long P = c->n_pairs, R = c->n_reads;
   stage_begin(c, "edge_emit");
-  AMGCHK(c->s3.ensure((size_t)(P + 2) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(P + 2) * sizeof(long long)));
-  unsigned int* width = c->s3.as<unsigned int>();
   long long* base = c->s5.as<long long>();
   // at most two directed edges per class: the arrays are sized before the exact count is known
   const long long cap = 2 * P;
@@ -849,15 +836,13 @@ int bs_finish_from_pairs(amg_ctx* c) {
   AMGCHK(c->read_fix.ensure((size_t)R + 1));
   {
     ClearList cl;
-    if (P > 0) cl.add(width + P, sizeof(unsigned int));
     cl.add(c->read_fix.p, (size_t)R + 1);
     AMGCHK(clear_many(c, cl));
   }
   long long total = 0;
   if (P > 0) {
-    hipLaunchKernelGGL(k_pair_width, dim3(blocks_for(P, 256)), dim3(256), 0, st,
-                       c->pair_key.as<unsigned long long>(), P, width);
-    AMGCHK(prim_exscan_u32_to_i64(c, width, base, (size_t)P + 1));
+    // a class is one directed edge (self-loop) or two: the widths are made by the scan that sums them
+    AMGCHK(prim_exscan_pair_width(c, c->pair_key.as<unsigned long long>(), base, (size_t)P));
     hipLaunchKernelGGL(k_emit_edges, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                        c->pair_key.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(),
                        c->pair_first.as<unsigned long long>(), P, base, c->edge_src.as<int>(),

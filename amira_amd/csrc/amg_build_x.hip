@@ -486,19 +486,6 @@ __global__ void k_x_rank_setflags(const unsigned int* __restrict__ first2, long 
   flags[(~fi) >> shift] = 1;
 }
 
-__global__ void k_x_rank_words(const unsigned char* __restrict__ flags, long long n_words,
-                               unsigned int* __restrict__ bits, unsigned int* __restrict__ cnt) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_words) return;
-  const uint4* p = reinterpret_cast<const uint4*>(flags + 32 * i);
-  const uint4 a = p[0], b = p[1];
-  auto nib = [](unsigned int x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };
-  const unsigned int w = nib(a.x) | (nib(a.y) << 4) | (nib(a.z) << 8) | (nib(a.w) << 12) | (nib(b.x) << 16) |
-                         (nib(b.y) << 20) | (nib(b.z) << 24) | (nib(b.w) << 28);
-  bits[i] = w;
-  cnt[i] = (unsigned int)__popc(w);
-}
-
 __device__ __forceinline__ long long x_rank_of(unsigned int t, const unsigned int* __restrict__ bits,
                                                const long long* __restrict__ prefix) {
   const unsigned int w = bits[t >> 5];
@@ -956,8 +943,7 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   hipStream_t st = c->stream;
   const long long words = (c->n_tokens >> 5) + 2;
   AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
-  AMGCHK(c->s2.ensure((size_t)(words + 1) * sizeof(unsigned int)));
-  AMGCHK(c->s5.ensure((size_t)(words + 1) * sizeof(long long)));
+  AMGCHK(c->s5.ensure((size_t)(words + 2) * sizeof(long long)));
   AMGCHK(c->s0.ensure((size_t)words * 32 + 64));
   if (c->rank_flags_clean != words) {  // (else: zeroed behind the table pass's read-back, read_status)
     ClearList cl;
@@ -967,9 +953,8 @@ static int x_rank_bitmap(amg_ctx* c, const unsigned int* first2, long long n, in
   c->rank_flags_clean = 0;
   hipLaunchKernelGGL(k_x_rank_setflags, dim3(blocks_for(n, 256)), dim3(256), 0, st, first2, n, shift,
                      c->s0.as<unsigned char>());
-  hipLaunchKernelGGL(k_x_rank_words, dim3(blocks_for(words, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
-                     words, c->s1.as<unsigned int>(), c->s2.as<unsigned int>());
-  return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
+  // the flag bytes are folded into the bitmap words by the scan that counts them (one launch, no count array)
+  return prim_exscan_flag_words(c, c->s0.as<unsigned char>(), c->s1.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
 // the status words after a table pass; ctrs != nullptr: the pass took its claims from the X_CTRS counters there —

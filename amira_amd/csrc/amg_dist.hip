@@ -576,24 +576,6 @@ __global__ void k_d_setflags(const unsigned char* __restrict__ recs, long long n
     atomicOr(bits + (t >> 5), 1u << (t & 31));
 }
 
-__global__ void k_d_fold_words(const unsigned char* __restrict__ flags, long long n_words,
-                               unsigned int* __restrict__ bits, unsigned int* __restrict__ cnt) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_words) return;
-  unsigned int w;
-  if (flags) {
-    const uint4* p = reinterpret_cast<const uint4*>(flags + 32 * i);
-    const uint4 a = p[0], b = p[1];
-    auto nib = [](unsigned int x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };
-    w = nib(a.x) | (nib(a.y) << 4) | (nib(a.z) << 8) | (nib(a.w) << 12) | (nib(b.x) << 16) | (nib(b.y) << 20) |
-        (nib(b.z) << 24) | (nib(b.w) << 28);
-    bits[i] = w;
-  } else {
-    w = bits[i];
-  }
-  cnt[i] = (unsigned int)__popc(w);
-}
-
 __device__ __forceinline__ long long d_rank_of(unsigned long long t, const unsigned int* __restrict__ bits,
                                                const long long* __restrict__ prefix) {
   const unsigned int w = bits[t >> 5];
@@ -607,7 +589,6 @@ static int d_rank_bitmap(amg_ctx* c, const unsigned char* recs, long long n_slot
   hipStream_t st = c->stream;
   const long long words = ((c->tok_total > 0 ? c->tok_total : 1) >> 5) + 2;
   AMGCHK(c->s1.ensure((size_t)words * sizeof(unsigned int)));
-  AMGCHK(c->s2.ensure((size_t)(words + 2) * sizeof(unsigned int)));
   AMGCHK(c->s5.ensure((size_t)(words + 2) * sizeof(long long)));
   const bool bytes = n_total * 64 > c->tok_total;
   unsigned char* flags = nullptr;
@@ -619,14 +600,13 @@ static int d_rank_bitmap(amg_ctx* c, const unsigned char* recs, long long n_slot
   } else {
     cl.add(c->s1.p, (size_t)words * sizeof(unsigned int));
   }
-  cl.add(c->s2.as<unsigned int>() + words, sizeof(unsigned int));
   AMGCHK(clear_many(c, cl));
   if (n_slots > 0)
     hipLaunchKernelGGL(k_d_setflags, dim3(nblk(n_slots, 256)), dim3(256), 0, st, recs, n_slots, rec_bytes, shift,
                        flags, c->s1.as<unsigned int>());
-  hipLaunchKernelGGL(k_d_fold_words, dim3(nblk(words, 256)), dim3(256), 0, st, flags, words, c->s1.as<unsigned int>(),
-                     c->s2.as<unsigned int>());
-  return prim_exscan_u32_to_i64(c, c->s2.as<unsigned int>(), c->s5.as<long long>(), (size_t)words + 1);
+  // the scan folds the flag bytes into the bitmap words (or takes the words as they are) and counts them in one launch
+  if (flags) return prim_exscan_flag_words(c, flags, c->s1.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
+  return prim_exscan_bits_popc(c, c->s1.as<unsigned int>(), c->s5.as<long long>(), (size_t)words);
 }
 
 // node arrays in global id order, straight from the gathered records

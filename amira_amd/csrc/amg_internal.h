@@ -259,6 +259,8 @@ struct amg_ctx {
   DevBuf gm_list;      // int32 [questions] occupied slots
   DevBuf gm_q;         // int32 [gapped reads x GF_MAXGAP] question slot per None run
   DevBuf gm_pool;      // int32 path records
+  DevBuf gm_gene;      // int32 per pool entry of a one-answer question: last gene of the path node (k_corr_gapped_lean)
+  DevBuf gm_fail;      // int32 [gapped reads] the reads k_corr_gapped_lean left to k_corr_gapped_fast
   DevBuf gm_ctr;       // uint64[4]         {questions listed, pool ints used}
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t
@@ -278,6 +280,9 @@ int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
                       const unsigned int* vin, unsigned int* vout, size_t n, int end_bit);
 int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n);
 int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n);
+int prim_exscan_flag_words(amg_ctx* c, const unsigned char* flags, unsigned int* bits, long long* out, size_t n_words);
+int prim_exscan_bits_popc(amg_ctx* c, const unsigned int* bits, long long* out, size_t n_words);
+int prim_exscan_pair_width(amg_ctx* c, const unsigned long long* pkey, long long* out, size_t n_pairs);
 
 // one launch that zeroes up to 8 device ranges (a hipMemsetAsync is a kernel launch of its own: ~5 us
 // each, and a build issued ~40 of them); sizes are rounded up to 4 bytes — pad the allocations

@@ -1279,7 +1279,8 @@ __global__ __launch_bounds__(256) void k_gap_queries(const GapRec* __restrict__ 
 __global__ __launch_bounds__(64, 8) void k_gap_dfs(GView g, const int* __restrict__ qlist, long long n_queries,
                                                     const unsigned long long* __restrict__ qtab,
                                                     unsigned long long* pool_used, unsigned long long pool_cap,
-                                                    int* __restrict__ qpool, int4* __restrict__ qres) {
+                                                    int* __restrict__ qpool, int4* __restrict__ qres,
+                                                    int* __restrict__ qgene) {
   __shared__ int s_pool[GF_POOL];
   __shared__ int s_used;
   const long long qi = blockIdx.x;
@@ -1306,31 +1307,160 @@ __global__ __launch_bounds__(64, 8) void k_gap_dfs(GView g, const int* __restric
     if (off + (unsigned long long)used <= pool_cap) {
       for (int i = lane; i < used; i += 64) qpool[off + i] = s_pool[i];
       res = make_int4((int)off, used, np, 0);
+      // a question with ONE answer (nearly all of them) also keeps the last gene of every node of its path, taken in the
+      // path's direction (get_gene_mer_genes / get_reverse_gene_mer_genes :588-598): what k_corr_gapped_lean writes out
+      if (np == 1 && used <= GM_INLINE) {
+        const int len = s_pool[1];
+        if (lane < len) qgene[off + 2 + lane] = oriented_tok(g, s_pool[2 + lane], s_pool[2 + len + lane], g.k - 1);
+      }
     }
   }
   if (lane == 0) qres[slot] = res;
+}
+
+// ---- re-threading, the common case: SIXTEEN LANES per read.
+// k_corr_gapped_fast gives a read a whole wave and spends ~900 instructions on it, most of them with a handful of
+// useful lanes, and its waves wait two thirds of their time on a chain of five dependent loads (rocprofv3 counters,
+// profiles/r5_*): the kernel is bound by instruction issue and by that chain, not by bytes.  Nearly every read asks
+// questions the path memo answered with exactly ONE path (after filter_graph the error bubbles are gone: between two
+// terminals of a read there is the genome's path and nothing else).  Then nothing has to be chosen — no cartesian
+// product, no shared-gene count, no mean coverage — and the corrected read is the original one with, for every None
+// run (ps, pe), the genes k + ps .. k + pe - 1 replaced by the last genes of the path's nodes 1 .. len - 1:
+//   * a live window w of the read spells the read's own genes w .. w + k - 1, so every gene that comes from a live
+//     window is a token of the read itself (no node-token gather);
+//   * the path's first node is window ps; its last node is window pe's NODE in whatever direction the path arrives
+//     (new_find_paths_between_nodes :2292-2342 accepts any), so its gene comes from the memo like the interior ones —
+//     unless the next run starts at pe: then the later replacement overwrites the shared terminal (insert_elements
+//     :1166-1203) and the gene is the read's own again.
+// A group of 16 lanes takes one read: lane q owns None run q (k_gap_queries entered at most 16 per read), the group's
+// prefix sums run over DPP row shifts (a DPP row IS 16 lanes), and the output genes are written 16 at a time.  Four
+// reads per wave share every instruction and keep four chains of loads in flight.  A read that does not qualify (no
+// memo entry, a question with no or several answers, an answer beyond the inline stretch, a path of one node) is
+// appended to a list that k_corr_gapped_fast then walks: same results by construction, checked against the oracle
+// through the whole sweep at full size and by the fuzzers.
+#define GL_GROUP 16
+#define GL_THREADS 256
+__device__ __forceinline__ int row_scan_incl(int v) {  // inclusive prefix sum inside a DPP row of 16 lanes
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  return v;
+}
+
+__global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, const int* __restrict__ qgene,
+                                                                  int* __restrict__ fail_list,
+                                                                  unsigned long long* __restrict__ n_fail) {
+  // per read and run: {first output index of the run's genes, their number, output - token shift behind them, where
+  // the path's genes are in qgene}
+  __shared__ int4 s_run[GL_THREADS / GL_GROUP][GL_GROUP];
+  const CorrArgs& a = A.a;
+  const int k = A.g.k;
+  const int lane = threadIdx.x & 63, l16 = threadIdx.x & (GL_GROUP - 1), grp = threadIdx.x / GL_GROUP;
+  const int sh = lane & ~(GL_GROUP - 1);  // first lane of this group inside its wave
+  const long long gi = (long long)blockIdx.x * (GL_THREADS / GL_GROUP) + grp;
+  const bool have = gi < A.n_gapped;
+  GapRec rec;
+  rec.r = 0; rec.L0 = 0; rec.start = 0; rec.end = -1; rec.t0 = 0; rec.dst = 0; rec.mask = 0ull; rec.pad = 0;
+  if (have) rec = A.rec[gi];
+  const unsigned long long lv = rec.mask;
+  const int nwin = rec.L0 - k + 1;
+  bool ok = have && nwin <= 64 && lv != 0ull;
+  // the read's None runs as k_gap_queries numbered them: run q ends at the q-th window that is not live while the
+  // next one is (identify_path_terminals :1375-1386)
+  const int first = rec.start, last = rec.end;
+  const unsigned long long inside =
+      (last >= 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << (first & 63)) - 1ull);
+  unsigned long long ends = ok ? (~lv & inside & (lv >> 1)) : 0ull;
+  const int n_gaps = __popcll(ends);
+  ok = ok && n_gaps >= 1 && n_gaps <= GF_MAXGAP;
+  int slot = -1;
+  if (ok && l16 < n_gaps) slot = A.gq[gi * GF_MAXGAP + l16];
+  // (k_gap_queries left gq[0] = -1 on a read it did not enter)
+  const bool mine = ok && l16 < n_gaps;
+  int4 res = make_int4(0, -1, 0, 0);
+  if (mine && slot >= 0) res = A.qres[slot];
+  int ps = 0, pe = 0;
+  if (mine) {
+    unsigned long long e = ends;
+    for (int j = 0; j < l16; ++j) e &= e - 1ull;
+    const int i = __ffsll((long long)e) - 1;
+    ps = 63 - __clzll((long long)(lv & ((1ull << i) - 1ull)));
+    pe = i + 1;
+  }
+  const int len = (mine && res.y >= 4) ? (res.y - 2) >> 1 : 0;  // one record [run, len, nodes, dirs]
+  const bool good = !mine || (slot >= 0 && res.z == 1 && res.y >= 6 && res.y <= GM_INLINE && len >= 2);
+  // every run of the read has to qualify: the group's 16 bits of the wave's ballot
+  const unsigned int bad16 = (unsigned int)((__ballot(!good) >> sh) & 0xffffull);
+  ok = ok && bad16 == 0u;
+  // does the next run start where this one ends?  (its ps from the neighbouring lane: row_shl:1)
+  const int ps_next = __builtin_amdgcn_update_dpp(-1, ps, 0x101, 0xf, 0xf, false);
+  const int shared = (mine && l16 + 1 < n_gaps && ps_next == pe) ? 1 : 0;
+  const int c = mine ? len - 1 - shared : 0;            // genes the run brings
+  const int rep = mine ? pe - ps - shared : 0;          // genes of the read they replace: k + ps .. k + pe - 1 - shared
+  const int incl = row_scan_incl(c - rep);
+  const int d_before = incl - (c - rep);
+  if (mine) s_run[grp][l16] = make_int4(ps + k - first + d_before, c, incl, res.x + 3);  // (path node 1 sits at res.x + 2 + 1)
+  const int total_delta = __shfl(incl, sh + (n_gaps > 0 ? n_gaps - 1 : 0), 64);
+  __syncthreads();
+  const int ng = ok ? (last + k - first) + total_delta : 0;
+  if (ok) {
+    for (int o = l16; o < ng; o += GL_GROUP) {
+      int tok_shift = 0, src = -1;
+      for (int q = 0; q < n_gaps; ++q) {
+        const int4 rq = s_run[grp][q];
+        if (o >= rq.x) {
+          src = o < rq.x + rq.y ? rq.w + (o - rq.x) : -1;
+          tok_shift = rq.z;
+        }
+      }
+      const int v = src >= 0 ? qgene[src] : a.tokens[rec.t0 + first + o - tok_shift];
+      a.tmp_tok[rec.dst + o] = v;
+    }
+    if (l16 == 0) a.new_len[rec.r] = (unsigned int)ng;
+  }
+  // the reads left to the wave-per-read kernel: one atomicAdd per wave
+  const bool fail = have && !ok && l16 == 0;
+  const unsigned long long fm = __ballot(fail);
+  if (fm) {
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)fm) - 1) base = atomicAdd(n_fail, (unsigned long long)__popcll(fm));
+    base = (unsigned long long)bcast_i64((long long)base, __ffsll((long long)fm) - 1);
+    if (fail) fail_list[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)gi;
+  }
 }
 
 // GF_WPB reads (waves) per workgroup.  The LDS of a workgroup is held until its LAST wave is done
 // and reads differ a lot in work (runs, paths): with four waves per workgroup the kernel ran at
 // half its occupancy limit waiting for stragglers (2.05 ms; 1.83 ms with two, 1.80 ms with one).
 #define GF_WPB 1
-__global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) {
-  __shared__ int s_node[GF_WPB][GF_MAXW];
-  __shared__ signed char s_dir[GF_WPB][GF_MAXW];
-  __shared__ int s_tok[GF_WPB][GF_MAXW + AMG_MAX_K];
-  __shared__ int s_gap[GF_WPB][GF_MAXGAP * 3];  // ps, pe, n_paths
-  __shared__ int s_pool[GF_WPB][GF_POOL];
-  __shared__ int s_used[GF_WPB];
-  __shared__ int s_cnode[GF_WPB][GF_CAND];
-  __shared__ signed char s_cdir[GF_WPB][GF_CAND];
-  __shared__ int s_gene[GF_WPB][GF_CAND + AMG_MAX_K];
-  __shared__ int s_best[GF_WPB][GF_CAND + AMG_MAX_K];
+struct GfLds {  // one read's staging
+  int node[GF_MAXW];
+  signed char dir[GF_MAXW];
+  int tok[GF_MAXW + AMG_MAX_K];
+  int gap[GF_MAXGAP * 3];  // ps, pe, n_paths
+  int pool[GF_POOL];
+  int used;
+  int cnode[GF_CAND];
+  signed char cdir[GF_CAND];
+  int gene[GF_CAND + AMG_MAX_K];
+  int best[GF_CAND + AMG_MAX_K];
+};
+
+__device__ __forceinline__ void gapped_fast_read(const GapArgs& A, long long gi, int lane, GfLds& S) {
   const CorrArgs& a = A.a;
   const GView& g = A.g;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long gi = (long long)blockIdx.x * GF_WPB + wv;
-  if (gi >= A.n_gapped) return;
+  const int wv = 0;
+  int (*s_node)[GF_MAXW] = &S.node;
+  signed char (*s_dir)[GF_MAXW] = &S.dir;
+  int (*s_tok)[GF_MAXW + AMG_MAX_K] = &S.tok;
+  int (*s_gap)[GF_MAXGAP * 3] = &S.gap;
+  int (*s_pool)[GF_POOL] = &S.pool;
+  int* s_used = &S.used;
+  int (*s_cnode)[GF_CAND] = &S.cnode;
+  signed char (*s_cdir)[GF_CAND] = &S.cdir;
+  int (*s_gene)[GF_CAND + AMG_MAX_K] = &S.gene;
+  int (*s_best)[GF_CAND + AMG_MAX_K] = &S.best;
   const GapRec rec = A.rec[gi];
   const long long r = rec.r, t0 = rec.t0, dst = rec.dst;
   const int L0 = rec.L0;
@@ -1556,6 +1686,19 @@ __global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A) 
   for (int q = lane; q < best_ng; q += 64) a.tmp_tok[dst + q] = BEST[q];
   if (lane == 0) a.new_len[r] = (unsigned int)best_ng;
 }
+
+// list == nullptr: every re-threaded read; else the *n_list reads k_corr_gapped_lean left (a count the host never sees:
+// the workgroups walk the list with a grid stride)
+__global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A, const int* __restrict__ list,
+                                                                    const unsigned long long* __restrict__ n_list) {
+  __shared__ GfLds s_lds;
+  const long long n = list ? (long long)*n_list : A.n_gapped;
+  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+    gapped_fast_read(A, list ? (long long)list[i] : i, (int)threadIdx.x, s_lds);
+    wave_sync();  // the next read reuses the staging
+  }
+}
+
 
 // ---- positions for gapped reads: one wave per read (general path: any N, M)
 #define NW_LDS_N 1024       // rows kept in LDS (rolling anti-diagonals, op list)
@@ -2250,10 +2393,11 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
         const unsigned long long qcap = (unsigned long long)n_queries * (GM_INLINE + 32ull) + 4096ull;
         if (qcap <= 0x7fffffffull) {  // (pool offsets are ints)
         AMGCHK(c->gm_pool.ensure((size_t)qcap * sizeof(int)));
+        AMGCHK(c->gm_gene.ensure((size_t)qcap * sizeof(int)));
         if (n_queries > 0)
           hipLaunchKernelGGL(k_gap_dfs, dim3((unsigned int)n_queries), dim3(64), 0, st, make_view(c), c->gm_list.as<int>(),
                              n_queries, c->gm_tab.as<unsigned long long>(), c->gm_ctr.as<unsigned long long>() + 1, qcap,
-                             c->gm_pool.as<int>(), c->gm_res.as<int4>());
+                             c->gm_pool.as<int>(), c->gm_res.as<int4>(), c->gm_gene.as<int>());
         gq = c->gm_q.as<int>();
         }
       }
@@ -2298,8 +2442,20 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
         const bool use_fast = !(nf && nf[0] == '1');
         gcl.add(need_slow, ((size_t)n_gapped + 4) & ~(size_t)3, use_fast ? 0u : 0x01010101u);  // (the buffer has 64 spare bytes)
         AMGCHK(clear_many(c, gcl));
-        if (use_fast)
-          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, GF_WPB)), dim3(64 * GF_WPB), 0, st, G);
+        const char* nl = getenv("AMG_NO_LEAN_GAPPED");  // A/B + test switch: every read through the wave-per-read kernel
+        if (use_fast && gq && !(nl && nl[0] == '1')) {
+          // sixteen lanes per read where every question has one answer; the others are listed for the wave-per-read
+          // kernel, which walks the list with a grid stride (its length stays on the device: gm_ctr[2])
+          AMGCHK(c->gm_fail.ensure((size_t)(n_gapped + 1) * sizeof(int)));
+          unsigned long long* n_fail = c->gm_ctr.as<unsigned long long>() + 2;  // (zeroed with the memo's counters)
+          hipLaunchKernelGGL(k_corr_gapped_lean, dim3(nblk(n_gapped, GL_THREADS / GL_GROUP)), dim3(GL_THREADS), 0, st, G,
+                             c->gm_gene.as<int>(), c->gm_fail.as<int>(), n_fail);
+          const unsigned int walkers = (unsigned int)(n_gapped < 16384 ? n_gapped : 16384);
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(walkers), dim3(64 * GF_WPB), 0, st, G, c->gm_fail.as<int>(), n_fail);
+        } else if (use_fast) {
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3((unsigned int)n_gapped), dim3(64 * GF_WPB), 0, st, G, (const int*)nullptr,
+                             (const unsigned long long*)nullptr);
+        }
       } else {
         AMGCHK(clear_many(c, gcl));  // (the status words alone)
       }

@@ -23,8 +23,55 @@ __device__ __forceinline__ unsigned long long sc_word(unsigned int state, unsign
   return ((unsigned long long)state << 62) | ((unsigned long long)(epoch & 0x3fffu) << 48) | (v & SC_VAL_MASK);
 }
 
-template <class In>
-__global__ __launch_bounds__(SC_THREADS) void k_exscan(const In* __restrict__ in, long long* __restrict__ out,
+// What is scanned is what a LOADER makes of element i — an array entry, or something computed on the way that would
+// otherwise be a kernel of its own writing an array only the scan reads (the passes launch ~200 kernels per cleaning
+// sweep and every launch costs ~5 us however little it does):
+//   LoadArr<T>      in[i]
+//   LoadFlagWords   the ranking bitmaps of amg_build_x.hip / amg_dist.hip: 32 flag bytes folded into bitmap word i
+//                   (stored as a side effect), the value scanned is its popcount
+//   LoadBitsPopc    popcount of bitmap word i
+//   LoadPairWidth   directed edges of edge class i: a self-loop has one, every other class two
+template <class T>
+struct LoadArr {
+  const T* in;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const { return (unsigned long long)in[i]; }
+};
+struct LoadFlagWords {
+  const unsigned char* flags;
+  unsigned int* bits;
+  long long n_words;  // elements from here on count 0 (the scan's terminator: its prefix is the number of set bits)
+  __device__ __forceinline__ unsigned long long operator()(long long i) const {
+    if (i >= n_words) return 0ull;
+    const uint4* p = reinterpret_cast<const uint4*>(flags + 32 * i);
+    const uint4 a = p[0], b = p[1];
+    auto nib = [](unsigned int x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };
+    const unsigned int w = nib(a.x) | (nib(a.y) << 4) | (nib(a.z) << 8) | (nib(a.w) << 12) | (nib(b.x) << 16) |
+                           (nib(b.y) << 20) | (nib(b.z) << 24) | (nib(b.w) << 28);
+    bits[i] = w;
+    return (unsigned long long)__popc(w);
+  }
+};
+struct LoadBitsPopc {
+  const unsigned int* bits;
+  long long n_words;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const {
+    return i < n_words ? (unsigned long long)__popc(bits[i]) : 0ull;
+  }
+};
+struct LoadPairWidth {
+  const unsigned long long* pkey;
+  long long n_pairs;  // elements from here on count 0 (the scan's terminator)
+  __device__ __forceinline__ unsigned long long operator()(long long i) const {
+    if (i >= n_pairs) return 0ull;
+    const unsigned long long key = pkey[i];
+    const unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
+    const unsigned int hi = (unsigned int)(key & 0xffffffffull) - 1u;
+    return lo == hi ? 1ull : 2ull;
+  }
+};
+
+template <class Load>
+__global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __restrict__ out,
                                                         long long n, unsigned long long* counter,
                                                         unsigned long long ticket_base, unsigned long long* status,
                                                         unsigned int epoch) {
@@ -41,7 +88,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_exscan(const In* __restrict__ in
 #pragma unroll
   for (int r = 0; r < SC_ROWS; ++r) {
     const long long i = w0 + r * 64 + lane;
-    x[r] = i < n ? (unsigned long long)in[i] : 0ull;
+    x[r] = i < n ? load(i) : 0ull;
   }
   unsigned long long row_off = 0;
 #pragma unroll
@@ -107,8 +154,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_exscan(const In* __restrict__ in
   }
 }
 
-template <class In>
-static int exscan(amg_ctx* c, const In* in, long long* out, size_t n) {
+template <class Load>
+static int exscan(amg_ctx* c, Load load, long long* out, size_t n) {
   if (n == 0) return AMG_OK;
   const unsigned long long tiles = (n + SC_TILE - 1) / SC_TILE;
   // [0] the ticket counter, [8 ...] one status word per tile
@@ -126,16 +173,30 @@ static int exscan(amg_ctx* c, const In* in, long long* out, size_t n) {
   }
   const unsigned int epoch = ++c->scan_epoch;
   unsigned long long* st = c->scan_state.as<unsigned long long>();
-  hipLaunchKernelGGL(k_exscan<In>, dim3((unsigned int)tiles), dim3(SC_THREADS), 0, c->stream, in, out, (long long)n, st,
+  hipLaunchKernelGGL(k_exscan<Load>, dim3((unsigned int)tiles), dim3(SC_THREADS), 0, c->stream, load, out, (long long)n, st,
                      c->scan_tickets, st + 8, epoch);
   c->scan_tickets += tiles;
   return AMG_OK;
 }
 
 int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n) {
-  return exscan<unsigned int>(c, in, out, n);
+  return exscan(c, LoadArr<unsigned int>{in}, out, n);
 }
 
 int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n) {
-  return exscan<long long>(c, in, out, n);
+  return exscan(c, LoadArr<long long>{in}, out, n);
+}
+
+// flags[32 n_words] -> bits[n_words]; out[i] = set bits before word i for i <= n_words (out[n_words] = number of set bits)
+int prim_exscan_flag_words(amg_ctx* c, const unsigned char* flags, unsigned int* bits, long long* out, size_t n_words) {
+  return exscan(c, LoadFlagWords{flags, bits, (long long)n_words}, out, n_words + 1);
+}
+
+int prim_exscan_bits_popc(amg_ctx* c, const unsigned int* bits, long long* out, size_t n_words) {
+  return exscan(c, LoadBitsPopc{bits, (long long)n_words}, out, n_words + 1);
+}
+
+// out[i] = first directed edge of edge class i, out[n_pairs] = number of directed edges
+int prim_exscan_pair_width(amg_ctx* c, const unsigned long long* pkey, long long* out, size_t n_pairs) {
+  return exscan(c, LoadPairWidth{pkey, (long long)n_pairs}, out, n_pairs + 1);
 }

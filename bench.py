@@ -427,8 +427,7 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
                         "tok_node": pinned(cap_t, torch.int32), "tok_dir": pinned(cap_t, torch.int8),
                         "c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
-                        "c_pos_src": pinned(cap_r, torch.int64),
-                        "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32)}
+                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)}
 
         def step(self):
             eng = self.eng
@@ -451,7 +450,7 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
             eng.build(k)
             eng.remove_short_linear_paths(k)
             n_out = eng.correct_reads()
-            eng.corrected32(*n_out, buf=self.buf)
+            eng.corrected(*n_out, True, buf=self.buf)
             eng.adopt_corrected()
             eng.build(k)
             eng.nodes(self.buf)
@@ -826,7 +825,7 @@ def main():
             stage_ms[name][0] += ms
             stage_ms[name][1] += 1
 
-    def sweep_after_first_build(record, readback=None, moved=None):
+    def sweep_after_first_build(record, readback=None, moved=None, full=True):
         if not (merge or args.fused_filter):
             eng.filter(3, 1)
             if record:
@@ -846,9 +845,15 @@ def main():
         n_out = eng.correct_reads()
         if record:
             tally()
-        if readback is not None:   # the corrected calls + positions the reference hands on (graph_utils.py:165):
-            # 32-bit positions, and only those the correction PRODUCED — an untouched or trimmed read's positions are a
-            # slice of the arrays the caller already has (amg_get_corrected32)
+        if readback is not None and full:
+            # the corrected calls + positions the reference hands on (graph_utils.py:165) as the drop-in hands them on:
+            # contiguous corrected position arrays, every read's (Engine.corrected = what amira_amd.io.DeviceCorrected
+            # fetches for GeneMerGraph.correct_reads' mappings)
+            eng.corrected(*n_out, True, buf=readback)
+        elif readback is not None:
+            # the boundary's lighter form: 32-bit positions, and only those the correction PRODUCED — an untouched or
+            # trimmed read's positions are a slice of the arrays the caller already has, named by offset
+            # (amg_get_corrected32); putting the two together is left to the caller
             got = eng.corrected32(*n_out, buf=readback)
             if moved is not None:
                 moved["new_positions"] = len(got["new_start"])
@@ -947,12 +952,13 @@ def main():
             buf.update({"c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
                         "c_pos_src": pinned(cap_r, torch.int64),
-                        "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32)})
+                        "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32),
+                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)})
         side = torch.cuda.Stream(device=dev)
         moved = {}
         ev_reads, ev_pos = torch.cuda.Event(), torch.cuda.Event()
 
-        def e2e_step():
+        def e2e_step(full=True):
             with torch.cuda.stream(side):
                 d_toks.copy_(h_toks, non_blocking=True)
                 d_offs.copy_(h_offs, non_blocking=True)
@@ -968,31 +974,43 @@ def main():
             if w["sweep"]:
                 ev_pos.synchronize()
                 eng.set_positions32_device(d_gs32.data_ptr(), d_ge32.data_ptr(), d_rl.data_ptr())
-                sweep_after_first_build(False, readback=buf, moved=moved)
+                sweep_after_first_build(False, readback=buf, moved=moved, full=full)
             eng.nodes(buf)
             eng.edges(buf)
             eng.read_nodes(buf)
 
-        e2e_step()
-        torch.cuda.synchronize()
-        n_e2e = max(2, min(args.steps, 5))
-        t0 = time.perf_counter()
-        for _ in range(n_e2e):
-            e2e_step()
-        torch.cuda.synchronize()
-        de = (time.perf_counter() - t0) / n_e2e
+        def timed_e2e(full):
+            e2e_step(full)
+            torch.cuda.synchronize()
+            n = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                e2e_step(full)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n, n
+
+        de, n_e2e = timed_e2e(True)
         h2d = T * 4 + (N + 1) * 8 + (T * 8 + N * 8 if w["sweep"] else 0)
         c_fin = eng.counts()
-        d2h = (c_fin["n_nodes"] * (4 * k + 4 + 8 + 1 + 4 + 1) + c_fin["n_edges"] * 14 + c_fin["n_tokens"] * 5
-               + (c_fin["n_tokens"] * 4 + c_fin["n_reads"] * 21 + moved.get("new_positions", 0) * 8 if w["sweep"] else 0))
+        d2h_graph = c_fin["n_nodes"] * (4 * k + 4 + 8 + 1 + 4 + 1) + c_fin["n_edges"] * 14 + c_fin["n_tokens"] * 5
+        d2h = d2h_graph + (c_fin["n_tokens"] * (4 + 16) + c_fin["n_reads"] * 13 if w["sweep"] else 0)
         e2e = {"value": n_windows / de, "unit": "gene-mers/s", "ms_per_step": de * 1e3, "steps": n_e2e,
                "timed_region": "SURVEY 8(d): host CSR arrays -> host graph arrays, H2D and D2H inside the clock",
                "h2d_bytes": int(h2d), "d2h_bytes": int(d2h),
                "region": "pinned host CSR (genes, offsets, gene positions as int32, read lengths) -> H2D -> the step -> D2H "
                          "of the final graph (node + edge arrays, node id and direction per window)"
-                         + (" and of the corrected calls with the positions the correction produced (int32; the other "
-                            "reads' positions are slices of the caller's own arrays, named by offset)" if w["sweep"] else "")
+                         + (" and of the corrected calls with EVERY read's corrected positions as contiguous 64-bit arrays "
+                            "(Engine.corrected: what the drop-in's correct_reads mappings fetch)" if w["sweep"] else "")
                          + "; position upload overlapped with the first build on a second stream"}
+        if w["sweep"]:
+            dd, n_dd = timed_e2e(False)
+            d2h32 = d2h_graph + c_fin["n_tokens"] * 4 + c_fin["n_reads"] * 21 + moved.get("new_positions", 0) * 8
+            e2e["delta_positions32"] = {
+                "value": n_windows / dd, "unit": "gene-mers/s", "ms_per_step": dd * 1e3, "steps": n_dd, "d2h_bytes": int(d2h32),
+                "what": "the same region with the corrected positions in the boundary's lighter form (amg_get_corrected32: "
+                        "int32, only the positions the corrections produced + an offset per read into the caller's own "
+                        "arrays; the gather into contiguous arrays is left to the caller, outside the clock) — the round-4 "
+                        "`e2e` figure"}
 
     if e2e is not None and w["sweep"]:
         try:

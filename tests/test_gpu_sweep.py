@@ -86,6 +86,15 @@ def test_sweep_synthetic(eng, seed, N, L, V, k, err):
     run_sweep(eng, reads, pos, fq, k)
 
 
+@pytest.mark.parametrize("seed,N,L,V,k,err", [(17, 800, 40, 150, 5, 0.05), (31, 600, 60, 400, 5, 0.04), (11, 400, 24, 200, 3, 0.03)])
+def test_sweep_with_every_read_rethreaded_by_a_wave(eng, monkeypatch, seed, N, L, V, k, err):
+    """AMG_NO_LEAN_GAPPED=1: no read takes the sixteen-lanes-per-read kernel (k_corr_gapped_lean, the default for reads
+    whose questions have one answer each): the wave-per-read kernel alone gives the same corrected reads"""
+    monkeypatch.setenv("AMG_NO_LEAN_GAPPED", "1")
+    reads, pos, fq = P.synth_inputs(seed, N, L, V, err)
+    run_sweep(eng, reads, pos, fq, k)
+
+
 @pytest.mark.parametrize("name,k", [("nine", 3), ("nine", 5), ("three", 5), ("four", 5), ("six", 5)])
 def test_sweep_fixture(eng, name, k):
     calls, pos = P.fixture(name)
