@@ -1354,6 +1354,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, cons
   // per read and run: {first output index of the run's genes, their number, output - token shift behind them, where
   // the path's genes are in qgene}
   __shared__ int4 s_run[GL_THREADS / GL_GROUP][GL_GROUP];
+  __shared__ int s_tk[GL_THREADS / GL_GROUP][64 + AMG_MAX_K];  // the read's own genes (a qualifying read has <= 64 windows)
   const CorrArgs& a = A.a;
   const int k = A.g.k;
   const int lane = threadIdx.x & 63, l16 = threadIdx.x & (GL_GROUP - 1), grp = threadIdx.x / GL_GROUP;
@@ -1362,6 +1363,10 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, cons
   const bool have = gi < A.n_gapped;
   GapRec rec;
   rec.r = 0; rec.L0 = 0; rec.start = 0; rec.end = -1; rec.t0 = 0; rec.dst = 0; rec.mask = 0ull; rec.pad = 0;
+  // the chain of dependent loads is what a read costs here: the record and the read's question slots leave together
+  // (the slots of runs the read does not have are not initialised and not looked at), the read's genes and the
+  // answers' headers follow, the answers' genes last
+  int slot = have ? A.gq[gi * GF_MAXGAP + l16] : -1;
   if (have) rec = A.rec[gi];
   const unsigned long long lv = rec.mask;
   const int nwin = rec.L0 - k + 1;
@@ -1374,12 +1379,15 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, cons
   unsigned long long ends = ok ? (~lv & inside & (lv >> 1)) : 0ull;
   const int n_gaps = __popcll(ends);
   ok = ok && n_gaps >= 1 && n_gaps <= GF_MAXGAP;
-  int slot = -1;
-  if (ok && l16 < n_gaps) slot = A.gq[gi * GF_MAXGAP + l16];
   // (k_gap_queries left gq[0] = -1 on a read it did not enter)
   const bool mine = ok && l16 < n_gaps;
+  if (!mine) slot = -1;
   int4 res = make_int4(0, -1, 0, 0);
   if (mine && slot >= 0) res = A.qres[slot];
+  if (ok) {  // genes first .. last + k - 1 of the read, staged while the answers' headers are on their way
+    const int span = last + k - first;
+    for (int i = l16; i < span; i += GL_GROUP) s_tk[grp][i] = a.tokens[rec.t0 + first + i];
+  }
   int ps = 0, pe = 0;
   if (mine) {
     unsigned long long e = ends;
@@ -1414,7 +1422,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, cons
           tok_shift = rq.z;
         }
       }
-      const int v = src >= 0 ? qgene[src] : a.tokens[rec.t0 + first + o - tok_shift];
+      const int v = src >= 0 ? qgene[src] : s_tk[grp][o - tok_shift];
       a.tmp_tok[rec.dst + o] = v;
     }
     if (l16 == 0) a.new_len[rec.r] = (unsigned int)ng;

@@ -631,6 +631,110 @@ def run_front_end(w, vocab, toks, offs, k, n_windows):
     return out
 
 
+def _bubble_inputs(seed, N, L, V, err):
+    """gene calls with compact positions (60-base genes every 80 bases) and nucleotide reads that agree with them: every
+    gene name owns one pseudo-random sequence, laid down (reverse-complemented for '-') at its position on each read,
+    random filler in between — reads through the same genes share their k-mers (the shape tests/golden/procedures.py
+    synth_fastq gives the bubble-popping goldens)"""
+    from amira_amd import synth
+    ids, sts = synth.loop_reads(seed, N, L, V, err, 0)
+    calls = synth.to_read_dict(ids, sts, synth.gene_names(V, 0))
+    rng = np.random.default_rng(seed + 1)
+    comp = np.zeros(256, np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    gene_seq = {}
+    pos, fq = {}, {}
+    for rid, genes in calls.items():
+        pos[rid] = [(80 * i, 80 * i + 59) for i in range(len(genes))]
+        seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 80 * len(genes) + 40)].copy()
+        for g, (a, b) in zip(genes, pos[rid]):
+            piece = gene_seq.get(g[1:])
+            if piece is None:
+                piece = gene_seq[g[1:]] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 60)]
+            seq[a:b + 1] = piece if g[0] == "+" else comp[piece][::-1]
+        text = seq.tobytes().decode()
+        fq[rid] = {"sequence": text, "quality": "I" * len(text)}
+    return calls, pos, fq
+
+
+def run_bubbles(local_rank, with_cpu=True):
+    """SURVEY 8 row f1 (construct_graph.py:2148-2250 correct_low_coverage_paths, graph_utils.py:127-181): the device
+    sketch kernel priced against the HBM roofline on a large batch, and the whole driver iterative_bubble_popping on a
+    small read set with nucleotide reads, the pure-Python oracle (its own MinHash restatement) beside it."""
+    import ctypes as C
+    import tempfile
+    from amira_amd import Engine, _ffi, graph_utils as gu
+    out = {}
+    # ---- k_minhash on one batch: 2^27 bases in 1 000-base segments, the node sketch's parameters (ksize 11, scaled 10)
+    n_seg, seg_len, ksize, scaled = 1 << 17, 1000, 11, 10
+    rng = np.random.default_rng(11)
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_seg * seg_len, dtype=np.uint8)]
+    offs = np.arange(n_seg + 1, dtype=np.int64) * seg_len
+    sets = (np.arange(n_seg, dtype=np.int32) >> 4)
+    cap = len(bases) // scaled * 2
+    o_set, o_hash = np.empty(cap, np.int32), np.empty(cap, np.uint64)
+    eng = Engine(local_rank)
+    try:
+        eng.set_timing(True)
+        n = C.c_int64(0)
+        best_ms, wall = None, None
+        for rep in range(3):
+            t = time.perf_counter()
+            _ffi.check(_ffi.lib.amg_minhash(eng._h, _ffi.ptr(bases), _ffi.ptr(offs), _ffi.ptr(sets), n_seg, ksize, scaled,
+                                            _ffi.ptr(o_set), _ffi.ptr(o_hash), cap, C.byref(n)))
+            dt = time.perf_counter() - t
+            ms = dict(eng.timings()).get("minhash")
+            if ms is not None and (best_ms is None or ms < best_ms):
+                best_ms, wall = ms, dt
+        kept = int(n.value)
+        alg = len(bases) + 12 * kept   # 1 B per base in, {set id 4 B, hash 8 B} per kept hash out (DESIGN.md section 3)
+        out["minhash_kernel"] = {
+            "bases": int(len(bases)), "segments": n_seg, "ksize": ksize, "scaled": scaled, "kept_hashes": kept,
+            "kernel_ms": round(best_ms, 4), "call_ms_with_pcie": round(wall * 1e3, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_minhash", "algorithmic_bytes": alg,
+                         "achieved": alg / (best_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bases_per_s": len(bases) / (best_ms * 1e-3),
+                         "note": "one thread hashes one k-mer start (MurmurHash3_x64_128 over the canonical 11-mer: ~150 "
+                                 "integer instructions per byte read): the kernel is bound by instruction issue, not by "
+                                 "bytes — the fraction says how far from the HBM line it sits, not that bytes are wasted"}}
+    finally:
+        eng.close()
+    # ---- the driver on reads with nucleotide sequences: three cleaning iterations with bubble popping
+    N, L, V, k, err = 500, 30, 150, 3, 0.04   # (the pure-Python oracle beside it takes ~25 s at this size)
+    calls, pos, fq = _bubble_inputs(4242, N, L, V, err)
+    n_windows = sum(max(0, len(v) - k + 1) for v in calls.values())
+
+    def drive(mod):
+        short, short_pos = {}, {}
+        with tempfile.TemporaryDirectory() as tmp:
+            t = time.perf_counter()
+            reads, positions = mod.iterative_bubble_popping({r: list(v) for r, v in calls.items()},
+                                                            {r: list(v) for r, v in pos.items()}, 3, k, 1, short, short_pos,
+                                                            fq, tmp, 3, set(), 2)
+            return time.perf_counter() - t, sum(len(v) for v in reads.values())
+
+    import contextlib
+    import io
+    with contextlib.redirect_stderr(io.StringIO()):
+        drive(gu)
+        t_dev, genes_dev = drive(gu)
+    out["iterative_bubble_popping"] = {"reads": N, "genes_per_read": L, "k": k, "gene_mers": n_windows,
+                                       "s_per_call": round(t_dev, 3), "gene_mers_per_s": n_windows / t_dev,
+                                       "genes_out": genes_dev, "bases": sum(len(v["sequence"]) for v in fq.values())}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from amira_oracle import driver as odriver
+        with contextlib.redirect_stderr(io.StringIO()):
+            t_cpu, genes_cpu = drive(odriver)
+        out["iterative_bubble_popping"]["cpu_baseline"] = {
+            "s_per_call": round(t_cpu, 3), "gene_mers_per_s": n_windows / t_cpu, "cores": 1, "kind": "port",
+            "same_result": genes_cpu == genes_dev,
+            "sample": "the same call on the same reads through the pure-Python oracle (oracle/amira_oracle, its own "
+                      "restatement of sourmash's sketch)"}
+    return out
+
+
 def run_multi_k(w, vocab, toks, offs, local_rank):
     """SURVEY 8 row f3 (graph_utils.py:258-296 choose_kmer_size): the seven graphs k = 3, 5, ..., 15 of the workload's
     reads as ONE amg_build_multi call (two passes over the tokens for all seven, fingerprint keys) against seven
@@ -1025,18 +1129,21 @@ def main():
     if w["sweep"] and world == 1 and not merge and not args.no_e2e:
         api_e2e = run_api_e2e(w, vocab, toks, offs, k, n_windows)
 
-    front_end = multi_k = None
+    front_end = multi_k = bubbles = None
     if w["sweep"] and world == 1 and not merge and not args.no_e2e and rank == 0:
         for name, fn in (("front_end", lambda: run_front_end(w, vocab, toks, offs, k, n_windows)),
-                         ("multi_k", lambda: run_multi_k(w, vocab, toks, offs, local_rank))):
+                         ("multi_k", lambda: run_multi_k(w, vocab, toks, offs, local_rank)),
+                         ("bubbles", lambda: run_bubbles(local_rank, with_cpu=not args.no_cpu_baseline))):
             try:
                 got = fn()
             except Exception as err:  # noqa: BLE001  (extra figures: never cost the line)
                 got = {"error": repr(err)}
             if name == "front_end":
                 front_end = got
-            else:
+            elif name == "multi_k":
                 multi_k = got
+            else:
+                bubbles = got
 
     out = None
     if rank == 0:
@@ -1149,6 +1256,8 @@ def main():
             out["front_end"] = front_end
         if multi_k is not None:
             out["multi_k"] = multi_k
+        if bubbles is not None:
+            out["bubbles"] = bubbles
         out.update(cpu)
     # ---- BASELINE configs[3] beside it: build + read-path clustering through the Python API (its own engine)
     if rank == 0 and world == 1 and not merge and w["sweep"] and not args.no_cfg4 and not args.no_e2e:
