@@ -1038,7 +1038,8 @@ int bx_nodes(amg_ctx* c, int k, int* which) {
 
 // the table pass alone: claims 0 .. n_local_nodes-1 with their first-seen / slot arrays
 // sharded: claim ids may come from shard counters (then x_nspace > n_nodes: ids nobody took in between)
-int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
+// rank_follows: the caller ranks the claims next (x_rank_bitmap): its flag bytes are zeroed behind the status read-back
+int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follows) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens;
@@ -1056,7 +1057,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded) {
   const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
   const size_t tab_slots = (size_t)c->node_slots + home_n;
   const long long claim_bound = ((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
-  const bool plain = sharded;  // the caller is the plain build: ranking follows the read-back directly
+  const bool plain = sharded && rank_follows;  // the caller is the plain build: ranking follows the read-back directly
   c->rank_flags_clean = 0;
   sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
@@ -1311,8 +1312,8 @@ int bx_node_count(amg_ctx* c, bool tag) {
 
 // the table pass alone: tok_node from x_final, edge-class claims 0 .. n_local_pairs-1
 // lone: x_ftag marks the nodes of coverage 1 (bx_node_count); their classes bypass the table
-// sharded: as bx_nodes_upsert's
-int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
+// sharded, rank_follows: as bx_nodes_upsert's
+int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_follows) {
   *which = 0;
   hipStream_t st = c->stream;
   const long long T = c->n_tokens, D = c->n_nodes;
@@ -1333,7 +1334,7 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded) {
   // claims: at most one per table slot, plus (lone) two classes per single node, never more than the windows
   long long claim_bound = (long long)tab_slots + (lone ? 2 * D : 0);
   claim_bound = (claim_bound < T ? claim_bound : T) + 1;
-  const bool plain = sharded;  // the caller is the plain build: counting and ranking follow, nobody else writes s0
+  const bool plain = sharded && rank_follows;  // the caller is the plain build: counting and ranking follow, nobody else writes s0
   c->rank_flags_clean = 0;
   sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter

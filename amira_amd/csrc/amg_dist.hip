@@ -148,20 +148,31 @@ __device__ __forceinline__ unsigned long long tuple_fingerprint(const int* tok, 
   return h ? h : 1ull;
 }
 
+// (claim ids nobody took — shard counters leave holes — have first-seen 0: they get destination `world`, which sorts
+// behind every rank and is never sent; `bucket`: destinations are wanted, i.e. world > 1 or there are holes)
 __global__ void k_xd_node_keys(const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
-                               long long n, int k, int bits, int two, unsigned long long seed, unsigned int world,
+                               const unsigned int* __restrict__ first2,
+                               long long n, int k, int bits, int two, unsigned long long seed, unsigned int world, int bucket,
                                unsigned long long* __restrict__ keys, unsigned int* __restrict__ dest,
                                unsigned int* __restrict__ idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (x_first_inv(first2, i) == 0u) {
+    keys[i] = 0ull;
+    if (bucket) {
+      dest[i] = world;
+      idx[i] = (unsigned int)i;
+    }
+    return;
+  }
   const Slot16 s = tab[slot_by_claim[i]];
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys: no tag there
   int tok[AMG_MAX_K];
   for (int j = 0; j < k; ++j) tok[j] = x_unpack(s.w1, tag, bits, j);
   const unsigned long long key = tuple_fingerprint(tok, k, seed);
   keys[i] = key;
-  if (world > 1) {
-    dest[i] = owner_of(key, world);
+  if (bucket) {
+    dest[i] = world > 1 ? owner_of(key, world) : 0u;
     idx[i] = (unsigned int)i;
   }
 }
@@ -190,11 +201,11 @@ __global__ void k_xd_node_pack(const unsigned int* __restrict__ order, long long
 }
 
 __global__ void k_xd_edge_dest(const Slot16* __restrict__ etab, const unsigned int* __restrict__ slot_by_claim,
-                               long long n, unsigned int world, unsigned int* __restrict__ dest,
-                               unsigned int* __restrict__ idx) {
+                               const unsigned int* __restrict__ first2, long long n, unsigned int world,
+                               unsigned int* __restrict__ dest, unsigned int* __restrict__ idx) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  dest[i] = owner_of(etab[slot_by_claim[i]].w1, world);
+  dest[i] = x_first_inv(first2, i) == 0u ? world : (world > 1 ? owner_of(etab[slot_by_claim[i]].w1, world) : 0u);
   idx[i] = (unsigned int)i;
 }
 
@@ -224,17 +235,26 @@ static int bucketing(amg_ctx* c, long long n, Bucketing* b) {
   b->order = b->dest_sorted + (n + 1);
   return AMG_OK;
 }
-static const unsigned int* send_order(const amg_ctx* c, long long n) {
-  return c->world > 1 ? c->dist_a.as<unsigned int>() + 3 * (n + 1) : nullptr;
+// order in which the local records leave (nullptr: local order — one destination and no unclaimed ids in between);
+// the bucketing ran over c->dist_nspace claim ids
+static const unsigned int* send_order(const amg_ctx* c) {
+  return c->dist_sorted ? c->dist_a.as<unsigned int>() + 3 * (c->dist_nspace + 1) : nullptr;
 }
 
 // per-destination send counts of n records whose destinations are in dest[]: sorts (dest, idx)
 // into (dest_sorted, order) and fills send_counts.  One destination: nothing to sort, the records leave in local
 // order (send_order() == nullptr) and no count has to come back from the device.
-static int dest_counts(amg_ctx* c, long long n, int world, const Bucketing& b, int64_t* send_counts) {
+// n: ids bucketed (claim ids in use, holes included), n_real: the records among them
+static int dest_counts(amg_ctx* c, long long n, long long n_real, int world, const Bucketing& b, int64_t* send_counts) {
   hipStream_t st = c->stream;
+  c->dist_nspace = n;
+  c->dist_sorted = world > 1 || n != n_real;
   if (world == 1) {
-    send_counts[0] = n;
+    send_counts[0] = n_real;
+    if (n == n_real) return AMG_OK;
+    // one destination, but unclaimed ids in between: the sort moves them behind the records
+    if (n > 0)
+      AMGCHK(prim_sort_u32_u32(c, b.dest, b.dest_sorted, b.idx, b.order, (size_t)n, 2));
     return AMG_OK;
   }
   AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
@@ -254,14 +274,15 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
   hipStream_t st = c->stream;
   for (int attempt = 0;; ++attempt) {
     int which = 0;
-    int r = bx_nodes_upsert(c, k, &which);
+    int r = bx_nodes_upsert(c, k, &which, !getenv("AMG_DIST_ONE_COUNTER"), false);  // claims from the shard counters (A/B switch)
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
     ++c->retries;
     if (c->node_slots >= (1ll << 30)) return amg_fail(AMG_E_OVERFLOW, "node table at maximum size");
     c->node_slots = c->node_slots * 4 > (1ll << 30) ? (1ll << 30) : c->node_slots * 4;
   }
-  const long long n = c->n_local_nodes, T = c->n_tokens;
+  // claim ids in use lie below n (shard counters: with ids nobody took in between, first-seen 0)
+  const long long n = c->x_nspace, T = c->n_tokens;
   // local occurrence counts per claim, straight from the per-window claims
   stage_begin(c, "node_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
@@ -273,9 +294,10 @@ static int nodes_local_x(amg_ctx* c, int k, int world, int64_t* send_counts) {
   AMGCHK(c->dist_first.ensure((size_t)(n + 1) * sizeof(unsigned long long)));  // keys per claim
   if (n > 0)
     hipLaunchKernelGGL(k_xd_node_keys, dim3(nblk(n, 256)), dim3(256), 0, st, c->node_tab.as<Slot16>(),
-                       c->x_slot.as<unsigned int>(), n, k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->seed,
-                       (unsigned int)world, c->dist_first.as<unsigned long long>(), b.dest, b.idx);
-  const int r = dest_counts(c, n, world, b, send_counts);
+                       c->x_slot.as<unsigned int>(), c->x_first.as<unsigned int>(), n, k, c->x_bits,
+                       (long long)k * c->x_bits > 63 ? 1 : 0, c->seed, (unsigned int)world,
+                       (world > 1 || n != c->n_local_nodes) ? 1 : 0, c->dist_first.as<unsigned long long>(), b.dest, b.idx);
+  const int r = dest_counts(c, n, c->n_local_nodes, world, b, send_counts);
   stage_end(c);
   return r;
 }
@@ -284,13 +306,13 @@ static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
   hipStream_t st = c->stream;
   for (int attempt = 0;; ++attempt) {
     int which = 0;
-    int r = bx_edges_upsert(c, &which);
+    int r = bx_edges_upsert(c, &which, false, !getenv("AMG_DIST_ONE_COUNTER"), false);
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 2 || attempt >= 8) return r;
     ++c->retries;
     c->edge_slots *= 4;
   }
-  const long long n = c->n_local_pairs, T = c->n_tokens;
+  const long long n = c->x_espace, T = c->n_tokens;  // (claim ids in use lie below n: see nodes_local_x)
   stage_begin(c, "edge_count");
   AMGCHK(c->dist_lcnt.ensure((size_t)(n + 2) * sizeof(unsigned int)));
   AMGCHK(count_ids(c, c->tok_pair.as<int>(), T, nullptr, n, c->dist_lcnt.as<unsigned int>(), 5));
@@ -298,10 +320,10 @@ static int edges_local_x(amg_ctx* c, int world, int64_t* send_counts) {
   stage_begin(c, "merge_edge_bucket");
   Bucketing b;
   AMGCHK(bucketing(c, n, &b));
-  if (n > 0 && world > 1)
+  if (n > 0 && (world > 1 || n != c->n_local_pairs))
     hipLaunchKernelGGL(k_xd_edge_dest, dim3(nblk(n, 256)), dim3(256), 0, st, c->edge_tab.as<Slot16>(),
-                       c->x_eslot.as<unsigned int>(), n, (unsigned int)world, b.dest, b.idx);
-  const int r = dest_counts(c, n, world, b, send_counts);
+                       c->x_eslot.as<unsigned int>(), c->x_efirst.as<unsigned int>(), n, (unsigned int)world, b.dest, b.idx);
+  const int r = dest_counts(c, n, c->n_local_pairs, world, b, send_counts);
   stage_end(c);
   return r;
 }
@@ -369,7 +391,7 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   if (n > 0 && world > 1)
     hipLaunchKernelGGL(k_dist_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
                        c->dist_slot.as<unsigned int>(), n, c->node_tab.as<Slot>(), (unsigned int)world, b.dest, b.idx);
-  return dest_counts(c, n, world, b, send_counts);
+  return dest_counts(c, n, n, world, b, send_counts);
 }
 
 extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
@@ -377,7 +399,7 @@ extern "C" int amg_dist_nodes_pack(amg_ctx* c, void* send_buf) {
   const long long n = c->n_local_nodes;
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
-  const unsigned int* order = send_order(c, n);
+  const unsigned int* order = send_order(c);
   stage_begin(c, "merge_node_pack");
   if (c->dist_x)
     hipLaunchKernelGGL(k_xd_node_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,
@@ -684,10 +706,10 @@ extern "C" int amg_dist_nodes_global(amg_ctx* c, const void* all_records, int64_
   const long long nl = c->n_local_nodes;
   const unsigned long long* rep = reinterpret_cast<const unsigned long long*>(my_replies);
   if (nl > 0 && c->dist_x)
-    hipLaunchKernelGGL(k_replies_to_claims, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c, nl), bits,
+    hipLaunchKernelGGL(k_replies_to_claims, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c), bits,
                        prefix, c->x_final.as<int>());
   else if (nl > 0)
-    hipLaunchKernelGGL(k_replies_to_slots, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c, nl), bits,
+    hipLaunchKernelGGL(k_replies_to_slots, dim3(nblk(nl, 256)), dim3(256), 0, st, rep, nl, send_order(c), bits,
                        prefix, c->dist_slot.as<unsigned int>(), c->node_tab.as<Slot>(), c->node_tokens.as<int>(), c->k,
                        c->packed_nodes ? 1 : 0);
   // distinct first-seen values <=> as many bits as records
@@ -758,7 +780,7 @@ extern "C" int amg_dist_edges_local(amg_ctx* c, int32_t world, int64_t* send_cou
   if (n > 0 && world > 1)
     hipLaunchKernelGGL(k_dist_dest, dim3(nblk(n, 256)), dim3(256), 0, st,
                        c->dist_slot.as<unsigned int>(), n, c->edge_tab.as<Slot>(), (unsigned int)world, b.dest, b.idx);
-  return dest_counts(c, n, world, b, send_counts);
+  return dest_counts(c, n, n, world, b, send_counts);
 }
 
 extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
@@ -766,7 +788,7 @@ extern "C" int amg_dist_edges_pack(amg_ctx* c, void* send_buf) {
   const long long n = c->n_local_pairs;
   if (n == 0) return AMG_OK;
   if (!send_buf) return amg_fail(AMG_E_ARG, "null send buffer");
-  const unsigned int* order = send_order(c, n);
+  const unsigned int* order = send_order(c);
   stage_begin(c, "merge_edge_pack");
   if (c->dist_x)
     hipLaunchKernelGGL(k_xd_edge_pack, dim3(nblk(n, 256)), dim3(256), 0, c->stream, order, n,

@@ -231,6 +231,8 @@ struct amg_ctx {
   int world = 1;
   int64_t n_owned = 0;
   uint32_t dist_min_node = 1, dist_min_edge = 1;  // fused filter of the next merged build
+  int64_t dist_nspace = 0;   // ids the current bucketing ran over (local records + claim ids nobody took)
+  bool dist_sorted = false;  // the local records leave in sorted order (send_order)
   DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_gtab, dist_lcnt;
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
@@ -352,12 +354,12 @@ int ensure_adjacency(amg_ctx* c);
 bool bx_applicable(const amg_ctx* c, int k);
 bool bx_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
-int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded = false);
+int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded = false, bool rank_follows = true);
 int bx_nodes_rank(amg_ctx* c);
 int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov = 0);
 int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which);
 int bx_flag_dead_reads(amg_ctx* c);
-int bx_edges_upsert(amg_ctx* c, int* which, bool lone = false, bool sharded = false);
+int bx_edges_upsert(amg_ctx* c, int* which, bool lone = false, bool sharded = false, bool rank_follows = true);
 int bx_edges_rank(amg_ctx* c, unsigned int min_edge_cov = 0, bool nodes_counted = false);
 int bx_node_count(amg_ctx* c, bool tag);
 int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long long n_ids,

@@ -1851,17 +1851,24 @@ __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
 
 #define NWF_WPB 1  // reads per workgroup (see GF_WPB: most reads take the shortcut, some fill a matrix:
                    // 0.94 ms with four, 0.87 with two, 0.71 with one)
-__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
-  __shared__ int s_x[NWF_WPB][NWF_MAX_N];
-  __shared__ unsigned int s_opw[NWF_WPB][(NWF_MAX_N + NWF_MAX_M) / 16 + 1];  // alignment ops, 2 bits each
-  __shared__ long long s_gs[NWF_WPB][NWF_MAX_N];
-  __shared__ long long s_ge[NWF_WPB][NWF_MAX_N];
-  __shared__ long long s_ogs[NWF_WPB][NWF_MAX_M];  // positions of the original genes
-  __shared__ long long s_oge[NWF_WPB][NWF_MAX_M];
+struct NwfLds {  // one read's staging
+  int x[NWF_MAX_N];
+  unsigned int opw[(NWF_MAX_N + NWF_MAX_M) / 16 + 1];  // alignment ops, 2 bits each
+  long long gs[NWF_MAX_N];
+  long long ge[NWF_MAX_N];
+  long long ogs[NWF_MAX_M];  // positions of the original genes
+  long long oge[NWF_MAX_M];
+};
+
+__device__ __forceinline__ void nw_fast_read(const NwArgs& A, long long gi, int lane, NwfLds& S) {
+  int (*s_x)[NWF_MAX_N] = &S.x;
+  unsigned int (*s_opw)[(NWF_MAX_N + NWF_MAX_M) / 16 + 1] = &S.opw;
+  long long (*s_gs)[NWF_MAX_N] = &S.gs;
+  long long (*s_ge)[NWF_MAX_N] = &S.ge;
+  long long (*s_ogs)[NWF_MAX_M] = &S.ogs;
+  long long (*s_oge)[NWF_MAX_M] = &S.oge;
   const CorrArgs& a = A.a;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long gi = (long long)blockIdx.x * NWF_WPB + wv;
-  if (gi >= A.n_gapped) return;
+  const int wv = 0;
   // The kernel is bound by its chain of dependent global loads (one wave per read, ~15 us per
   // wave at full occupancy), not by the fill: one record load, then every per-gene load of the
   // read in one batch (the original positions included: the carry-over below reads them from
@@ -2078,6 +2085,129 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
     }
     A.o_gs[pdst + q] = sv;
     A.o_ge[pdst + q] = ev;
+  }
+}
+
+// list == nullptr: every re-threaded read; else the *n_list reads k_corr_nw_lean left (a count the host never sees)
+__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A, const int* __restrict__ list,
+                                                               const unsigned long long* __restrict__ n_list) {
+  __shared__ NwfLds s_lds;
+  const long long n = list ? (long long)*n_list : A.n_gapped;
+  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+    nw_fast_read(A, list ? (long long)list[i] : i, (int)threadIdx.x, s_lds);
+    wave_sync();  // the next read reuses the staging
+  }
+}
+
+// ---- position carry-over, the common case: SIXTEEN LANES per read (see k_corr_gapped_lean).
+// Equally long gene lists that differ in at most two places (and, for two, are not shift-equal up to the second one)
+// have the diagonal as their only optimal alignment (the proof stands in k_corr_nw_fast above): column q pairs x[q]
+// with y[q], a matching column takes the next unused original position — position number (matches before q) — and
+// a mismatching one takes (end of the nearest earlier matching column or 0, start of the nearest later one or read
+// length - 1) (:1314-1325, replace_invalid_gene_positions :1669-1691).  Everything is bit arithmetic on the read's
+// 64-bit mismatch mask, assembled from the wave's ballots; original positions are read straight from their pool
+// (position numbers trail q by at most two: the loads stay coalesced), nothing is staged but the two gene lists.
+// Reads that are not of this kind (lengths differ, three or more differing places, a shift-equal pair) go to the list
+// k_corr_nw_fast walks.
+__device__ __forceinline__ unsigned long long group_mask64(const bool* bit, int sh) {  // bit[t] of lane l -> mask bit 16 t + l
+  unsigned long long m = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) m |= ((__ballot(bit[t]) >> sh) & 0xffffull) << (16 * t);
+  return m;
+}
+
+__global__ __launch_bounds__(GL_THREADS) void k_corr_nw_lean(NwArgs A, int* __restrict__ fail_list,
+                                                              unsigned long long* __restrict__ n_fail) {
+  __shared__ int s_xy[GL_THREADS / GL_GROUP][2][64 + 1];
+  const CorrArgs& a = A.a;
+  const int lane = threadIdx.x & 63, l16 = threadIdx.x & (GL_GROUP - 1), grp = threadIdx.x / GL_GROUP;
+  const int sh = lane & ~(GL_GROUP - 1);
+  const long long gi = (long long)blockIdx.x * (GL_THREADS / GL_GROUP) + grp;
+  const bool have = gi < A.n_gapped;
+  NwRec q;
+  q.r = 0; q.M = 0; q.N = 0; q.pad = 0; q.t0 = 0; q.dst = 0; q.pdst = 0; q.poff = 0;
+  if (have) q = A.rec[gi];
+  const int N = q.N, M = q.M;
+  const bool mine = have && N > 0;            // (N == 0: original genes kept, or a read for the general kernel)
+  bool ok = mine && N == M && N <= 64;
+  int x[4], y[4];
+  bool mis[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 16 * t + l16;
+    x[t] = (ok && i < N) ? a.tmp_tok[q.dst + i] : -2;
+    y[t] = (ok && i < N) ? a.tokens[q.t0 + i] : -1;
+  }
+  const long long rl = (ok && a.read_len) ? a.read_len[q.r] : 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 16 * t + l16;
+    mis[t] = ok && i < N && x[t] != y[t];
+    s_xy[grp][0][i] = x[t];
+    s_xy[grp][1][i] = y[t];
+  }
+  const unsigned long long mm = group_mask64(mis, sh);
+  const int m = __popcll(mm);
+  __syncthreads();
+  bool eqa[4], eqb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = 16 * t + l16;
+    const bool in = ok && i < N - 1;
+    eqa[t] = in && x[t] == s_xy[grp][1][i + 1];   // x[i] == y[i+1]
+    eqb[t] = in && s_xy[grp][0][i + 1] == y[t];   // x[i+1] == y[i]
+  }
+  const unsigned long long eq_a = group_mask64(eqa, sh), eq_b = group_mask64(eqb, sh);
+  if (m == 2) {
+    const int b = 63 - __clzll((long long)mm);
+    const unsigned long long upto_b = (1ull << b) - 1ull;
+    ok = ok && (eq_a & upto_b) != upto_b && (eq_b & upto_b) != upto_b;
+  } else {
+    ok = ok && m <= 1;
+  }
+  if (ok) {
+    const long long NONE = (long long)0x8000000000000000ull;
+    const long long *pgs, *pge;
+    pos_base(a, q.poff, pgs, pge);
+    const unsigned long long valid = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+    const unsigned long long hit = ~mm & valid;  // matching columns
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = 16 * t + l16;
+      if (i >= N) continue;
+      const unsigned long long below = (1ull << i) - 1ull;
+      long long sv, ev;
+      if ((hit >> i) & 1ull) {
+        const int cur = __popcll(hit & below);
+        sv = pgs[cur];
+        ev = pge[cur];
+      } else {
+        // (None, None): the end of the nearest earlier matching column (0 if none), the start of the nearest later
+        // one (read length - 1 if none); position numbers = matching columns before that column
+        const unsigned long long before = hit & below, after = i >= 63 ? 0ull : (hit >> (i + 1)) << (i + 1);
+        sv = 0;
+        if (before) {
+          const int p = 63 - __clzll((long long)before);
+          sv = pge[__popcll(hit & ((1ull << p) - 1ull))];
+        }
+        ev = rl - 1;
+        if (after) {
+          const int nx = __ffsll((long long)after) - 1;
+          ev = pgs[__popcll(hit & ((1ull << nx) - 1ull))];
+        }
+        (void)NONE;
+      }
+      A.o_gs[q.pdst + i] = sv;
+      A.o_ge[q.pdst + i] = ev;
+    }
+  }
+  const bool fail = mine && !ok && l16 == 0;
+  const unsigned long long fm = __ballot(fail);
+  if (fm) {
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)fm) - 1) base = atomicAdd(n_fail, (unsigned long long)__popcll(fm));
+    base = (unsigned long long)bcast_i64((long long)base, __ffsll((long long)fm) - 1);
+    if (fail) fail_list[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)gi;
   }
 }
 
@@ -2522,6 +2652,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       cl.add(nw_size, (size_t)(n_gapped + 1) * sizeof(long long));
       cl.add(plen, (size_t)(n_gapped + 1) * sizeof(long long));
       cl.add(n_general_d, sizeof(unsigned long long));
+      cl.add(c->gm_ctr.as<unsigned long long>() + 3, sizeof(unsigned long long));  // reads k_corr_nw_lean leaves to k_corr_nw_fast
       AMGCHK(clear_many(c, cl));
     }
     AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
@@ -2576,8 +2707,20 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     W.big_off = nw_off;
     W.big_buf = c->nw_big.as<unsigned char>();
     W.allow_fast = allow_fast;
-    if (W.allow_fast)
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, NWF_WPB)), dim3(64 * NWF_WPB), 0, st, W);
+    const char* nln = getenv("AMG_NO_LEAN_NW");  // A/B + test switch: every read through the wave-per-read kernel
+    if (W.allow_fast && !(nln && nln[0] == '1')) {
+      // sixteen lanes per read where the diagonal is provably the alignment; the others are listed for the wave-per-read
+      // kernel, which walks the list with a grid stride (its length stays on the device)
+      AMGCHK(c->gm_fail.ensure((size_t)(n_gapped + 1) * sizeof(int)));
+      unsigned long long* n_fail = c->gm_ctr.as<unsigned long long>() + 3;  // (zeroed with the sizes above)
+      hipLaunchKernelGGL(k_corr_nw_lean, dim3(nblk(n_gapped, GL_THREADS / GL_GROUP)), dim3(GL_THREADS), 0, st, W,
+                         c->gm_fail.as<int>(), n_fail);
+      const unsigned int walkers = (unsigned int)(n_gapped < 16384 ? n_gapped : 16384);
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3(walkers), dim3(64 * NWF_WPB), 0, st, W, c->gm_fail.as<int>(), n_fail);
+    } else if (W.allow_fast) {
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W, (const int*)nullptr,
+                         (const unsigned long long*)nullptr);
+    }
     if (n_general > 0)  // reads too long for the register-resident kernel
       hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
     stage_end(c);
