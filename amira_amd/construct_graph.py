@@ -1869,7 +1869,7 @@ class GeneMerGraph(BubblePopping):
             process_anchors(sub_tree, nodeAnchors, a1, full_blocks, reads, node_tree, threshold)
         return self._paths_from_full_blocks(full_blocks, gene_call_subset, threshold, geneOfInterest, cores)
 
-    def _paths_from_full_blocks(self, full_blocks, gene_call_subset, threshold, geneOfInterest, cores):
+    def _paths_from_full_blocks(self, full_blocks, gene_call_subset, threshold, geneOfInterest, cores, _batch=None):
         """the second half of get_full_paths (:2738-2782): gene paths of the full blocks, block filter, the
         differentiating path of every kept block"""
         gene_blocks = {}
@@ -1881,10 +1881,22 @@ class GeneMerGraph(BubblePopping):
                 got = spelled[f] = self.get_genes_in_unitig(list(f))
             return got
 
-        # the windows of ALL blocks go to the device in one batch (the reference asks block by block, :2741-2746)
-        plans = [(f,) + self._sublist_windows(genes_of(f), geneOfInterest) for f in full_blocks]
-        fwd_lists = [list(c) for _, _, uniq in plans for c in uniq]
-        hits = self._match_gene_lists(fwd_lists + [self.reverse_list_of_genes(x) for x in fwd_lists]) if fwd_lists else []
+        # the windows of ALL blocks go to the device in one batch (the reference asks block by block, :2741-2746);
+        # _batch: the caller searches for the windows of SEVERAL genes' blocks at once — the first call (no hits yet)
+        # hands back what to look for, the second one comes with the answers
+        if _batch is not None and "hits" not in _batch:
+            plans = [(f,) + self._sublist_windows(genes_of(f), geneOfInterest) for f in full_blocks]
+            fwd_lists = [list(c) for _, _, uniq in plans for c in uniq]
+            _batch.update(plans=plans, spelled=spelled, fwd_lists=fwd_lists)
+            return None
+        if _batch is not None:
+            plans, fwd_lists, hits = _batch["plans"], _batch["fwd_lists"], _batch["hits"]
+            spelled.update(_batch["spelled"])
+        else:
+            plans = [(f,) + self._sublist_windows(genes_of(f), geneOfInterest) for f in full_blocks]
+            fwd_lists = [list(c) for _, _, uniq in plans for c in uniq]
+            hits = (self._match_gene_lists(fwd_lists + [self.reverse_list_of_genes(x) for x in fwd_lists])
+                    if fwd_lists else [])
         at, n_all = 0, len(fwd_lists)
         for f, combs, uniq in plans:
             options = self._sublists_from_hits(combs, uniq, hits[at:at + len(uniq)],
@@ -1930,7 +1942,7 @@ class GeneMerGraph(BubblePopping):
         return final_paths, coverages
 
     def split_into_subpaths(self, geneOfInterest, pathsOfinterest, path_coverages, path_reads,
-                            mean_node_coverage=None):
+                            mean_node_coverage=None, _hits=None):
         """allele clusters: reads holding a path exactly once, forward orientation first, the
         reverse complement only when there is no forward occurrence (:2360-2455).  The
         reference scans every read for every path on the host; here all paths and their
@@ -1942,7 +1954,8 @@ class GeneMerGraph(BubblePopping):
         paths = list(pathsOfinterest)
         fwd_lists = [list(p) for p in paths]
         rev_lists = [self.reverse_list_of_genes(f) for f in fwd_lists]
-        hits = self._match_gene_lists(fwd_lists + rev_lists)
+        # (_hits: the occurrences of these lists, found by the caller together with other genes' paths)
+        hits = _hits if _hits is not None else self._match_gene_lists(fwd_lists + rev_lists)
         for pi, path in enumerate(paths):
             fwd = fwd_lists[pi]
             named = list(path)
@@ -2117,7 +2130,7 @@ class GeneMerGraph(BubblePopping):
             memo[suffix] = any(r.endswith(suffix) for r in self._read_ids)
         return memo[suffix]
 
-    def _reads_on_nodes(self, node_ids):
+    def _reads_on_nodes(self, node_ids, _rows_of=None):
         """collect_reads_in_path (:1497-1504) for nodes given by device id, with the rows of the reads: the SET of read
         names is made by the same update() calls, node by node — the order in which it iterates later is the order of
         the reference's set — and the rows come out of the node -> reads lists themselves, not out of a name -> row
@@ -2127,11 +2140,16 @@ class GeneMerGraph(BubblePopping):
         node_ids = [i for i in node_ids if v.alive[i]]
         # the reads of these few nodes by one batched device search over the per-window node ids (k_match with
         # one-node patterns: hits ordered by node, read, position) — not the node -> reads lists of every node
-        off, hit_read, _ = self._engine.match_patterns(1, [[i] for i in node_ids])
-        off = off.tolist()
+        # (_rows_of: {node id: rows} when the caller has searched for several genes' nodes at once)
+        if _rows_of is None:
+            off, hit_read, _ = self._engine.match_patterns(1, [[i] for i in node_ids])
+            off = off.tolist()
+            per_node = [hit_read[off[j]:off[j + 1]] for j in range(len(node_ids))]
+        else:
+            per_node = [_rows_of[i] for i in node_ids]
         reads, all_names, all_rows = set(), [], []
         for j in range(len(node_ids)):
-            rows = hit_read[off[j]:off[j + 1]]
+            rows = per_node[j]
             if len(rows) > 1:
                 rows = rows[np.concatenate([[True], rows[1:] != rows[:-1]])]   # a read once per node, in read order
             names = names_of[rows].tolist()
@@ -2142,57 +2160,95 @@ class GeneMerGraph(BubblePopping):
         self._known_rows.update(row_of)
         return reads, np.asarray(list(map(row_of.__getitem__, reads)), dtype=np.int64)
 
-    def _cluster_gene_native(self, geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
-                             path_reads):
-        """one gene of assign_reads_to_genes (:2896-2937) with the block search in native code
+    def _cluster_genes_native(self, listOfGenes, mean_node_coverage, cores, allele_counts, clustered_reads, path_reads):
+        """assign_reads_to_genes (:2896-2937) for ALL genes of interest with the block search in native code
         (amira_amd.clustering / amg_cluster_full_blocks): the reads, their node lists and the blocks stay integer
         arrays; node hashes are made for the nodes these reads run through, objects for the few nodes and edges the
-        anchor selection and the unitig spelling look at."""
+        anchor selection and the unitig spelling look at.  The reference takes the genes one after another and scans
+        the reads three times per gene (the reads on the gene's nodes, the windows of its blocks, its final paths);
+        nothing a gene's scans look for depends on another gene's result, so each of the three searches is made ONCE,
+        for all genes together (three k_match passes over the reads instead of three per gene), and only the last
+        step — alleles into `clustered_reads` / `allele_counts` / `path_reads`, which the genes share — runs gene
+        by gene in the caller's order."""
         v = self._v()
-        node_ids = self._node_ids_containing([geneOfInterest])
-        hashes = [v.hash_at(i) for i in node_ids]
-        reads_with_gene, rows = self._reads_on_nodes(node_ids)
         threshold = mean_node_coverage / 20
-        # the reads' node lists, laid end to end
+        jobs = []
+        for geneOfInterest in listOfGenes:
+            node_ids = self._node_ids_containing([geneOfInterest])
+            jobs.append({"gene": geneOfInterest, "node_ids": node_ids, "hashes": [v.hash_at(i) for i in node_ids]})
+        # ---- search 1: the reads on every gene's nodes (one-node patterns over the per-window node ids)
+        wanted = list(dict.fromkeys(i for j in jobs for i in j["node_ids"] if v.alive[i]))
+        rows_of = {}
+        if wanted:
+            off, hit_read, _ = self._engine.match_patterns(1, [[i] for i in wanted])
+            off = off.tolist()
+            rows_of = {i: hit_read[off[n]:off[n + 1]] for n, i in enumerate(wanted)}
         tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
-        a = offs[rows]
-        n = offs[rows + 1] - a - k + 1
-        starts = np.zeros(len(rows) + 1, dtype=np.int64)
-        np.cumsum(n, out=starts[1:])
-        within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], n)
-        seq = tok_node[np.repeat(a, n) + within]
-        st = _clustering.anchor_stats(seq, starts, np.argsort(rows, kind="stable"), node_ids, len(v.alive))
-        anchors = self.get_AMR_anchors(hashes, _stats={h: (bool(x[0]), bool(x[1]), int(x[2]), int(x[3]))
-                                                       for h, x in zip(hashes, st.tolist())})
-        uniq = np.unique(seq)
-        uniq = uniq[uniq >= 0]
-        nh = v.node_hash_table(uniq)
-        memo = getattr(self, "_py_hash_memo", None)
-        if memo is None or memo[0] is not v:
-            memo = self._py_hash_memo = (v, np.zeros(len(v.alive), np.int64), np.zeros(len(v.alive), bool))
-        py_hash, known = memo[1], memo[2]
-        new = uniq[~known[uniq]]
-        if len(new):
-            py_hash[new] = [hash(h) for h in nh[new].tolist()]
-            known[new] = True
-        anchor_list = list(anchors)                       # the set's iteration order, as `for a1 in nodeAnchors` meets it
-        by_hash = {h: i for i, h in enumerate(sorted(anchor_list))}
-        anchor_ids = [v.node_of_hash[h] for h in anchor_list]
-        blocks = _clustering.full_block_ids(seq, starts, anchor_ids, [by_hash[h] for h in anchor_list], py_hash,
-                                            hash(None))
-        full_blocks = {tuple(nh[b].tolist()): True for b in blocks}
-        in_subset = np.zeros(len(self._read_ids) + 1, bool)
-        in_subset[rows] = True
-        subset = _SubsetRows(2 * len(rows))   # (reads and their "_reverse" twins: get_all_sublists only asks which rows count)
-        self._subset_rows_memo = (subset, len(subset), in_subset)
-        paths, seen, coverages = self._paths_from_full_blocks(full_blocks, subset, threshold, geneOfInterest, cores)
-        self.get_singleton_paths(seen, anchors, paths, coverages)
-        alleles, _ = self.split_into_subpaths(geneOfInterest, paths, coverages, path_reads, mean_node_coverage)
-        self.assign_final_alleles_to_components(alleles, clustered_reads, allele_counts, geneOfInterest)
-        by_component = {}
-        for h in hashes:
-            by_component.setdefault(self.get_node_by_hash(h).get_component(), set()).add(h)
-        self.collect_component_missed_genes(by_component, clustered_reads, allele_counts, geneOfInterest, path_reads)
+        for j in jobs:
+            geneOfInterest, node_ids, hashes = j["gene"], j["node_ids"], j["hashes"]
+            reads_with_gene, rows = self._reads_on_nodes(node_ids, _rows_of=rows_of)
+            # the reads' node lists, laid end to end
+            a = offs[rows]
+            n = offs[rows + 1] - a - k + 1
+            starts = np.zeros(len(rows) + 1, dtype=np.int64)
+            np.cumsum(n, out=starts[1:])
+            within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], n)
+            seq = tok_node[np.repeat(a, n) + within]
+            st = _clustering.anchor_stats(seq, starts, np.argsort(rows, kind="stable"), node_ids, len(v.alive))
+            anchors = self.get_AMR_anchors(hashes, _stats={h: (bool(x[0]), bool(x[1]), int(x[2]), int(x[3]))
+                                                           for h, x in zip(hashes, st.tolist())})
+            uniq = np.unique(seq)
+            uniq = uniq[uniq >= 0]
+            nh = v.node_hash_table(uniq)
+            memo = getattr(self, "_py_hash_memo", None)
+            if memo is None or memo[0] is not v:
+                memo = self._py_hash_memo = (v, np.zeros(len(v.alive), np.int64), np.zeros(len(v.alive), bool))
+            py_hash, known = memo[1], memo[2]
+            new = uniq[~known[uniq]]
+            if len(new):
+                py_hash[new] = [hash(h) for h in nh[new].tolist()]
+                known[new] = True
+            anchor_list = list(anchors)                   # the set's iteration order, as `for a1 in nodeAnchors` meets it
+            by_hash = {h: i for i, h in enumerate(sorted(anchor_list))}
+            anchor_ids = [v.node_of_hash[h] for h in anchor_list]
+            blocks = _clustering.full_block_ids(seq, starts, anchor_ids, [by_hash[h] for h in anchor_list], py_hash,
+                                                hash(None))
+            full_blocks = {tuple(nh[b].tolist()): True for b in blocks}
+            in_subset = np.zeros(len(self._read_ids) + 1, bool)
+            in_subset[rows] = True
+            subset = _SubsetRows(2 * len(rows))   # (reads and their "_reverse" twins: get_all_sublists only asks which rows count)
+            j.update(anchors=anchors, full_blocks=full_blocks, subset=subset, in_subset=in_subset, batch={})
+            self._paths_from_full_blocks(full_blocks, subset, threshold, geneOfInterest, cores, _batch=j["batch"])
+        # ---- search 2: the windows of every gene's blocks, forward and reverse complemented
+        fwd_all = [x for j in jobs for x in j["batch"]["fwd_lists"]]
+        hits = self._match_gene_lists(fwd_all + [self.reverse_list_of_genes(x) for x in fwd_all]) if fwd_all else []
+        at, n_all = 0, len(fwd_all)
+        for j in jobs:
+            m = len(j["batch"]["fwd_lists"])
+            j["batch"]["hits"] = hits[at:at + m] + hits[n_all + at:n_all + at + m]
+            at += m
+            self._subset_rows_memo = (j["subset"], len(j["subset"]), j["in_subset"])
+            paths, seen, coverages = self._paths_from_full_blocks(j["full_blocks"], j["subset"], threshold, j["gene"],
+                                                                  cores, _batch=j["batch"])
+            self.get_singleton_paths(seen, j["anchors"], paths, coverages)
+            j.update(paths=paths, coverages=coverages, batch=None)
+        # ---- search 3: every gene's final paths, forward and reverse complemented
+        fwd_all = [list(p) for j in jobs for p in j["paths"]]
+        rev_all = [self.reverse_list_of_genes(f) for f in fwd_all]
+        hits = self._match_gene_lists(fwd_all + rev_all) if fwd_all else []
+        at, n_all = 0, len(fwd_all)
+        for j in jobs:   # the part the genes share, in the caller's order
+            geneOfInterest, hashes = j["gene"], j["hashes"]
+            m = len(j["paths"])
+            own = hits[at:at + m] + hits[n_all + at:n_all + at + m]
+            at += m
+            alleles, _ = self.split_into_subpaths(geneOfInterest, j["paths"], j["coverages"], path_reads,
+                                                  mean_node_coverage, _hits=own)
+            self.assign_final_alleles_to_components(alleles, clustered_reads, allele_counts, geneOfInterest)
+            by_component = {}
+            for h in hashes:
+                by_component.setdefault(self.get_node_by_hash(h).get_component(), set()).add(h)
+            self.collect_component_missed_genes(by_component, clustered_reads, allele_counts, geneOfInterest, path_reads)
 
     def _assign_reads_to_genes(self, listOfGenes, cores, allele_counts, mean_node_coverage):
         clustered_reads, path_reads = {}, {}
@@ -2202,11 +2258,11 @@ class GeneMerGraph(BubblePopping):
         # Python block search, which carries the names around as the reference does, keeps such inputs)
         native = (not self._host_edits and hasattr(Tree, "from_flat") and not os.environ.get("AMG_CLUSTER_PYTHON")
                   and _clustering.emulation_ok() and not self._any_read_name_ends_with("_reverse"))
+        if native:
+            self._cluster_genes_native(list(listOfGenes), mean_node_coverage, cores, allele_counts, clustered_reads,
+                                       path_reads)
+            listOfGenes = ()
         for geneOfInterest in listOfGenes:
-            if native:
-                self._cluster_gene_native(geneOfInterest, mean_node_coverage, cores, allele_counts, clustered_reads,
-                                          path_reads)
-                continue
             hashes = [n.__hash__() for n in self.get_nodes_containing(geneOfInterest)]
             reads_with_gene = self.collect_reads_in_path(hashes)
             node_tree = None if self._host_edits else self._node_tree_from_device_ids(reads_with_gene)

@@ -983,7 +983,7 @@ extern "C" int amg_build(amg_ctx* c, int32_t k) {
 // nodes below the threshold never get an id, an array entry or an edge (an uncorrected graph is ~99 % such
 // nodes), their windows read None and their reads are queued for correction — the state a caller of
 // amg_build + amg_filter finds, except that ids number the survivors only (first-seen order among them).
-// Elsewhere (fingerprint keys, AMG_FUSED) it IS amg_build + amg_filter.
+// Elsewhere (fingerprint keys) it IS amg_build + amg_filter.
 extern "C" int amg_build_filtered(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov) {
   bool fused = false;
   const int r = build_impl(c, k, min_node_cov < 1 ? 1 : min_node_cov, min_edge_cov < 1 ? 1 : min_edge_cov, &fused);
@@ -1023,11 +1023,7 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;
     int r;
-    if (exact && bf_applicable(c, k)) {  // one fused table pass (amg_build_f.hip)
-      r = bf_tables(c, k, &which);
-      if (r == AMG_OK) r = bx_nodes_rank(c);
-      if (r == AMG_OK) r = bf_finish(c);
-    } else if (exact && min_node_cov > 0 && !getenv("AMG_NO_FUSED_FILTER")) {
+    if (exact && min_node_cov > 0 && !getenv("AMG_NO_FUSED_FILTER")) {
       r = bx_nodes_filtered(c, k, min_node_cov, &which);
       if (r == AMG_OK) r = bx_edges(c, &which, min_edge_cov);
       *fused = true;

@@ -27,103 +27,8 @@
 #include "amg_tile.h"
 #include "amg_x.h"
 
-// ------------------------------------------------------------------ nodes
-template <bool TWO, int K>  // K > 0: k known at compile time (the common odd sizes), 0: any k
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_x(
-    const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int k, int two_v,
-    int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit,
-    int* __restrict__ tok_claim, signed char* __restrict__ tok_dir, unsigned long long* status,
-    unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate, XW2 xf) {
-  if (!AMG_EXPERIMENTS) ablate = 0;
-  __shared__ int s_tok[TILE + AMG_MAX_K];
-  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
-  __shared__ unsigned int s_wave[TILE_THREADS / 64];
-  __shared__ unsigned long long s_base;
-  const long long t0 = (long long)blockIdx.x * TILE;
-  stage_tile(tokens, bnd_bits, n_tokens, k, t0, s_tok, s_bits, two_v, status);
-  const int flip = two_v - 1;
-  unsigned long long w1[TILE_ITEMS];
-  unsigned int idx[TILE_ITEMS], tag[TILE_ITEMS], id1[TILE_ITEMS], lw[TILE_ITEMS], hw[TWO ? 1 : TILE_ITEMS];
-  unsigned int lowbits = 0;  // per window: 1 = first direction is -1 (low bit of its first-seen value)
-  int slot[TILE_ITEMS];
-  ulonglong2 v[TILE_ITEMS];
-  int dirs[TILE_ITEMS];
-  unsigned int valid = 0, created = 0, last = 0;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    const int i = threadIdx.x + it * TILE_THREADS;
-    const long long t = t0 + i;
-    bool inside, is_last;
-    tile_window(s_bits, i, k, inside, is_last);
-    const bool ok = (t + k <= n_tokens) && inside;
-    dirs[it] = 0;
-    slot[it] = -1;
-    id1[it] = 0;
-    lw[it] = 0;
-    if (!TWO) hw[TWO ? 0 : it] = 0;
-    if (ok) {
-      LdsView w{s_tok + i};
-      int dir;
-      if (K > 0) {
-        dir = x_canon_pack<(K > 0 ? K : 1), TWO>(s_tok + i, flip, bits, w1[it], tag[it]);
-      } else {
-        dir = canon_dir(w, k, flip);
-        if (dir != 0) x_pack(w, k, flip, dir, bits, w1[it], tag[it]);
-      }
-      if (dir == 0) {
-        status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
-      } else {
-        dirs[it] = dir;
-        idx[it] = (unsigned int)mix64(w1[it] ^ ((unsigned long long)tag[it] * 0x9E3779B97F4A7C15ull)) & mask;
-        if (dir < 0) lowbits |= 1u << it;
-        valid |= 1u << it;
-        if (is_last) last |= 1u << it;
-      }
-    }
-  }
-  // first probe of every window in flight before any of them is examined
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(tab + idx[it]);
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (!(valid & (1u << it))) continue;
-    bool made;
-    unsigned long long w2v;
-    if (ablate & 8) {  // timing experiment: no probe
-      slot[it] = (int)idx[it];
-      w2v = 1ull + (w1[it] & 1023ull);
-      made = false;
-    } else
-    slot[it] = x_upsert<TWO>(tab, mask, w1[it], tag[it], idx[it], v[it], probe_limit,
-                              status + ST_OVERFLOW, w2v, made);
-    lw[it] = (unsigned int)w2v;
-    if (!TWO) hw[TWO ? 0 : it] = (unsigned int)(w2v >> 32);
-    if (slot[it] < 0) status[ST_OVERFLOW] = 1;
-    if (made) created |= 1u << it;
-  }
-  if (!(ablate & 4))
-  x_claim<TWO, 1>(tab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + threadIdx.x, lowbits, xf, first2,
-                  slot_by_claim, status + ST_NODE_INSERTS, status + ST_MISC, s_wave, &s_base, (ablate & 2) != 0);
-  else {
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it) id1[it] = xw2_id1<TWO>((unsigned long long)lw[it], xf);
-  }
-  if (ablate & 1) return;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    const long long t = t0 + threadIdx.x + it * TILE_THREADS;
-    if (t >= n_tokens) continue;
-    int out = -1;
-    if (slot[it] >= 0)
-      out = (int)((id1[it] - 1u) | ((last & (1u << it)) ? AMG_LAST_FLAG : 0u) | ((created & (1u << it)) ? AMG_MADE_FLAG : 0u));
-    __builtin_nontemporal_store(out, tok_claim + t);
-    __builtin_nontemporal_store(slot[it] >= 0 ? (signed char)dirs[it] : (signed char)0, tok_dir + t);
-  }
-}
-
 // ------------------------------------------------------------------ nodes, four consecutive windows per thread
-// Same result as k_nodes_x with less around the probe: a thread's 4 + k - 1 tokens leave LDS in 128-bit reads, the
+// Every gene-mer size (K = 0: k at run time): a thread's 4 + k - 1 tokens leave LDS in 128-bit reads, the
 // common 16-bit packing shares half-words between the windows, the results leave as one 16-byte and one 4-byte
 // store per thread, creators are counted with ballots, and the hit path (the key with its id in the first slot
 // probed: nearly every window of a rebuild) is straight-line code.  Streams are non-temporal so that the L2s keep
@@ -220,25 +125,16 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
         continue;
       }
       idx[w] = (unsigned int)mix64(w1[w] ^ ((unsigned long long)tag[w] * 0x9E3779B97F4A7C15ull)) & mask;
-#if defined(AMG_ABLATE_PREDICT)
-      // timing experiment (tools/predict_probe.sh): what would the pass cost if the windows after a thread's first
-      // found their key through a dense, id-ordered array (lanes 4 entries apart, a thread's entries adjacent)
-      // instead of a hashed slot?  Windows 1..3 load from consecutive slots and "find" their key; no graph.
-      v[w] = *reinterpret_cast<const ulonglong2*>(tab + (w == 0 ? idx[w] : (((unsigned int)(t0 + i0) + (unsigned int)w) & 0xffffu)));
-#elif !defined(AMG_ABLATE_NOPROBE)
       v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
-#endif
       if (dir < 0) ndir |= 1u << w;
       valid |= 1u << w;
       if ((b >> (w + k - 1)) & 1u) last |= 1u << w;
     }
-#ifndef AMG_W2_CAS
     if constexpr (TWO)  // the slot belongs to whoever takes w1: two memory-side operations per creation instead of three
       f_table_phase_own<1>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2, slot_by_claim,
                            ctrs ? ctrs : status + ST_NODE_INSERTS, cap, probe_limit, status, 1, id1, s_wave, &made, 0u, 0u,
                            cshard);
     else
-#endif
     f_table_phase<TWO, 1, false>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + i0, ndir, xf, first2,
                                  slot_by_claim, ctrs ? ctrs : status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1,
                                  id1, s_wave, &made, 0u, 0u, 0u, 0u, cshard);
@@ -283,9 +179,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
 // does not find its slot free or its own (AMG_BUCKET_PROBES = 1 slot looked at; error gene-mers, genes in many copies) goes to its
 // hashed slot as before.  A thread's four windows lie 256 apart, so the 64 lanes of one probe instruction look at
 // 64 consecutive windows: ~64 * 2 / (k + 1) distinct lines instead of 64.
-#ifndef AMG_BUCKET_PROBES
 #define AMG_BUCKET_PROBES 1  // measured on cfg 3 (first build / rebuild, ms): 1: 0.92 / 0.35, 2: 0.97 / 0.36, 3: 1.00 / 0.37, 8: 1.16 / 0.43
-#endif
 template <bool TWO, int K, bool B16, bool HEAD = false>
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
     const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits, long long n_tokens, int two_v,
@@ -375,41 +269,22 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
         }
       }
       idx[w] = (unsigned int)best * 8u + (unsigned int)((plus ? bj : K - 1 - bj) & 7);
-#ifndef AMG_ABLATE_NOPROBE
       v[w] = *reinterpret_cast<const ulonglong2*>(tab + idx[w]);  // in flight while the next window is prepared
-#endif
       if (dir < 0) ndir |= 1u << w;
       valid |= 1u << w;
       if ((b >> (K - 1)) & 1u) last |= 1u << w;
     }
-#ifndef AMG_W2_CAS
     if constexpr (TWO)
       f_table_phase_own<1, TILE_THREADS, AMG_BUCKET_PROBES>(tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir,
                                                             xf, first2, slot_by_claim, ctrs ? ctrs : status + ST_NODE_INSERTS,
                                                             cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n,
                                                             cshard);
     else
-#endif
     f_table_phase<TWO, 1, false, TILE_THREADS, AMG_BUCKET_PROBES>(
         tab, mask, valid, w1, tag, idx, v, (unsigned int)t0 + tid, ndir, xf, first2, slot_by_claim,
         ctrs ? ctrs : status + ST_NODE_INSERTS, 0u, cap, probe_limit, status, 1, id1, s_wave, &made, valid, home_n, 0u, 0u,
         cshard);
   }
-#ifdef AMG_M_DIR_LDS
-  // directions leave as one 4-byte store per thread: bytes through LDS (the token tile is no longer needed)
-  __syncthreads();
-  signed char* s_dir = reinterpret_cast<signed char*>(s_tok);
-#pragma unroll
-  for (int w = 0; w < TILE_ITEMS; ++w)
-    s_dir[w * TILE_THREADS + tid] = id1[w] ? ((ndir & (1u << w)) ? (signed char)-1 : (signed char)1) : (signed char)0;
-  __syncthreads();
-  if (t0 + 4 * tid + 4 <= n_tokens) {
-    __builtin_nontemporal_store(reinterpret_cast<const unsigned int*>(s_dir)[tid], reinterpret_cast<unsigned int*>(tok_dir + t0) + tid);
-  } else {
-    for (int j = 0; j < 4; ++j)
-      if (t0 + 4 * tid + j < n_tokens) tok_dir[t0 + 4 * tid + j] = s_dir[4 * tid + j];
-  }
-#endif
 #pragma unroll
   for (int w = 0; w < TILE_ITEMS; ++w) {
     const long long t = t0 + w * TILE_THREADS + tid;
@@ -418,9 +293,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_m(
                                  ((made & (1u << w)) ? AMG_MADE_FLAG : 0u))
                          : -1;
     __builtin_nontemporal_store(o, tok_claim + t);
-#ifndef AMG_M_DIR_LDS
     __builtin_nontemporal_store(id1[w] ? ((ndir & (1u << w)) ? (signed char)-1 : (signed char)1) : (signed char)0, tok_dir + t);
-#endif
   }
 }
 
@@ -640,88 +513,6 @@ __global__ void k_xc_label(const int* __restrict__ parent, const unsigned int* _
   node_comp[node] = (int)x_rank_of(first >> 1, bits, prefix) + 1;
 }
 
-// ------------------------------------------------------------------ edges
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_x(
-    long long n_tokens, const int* __restrict__ tok_claim, const signed char* __restrict__ tok_dir,
-    const int* __restrict__ final_of_claim, int* __restrict__ tok_node, Slot16* etab,
-    unsigned int emask, unsigned int probe_limit, unsigned long long* status,
-    int* __restrict__ tok_pair, unsigned int* first2, unsigned int* __restrict__ slot_by_claim, int ablate,
-    XW2 xf) {
-  if (!AMG_EXPERIMENTS) ablate = 0;
-  __shared__ int s_id[TILE + 1];
-  __shared__ signed char s_dir[TILE + 1];  // 0: no window; bit 7 clear
-  __shared__ unsigned char s_last[TILE + 1];
-  __shared__ unsigned int s_wave[TILE_THREADS / 64];
-  __shared__ unsigned long long s_base;
-  const long long t0 = (long long)blockIdx.x * TILE;
-  for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
-    const long long t = t0 + i;
-    int raw = -1;
-    signed char d = 0;
-    if (t < n_tokens) {
-      raw = __builtin_nontemporal_load(tok_claim + t);
-      d = __builtin_nontemporal_load(tok_dir + t);
-    }
-    int id = -1;
-    if (raw != -1) id = (ablate & 64) ? (int)((unsigned int)raw & ~AMG_FLAG_MASK)  // timing experiment
-                                      : final_of_claim[(unsigned int)raw & ~AMG_FLAG_MASK];
-    s_id[i] = id;
-    s_dir[i] = d;
-    s_last[i] = (raw == -1 || ((unsigned int)raw & AMG_LAST_FLAG)) ? 1 : 0;
-    if (i < TILE && t < n_tokens) __builtin_nontemporal_store(id, tok_node + t);
-  }
-  __syncthreads();
-  unsigned long long key[TILE_ITEMS];
-  unsigned int idx[TILE_ITEMS], id1[TILE_ITEMS], tag[TILE_ITEMS] = {}, lw[TILE_ITEMS], hw[TILE_ITEMS];
-  unsigned int lowbits = 0;  // per adjacency: its 3 orientation bits (low bits of its first-seen value)
-  int slot[TILE_ITEMS];
-  ulonglong2 v[TILE_ITEMS];
-  unsigned int valid = 0, created = 0;
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    const int i = threadIdx.x + it * TILE_THREADS;
-    slot[it] = -1;
-    id1[it] = 0;
-    lw[it] = 0;
-    hw[it] = 0;
-    if (s_last[i] || s_id[i] < 0 || s_id[i + 1] < 0) continue;
-    // adjacency (A, dA) -> (B, dB): windows t and t + 1 of the same read
-    const unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
-    const int dA = s_dir[i], dB = s_dir[i + 1];
-    const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
-    const unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
-    key[it] = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
-    const unsigned int orient = (a == lo ? 1u : 0u) | (dA > 0 ? 2u : 0u) | (dB > 0 ? 4u : 0u);
-    lowbits |= orient << (3 * it);
-    idx[it] = (unsigned int)mix64(key[it]) & emask;
-    valid |= 1u << it;
-  }
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it)
-    if (valid & (1u << it)) v[it] = *reinterpret_cast<const ulonglong2*>(etab + idx[it]);
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    if (!(valid & (1u << it))) continue;
-    bool made;
-    unsigned long long w2v;
-    slot[it] = x_upsert<false>(etab, emask, key[it], 0u, idx[it], v[it], probe_limit,
-                               status + ST_OVERFLOW, w2v, made);
-    lw[it] = (unsigned int)w2v;
-    hw[it] = (unsigned int)(w2v >> 32);
-    if (slot[it] < 0) status[ST_OVERFLOW] = 2;
-    if (made) created |= 1u << it;
-  }
-  x_claim<false, 3>(etab, slot, lw, hw, id1, created, tag, (unsigned int)t0 + threadIdx.x, lowbits, xf, first2,
-                    slot_by_claim, status + ST_PAIR_INSERTS, status + ST_MISC, s_wave, &s_base, false);
-#pragma unroll
-  for (int it = 0; it < TILE_ITEMS; ++it) {
-    const long long t = t0 + threadIdx.x + it * TILE_THREADS;
-    if (t < n_tokens)
-      __builtin_nontemporal_store(slot[it] >= 0 ? (int)((id1[it] - 1u) | ((created & (1u << it)) ? AMG_MADE_FLAG : 0u)) : -1,
-                                  tok_pair + t);
-  }
-}
-
 // ------------------------------------------------------------------ edges, four adjacencies per thread
 // HOME = 0: a thread's four adjacencies are consecutive (one LDS read of its neighbours' words, one 16-byte store of its
 // results), every class lives where its key hashes to.
@@ -851,14 +642,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_edges_v(
     } else {
       idx[w] = (HOME ? home_n : 0u) + ((unsigned int)mix64(key[w]) & emask);
     }
-#ifndef AMG_ABLATE_NOPROBE
     v[w] = *reinterpret_cast<const ulonglong2*>(etab + idx[w]);
-#endif
   }
-#ifdef AMG_LONE_ABL  // timing experiment (tools/edge_lone_probe.sh); the build fails after the pass
-  if (LONE && (AMG_LONE_ABL) == 1) valid &= ~lone, lone = 0u;
-  if (blockIdx.x == 0 && tid == 0) status[ST_MISC] = 1ull;
-#endif
   unsigned int made = 0;
   if constexpr (HOME)
     f_table_phase<false, 3, false, TILE_THREADS, 1, LONE>(etab, emask, valid, key, etag, idx, v, (unsigned int)t0 + tid,
@@ -1052,14 +837,14 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
   // bucket region of the node table (k_nodes_m): one 8-slot line per gene rank in front of the hashed slots, for the
   // gene-mer sizes that have a compile-time kernel; AMG_NODE_BUCKETS=0: hashed slots only (k_nodes_v; A/B switch)
   const char* nb = getenv("AMG_NODE_BUCKETS");
-  const bool buckets = !(nb && atoi(nb) == 0) && !getenv("AMG_X_OLD_PASS") && !getenv("AMG_X_GENERIC_K") &&
+  const bool buckets = !(nb && atoi(nb) == 0) && !getenv("AMG_X_GENERIC_K") &&
                        (k == 3 || k == 5 || k == 7) && n_tiles > 0;
   const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
   const size_t tab_slots = (size_t)c->node_slots + home_n;
   const long long claim_bound = ((long long)tab_slots < T ? (long long)tab_slots : T) + 1;
   const bool plain = sharded && rank_follows;  // the caller is the plain build: ranking follows the read-back directly
   c->rank_flags_clean = 0;
-  sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
+  sharded = sharded && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
   const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
   const size_t max_claims = sharded ? (size_t)head_cap + (size_t)cap * F_SHARDS + 1 : (size_t)claim_bound;
@@ -1085,32 +870,10 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
     AMGCHK(bs_read_stats(c, k, &cl));
   }
 
-  const char* abl = getenv("AMG_X_ABLATE");  // timing experiments (tools/ablate_probe.py): the build fails
-  const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 63) : 0;
-#ifdef AMG_EXP_CTR
-  {
-    void* p = nullptr;
-    hipGetSymbolAddress(&p, HIP_SYMBOL(g_exp_ctr));
-    hipMemsetAsync(p, 0, 64 * 16 * 8, st);
-  }
-#endif
-  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles) > 0) ? "node_upsert_head" : "node_upsert");
+  stage_begin(c, (n_tiles > 0 && head_tiles(c, n_tiles) > 0) ? "node_upsert_head" : "node_upsert");
   if (n_tiles > 0) {
     const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
-    if (getenv("AMG_X_OLD_PASS")) {  // A/B switch: one window per lane, strided (the round-1 kernel)
-      auto kern = two ? k_nodes_x<true, 0> : k_nodes_x<false, 0>;
-      if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
-        if (k == 3) kern = two ? k_nodes_x<true, 3> : k_nodes_x<false, 3>;
-        if (k == 5) kern = two ? k_nodes_x<true, 5> : k_nodes_x<false, 5>;
-        if (k == 7) kern = two ? k_nodes_x<true, 7> : k_nodes_x<false, 7>;
-      }
-      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                         c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
-                         c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
-                         c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
-                         c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
-                         c->x_slot.as<unsigned int>(), ablate, xw2_for(max_claims, T));
-    } else if (buckets) {
+    if (buckets) {
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
       auto kern = k_nodes_m<false, 3, false>;
       auto kern_head = k_nodes_m<false, 3, false, true>;
@@ -1177,10 +940,6 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   unsigned long long most = 0;
   AMGCHK(read_status(c, hs, ctrs, ST_NODE_INSERTS, &most, plain));
-  if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
-#ifdef AMG_EXP_CTR
-  if ((AMG_EXP_CTR) == 1 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
-#endif
   if (hs[ST_BADINPUT])
     return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
                                                     : "a token lies outside [0, two_v)");
@@ -1260,6 +1019,7 @@ int bx_nodes_rank(amg_ctx* c) {
                        c->node_tokens.as<int>(),
                        c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
   } else if (D > 0) {
+    c->rank_flags_clean = 0;  // (s0 is about to be reused by whoever comes next: nothing of it is known to be zero)
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
                        D, c->s1.as<unsigned int>(),
                        c->s3.as<unsigned int>());
@@ -1283,7 +1043,7 @@ int bx_edges(amg_ctx* c, int* which, unsigned int min_edge_cov) {
   if (min_edge_cov == 0) {
     const char* e = getenv("AMG_EDGE_LONE");  // A/B + test switch: 0 never, 1 whenever the kernel allows it
     const char* eh = getenv("AMG_EDGE_HOME");
-    const bool can = !getenv("AMG_X_OLD_PASS") && !(eh && atoi(eh) == 0) && c->n_nodes > 0;
+    const bool can = !(eh && atoi(eh) == 0) && c->n_nodes > 0;
     // worth its extra words per window where many nodes are single: more than one node per 16 windows
     lone = can && (e ? atoi(e) != 0 : c->n_nodes * 16 > c->n_tokens);
     AMGCHK(bx_node_count(c, lone));
@@ -1321,7 +1081,7 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   unsigned long long hs[ST_WORDS];
   // home slots (k_edges_v<.., true>): one per node id in front of the hashed slots; AMG_EDGE_HOME=0: none (A/B switch)
   const char* eh = getenv("AMG_EDGE_HOME");
-  const long long home_n = (getenv("AMG_X_OLD_PASS") || (eh && atoi(eh) == 0)) ? 0 : ((D + 7) & ~7ll);
+  const long long home_n = (eh && atoi(eh) == 0) ? 0 : ((D + 7) & ~7ll);
   // hashed slots: with home slots only the classes that do not join ids n and n + 1 (one in ten on gene-call reads)
   // need one — sized for a quarter of the nodes; an input that needs more overflows once and is rebuilt 4x larger
   const int64_t want_slots = (int64_t)slots_for((uint64_t)(home_n ? D / 4 + 1 : D));
@@ -1336,7 +1096,7 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   claim_bound = (claim_bound < T ? claim_bound : T) + 1;
   const bool plain = sharded && rank_follows;  // the caller is the plain build: counting and ranking follow, nobody else writes s0
   c->rank_flags_clean = 0;
-  sharded = sharded && !getenv("AMG_X_OLD_PASS") && shard_claims(n_tiles);
+  sharded = sharded && shard_claims(n_tiles);
   const unsigned int cap = sharded ? shard_share(claim_bound) : (unsigned int)claim_bound;  // per counter
   const long long head_cap = sharded ? dense_tiles(c, n_tiles) * TILE : 0;                  // ids of the first tiles
   const size_t max_claims = sharded ? (size_t)head_cap + (size_t)cap * F_SHARDS + 1 : (size_t)claim_bound;
@@ -1349,13 +1109,6 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   AMGCHK(c->edge_tab.ensure((tab_slots + (lone ? max_claims : 0)) * sizeof(Slot16)));  // (lone classes: slot = tab_slots + claim)
   AMGCHK(c->x_efirst.ensure(2 * max_claims * sizeof(unsigned int)));
   AMGCHK(c->x_eslot.ensure(max_claims * sizeof(unsigned int)));
-#ifdef AMG_EXP_CTR
-  {
-    void* p = nullptr;
-    hipGetSymbolAddress(&p, HIP_SYMBOL(g_exp_ctr));
-    hipMemsetAsync(p, 0, 64 * 16 * 8, st);
-  }
-#endif
   stage_begin(c, "edge_table_clear");
   {
     ClearList cl;
@@ -1366,17 +1119,8 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
     AMGCHK(clear_many(c, cl));
   }
   stage_end(c);
-  const char* abl = getenv("AMG_X_ABLATE");
-  const int ablate = (AMG_EXPERIMENTS && abl) ? (atoi(abl) & 64) : 0;  // bit 64: edge pass without the claim -> node id gather
-  stage_begin(c, (n_tiles > 0 && !getenv("AMG_X_OLD_PASS") && head_tiles(c, n_tiles) > 0) ? "edge_upsert_head" : "edge_upsert");
-  if (n_tiles > 0 && getenv("AMG_X_OLD_PASS"))  // A/B switch: one adjacency per lane, strided (the round-1 kernel)
-    hipLaunchKernelGGL(k_edges_x, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, T, c->tok_slot.as<int>(),
-                       c->tok_dir.as<signed char>(), c->x_final.as<int>(), c->tok_node.as<int>(),
-                       c->edge_tab.as<Slot16>(), (unsigned int)(c->edge_slots - 1), kProbeLimitX,
-                       c->status.as<unsigned long long>(), c->tok_pair.as<int>(),
-                       c->x_efirst.as<unsigned int>(), c->x_eslot.as<unsigned int>(), ablate,
-                       xw2_for(max_claims, T));
-  else if (n_tiles > 0) {
+  stage_begin(c, (n_tiles > 0 && head_tiles(c, n_tiles) > 0) ? "edge_upsert_head" : "edge_upsert");
+  if (n_tiles > 0) {
     const long long head = head_tiles(c, n_tiles);  // (see bx_nodes_upsert: the genome's classes get the lowest claims)
     for (int part = 0; part < 2; ++part) {
       const long long lo = part == 0 ? 0 : head, cnt = part == 0 ? head : n_tiles - head;
@@ -1400,10 +1144,6 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
   unsigned long long most = 0;
   AMGCHK(read_status(c, hs, ctrs, ST_PAIR_INSERTS, &most, plain));
-  if (ablate) return amg_fail(AMG_E_STATE, "AMG_X_ABLATE is set: timing experiment, no graph");
-#ifdef AMG_EXP_CTR
-  if ((AMG_EXP_CTR) == 2 && (AMG_EXP_MODE) == 2) return amg_fail(AMG_E_STATE, "AMG_EXP_CTR: timing experiment, no graph");
-#endif
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");
   if (hs[ST_OVERFLOW]) {
     *which = 2;
@@ -1470,6 +1210,7 @@ int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal) {
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
                        c->pair_cnt.as<unsigned int>(), final_of_claim, efinal);
   } else if (P > 0) {
+    c->rank_flags_clean = 0;
     if (efinal) return amg_fail(AMG_E_STATE, "bx_pairs_rank: class ids per claim need the bitmap ranking");
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->x_efirst.as<unsigned int>(),
                        P, c->s1.as<unsigned int>(),

@@ -10,13 +10,6 @@
 
 #include "../../include/amg.h"
 
-// Timing-experiment switches inside the kernels (AMG_X_ABLATE, AMG_GAP_ABLATE; tools/*_probe.py)
-// exist only in builds made with -DAMG_EXPERIMENTS=1 (make EXPERIMENTS=1): the shipped kernels
-// carry no trace of them.
-#ifndef AMG_EXPERIMENTS
-#define AMG_EXPERIMENTS 0
-#endif
-
 // ------------------------------------------------------------------ error plumbing
 extern thread_local std::string g_amg_err;
 int amg_fail(int code, const char* fmt, ...);
@@ -212,7 +205,7 @@ struct amg_ctx {
   bool exact_keys = false;   // this build used the exact-key path
   int x_bits = 0;            // bits per token in the packed tuple
   int64_t x_nspace = 0, x_espace = 0;  // claim ids in use are below these (== n_nodes / n_pairs unless the
-                                       // claims were handed out in interleaved shards: amg_build_f.hip)
+                                       // claims came from the shard counters: XShard in amg_x.h)
   int64_t x_max_claims = 0, x_max_eclaims = 0;  // capacity of the per-claim arrays (second half of x_first / x_efirst starts there)
   bool dist_x = false;       // this merged build keeps its LOCAL tables in the exact-key layout
   DevBuf x_first, x_slot;    // uint32[claims]  ~first_seen of a node claim, its table slot
@@ -371,9 +364,6 @@ int count_ids_remap(amg_ctx* c, int* claims, long long n, const int* remap, long
 int bx_bits(const amg_ctx* c, int k);
 int bx_pairs_rank(amg_ctx* c, const int* final_of_claim, int* efinal);
 int bx_components_from_claims(amg_ctx* c);
-bool bf_applicable(const amg_ctx* c, int k);
-int bf_tables(amg_ctx* c, int k, int* which);
-int bf_finish(amg_ctx* c);
 int bs_count_by_slot(amg_ctx* c, const int* slots, int* ids_scratch, long long n, Slot* tab,
                      const unsigned int* slot_sorted, long long n_ids, unsigned int* out, int kind);
 

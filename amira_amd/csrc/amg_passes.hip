@@ -922,7 +922,6 @@ struct GapArgs {
   unsigned int cand_stride;
   unsigned char* final_cls;
   unsigned char* need_slow;  // per gapped read: 1 = the wave-per-read fast kernel gave up
-  int ablate;                // timing experiments (AMG_GAP_ABLATE): 1 stop before the DFS, 2 stop after it
   // path memo (k_gap_queries / k_gap_dfs): the same (start node, direction, end node) question is asked by every read
   // that lost the same stretch of the genome — about nine times each at 3 000x depth — and answered once
   const int* gq;             // per gapped read GF_MAXGAP query slots in run order; [0] < 0: no memo for this read
@@ -1107,7 +1106,7 @@ __device__ __forceinline__ bool nw_fast_ok(long long N, long long M) {
 // scratch spends its time in dependent LDS/scratch round trips.)
 // Emits [run, len, nodes, dirs] records; returns the number of paths, -1 on pool overflow.
 __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distance, int run, int* pool,
-                              int* used, int lane, unsigned long long* dbg = nullptr) {
+                              int* used, int lane) {
   int my_node = 0, my_dir = 0, my_cur = 0, my_lim = 0, my_off = 0;
   int depth = 0, n_paths = 0;
   bool overflow = false;
@@ -1117,11 +1116,8 @@ __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distan
   }
   bool entering = true;
   int2 first_ent = make_int2(-1, 0);
-  unsigned int n_iter = 0, n_enter = 0;
   while (depth >= 0) {
     const int d = __builtin_amdgcn_readfirstlane(depth);
-    ++n_iter;
-    if (entering) ++n_enter;
     if (entering) {
       const int L = d + 1;
       const int cur_node = __builtin_amdgcn_readlane(my_node, d);
@@ -1189,12 +1185,6 @@ __device__ int dfs_paths_wave(const GView& g, int s, int sdir, int e, int distan
       --depth;
       first_ent.x = -1;  // back in an older row: its first entry was consumed long ago
     }
-  }
-  if (dbg && lane == 0) {
-    atomicAdd(dbg + 0, (unsigned long long)n_iter);
-    atomicAdd(dbg + 1, (unsigned long long)n_enter);
-    atomicAdd(dbg + 2, 1ull);
-    atomicAdd(dbg + 3, (unsigned long long)n_paths);
   }
   return overflow ? -1 : n_paths;
 }
@@ -1515,7 +1505,6 @@ __device__ __forceinline__ void gapped_fast_read(const GapArgs& A, long long gi,
     return;
   }
   wave_sync();
-  if (AMG_EXPERIMENTS && A.ablate == 1) return;
   // ---- the paths of every run, runs in read order: copied from the memo when the read's questions were entered
   // there (k_gap_queries) — lane q looks run q up, then all copies are in flight together — otherwise one
   // wave-cooperative DFS per run
@@ -1550,8 +1539,7 @@ __device__ __forceinline__ void gapped_fast_read(const GapArgs& A, long long gi,
   } else {
     for (int q = 0; q < n_gaps && !bad; ++q) {
       const int ps = GAP[3 * q], pe = GAP[3 * q + 1];
-      const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane,
-                                    (AMG_EXPERIMENTS && A.ablate == 3) ? A.status + 8 : nullptr);
+      const int np = dfs_paths_wave(g, W[ps], Dr[ps], W[pe], 2 * g.k, q, POOL, &s_used[wv], lane);
       if (lane == 0) GAP[3 * q + 2] = np < 0 ? 0 : np;
       bad = np < 0;
     }
@@ -1561,7 +1549,6 @@ __device__ __forceinline__ void gapped_fast_read(const GapArgs& A, long long gi,
     return;
   }
   wave_sync();
-  if (AMG_EXPERIMENTS && A.ablate == 2) return;
   unsigned long long n_combo = 1;
   bool dead_end = false;
   for (int q = 0; q < n_gaps; ++q) {
@@ -2571,10 +2558,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       G.gq = gq;
       G.qres = c->gm_res.as<int4>();
       G.qpool = c->gm_pool.as<int>();
-      {
-        const char* ga = getenv("AMG_GAP_ABLATE");
-        G.ablate = (AMG_EXPERIMENTS && ga) ? atoi(ga) : 0;
-      }
       if (attempt == 0) {
         const char* nf = getenv("AMG_NO_FAST_GAPPED");  // debugging / A-B switch
         const bool use_fast = !(nf && nf[0] == '1');
@@ -2602,9 +2585,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       hipLaunchKernelGGL(k_corr_gapped, dim3(blocks), dim3(64), 0, st, G);
       unsigned long long hs[ST_WORDS];
       AMGCHK(fetch_status(c, hs));
-      if (G.ablate == 3)
-        fprintf(stderr, "[amg] DFS: %llu runs, %llu loop iterations, %llu nodes entered, %llu paths\n", hs[10], hs[8],
-                hs[9], hs[11]);
       if (!hs[ST_OVERFLOW]) break;
       if (attempt >= 8) return amg_fail(AMG_E_OVERFLOW, "correct_reads: path pool overflow");
       pool_cap = hs[ST_COMPACT_A] * 2 + (1ull << 20);

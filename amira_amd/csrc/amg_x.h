@@ -306,9 +306,6 @@ __device__ __forceinline__ int f_canon_pack16(const int* a, int flip, unsigned l
 // The creators of a wave are counted with ballots and served by one atomicAdd of the wave:
 // no LDS, no workgroup barrier.
 #define F_SHARDS 64
-#ifdef AMG_EXP_CTR
-static __device__ unsigned long long g_exp_ctr[64 * 16];
-#endif
 #define F_CTR_STRIDE 16  // counters 128 bytes apart (u64 words)
 
 // Chunked shards (the plain table passes, round 4): a WORKGROUP takes its claims from the counter of its shard
@@ -388,15 +385,7 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
       created |= 1u << it;
       continue;
     }
-#ifdef AMG_ABLATE_NOPROBE  // timing experiment (tools/noprobe_probe.sh): every window "finds" its key; no graph
-    const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx[it] & 1023ull));
-#elif defined(AMG_ABLATE_PREDICT)  // (tools/predict_probe.sh) windows 1..3 of a node-pass thread "find" theirs; the load is consumed
-    const unsigned long long c1 = (it == 0 || which != 1) ? v[it].x : w1[it],
-                             c2 = (it == 0 || which != 1) ? v[it].y
-                                                          : (((unsigned long long)tag[it] << 32) | (1ull + ((idx[it] ^ v[it].x ^ v[it].y) & 1023ull)));
-#else
     const unsigned long long c1 = v[it].x, c2 = v[it].y;
-#endif
     const bool mine = c1 == w1[it] && (!TWO || (unsigned int)(c2 >> 32) == tag[it]);
     if (mine && (unsigned int)c2 != 0u) {
       lw[it] = (unsigned int)c2;
@@ -522,21 +511,6 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
       total += cnt;
     }
     if (total) {  // workgroup-uniform
-#ifdef AMG_EXP_CTR  // timing experiment (tools/ctr_probe.sh): is the single claim counter what a first build waits for?
-      // AMG_EXP_CTR: 1 node pass, 2 edge pass; AMG_EXP_MODE 1: a second returning atomic on the same word,
-      // 2: 64 counters with disjoint claim ranges (the counts the host reads are garbage: the build stops after the pass)
-      if ((AMG_EXP_CTR) == which) {
-        if (threadIdx.x == 0) {
-          if ((AMG_EXP_MODE) == 1) {
-            const unsigned int z = (unsigned int)atomicAdd(ctr, 0ull);
-            s_wave[TILE_THREADS / 64] = (unsigned int)atomicAdd(ctr, (unsigned long long)total) + (z & 0x80000000u);
-          } else {
-            const unsigned int sh = blockIdx.x & 63u;
-            s_wave[TILE_THREADS / 64] = sh * (cap >> 6) + (unsigned int)atomicAdd(g_exp_ctr + sh * 16u, (unsigned long long)total);
-          }
-        }
-      } else
-#endif
       if (threadIdx.x == 0)
         s_wave[TILE_THREADS / 64] =
             (unsigned int)atomicAdd(xs.counter(ctr), (unsigned long long)total);
@@ -558,9 +532,6 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
         // the creator's first-seen goes to its own word with a plain store; everybody else raises the
         // claim's other word with atomicMax (both zero-initialised, first-seen = the larger): nothing
         // has to be ordered against the publication of the id
-#if defined(AMG_LONE_ABL) && (AMG_LONE_ABL) == 2
-        if (!(LONE && (lone & (1u << it))))
-#endif
         first2[2u * claim + 1u] = fi(it);
         id1[it] = claim + 1u;
         const unsigned long long pub =
@@ -568,12 +539,8 @@ __device__ __forceinline__ void f_table_phase(Slot16* tab, unsigned int mask, un
                       (unsigned long long)(claim + 1u)
                 : ((unsigned long long)fi(it) << 32) | (unsigned long long)(claim + 1u);
         if (LONE && (lone & (1u << it))) {
-#if !defined(AMG_LONE_ABL) || (AMG_LONE_ABL) != 2
           slot_by_claim[claim] = lone_base + claim;
-#if !defined(AMG_LONE_ABL) || (AMG_LONE_ABL) != 3
           *reinterpret_cast<ulonglong2*>(tab + lone_base + claim) = make_ulonglong2(w1[it], pub);
-#endif
-#endif
         } else {
           slot_by_claim[claim] = (unsigned int)slot[it];
           __hip_atomic_store(&tab[slot[it]].w2, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -676,6 +643,10 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
                                                   int which, unsigned int (&id1)[TILE_ITEMS], unsigned int* s_wave,
                                                   unsigned int* made_out, unsigned int homed = 0u, unsigned int off = 0u,
                                                   XShard xs = XShard{-1, 0u}) {
+  // a key that met a pending slot in its bucket line goes straight to its hashed slot in the redo rounds below: with
+  // more than one slot of the line probed, a later thread could create the same key in the line's NEXT slot (two claims
+  // for one key).  One probe per line is what was measured fastest anyway.
+  static_assert(HOME_PROBES == 1, "the own-slot protocol looks at one slot of a bucket line");
   // xs.shard >= 0: ctr is the array of shard counters, cap a shard's share (XShard)
   unsigned long long* const myctr = xs.counter(ctr);
   cap = xs.limit(cap);
@@ -692,11 +663,7 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
     id1[it] = 0;
     slot[it] = (int)idx0[it];
     if (!(valid & (1u << it))) continue;
-#ifdef AMG_ABLATE_NOPROBE
-    const unsigned long long c1 = w1[it], c2 = ((unsigned long long)tag[it] << 32) | (1ull + (idx0[it] & 1023ull));
-#else
     const unsigned long long c1 = v[it].x, c2 = v[it].y;
-#endif
     // the key with its id, as the first probe load returned it: done (almost every window of a rebuild)
     if (c1 == w1[it] && (unsigned int)(c2 >> 32) == tag[it] && (unsigned int)c2 != 0u)
       id1[it] = (unsigned int)c2;
@@ -771,10 +738,8 @@ __device__ __forceinline__ void f_table_phase_own(Slot16* tab, unsigned int mask
             li = 0;
           }
           const unsigned int claim = claim_of(li);
-#if !defined(AMG_NODE_ABL) || (AMG_NODE_ABL) != 1  // (1: timing experiment, tools/node_abl_probe.sh: the per-claim stores left out)
           first2[2u * claim + 1u] = fi(it);  // the creator's own word, plain store (others raise the other word)
           slot_by_claim[claim] = (unsigned int)slot[it];
-#endif
           id1[it] = claim + 1u;
           const unsigned long long pub = ((unsigned long long)tag[it] << 32) |
                                          (unsigned long long)((tpos(it) >> f.cshift) << f.ib) | (unsigned long long)(claim + 1u);

@@ -1158,14 +1158,12 @@ def main():
         per_kernel = {s: {"ms_per_step": round(stage_tot[s], 3), "avg_launch_ms": round(stage_avg[s], 4),
                           "achieved_GBs": round(cands[s] / (stage_avg[s] * 1e-3) / 1e9, 1)} for s in ranked[:4]}
         exact = bool(counts.get("exact_keys"))
-        old_pass = bool(os.environ.get("AMG_X_OLD_PASS"))
         buckets = os.environ.get("AMG_NODE_BUCKETS", "1") != "0" and k in (3, 5, 7) and not os.environ.get("AMG_X_GENERIC_K")
-        kernel_of = {"graph_upsert": "k_graph_x",
-                     "node_upsert": ("k_nodes_x" if old_pass else "k_nodes_m" if buckets else "k_nodes_v") if exact else "k_node_upsert",
-                     "edge_upsert": ("k_edges_x" if old_pass else "k_edges_v") if exact else "k_edges",
+        kernel_of = {"node_upsert": ("k_nodes_m" if buckets else "k_nodes_v") if exact else "k_node_upsert",
+                     "edge_upsert": "k_edges_v" if exact else "k_edges",
                      "node_count": "k_count_ids",
-                     "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
-                     "correct_gapped": "k_corr_gapped_fast"}
+                     "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_lean + k_corr_nw_fast",
+                     "correct_gapped": "k_corr_gapped_lean + k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
                                                         "node_upsert_head", "node_upsert", "node_rank", "node_filter", "edge_table_clear", "edge_upsert_head",
                                                         "edge_upsert",

@@ -25,9 +25,7 @@ def _invariants(eng, c, L, k):
 
 
 @pytest.mark.parametrize("workload,k,exact", [("cfg2", None, 1), ("cfg3", None, 1), ("cfg3", 3, 1),
-                                                  ("cfg2", 7, 0), ("cfg3-fused", None, 1), ("cfg3-fused", 3, 1),
-                                                  ("cfg3-split", None, 1), ("cfg3-split", 3, 1),
-                                                  ("cfg3-onecounter", None, 1)])
+                                                  ("cfg2", 7, 0), ("cfg3-onecounter", None, 1)])
 def test_full_size_build_equals_c_oracle(workload, k, exact, monkeypatch):
     """k = None: the configuration's own k (5: two-word exact keys); k = 3: one-word exact keys;
     k = 7 on the 5 000-gene vocabulary (98 bits): the verified-fingerprint path"""
@@ -41,12 +39,6 @@ def test_full_size_build_equals_c_oracle(workload, k, exact, monkeypatch):
         monkeypatch.setenv("AMG_EDGE_LONE", "0")
         monkeypatch.setenv("AMG_COUNT_LIST_SEG", "8")
         workload = workload[:-11]
-    if workload.endswith("-fused"):   # the one-pass table kernel (amg_build_f.hip), off by default
-        monkeypatch.setenv("AMG_FUSED", "1")
-        workload = workload[:-6]
-    if workload.endswith("-split"):   # the same kernel as two launches (node half, edge half)
-        monkeypatch.setenv("AMG_FUSED", "2")
-        workload = workload[:-6]
     w = dict(bench.WORKLOADS[workload])
     if k is not None:
         w["k"] = k

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_probe3.sh <tag> [bench args...] — issue / wait / texture-path / launch counters of one bench
-# run, one --pmc pass per group (environment, e.g. AMG_FUSED, is inherited)
+# run, one --pmc pass per group (the environment is inherited)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -17,4 +17,4 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_I
 done
 cd $R && python3 tools/pmc_summary.py $dirs > gpurun_out/pmc3_${tag}_summary.txt
 find gpurun_out -name "*.db" -path "*pmc3_${tag}_*" -delete
-grep -A60 "^k_graph_x\|^k_nodes_x\|^k_edges_x" gpurun_out/pmc3_${tag}_summary.txt | head -150
+grep -A60 "^k_nodes_m\|^k_edges_v\|^k_corr_" gpurun_out/pmc3_${tag}_summary.txt | head -150

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_probe4.sh <tag> [bench args...] — texture-path (TA / TCP), vector-memory issue and L2 counters of the
-# table passes of one bench run, one --pmc pass per group (environment, e.g. AMG_FUSED, is inherited)
+# table passes of one bench run, one --pmc pass per group (the environment is inherited)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -16,4 +16,4 @@ for C in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_
 done
 cd $R && python3 tools/pmc_summary.py $dirs > gpurun_out/pmc4_${tag}_summary.txt
 find gpurun_out -name "*.db" -path "*pmc4_${tag}_*" -delete
-grep -A22 "^k_graph_x\|^k_nodes_x\|^k_edges_x" gpurun_out/pmc4_${tag}_summary.txt | head -120
+grep -A22 "^k_nodes_m\|^k_edges_v\|^k_corr_" gpurun_out/pmc4_${tag}_summary.txt | head -120
