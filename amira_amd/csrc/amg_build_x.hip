@@ -800,6 +800,14 @@ static long long shard_space(unsigned long long most, long long head_cap, size_t
   return s < (long long)max_claims ? s : (long long)max_claims;
 }
 
+// bits per token of the packed tuple: 16 whenever that fits (constant shifts in the kernels); AMG_X_TIGHT_BITS=1:
+// as few as the vocabulary needs (test switch: the kernels' general packing, which large vocabularies take)
+int bx_bits(const amg_ctx* c, int k) {
+  const int need = ilog2_ceil((uint64_t)(c->two_v > 2 ? c->two_v : 2));
+  if (need <= 16 && (long long)k * 16 <= 94 && !getenv("AMG_X_TIGHT_BITS")) return 16;
+  return need;
+}
+
 bool bx_applicable(const amg_ctx* c, int k) {
   if (c->dist_mode || c->count_inline) return false;
   return bx_fits(c, k);
