@@ -831,6 +831,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)   # (a fresh box runs its first steps 3 % slower)
     ap.add_argument("--workload", default="cfg3-sweep", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="cpu_baseline_python on SURVEY 8(d)'s full 1 %% read sample (~100 s of one core) instead of the "
+                         "~12 s sample of the default line")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the extra `cfg4` object (read-path clustering) of the default line")
     ap.add_argument("--no-fused-line", action="store_true", help="skip the extra `fused_first_filter` measurement")
@@ -861,7 +864,7 @@ def main():
     cpu = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "cfg4":
         cpu["cpu_baseline"] = cpu_baseline_c(w)
-        cpu["cpu_baseline_python"] = cpu_baseline(w)
+        cpu["cpu_baseline_python"] = cpu_baseline(w, budget_s=1e9) if args.full_cpu_baseline else cpu_baseline(w)
         cpu["cpu_baseline_ncore"] = cpu_baseline_ncore(w)
 
     cpu4 = None
