@@ -387,7 +387,7 @@ extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
   o->n_components = c->n_components;
   o->node_table_slots = c->node_slots;
   o->edge_table_slots = c->edge_slots;
-  o->exact_keys = c->exact_keys ? 1 : 0;
+  o->exact_keys = c->exact_keys ? (c->x_fp ? 2 : 1) : 0;  // 2: 16-byte slots keyed by verified 94-bit fingerprints
   o->reserved = 0;
   o->build_retries = c->retries;
   AMGCHK(count_flags(c, c->node_alive, c->n_nodes, &o->n_live_nodes));

@@ -27,6 +27,63 @@
 #include "amg_tile.h"
 #include "amg_x.h"
 
+// ------------------------------------------------------------------ tuples that do not fit the slot: 94-bit fingerprints
+// k * ceil(log2 2V) > 94 (k >= 7 on a 20 000-gene vocabulary): the key of the SAME 16-byte slots, claim ids and dense
+// per-claim arrays is a 94-bit fingerprint of the canonical tuple instead of the tuple itself (w1 = 63 bits, tag = 31).
+// Nothing else of the build changes; what a slot no longer says is read from the token stream where it is needed:
+//   * a node's tokens (k_x_assign_nodes*) are the window at its first-seen position, canonical by its direction bit;
+//   * every window's tuple is compared with the tuple at its claim's first-seen position (k_x_verify_fp: the creator's
+//     window — for the genome's nodes a few hundred kilobytes of the stream's head, L2-resident): two gene-mers that
+//     share a fingerprint raise ST_COLLISION and the build is repeated with the next seed (AMG_TEST_WEAK_FP cuts the
+//     fingerprint to 12 bits so that this happens).
+// The round-1 path for such k — 32-byte slots, sorted compaction lists, a packed-tuple gather per window in the edge
+// pass — took 3.5 to 6 times as long per build as the exact-key path (bench.py multi_k); it stays for inputs beyond
+// 2^29 tokens, for the multi-GPU merge and behind AMG_KEY_MODE=fp.
+template <class View>
+__device__ __forceinline__ void x_fp94(const View& w, int k, int flip, int dir, unsigned long long seed, int weak,
+                                       unsigned long long& w1, unsigned int& tag) {
+  unsigned long long h1 = seed, h2 = seed ^ 0xC2B2AE3D27D4EB4Full;
+  for (int j = 0; j < k; ++j) {
+    const unsigned long long c = (unsigned long long)(unsigned int)canon_tok(w, k, flip, dir, j);
+    h1 = (h1 ^ c) * 0x9E3779B97F4A7C15ull;
+    h1 ^= h1 >> 29;
+    h2 = (h2 + c) * 0xD6E8FEB86659FD93ull;
+    h2 ^= h2 >> 31;
+  }
+  h1 = mix64(h1);
+  h2 = mix64(h2 ^ (h1 >> 7));
+  if (weak) {  // test hook: 12 bits
+    h1 &= 0xfffull;
+    h2 = 0ull;
+  }
+  w1 = (h1 << 1) | 1ull;
+  tag = ((unsigned int)h2 << 1) | 1u;
+}
+
+// fingerprint keys: the tuple of every window against the tuple at its claim's first-seen position
+__global__ __launch_bounds__(256) void k_x_verify_fp(const int* __restrict__ tokens, long long n_tokens, int k, int flip,
+                                                      const int* __restrict__ tok_claim,
+                                                      const signed char* __restrict__ tok_dir,
+                                                      const unsigned int* __restrict__ first2,
+                                                      unsigned long long* status) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tokens) return;
+  const int raw = tok_claim[t];
+  if (raw == -1) return;
+  const unsigned int claim = (unsigned int)raw & ~AMG_FLAG_MASK;
+  const unsigned int first = ~x_first_inv(first2, claim);
+  const long long f = (long long)(first >> 1);
+  if (f == t) return;  // the first occurrence itself
+  const int dir = tok_dir[t], fdir = (first & 1u) ? -1 : 1;
+  bool same = true;
+  for (int j = 0; j < k; ++j) {
+    const int a = dir > 0 ? tokens[t + j] : flip - tokens[t + k - 1 - j];
+    const int b = fdir > 0 ? tokens[f + j] : flip - tokens[f + k - 1 - j];
+    same = same && a == b;
+  }
+  if (!same) status[ST_COLLISION] = 1;  // benign race: every writer stores 1
+}
+
 // ------------------------------------------------------------------ nodes, four consecutive windows per thread
 // Every gene-mer size (K = 0: k at run time): a thread's 4 + k - 1 tokens leave LDS in 128-bit reads, the
 // common 16-bit packing shares half-words between the windows, the results leave as one 16-byte and one 4-byte
@@ -40,7 +97,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
     int bits, Slot16* tab, unsigned int mask, unsigned int probe_limit, int* __restrict__ tok_claim,
     signed char* __restrict__ tok_dir, unsigned long long* status, unsigned int* first2,
     unsigned int* __restrict__ slot_by_claim, unsigned int cap, XW2 xf, unsigned int tile0,
-    unsigned long long* ctrs, unsigned int head_cap) {
+    unsigned long long* ctrs, unsigned int head_cap, unsigned long long fp_seed, int fp_weak) {
+  // bits == 0 (K == 0 only): the key is a 94-bit fingerprint of the canonical tuple (x_fp94)
   typedef int i4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) int s_tok[TILE + AMG_MAX_K + 4];
   __shared__ unsigned int s_bits[TILE_BIT_WORDS];
@@ -118,7 +176,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_nodes_v(
       } else {
         LdsView win{s_tok + i0 + w};
         dir = canon_dir(win, k, flip);
-        if (dir != 0) x_pack(win, k, flip, dir, bits, w1[w], tag[w]);
+        if (dir != 0) {
+          if (bits == 0)
+            x_fp94(win, k, flip, dir, fp_seed, fp_weak, w1[w], tag[w]);
+          else
+            x_pack(win, k, flip, dir, bits, w1[w], tag[w]);
+        }
       }
       if (dir == 0) {
         status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
@@ -370,7 +433,7 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2,
                                         const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
                                         int k, int nbits, int two, int* __restrict__ final_of_claim,
                                         int* __restrict__ node_tokens, long long* __restrict__ node_first,
-                                        unsigned char* __restrict__ node_alive) {
+                                        unsigned char* __restrict__ node_alive, const int* __restrict__ tokens, int flip) {
   long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_nodes) return;
   if (x_first_inv(first2, c) == 0u) return;  // unclaimed
@@ -379,6 +442,11 @@ __global__ void k_x_assign_nodes_ranked(const unsigned int* __restrict__ first2,
   final_of_claim[c] = (int)i;
   node_first[i] = (long long)first;
   node_alive[i] = 1;
+  if (nbits == 0) {  // fingerprint keys: the tuple is the window at the first-seen position, canonical by its direction bit
+    const long long f = (long long)(first >> 1);
+    for (int j = 0; j < k; ++j) node_tokens[i * k + j] = (first & 1u) ? flip - tokens[f + k - 1 - j] : tokens[f + j];
+    return;
+  }
   const Slot16 s = tab[slot_by_claim[c]];
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys keep the creator's first-seen there
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, nbits, j);
@@ -433,13 +501,19 @@ __global__ void k_x_assign_nodes(const unsigned int* __restrict__ first_sorted,
                                  const Slot16* __restrict__ tab, const unsigned int* __restrict__ slot_by_claim,
                                  int k, int bits, int two, int* __restrict__ final_of_claim,
                                  int* __restrict__ node_tokens, long long* __restrict__ node_first,
-                                 unsigned char* __restrict__ node_alive) {
+                                 unsigned char* __restrict__ node_alive, const int* __restrict__ tokens, int flip) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const unsigned int c = claim_sorted[i];
   final_of_claim[c] = (int)i;
   node_first[i] = (long long)first_sorted[i];
   node_alive[i] = 1;
+  if (bits == 0) {  // fingerprint keys (see k_x_assign_nodes_ranked)
+    const unsigned int first = first_sorted[i];
+    const long long f = (long long)(first >> 1);
+    for (int j = 0; j < k; ++j) node_tokens[i * k + j] = (first & 1u) ? flip - tokens[f + k - 1 - j] : tokens[f + j];
+    return;
+  }
   const Slot16 s = tab[slot_by_claim[c]];
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;  // one-word keys keep the creator's first-seen there
   for (int j = 0; j < k; ++j) node_tokens[i * k + j] = x_unpack(s.w1, tag, bits, j);
@@ -814,13 +888,24 @@ bool bx_applicable(const amg_ctx* c, int k) {
 }
 
 // the tuple fits the slot and first-seen fits 32 bits (per shard in a merged build)
-bool bx_fits(const amg_ctx* c, int k) {
+// the canonical tuple itself fits the 94 key bits of a slot
+bool bx_tuple_fits(const amg_ctx* c, int k) {
   if (c->weak_fp_builds > 0) return false;
-  const char* e = getenv("AMG_KEY_MODE");  // A/B + test switch: "fp" forces the fingerprint path
+  const char* e = getenv("AMG_KEY_MODE");  // A/B + test switch: "fp" forces the 32-byte fingerprint path
   if (e && e[0] == 'f') return false;
   if ((long long)k * bx_bits(c, k) > 94) return false;
   if (c->n_tokens >= (1ll << 29)) return false;  // 32-bit first-seen: (token << 3) | orientation
   return true;
+}
+
+// the 16-byte-slot build applies: the tuple fits, or its 94-bit fingerprint is the key (x_fp94)
+bool bx_fits(const amg_ctx* c, int k) {
+  if (bx_tuple_fits(c, k)) return true;
+  const char* e = getenv("AMG_KEY_MODE");
+  if (e && e[0] == 'f') return false;
+  if (c->n_tokens >= (1ll << 29)) return false;
+  // (a tuple that WOULD fit, with the weak-fingerprint test hook set, keeps exercising the 32-byte path)
+  return (long long)k * bx_bits(c, k) > 94;
 }
 
 // windows -> node table, claim ids, node ids, node arrays.  AMG_E_OVERFLOW + *which = 1: table full
@@ -840,12 +925,13 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
   c->exact_keys = true;
   c->packed_nodes = false;
   c->x_bits = bx_bits(c, k);
+  c->x_fp = (long long)k * c->x_bits > 94;  // the tuple does not fit the slot: its 94-bit fingerprint is the key (x_fp94)
   const long long n_tiles = (T + TILE - 1) / TILE;
 
   // bucket region of the node table (k_nodes_m): one 8-slot line per gene rank in front of the hashed slots, for the
   // gene-mer sizes that have a compile-time kernel; AMG_NODE_BUCKETS=0: hashed slots only (k_nodes_v; A/B switch)
   const char* nb = getenv("AMG_NODE_BUCKETS");
-  const bool buckets = !(nb && atoi(nb) == 0) && !getenv("AMG_X_GENERIC_K") &&
+  const bool buckets = !(nb && atoi(nb) == 0) && !getenv("AMG_X_GENERIC_K") && !c->x_fp &&
                        (k == 3 || k == 5 || k == 7) && n_tiles > 0;
   const size_t home_n = buckets ? (size_t)4 * (size_t)c->two_v : 0;  // 8 slots x (two_v / 2) gene ranks
   const size_t tab_slots = (size_t)c->node_slots + home_n;
@@ -880,7 +966,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
 
   stage_begin(c, (n_tiles > 0 && head_tiles(c, n_tiles) > 0) ? "node_upsert_head" : "node_upsert");
   if (n_tiles > 0) {
-    const bool two = (long long)k * c->x_bits > 63;  // tuple spills into w2?
+    const bool two = c->x_fp || (long long)k * c->x_bits > 63;  // tuple spills into w2?
     if (buckets) {
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
       auto kern = k_nodes_m<false, 3, false>;
@@ -912,7 +998,7 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
       const bool b16 = c->x_bits == 16 && (k == 3 || k == 5);
       auto kern = two ? k_nodes_v<true, 0, false> : k_nodes_v<false, 0, false>;
       auto kern_head = two ? k_nodes_v<true, 0, false, true> : k_nodes_v<false, 0, false, true>;
-      if (!getenv("AMG_X_GENERIC_K")) {  // A/B switch
+      if (!getenv("AMG_X_GENERIC_K") && !c->x_fp) {  // A/B switch
         if (b16 && k == 3) kern = k_nodes_v<false, 3, true>, kern_head = k_nodes_v<false, 3, true, true>;
         else if (b16 && k == 5) kern = k_nodes_v<true, 5, true>, kern_head = k_nodes_v<true, 5, true, true>;
         else if (k == 3) kern = two ? k_nodes_v<true, 3, false> : k_nodes_v<false, 3, false>,
@@ -936,16 +1022,25 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
           stage_begin(c, "node_upsert");
         }
         hipLaunchKernelGGL(part == 0 ? kern_head : kern, dim3((unsigned)cnt), dim3(TILE_THREADS), 0, st, c->tokens.as<int>(),
-                           c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_bits,
+                           c->bnd_bits.as<unsigned int>(), T, k, c->two_v, c->x_fp ? 0 : c->x_bits,
                            c->node_tab.as<Slot16>(), (unsigned int)(c->node_slots - 1), kProbeLimitX,
                            c->tok_slot.as<int>(), c->tok_dir.as<signed char>(),
                            c->status.as<unsigned long long>(), c->x_first.as<unsigned int>(),
                            c->x_slot.as<unsigned int>(), cap, xw2_for(max_claims, T), (unsigned int)lo, ctrs,
-                           (unsigned int)head_cap);
+                           (unsigned int)head_cap, (unsigned long long)c->seed, c->weak_fp_builds > 0 ? 1 : 0);
       }
     }
   }
   stage_end(c);  // the stage is the kernel alone: its time is what bench.py prices against the roofline
+  if (c->x_fp && n_tiles > 0) {
+    // fingerprint keys: every window's tuple against its claim's first occurrence; a mismatch raises ST_COLLISION,
+    // which the next read-back of the status words reports (bx_edges_upsert / bx_nodes_filtered): which = 3
+    stage_begin(c, "node_verify");
+    hipLaunchKernelGGL(k_x_verify_fp, dim3(blocks_for(T, 256)), dim3(256), 0, st, c->tokens.as<int>(), T, k, c->two_v - 1,
+                       c->tok_slot.as<int>(), c->tok_dir.as<signed char>(), c->x_first.as<unsigned int>(),
+                       c->status.as<unsigned long long>());
+    stage_end(c);
+  }
   unsigned long long most = 0;
   AMGCHK(read_status(c, hs, ctrs, ST_NODE_INSERTS, &most, plain));
   if (hs[ST_BADINPUT])
@@ -994,7 +1089,15 @@ int bx_nodes_filtered(amg_ctx* c, int k, unsigned int min_cov, int* which) {
   {
     FetchList l;
     l.add(kept);
-    AMGCHK(fetch(c, l, &D));
+    l.add(c->status.as<unsigned long long>() + ST_COLLISION);
+    unsigned long long v[2] = {0, 0};
+    AMGCHK(fetch(c, l, v));
+    D = v[0];
+    if (v[1]) {  // two gene-mers share a fingerprint (k_x_verify_fp): the build is repeated with the next seed
+      stage_end(c);
+      *which = 3;
+      return AMG_E_OVERFLOW;
+    }
   }
   stage_end(c);
   c->n_nodes = (int64_t)D;
@@ -1023,9 +1126,9 @@ int bx_nodes_rank(amg_ctx* c) {
     hipLaunchKernelGGL(k_x_assign_nodes_ranked, dim3(blocks_for(S, 256)), dim3(256), 0, st,
                        c->x_first.as<unsigned int>(), S,
                        c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
-                       c->x_slot.as<unsigned int>(), k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->x_final.as<int>(),
-                       c->node_tokens.as<int>(),
-                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+                       c->x_slot.as<unsigned int>(), k, c->x_fp ? 0 : c->x_bits, (c->x_fp || (long long)k * c->x_bits > 63) ? 1 : 0,
+                       c->x_final.as<int>(), c->node_tokens.as<int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>(), c->tokens.as<int>(), c->two_v - 1);
   } else if (D > 0) {
     c->rank_flags_clean = 0;  // (s0 is about to be reused by whoever comes next: nothing of it is known to be zero)
     hipLaunchKernelGGL(k_x_sort_keys, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->x_first.as<unsigned int>(),
@@ -1035,8 +1138,9 @@ int bx_nodes_rank(amg_ctx* c) {
                              c->s4.as<unsigned int>(), (size_t)D, ilog2_ceil((uint64_t)T * 2 + 2) + 1));
     hipLaunchKernelGGL(k_x_assign_nodes, dim3(blocks_for(D, 256)), dim3(256), 0, st, c->s2.as<unsigned int>(),
                        c->s4.as<unsigned int>(), D, c->node_tab.as<Slot16>(), c->x_slot.as<unsigned int>(),
-                       k, c->x_bits, (long long)k * c->x_bits > 63 ? 1 : 0, c->x_final.as<int>(), c->node_tokens.as<int>(),
-                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
+                       k, c->x_fp ? 0 : c->x_bits, (c->x_fp || (long long)k * c->x_bits > 63) ? 1 : 0, c->x_final.as<int>(),
+                       c->node_tokens.as<int>(), c->node_first.as<long long>(), c->node_alive.as<unsigned char>(),
+                       c->tokens.as<int>(), c->two_v - 1);
   }
   stage_end(c);
   return AMG_OK;
@@ -1153,6 +1257,10 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   unsigned long long most = 0;
   AMGCHK(read_status(c, hs, ctrs, ST_PAIR_INSERTS, &most, plain));
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "edge pass: a claim id was never published");
+  if (hs[ST_COLLISION]) {  // fingerprint keys: k_x_verify_fp found two gene-mers under one key
+    *which = 3;
+    return AMG_E_OVERFLOW;
+  }
   if (hs[ST_OVERFLOW]) {
     *which = 2;
     return AMG_E_OVERFLOW;

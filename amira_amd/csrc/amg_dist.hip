@@ -355,7 +355,7 @@ extern "C" int amg_dist_nodes_local(amg_ctx* c, int32_t k, int64_t token_base, i
   c->count_inline = false;  // local occurrence counts come from bs_count_by_slot, not per-window atomics
   bs_size_tables(c);
   c->exact_keys = false;
-  c->dist_x = bx_fits(c, k);
+  c->dist_x = bx_tuple_fits(c, k);  // (the records carry the tuple: the slots must hold it)
   if (c->dist_x) return nodes_local_x(c, k, world, send_counts);
   for (int tries = 0;; ++tries) {
     int which = 0;

@@ -204,6 +204,7 @@ struct amg_ctx {
   // ---- exact-key build (amg_build_x.hip): arrays indexed by CLAIM id (order of slot creation)
   bool exact_keys = false;   // this build used the exact-key path
   int x_bits = 0;            // bits per token in the packed tuple
+  bool x_fp = false;         // the tuple does not fit the slot: the key is its 94-bit fingerprint (amg_build_x.hip, x_fp94)
   int64_t x_nspace = 0, x_espace = 0;  // claim ids in use are below these (== n_nodes / n_pairs unless the
                                        // claims came from the shard counters: XShard in amg_x.h)
   int64_t x_max_claims = 0, x_max_eclaims = 0;  // capacity of the per-claim arrays (second half of x_first / x_efirst starts there)
@@ -346,6 +347,7 @@ int ensure_components(amg_ctx* c);
 int ensure_adjacency(amg_ctx* c);
 bool bx_applicable(const amg_ctx* c, int k);
 bool bx_fits(const amg_ctx* c, int k);
+bool bx_tuple_fits(const amg_ctx* c, int k);
 int bx_nodes(amg_ctx* c, int k, int* which);
 int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded = false, bool rank_follows = true);
 int bx_nodes_rank(amg_ctx* c);

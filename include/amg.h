@@ -78,7 +78,10 @@ typedef struct amg_counts_t {
   int32_t k;
   int32_t two_v;
   int32_t exact_keys;     /* 1: the build keyed nodes by the packed tuple itself (k * bits */
-                          /* per token <= 94), 0: by a verified 64-bit fingerprint        */
+                          /* per token <= 94); 2: the same 16-byte slots keyed by a 94-bit */
+                          /* fingerprint, every window verified against its key's first    */
+                          /* occurrence in the token stream; 0: 32-byte slots, verified    */
+                          /* 64-bit fingerprint (>= 2^29 tokens, the merge, AMG_KEY_MODE=fp) */
   int32_t reserved;
 } amg_counts_t;
 

@@ -105,7 +105,8 @@ def test_key_mode_follows_tuple_width(eng):
     assert _run(eng, reads, 6)["exact_keys"] == 1           # 60 bits: one word
     assert _run(eng, reads, 7)["exact_keys"] == 1           # 70 bits: spills into the tag
     assert _run(eng, reads, 9)["exact_keys"] == 1           # 90 bits
-    assert _run(eng, reads, 10)["exact_keys"] == 0          # 100 bits: fingerprint path
+    assert _run(eng, reads, 10)["exact_keys"] == 2          # 100 bits: the same slots keyed by a verified 94-bit fingerprint
+    assert _run(eng, reads, 13)["exact_keys"] == 2          # 130 bits
 
 
 def test_rebuild_on_same_context(eng):

@@ -25,10 +25,10 @@ def _invariants(eng, c, L, k):
 
 
 @pytest.mark.parametrize("workload,k,exact", [("cfg2", None, 1), ("cfg3", None, 1), ("cfg3", 3, 1),
-                                                  ("cfg2", 7, 0), ("cfg3-onecounter", None, 1)])
+                                                  ("cfg2", 7, 2), ("cfg3", 7, 2), ("cfg3-onecounter", None, 1)])
 def test_full_size_build_equals_c_oracle(workload, k, exact, monkeypatch):
     """k = None: the configuration's own k (5: two-word exact keys); k = 3: one-word exact keys;
-    k = 7 on the 5 000-gene vocabulary (98 bits): the verified-fingerprint path"""
+    k = 7 (98 / 112 bits): the 16-byte slots keyed by verified 94-bit fingerprints"""
     import bench
     from amira_amd import Engine
     if workload.endswith("-onecounter"):

@@ -51,6 +51,45 @@ def test_fingerprint_collisions_are_detected_and_rebuilt(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("filtered", [False, True])
+def test_fingerprint_collisions_in_the_16_byte_slots_are_detected_and_rebuilt(monkeypatch, filtered):
+    """k = 11 on a 300-gene vocabulary (110 bits): the tuple does not fit a slot and its 94-bit fingerprint is the key;
+    every window is compared with its claim's first occurrence in the token stream (k_x_verify_fp).  With the fingerprint
+    cut to 12 bits on the first attempt distinct gene-mers share keys: the check must flag it and the rebuild (next
+    seed, full fingerprint) must equal the oracle — in the plain and in the filtered build"""
+    import procedures as P
+    from amira_amd import Engine, tokenize
+    from amira_oracle import GeneMerGraph
+    monkeypatch.setenv("AMG_TEST_WEAK_FP", "1")
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng = Engine(0)
+    eng.set_reads(toks, offs, vocab.two_v)
+    g = GeneMerGraph(reads, 11)
+    if filtered:
+        eng.build_filtered(11, 2, 1)
+        g.filter_graph(2, 1)
+    else:
+        eng.build(11)
+    c = eng.counts()
+    assert c["build_retries"] >= 1 and c["exact_keys"] == 2
+    if filtered:
+        # (a filtered build numbers the survivors only: compared through the plain build + filter of the same engine)
+        other = Engine(0)
+        other.set_reads(toks, offs, vocab.two_v)
+        monkeypatch.delenv("AMG_TEST_WEAK_FP")
+        other.build(11)
+        other.filter(2, 1)
+        compare_engine_to_oracle(other, oracle_arrays(g, vocab, read_ids, offs, 11), live_only=True)
+        a, b = eng.nodes(), other.nodes()
+        live = b["alive"] != 0
+        assert np.array_equal(a["tokens"], b["tokens"][live]) and np.array_equal(a["coverage"], b["coverage"][live])
+        other.close()
+    else:
+        compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 11))
+    eng.close()
+
+
 @pytest.mark.parametrize("key_mode", ["exact", "fp"])
 @pytest.mark.parametrize("damage", ["first_offset", "decreasing", "last_offset", "token_high", "token_negative"])
 def test_malformed_device_csr_is_refused(monkeypatch, key_mode, damage):
