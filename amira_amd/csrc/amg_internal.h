@@ -256,7 +256,7 @@ struct amg_ctx {
   DevBuf gm_q;         // int32 [gapped reads x GF_MAXGAP] question slot per None run
   DevBuf gm_pool;      // int32 path records
   DevBuf gm_gene;      // int32 per pool entry of a one-answer question: last gene of the path node (k_corr_gapped_lean)
-  DevBuf gm_fail;      // int32 [gapped reads] the reads k_corr_gapped_lean left to k_corr_gapped_fast
+  DevBuf gm_fail;      // uint8 [gapped reads] 1: the sixteen-lanes-per-read kernel left the read to the wave-per-read one
   DevBuf gm_ctr;       // uint64[4]         {questions listed, pool ints used}
   DevBuf nw_rec;       // per gapped read: the record k_corr_nw_fast starts from
   DevBuf bnd_bits;     // uint32[(n_tokens >> 5) + pad]: bit t set when a read ends at token t

@@ -1326,8 +1326,8 @@ __global__ __launch_bounds__(64, 8) void k_gap_dfs(GView g, const int* __restric
 // prefix sums run over DPP row shifts (a DPP row IS 16 lanes), and the output genes are written 16 at a time.  Four
 // reads per wave share every instruction and keep four chains of loads in flight.  A read that does not qualify (no
 // memo entry, a question with no or several answers, an answer beyond the inline stretch, a path of one node) is
-// appended to a list that k_corr_gapped_fast then walks: same results by construction, checked against the oracle
-// through the whole sweep at full size and by the fuzzers.
+// flagged for k_corr_gapped_fast: same results by construction, checked against the oracle through the whole sweep at
+// full size and by the fuzzers.
 #define GL_GROUP 16
 #define GL_THREADS 256
 __device__ __forceinline__ int row_scan_incl(int v) {  // inclusive prefix sum inside a DPP row of 16 lanes
@@ -1339,8 +1339,7 @@ __device__ __forceinline__ int row_scan_incl(int v) {  // inclusive prefix sum i
 }
 
 __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, const int* __restrict__ qgene,
-                                                                  int* __restrict__ fail_list,
-                                                                  unsigned long long* __restrict__ n_fail) {
+                                                                  unsigned char* __restrict__ left) {
   // per read and run: {first output index of the run's genes, their number, output - token shift behind them, where
   // the path's genes are in qgene}
   __shared__ int4 s_run[GL_THREADS / GL_GROUP][GL_GROUP];
@@ -1417,15 +1416,9 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_gapped_lean(GapArgs A, cons
     }
     if (l16 == 0) a.new_len[rec.r] = (unsigned int)ng;
   }
-  // the reads left to the wave-per-read kernel: one atomicAdd per wave
-  const bool fail = have && !ok && l16 == 0;
-  const unsigned long long fm = __ballot(fail);
-  if (fm) {
-    unsigned long long base = 0;
-    if (lane == __ffsll((long long)fm) - 1) base = atomicAdd(n_fail, (unsigned long long)__popcll(fm));
-    base = (unsigned long long)bcast_i64((long long)base, __ffsll((long long)fm) - 1);
-    if (fail) fail_list[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)gi;
-  }
+  // the reads left to the wave-per-read kernel: a flag per read (a list would need a counter, and one counter word
+  // takes ~100 returning atomics per microsecond: 30 k waves with a read to hand over were 0.3 ms of this kernel)
+  if (have && l16 == 0) left[gi] = ok ? 0 : 1;
 }
 
 // GF_WPB reads (waves) per workgroup.  The LDS of a workgroup is held until its LAST wave is done
@@ -1682,14 +1675,23 @@ __device__ __forceinline__ void gapped_fast_read(const GapArgs& A, long long gi,
   if (lane == 0) a.new_len[r] = (unsigned int)best_ng;
 }
 
-// list == nullptr: every re-threaded read; else the *n_list reads k_corr_gapped_lean left (a count the host never sees:
-// the workgroups walk the list with a grid stride)
-__global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A, const int* __restrict__ list,
-                                                                    const unsigned long long* __restrict__ n_list) {
+// left == nullptr: every re-threaded read, one per workgroup; else the reads k_corr_gapped_lean flagged: a workgroup
+// takes LEAN_CHUNK consecutive reads, lane l looks at read l's flag and the wave works through the flagged ones
+#define LEAN_CHUNK 32
+__global__ __launch_bounds__(64 * GF_WPB, 8) void k_corr_gapped_fast(GapArgs A, const unsigned char* __restrict__ left) {
   __shared__ GfLds s_lds;
-  const long long n = list ? (long long)*n_list : A.n_gapped;
-  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
-    gapped_fast_read(A, list ? (long long)list[i] : i, (int)threadIdx.x, s_lds);
+  const int lane = (int)threadIdx.x;
+  if (!left) {
+    if ((long long)blockIdx.x < A.n_gapped) gapped_fast_read(A, (long long)blockIdx.x, lane, s_lds);
+    return;
+  }
+  const long long base = (long long)blockIdx.x * LEAN_CHUNK;
+  const bool mine = lane < LEAN_CHUNK && base + lane < A.n_gapped && left[base + lane] != 0;
+  unsigned long long todo = __ballot(mine);
+  while (todo) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    gapped_fast_read(A, base + b, lane, s_lds);
     wave_sync();  // the next read reuses the staging
   }
 }
@@ -2075,13 +2077,21 @@ __device__ __forceinline__ void nw_fast_read(const NwArgs& A, long long gi, int 
   }
 }
 
-// list == nullptr: every re-threaded read; else the *n_list reads k_corr_nw_lean left (a count the host never sees)
-__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A, const int* __restrict__ list,
-                                                               const unsigned long long* __restrict__ n_list) {
+// left == nullptr: every re-threaded read, one per workgroup; else the reads k_corr_nw_lean flagged (see k_corr_gapped_fast)
+__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A, const unsigned char* __restrict__ left) {
   __shared__ NwfLds s_lds;
-  const long long n = list ? (long long)*n_list : A.n_gapped;
-  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
-    nw_fast_read(A, list ? (long long)list[i] : i, (int)threadIdx.x, s_lds);
+  const int lane = (int)threadIdx.x;
+  if (!left) {
+    if ((long long)blockIdx.x < A.n_gapped) nw_fast_read(A, (long long)blockIdx.x, lane, s_lds);
+    return;
+  }
+  const long long base = (long long)blockIdx.x * LEAN_CHUNK;
+  const bool mine = lane < LEAN_CHUNK && base + lane < A.n_gapped && left[base + lane] != 0;
+  unsigned long long todo = __ballot(mine);
+  while (todo) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    nw_fast_read(A, base + b, lane, s_lds);
     wave_sync();  // the next read reuses the staging
   }
 }
@@ -2094,8 +2104,8 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A, const i
 // length - 1) (:1314-1325, replace_invalid_gene_positions :1669-1691).  Everything is bit arithmetic on the read's
 // 64-bit mismatch mask, assembled from the wave's ballots; original positions are read straight from their pool
 // (position numbers trail q by at most two: the loads stay coalesced), nothing is staged but the two gene lists.
-// Reads that are not of this kind (lengths differ, three or more differing places, a shift-equal pair) go to the list
-// k_corr_nw_fast walks.
+// Reads that are not of this kind (lengths differ, three or more differing places, a shift-equal pair) are flagged for
+// k_corr_nw_fast.
 __device__ __forceinline__ unsigned long long group_mask64(const bool* bit, int sh) {  // bit[t] of lane l -> mask bit 16 t + l
   unsigned long long m = 0;
 #pragma unroll
@@ -2103,8 +2113,7 @@ __device__ __forceinline__ unsigned long long group_mask64(const bool* bit, int 
   return m;
 }
 
-__global__ __launch_bounds__(GL_THREADS) void k_corr_nw_lean(NwArgs A, int* __restrict__ fail_list,
-                                                              unsigned long long* __restrict__ n_fail) {
+__global__ __launch_bounds__(GL_THREADS) void k_corr_nw_lean(NwArgs A, unsigned char* __restrict__ left) {
   __shared__ int s_xy[GL_THREADS / GL_GROUP][2][64 + 1];
   const CorrArgs& a = A.a;
   const int lane = threadIdx.x & 63, l16 = threadIdx.x & (GL_GROUP - 1), grp = threadIdx.x / GL_GROUP;
@@ -2188,14 +2197,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_corr_nw_lean(NwArgs A, int* __re
       A.o_ge[q.pdst + i] = ev;
     }
   }
-  const bool fail = mine && !ok && l16 == 0;
-  const unsigned long long fm = __ballot(fail);
-  if (fm) {
-    unsigned long long base = 0;
-    if (lane == __ffsll((long long)fm) - 1) base = atomicAdd(n_fail, (unsigned long long)__popcll(fm));
-    base = (unsigned long long)bcast_i64((long long)base, __ffsll((long long)fm) - 1);
-    if (fail) fail_list[base + __popcll(fm & ((1ull << lane) - 1ull))] = (int)gi;
-  }
+  if (have && l16 == 0) left[gi] = (mine && !ok) ? 1 : 0;  // (a flag per read, not a list: see k_corr_gapped_lean)
 }
 
 // ---- compaction into the corrected CSR
@@ -2565,17 +2567,16 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
         AMGCHK(clear_many(c, gcl));
         const char* nl = getenv("AMG_NO_LEAN_GAPPED");  // A/B + test switch: every read through the wave-per-read kernel
         if (use_fast && gq && !(nl && nl[0] == '1')) {
-          // sixteen lanes per read where every question has one answer; the others are listed for the wave-per-read
-          // kernel, which walks the list with a grid stride (its length stays on the device: gm_ctr[2])
-          AMGCHK(c->gm_fail.ensure((size_t)(n_gapped + 1) * sizeof(int)));
-          unsigned long long* n_fail = c->gm_ctr.as<unsigned long long>() + 2;  // (zeroed with the memo's counters)
+          // sixteen lanes per read where every question has one answer; the others are flagged for the wave-per-read
+          // kernel (no count comes back to the host)
+          AMGCHK(c->gm_fail.ensure((size_t)n_gapped + 64));
           hipLaunchKernelGGL(k_corr_gapped_lean, dim3(nblk(n_gapped, GL_THREADS / GL_GROUP)), dim3(GL_THREADS), 0, st, G,
-                             c->gm_gene.as<int>(), c->gm_fail.as<int>(), n_fail);
-          const unsigned int walkers = (unsigned int)(n_gapped < 16384 ? n_gapped : 16384);
-          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(walkers), dim3(64 * GF_WPB), 0, st, G, c->gm_fail.as<int>(), n_fail);
+                             c->gm_gene.as<int>(), c->gm_fail.as<unsigned char>());
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3(nblk(n_gapped, LEAN_CHUNK)), dim3(64 * GF_WPB), 0, st, G,
+                             c->gm_fail.as<unsigned char>());
         } else if (use_fast) {
-          hipLaunchKernelGGL(k_corr_gapped_fast, dim3((unsigned int)n_gapped), dim3(64 * GF_WPB), 0, st, G, (const int*)nullptr,
-                             (const unsigned long long*)nullptr);
+          hipLaunchKernelGGL(k_corr_gapped_fast, dim3((unsigned int)n_gapped), dim3(64 * GF_WPB), 0, st, G,
+                             (const unsigned char*)nullptr);
         }
       } else {
         AMGCHK(clear_many(c, gcl));  // (the status words alone)
@@ -2632,7 +2633,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
       cl.add(nw_size, (size_t)(n_gapped + 1) * sizeof(long long));
       cl.add(plen, (size_t)(n_gapped + 1) * sizeof(long long));
       cl.add(n_general_d, sizeof(unsigned long long));
-      cl.add(c->gm_ctr.as<unsigned long long>() + 3, sizeof(unsigned long long));  // reads k_corr_nw_lean leaves to k_corr_nw_fast
       AMGCHK(clear_many(c, cl));
     }
     AMGCHK(c->nw_rec.ensure((size_t)(n_gapped + 1) * sizeof(NwRec)));
@@ -2689,17 +2689,15 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     W.allow_fast = allow_fast;
     const char* nln = getenv("AMG_NO_LEAN_NW");  // A/B + test switch: every read through the wave-per-read kernel
     if (W.allow_fast && !(nln && nln[0] == '1')) {
-      // sixteen lanes per read where the diagonal is provably the alignment; the others are listed for the wave-per-read
-      // kernel, which walks the list with a grid stride (its length stays on the device)
-      AMGCHK(c->gm_fail.ensure((size_t)(n_gapped + 1) * sizeof(int)));
-      unsigned long long* n_fail = c->gm_ctr.as<unsigned long long>() + 3;  // (zeroed with the sizes above)
+      // sixteen lanes per read where the diagonal is provably the alignment; the others are flagged for the wave-per-read kernel
+      AMGCHK(c->gm_fail.ensure((size_t)n_gapped + 64));
       hipLaunchKernelGGL(k_corr_nw_lean, dim3(nblk(n_gapped, GL_THREADS / GL_GROUP)), dim3(GL_THREADS), 0, st, W,
-                         c->gm_fail.as<int>(), n_fail);
-      const unsigned int walkers = (unsigned int)(n_gapped < 16384 ? n_gapped : 16384);
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3(walkers), dim3(64 * NWF_WPB), 0, st, W, c->gm_fail.as<int>(), n_fail);
+                         c->gm_fail.as<unsigned char>());
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, LEAN_CHUNK)), dim3(64 * NWF_WPB), 0, st, W,
+                         c->gm_fail.as<unsigned char>());
     } else if (W.allow_fast) {
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W, (const int*)nullptr,
-                         (const unsigned long long*)nullptr);
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W,
+                         (const unsigned char*)nullptr);
     }
     if (n_general > 0)  // reads too long for the register-resident kernel
       hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
