@@ -2077,127 +2077,12 @@ __device__ __forceinline__ void nw_fast_read(const NwArgs& A, long long gi, int 
   }
 }
 
-// left == nullptr: every re-threaded read, one per workgroup; else the reads k_corr_nw_lean flagged (see k_corr_gapped_fast)
-__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A, const unsigned char* __restrict__ left) {
+// (Sixteen lanes per read for the reads whose alignment is provably the diagonal — three reads in four — were built and
+// measured in round 5: 0.27 ms for them plus 0.56 ms for the others against 0.575 ms for everybody here.  The pass IS
+// the reads that fill a matrix, ~3 000 instructions each; the diagonal ones ride along for nothing.)
+__global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   __shared__ NwfLds s_lds;
-  const int lane = (int)threadIdx.x;
-  if (!left) {
-    if ((long long)blockIdx.x < A.n_gapped) nw_fast_read(A, (long long)blockIdx.x, lane, s_lds);
-    return;
-  }
-  const long long base = (long long)blockIdx.x * LEAN_CHUNK;
-  const bool mine = lane < LEAN_CHUNK && base + lane < A.n_gapped && left[base + lane] != 0;
-  unsigned long long todo = __ballot(mine);
-  while (todo) {
-    const int b = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    nw_fast_read(A, base + b, lane, s_lds);
-    wave_sync();  // the next read reuses the staging
-  }
-}
-
-// ---- position carry-over, the common case: SIXTEEN LANES per read (see k_corr_gapped_lean).
-// Equally long gene lists that differ in at most two places (and, for two, are not shift-equal up to the second one)
-// have the diagonal as their only optimal alignment (the proof stands in k_corr_nw_fast above): column q pairs x[q]
-// with y[q], a matching column takes the next unused original position — position number (matches before q) — and
-// a mismatching one takes (end of the nearest earlier matching column or 0, start of the nearest later one or read
-// length - 1) (:1314-1325, replace_invalid_gene_positions :1669-1691).  Everything is bit arithmetic on the read's
-// 64-bit mismatch mask, assembled from the wave's ballots; original positions are read straight from their pool
-// (position numbers trail q by at most two: the loads stay coalesced), nothing is staged but the two gene lists.
-// Reads that are not of this kind (lengths differ, three or more differing places, a shift-equal pair) are flagged for
-// k_corr_nw_fast.
-__device__ __forceinline__ unsigned long long group_mask64(const bool* bit, int sh) {  // bit[t] of lane l -> mask bit 16 t + l
-  unsigned long long m = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) m |= ((__ballot(bit[t]) >> sh) & 0xffffull) << (16 * t);
-  return m;
-}
-
-__global__ __launch_bounds__(GL_THREADS) void k_corr_nw_lean(NwArgs A, unsigned char* __restrict__ left) {
-  __shared__ int s_xy[GL_THREADS / GL_GROUP][2][64 + 1];
-  const CorrArgs& a = A.a;
-  const int lane = threadIdx.x & 63, l16 = threadIdx.x & (GL_GROUP - 1), grp = threadIdx.x / GL_GROUP;
-  const int sh = lane & ~(GL_GROUP - 1);
-  const long long gi = (long long)blockIdx.x * (GL_THREADS / GL_GROUP) + grp;
-  const bool have = gi < A.n_gapped;
-  NwRec q;
-  q.r = 0; q.M = 0; q.N = 0; q.pad = 0; q.t0 = 0; q.dst = 0; q.pdst = 0; q.poff = 0;
-  if (have) q = A.rec[gi];
-  const int N = q.N, M = q.M;
-  const bool mine = have && N > 0;            // (N == 0: original genes kept, or a read for the general kernel)
-  bool ok = mine && N == M && N <= 64;
-  int x[4], y[4];
-  bool mis[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = 16 * t + l16;
-    x[t] = (ok && i < N) ? a.tmp_tok[q.dst + i] : -2;
-    y[t] = (ok && i < N) ? a.tokens[q.t0 + i] : -1;
-  }
-  const long long rl = (ok && a.read_len) ? a.read_len[q.r] : 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = 16 * t + l16;
-    mis[t] = ok && i < N && x[t] != y[t];
-    s_xy[grp][0][i] = x[t];
-    s_xy[grp][1][i] = y[t];
-  }
-  const unsigned long long mm = group_mask64(mis, sh);
-  const int m = __popcll(mm);
-  __syncthreads();
-  bool eqa[4], eqb[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = 16 * t + l16;
-    const bool in = ok && i < N - 1;
-    eqa[t] = in && x[t] == s_xy[grp][1][i + 1];   // x[i] == y[i+1]
-    eqb[t] = in && s_xy[grp][0][i + 1] == y[t];   // x[i+1] == y[i]
-  }
-  const unsigned long long eq_a = group_mask64(eqa, sh), eq_b = group_mask64(eqb, sh);
-  if (m == 2) {
-    const int b = 63 - __clzll((long long)mm);
-    const unsigned long long upto_b = (1ull << b) - 1ull;
-    ok = ok && (eq_a & upto_b) != upto_b && (eq_b & upto_b) != upto_b;
-  } else {
-    ok = ok && m <= 1;
-  }
-  if (ok) {
-    const long long NONE = (long long)0x8000000000000000ull;
-    const long long *pgs, *pge;
-    pos_base(a, q.poff, pgs, pge);
-    const unsigned long long valid = N == 64 ? ~0ull : ((1ull << N) - 1ull);
-    const unsigned long long hit = ~mm & valid;  // matching columns
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = 16 * t + l16;
-      if (i >= N) continue;
-      const unsigned long long below = (1ull << i) - 1ull;
-      long long sv, ev;
-      if ((hit >> i) & 1ull) {
-        const int cur = __popcll(hit & below);
-        sv = pgs[cur];
-        ev = pge[cur];
-      } else {
-        // (None, None): the end of the nearest earlier matching column (0 if none), the start of the nearest later
-        // one (read length - 1 if none); position numbers = matching columns before that column
-        const unsigned long long before = hit & below, after = i >= 63 ? 0ull : (hit >> (i + 1)) << (i + 1);
-        sv = 0;
-        if (before) {
-          const int p = 63 - __clzll((long long)before);
-          sv = pge[__popcll(hit & ((1ull << p) - 1ull))];
-        }
-        ev = rl - 1;
-        if (after) {
-          const int nx = __ffsll((long long)after) - 1;
-          ev = pgs[__popcll(hit & ((1ull << nx) - 1ull))];
-        }
-        (void)NONE;
-      }
-      A.o_gs[q.pdst + i] = sv;
-      A.o_ge[q.pdst + i] = ev;
-    }
-  }
-  if (have && l16 == 0) left[gi] = (mine && !ok) ? 1 : 0;  // (a flag per read, not a list: see k_corr_gapped_lean)
+  if ((long long)blockIdx.x < A.n_gapped) nw_fast_read(A, (long long)blockIdx.x, (int)threadIdx.x, s_lds);
 }
 
 // ---- compaction into the corrected CSR
@@ -2687,18 +2572,8 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     W.big_off = nw_off;
     W.big_buf = c->nw_big.as<unsigned char>();
     W.allow_fast = allow_fast;
-    const char* nln = getenv("AMG_NO_LEAN_NW");  // A/B + test switch: every read through the wave-per-read kernel
-    if (W.allow_fast && !(nln && nln[0] == '1')) {
-      // sixteen lanes per read where the diagonal is provably the alignment; the others are flagged for the wave-per-read kernel
-      AMGCHK(c->gm_fail.ensure((size_t)n_gapped + 64));
-      hipLaunchKernelGGL(k_corr_nw_lean, dim3(nblk(n_gapped, GL_THREADS / GL_GROUP)), dim3(GL_THREADS), 0, st, W,
-                         c->gm_fail.as<unsigned char>());
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3(nblk(n_gapped, LEAN_CHUNK)), dim3(64 * NWF_WPB), 0, st, W,
-                         c->gm_fail.as<unsigned char>());
-    } else if (W.allow_fast) {
-      hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W,
-                         (const unsigned char*)nullptr);
-    }
+    if (W.allow_fast)
+      hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W);
     if (n_general > 0)  // reads too long for the register-resident kernel
       hipLaunchKernelGGL(k_corr_nw, dim3((unsigned int)n_gapped), dim3(64), 0, st, W);
     stage_end(c);

@@ -1165,7 +1165,7 @@ def main():
         kernel_of = {"node_upsert": ("k_nodes_m" if buckets else "k_nodes_v") if exact else "k_node_upsert",
                      "edge_upsert": "k_edges_v" if exact else "k_edges",
                      "node_count": "k_count_ids",
-                     "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_lean + k_corr_nw_fast",
+                     "edge_count": "k_count_ids", "correct_positions": "k_corr_nw_fast",
                      "correct_gapped": "k_corr_gapped_lean + k_corr_gapped_fast"}
         build_ms = sum(stage_tot.get(n, 0.0) for n in ("read_stats", "table_clear", "graph_upsert", "node_table_clear",
                                                         "node_upsert_head", "node_upsert", "node_rank", "node_filter", "edge_table_clear", "edge_upsert_head",

@@ -88,11 +88,9 @@ def test_sweep_synthetic(eng, seed, N, L, V, k, err):
 
 @pytest.mark.parametrize("seed,N,L,V,k,err", [(17, 800, 40, 150, 5, 0.05), (31, 600, 60, 400, 5, 0.04), (11, 400, 24, 200, 3, 0.03)])
 def test_sweep_with_every_read_rethreaded_by_a_wave(eng, monkeypatch, seed, N, L, V, k, err):
-    """AMG_NO_LEAN_GAPPED=1 / AMG_NO_LEAN_NW=1: no read takes the sixteen-lanes-per-read kernels (k_corr_gapped_lean,
-    k_corr_nw_lean: the default for reads whose questions have one answer each / whose alignment is provably the
-    diagonal): the wave-per-read kernels alone give the same corrected reads and positions"""
+    """AMG_NO_LEAN_GAPPED=1: no read takes the sixteen-lanes-per-read kernel (k_corr_gapped_lean, the default for reads
+    whose questions have one answer each): the wave-per-read kernel alone gives the same corrected reads"""
     monkeypatch.setenv("AMG_NO_LEAN_GAPPED", "1")
-    monkeypatch.setenv("AMG_NO_LEAN_NW", "1")
     reads, pos, fq = P.synth_inputs(seed, N, L, V, err)
     run_sweep(eng, reads, pos, fq, k)
 
