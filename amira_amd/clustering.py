@@ -26,10 +26,16 @@ def emulation_ok():
     tuples of big ints / None, once per process, ~2 ms)"""
     global _OK
     if _OK is None:
+        why = "its sets do not iterate as CPython 3.8 - 3.12's do"
         try:
             _OK = _self_check()
-        except Exception:  # noqa: BLE001 - a missing symbol or anything else: the Python path stays in charge
-            _OK = False
+        except Exception as err:  # noqa: BLE001 - a missing symbol or anything else: the Python path stays in charge
+            _OK, why = False, repr(err)
+        if not _OK:
+            import sys
+            sys.stderr.write("amira_amd: the native block search of the read-path clustering is switched off on this "
+                             f"interpreter ({why}); assign_reads_to_genes runs its pure-Python block search, about "
+                             "three times slower, with the same results\n")
     return _OK
 
 
