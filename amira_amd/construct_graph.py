@@ -953,12 +953,26 @@ class GeneMerGraph(BubblePopping):
         if not self._host_edits and getattr(edge, "_amg_id", None) is not None:
             self._settle_leases()
             self._engine.remove_edges([edge._amg_id])
-            self._pass_log.append(("remove_edges", [int(edge._amg_id)]))
+            # a loop that removes many edges one at a time replays as ONE device call (pickling: rebuild + replay)
+            if self._pass_log and self._pass_log[-1][0] == "remove_edges":
+                self._pass_log[-1][1].append(int(edge._amg_id))
+            else:
+                self._pass_log.append(("remove_edges", [int(edge._amg_id)]))
             # (source id, target id, source direction, target direction): tip clipping wants to know whether the twin
             # of every edge removed one at a time is gone as well
             self._lone_edges.add((edge.get_sourceNode()._amg_id, edge.get_targetNode()._amg_id,
                                   edge.get_sourceNodeDirection(), edge.get_targetNodeDirection()))
-            self._invalidate()
+            # the view follows in place instead of being thrown away (re-fetching every array of the graph per removed
+            # edge made such a loop quadratic): the edge's alive flag, which the lazily made edge lists look at, the
+            # source node's list if it exists already, and the edge's entry
+            v = self._v()
+            source = edge.get_sourceNode()   # (a list not made yet is made here, WITH the edge, and loses it below)
+            if edge.get_sourceNodeDirection() == 1:
+                source.remove_forward_edge_hash(edgeHash)
+            if edge.get_sourceNodeDirection() == -1:
+                source.remove_backward_edge_hash(edgeHash)
+            v.arrays["edges"]["alive"][edge._amg_id] = 0
+            del v.edges[edgeHash]
             return
         source = edge.get_sourceNode()
         if edge.get_sourceNodeDirection() == 1:

@@ -294,12 +294,39 @@ __global__ void k_uf_init(int* parent, long long n) {
   if (i < n) parent[i] = (int)i;
 }
 
+// Node ids are first-seen ranks: nine edge classes in ten join ids n and n + 1, so a component is mostly a few long
+// RUNS of consecutive ids.  The runs are linked before any union: starts[n] = 0 where a class (n - 1, n) exists, a
+// prefix sum numbers the runs, every node's parent is its run's first node (a flat forest, parent <= self), and the
+// union-find proper only sees the classes that do NOT join consecutive ids.  (One pass of hooks over all classes built
+// long chains along those runs first and then halved them: 0.11 ms per call for 0.5 M classes, twice per cleaning sweep,
+// and at W emulated ranks the merged graph's 0.5 M x W classes on every rank.)
+__global__ void k_uf_links(const unsigned long long* __restrict__ pkey, long long n_pairs, unsigned int* __restrict__ starts) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const unsigned long long key = pkey[i];
+  const unsigned int a = (unsigned int)((key >> 32) & 0x7fffffffull), b = (unsigned int)(key & 0xffffffffull) - 1u;
+  if (b == a + 1u) starts[b] = 0u;  // (both classes of such a pair, the two signs, store the same word)
+}
+
+__global__ void k_uf_run_starts(const unsigned int* __restrict__ starts, const long long* __restrict__ run_of, long long n,
+                                int* __restrict__ run_start) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && starts[i]) run_start[run_of[i]] = (int)i;
+}
+
+__global__ void k_uf_init_runs(const unsigned int* __restrict__ starts, const long long* __restrict__ run_of,
+                               const int* __restrict__ run_start, long long n, int* __restrict__ parent) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) parent[i] = run_start[run_of[i] + (long long)starts[i] - 1];  // (run_of = runs started BEFORE i)
+}
+
 __global__ void k_uf_union(const unsigned long long* __restrict__ pkey, long long n_pairs, int* parent) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
   unsigned long long key = pkey[i];
   int a = (int)((key >> 32) & 0x7fffffffull);
   int b = (int)((key & 0xffffffffull) - 1ull);
+  if (b == a + 1) return;  // linked as a run already (k_uf_links)
   while (true) {
     a = uf_find(parent, a);
     b = uf_find(parent, b);
@@ -893,10 +920,26 @@ int ensure_components(amg_ctx* c) {
   int* root_copy = reinterpret_cast<int*>(is_root + (D + 2));
   long long ncomp = 0;
   if (D > 0) {
-    hipLaunchKernelGGL(k_uf_init, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D);
-    if (P > 0)
+    if (P > 0) {
+      // runs of consecutive ids first (k_uf_links), the other classes through the union-find
+      AMGCHK(c->s3.ensure((size_t)(D + 2) * sizeof(unsigned int)));
+      AMGCHK(c->s4.ensure((size_t)(D + 2) * sizeof(int)));
+      AMGCHK(c->s5.ensure((size_t)(D + 2) * sizeof(long long)));
+      unsigned int* starts = c->s3.as<unsigned int>();
+      int* run_start = c->s4.as<int>();
+      long long* run_of = c->s5.as<long long>();
+      ClearList cl;
+      cl.add(starts, (size_t)D * sizeof(unsigned int), 1u);
+      AMGCHK(clear_many(c, cl));
+      hipLaunchKernelGGL(k_uf_links, dim3(blocks_for(P, 256)), dim3(256), 0, st, c->pair_key.as<unsigned long long>(), P, starts);
+      AMGCHK(prim_exscan_u32_to_i64(c, starts, run_of, (size_t)D));
+      hipLaunchKernelGGL(k_uf_run_starts, dim3(blocks_for(D, 256)), dim3(256), 0, st, starts, run_of, D, run_start);
+      hipLaunchKernelGGL(k_uf_init_runs, dim3(blocks_for(D, 256)), dim3(256), 0, st, starts, run_of, run_start, D, parent);
       hipLaunchKernelGGL(k_uf_union, dim3(blocks_for(P, 256)), dim3(256), 0, st,
                          c->pair_key.as<unsigned long long>(), P, parent);
+    } else {
+      hipLaunchKernelGGL(k_uf_init, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D);
+    }
     hipLaunchKernelGGL(k_uf_roots, dim3(blocks_for(D, 256)), dim3(256), 0, st, parent, D, is_root, root_copy);
     AMGCHK(prim_exscan_u32_to_i64(c, is_root, c->s1.as<long long>(), (size_t)D + 1));
     hipLaunchKernelGGL(k_uf_label, dim3(blocks_for(D, 256)), dim3(256), 0, st, root_copy,
