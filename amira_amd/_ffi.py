@@ -65,6 +65,7 @@ def _load():
         "amg_get_nodes": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_get_edges": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_get_read_nodes": (C.c_int, [P, P, P]),
+        "amg_get_read_nodes_rows": (C.c_int, [P, P, P, I64, P]),
         "amg_get_node_adj": (C.c_int, [P, P, P]),
         "amg_get_node_reads": (C.c_int, [P, P, P]),
         "amg_filter": (C.c_int, [P, U32, U32]),

@@ -644,13 +644,14 @@ class GeneMerGraph(BubblePopping):
             return self._view
         eng, vocab, k = self._engine, self._vocab, self._kmerSize
         nodes, edges = eng.nodes(), eng.edges()
-        tok_node = eng.read_node_ids()
         adj_off, adj_edge = eng.node_adj()
         v = _View()
         v._nh_table = None
-        # the window directions (60 MB per million reads) and the node -> reads lists (computed on the device for ALL
-        # nodes, 4 bytes per window) are fetched when somebody asks for them: read-path clustering needs neither
-        arrays = v.arrays = _LazyArrays({"nodes": nodes, "edges": edges, "tok_node": tok_node})
+        # the per-window node ids (240 MB per million reads), the window directions (60 MB) and the node -> reads lists
+        # (computed on the device for ALL nodes, 4 bytes per window) are fetched when somebody asks for them: read-path
+        # clustering asks the device for the windows of the reads it looks at instead (Engine.read_node_ids_of)
+        arrays = v.arrays = _LazyArrays({"nodes": nodes, "edges": edges})
+        arrays.makers["tok_node"] = lambda: {"tok_node": eng.read_node_ids()}
         arrays.makers["tok_dir"] = lambda: {"tok_dir": eng.read_dirs()}
         arrays.makers["node_reads_off"] = arrays.makers["node_reads"] = \
             lambda: dict(zip(("node_reads_off", "node_reads"), eng.node_reads()))
@@ -729,7 +730,7 @@ class GeneMerGraph(BubblePopping):
 
         def window_ids(r):
             a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
-            return a, n, tok_node[a:a + n].tolist()
+            return a, n, arrays["tok_node"][a:a + n].tolist()   # (fetched on first use)
 
         def make_nodes(r):
             _, _, ids = window_ids(r)
@@ -2197,17 +2198,14 @@ class GeneMerGraph(BubblePopping):
             off, hit_read, _ = self._engine.match_patterns(1, [[i] for i in wanted])
             off = off.tolist()
             rows_of = {i: hit_read[off[n]:off[n + 1]] for n, i in enumerate(wanted)}
-        tok_node, offs, k = v.arrays["tok_node"], self._read_off, self._kmerSize
+        offs, k = self._read_off, self._kmerSize
         for j in jobs:
             geneOfInterest, node_ids, hashes = j["gene"], j["node_ids"], j["hashes"]
             reads_with_gene, rows = self._reads_on_nodes(node_ids, _rows_of=rows_of)
-            # the reads' node lists, laid end to end
+            # the reads' node lists, laid end to end: gathered on the device (the per-window array of the whole read set
+            # never crosses PCIe for this)
             a = offs[rows]
-            n = offs[rows + 1] - a - k + 1
-            starts = np.zeros(len(rows) + 1, dtype=np.int64)
-            np.cumsum(n, out=starts[1:])
-            within = np.arange(int(starts[-1]), dtype=np.int64) - np.repeat(starts[:-1], n)
-            seq = tok_node[np.repeat(a, n) + within]
+            seq, starts = self._engine.read_node_ids_of(a, offs[rows + 1] - a - k + 1)
             st = _clustering.anchor_stats(seq, starts, np.argsort(rows, kind="stable"), node_ids, len(v.alive))
             anchors = self.get_AMR_anchors(hashes, _stats={h: (bool(x[0]), bool(x[1]), int(x[2]), int(x[3]))
                                                            for h, x in zip(hashes, st.tolist())})

@@ -463,6 +463,42 @@ extern "C" int amg_get_read_nodes(amg_ctx* c, int32_t* tok_node, int8_t* tok_dir
   return AMG_OK;
 }
 
+// the node ids of the windows of a FEW reads, laid end to end (read-path clustering looks at the reads of a gene's
+// nodes: tens of thousands of a million — the whole per-window array is 4 bytes per gene of the read set over PCIe)
+__global__ __launch_bounds__(256) void k_gather_read_nodes(const int* __restrict__ tok_node,
+                                                            const long long* __restrict__ first, const long long* __restrict__ start,
+                                                            long long n_rows, int* __restrict__ out) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const long long a = first[r], o = start[r], n = start[r + 1] - o;
+  for (long long i = threadIdx.x & 63; i < n; i += 64) out[o + i] = tok_node[a + i];
+}
+
+extern "C" int amg_get_read_nodes_rows(amg_ctx* c, const int64_t* first_token, const int64_t* out_start, int64_t n_rows,
+                                       int32_t* node_ids) {
+  NEED_BUILT(c);
+  if (n_rows < 0 || (n_rows > 0 && (!first_token || !out_start || !node_ids))) return amg_fail(AMG_E_ARG, "bad arguments");
+  if (n_rows == 0) return AMG_OK;
+  const long long total = out_start[n_rows];
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const long long n = out_start[r + 1] - out_start[r];
+    if (out_start[0] != 0 || n < 0 || first_token[r] < 0 || first_token[r] + n > c->n_tokens)
+      return amg_fail(AMG_E_ARG, "amg_get_read_nodes_rows: row %lld lies outside the read set", (long long)r);
+  }
+  if (total == 0) return AMG_OK;
+  hipStream_t st = c->stream;
+  AMGCHK(c->s0.ensure((size_t)n_rows * sizeof(long long)));
+  AMGCHK(c->s1.ensure((size_t)(n_rows + 1) * sizeof(long long)));
+  AMGCHK(c->s2.ensure((size_t)total * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(c->s0.p, first_token, (size_t)n_rows * sizeof(long long), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->s1.p, out_start, (size_t)(n_rows + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_gather_read_nodes, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, c->tok_node.as<int>(),
+                     c->s0.as<long long>(), c->s1.as<long long>(), (long long)n_rows, c->s2.as<int>());
+  HIPCHK(hipMemcpyAsync(node_ids, c->s2.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
 extern "C" int amg_get_node_adj(amg_ctx* c, int64_t* offsets, int32_t* edge_ids) {
   NEED_BUILT(c);
   AMGCHK(ensure_adjacency(c));

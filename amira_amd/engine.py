@@ -176,6 +176,16 @@ class Engine:
         check(_ffi.lib.amg_get_read_nodes(self._h, ptr(node), None))
         return node
 
+    def read_node_ids_of(self, first_token, n_windows):
+        """the node ids of the windows of a few reads laid end to end: row r = windows first_token[r] ..
+        first_token[r] + n_windows[r] - 1; returns (node ids, start of every row in them)"""
+        first_token = np.ascontiguousarray(first_token, np.int64)
+        starts = np.zeros(len(first_token) + 1, np.int64)
+        np.cumsum(n_windows, out=starts[1:])
+        out = np.empty(int(starts[-1]), np.int32)
+        check(_ffi.lib.amg_get_read_nodes_rows(self._h, ptr(first_token), ptr(starts), len(first_token), ptr(out)))
+        return out, starts
+
     def read_dirs(self, buf=None):
         """the gene-mer direction per window alone"""
         T = self.sizes()[1]

@@ -175,6 +175,11 @@ int amg_get_edges(amg_ctx* ctx, int32_t* src, int32_t* tgt, int8_t* sdir, int8_t
  * reference's _readNodes) and direction (+1/-1, 0 where no node)
  * — get_readNodes / get_readNodeDirections (construct_graph.py:117-123) */
 int amg_get_read_nodes(amg_ctx* ctx, int32_t* tok_node, int8_t* tok_dir);
+/* the same for a FEW reads: row r = the windows first_token[r] .. first_token[r] + (out_start[r + 1] - out_start[r]) - 1
+ * (token indices of the read set), written to node_ids[out_start[r] ..) — out_start[0] = 0, out_start[n_rows] entries
+ * in all; what read-path clustering asks for the reads of a gene's nodes instead of the whole per-window array */
+int amg_get_read_nodes_rows(amg_ctx* ctx, const int64_t* first_token, const int64_t* out_start, int64_t n_rows,
+                            int32_t* node_ids);
 /* adjacency, 2 rows per node: row 2*n = forwardEdgeHashes, row 2*n+1 =
  * backwardEdgeHashes of node n, edge ids in list order (construct_node.py:79-101);
  * offsets[2*n_nodes + 1], edge_ids[n_edges].  Dead edges stay listed; test `alive`. */
