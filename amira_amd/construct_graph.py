@@ -2162,16 +2162,22 @@ class GeneMerGraph(BubblePopping):
             per_node = [hit_read[off[j]:off[j + 1]] for j in range(len(node_ids))]
         else:
             per_node = [_rows_of[i] for i in node_ids]
-        reads, all_names, all_rows = set(), [], []
-        for j in range(len(node_ids)):
-            rows = per_node[j]
-            if len(rows) > 1:
-                rows = rows[np.concatenate([[True], rows[1:] != rows[:-1]])]   # a read once per node, in read order
-            names = names_of[rows].tolist()
-            reads.update(names)
-            all_names += names
-            all_rows += rows.tolist()
-        row_of = dict(zip(all_names, all_rows))
+        # The reference's set is filled node by node with every read of the node (update() with a LIST: item by item, a
+        # name already there changes nothing), so what the set becomes — and the order in which it iterates — follows
+        # from the FIRST time each read shows up in that sequence alone: the rows' first occurrences, in order, are
+        # found on the arrays and only those names are made and added (a read sits on ~k nodes of a gene: one name in
+        # five of the sequence).
+        seq = np.concatenate(per_node).astype(np.int64) if per_node else np.zeros(0, np.int64)
+        reads = set()
+        if len(seq) == 0:
+            return reads, np.zeros(0, np.int64)
+        at = np.arange(len(seq), dtype=np.int64)
+        first_at = np.empty(int(seq.max()) + 1, np.int64)
+        first_at[seq[::-1]] = at[::-1]                  # (written back to front: the first occurrence is what stays)
+        order = seq[first_at[seq] == at]                # distinct rows in the order they first appear
+        names = names_of[order].tolist()
+        reads.update(names)
+        row_of = dict(zip(names, order.tolist()))
         self._known_rows.update(row_of)
         return reads, np.asarray(list(map(row_of.__getitem__, reads)), dtype=np.int64)
 
