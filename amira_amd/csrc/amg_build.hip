@@ -385,7 +385,7 @@ __global__ void k_uf_label(const int* __restrict__ root, const long long* __rest
 // with a second launch that walks the segments, microseconds, instead of a second sweep over the whole array for a few
 // thousand increments.  list: [0] a segment ran over (the list is then not used), [2 + b] ids in workgroup b's segment,
 // segments from COUNT_LIST_HEAD on.
-#define COUNT_LIST_SEG 2048  // (256 ran over on the node count of a first build: ~270 k second occurrences of error gene-mers beyond the LDS range)
+#define COUNT_LIST_SEG 256
 #define COUNT_MAX_BLOCKS 256
 #define COUNT_LIST_HEAD (2 + COUNT_MAX_BLOCKS)
 // state: [0..3] ids beyond the range of sweep r, [4..7] sweep r finished the job
