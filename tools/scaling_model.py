@@ -1,4 +1,4 @@
-"""usage: python tools/scaling_model.py [reads_per_rank] > profiles/r4_scaling_model.json
+"""usage: python tools/scaling_model.py [reads_per_rank [worlds, e.g. 1,8]] > profiles/r5_scaling_model.json
 
 A MODEL, not a measurement, of `bench.py --gpus N` (weak scaling, N x reads_per_rank reads, every build merged by key
 owner): the whole cleaning sweep is run with W = 1, 2, 4, 8 EMULATED ranks on the one GPU there is (one Engine per
@@ -24,6 +24,7 @@ from amira_amd import Engine
 from amira_amd import dist as D
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+WORLDS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8)   # a subset: for a profiler run
 LINK_GBS, COLL_LAT_US, SYNC_US = 153.0 * 0.8, 25.0, 60.0   # xGMI link (80 % of 153 GB/s), per-collective latency, host round trip
 w = bench.WORKLOADS["cfg3-sweep"]
 L, k = w["L"], w["k"]
@@ -93,7 +94,7 @@ for rep in range(3):
 e.close()
 out["single_gpu_fused_sweep_ms"] = round(single, 3)
 
-for W in (1, 2, 4, 8):
+for W in WORLDS:
     vocab, toks, offs = bench.make_tokens(w, 0, W * N)
     engines = []
     for r in range(W):
@@ -141,7 +142,7 @@ for W in (1, 2, 4, 8):
         "predicted_weak_scaling_efficiency_vs_single_gpu_sweep": round(single / (t_rank + t_wire + t_sync), 3)}
     for en in engines:
         en.close()
-base = out["worlds"]["1"]["predicted_sweep_ms"]
+base = out["worlds"].get("1", {}).get("predicted_sweep_ms", float("nan"))
 for W in out["worlds"]:
     out["worlds"][W]["predicted_weak_scaling_efficiency_vs_merged_n1"] = round(base / out["worlds"][W]["predicted_sweep_ms"], 3)
 print(json.dumps(out, indent=1))
