@@ -280,6 +280,75 @@ __global__ void k_row_offsets(const unsigned int* __restrict__ keys, long long n
   for (long long r = prev + 1; r <= cur; ++r) off[r] = i;
 }
 
+// The same lists WITHOUT a sort, for graphs of up to a few million edges (every graph of a cleaning sweep after the first
+// filter): a library radix sort is a dozen launches of ~5 us whatever it sorts.
+//   k_adjc_ticket  every edge draws a ticket of its row (rows zeroed before): row sizes and a place inside the row
+//   (scan)         row sizes -> CSR offsets
+//   k_adjc_fill    every edge drops its id at offset + ticket (any order within the row)
+//   k_adjc_rows    a thread per row puts the row's ids in ascending order (= list order: edge ids follow insertion
+//                  order); rows longer than ADJ_SMALL are left to k_adjc_long, a workgroup per long row (hub nodes)
+#define ADJ_SMALL 32
+__device__ __forceinline__ unsigned int adj_row_of(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir,
+                                                   long long e) {
+  return 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
+}
+
+__global__ void k_adjc_ticket(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir, long long n_edges,
+                              unsigned int* __restrict__ cnt, unsigned int* __restrict__ tick) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_edges) tick[e] = atomicAdd(&cnt[adj_row_of(e_src, e_sdir, e)], 1u);
+}
+
+__global__ void k_adjc_fill(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir, long long n_edges,
+                            const long long* __restrict__ off, const unsigned int* __restrict__ tick,
+                            unsigned int* __restrict__ tmp) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_edges) tmp[off[adj_row_of(e_src, e_sdir, e)] + tick[e]] = (unsigned int)e;
+}
+
+__global__ void k_adjc_rows(const long long* __restrict__ off, long long n_rows, const unsigned int* __restrict__ tmp,
+                            int* __restrict__ adj_edge, unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const long long o = off[r];
+  const int cnt = (int)(off[r + 1] - o);
+  if (cnt == 0) return;
+  if (cnt > ADJ_SMALL) {
+    long_rows[atomicAdd(n_long, 1ull)] = (unsigned int)r;
+    return;
+  }
+  unsigned int e[ADJ_SMALL];
+  for (int j = 0; j < cnt; ++j) {  // insertion sort: tickets come nearly in order
+    const unsigned int x = tmp[o + j];
+    int p = j;
+    while (p > 0 && e[p - 1] > x) {
+      e[p] = e[p - 1];
+      --p;
+    }
+    e[p] = x;
+  }
+  for (int j = 0; j < cnt; ++j) adj_edge[o + j] = (int)e[j];
+}
+
+// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids
+__global__ __launch_bounds__(256) void k_adjc_long(const unsigned int* __restrict__ long_rows,
+                                                   const unsigned long long* __restrict__ n_long,
+                                                   const long long* __restrict__ off, const unsigned int* __restrict__ tmp,
+                                                   int* __restrict__ adj_edge) {
+  const unsigned long long n = *n_long;
+  for (unsigned long long q = blockIdx.x; q < n; q += gridDim.x) {
+    const unsigned int r = long_rows[q];
+    const long long o = off[r];
+    const int cnt = (int)(off[r + 1] - o);
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const unsigned int x = tmp[o + j];
+      int rank = 0;
+      for (int i = 0; i < cnt; ++i) rank += tmp[o + i] < x ? 1 : 0;
+      adj_edge[o + rank] = (int)x;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ components
 // Union-find with parent[x] <= x.  Only the hook (a root gets a smaller parent) is an atomic;
 // every other access is a PLAIN load or store that the issuing XCD's L2 may serve stale.  That
@@ -966,6 +1035,34 @@ int ensure_adjacency(amg_ctx* c) {
   AMGCHK(c->s1.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->s2.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->s3.ensure((size_t)(E + 2) * sizeof(unsigned int)));
+  const char* force_sort = getenv("AMG_ADJ_SORT");  // A/B switch and test hook: the sorted route for every graph
+  if (E > 0 && E <= (4ll << 20) && !(force_sort && force_sort[0] == '1')) {
+    AMGCHK(c->s1.ensure((size_t)(2 * D + 2 > E + 2 ? 2 * D + 2 : E + 2) * sizeof(unsigned int)));
+    unsigned int* cnt = c->s1.as<unsigned int>();
+    unsigned int* tick = c->s2.as<unsigned int>();
+    unsigned int* tmp = c->s3.as<unsigned int>();
+    AMGCHK(c->s4.ensure((size_t)(E / ADJ_SMALL + 2) * sizeof(unsigned int)));
+    unsigned int* long_rows = c->s4.as<unsigned int>();
+    unsigned long long* n_long = c->status.as<unsigned long long>() + ST_COMPACT_B;
+    {
+      ClearList cl;
+      cl.add(cnt, (size_t)(2 * D + 2) * sizeof(unsigned int));
+      cl.add(n_long, sizeof(unsigned long long));
+      AMGCHK(clear_many(c, cl));
+    }
+    hipLaunchKernelGGL(k_adjc_ticket, dim3(blocks_for(E, 256)), dim3(256), 0, st, c->edge_src.as<int>(),
+                       c->edge_sdir.as<signed char>(), E, cnt, tick);
+    AMGCHK(prim_exscan_u32_to_i64(c, cnt, c->adj_off.as<long long>(), (size_t)(2 * D + 1)));
+    hipLaunchKernelGGL(k_adjc_fill, dim3(blocks_for(E, 256)), dim3(256), 0, st, c->edge_src.as<int>(),
+                       c->edge_sdir.as<signed char>(), E, c->adj_off.as<long long>(), tick, tmp);
+    hipLaunchKernelGGL(k_adjc_rows, dim3(blocks_for(2 * D, 256)), dim3(256), 0, st, c->adj_off.as<long long>(), 2 * D, tmp,
+                       c->adj_edge.as<int>(), long_rows, n_long);
+    hipLaunchKernelGGL(k_adjc_long, dim3(256), dim3(256), 0, st, long_rows, n_long, c->adj_off.as<long long>(), tmp,
+                       c->adj_edge.as<int>());
+    stage_end(c);
+    c->adj_valid = true;
+    return AMG_OK;
+  }
   if (E > 0) {
     hipLaunchKernelGGL(k_adj_keys, dim3(blocks_for(E, 256)), dim3(256), 0, st,
                        c->edge_src.as<int>(), c->edge_sdir.as<signed char>(), E,

@@ -113,6 +113,7 @@ enum {
   ST_COMPACT_B = 8,
   ST_MISC = 9,
   ST_BADINPUT = 10,      // malformed CSR: 1 = read offsets, 2 = a token outside [0, two_v)
+  ST_COV_SUM = 11,       // tip clipping: sum of the live nodes' coverages, [12] = number of live nodes
   ST_WORDS = 16
 };
 
@@ -189,7 +190,7 @@ struct amg_ctx {
   DevBuf ladj_off;  // int64[2 n_nodes + 1]
   DevBuf ladj;      // int2[n_live_edges]  {target node, target direction}
   DevBuf ladj_rows; // int4[2 n_nodes]  {offset, live count, first target, first direction}
-  DevBuf ladj_cnt, ladj_pos, ladj_keys;  // scratch of the live-adjacency build (callers hold s0..s5)
+  DevBuf ladj_pos, ladj_keys;  // scratch of the live-adjacency build (callers hold s0..s5)
   bool ladj_valid = false;
   bool comp_valid = false, adj_valid = false;  // component ids / full edge lists of the built graph are made on demand
   // reads
@@ -276,6 +277,13 @@ int prim_sort_u32_u32(amg_ctx* c, const unsigned int* kin, unsigned int* kout,
                       const unsigned int* vin, unsigned int* vout, size_t n, int end_bit);
 int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n);
 int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, size_t n);
+int prim_exscan_u32_pair(amg_ctx* c, const unsigned int* in_a, long long* out_a, const unsigned int* in_b, long long* out_b,
+                         size_t n);
+int prim_exscan_i64_pair(amg_ctx* c, const long long* in_a, long long* out_a, const long long* in_b, long long* out_b,
+                         size_t n);
+int prim_exscan_bytes_set(amg_ctx* c, const unsigned char* in, long long* out, size_t n);
+int prim_exscan_apply_kill(amg_ctx* c, unsigned char* kill, unsigned char* alive, long long* out, size_t n);
+int prim_exscan_keep_and_len(amg_ctx* c, const unsigned int* len, long long* out_keep, long long* out_off, size_t n);
 int prim_exscan_flag_words(amg_ctx* c, const unsigned char* flags, unsigned int* bits, long long* out, size_t n_words);
 int prim_exscan_bits_popc(amg_ctx* c, const unsigned int* bits, long long* out, size_t n_words);
 int prim_exscan_pair_width(amg_ctx* c, const unsigned long long* pkey, long long* out, size_t n_pairs);

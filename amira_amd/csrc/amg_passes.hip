@@ -147,12 +147,6 @@ struct GView {
 // Live adjacency straight from the live edges: flag + scan squeezes the removed edges out in edge
 // order, a stable sort by row (2 * source + side) groups them, so a row lists its live edges in
 // the order of the reference's forward / backward lists (edge ids ascend in insertion order).
-__global__ void k_live_flags(const unsigned char* __restrict__ e_alive, long long n_edges,
-                             unsigned int* __restrict__ flags) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e <= n_edges) flags[e] = (e < n_edges && e_alive[e]) ? 1u : 0u;
-}
-
 __global__ void k_live_keys(const unsigned char* __restrict__ e_alive, const int* __restrict__ e_src,
                             const signed char* __restrict__ e_sdir, const long long* __restrict__ pos,
                             long long n_edges, unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
@@ -275,7 +269,6 @@ static int ensure_live_adj(amg_ctx* c) {
   hipStream_t st = c->stream;
   const long long rows = 2 * c->n_nodes, E = c->n_edges;
   AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
-  AMGCHK(c->ladj_cnt.ensure((size_t)(E + 2) * sizeof(unsigned int)));
   AMGCHK(c->ladj_pos.ensure((size_t)(E + 2) * sizeof(long long)));
   unsigned long long* ctr = c->status.as<unsigned long long>() + ST_COMPACT_A;  // [0] entries handed out, [1] long rows
   {
@@ -284,9 +277,7 @@ static int ensure_live_adj(amg_ctx* c) {
     cl.add(ctr, 2 * sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
   }
-  hipLaunchKernelGGL(k_live_flags, dim3(nblk(E + 1, 256)), dim3(256), 0, st, c->edge_alive.as<unsigned char>(), E,
-                     c->ladj_cnt.as<unsigned int>());
-  AMGCHK(prim_exscan_u32_to_i64(c, c->ladj_cnt.as<unsigned int>(), c->ladj_pos.as<long long>(), (size_t)E + 1));
+  AMGCHK(prim_exscan_bytes_set(c, c->edge_alive.as<unsigned char>(), c->ladj_pos.as<long long>(), (size_t)E));
   long long total = 0;
   {
     FetchList l;
@@ -370,7 +361,10 @@ extern "C" int amg_remove_edges(amg_ctx* c, const int32_t* edge_ids, int64_t n) 
 
 // ------------------------------------------------------------------ remove_short_linear_paths (:679-720)
 #define CLIP_MAX 64
-__global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double thr,
+// acc = {sum of the live nodes' coverages, number of live nodes} (k_comp_hist): the threshold is 1.5 x their mean
+// (:868-871, statistics.mean over live nodes) — the quotient of the two integers as doubles is correctly rounded,
+// == float(Fraction(sum, n)), on the device as on the host
+__global__ void k_clip_mark(GView g, long long n_nodes, int min_length, const unsigned long long* __restrict__ acc,
                             const unsigned int* __restrict__ comp_live,
                             const unsigned char* __restrict__ protect,
                             unsigned char* __restrict__ kill) {
@@ -398,6 +392,7 @@ __global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double t
     r = lin_step(g, tgt, td == 1, &tgt, &td);
   }
   if (!(len > 0 && len < min_length)) return;
+  const double thr = ((double)acc[0] / (double)acc[1]) * 1.5;
   bool all_high = true;
   for (int j = 0; j < len; ++j) all_high = all_high && ((double)g.n_cov[path[j]] > thr);
   if (all_high) return;
@@ -418,11 +413,17 @@ __global__ void k_clip_mark(GView g, long long n_nodes, int min_length, double t
 // thousands of atomics on one address, ~90 per microsecond)
 __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* __restrict__ alive,
                             const unsigned int* __restrict__ cov, long long n, unsigned int min_cov,
-                            unsigned int* __restrict__ live_cnt, unsigned int* __restrict__ high_cnt) {
+                            unsigned int* __restrict__ live_cnt, unsigned int* __restrict__ high_cnt,
+                            unsigned long long* __restrict__ acc /* or null: {sum of live coverages, live nodes} */) {
   int cid = -1;
   unsigned int n_live = 0, n_high = 0;
+  unsigned long long s_cov = 0, s_n = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     if (!alive[i]) continue;
+    if (acc) {
+      s_cov += cov[i];
+      s_n += 1;
+    }
     const int id = comp[i];
     if (id != cid) {
       if (cid >= 0) {
@@ -435,8 +436,18 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
     ++n_live;
     n_high += (high_cnt && cov[i] >= min_cov) ? 1u : 0u;
   }
-  bool active = cid >= 0;
   const int lane = threadIdx.x & 63;
+  if (acc) {
+    for (int d = 32; d > 0; d >>= 1) {
+      s_cov += __shfl_xor(s_cov, d, 64);
+      s_n += __shfl_xor(s_n, d, 64);
+    }
+    if (lane == 0 && s_n) {
+      atomicAdd(&acc[0], s_cov);
+      atomicAdd(&acc[1], s_n);
+    }
+  }
+  bool active = cid >= 0;
   // most nodes share one giant component: aggregate equal ids inside the wave so that a
   // wave issues one atomic per distinct component instead of one per node
   unsigned long long todo = __ballot(active);
@@ -459,49 +470,20 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
   }
 }
 
-__global__ void k_cov_sum(const unsigned int* __restrict__ cov, const unsigned char* __restrict__ alive,
-                          long long n, unsigned long long* out /*[2]: sum, count*/) {
-  unsigned long long s = 0, c = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    if (alive[i]) {
-      s += cov[i];
-      c += 1;
-    }
-  for (int d = 32; d > 0; d >>= 1) {
-    s += __shfl_down(s, d, 64);
-    c += __shfl_down(c, d, 64);
-  }
-  if ((threadIdx.x & 63) == 0 && c) {
-    atomicAdd(&out[0], s);
-    atomicAdd(&out[1], c);
-  }
-}
-
-__global__ void k_apply_kill(const unsigned char* __restrict__ kill, unsigned char* __restrict__ alive,
-                             long long n, unsigned int* __restrict__ flag32) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned int f = (kill[i] && alive[i]) ? 1u : 0u;
-  if (f) alive[i] = 0;
-  flag32[i] = f;
-}
-
-__global__ void k_scatter_ids(const unsigned int* __restrict__ flag32, const long long* __restrict__ pos,
+__global__ void k_scatter_ids(const unsigned char* __restrict__ killed, const long long* __restrict__ pos,
                               long long n, int* __restrict__ out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flag32[i]) out[pos[i]] = (int)i;
+  if (i < n && killed[i]) out[pos[i]] = (int)i;
 }
 
 // kill[] (s0) -> node_alive, removal side effects, ascending list of removed ids
 static int finish_kill(amg_ctx* c, int64_t* n_removed, int32_t* removed_ids) {
   hipStream_t st = c->stream;
   const long long D = c->n_nodes;
-  AMGCHK(c->s1.ensure((size_t)(D + 2) * sizeof(unsigned int)));
   AMGCHK(c->s2.ensure((size_t)(D + 2) * sizeof(long long)));
-  hipLaunchKernelGGL(k_apply_kill, dim3(nblk(D, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
-                     c->node_alive.as<unsigned char>(), D, c->s1.as<unsigned int>());
-  HIPCHK(hipMemsetAsync(c->s1.as<unsigned int>() + D, 0, sizeof(unsigned int), st));
-  AMGCHK(prim_exscan_u32_to_i64(c, c->s1.as<unsigned int>(), c->s2.as<long long>(), (size_t)D + 1));
+  // the scan applies what it counts: a marked live node dies, kill[] is left as "removed by this call"
+  AMGCHK(prim_exscan_apply_kill(c, c->s0.as<unsigned char>(), c->node_alive.as<unsigned char>(), c->s2.as<long long>(),
+                                (size_t)D));
   long long total = 0;
   {
     FetchList l;
@@ -511,7 +493,7 @@ static int finish_kill(amg_ctx* c, int64_t* n_removed, int32_t* removed_ids) {
   if (n_removed) *n_removed = total;
   if (removed_ids && total > 0) {
     AMGCHK(c->s3.ensure((size_t)total * sizeof(int)));
-    hipLaunchKernelGGL(k_scatter_ids, dim3(nblk(D, 256)), dim3(256), 0, st, c->s1.as<unsigned int>(),
+    hipLaunchKernelGGL(k_scatter_ids, dim3(nblk(D, 256)), dim3(256), 0, st, c->s0.as<unsigned char>(),
                        c->s2.as<long long>(), D, c->s3.as<int>());
     HIPCHK(hipMemcpyAsync(removed_ids, c->s3.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, st));
   }
@@ -532,31 +514,20 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   stages_reset(c);
   AMGCHK(ensure_components(c));
   stage_begin(c, "clip");
-  // mean node coverage (:868-871): statistics.mean over live nodes, * 1.5 in double
-  unsigned long long* acc = c->status.as<unsigned long long>() + ST_COMPACT_A;
-  HIPCHK(hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(k_cov_sum, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_cov.as<unsigned int>(),
-                     c->node_alive.as<unsigned char>(), D, acc);
-  unsigned long long h[2] = {0, 0};
-  {
-    FetchList l;
-    l.add_words(acc, 2);
-    AMGCHK(fetch(c, l, h));
-  }
-  if (h[1] == 0) { stage_end(c); return AMG_OK; }
-  double mean = (double)h[0] / (double)h[1];  // correctly rounded, == float(Fraction(sum, n))
-  double thr = mean * 1.5;
+  // live nodes per component, and the mean node coverage's two integers (:868-871), in one pass
+  unsigned long long* acc = c->status.as<unsigned long long>() + ST_COV_SUM;  // (the live adjacency below uses ST_COMPACT_*)
   AMGCHK(c->s0.ensure((size_t)D + 8));
   AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
   {
     ClearList cl;
+    cl.add(acc, 2 * sizeof(unsigned long long));
     cl.add(c->s0.p, (size_t)D + 8);
     cl.add(c->s4.p, (size_t)(c->n_components + 2) * sizeof(unsigned int));
     AMGCHK(clear_many(c, cl));
   }
   hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
-                     c->s4.as<unsigned int>(), (unsigned int*)nullptr);
+                     c->s4.as<unsigned int>(), (unsigned int*)nullptr, acc);
   unsigned char* d_protect = nullptr;
   if (protect) {
     AMGCHK(c->s5.ensure((size_t)D + 8));
@@ -565,7 +536,7 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   }
   AMGCHK(ensure_live_adj(c));
   hipLaunchKernelGGL(k_clip_mark, dim3(nblk(D, 128)), dim3(128), 0, st, make_view(c), D, (int)min_length,
-                     thr, c->s4.as<unsigned int>(), d_protect, c->s0.as<unsigned char>());
+                     acc, c->s4.as<unsigned int>(), d_protect, c->s0.as<unsigned char>());
   int r = finish_kill(c, n_removed, removed_ids);
   stage_end(c);
   c->have_corrected = false;
@@ -598,7 +569,8 @@ extern "C" int amg_remove_low_coverage_components(amg_ctx* c, uint32_t min_cov) 
   unsigned int* live = c->s4.as<unsigned int>();
   unsigned int* high = live + nc;
   hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
-                     c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, min_cov, live, high);
+                     c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, min_cov, live, high,
+                     (unsigned long long*)nullptr);
   hipLaunchKernelGGL(k_kill_low_components, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_comp.as<int>(),
                      c->node_alive.as<unsigned char>(), high, D, c->s0.as<unsigned char>());
   c->have_corrected = false;
@@ -648,6 +620,7 @@ struct CorrArgs {
   unsigned long long* lmask;      // live-window mask of a flagged read with <= 64 windows (0 otherwise)
   unsigned long long* n_runs;     // None runs over all re-threaded reads: 16 partial sums, 16 words apart
   unsigned char* cls;
+  unsigned char* cls_final;  // starts as a copy of cls (k_corr_classify writes both); the re-threading may turn a read into RC_KEEP_ORIG
   int* r_start;
   int* r_end;
   unsigned int* bound;
@@ -784,6 +757,7 @@ __global__ __launch_bounds__(256) void k_corr_classify(CorrArgs a) {
   }
   if (have) {
     a.cls[r] = cls;
+    a.cls_final[r] = cls;
     a.r_start[r] = start;
     a.r_end[r] = end;
     a.bound[r] = bound;    // temp space: only re-threaded reads are staged
@@ -2085,17 +2059,10 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   if ((long long)blockIdx.x < A.n_gapped) nw_fast_read(A, (long long)blockIdx.x, (int)threadIdx.x, s_lds);
 }
 
-// ---- compaction into the corrected CSR
-__global__ void k_corr_keep(const unsigned int* __restrict__ new_len, long long n_reads,
-                            unsigned int* __restrict__ keep) {
-  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads) keep[r] = new_len[r] > 0 ? 1u : 0u;  // len(list_of_genes) > 0 (:1130)
-}
-
+// ---- compaction into the corrected CSR: a read is kept when len(list_of_genes) > 0 (:1130)
 struct PackArgs {
   CorrArgs a;
-  const unsigned int* keep;
-  const long long* new_idx;    // exscan(keep)
+  const long long* new_idx;    // exscan(new_len > 0)
   const long long* new_off;    // exscan(new_len)
   const unsigned char* final_cls;
   int* o_tok;
@@ -2123,7 +2090,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   if (blockIdx.x == 0 && threadIdx.x == 0) A.o_off[A.out_reads] = A.out_tokens;
   long long dst = 0, src = 0;  // src: token index; bit 62 set = in the temp area
   int n = 0;
-  if (r < a.n_reads && A.keep[r]) {
+  if (r < a.n_reads && a.new_len[r] > 0) {
     dst = A.new_off[r];
     n = (int)a.new_len[r];
     const unsigned char fc = A.final_cls[r];
@@ -2308,6 +2275,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.flip = c->two_v - 1;
   a.have_pos = c->have_pos ? 1 : 0;
   a.cls = cls;
+  a.cls_final = final_cls;
   a.r_start = r_start;
   a.r_end = r_end;
   a.bound = bound;
@@ -2332,12 +2300,11 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.lmask = c->gm_mask.as<unsigned long long>();
   a.n_runs = n_runs_d;
   if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * CLS_READS)), dim3(256), 0, st, a);  // also new_len, flag, max
-  AMGCHK(prim_exscan_u32_to_i64(c, bound, tmp_off, (size_t)R + 1));
+  // where the re-threaded reads' genes are staged, and the list of gapped reads: two scans, one launch
+  AMGCHK(prim_exscan_u32_pair(c, bound, tmp_off, flag, new_idx, (size_t)R));
   long long tmp_total = 0;
   unsigned long long max_bound = 0;
 
-  // list of gapped reads
-  AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
   long long n_gapped = 0, total_runs = 0;
   {
     FetchList l;
@@ -2358,7 +2325,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   DevBuf& tmpTok = c->s4;
   AMGCHK(tmpTok.ensure((size_t)(tmp_total + 4) * sizeof(int)));
   a.tmp_tok = tmpTok.as<int>();
-  HIPCHK(hipMemcpyAsync(final_cls, cls, (size_t)R, hipMemcpyDeviceToDevice, st));
 
   if (n_gapped > 0) {
     stage_begin(c, "live_adjacency");
@@ -2482,15 +2448,8 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   // ---- shape of the corrected set (before the position carry-over, which writes its reads'
   // positions straight into the output arrays)
   stage_begin(c, "correct_pack");
-  if (R > 0) hipLaunchKernelGGL(k_corr_keep, dim3(nblk(R, 256)), dim3(256), 0, st, new_len, R, flag);
-  {
-    ClearList cl;
-    cl.add(flag + R, sizeof(unsigned int));
-    cl.add(new_len + R, sizeof(unsigned int));
-    AMGCHK(clear_many(c, cl));
-  }
-  AMGCHK(prim_exscan_u32_to_i64(c, flag, new_idx, (size_t)R + 1));
-  AMGCHK(prim_exscan_u32_to_i64(c, new_len, new_off, (size_t)R + 1));
+  // which reads stay and where their genes go: both scans in one launch, straight from the lengths
+  AMGCHK(prim_exscan_keep_and_len(c, new_len, new_idx, new_off, (size_t)R));
   long long out_reads = 0, out_tokens = 0;
   FetchList shape;
   shape.add(new_idx + R);
@@ -2524,8 +2483,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     hipLaunchKernelGGL(k_nw_sizes, dim3(nblk(n_gapped, 256)), dim3(256), 0, st, c->c_orig.as<int>(),
                        n_gapped, a.read_off, new_len, tmp_off, new_off, final_cls, nw_size, allow_fast,
                        n_general_d, c->nw_rec.as<NwRec>(), a.pos_off, plen);
-    AMGCHK(prim_exscan_i64(c, nw_size, nw_off, (size_t)n_gapped + 1));
-    AMGCHK(prim_exscan_i64(c, plen, poffs, (size_t)n_gapped + 1));
+    AMGCHK(prim_exscan_i64_pair(c, nw_size, nw_off, plen, poffs, (size_t)n_gapped));
     shape.add(nw_off + n_gapped);
     shape.add(poffs + n_gapped);
     shape.add(n_general_d);
@@ -2583,7 +2541,6 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   stage_begin(c, "correct_pack");
   PackArgs Pk;
   Pk.a = a;
-  Pk.keep = flag;
   Pk.new_idx = new_idx;
   Pk.new_off = new_off;
   Pk.final_cls = final_cls;

@@ -31,10 +31,41 @@ __device__ __forceinline__ unsigned long long sc_word(unsigned int state, unsign
 //                   (stored as a side effect), the value scanned is its popcount
 //   LoadBitsPopc    popcount of bitmap word i
 //   LoadPairWidth   directed edges of edge class i: a self-loop has one, every other class two
+//   LoadArrN<T>, LoadNonzero, LoadByteSet   in[i] / (in[i] != 0) with the terminator built in
+// Two scans that do not depend on each other travel as ONE launch (k_exscan<LA, LB>: tiles [0, tiles_a) scan the first
+// array, the tiles behind them the second, whose look-back stops at its own first tile).
 template <class T>
 struct LoadArr {
   const T* in;
   __device__ __forceinline__ unsigned long long operator()(long long i) const { return (unsigned long long)in[i]; }
+};
+template <class T>
+struct LoadArrN {  // in[i] for i < n, 0 from there on (the scan's terminator: no cleared element behind the array)
+  const T* in;
+  long long n;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const { return i < n ? (unsigned long long)in[i] : 0ull; }
+};
+struct LoadNonzero {  // 1 where in[i] != 0, i < n
+  const unsigned int* in;
+  long long n;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const { return i < n && in[i] != 0u ? 1ull : 0ull; }
+};
+struct LoadByteSet {  // 1 where byte i is set, i < n
+  const unsigned char* in;
+  long long n;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const { return i < n && in[i] != 0 ? 1ull : 0ull; }
+};
+struct LoadApplyKill {  // node removal: a marked live node dies; kill[i] is left as "removed now" and counted
+  unsigned char* kill;
+  unsigned char* alive;
+  long long n;
+  __device__ __forceinline__ unsigned long long operator()(long long i) const {
+    if (i >= n) return 0ull;
+    const bool f = kill[i] != 0 && alive[i] != 0;
+    if (f) alive[i] = 0;
+    kill[i] = f ? 1 : 0;
+    return f ? 1ull : 0ull;
+  }
 };
 struct LoadFlagWords {
   const unsigned char* flags;
@@ -70,9 +101,14 @@ struct LoadPairWidth {
   }
 };
 
-template <class Load>
-__global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __restrict__ out,
-                                                        long long n, unsigned long long* counter,
+struct LoadNone {
+  __device__ __forceinline__ unsigned long long operator()(long long) const { return 0ull; }
+};
+
+template <class Load, class LoadB = LoadNone>
+__global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __restrict__ out_a,
+                                                        long long n_a, LoadB load_b, long long* __restrict__ out_b,
+                                                        long long n_b, long long tiles_a, unsigned long long* counter,
                                                         unsigned long long ticket_base, unsigned long long* status,
                                                         unsigned int epoch) {
   __shared__ unsigned long long s_wave[SC_THREADS / 64];
@@ -82,13 +118,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __r
   if (threadIdx.x == 0) s_tile = (unsigned int)(atomicAdd(counter, 1ull) - ticket_base);
   __syncthreads();
   const long long tile = s_tile;
-  const long long w0 = tile * SC_TILE + (long long)wave * (64 * SC_ROWS);
+  // the second array's tiles (block-uniform; never taken with LoadNone: tiles_a is then the whole grid)
+  const bool second = tile >= tiles_a;
+  const long long seg0 = second ? tiles_a : 0;  // first tile of this tile's array: where its look-back ends
+  const long long n = second ? n_b : n_a;
+  long long* __restrict__ out = second ? out_b : out_a;
+  const long long w0 = (tile - seg0) * SC_TILE + (long long)wave * (64 * SC_ROWS);
   // ---- the wave's 1024 elements as 16 coalesced rows; inclusive scan of every row, rows chained
   unsigned long long x[SC_ROWS], inc[SC_ROWS];
 #pragma unroll
   for (int r = 0; r < SC_ROWS; ++r) {
     const long long i = w0 + r * 64 + lane;
-    x[r] = i < n ? load(i) : 0ull;
+    x[r] = i < n ? (second ? load_b(i) : load(i)) : 0ull;
   }
   unsigned long long row_off = 0;
 #pragma unroll
@@ -114,16 +155,17 @@ __global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __r
   // ---- look-back (first wave): sum of everything before this tile
   if (wave == 0) {
     unsigned long long excl = 0;
-    if (tile == 0) {
-      if (lane == 0) __hip_atomic_store(status, sc_word(2u, epoch, tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == seg0) {
+      if (lane == 0)
+        __hip_atomic_store(status + tile, sc_word(2u, epoch, tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (lane == 0)
         __hip_atomic_store(status + tile, sc_word(1u, epoch, tile_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (long long look = tile - 1;; look -= 64) {
         const long long idx = look - lane;
-        unsigned int state = 2u;  // before the first tile: an inclusive prefix of 0
+        unsigned int state = 2u;  // before the array's first tile: an inclusive prefix of 0
         unsigned long long val = 0;
-        if (idx >= 0) {
+        if (idx >= seg0) {
           unsigned long long w;
           do {  // the tile at idx has started (tickets are taken in order) and publishes without waiting for anybody
             w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,10 +196,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_exscan(Load load, long long* __r
   }
 }
 
-template <class Load>
-static int exscan(amg_ctx* c, Load load, long long* out, size_t n) {
-  if (n == 0) return AMG_OK;
-  const unsigned long long tiles = (n + SC_TILE - 1) / SC_TILE;
+template <class Load, class LoadB = LoadNone>
+static int exscan(amg_ctx* c, Load load, long long* out, size_t n, LoadB load_b = LoadNone{}, long long* out_b = nullptr,
+                  size_t n_b = 0) {
+  if (n == 0 && n_b == 0) return AMG_OK;
+  const unsigned long long tiles_a = (n + SC_TILE - 1) / SC_TILE;
+  const unsigned long long tiles = tiles_a + (n_b + SC_TILE - 1) / SC_TILE;
   // [0] the ticket counter, [8 ...] one status word per tile
   const size_t need = (size_t)(tiles + 8) * sizeof(unsigned long long);
   if (need > c->scan_state.cap || c->scan_epoch >= 0x3fffu) {
@@ -173,8 +217,8 @@ static int exscan(amg_ctx* c, Load load, long long* out, size_t n) {
   }
   const unsigned int epoch = ++c->scan_epoch;
   unsigned long long* st = c->scan_state.as<unsigned long long>();
-  hipLaunchKernelGGL(k_exscan<Load>, dim3((unsigned int)tiles), dim3(SC_THREADS), 0, c->stream, load, out, (long long)n, st,
-                     c->scan_tickets, st + 8, epoch);
+  hipLaunchKernelGGL((k_exscan<Load, LoadB>), dim3((unsigned int)tiles), dim3(SC_THREADS), 0, c->stream, load, out,
+                     (long long)n, load_b, out_b, (long long)n_b, (long long)tiles_a, st, c->scan_tickets, st + 8, epoch);
   c->scan_tickets += tiles;
   return AMG_OK;
 }
@@ -185,6 +229,35 @@ int prim_exscan_u32_to_i64(amg_ctx* c, const unsigned int* in, long long* out, s
 
 int prim_exscan_i64(amg_ctx* c, const long long* in, long long* out, size_t n) {
   return exscan(c, LoadArr<long long>{in}, out, n);
+}
+
+// two independent scans of n + 1 elements each (in[n] counts 0: out[n] = the sum), one launch
+int prim_exscan_u32_pair(amg_ctx* c, const unsigned int* in_a, long long* out_a, const unsigned int* in_b, long long* out_b,
+                         size_t n) {
+  return exscan(c, LoadArrN<unsigned int>{in_a, (long long)n}, out_a, n + 1, LoadArrN<unsigned int>{in_b, (long long)n}, out_b,
+                n + 1);
+}
+
+int prim_exscan_i64_pair(amg_ctx* c, const long long* in_a, long long* out_a, const long long* in_b, long long* out_b,
+                         size_t n) {
+  return exscan(c, LoadArrN<long long>{in_a, (long long)n}, out_a, n + 1, LoadArrN<long long>{in_b, (long long)n}, out_b,
+                n + 1);
+}
+
+// out[i] = set bytes before byte i for i <= n
+int prim_exscan_bytes_set(amg_ctx* c, const unsigned char* in, long long* out, size_t n) {
+  return exscan(c, LoadByteSet{in, (long long)n}, out, n + 1);
+}
+
+// alive[i] = 0 and kill[i] = 1 where kill[i] was set on a live node (kill[i] = 0 elsewhere); out[i] = nodes removed
+// before node i for i <= n
+int prim_exscan_apply_kill(amg_ctx* c, unsigned char* kill, unsigned char* alive, long long* out, size_t n) {
+  return exscan(c, LoadApplyKill{kill, alive, (long long)n}, out, n + 1);
+}
+
+// out_keep = exscan(len[i] != 0), out_off = exscan(len[i]) over n + 1 elements, one launch
+int prim_exscan_keep_and_len(amg_ctx* c, const unsigned int* len, long long* out_keep, long long* out_off, size_t n) {
+  return exscan(c, LoadNonzero{len, (long long)n}, out_keep, n + 1, LoadArrN<unsigned int>{len, (long long)n}, out_off, n + 1);
 }
 
 // flags[32 n_words] -> bits[n_words]; out[i] = set bits before word i for i <= n_words (out[n_words] = number of set bits)
