@@ -728,8 +728,15 @@ class GeneMerGraph(BubblePopping):
         v._make_edge = make_edge
         offs, nh = self._read_off, v.node_hash
 
+        single_rows = [0]
+
         def window_ids(r):
             a, n = int(offs[r]), int(offs[r + 1] - offs[r]) - k + 1
+            if n > 0 and single_rows[0] < 64 and not dict.__contains__(arrays, "tok_node"):
+                # the first few reads somebody looks up are gathered on the device one by one (read-path clustering asks
+                # for one read per allele); whoever keeps asking gets the whole per-window array, once
+                single_rows[0] += 1
+                return a, n, eng.read_node_ids_of([a], [n])[0].tolist()
             return a, n, arrays["tok_node"][a:a + n].tolist()   # (fetched on first use)
 
         def make_nodes(r):

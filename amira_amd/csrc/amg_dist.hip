@@ -816,17 +816,6 @@ extern "C" int amg_dist_edges_reduce(amg_ctx* c, const void* recv_buf, int64_t n
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_flag_dead_reads(const int* __restrict__ tok_node,
-                                                          const long long* __restrict__ read_off,
-                                                          long long n_reads, unsigned char* __restrict__ read_fix) {
-  long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_reads) return;
-  const int lane = threadIdx.x & 63;
-  bool hit = false;
-  for (long long t = read_off[r] + lane; t < read_off[r + 1]; t += 64) hit = hit || (tok_node[t] == -2);
-  if (__any(hit) && lane == 0) read_fix[r] = 1;
-}
-
 // edge classes in first-seen order (the input of the edge emission), straight from the gathered records
 __global__ void k_global_pairs(const unsigned char* __restrict__ recs, long long n_slots,
                                const unsigned int* __restrict__ bits, const long long* __restrict__ prefix,
@@ -868,10 +857,9 @@ extern "C" int amg_dist_edges_global(amg_ctx* c, const void* all_records, int64_
   if ((long long)set != n)
     return amg_fail(AMG_E_DIST, "global edge table inconsistent: %lld records, %llu distinct first-seen positions", n, set);
   AMGCHK(bs_finish_from_pairs(c));
-  if (c->dist_min_node > 1 && c->n_reads > 0)
+  if (c->dist_min_node > 1)
     // fused filter: reads that lost a node join _readsToCorrect (remove_node_from_reads :442-461)
-    hipLaunchKernelGGL(k_flag_dead_reads, dim3(nblk(c->n_reads, 4)), dim3(256), 0, st, c->tok_node.as<int>(),
-                       c->read_off.as<long long>(), c->n_reads, c->read_fix.as<unsigned char>());
+    AMGCHK(bx_flag_dead_reads(c));
   c->dist_min_node = c->dist_min_edge = 1;
   c->built = true;
   c->node_hint = c->n_local_nodes > 256 ? c->n_local_nodes : 256;

@@ -1693,6 +1693,7 @@ struct NwArgs {
   const long long* big_off;  // per gapped read: byte offset of its global scratch (big reads only)
   unsigned char* big_buf;
   int allow_fast;            // 0: every read takes the general kernel (debugging / A-B switch)
+  int shortcuts;             // 0: k_corr_nw_fast fills a matrix for every read (AMG_NW_NO_SHORTCUT=1: test switch)
 };
 
 __global__ __launch_bounds__(64) void k_corr_nw(NwArgs A) {
@@ -1919,11 +1920,47 @@ __device__ __forceinline__ void nw_fast_read(const NwArgs& A, long long gi, int 
       }
       diagonal = best < N - m;
     }
+    diagonal = diagonal && A.shortcuts != 0;
     if (diagonal && lane < N) {
       const bool match = ((mm >> lane) & 1ull) == 0ull;
       const int cur = __popcll(~mm & ((1ull << lane) - 1ull));  // matches before this column
       GS[lane] = match ? OGS[cur] : NONE;
       GE[lane] = match ? OGE[cur] : NONE;
+    }
+  }
+  // ---- second shortcut: the OFFSET-DIAGONAL CERTIFICATE, for a corrected list that is the original one with an end
+  // trimmed off and a few genes replaced (one re-threaded read in four of the cleaning sweep, and every one of them
+  // filled a matrix: ~3 000 instructions).  If every gene of x occurs in y at most once, and where it does at i + s for
+  // ONE offset s in [0, M - N], and at least two genes match, then: nothing off diagonal s scores, a detour from it
+  // costs two gaps, so every optimal alignment runs along diagonal s from the first to the last match; the ties that
+  // remain (where the s leading and M - N - s trailing gaps sit among the unmatched genes at either end) never move a
+  // matched column.  What the reference carries over (:1314-1325) is then: matched x[q] -> original position number
+  // s + (matches before q) — a gap column and a match consume an original position, a mismatching column does not —
+  // unmatched -> (None, None).  Checked against the reference's alignment exhaustively on short lists and on random
+  // trimmed / substituted / repeated ones in tests/test_nw_shortcut_cpu.py.
+  if (!diagonal && A.shortcuts != 0 && N <= M && N >= 2) {  // (M <= 64 here: lane j holds y[j])
+    int s_off = 0x7fffffff;
+    bool ok = true;
+    unsigned long long matched = 0ull;
+    for (int i = 0; i < N && ok; ++i) {  // wave-uniform: one gene of x against all of y per step
+      const int g = __builtin_amdgcn_readlane(x0, i);
+      const unsigned long long at = __ballot(lane < M && yj == g);
+      if (at != 0ull) {
+        const int si = __ffsll((long long)at) - 1 - i;
+        ok = (at & (at - 1ull)) == 0ull && (s_off == 0x7fffffff || si == s_off);
+        s_off = si;
+        matched |= 1ull << i;
+      }
+    }
+    ok = ok && s_off != 0x7fffffff && s_off >= 0 && s_off <= M - N && __popcll(matched) >= 2;
+    if (ok) {
+      diagonal = true;
+      if (lane < N) {
+        const bool match = ((matched >> lane) & 1ull) != 0ull;
+        const int cur = s_off + __popcll(matched & ((1ull << lane) - 1ull));
+        GS[lane] = match ? OGS[cur] : NONE;
+        GE[lane] = match ? OGE[cur] : NONE;
+      }
     }
   }
   if (!diagonal) {
@@ -2530,6 +2567,10 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     W.big_off = nw_off;
     W.big_buf = c->nw_big.as<unsigned char>();
     W.allow_fast = allow_fast;
+    {
+      const char* ns = getenv("AMG_NW_NO_SHORTCUT");
+      W.shortcuts = !(ns && ns[0] == '1');
+    }
     if (W.allow_fast)
       hipLaunchKernelGGL(k_corr_nw_fast, dim3((unsigned int)n_gapped), dim3(64 * NWF_WPB), 0, st, W);
     if (n_general > 0)  // reads too long for the register-resident kernel

@@ -73,3 +73,89 @@ def test_shortcut_never_contradicts_the_reference_alignment():
             claimed += 1
             assert reference_is_diagonal(nw, x, y), (x, y)
     assert claimed > 1000
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The offset-diagonal certificate (k_corr_nw_fast, second shortcut): a corrected list x that is the original list y with
+# an end trimmed off and a few genes replaced.  Rule: every gene of x occurs in y at most ONCE, and where it does, at
+# i + s for ONE offset s in [0, M - N]; at least two genes match.  Then every optimal alignment runs along diagonal s
+# from the first to the last match (gaps elsewhere cost 2 per detour and nothing off the diagonal scores), the ties that
+# remain (where the s leading / M - N - s trailing gaps sit among the unmatched genes at either end) never move a
+# matched column, and the positions the reference carries over are: matched x[q] -> original position number
+# s + (matches before q); unmatched -> (None, None).
+def certificate_positions(x, y):
+    """None when the rule does not apply, else per gene of x: index into the original positions, or None"""
+    n, m_ = len(x), len(y)
+    if n > m_ or n == 0:
+        return None
+    s, matched = None, []
+    for i, g in enumerate(x):
+        at = [j for j in range(m_) if y[j] == g]
+        if not at:
+            matched.append(False)
+            continue
+        if len(at) != 1:
+            return None
+        if s is None:
+            s = at[0] - i
+        elif at[0] - i != s:
+            return None
+        matched.append(True)
+    if s is None or not (0 <= s <= m_ - n) or sum(matched) < 2:
+        return None
+    out, before = [], 0
+    for q in range(n):
+        out.append(s + before if matched[q] else None)
+        before += 1 if matched[q] else 0
+    return out
+
+
+def reference_positions(nw, x, y):
+    """process_read_correction's loop over the alignment (construct_graph.py:1314-1325) with position NUMBERS for
+    positions: per gene of x the number of the original position it takes over, or None"""
+    out, cur = [], 0
+    for a, b in nw(None, x, y):
+        if a != "*":
+            if b != a:
+                out.append(None)
+            else:
+                out.append(cur)
+                cur += 1
+        else:
+            cur += 1
+    return out
+
+
+def test_offset_diagonal_certificate_never_contradicts_the_reference():
+    from amira_oracle.graph import GeneMerGraph
+    nw = GeneMerGraph.needleman_wunsch
+    claimed = 0
+    # exhaustive: every pair of lists with len(x) <= len(y) <= 5 over four symbols, and <= 6 over three (x may also hold
+    # two symbols y never has).  (Run once with len(y) <= 6 over four symbols: 229 M pairs, 8 minutes, no contradiction.)
+    for m_ in range(1, 7):
+        alpha = 4 if m_ <= 5 else 3
+        for n in range(1, m_ + 1):
+            for y in itertools.product(range(alpha), repeat=m_):
+                for x in itertools.product(range(alpha + 2), repeat=n):
+                    want = certificate_positions(x, y)
+                    if want is not None:
+                        claimed += 1
+                        assert reference_positions(nw, list(x), list(y)) == want, (x, y)
+    # random longer ones shaped like the re-threaded reads: a slice of y with replaced genes, sometimes a repeated gene
+    rng = random.Random(11)
+    for _ in range(6000):
+        m_ = rng.randint(6, 40)
+        y = rng.sample(range(1000), m_)
+        if rng.random() < 0.2:
+            y[rng.randrange(m_)] = y[rng.randrange(m_)]
+        a = rng.randint(0, 4)
+        b = m_ - rng.randint(0, 4)
+        x = y[a:b]
+        for _ in range(rng.randint(0, 5)):
+            if x:
+                x[rng.randrange(len(x))] = rng.choice([rng.randrange(1000, 1100), rng.choice(y)])
+        want = certificate_positions(x, y)
+        if want is not None:
+            claimed += 1
+            assert reference_positions(nw, x, y) == want, (x, y)
+    assert claimed > 5000
