@@ -437,14 +437,23 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
     n_high += (high_cnt && cov[i] >= min_cov) ? 1u : 0u;
   }
   const int lane = threadIdx.x & 63;
-  if (acc) {
+  if (acc) {  // one pair of atomics per WORKGROUP (a pair per wave: two thousand atomics on one line, ~15 us)
+    __shared__ unsigned long long s_part[2][4];
     for (int d = 32; d > 0; d >>= 1) {
       s_cov += __shfl_xor(s_cov, d, 64);
       s_n += __shfl_xor(s_n, d, 64);
     }
-    if (lane == 0 && s_n) {
-      atomicAdd(&acc[0], s_cov);
-      atomicAdd(&acc[1], s_n);
+    if (lane == 0) {
+      s_part[0][threadIdx.x >> 6] = s_cov;
+      s_part[1][threadIdx.x >> 6] = s_n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long n_all = s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
+      if (n_all) {
+        atomicAdd(&acc[0], s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3]);
+        atomicAdd(&acc[1], n_all);
+      }
     }
   }
   bool active = cid >= 0;
