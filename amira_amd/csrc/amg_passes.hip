@@ -2105,6 +2105,27 @@ __global__ __launch_bounds__(64 * NWF_WPB) void k_corr_nw_fast(NwArgs A) {
   if ((long long)blockIdx.x < A.n_gapped) nw_fast_read(A, (long long)blockIdx.x, (int)threadIdx.x, s_lds);
 }
 
+// live nodes of the graph the reads were corrected against (with PackArgs::dead_kept: an upper bound for the nodes of
+// the graph the corrected reads will make)
+__global__ __launch_bounds__(256) void k_count_alive(const unsigned char* __restrict__ alive, long long n,
+                                                     unsigned long long* out) {
+  __shared__ unsigned int s_part[4];
+  unsigned int c = 0;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      const unsigned int w = *reinterpret_cast<const unsigned int*>(alive + i);  // (flags are 0 / 1 bytes)
+      c += __popc(w & 0x01010101u);
+    } else {
+      for (long long j = i; j < n; ++j) c += alive[j] ? 1u : 0u;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) c += (unsigned int)__shfl_xor((int)c, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0 && (s_part[0] | s_part[1] | s_part[2] | s_part[3]))
+    atomicAdd(out, (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 // ---- compaction into the corrected CSR: a read is kept when len(list_of_genes) > 0 (:1130)
 struct PackArgs {
   CorrArgs a;
@@ -2119,6 +2140,7 @@ struct PackArgs {
   long long* o_posoff;       // per corrected read: pool index of its positions
   long long* o_rl;
   long long out_reads, out_tokens;  // the corrected CSR's last offset: o_off[out_reads] = out_tokens
+  unsigned long long* dead_kept;    // dead windows of the reads that keep their original genes: 16 partial sums, 16 words apart
 };
 
 // One wave packs 64 consecutive reads.  Lane l owns read l's record: where its genes come from (the read itself,
@@ -2136,10 +2158,15 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
   if (blockIdx.x == 0 && threadIdx.x == 0) A.o_off[A.out_reads] = A.out_tokens;
   long long dst = 0, src = 0;  // src: token index; bit 62 set = in the temp area
   int n = 0;
+  unsigned int dead = 0;  // windows of removed nodes this read brings back (see amg_correct_reads: the next build's table)
   if (r < a.n_reads && a.new_len[r] > 0) {
     dst = A.new_off[r];
     n = (int)a.new_len[r];
     const unsigned char fc = A.final_cls[r];
+    if (fc == RC_KEEP_ORIG) {
+      const long long nw = a.read_off[r + 1] - a.read_off[r] - a.k + 1;
+      dead = nw <= 64 ? (unsigned int)(nw - __popcll(a.lmask[r])) : (unsigned int)nw;
+    }
     long long poff = 0;
     if (fc == RC_GAPPED) {  // re-threaded read: genes staged in the temp area, positions written to the pool by
       src = a.tmp_off[r] | (1ll << 62);  // the carry-over kernels
@@ -2155,6 +2182,10 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
     A.o_changed[q] = (fc == RC_TRIM || fc == RC_GAPPED) ? 1 : 0;
     if (a.have_pos) A.o_posoff[q] = poff;
     if (a.read_len) A.o_rl[q] = a.read_len[r];
+  }
+  if (__ballot(dead != 0u) != 0ull) {
+    for (int d = 32; d > 0; d >>= 1) dead += (unsigned int)__shfl_xor((int)dead, d, 64);
+    if (lane == 0) atomicAdd(A.dead_kept + 16 * (blockIdx.x & 15), (unsigned long long)dead);
   }
   if (__ballot(n > 0) == 0ull) return;
   for (int j0 = 0; j0 < PACK_READS; j0 += 4) {
@@ -2332,13 +2363,14 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   stage_begin(c, "correct_classify");
   unsigned long long* mx = c->status.as<unsigned long long>() + ST_MISC;
   AMGCHK(c->gm_mask.ensure(per_read * sizeof(unsigned long long)));
-  AMGCHK(c->gm_ctr.ensure((256 + 16) * sizeof(unsigned long long)));
+  AMGCHK(c->gm_ctr.ensure((16 + 256 + 256 + 16) * sizeof(unsigned long long)));
   unsigned long long* n_runs_d = c->gm_ctr.as<unsigned long long>() + 16;  // [16 x 16 words]; [0..16) belong to the memo
+  unsigned long long* dead_kept_d = n_runs_d + 256;                         // [16 x 16 words] (k_corr_pack), then live nodes
   {
     ClearList cl;
     cl.add(bound, per_read * sizeof(unsigned int) * 3);
     cl.add(mx, sizeof(unsigned long long));
-    cl.add(n_runs_d, 256 * sizeof(unsigned long long));
+    cl.add(n_runs_d, (256 + 256 + 16) * sizeof(unsigned long long));
     AMGCHK(clear_many(c, cl));
   }
   a.gflag = flag;
@@ -2346,6 +2378,11 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   a.lmask = c->gm_mask.as<unsigned long long>();
   a.n_runs = n_runs_d;
   if (R > 0) hipLaunchKernelGGL(k_corr_classify, dim3(nblk(R, 4 * CLS_READS)), dim3(256), 0, st, a);  // also new_len, flag, max
+  // (for the next build's table: how many nodes are alive; rides along, read back with the pack step's words)
+  const bool count_alive = c->n_nodes >= (1ll << 20);
+  if (count_alive)
+    hipLaunchKernelGGL(k_count_alive, dim3(128), dim3(256), 0, st, c->node_alive.as<unsigned char>(), c->n_nodes,
+                       dead_kept_d + 256);
   // where the re-threaded reads' genes are staged, and the list of gapped reads: two scans, one launch
   AMGCHK(prim_exscan_u32_pair(c, bound, tmp_off, flag, new_idx, (size_t)R));
   long long tmp_total = 0;
@@ -2603,12 +2640,27 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
   Pk.out_reads = out_reads;
   Pk.out_tokens = out_tokens;
+  Pk.dead_kept = dead_kept_d;
   if (R > 0)
     hipLaunchKernelGGL(k_corr_pack, dim3(nblk(R, 4 * PACK_READS)), dim3(256), 0, st, Pk);
   else
     HIPCHK(hipMemcpyAsync(c->c_read_off.as<long long>() + out_reads, &out_tokens, sizeof(long long),
                           hipMemcpyHostToDevice, st));
-  AMGCHK(stream_wait(c));
+  {
+    // the call's last synchronisation; with it an upper bound for the nodes of the graph these reads will make (same k):
+    // every window of a corrected read is a live node of this graph — untouched reads, slices, re-threaded paths —
+    // except the dead windows of the reads that fell back to their original genes
+    FetchList l;
+    for (int i = 0; i < 16; ++i) l.add(dead_kept_d + 16 * i);
+    l.add(dead_kept_d + 256);
+    unsigned long long v[17];
+    AMGCHK(fetch(c, l, v));
+    unsigned long long bound = count_alive ? v[16] : (unsigned long long)c->n_nodes;
+    for (int i = 0; i < 16; ++i) bound += v[i];
+    c->c_node_bound = (int64_t)bound;
+    if (const char* e = getenv("AMG_TEST_NODE_BOUND")) c->c_node_bound = atoll(e);  // test hook: a bound that does not hold
+    c->c_node_bound_k = c->k;
+  }
   stage_end(c);
   c->c_reads = out_reads;
   c->c_tokens = out_tokens;
@@ -2857,6 +2909,12 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   c->have_corrected = false;
   c->built = false;
   c->match_valid = false;
+  // the next build's node table: not larger than the correction's bound asks for (a graph of uncorrected reads is
+  // mostly error nodes that do not come back: 5.4 M nodes before, 0.5 M after on BASELINE config 3).  A build with
+  // another k, or a bound that does not hold, costs what any undersized table costs: one repeated pass.
+  if (c->c_node_bound > 0 && c->c_node_bound_k == c->k && (c->node_hint == 0 || c->c_node_bound < c->node_hint))
+    c->node_hint = c->c_node_bound > 256 ? c->c_node_bound : 256;
+  c->c_node_bound = 0;
   return AMG_OK;
 }
 
@@ -2907,7 +2965,7 @@ extern "C" int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src) {
   dst->built = false;
   dst->have_corrected = false;
   dst->match_valid = false;
-  dst->node_hint = 0;
+  dst->node_hint = src->c_node_bound > 256 ? src->c_node_bound : 0;  // (amg_adopt_corrected: the same bound)
   dst->cnt_hint_reset = true;
   return AMG_OK;
 }
