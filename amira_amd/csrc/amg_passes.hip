@@ -30,7 +30,8 @@ __global__ void k_filter_edges(const int* __restrict__ src, const int* __restric
                                unsigned char* __restrict__ alive, long long n, unsigned int min_cov) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n || !alive[e]) return;
-  if (cov[e] < min_cov || !node_alive[src[e]] || !node_alive[tgt[e]]) alive[e] = 0;
+  // (an edge's coverage is at least 1: with the usual threshold of 1 the coverage array is not read at all)
+  if ((min_cov > 1 && cov[e] < min_cov) || !node_alive[src[e]] || !node_alive[tgt[e]]) alive[e] = 0;
 }
 
 // remove_node_from_reads (:442-461): one wave per read; windows of removed nodes become
