@@ -235,7 +235,7 @@ struct amg_ctx {
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
   bool match_valid = false;
   int64_t match_total = 0, match_npat = 0;
-  DevBuf match_read, match_pos, match_off;
+  DevBuf match_read, match_pos, match_off, match_wave;  // match_wave: hits per wave of k_match and their prefix
 
   // ---- scratch
   DevBuf status;       // unsigned long long[ST_WORDS]

@@ -33,15 +33,17 @@ struct MatchArgs {
   long long domain;
   int lds_words;              // words of has_bits staged in LDS (0: tested in global memory)
   unsigned long long* hits;   // nullptr: count only
-  unsigned long long* counter;
+  unsigned int* wave_count;   // count launch: hits of every wave of the grid
+  const long long* wave_base; // fill launch (same grid): where every wave's hits begin
   unsigned long long cap;
 };
 
 // Waves walk the reads (grid stride); each lane takes positions of the read.  Nearly every position holds a symbol
 // no pattern starts with: that is decided by one bit of a bitmap over the symbol domain staged in LDS once per
-// workgroup (5 KB for 20 000 genes) — not by two 8-byte gathers from the bucket table per gene — and the hits of a
-// read are counted first, given their places by ONE atomicAdd of the wave, and written in a second look (a single
-// counter word takes ~90 returning atomics per microsecond: one per hit made a batch with a million hits cost 10 ms).
+// workgroup (5 KB for 20 000 genes) — not by two 8-byte gathers from the bucket table per gene.  Hits are placed WITHOUT
+// atomics: the count launch leaves every wave's number of hits, a scan turns them into the waves' first places, the
+// fill launch (same grid, same reads per wave) writes from there.  (A single counter word takes ~100 returning atomics
+// per microsecond: one per hit made a million hits cost 10 ms, one per read with hits still 3.3 ms for 335 k hits.)
 #define MATCH_LDS_WORDS 12288  // 48 KB: 393 216 symbols
 __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
   extern __shared__ unsigned int s_has[];
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
   const int lane = threadIdx.x & 63;
   const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-  unsigned long long counted = 0;  // (count-only launches: one atomicAdd per wave at the very end)
+  unsigned long long counted = 0;  // hits of this wave so far (fill launch: its next place is wave_base + counted)
+  const unsigned long long my_base = A.hits ? (unsigned long long)A.wave_base[wave0] : 0ull;
   // MATCH_BATCH reads per iteration: their offsets and first 64 symbols are loaded for all of them before any is
   // looked at (a wave that walks one read at a time is bound by the chain offsets -> symbols of that one read); a read
   // none of whose symbols starts a pattern — nearly all of them — is done after that look
@@ -110,11 +113,8 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
     }
     const unsigned int total = __shfl(x, 63, 64);
     if (total == 0) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)total);
-    base = ((unsigned long long)(unsigned int)__shfl((int)(unsigned int)(base >> 32), 0, 64) << 32) |
-           (unsigned long long)(unsigned int)__shfl((int)(unsigned int)base, 0, 64);
-    unsigned long long at = base + (unsigned long long)(x - mine);
+    unsigned long long at = my_base + counted + (unsigned long long)(x - mine);
+    counted += total;
     scan([&](int p, long long i) {
       if (at < A.cap)
         A.hits[at] = ((unsigned long long)p << (READ_BITS + POS_BITS)) | ((unsigned long long)r << POS_BITS) |
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs A) {
   }
   if (!A.hits) {
     for (int d = 32; d > 0; d >>= 1) counted += __shfl_down(counted, d, 64);
-    if (lane == 0 && counted) atomicAdd(A.counter, counted);
+    if (lane == 0) A.wave_count[wave0] = (unsigned int)counted;
   }
 }
 
@@ -156,15 +156,22 @@ __global__ void k_pat_first(const int* __restrict__ pat, const long long* __rest
   if (ok) atomicAdd(&hist[key], 1u);
 }
 
-__global__ void k_hit_split(const unsigned long long* __restrict__ keys, long long n,
-                            int* __restrict__ hit_read, int* __restrict__ hit_pos,
-                            unsigned int* __restrict__ per_pat) {
+// sorted keys -> (read, position) per hit and the first hit of every pattern: hit i opens every pattern in
+// (pattern of hit i - 1, pattern of hit i], the place after the last hit opens the rest and n_pat (no atomics: a counter
+// per pattern took one atomic per hit, and a batch of few patterns with many hits queued them on a handful of words)
+__global__ void k_hit_split(const unsigned long long* __restrict__ keys, long long n, long long n_pat,
+                            int* __restrict__ hit_read, int* __restrict__ hit_pos, long long* __restrict__ pat_first) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long k = keys[i];
-  hit_pos[i] = (int)(k & ((1ull << POS_BITS) - 1));
-  hit_read[i] = (int)((k >> POS_BITS) & ((1ull << READ_BITS) - 1));
-  atomicAdd(&per_pat[k >> (READ_BITS + POS_BITS)], 1u);
+  if (i > n) return;
+  const long long prev = i > 0 ? (long long)(keys[i - 1] >> (READ_BITS + POS_BITS)) : -1;
+  long long cur = n_pat;
+  if (i < n) {
+    const unsigned long long k = keys[i];
+    hit_pos[i] = (int)(k & ((1ull << POS_BITS) - 1));
+    hit_read[i] = (int)((k >> POS_BITS) & ((1ull << READ_BITS) - 1));
+    cur = (long long)(k >> (READ_BITS + POS_BITS));
+  }
+  for (long long p = prev + 1; p <= cur; ++p) pat_first[p] = i;
 }
 
 extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, const int64_t* pat_offsets,
@@ -245,27 +252,33 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
   // once per workgroup)
   const unsigned int match_blocks = (unsigned int)std::min<long long>(nblk(c->n_reads, 16), 256ll * 16);
   A.hits = nullptr;
-  A.counter = c->status.as<unsigned long long>() + ST_MISC;
   A.cap = 0;
-  // ---- pass 1: count, pass 2: fill
-  HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
+  // ---- pass 1: count per wave, pass 2: fill from the waves' first places
+  const long long n_waves = (long long)match_blocks * 4;
+  AMGCHK(c->match_wave.ensure((size_t)(n_waves + 2) * (sizeof(unsigned int) + sizeof(long long)) + 16));
+  long long* wave_base = c->match_wave.as<long long>();
+  unsigned int* wave_count = reinterpret_cast<unsigned int*>(wave_base + (n_waves + 2));
+  A.wave_count = wave_count;
+  A.wave_base = wave_base;
+  HIPCHK(hipMemsetAsync(wave_count, 0, (size_t)(n_waves + 1) * sizeof(unsigned int), st));
   stage_begin(c, "match_count");  // (the stage is the kernel alone: bench.py prices it against the HBM roofline)
   if (c->n_reads > 0) hipLaunchKernelGGL(k_match, dim3(match_blocks), dim3(256), lds_bytes, st, A);
   stage_end(c);
+  AMGCHK(prim_exscan_u32_to_i64(c, wave_count, wave_base, (size_t)n_waves + 1));
   unsigned long long total = 0;
-  HIPCHK(hipMemcpyAsync(&total, A.counter, sizeof(total), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    FetchList l;
+    l.add(wave_base + n_waves);
+    AMGCHK(fetch(c, l, &total));
+  }
   AMGCHK(c->match_read.ensure((size_t)(total + 1) * sizeof(int)));
   AMGCHK(c->match_pos.ensure((size_t)(total + 1) * sizeof(int)));
-  AMGCHK(c->s5.ensure((size_t)(total + 1) * sizeof(unsigned long long) * 2 + (size_t)(n_pat + 2) * sizeof(unsigned int)));
+  AMGCHK(c->s5.ensure((size_t)(total + 1) * sizeof(unsigned long long) * 2));
   unsigned long long* keys = c->s5.as<unsigned long long>();
   unsigned long long* keys_sorted = keys + (total + 1);
-  unsigned int* per_pat = reinterpret_cast<unsigned int*>(keys_sorted + (total + 1));
-  HIPCHK(hipMemsetAsync(per_pat, 0, (size_t)(n_pat + 2) * sizeof(unsigned int), st));
   if (total > 0) {
     A.hits = keys;
     A.cap = total;
-    HIPCHK(hipMemsetAsync(A.counter, 0, sizeof(unsigned long long), st));
     stage_begin(c, "match_fill");
     hipLaunchKernelGGL(k_match, dim3(match_blocks), dim3(256), lds_bytes, st, A);
     stage_end(c);
@@ -275,10 +288,12 @@ extern "C" int amg_match_patterns(amg_ctx* c, int which, const int32_t* pat, con
     unsigned int* dummy_in = c->s2.as<unsigned int>();
     unsigned int* dummy_out = dummy_in + (total + 1);
     AMGCHK(prim_sort_u64_u32(c, keys, keys_sorted, dummy_in, dummy_out, (size_t)total, 64));
-    hipLaunchKernelGGL(k_hit_split, dim3(nblk((long long)total, 256)), dim3(256), 0, st, keys_sorted,
-                       (long long)total, c->match_read.as<int>(), c->match_pos.as<int>(), per_pat);
+    hipLaunchKernelGGL(k_hit_split, dim3(nblk((long long)total + 1, 256)), dim3(256), 0, st, keys_sorted,
+                       (long long)total, (long long)n_pat, c->match_read.as<int>(), c->match_pos.as<int>(),
+                       c->match_off.as<long long>());
+  } else {
+    HIPCHK(hipMemsetAsync(c->match_off.p, 0, (size_t)(n_pat + 1) * sizeof(long long), st));
   }
-  AMGCHK(prim_exscan_u32_to_i64(c, per_pat, c->match_off.as<long long>(), (size_t)n_pat + 1));
   HIPCHK(hipMemcpyAsync(hit_offsets, c->match_off.p, (size_t)(n_pat + 1) * sizeof(long long),
                         hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
