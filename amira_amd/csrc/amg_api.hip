@@ -229,7 +229,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,
                    &c->edge_src,  &c->edge_tgt,  &c->edge_sdir,  &c->edge_tdir, &c->edge_cov,
-                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_pos, &c->ladj_keys, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off, &c->match_wave,  &c->c_tokens_buf,
+                   &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_pos, &c->ladj_keys, &c->hub_bits, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off, &c->match_wave,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp, &c->scan_state,   &c->s0, &c->s1, &c->s2, &c->s3,
                    &c->s4, &c->s5, &c->cnt_state, &c->cnt_list, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->gm_mask, &c->gm_tab, &c->gm_res, &c->gm_list, &c->gm_q, &c->gm_pool, &c->gm_gene, &c->gm_fail, &c->gm_ctr, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->x_ncnt, &c->x_ftag, &c->f_ctrs, &c->x_efinal, &c->x_first_all, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};

@@ -330,22 +330,35 @@ __global__ void k_adjc_rows(const long long* __restrict__ off, long long n_rows,
   for (int j = 0; j < cnt; ++j) adj_edge[o + j] = (int)e[j];
 }
 
-// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids
+// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids; rows beyond HUGE_ROW are
+// left to the first HUB_BLOCKS workgroups, which put them in order through a bitmap (huge_row_in_order, amg_device.h)
+#define HUB_BLOCKS 8
 __global__ __launch_bounds__(256) void k_adjc_long(const unsigned int* __restrict__ long_rows,
                                                    const unsigned long long* __restrict__ n_long,
                                                    const long long* __restrict__ off, const unsigned int* __restrict__ tmp,
-                                                   int* __restrict__ adj_edge) {
+                                                   int* __restrict__ adj_edge, unsigned int* hub_bits, long long hub_words) {
+  __shared__ unsigned int s_wave[4];
   const unsigned long long n = *n_long;
   for (unsigned long long q = blockIdx.x; q < n; q += gridDim.x) {
     const unsigned int r = long_rows[q];
     const long long o = off[r];
     const int cnt = (int)(off[r + 1] - o);
+    if (cnt > HUGE_ROW) continue;
     for (int j = threadIdx.x; j < cnt; j += 256) {
       const unsigned int x = tmp[o + j];
       int rank = 0;
       for (int i = 0; i < cnt; ++i) rank += tmp[o + i] < x ? 1 : 0;
       adj_edge[o + rank] = (int)x;
     }
+  }
+  if (blockIdx.x >= HUB_BLOCKS) return;
+  for (unsigned long long q = blockIdx.x; q < n; q += HUB_BLOCKS) {  // (block-uniform: every thread takes the same rows)
+    const unsigned int r = long_rows[q];
+    const long long o = off[r];
+    const long long cnt = off[r + 1] - o;
+    if (cnt <= HUGE_ROW) continue;
+    huge_row_in_order(tmp + o, cnt, hub_bits + (long long)blockIdx.x * hub_words, hub_words, s_wave,
+                      [&](long long rank, unsigned int id) { adj_edge[o + rank] = (int)id; });
   }
 }
 
@@ -1057,8 +1070,10 @@ int ensure_adjacency(amg_ctx* c) {
                        c->edge_sdir.as<signed char>(), E, c->adj_off.as<long long>(), tick, tmp);
     hipLaunchKernelGGL(k_adjc_rows, dim3(blocks_for(2 * D, 256)), dim3(256), 0, st, c->adj_off.as<long long>(), 2 * D, tmp,
                        c->adj_edge.as<int>(), long_rows, n_long);
+    const long long hub_words = (E + 31) / 32 + 1;  // (scratch of the hub rows: HUB_BLOCKS bitmaps over the edge ids)
+    AMGCHK(c->hub_bits.ensure((size_t)HUB_BLOCKS * (size_t)hub_words * sizeof(unsigned int)));
     hipLaunchKernelGGL(k_adjc_long, dim3(256), dim3(256), 0, st, long_rows, n_long, c->adj_off.as<long long>(), tmp,
-                       c->adj_edge.as<int>());
+                       c->adj_edge.as<int>(), c->hub_bits.as<unsigned int>(), hub_words);
     stage_end(c);
     c->adj_valid = true;
     return AMG_OK;

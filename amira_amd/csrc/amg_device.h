@@ -156,6 +156,40 @@ __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigne
   return block_exscan<4>(v, total, s_wave);
 }
 
+// ------------------------------------------------------------------ a hub row's ids in ascending order
+// Rows of an adjacency list are put in order by rank (every id counts the smaller ids of its row): fine for the rows of
+// a gene-mer graph, quadratic in the row.  A row longer than HUGE_ROW goes through a bitmap over the id space instead —
+// clear, set one bit per id, prefix-count the words, read the ids off in order: O(ids / 32 + row) for a workgroup,
+// whatever the row's length (a hub with a million neighbours would otherwise hold one workgroup for an hour).
+// bits: this workgroup's scratch of `words` words; emit(rank, id).  All 256 threads of the workgroup call it.
+#define HUGE_ROW 1024
+template <class Emit>
+__device__ __forceinline__ void huge_row_in_order(const unsigned int* __restrict__ ids, long long cnt, unsigned int* bits,
+                                                  long long words, unsigned int* s_wave /*[4]*/, Emit emit) {
+  for (long long w = threadIdx.x; w < words; w += 256) bits[w] = 0u;
+  __threadfence();
+  __syncthreads();
+  for (long long j = threadIdx.x; j < cnt; j += 256) atomicOr(&bits[ids[j] >> 5], 1u << (ids[j] & 31u));
+  __threadfence();
+  __syncthreads();
+  const long long per = (words + 255) / 256;
+  const long long w0 = (long long)threadIdx.x * per, w1 = w0 + per < words ? w0 + per : words;
+  unsigned int mine = 0;
+  for (long long w = w0; w < w1; ++w)
+    mine += (unsigned int)__popc(__hip_atomic_load(bits + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  unsigned int total;
+  unsigned int rank = block_exscan_256(mine, &total, s_wave);
+  for (long long w = w0; w < w1; ++w) {
+    unsigned int v = __hip_atomic_load(bits + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v) {
+      const int b = __ffs((int)v) - 1;
+      v &= v - 1u;
+      emit((long long)rank++, (unsigned int)(w * 32 + b));
+    }
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------ union-find helpers (components)
 __device__ __forceinline__ int uf_ld(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // plain load, never hoisted

@@ -193,6 +193,7 @@ struct amg_ctx {
   DevBuf ladj;      // int2[n_live_edges]  {target node, target direction}
   DevBuf ladj_rows; // int4[2 n_nodes]  {offset, live count, first target, first direction}
   DevBuf ladj_pos, ladj_keys;  // scratch of the live-adjacency build (callers hold s0..s5)
+  DevBuf hub_bits;             // bitmaps over the edge ids for adjacency rows beyond HUGE_ROW (huge_row_in_order)
   bool ladj_valid = false;
   bool comp_valid = false, adj_valid = false;  // component ids / full edge lists of the built graph are made on demand
   // reads

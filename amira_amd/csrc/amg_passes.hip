@@ -241,17 +241,21 @@ __global__ void k_lr_finish(const unsigned int* __restrict__ keys, const unsigne
   lrows[key] = make_int4(off, cnt, e_tgt[e[0]], (int)e_tdir[e[0]]);
 }
 
-// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids
+// a workgroup per long row: every element finds its rank among the row's (distinct) edge ids; rows beyond HUGE_ROW are
+// left to the first LR_HUB_BLOCKS workgroups, which put them in order through a bitmap (huge_row_in_order, amg_device.h)
+#define LR_HUB_BLOCKS 8
 __global__ __launch_bounds__(256) void k_lr_long(const unsigned int* __restrict__ long_rows,
                                                  const unsigned long long* __restrict__ n_long,
                                                  const unsigned int* __restrict__ tmp, const int* __restrict__ e_tgt,
                                                  const signed char* __restrict__ e_tdir, int4* __restrict__ lrows,
-                                                 int2* __restrict__ lent) {
+                                                 int2* __restrict__ lent, unsigned int* hub_bits, long long hub_words) {
+  __shared__ unsigned int s_wave[4];
   const unsigned long long n = *n_long;
   for (unsigned long long r = blockIdx.x; r < n; r += gridDim.x) {
     const unsigned int key = long_rows[r];
     const int off = lrows[key].x, cnt = lrows[key].y;
     __syncthreads();  // (the row record is rewritten below: everybody has read it)
+    if (cnt > HUGE_ROW) continue;
     for (int j = threadIdx.x; j < cnt; j += 256) {
       const unsigned int x = tmp[off + j];
       int rank = 0;
@@ -259,6 +263,17 @@ __global__ __launch_bounds__(256) void k_lr_long(const unsigned int* __restrict_
       lent[off + rank] = make_int2(e_tgt[x], (int)e_tdir[x]);
       if (rank == 0) lrows[key] = make_int4(off, cnt, e_tgt[x], (int)e_tdir[x]);
     }
+  }
+  if (blockIdx.x >= LR_HUB_BLOCKS) return;
+  for (unsigned long long r = blockIdx.x; r < n; r += LR_HUB_BLOCKS) {  // (block-uniform)
+    const unsigned int key = long_rows[r];
+    const int off = lrows[key].x, cnt = lrows[key].y;
+    if (cnt <= HUGE_ROW) continue;  // (huge_row_in_order starts with a barrier: the record has been read by then)
+    huge_row_in_order(tmp + off, (long long)cnt, hub_bits + (long long)blockIdx.x * hub_words, hub_words, s_wave,
+                      [&](long long rank, unsigned int x) {
+                        lent[off + rank] = make_int2(e_tgt[x], (int)e_tdir[x]);
+                        if (rank == 0) lrows[key] = make_int4(off, cnt, e_tgt[x], (int)e_tdir[x]);
+                      });
   }
 }
 
@@ -303,8 +318,11 @@ static int ensure_live_adj(amg_ctx* c) {
                        c->ladj_rows.as<int4>(), tmp);
     hipLaunchKernelGGL(k_lr_finish, dim3(nblk(total, 256)), dim3(256), 0, st, keys, tick, total, tmp, c->edge_tgt.as<int>(),
                        c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>(), long_rows, ctr + 1);
+    const long long hub_words = (E + 31) / 32 + 1;  // (scratch of the hub rows: LR_HUB_BLOCKS bitmaps over the edge ids)
+    AMGCHK(c->hub_bits.ensure((size_t)LR_HUB_BLOCKS * (size_t)hub_words * sizeof(unsigned int)));
     hipLaunchKernelGGL(k_lr_long, dim3(64), dim3(256), 0, st, long_rows, ctr + 1, tmp, c->edge_tgt.as<int>(),
-                       c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>());
+                       c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>(),
+                       c->hub_bits.as<unsigned int>(), hub_words);
   }
   c->ladj_valid = true;
   return AMG_OK;

@@ -272,3 +272,20 @@ def test_positions_32_bit_at_the_boundary(seed, N, L, V, k, err):
     finally:
         wide.close()
         narrow.close()
+
+
+def test_sweep_with_a_hub_of_fifteen_hundred_neighbours(eng):
+    """one gene-mer followed by 1 500 different ones: the hub's rows of the adjacency lists (all edges, amg_finalize;
+    live edges, tip clipping and the correction) are longer than HUGE_ROW and are put in order through a bitmap over
+    the edge ids instead of by rank (huge_row_in_order, amg_device.h); a second, smaller hub takes the rank route"""
+    from amira_amd import synth
+    reads = {}
+    for i in range(1500):
+        for c in range(3):
+            reads[f"h{i:04d}_{c}"] = ["+a", "+b", "+c", f"+x{i}", f"+y{i}", f"+z{i}"]
+    for i in range(200):
+        for c in range(3):
+            reads[f"s{i:04d}_{c}"] = [f"-u{i}", f"+v{i}", "+d", "-e", "+f"]
+    pos = synth.positions_for(reads)
+    fq = P.FakeFastq(synth.fake_fastq_lengths(reads))
+    run_sweep(eng, reads, pos, fq, 3)
