@@ -2236,13 +2236,30 @@ class GeneMerGraph(BubblePopping):
             anchor_list = list(anchors)                   # the set's iteration order, as `for a1 in nodeAnchors` meets it
             by_hash = {h: i for i, h in enumerate(sorted(anchor_list))}
             anchor_ids = [v.node_of_hash[h] for h in anchor_list]
-            blocks = _clustering.full_block_ids(seq, starts, anchor_ids, [by_hash[h] for h in anchor_list], py_hash,
-                                                hash(None))
+            j.update(anchors=anchors, rows=rows, nh=nh,
+                     search=(seq, starts, anchor_ids, [by_hash[h] for h in anchor_list]))
+        # the block searches of the genes (host C++, amg_cluster_full_blocks: no shared state, the interpreter lock is
+        # released around the call) side by side; the node-hash table they read is complete by now
+        py_hash = self._py_hash_memo[1] if jobs else None
+        none_hash = hash(None)
+
+        def search(j):
+            return _clustering.full_block_ids(*j["search"], py_hash, none_hash)
+
+        if len(jobs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 16)) as pool:
+                found = list(pool.map(search, jobs))
+        else:
+            found = [search(j) for j in jobs]
+        for j, blocks in zip(jobs, found):
+            geneOfInterest, rows, nh = j["gene"], j.pop("rows"), j.pop("nh")
+            j.pop("search")
             full_blocks = {tuple(nh[b].tolist()): True for b in blocks}
             in_subset = np.zeros(len(self._read_ids) + 1, bool)
             in_subset[rows] = True
             subset = _SubsetRows(2 * len(rows))   # (reads and their "_reverse" twins: get_all_sublists only asks which rows count)
-            j.update(anchors=anchors, full_blocks=full_blocks, subset=subset, in_subset=in_subset, batch={})
+            j.update(full_blocks=full_blocks, subset=subset, in_subset=in_subset, batch={})
             self._paths_from_full_blocks(full_blocks, subset, threshold, geneOfInterest, cores, _batch=j["batch"])
         # ---- search 2: the windows of every gene's blocks, forward and reverse complemented
         fwd_all = [x for j in jobs for x in j["batch"]["fwd_lists"]]
