@@ -30,6 +30,16 @@ class Counts(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Xfer(C.Structure):
+    """include/amg.h amg_xfer: one exchange of a merged build (device pointers, host count arrays)"""
+    _fields_ = [("kind", C.c_int32), ("elem_bytes", C.c_int32), ("send", C.c_void_p), ("recv", C.c_void_p),
+                ("send_counts", C.POINTER(C.c_int64)), ("recv_counts", C.POINTER(C.c_int64)), ("count", C.c_int64)]
+
+
+XFER_ALL_TO_ALL, XFER_ALL_GATHER = 1, 2
+UNIQUE_ID_BYTES = 128
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -81,16 +91,18 @@ def _load():
         "amg_set_reads_from_corrected": (C.c_int, [P, P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),
         "amg_minhash": (C.c_int, [P, P, P, P, I64, I32, C.c_uint64, P, P, I64, C.POINTER(I64)]),
-        "amg_dist_record_bytes": (C.c_int, [I32, C.POINTER(I64), C.POINTER(I64)]),
-        "amg_dist_set_filter": (C.c_int, [P, U32, U32]),
-        "amg_dist_nodes_local": (C.c_int, [P, I32, I64, I64, I32, I32, P]),
-        "amg_dist_nodes_pack": (C.c_int, [P, P]),
-        "amg_dist_nodes_reduce": (C.c_int, [P, P, I64, I32, P, P, C.POINTER(I64)]),
-        "amg_dist_nodes_global": (C.c_int, [P, P, I64, I64, P]),
-        "amg_dist_edges_local": (C.c_int, [P, I32, P]),
-        "amg_dist_edges_pack": (C.c_int, [P, P]),
-        "amg_dist_edges_reduce": (C.c_int, [P, P, I64, I32, P, C.POINTER(I64)]),
-        "amg_dist_edges_global": (C.c_int, [P, P, I64, I64]),
+        "amg_dist_unique_id": (C.c_int, [P, I32]),
+        "amg_dist_init": (C.c_int, [P, P, I32, I32]),
+        "amg_dist_merge": (C.c_int, [P, I32, U32, U32]),
+        "amg_dist_finalize": (C.c_int, [P]),
+        "amg_dist_init_external": (C.c_int, [P, I32, I32]),
+        "amg_dist_merge_begin": (C.c_int, [P, I32, U32, U32]),
+        "amg_dist_merge_next": (C.c_int, [P, C.POINTER(Xfer)]),
+        "amg_dist_merge_local": (C.c_int, [C.POINTER(P), I32, I32, U32, U32]),
+        "amg_copy_d2h": (C.c_int, [P, P, P, I64]),
+        "amg_copy_h2d": (C.c_int, [P, P, P, I64]),
+        "amg_dist_stats": (C.c_int, [P, C.POINTER(I64), I32]),
+        "amg_dist_phase_ms": (C.c_int, [P, I32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), I32]),
         "amg_calls_load_json": (C.c_int, [C.c_char_p, C.POINTER(P)]),
         "amg_calls_counts": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64),
                                        C.POINTER(I64)]),
@@ -109,7 +121,6 @@ def _load():
         "amg_cluster_blocks_free": (C.c_int, [P]),
         "amg_py_tuple_hash": (I64, [P, I64]),
         "amg_pyset_script": (C.c_int, [P, I64, P, I32, P, P]),
-        "amg_fetch_words": (C.c_int, [P, P, I32, P]),
         "amg_last_timings": (C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
         "amg_set_timing": (C.c_int, [P, C.c_int]),
     }

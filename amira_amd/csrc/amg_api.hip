@@ -155,17 +155,6 @@ int stream_wait(amg_ctx* c) {
   return fetch(c, l, nullptr);
 }
 
-// a few device words for the host at the latency of the pinned mailbox (amira_amd/dist.py reads the counts of its
-// exchanges this way: a read-back through the framework costs three to four times as much)
-extern "C" int amg_fetch_words(amg_ctx* c, const void* device_words, int32_t n_words, uint64_t* out) {
-  if (!c || !device_words || !out) return amg_fail(AMG_E_ARG, "null argument");
-  if (n_words < 1 || n_words > FETCH_MAX) return amg_fail(AMG_E_ARG, "amg_fetch_words: 1 .. %d words", FETCH_MAX);
-  HIPCHK(hipSetDevice(c->device));
-  FetchList l;
-  l.add_words(device_words, n_words);
-  return fetch(c, l, reinterpret_cast<unsigned long long*>(out));
-}
-
 int fetch_status(amg_ctx* c, unsigned long long* out, const ClearList* filler) {
   FetchList l;
   l.add_words(c->status.p, ST_WORDS);
@@ -225,6 +214,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   stages_reset(c);
+  dist_release(c);
   DevBuf* all[] = {&c->tokens,    &c->read_off,  &c->gene_start, &c->gene_end,  &c->read_len,
                    &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,

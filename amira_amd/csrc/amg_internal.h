@@ -125,6 +125,8 @@ struct StageTime {
 
 static const uint64_t kAmgSeed0 = 0x9E3779B97F4A7C15ull;  // initial fingerprint seed (amg_build re-seeds on a collision)
 
+struct DistState;  // amg_dist.hip: communicator, buffers and progress of the ctx's merged builds
+
 struct amg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -227,11 +229,11 @@ struct amg_ctx {
 
   // ---- multi-GPU merge (amg_dist.hip)
   int world = 1;
-  int64_t n_owned = 0;
   uint32_t dist_min_node = 1, dist_min_edge = 1;  // fused filter of the next merged build
   int64_t dist_nspace = 0;   // ids the current bucketing ran over (local records + claim ids nobody took)
   bool dist_sorted = false;  // the local records leave in sorted order (send_order)
   DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_gtab, dist_lcnt;
+  DistState* dist = nullptr;
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
   bool match_valid = false;
@@ -341,6 +343,8 @@ int stream_wait(amg_ctx* c);  // hipStreamSynchronize at the latency of fetch()
 void stage_begin(amg_ctx* c, const char* name);
 void stage_end(amg_ctx* c);
 void stages_reset(amg_ctx* c);
+
+void dist_release(amg_ctx* c);  // amg_dist.hip
 
 // build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
 uint64_t pow2_at_least(uint64_t x);

@@ -113,13 +113,6 @@ class Engine:
     def stream(self):
         return _ffi.lib.amg_stream(self._h)
 
-    def fetch_words(self, dev_ptr, n):
-        """n (<= 96) int64 words of device memory, ordered after everything queued on the engine's stream, through the
-        engine's pinned mailbox (a few microseconds instead of a framework read-back)"""
-        out = np.empty(n, np.int64)
-        check(_ffi.lib.amg_fetch_words(self._h, C.c_void_p(dev_ptr), int(n), ptr(out)))
-        return out.tolist()
-
     def set_timing(self, on):
         """per-stage HIP-event timing (two events per stage, ~5 us of stream idle each): on by default"""
         check(_ffi.lib.amg_set_timing(self._h, 1 if on else 0))
@@ -341,47 +334,67 @@ class Engine:
             out[int(ids[0])] = set(np.unique(hs).tolist())
         return out
 
-    # ---- multi-GPU merge phases (device pointers in / out; see amira_amd/dist.py)
+    # ---- multi-GPU: read shards + key-owner table merge (include/amg.h; drivers in amira_amd/dist.py)
     @staticmethod
-    def dist_record_bytes(k):
-        nb, eb = C.c_int64(0), C.c_int64(0)
-        check(_ffi.lib.amg_dist_record_bytes(int(k), C.byref(nb), C.byref(eb)))
-        return nb.value, eb.value
+    def dist_unique_id():
+        """128 bytes naming an RCCL communicator: make them on one rank, hand them to all, then dist_init"""
+        buf = C.create_string_buffer(_ffi.UNIQUE_ID_BYTES)
+        check(_ffi.lib.amg_dist_unique_id(buf, _ffi.UNIQUE_ID_BYTES))
+        return buf.raw
 
-    def dist_set_filter(self, min_node_cov, min_edge_cov):
-        check(_ffi.lib.amg_dist_set_filter(self._h, int(min_node_cov), int(min_edge_cov)))
+    def dist_init(self, unique_id, rank, world):
+        """this engine becomes rank `rank` of `world` over RCCL (one engine per process and GPU)"""
+        assert len(unique_id) == _ffi.UNIQUE_ID_BYTES
+        check(_ffi.lib.amg_dist_init(self._h, C.c_char_p(unique_id), int(rank), int(world)))
 
-    def dist_nodes_local(self, k, token_base, token_total, world, attempt=0):
-        counts = np.zeros(world, np.int64)
-        check(_ffi.lib.amg_dist_nodes_local(self._h, int(k), int(token_base), int(token_total),
-                                            int(world), int(attempt), ptr(counts)))
-        return counts.tolist()
+    def dist_init_external(self, rank, world):
+        """rank `rank` of `world` with the exchanges performed by the caller (dist_merge_begin / dist_merge_next)"""
+        check(_ffi.lib.amg_dist_init_external(self._h, int(rank), int(world)))
 
-    def dist_edges_local(self, world):
-        counts = np.zeros(world, np.int64)
-        check(_ffi.lib.amg_dist_edges_local(self._h, int(world), ptr(counts)))
-        return counts.tolist()
+    def dist_merge(self, k, min_node_cov=1, min_edge_cov=1):
+        """collective: the merged build of all ranks' reads (thresholds > 1 fuse filter_graph into it)"""
+        check(_ffi.lib.amg_dist_merge(self._h, int(k), max(int(min_node_cov), 1), max(int(min_edge_cov), 1)))
 
-    def dist_pack(self, what, dev_ptr):
-        check(getattr(_ffi.lib, f"amg_dist_{what}_pack")(self._h, C.c_void_p(dev_ptr)))
+    def dist_merge_begin(self, k, min_node_cov=1, min_edge_cov=1):
+        check(_ffi.lib.amg_dist_merge_begin(self._h, int(k), max(int(min_node_cov), 1), max(int(min_edge_cov), 1)))
 
-    def dist_reduce(self, what, recv_ptr, n_recv, n_sources, owned_ptr, replies_ptr=None):
-        """owner side; returns the number of records written to owned_ptr (nodes also fill replies_ptr)"""
-        n = C.c_int64(0)
-        if what == "nodes":
-            check(_ffi.lib.amg_dist_nodes_reduce(self._h, C.c_void_p(recv_ptr), int(n_recv), int(n_sources),
-                                                 C.c_void_p(owned_ptr), C.c_void_p(replies_ptr), C.byref(n)))
-        else:
-            check(_ffi.lib.amg_dist_edges_reduce(self._h, C.c_void_p(recv_ptr), int(n_recv), int(n_sources),
-                                                 C.c_void_p(owned_ptr), C.byref(n)))
-        return n.value
+    def dist_merge_next(self):
+        """None when the build is complete, else the exchange to perform before the next call (an _ffi.Xfer)"""
+        x = _ffi.Xfer()
+        rc = _ffi.lib.amg_dist_merge_next(self._h, C.byref(x))
+        if rc < 0:
+            check(rc)
+        return x if rc == 1 else None
 
-    def dist_global(self, what, all_ptr, n_slots, n_total, replies_ptr=None):
-        if what == "nodes":
-            check(_ffi.lib.amg_dist_nodes_global(self._h, C.c_void_p(all_ptr), int(n_slots), int(n_total),
-                                                 C.c_void_p(replies_ptr)))
-        else:
-            check(_ffi.lib.amg_dist_edges_global(self._h, C.c_void_p(all_ptr), int(n_slots), int(n_total)))
+    @staticmethod
+    def dist_merge_local(engines, k, min_node_cov=1, min_edge_cov=1):
+        """len(engines) EMULATED ranks on one device (rank r = engines[r]): the device phases of the N-GPU run, the
+        exchanges as device copies"""
+        n = len(engines)
+        handles = (C.c_void_p * n)(*[e._h for e in engines])
+        check(_ffi.lib.amg_dist_merge_local(handles, n, int(k), max(int(min_node_cov), 1), max(int(min_edge_cov), 1)))
+
+    def dist_finalize(self):
+        check(_ffi.lib.amg_dist_finalize(self._h))
+
+    def copy_d2h(self, dev_ptr, host_array):
+        check(_ffi.lib.amg_copy_d2h(self._h, C.c_void_p(dev_ptr), ptr(host_array), host_array.nbytes))
+
+    def copy_h2d(self, dev_ptr, host_array):
+        check(_ffi.lib.amg_copy_h2d(self._h, C.c_void_p(dev_ptr), ptr(host_array), host_array.nbytes))
+
+    def dist_stats(self, reset=True):
+        out = (C.c_int64 * 8)()
+        check(_ffi.lib.amg_dist_stats(self._h, out, 1 if reset else 0))
+        return {"host_waits": out[0], "exchanges": out[1], "a2a_bytes_per_peer": out[2], "back_bytes_per_peer": out[3],
+                "ag_bytes_contributed": out[4], "repeated_builds": out[5], "a2a_bytes_sent": out[6]}
+
+    def dist_phase_ms(self, on=True):
+        """{phase: synchronised wall ms} of the merge driver since the last call; on: keep measuring"""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        n = _ffi.lib.amg_dist_phase_ms(self._h, 1 if on else 0, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
 
 
 # Engines (a HIP stream + grow-only device buffers each) are pooled per device: the reference's drivers build graph

@@ -54,8 +54,8 @@ enum {
   AMG_E_OVERFLOW = -5,   /* internal table overflow that retries could not resolve     */
   AMG_E_NOMEM = -6,
   AMG_E_DIST = -7,       /* multi-GPU merge inconsistency                              */
-  AMG_E_COLLISION = -8   /* merged build: two gene-mers share a 64-bit merge key; every rank
-                            repeats the build with attempt + 1 (amg_dist_nodes_local)    */
+  AMG_E_COLLISION = -8   /* merged build: two gene-mers shared a 64-bit merge key under every seed
+                            tried (amg_dist_merge repeats the build on every rank by itself) */
 };
 
 #define AMG_MAX_K 16
@@ -261,56 +261,60 @@ int amg_minhash(amg_ctx* ctx, const uint8_t* bases, const int64_t* seg_off, cons
 
 /* ---- multi-GPU: read-sharded build with a key-owner table merge — the single-graph result of
  *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
- *      Every rank holds a contiguous shard of the reads.  The library runs the device phases;
- *      the CALLER moves the record buffers between ranks with RCCL (torch.distributed
- *      all_to_all_single / all_gather_into_tensor on the device pointers below, issued on
- *      amg_stream(ctx) so that nothing but the count read-backs waits on the host), see
- *      amira_amd/dist.py.  All buffers here are DEVICE pointers the caller allocates; the phases
- *      are asynchronous on the ctx's stream.  Record sizes: amg_dist_record_bytes; a record's
- *      first 8 bytes (its merge key) are never zero, so zeroed padding can be told from records.
- *
- *      nodes:  local -> pack ==all-to-all==> reduce ==all-gather (survivors) + all-to-all back
- *              (replies)==> global          edges: local -> pack ==all-to-all==> reduce
- *              ==all-gather==> global ------------------------------------------------------- */
-int amg_dist_record_bytes(int32_t k, int64_t* node_bytes, int64_t* edge_bytes);
-/* Optional: fuse filter_graph(min_node_cov, min_edge_cov) (construct_graph.py:523-540) into
- * the NEXT merged build.  Owners then keep only nodes / edge classes that reach the thresholds,
- * so the (often 10x larger) set of low-coverage nodes is never replicated.  The resulting
- * state equals amg_dist build followed by amg_filter for everything the correction reads
- * (live nodes and edges, their coverages and list orders, masked windows, reads to correct);
- * ids number the surviving nodes / edges only and component ids are those of the filtered
- * graph.  Thresholds reset to (1, 1) = keep everything after the build. */
-int amg_dist_set_filter(amg_ctx* ctx, uint32_t min_node_cov, uint32_t min_edge_cov);
-/* local node table of this shard; token_base = global index of the shard's first token,
- * token_total = tokens over all shards; send_counts[world] = records per destination rank
- * (owner = hash of the merge key mod world).  attempt = the ranks' common retry counter: 0, and
- * + 1 on EVERY rank after any of them returned AMG_E_COLLISION (it selects the fingerprint seed
- * of the merge keys, which all ranks must share). */
-int amg_dist_nodes_local(amg_ctx* ctx, int32_t k, int64_t token_base, int64_t token_total,
-                         int32_t world, int32_t attempt, int64_t* send_counts);
-int amg_dist_nodes_pack(amg_ctx* ctx, void* send_buf);              /* destination order   */
-/* after the all-to-all: the n_recv records this rank owns the keys of, n_sources = ranks that
- * contributed any (records of ONE rank are distinct keys: no reduction needed).  Equal keys are
- * reduced (sum count, min first-seen); owned_out (room for n_recv records) receives the *n_owned
- * reduced records that reach the fused filter's threshold — what this rank contributes to the
- * all-gather; replies_out[n_recv] (8 bytes each) = for every received record, in the order
- * received, its key's global first-seen value or ~0 when the filter dropped the key — what goes
- * back to the senders (all-to-all with the split sizes of the first one swapped) */
-int amg_dist_nodes_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int32_t n_sources,
-                          void* owned_out, void* replies_out, int64_t* n_owned);
-/* after the all-gather and the reply exchange: all_records = n_slots record slots (equal-size
- * contributions, unused tails zeroed) holding n_total records; my_replies = one 8-byte reply per
- * record this rank sent, in send order.  Global node id = rank of first-seen (a prefix count over a
- * bitmap of the global token space); global node arrays on this rank, local windows -> global ids */
-int amg_dist_nodes_global(amg_ctx* ctx, const void* all_records, int64_t n_slots, int64_t n_total,
-                          const void* my_replies);
-/* the same for the edge classes (keyed by global node ids; no replies); the last call also emits
- * the directed edges, after which the ctx behaves as after amg_build (global graph, local reads) */
-int amg_dist_edges_local(amg_ctx* ctx, int32_t world, int64_t* send_counts);
-int amg_dist_edges_pack(amg_ctx* ctx, void* send_buf);
-int amg_dist_edges_reduce(amg_ctx* ctx, const void* recv_buf, int64_t n_recv, int32_t n_sources,
-                          void* owned_out, int64_t* n_owned);
-int amg_dist_edges_global(amg_ctx* ctx, const void* all_records, int64_t n_slots, int64_t n_total);
+ *      One process per GPU; every rank holds a contiguous shard of the reads in its ctx (amg_set_reads), rank r the
+ *      reads after rank r - 1's.  amg_dist_merge replaces amg_build / amg_build_filtered: every rank ends with the
+ *      graph GeneMerGraph would build from ALL reads (node / edge ids, coverages, list orders) and with the node ids
+ *      of its own reads' windows; filters and clipping then run identically everywhere, amg_correct_reads on the
+ *      rank's reads.  The library runs the device phases AND the exchanges between them (RCCL on the ctx's stream:
+ *      grouped ncclSend / ncclRecv all-to-alls to the key owners and back, ncclAllGather of the held records;
+ *      librccl is opened by amg_dist_init, libamg.so does not link it).  Collective: every rank calls with the same
+ *      arguments.  A failing rank tells its peers in the next count exchange (nobody waits for a rank that has left);
+ *      two gene-mers under one 64-bit merge key make every rank repeat the build with the next seed.
+ *      Phases and record formats: amira_amd/csrc/amg_dist.hip, DESIGN.md section 6. ------------------------------ */
+/* 128 bytes that name a communicator (ncclGetUniqueId): made on one rank, handed to every rank by the caller's own
+ * means (a file, a socket, MPI, torch.distributed's store), then passed to amg_dist_init by all of them */
+int amg_dist_unique_id(void* out, int32_t bytes);
+int amg_dist_init(amg_ctx* ctx, const void* unique_id, int32_t rank, int32_t world);
+/* min_node_cov / min_edge_cov > 1 fuse filter_graph (construct_graph.py:523-540) into the merge: owners answer "dropped"
+ * for nodes / edge classes below the thresholds, so the (often 10x larger) set of low-coverage nodes is never
+ * replicated.  The state then equals the merged build followed by amg_filter for everything the correction reads (live
+ * nodes and edges, their coverages and list orders, masked windows, reads to correct); ids number the survivors only
+ * and component ids are those of the filtered graph.  (1, 1): plain build. */
+int amg_dist_merge(amg_ctx* ctx, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
+/* releases the communicator and the merge buffers (amg_destroy does it too) */
+int amg_dist_finalize(amg_ctx* ctx);
+
+/* The same build with the exchanges left to the CALLER (another transport: the tests run ranks as processes over
+ * gloo, staging through the host): amg_dist_init_external instead of amg_dist_init, then amg_dist_merge_begin and
+ * amg_dist_merge_next until it returns 0.  A return of 1 means: perform *out on every rank, then call again.
+ * Buffers are DEVICE pointers owned by the ctx; counts are host arrays valid until the next call. */
+enum { AMG_XFER_ALL_TO_ALL = 1, AMG_XFER_ALL_GATHER = 2 };
+typedef struct amg_xfer {
+  int32_t kind;               /* AMG_XFER_*                                                                 */
+  int32_t elem_bytes;         /* bytes per element                                                          */
+  const void* send;           /* all-to-all: elements for rank 0, then rank 1, ...; all-gather: `count` elements */
+  void* recv;                 /* all-to-all: elements from rank 0, then rank 1, ...; all-gather: world * count   */
+  const int64_t* send_counts; /* all-to-all: elements for every rank [world]                                */
+  const int64_t* recv_counts; /* all-to-all: elements from every rank [world]                               */
+  int64_t count;              /* all-gather: elements every rank contributes                                */
+} amg_xfer;
+int amg_dist_init_external(amg_ctx* ctx, int32_t rank, int32_t world);
+int amg_dist_merge_begin(amg_ctx* ctx, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
+int amg_dist_merge_next(amg_ctx* ctx, amg_xfer* out);
+/* `world` EMULATED ranks: the ctxs of one process on one device, rank r = ctxs[r], the exchanges as device copies —
+ * the device phases are exactly those of the N-GPU run (tests on a one-GPU box, tools/scaling_model.py) */
+int amg_dist_merge_local(amg_ctx* const* ctxs, int32_t world, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
+/* bytes between a device pointer of the ctx's device and the host, ordered after the ctx's stream and synchronous
+ * (what a host-staged transport needs around its collectives) */
+int amg_copy_d2h(amg_ctx* ctx, const void* device_ptr, void* host_ptr, int64_t bytes);
+int amg_copy_h2d(amg_ctx* ctx, void* device_ptr, const void* host_ptr, int64_t bytes);
+/* counters of the ctx's merged builds since the last reset: out[0] host waits on exchanged counts, [1] exchanges,
+ * [2] most bytes of records sent to ONE peer, [3] the same of replies, [4] bytes contributed to the all-gathers,
+ * [5] builds repeated after a merge-key collision, [6] bytes of records sent to all peers */
+int amg_dist_stats(amg_ctx* ctx, int64_t* out, int32_t reset);
+/* synchronised wall time per phase of the merge driver since the last call (on = 1: keep measuring — every phase is
+ * bracketed by stream synchronisations —, 0: stop); names[i] are static strings; returns the number of phases */
+int amg_dist_phase_ms(amg_ctx* ctx, int32_t on, const char** names, double* ms, int32_t cap);
 
 /* ---- native front-end / write-back (host code, no GPU needed):
  *      gene-call JSON {"read": ["+geneA", "-geneB", ...]} as dumped / reloaded by the reference
@@ -375,10 +379,6 @@ int64_t amg_py_tuple_hash(const int64_t* item_hashes, int64_t n);
  * iteration order (out_off[n_sets + 1], out_keys). */
 int amg_pyset_script(const int32_t* ops, int64_t n_ops, const int64_t* key_hash, int32_t n_sets,
                      int32_t* out_keys, int64_t* out_off);
-
-/* n_words (<= 96) 64-bit words of device memory to the host, ordered after everything queued on the ctx's stream, at
- * the latency of the ctx's pinned mailbox (~10 us): how amira_amd/dist.py reads the record counts of its exchanges */
-int amg_fetch_words(amg_ctx* ctx, const void* device_words, int32_t n_words, uint64_t* out);
 
 /* ---- per-stage device time of the last call, for bench.py ------------------------- */
 /* names[i] points at static strings; returns the number of stages (<= cap). */

@@ -187,8 +187,9 @@ def test_sharded_sweep_equals_unsharded(world):
         e.close()
 
 
-def test_dist_build_over_rccl_world1():
-    """the torch.distributed driver itself (RCCL collectives on device tensors), world = 1"""
+def test_dist_build_over_rccl_world1(monkeypatch):
+    """amg_dist_init / amg_dist_merge over RCCL itself (libamg's own communicator; its ncclSend / ncclRecv groups and
+    all-gathers on the engine's stream), world = 1 with every exchange forced through the transport"""
     import os
     import socket
     import torch
@@ -197,18 +198,95 @@ def test_dist_build_over_rccl_world1():
     from amira_amd.dist import dist_build
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    monkeypatch.setenv("AMG_DIST_ALWAYS_EXCHANGE", "1")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
         vocab, toks, offs, _ = tokenize(reads)
         ref = Engine(0); ref.set_reads(toks, offs, vocab.two_v); ref.build(5)
-        eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v); dist_build(eng, 5, always_exchange=True)
+        eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v); dist_build(eng, 5)
+        assert eng.dist_stats()["exchanges"] == 10     # five per kind of record, all of them through RCCL
         assert_same_graph(graph_state(eng), graph_state(ref))
         assert np.array_equal(eng.read_nodes()[0], ref.read_nodes()[0])
         eng.close(); ref.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_dist_merge_without_torch_distributed():
+    """the C entry points alone, as a C caller would use them: unique id, amg_dist_init, amg_dist_merge (world 1)"""
+    from amira_amd import Engine, tokenize
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    vocab, toks, offs, _ = tokenize(reads)
+    ref = Engine(0); ref.set_reads(toks, offs, vocab.two_v); ref.build(5)
+    eng = Engine(0); eng.set_reads(toks, offs, vocab.two_v)
+    eng.dist_init(Engine.dist_unique_id(), 0, 1)
+    eng.dist_merge(5)
+    assert_same_graph(graph_state(eng), graph_state(ref))
+    eng.dist_finalize()
+    eng.dist_merge(5)          # world 1 needs no communicator
+    assert_same_graph(graph_state(eng), graph_state(ref))
+    eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_merge_key_collisions_repeat_the_build_on_every_rank(world, monkeypatch):
+    """merge keys cut to 10 bits on the first attempt (test hook): gene-mers share them, some rank notices (a tuple that
+    is not its key's holder's; on fingerprint shards the edge pass's verify), everybody learns it in the next count
+    exchange and repeats the build with the next seed"""
+    from amira_amd import Engine, tokenize
+    from amira_amd.dist import dist_build_loopback
+    monkeypatch.setenv("AMG_TEST_DIST_WEAK_KEYS", "1")
+    reads, _, _ = P.synth_inputs(17, 800, 40, 150, 0.05)
+    k = 5
+    vocab, toks, offs, _ = tokenize(reads)
+    ref = Engine(0); ref.set_reads(toks, offs, vocab.two_v); ref.build(k)
+    want = graph_state(ref)
+    engines = []
+    for t, o, lo, hi in make_shards(toks, offs, world):
+        e = Engine(0); e.set_reads(t, o, vocab.two_v); engines.append(e)
+    dist_build_loopback(engines, k)
+    for e in engines:
+        assert e.dist_stats()["repeated_builds"] == 1
+        assert_same_graph(graph_state(e), want)
+    for e in engines + [ref]:
+        e.close()
+
+
+def test_failing_rank_releases_its_peers(monkeypatch):
+    """a rank whose device phase fails takes part in the next count exchange with a negative code: nobody waits for it,
+    everybody raises — the failing rank its own error, the others "rank 1 failed" """
+    from amira_amd import Engine, tokenize
+    from amira_amd._ffi import AmgError
+    monkeypatch.setenv("AMG_TEST_DIST_FAIL", "1")
+    reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
+    vocab, toks, offs, _ = tokenize(reads)
+    engines = []
+    for t, o, lo, hi in make_shards(toks, offs, 3):
+        e = Engine(0); e.set_reads(t, o, vocab.two_v); engines.append(e)
+    for r, e in enumerate(engines):
+        e.dist_init_external(r, 3)
+        e.dist_merge_begin(5)
+    # by hand what amg_dist_merge_local does, to see every rank's own verdict
+    xs = [e.dist_merge_next() for e in engines]
+    assert all(x is not None and x.kind == 1 and x.elem_bytes == 32 for x in xs)     # the count messages
+    msgs = [np.empty(3 * 4, np.int64) for _ in engines]
+    for e, x, m in zip(engines, xs, msgs):
+        e.copy_d2h(x.send, m)
+    for dst, (e, x) in enumerate(zip(engines, xs)):
+        e.copy_h2d(x.recv, np.concatenate([m[4 * dst: 4 * dst + 4] for m in msgs]))
+    codes = []
+    for e in engines:
+        with pytest.raises(AmgError) as err:
+            e.dist_merge_next()
+        codes.append(err.value.code)
+    assert codes == [-7, -3, -7]          # AMG_E_DIST on the peers, the failing rank's own AMG_E_STATE
+    monkeypatch.delenv("AMG_TEST_DIST_FAIL")
+    from amira_amd.dist import dist_build_loopback
+    dist_build_loopback(engines, 5)       # the engines are usable afterwards
+    for e in engines:
+        e.close()
 
 
 def live_state(eng):
@@ -378,12 +456,13 @@ def test_dist_build_over_rccl_two_processes(tmp_path, empty_rank):
     ref.close()
 
 
-def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep):
+def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep, env=None):
     """one rank of a multi-PROCESS merged build whose ranks share ONE GPU: torch.distributed over gloo (the record
     buffers are staged through the host around the collectives, amira_amd/dist.py) — everything of the N > 1 driver
     except the RCCL transport: count exchanges, padded all-gather, reply trip, the order of the collectives"""
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(env or {})
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -425,12 +504,12 @@ def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep):
     dist.destroy_process_group()
 
 
-def _run_gloo(tmp_path, world, empty_rank, sweep):
+def _run_gloo(tmp_path, world, empty_rank, sweep, env=None):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, str(tmp_path), empty_rank, sweep)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, str(tmp_path), empty_rank, sweep, env)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -444,10 +523,15 @@ def _run_gloo(tmp_path, world, empty_rank, sweep):
 
 
 @pytest.mark.parametrize("world,empty_rank", [(2, None), (3, 1)])
-def test_dist_build_between_processes_sharing_the_gpu(tmp_path, world, empty_rank, key_mode):
-    """the torch.distributed driver between real processes (gloo, one GPU shared): every rank ends with the unsharded graph"""
+@pytest.mark.parametrize("weak_keys", [False, True])
+def test_dist_build_between_processes_sharing_the_gpu(tmp_path, world, empty_rank, key_mode, weak_keys):
+    """the merge between real processes (gloo, one GPU shared: libamg asks for the exchanges, amira_amd.dist performs
+    them through the host): every rank ends with the unsharded graph; weak_keys: after a repeated build (merge-key
+    collisions on the first attempt, test hook)"""
     from amira_amd import Engine, tokenize
-    got = _run_gloo(tmp_path, world, empty_rank, sweep=False)
+    if weak_keys and (world, empty_rank) != (2, None):
+        pytest.skip("one configuration is enough")
+    got = _run_gloo(tmp_path, world, empty_rank, sweep=False, env={"AMG_TEST_DIST_WEAK_KEYS": "1"} if weak_keys else None)
     reads, _, _ = P.synth_inputs(17, 800, 40, 150, 0.05)
     vocab, toks, offs, _ = tokenize(reads)
     ref = Engine(0)
