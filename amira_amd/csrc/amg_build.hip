@@ -980,6 +980,7 @@ int bs_finish_from_pairs(amg_ctx* c) {
   c->n_edges = total;
   stage_end(c);
   c->ladj_valid = false;
+  c->ladj_stale = false;
   c->comp_valid = false;
   c->adj_valid = false;
   c->n_components = 0;

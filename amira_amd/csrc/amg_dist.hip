@@ -87,7 +87,7 @@ struct DistState {
   int n_sources = 0;
   bool exchanged = false;
   DevBuf cnt_send, cnt_recv, hc_send, hc_recv, offs;
-  DevBuf send, recv, rep_out, rep_in, held, held_pad, gathered, own_cnt;
+  DevBuf send, recv, rep_out, rep_in, held, held_pad, gathered;
   const void* gathered_p = nullptr;
   const void* recv_p = nullptr;    // the records this rank owns the keys of (one rank: what it packed)
   void* rep_out_p = nullptr;       // the answers to them
@@ -96,6 +96,8 @@ struct DistState {
   int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double phase_ms[2 * S_N] = {0};
   bool time_phases = false;
+  int phase_now = -1;
+  std::chrono::steady_clock::time_point phase_t0;
 };
 
 static DistState* dm(amg_ctx* c) {
@@ -160,7 +162,7 @@ void dist_release(amg_ctx* c) {
   if (!d) return;
   if (d->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
   DevBuf* all[] = {&d->cnt_send, &d->cnt_recv, &d->hc_send, &d->hc_recv, &d->offs, &d->send, &d->recv, &d->rep_out,
-                   &d->rep_in, &d->held, &d->held_pad, &d->gathered, &d->own_cnt};
+                   &d->rep_in, &d->held, &d->held_pad, &d->gathered};
   for (DevBuf* b : all) b->release();
   delete d;
   c->dist = nullptr;
@@ -392,24 +394,86 @@ static const unsigned int* send_order(const amg_ctx* c) {
   return c->dist_sorted ? c->dist_a.as<unsigned int>() + 3 * (c->dist_nspace + 1) : nullptr;
 }
 
-// n ids bucketed (claim ids in use, holes included), n_real records among them: sorts (dest, idx) into (dest_sorted,
-// order) and leaves the per-destination counts in dist_cnt ON THE DEVICE (world > 1; one rank: n_real, known here)
+// Records by destination without a sort: a histogram of the destinations (LDS per tile, one atomic per tile and bin), the
+// bins' first places, and a scatter in which every tile reserves its stretch of each bin with one atomic.  The order of
+// the records INSIDE a destination is whatever the atomics make it — owners sum counts and minimise first-seen values,
+// and replies come back in the order the records left.  (A library radix sort of 5.4 M (destination, index) pairs was
+// ~0.25 ms of a first build's node phase.)
+#define BK_MAX 256
+#define BK_PER 8
+__global__ __launch_bounds__(256) void k_bucket_hist(const unsigned int* __restrict__ dest, long long n, int bins,
+                                                     unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[BK_MAX];
+  for (int b = threadIdx.x; b < bins; b += 256) h[b] = 0u;
+  __syncthreads();
+  const long long i0 = (long long)blockIdx.x * (256 * BK_PER) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) {
+    const long long i = i0 + (long long)j * 256;
+    if (i < n) atomicAdd(&h[dest[i]], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 256)
+    if (h[b]) atomicAdd(&counts[b], (unsigned long long)h[b]);
+}
+__global__ void k_bucket_starts(const unsigned long long* __restrict__ counts, int bins, unsigned long long* __restrict__ cursor) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned long long s = 0;
+  for (int b = 0; b < bins; ++b) {
+    cursor[b] = s;
+    s += counts[b];
+  }
+}
+__global__ __launch_bounds__(256) void k_bucket_scatter(const unsigned int* __restrict__ dest, long long n, int bins,
+                                                        unsigned long long* __restrict__ cursor, unsigned int* __restrict__ order) {
+  __shared__ unsigned int h[BK_MAX];
+  __shared__ unsigned long long base[BK_MAX];
+  for (int b = threadIdx.x; b < bins; b += 256) h[b] = 0u;
+  __syncthreads();
+  const long long i0 = (long long)blockIdx.x * (256 * BK_PER) + threadIdx.x;
+  unsigned int d[BK_PER], rank[BK_PER];
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) {
+    const long long i = i0 + (long long)j * 256;
+    d[j] = 0u;
+    rank[j] = 0u;
+    if (i < n) {
+      d[j] = dest[i];
+      rank[j] = atomicAdd(&h[d[j]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 256)
+    if (h[b]) base[b] = atomicAdd(&cursor[b], (unsigned long long)h[b]);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < BK_PER; ++j) {
+    const long long i = i0 + (long long)j * 256;
+    if (i < n) order[base[d[j]] + rank[j]] = (unsigned int)i;
+  }
+}
+
+// n ids bucketed (claim ids in use, holes included: destination `world`), n_real records among them: `order` lists the
+// ids by destination and the per-destination counts stay in dist_cnt ON THE DEVICE (one rank without holes: nothing to do)
 static int dest_counts(amg_ctx* c, long long n, long long n_real, int world, const Bucketing& b) {
   hipStream_t st = c->stream;
   c->dist_nspace = n;
   c->dist_sorted = world > 1 || n != n_real;
-  if (world == 1) {
-    // one destination; with unclaimed ids in between the sort moves them behind the records
-    if (n != n_real && n > 0) AMGCHK(prim_sort_u32_u32(c, b.dest, b.dest_sorted, b.idx, b.order, (size_t)n, 2));
+  if (!c->dist_sorted) return AMG_OK;
+  const int bins = world + 1;
+  AMGCHK(c->dist_cnt.ensure((size_t)(2 * bins + 2) * sizeof(unsigned long long)));
+  unsigned long long* counts = c->dist_cnt.as<unsigned long long>();
+  unsigned long long* cursor = counts + bins + 1;
+  HIPCHK(hipMemsetAsync(counts, 0, (size_t)(2 * bins + 2) * sizeof(unsigned long long), st));
+  if (n <= 0) return AMG_OK;
+  if (bins <= BK_MAX) {
+    hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(n, 256 * BK_PER)), dim3(256), 0, st, b.dest, n, bins, counts);
+    hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(1), 0, st, counts, bins, cursor);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nblk(n, 256 * BK_PER)), dim3(256), 0, st, b.dest, n, bins, cursor, b.order);
     return AMG_OK;
   }
-  AMGCHK(c->dist_cnt.ensure((size_t)(world + 1) * sizeof(unsigned long long)));
-  HIPCHK(hipMemsetAsync(c->dist_cnt.p, 0, (size_t)(world + 1) * sizeof(unsigned long long), st));
-  if (n > 0) {
-    AMGCHK(prim_sort_u32_u32(c, b.dest, b.dest_sorted, b.idx, b.order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
-    hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, b.dest_sorted, n, (unsigned int)world,
-                       c->dist_cnt.as<unsigned long long>());
-  }
+  AMGCHK(prim_sort_u32_u32(c, b.dest, b.dest_sorted, b.idx, b.order, (size_t)n, ilog2_ceil((uint64_t)world + 1) + 1));
+  hipLaunchKernelGGL(k_dest_counts, dim3(nblk(world, 64)), dim3(64), 0, st, b.dest_sorted, n, (unsigned int)world, counts);
   return AMG_OK;
 }
 
@@ -582,13 +646,21 @@ static int edges_local(amg_ctx* c, DistState* d) {
 }
 
 // ------------------------------------------------------------------ phase: owner-side reduce
-// Records of one key arrive from every rank that saw it.  They meet in an open-addressing table of 16-byte slots keyed
-// by the merge key: first-seen = the minimum (atomicMax of the complement), count = the sum, kept in a dense array
-// by slot.  Records that all come from ONE rank are distinct keys already: no table.  Every record is answered with
-// its key's global first-seen and total, or "dropped" when the total stays below the fused filter's threshold.
-struct OSlot {
-  unsigned long long key, first_inv;
+// Records of one key arrive from every rank that saw it.  They meet in an open-addressing table keyed by the merge key,
+// one 32-byte slot = one sector per key.  The record that CREATES a slot (one compare-and-swap on the key) leaves its
+// first-seen and count there with plain stores in fields of its own; only the records that FIND their key pay atomics
+// (atomicMax on the complement of first-seen, atomicAdd on the count) in the slot's shared fields — nine keys in ten of
+// an uncorrected read set come in one record.  Records that all come from ONE rank are distinct keys already: no
+// table.  Every record is answered with its key's global first-seen and total, or "dropped" when the total stays
+// below the fused filter's threshold.
+struct __attribute__((aligned(32))) OSlot {
+  unsigned long long key;
+  unsigned long long first_inv;  // others: ~min first-seen (0: nobody but the creator)
+  unsigned long long cfirst;     // creator's first-seen
+  unsigned int cnt;              // others' counts
+  unsigned int ccnt;             // creator's count
 };
+static_assert(sizeof(OSlot) == 32, "owner slot = one sector");
 
 __device__ __forceinline__ bool edge_key_self_loop(unsigned long long key) {
   const unsigned int lo = (unsigned int)((key >> 32) & 0x7fffffffull);
@@ -597,7 +669,7 @@ __device__ __forceinline__ bool edge_key_self_loop(unsigned long long key) {
 }
 
 __global__ void k_own_upsert(const unsigned long long* __restrict__ recs, long long n, OSlot* tab, unsigned long long mask,
-                             unsigned int* __restrict__ cnt, unsigned int* __restrict__ recslot, unsigned long long* status) {
+                             unsigned int* __restrict__ recslot, unsigned long long* status) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long key = recs[3 * j], fi = ~recs[3 * j + 1];
@@ -608,11 +680,16 @@ __global__ void k_own_upsert(const unsigned long long* __restrict__ recs, long l
     unsigned long long cur = ld_u64(&s->key);
     if (cur == 0ull) {
       cur = atomicCAS(&s->key, 0ull, key);
-      if (cur == 0ull) cur = key;
+      if (cur == 0ull) {
+        s->cfirst = ~fi;
+        s->ccnt = c;
+        recslot[j] = (unsigned int)idx;
+        return;
+      }
     }
     if (cur == key) {
       if (ld_u64(&s->first_inv) < fi) atomicMax(&s->first_inv, fi);
-      atomicAdd(cnt + idx, c);
+      atomicAdd(&s->cnt, c);
       recslot[j] = (unsigned int)idx;
       return;
     }
@@ -627,17 +704,18 @@ __global__ void k_own_upsert(const unsigned long long* __restrict__ recs, long l
 
 template <bool MULTI>
 __global__ void k_own_reply(const unsigned long long* __restrict__ recs, long long n, int is_edge, unsigned int min_cov,
-                            const OSlot* __restrict__ tab, const unsigned int* __restrict__ cnt,
-                            const unsigned int* __restrict__ recslot, unsigned long long* __restrict__ replies) {
+                            const OSlot* __restrict__ tab, const unsigned int* __restrict__ recslot,
+                            unsigned long long* __restrict__ replies) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long key = recs[3 * j];
   unsigned long long gfirst = recs[3 * j + 1];
   unsigned long long total = (unsigned int)recs[3 * j + 2];
   if (MULTI) {
-    const unsigned int s = recslot[j];
-    gfirst = ~tab[s].first_inv;
-    total = cnt[s];
+    const OSlot s = tab[recslot[j]];
+    const unsigned long long others = ~s.first_inv;  // (nobody but the creator: ~0)
+    gfirst = s.cfirst < others ? s.cfirst : others;
+    total = (unsigned long long)s.ccnt + s.cnt;
   }
   // (edge classes that are self-loops count twice)
   const unsigned long long cov = (is_edge && edge_key_self_loop(key)) ? total * 2 : total;
@@ -656,20 +734,19 @@ static int reduce_records(amg_ctx* c, DistState* d, int is_edge) {
   unsigned long long* status = c->status.as<unsigned long long>();
   if (!multi) {
     hipLaunchKernelGGL(k_own_reply<false>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, is_edge, min_cov,
-                       (const OSlot*)nullptr, (const unsigned int*)nullptr, (const unsigned int*)nullptr, replies);
+                       (const OSlot*)nullptr, (const unsigned int*)nullptr, replies);
     return AMG_OK;
   }
   const uint64_t slots = pow2_at_least((uint64_t)n * 2 + 16);
   {
     ClearList cl;
     cl.add(c->dist_gtab.p, (size_t)slots * sizeof(OSlot));
-    cl.add(d->own_cnt.p, (size_t)slots * sizeof(unsigned int));
     AMGCHK(clear_many(c, cl));
   }
   hipLaunchKernelGGL(k_own_upsert, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, c->dist_gtab.as<OSlot>(),
-                     (unsigned long long)(slots - 1), d->own_cnt.as<unsigned int>(), c->s3.as<unsigned int>(), status);
+                     (unsigned long long)(slots - 1), c->s3.as<unsigned int>(), status);
   hipLaunchKernelGGL(k_own_reply<true>, dim3(nblk(n, 256)), dim3(256), 0, st, recs, n, is_edge, min_cov,
-                     c->dist_gtab.as<OSlot>(), d->own_cnt.as<unsigned int>(), c->s3.as<unsigned int>(), replies);
+                     c->dist_gtab.as<OSlot>(), c->s3.as<unsigned int>(), replies);
   return AMG_OK;
 }
 
@@ -1084,6 +1161,16 @@ static void xfer_ag(DistState* d, amg_xfer* x, const void* send, void* recv, int
   if (stat) d->st[4] += count * elem_bytes;
 }
 
+// per-phase clock of the driver (amg_dist_phase_ms): the phase that ends is booked, `next` begins (-1: none)
+static void phase_tick(amg_ctx* c, DistState* d, int next) {
+  if (!d->time_phases) return;
+  (void)hipStreamSynchronize(c->stream);
+  const auto now = std::chrono::steady_clock::now();
+  if (d->phase_now >= 0) d->phase_ms[d->phase_now] += std::chrono::duration<double, std::milli>(now - d->phase_t0).count();
+  d->phase_now = next;
+  d->phase_t0 = now;
+}
+
 // runs the machine up to its next exchange.  1: *x is to be performed, then call again; 0: the build is complete
 static int advance(amg_ctx* c, amg_xfer* x) {
   DistState* d = dm(c);
@@ -1093,6 +1180,7 @@ static int advance(amg_ctx* c, amg_xfer* x) {
   unsigned long long* status = c->status.as<unsigned long long>();
   for (;;) {
     const int is_edge = d->kind;
+    phase_tick(c, d, d->kind * S_N + d->state);
     switch (d->state) {
       case S_LOCAL: {
         const int r = is_edge ? edges_local(c, d) : nodes_local(c, d);
@@ -1192,7 +1280,6 @@ static int advance(amg_ctx* c, amg_xfer* x) {
         if (d->n_sources > 1) {
           const uint64_t slots = pow2_at_least((uint64_t)d->n_recv * 2 + 16);
           AMGCHK(c->dist_gtab.ensure((size_t)slots * sizeof(OSlot)));
-          AMGCHK(d->own_cnt.ensure((size_t)slots * sizeof(unsigned int)));
           AMGCHK(c->s3.ensure((size_t)(d->n_recv + 1) * sizeof(unsigned int)));
         }
         stage_begin(c, is_edge ? "merge_edge_pack" : "merge_node_pack");
@@ -1336,19 +1423,9 @@ extern "C" int amg_dist_merge_next(amg_ctx* c, amg_xfer* out) {
   if (!out) return amg_fail(AMG_E_ARG, "null xfer");
   DistState* d = dm(c);
   if (d->state == S_IDLE) return amg_fail(AMG_E_STATE, "amg_dist_merge_begin first");
-  const int ph = d->kind * S_N + d->state;
-  std::chrono::steady_clock::time_point t0;
-  if (d->time_phases) {
-    (void)hipStreamSynchronize(c->stream);
-    t0 = std::chrono::steady_clock::now();
-  }
   const int r = advance(c, out);
   if (r < 0) d->state = S_IDLE;
-  if (d->time_phases) {
-    // (a call that runs through several states — one rank, nothing on the wire — is booked on the state it began in)
-    (void)hipStreamSynchronize(c->stream);
-    d->phase_ms[ph] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
+  phase_tick(c, d, -1);
   return r;
 }
 

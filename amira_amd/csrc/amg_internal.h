@@ -197,6 +197,7 @@ struct amg_ctx {
   DevBuf ladj_pos, ladj_keys;  // scratch of the live-adjacency build (callers hold s0..s5)
   DevBuf hub_bits;             // bitmaps over the edge ids for adjacency rows beyond HUGE_ROW (huge_row_in_order)
   bool ladj_valid = false;
+  bool ladj_stale = false;  // the live lists are those of the graph before some NODES died (ensure_live_adj patches them)
   bool comp_valid = false, adj_valid = false;  // component ids / full edge lists of the built graph are made on demand
   // reads
   DevBuf read_fix;  // uint8[n_reads]  read is in _readsToCorrect

@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256) void k_mask_reads(int* __restrict__ tok_node,
 
 static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
   hipStream_t st = c->stream;
+  // NODES died, and every edge that dies with them has a dead end (no edge falls to a coverage threshold of its own):
+  // live lists that exist stay and are brought up to date when somebody walks them again (ensure_live_adj: k_lr_patch)
+  if (c->ladj_valid && min_edge_cov <= 1 && !getenv("AMG_NO_LADJ_PATCH")) c->ladj_stale = true;  // (A/B + test switch)
+  else if (!c->ladj_stale || min_edge_cov > 1) c->ladj_stale = false;
   c->ladj_valid = false;
   c->match_valid = false;  // node-id patterns of a cached K6 result may name removed nodes
   if (c->n_edges > 0)
@@ -280,9 +284,45 @@ __global__ __launch_bounds__(256) void k_lr_long(const unsigned int* __restrict_
 // forward/backward edge lists with the removed edges squeezed out: the walkers below then
 // never touch a dead edge (a hub node of an uncorrected graph lists hundreds of them), and the
 // lists of the removed edges are never made at all
+// The live lists after NODES died: a row of a dead node empties, the other rows drop their entries with a dead
+// target, in place and in order — one pass over the row records with the targets' alive bytes out of the L2, where
+// making the lists again from the live edges is a flag, a scan and five passes over them
+__global__ void k_lr_patch(int4* __restrict__ lrows, int2* __restrict__ lent, long long n_rows,
+                           const unsigned char* __restrict__ n_alive) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const int4 rw = lrows[r];
+  if (rw.y == 0) return;
+  if (!n_alive[r >> 1]) {
+    lrows[r] = make_int4(rw.x, 0, 0, 0);
+    return;
+  }
+  if (rw.y == 1) {
+    if (!n_alive[rw.z]) lrows[r] = make_int4(rw.x, 0, 0, 0);
+    return;
+  }
+  int w = 0;
+  int2 first = make_int2(0, 0);
+  for (int j = 0; j < rw.y; ++j) {
+    const int2 e = lent[rw.x + j];
+    if (!n_alive[e.x]) continue;
+    if (w != j) lent[rw.x + w] = e;
+    if (w == 0) first = e;
+    ++w;
+  }
+  if (w != rw.y) lrows[r] = make_int4(rw.x, w, first.x, first.y);
+}
+
 static int ensure_live_adj(amg_ctx* c) {
   if (c->ladj_valid) return AMG_OK;
   hipStream_t st = c->stream;
+  if (c->ladj_stale) {
+    hipLaunchKernelGGL(k_lr_patch, dim3(nblk(2 * c->n_nodes, 256)), dim3(256), 0, st, c->ladj_rows.as<int4>(),
+                       c->ladj.as<int2>(), 2 * c->n_nodes, c->node_alive.as<unsigned char>());
+    c->ladj_stale = false;
+    c->ladj_valid = true;
+    return AMG_OK;
+  }
   const long long rows = 2 * c->n_nodes, E = c->n_edges;
   AMGCHK(c->ladj_rows.ensure((size_t)(rows + 2) * sizeof(int4)));
   AMGCHK(c->ladj_pos.ensure((size_t)(E + 2) * sizeof(long long)));
@@ -372,6 +412,7 @@ extern "C" int amg_remove_edges(amg_ctx* c, const int32_t* edge_ids, int64_t n) 
   hipLaunchKernelGGL(k_kill_listed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->s0.as<int>(), (long long)n,
                      c->n_edges, c->edge_alive.as<unsigned char>());
   c->ladj_valid = false;
+  c->ladj_stale = false;  // (an edge left with both ends alive: the lists are made again)
   c->match_valid = false;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->have_corrected = false;

@@ -116,6 +116,44 @@ def test_low_coverage_components(eng):
         compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
 
 
+@pytest.mark.parametrize("patch", [True, False])
+def test_live_lists_after_nodes_died(eng, monkeypatch, patch):
+    """filter -> correct_reads (the live forward / backward lists exist now) -> more nodes die (a component filter, then
+    listed nodes) -> correct_reads again: the walkers must see the lists of the graph as it is NOW — brought up to date
+    in place (k_lr_patch) or made again (AMG_NO_LADJ_PATCH=1) — against the oracle"""
+    from amira_amd import tokenize
+    from amira_oracle import GeneMerGraph
+    if not patch:
+        monkeypatch.setenv("AMG_NO_LADJ_PATCH", "1")
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    k = 5
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    eng.set_positions(gs, ge, np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64))
+    eng.build(k)
+    g = GeneMerGraph(reads, k, {r: list(v) for r, v in pos.items()})
+    order = list(g.get_nodes())                                          # engine node id = position here
+    eng.filter(3, 1)
+    g.filter_graph(3, 1)
+    # the engine re-threads: its lists exist from here on (checked against an oracle graph of its own — the reference's
+    # correct_reads rewrites the gene positions it was given, so `g` itself corrects only once, below)
+    g0 = GeneMerGraph(reads, k, {r: list(v) for r, v in pos.items()})
+    g0.filter_graph(3, 1)
+    check_corrected(eng, vocab, read_ids, *g0.correct_reads(fq))
+    eng.remove_low_coverage_components(12)
+    g.remove_low_coverage_components(12)
+    # every ninth live node of the middle of the graph goes too (remove_node, construct_graph.py:463-484)
+    live = [i for i, h in enumerate(order) if h in g.get_nodes()]
+    victims = live[len(live) // 4: 3 * len(live) // 4: 9]
+    assert len(victims) > 5
+    for i in victims:
+        g.remove_node(g.get_node_by_hash(order[i]))
+    eng.remove_nodes(victims)
+    compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, k), live_only=True)
+    check_corrected(eng, vocab, read_ids, *g.correct_reads(fq))
+
+
 def test_borrowed_device_inputs(eng):
     """inputs handed over as borrowed device pointers (on_device = 2): same corrected reads as
     with copied inputs, and the caller's arrays are untouched after build / correct / adopt"""

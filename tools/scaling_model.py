@@ -1,21 +1,22 @@
-"""usage: python tools/scaling_model.py [reads_per_rank [worlds, e.g. 1,8]] > profiles/r5_scaling_model.json
+"""usage: python tools/scaling_model.py [reads_per_rank [worlds, e.g. 1,8]] > profiles/r6_scaling_model.json
 
 A MODEL, not a measurement, of `bench.py --gpus N` (weak scaling, N x reads_per_rank reads, every build merged by key
 owner): the whole cleaning sweep is run with W = 1, 2, 4, 8 EMULATED ranks on the one GPU there is (one Engine per
-rank, loop-back exchange: the device phases are exactly those of the N-GPU run, only the wire is missing) and every
-device phase is timed per rank (synchronised wall time of the phase call, summed over the ranks of a step and divided
-by W).  Bytes that would cross xGMI are counted per exchange from the actual record counts.  From these:
+rank, amg_dist_merge_local: the device phases are exactly those of the N-GPU run, only the wire is missing) and every
+device phase is timed per rank (synchronised wall time of the phase, summed over the ranks of a step and divided by W:
+libamg's own per-phase clock for the merge, amg_dist_phase_ms, a wrapper around the Engine call for the rest).  Bytes
+that would cross xGMI, exchanges and host waits are counted by the merge driver itself (amg_dist_stats).  From these:
 
     t_rank(N)  = device ms of one rank's sweep at world N            (measured, emulated)
     t_wire(N)  = sum over exchanges of (bytes one rank sends to ONE peer) / link GB/s + latency per collective
                  (all-to-all / all-gather on a fully connected xGMI node: every peer has its own link, 7 links busy
                  at once, so the time of an exchange is the per-peer share over one link)
-    t_sync(N)  = host round trips per sweep (count exchanges whose result the host waits for) x t_roundtrip
+    t_sync(N)  = host waits per sweep on exchanged counts x t_roundtrip
     efficiency = t_rank(1, unmerged single-GPU sweep with the same fused first filter) / (t_rank(N) + t_wire(N) + t_sync(N))
 
 Assumptions are in the output ("assumptions").  The replicated share (phases every rank runs on the GLOBAL graph:
-ranking, emission, filter, clipping, live adjacency, components) is reported separately: it is what does not shrink
-with N."""
+unpacking the gathered records, emission, filter, clipping, live adjacency, components) is reported separately: it is
+what does not shrink with N."""
 import collections, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,55 +30,23 @@ LINK_GBS, COLL_LAT_US, SYNC_US = 153.0 * 0.8, 25.0, 60.0   # xGMI link (80 % of 
 w = bench.WORKLOADS["cfg3-sweep"]
 L, k = w["L"], w["k"]
 acc = collections.defaultdict(float)
-wire = collections.defaultdict(float)
-syncs = collections.Counter()
 
 
 def timed(name, fn):
     def wrap(self, *a, **kw):
         torch.cuda.synchronize(); t = time.perf_counter(); r = fn(self, *a, **kw); torch.cuda.synchronize()
-        tag = name + (":" + str(a[0]) if name in ("dist_pack", "dist_reduce", "dist_global") else "")
-        acc[tag] += (time.perf_counter() - t) * 1e3
+        acc[name] += (time.perf_counter() - t) * 1e3
         return r
     return wrap
 
 
-for n in ("dist_nodes_local", "dist_edges_local", "dist_pack", "dist_reduce", "dist_global", "filter", "correct_reads",
-          "adopt_corrected", "remove_short_linear_paths", "finalize", "build", "build_filtered"):
+for n in ("filter", "correct_reads", "adopt_corrected", "remove_short_linear_paths", "finalize", "build", "build_filtered"):
     setattr(Engine, n, timed(n, getattr(Engine, n)))
 
-# count what would travel: wrap the generator the drivers share
-plain_steps = D.steps
-
-
-def counting_steps(engine, kk, world, rank, *a, **kw):
-    gen = plain_steps(engine, kk, world, rank, *a, **kw)
-    reply = None
-    while True:
-        try:
-            req = gen.send(reply)
-        except StopIteration:
-            return
-        if req[0] == "a2a":
-            sc, rec = req[2], req[3]
-            wire["a2a_bytes_per_peer"] += max((c for i, c in enumerate(sc) if i != rank), default=0) * rec
-            wire["a2a_bytes_sent"] += sum(c for i, c in enumerate(sc) if i != rank) * rec
-            syncs["count exchange (a2a)"] += 1
-            syncs["send counts read-back"] += 1
-        elif req[0] == "ag":
-            wire["ag_bytes_per_peer"] += req[2] * req[3]
-            syncs["count exchange (ag)"] += 1
-            syncs["owned count read-back"] += 1
-        else:
-            wire["back_bytes_per_peer"] += max((c for i, c in enumerate(req[2]) if i != rank), default=0) * 8
-        reply = yield req
-
-
-D.steps = counting_steps
 out = {"what": "model of bench.py --gpus N from emulated ranks on one GPU; NOT a multi-GPU measurement", "reads_per_rank": N,
        "assumptions": {"link_GBs": LINK_GBS, "collective_latency_us": COLL_LAT_US, "host_round_trip_us": SYNC_US,
                        "topology": "8 GPUs fully connected, one xGMI link per peer: an exchange takes (bytes to ONE peer) / link",
-                       "device_ms": "synchronised wall time of each phase call, summed over a step's ranks, / W"},
+                       "device_ms": "synchronised wall time of each phase, summed over a step's ranks, / W"},
        "worlds": {}}
 
 # the single-GPU yardstick: the same sweep unmerged, first filter fused (what the merged path is compared with)
@@ -98,7 +67,6 @@ for W in WORLDS:
     vocab, toks, offs = bench.make_tokens(w, 0, W * N)
     engines = []
     for r in range(W):
-        lo, hi = r * N, (r + 1) * N
         en = Engine(0)
         en.set_timing(False)
         engines.append(en)
@@ -108,7 +76,9 @@ for W in WORLDS:
             lo, hi = r * N, (r + 1) * N
             en.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
             en.set_positions(gs, ge, rl)
-        acc.clear(); wire.clear(); syncs.clear()
+            en.dist_stats(reset=True)
+            en.dist_phase_ms(on=True)
+        acc.clear()
         torch.cuda.synchronize()
         D.dist_build_loopback(engines, k, 3, 1)
         for en in engines:
@@ -122,21 +92,28 @@ for W in WORLDS:
         for en in engines:
             en.finalize()
         torch.cuda.synchronize()
-        best = ({n: v / W for n, v in acc.items()}, {n: v / W for n, v in wire.items()}, {n: v / W for n, v in syncs.items()})
-    phases, wires, sync = best
-    replicated = sum(v for n, v in phases.items() if n.startswith("dist_global") or n in ("filter", "remove_short_linear_paths", "finalize"))
+        phases = collections.defaultdict(float)
+        stats = collections.defaultdict(float)
+        for en in engines:
+            for name, ms in en.dist_phase_ms(on=False).items():
+                phases["merge:" + name] += ms / W
+            for name, v in en.dist_stats(reset=True).items():
+                stats[name] += v / W
+        for name, ms in acc.items():
+            phases[name] += ms / W
+        best = (dict(phases), dict(stats))
+    phases, stats = best
+    replicated = sum(v for n, v in phases.items() if n.endswith("_global") or n in ("filter", "remove_short_linear_paths", "finalize"))
     t_rank = sum(phases.values())
-    n_coll = sync.get("count exchange (a2a)", 0) * 2 + sync.get("count exchange (ag)", 0) * 2 + 3   # counts + data (+ the replies)
-    t_wire = 0.0 if W == 1 else (sum(wires.get(n, 0.0) for n in ("a2a_bytes_per_peer", "ag_bytes_per_peer", "back_bytes_per_peer"))
-                                 / (LINK_GBS * 1e9) * 1e3 + n_coll * COLL_LAT_US * 1e-3)
-    n_sync = sum(sync.values()) + 3     # + the token-count all-gather of each merged build
-    t_sync = 0.0 if W == 1 else n_sync * SYNC_US * 1e-3
+    t_wire = 0.0 if W == 1 else (sum(stats.get(n, 0.0) for n in ("a2a_bytes_per_peer", "back_bytes_per_peer", "ag_bytes_contributed"))
+                                 / (LINK_GBS * 1e9) * 1e3 + stats["exchanges"] * COLL_LAT_US * 1e-3)
+    t_sync = 0.0 if W == 1 else stats["host_waits"] * SYNC_US * 1e-3
     out["worlds"][str(W)] = {
         "device_ms_per_rank_per_phase": {n: round(v, 3) for n, v in sorted(phases.items())},
         "device_ms_per_rank": round(t_rank, 3), "replicated_ms_per_rank": round(replicated, 3),
         "replicated_share": round(replicated / t_rank, 3),
-        "bytes_per_rank": {n: int(v) for n, v in wires.items()},
-        "host_round_trips_per_sweep": n_sync, "wire_ms": round(t_wire, 3), "sync_ms": round(t_sync, 3),
+        "per_rank_per_sweep": {n: int(v) for n, v in stats.items()},
+        "host_round_trips_per_sweep": stats["host_waits"], "wire_ms": round(t_wire, 3), "sync_ms": round(t_sync, 3),
         "predicted_sweep_ms": round(t_rank + t_wire + t_sync, 3),
         "predicted_weak_scaling_efficiency_vs_merged_n1": None,
         "predicted_weak_scaling_efficiency_vs_single_gpu_sweep": round(single / (t_rank + t_wire + t_sync), 3)}
