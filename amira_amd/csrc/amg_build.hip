@@ -286,8 +286,7 @@ __global__ void k_row_offsets(const unsigned int* __restrict__ keys, long long n
 //   (scan)         row sizes -> CSR offsets
 //   k_adjc_fill    every edge drops its id at offset + ticket (any order within the row)
 //   k_adjc_rows    a thread per row puts the row's ids in ascending order (= list order: edge ids follow insertion
-//                  order); rows longer than ADJ_SMALL are left to k_adjc_long, a workgroup per long row (hub nodes)
-#define ADJ_SMALL 32
+//                  order; rows of 3 .. 64 by the wave); rows longer than a wave are left to k_adjc_long, a workgroup per long row (hub nodes)
 __device__ __forceinline__ unsigned int adj_row_of(const int* __restrict__ e_src, const signed char* __restrict__ e_sdir,
                                                    long long e) {
   return 2u * (unsigned int)e_src[e] + (e_sdir[e] > 0 ? 0u : 1u);
@@ -306,28 +305,30 @@ __global__ void k_adjc_fill(const int* __restrict__ e_src, const signed char* __
   if (e < n_edges) tmp[off[adj_row_of(e_src, e_sdir, e)] + tick[e]] = (unsigned int)e;
 }
 
-__global__ void k_adjc_rows(const long long* __restrict__ off, long long n_rows, const unsigned int* __restrict__ tmp,
-                            int* __restrict__ adj_edge, unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
+__global__ __launch_bounds__(256) void k_adjc_rows(const long long* __restrict__ off, long long n_rows,
+                                                   const unsigned int* __restrict__ tmp, int* __restrict__ adj_edge,
+                                                   unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
   long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rows) return;
-  const long long o = off[r];
-  const int cnt = (int)(off[r + 1] - o);
-  if (cnt == 0) return;
-  if (cnt > ADJ_SMALL) {
+  long long o = 0;
+  int cnt = 0;
+  if (r < n_rows) {
+    o = off[r];
+    cnt = (int)(off[r + 1] - o);
+  }
+  bool mine = cnt > 2;
+  if (cnt == 1) {
+    adj_edge[o] = (int)tmp[o];
+  } else if (cnt == 2) {
+    const unsigned int a = tmp[o], b = tmp[o + 1];
+    adj_edge[o] = (int)(a < b ? a : b);
+    adj_edge[o + 1] = (int)(a < b ? b : a);
+  } else if (cnt > WAVE_ROW_MAX) {
     long_rows[atomicAdd(n_long, 1ull)] = (unsigned int)r;
-    return;
+    mine = false;
   }
-  unsigned int e[ADJ_SMALL];
-  for (int j = 0; j < cnt; ++j) {  // insertion sort: tickets come nearly in order
-    const unsigned int x = tmp[o + j];
-    int p = j;
-    while (p > 0 && e[p - 1] > x) {
-      e[p] = e[p - 1];
-      --p;
-    }
-    e[p] = x;
-  }
-  for (int j = 0; j < cnt; ++j) adj_edge[o + j] = (int)e[j];
+  // rows of 3 .. 64 ids: by the wave, one row at a time (wave_rows_in_order, amg_device.h)
+  wave_rows_in_order(mine, 0u, o, cnt, tmp,
+                     [&](unsigned int, long long ro, int, int rank, unsigned int x) { adj_edge[ro + rank] = (int)x; });
 }
 
 // a workgroup per long row: every element finds its rank among the row's (distinct) edge ids; rows beyond HUGE_ROW are
@@ -981,6 +982,7 @@ int bs_finish_from_pairs(amg_ctx* c) {
   stage_end(c);
   c->ladj_valid = false;
   c->ladj_stale = false;
+  c->pristine = !c->comp_from_claims;  // (a filtered build's labels are those of the graph BEFORE its filter)
   c->comp_valid = false;
   c->adj_valid = false;
   c->n_components = 0;
@@ -1055,7 +1057,7 @@ int ensure_adjacency(amg_ctx* c) {
     unsigned int* cnt = c->s1.as<unsigned int>();
     unsigned int* tick = c->s2.as<unsigned int>();
     unsigned int* tmp = c->s3.as<unsigned int>();
-    AMGCHK(c->s4.ensure((size_t)(E / ADJ_SMALL + 2) * sizeof(unsigned int)));
+    AMGCHK(c->s4.ensure((size_t)(E / WAVE_ROW_MAX + 2) * sizeof(unsigned int)));
     unsigned int* long_rows = c->s4.as<unsigned int>();
     unsigned long long* n_long = c->status.as<unsigned long long>() + ST_COMPACT_B;
     {

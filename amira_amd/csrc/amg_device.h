@@ -162,6 +162,31 @@ __device__ __forceinline__ unsigned int block_exscan_256(unsigned int v, unsigne
 // clear, set one bit per id, prefix-count the words, read the ids off in order: O(ids / 32 + row) for a workgroup,
 // whatever the row's length (a hub with a million neighbours would otherwise hold one workgroup for an hour).
 // bits: this workgroup's scratch of `words` words; emit(rank, id).  All 256 threads of the workgroup call it.
+// Rows of 3 .. 64 edge ids in ascending order by the WAVE, one row at a time: every lane that holds such a row (`mine`)
+// is served in turn — lane j takes the row's j-th id, its rank is the number of smaller ids (one shuffle per id of the
+// row), emit(row's tag, row's offset, row's length, rank, id) places it.  A thread per row with an insertion sort in a private array was the tail
+// of the list kernels: a row of thirty ids is ~500 dependent scratch accesses of ONE lane (0.9 ms for the genome rows
+// of a graph that carries the residual error nodes of eight read sets), here ~30 shuffles of a wave.
+// Every lane of the wave must call (no early returns before).
+#define WAVE_ROW_MAX 64
+template <class Emit>
+__device__ __forceinline__ void wave_rows_in_order(bool mine, unsigned int tag, long long off, int cnt,
+                                                   const unsigned int* __restrict__ ids, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(mine);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const long long o = __shfl(off, leader, 64);
+    const int n = __shfl(cnt, leader, 64);
+    const unsigned int tg = __shfl(tag, leader, 64);
+    const unsigned int x = lane < n ? ids[o + lane] : 0xffffffffu;
+    int rank = 0;
+    for (int q = 0; q < n; ++q) rank += __shfl(x, q, 64) < x ? 1 : 0;
+    if (lane < n) emit(tg, o, n, rank, x);
+  }
+}
+
 #define HUGE_ROW 1024
 template <class Emit>
 __device__ __forceinline__ void huge_row_in_order(const unsigned int* __restrict__ ids, long long cnt, unsigned int* bits,

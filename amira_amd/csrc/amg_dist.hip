@@ -51,9 +51,21 @@ static inline unsigned int nblk(long long n, int per) {
 
 #define REC_BYTES 24    // {u64 merge key, u64 first-seen, u32 count, u32 pad}: what travels to the owners (both kinds)
 #define REPLY_WORDS 2   // {u64 global first-seen | REPLY_DROPPED, u64 total count}: what comes back per record
-#define HELD_EDGE_BYTES 24  // {u64 class key, u64 first-seen, u32 count, u32 pad}
-// held node record: {u64 first-seen, u32 count, u32 k, i32 tok[k]} padded to 8 bytes
-static inline size_t held_node_bytes(int k) { return (size_t)((16 + 4 * k + 7) & ~7); }
+// held records are arrays of 32-bit words (they are the bytes of the all-gathers: 20 + 24 bytes per class + node of a
+// rebuilt graph at k = 5, where 8-byte fields and padding made 24 + 40):
+//   edge class: {key lo, key hi, first-seen lo, first-seen hi, count}
+//   node:       {first-seen lo, first-seen hi, count, tokens: two per word while every token fits 16 bits, else one}
+#define HELD_EDGE_BYTES 20
+static inline bool held_tok16(int two_v) { return two_v <= 65536; }
+static inline size_t held_node_bytes(int k, int two_v) { return (size_t)(4 * (3 + (held_tok16(two_v) ? (k + 1) / 2 : k))); }
+__device__ __forceinline__ void held_put_tokens(unsigned int* w, const int* tok, int k, bool t16) {
+  if (!t16) {
+    for (int x = 0; x < k; ++x) w[x] = (unsigned int)tok[x];
+    return;
+  }
+  for (int x = 0; x < k; x += 2)
+    w[x >> 1] = ((unsigned int)tok[x] & 0xffffu) | (x + 1 < k ? ((unsigned int)tok[x + 1] << 16) : 0u);
+}
 #define REPLY_DROPPED (~0ull)
 #define CNT_WORDS 4     // count message per peer: {records | code < 0, tokens of my shard, attempt, kind}
 #define HC_WORDS 2      // held-count message: {records held | code < 0, attempt}
@@ -775,7 +787,7 @@ __global__ void k_xh_emit_nodes(const unsigned long long* __restrict__ replies, 
                                 unsigned long long base, const unsigned int* __restrict__ bits,
                                 const long long* __restrict__ prefix, const Slot16* __restrict__ tab,
                                 const unsigned int* __restrict__ slot_by_claim, int k, int xbits, int two,
-                                unsigned char* __restrict__ out, int rec_bytes) {
+                                unsigned int* __restrict__ out, int rec_words, int t16) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long g = replies[2 * j];
@@ -783,22 +795,22 @@ __global__ void k_xh_emit_nodes(const unsigned long long* __restrict__ replies, 
   const unsigned int c = order ? order[j] : (unsigned int)j;
   const unsigned int local = ~x_first_inv(first2, c);
   if (base + (unsigned long long)local != g) return;
-  unsigned char* rec = out + (size_t)d_rank_of(local >> 1, bits, prefix) * rec_bytes;
-  *reinterpret_cast<unsigned long long*>(rec) = g;
-  unsigned int* u = reinterpret_cast<unsigned int*>(rec + 8);
-  u[0] = (unsigned int)replies[2 * j + 1];
-  u[1] = (unsigned int)k;
+  unsigned int* w = out + (size_t)d_rank_of(local >> 1, bits, prefix) * rec_words;
+  w[0] = (unsigned int)g;
+  w[1] = (unsigned int)(g >> 32);
+  w[2] = (unsigned int)replies[2 * j + 1];
   const Slot16 s = tab[slot_by_claim[c]];
   const unsigned int tag = two ? (unsigned int)(s.w2 >> 32) : 0u;
-  int* tk = reinterpret_cast<int*>(rec + 16);
-  for (int x = 0; x < k; ++x) tk[x] = x_unpack(s.w1, tag, xbits, x);
+  int tok[AMG_MAX_K];
+  for (int x = 0; x < k; ++x) tok[x] = x_unpack(s.w1, tag, xbits, x);
+  held_put_tokens(w + 3, tok, k, t16 != 0);
 }
 
 __global__ void k_xh_emit_edges(const unsigned long long* __restrict__ replies, long long n,
                                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ first2,
                                 unsigned long long base, const unsigned int* __restrict__ bits,
                                 const long long* __restrict__ prefix, const unsigned long long* __restrict__ sent,
-                                unsigned long long* __restrict__ out) {
+                                unsigned int* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned long long g = replies[2 * j];
@@ -806,10 +818,13 @@ __global__ void k_xh_emit_edges(const unsigned long long* __restrict__ replies, 
   const unsigned int c = order ? order[j] : (unsigned int)j;
   const unsigned int local = ~x_first_inv(first2, c);
   if (base + (unsigned long long)local != g) return;
-  unsigned long long* q = out + 3 * d_rank_of(local >> 3, bits, prefix);
-  q[0] = sent[3 * j];
-  q[1] = g;
-  q[2] = replies[2 * j + 1] & 0xffffffffull;
+  unsigned int* w = out + 5 * d_rank_of(local >> 3, bits, prefix);
+  const unsigned long long key = sent[3 * j];
+  w[0] = (unsigned int)key;
+  w[1] = (unsigned int)(key >> 32);
+  w[2] = (unsigned int)g;
+  w[3] = (unsigned int)(g >> 32);
+  w[4] = (unsigned int)replies[2 * j + 1];
 }
 
 // fingerprint shards: the compaction list is in local first-seen order already — a flag per entry, a scan
@@ -826,37 +841,41 @@ __global__ void k_fh_flags(const unsigned long long* __restrict__ replies, long 
 __global__ void k_fh_emit_nodes(const unsigned long long* __restrict__ replies, long long n,
                                 const unsigned int* __restrict__ order, const unsigned long long* __restrict__ firsts,
                                 const unsigned int* __restrict__ flag, const long long* __restrict__ pos,
-                                const int* __restrict__ tokens, int k, int two_v, unsigned char* __restrict__ out,
-                                int rec_bytes) {
+                                const int* __restrict__ tokens, int k, int two_v, unsigned int* __restrict__ out,
+                                int rec_words, int t16) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned int i = order ? order[j] : (unsigned int)j;
   if (!flag[i]) return;
-  unsigned char* rec = out + (size_t)pos[i] * rec_bytes;
-  *reinterpret_cast<unsigned long long*>(rec) = replies[2 * j];
-  unsigned int* u = reinterpret_cast<unsigned int*>(rec + 8);
-  u[0] = (unsigned int)replies[2 * j + 1];
-  u[1] = (unsigned int)k;
+  unsigned int* w = out + (size_t)pos[i] * rec_words;
+  const unsigned long long g = replies[2 * j];
+  w[0] = (unsigned int)g;
+  w[1] = (unsigned int)(g >> 32);
+  w[2] = (unsigned int)replies[2 * j + 1];
   const unsigned long long first = firsts[i];  // local: the node pass ran with token base 0
   const long long t = (long long)(first >> 1);
   const int dir = (first & 1ull) ? -1 : 1;
   const int flip = two_v - 1;
-  int* tk = reinterpret_cast<int*>(rec + 16);
-  for (int x = 0; x < k; ++x) tk[x] = dir > 0 ? tokens[t + x] : flip - tokens[t + k - 1 - x];
+  int tok[AMG_MAX_K];
+  for (int x = 0; x < k; ++x) tok[x] = dir > 0 ? tokens[t + x] : flip - tokens[t + k - 1 - x];
+  held_put_tokens(w + 3, tok, k, t16 != 0);
 }
 
 __global__ void k_fh_emit_edges(const unsigned long long* __restrict__ replies, long long n,
                                 const unsigned int* __restrict__ order, const unsigned int* __restrict__ flag,
                                 const long long* __restrict__ pos, const unsigned long long* __restrict__ sent,
-                                unsigned long long* __restrict__ out) {
+                                unsigned int* __restrict__ out) {
   long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned int i = order ? order[j] : (unsigned int)j;
   if (!flag[i]) return;
-  unsigned long long* q = out + 3 * pos[i];
-  q[0] = sent[3 * j];
-  q[1] = replies[2 * j];
-  q[2] = replies[2 * j + 1] & 0xffffffffull;
+  unsigned int* w = out + 5 * pos[i];
+  const unsigned long long key = sent[3 * j], g = replies[2 * j];
+  w[0] = (unsigned int)key;
+  w[1] = (unsigned int)(key >> 32);
+  w[2] = (unsigned int)g;
+  w[3] = (unsigned int)(g >> 32);
+  w[4] = (unsigned int)replies[2 * j + 1];
 }
 
 // holders ranked, held records emitted in local first-seen order, the number held in d->hc_send
@@ -867,7 +886,7 @@ static int hold_records(amg_ctx* c, DistState* d, int is_edge) {
   const unsigned int* order = send_order(c);
   const int shift = is_edge ? 3 : 1;
   const unsigned long long base = (unsigned long long)c->tok_base << shift;
-  const int rb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k);
+  const int rb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k, c->two_v);
   unsigned long long* status = c->status.as<unsigned long long>();
   const long long* n_held = nullptr;
   if (c->dist_x) {
@@ -890,11 +909,11 @@ static int hold_records(amg_ctx* c, DistState* d, int is_edge) {
       hipLaunchKernelGGL(k_xh_emit_nodes, dim3(nblk(n, 256)), dim3(256), 0, st, rep, n, order, first2, base,
                          c->s1.as<unsigned int>(), c->s5.as<long long>(), c->node_tab.as<Slot16>(),
                          c->x_slot.as<unsigned int>(), c->k, c->x_bits, (long long)c->k * c->x_bits > 63 ? 1 : 0,
-                         d->held.as<unsigned char>(), rb);
+                         d->held.as<unsigned int>(), rb / 4, held_tok16(c->two_v) ? 1 : 0);
     else if (n > 0)
       hipLaunchKernelGGL(k_xh_emit_edges, dim3(nblk(n, 256)), dim3(256), 0, st, rep, n, order, first2, base,
                          c->s1.as<unsigned int>(), c->s5.as<long long>(), d->send.as<unsigned long long>(),
-                         d->held.as<unsigned long long>());
+                         d->held.as<unsigned int>());
     n_held = c->s5.as<long long>() + words;
   } else {
     AMGCHK(c->s4.ensure((size_t)(n + 2) * sizeof(unsigned int)));
@@ -911,10 +930,10 @@ static int hold_records(amg_ctx* c, DistState* d, int is_edge) {
     if (n > 0 && !is_edge)
       hipLaunchKernelGGL(k_fh_emit_nodes, dim3(nblk(n, 256)), dim3(256), 0, st, rep, n, order,
                          c->dist_first.as<unsigned long long>(), flag, pos, c->tokens.as<int>(), c->k, c->two_v,
-                         d->held.as<unsigned char>(), rb);
+                         d->held.as<unsigned int>(), rb / 4, held_tok16(c->two_v) ? 1 : 0);
     else if (n > 0)
       hipLaunchKernelGGL(k_fh_emit_edges, dim3(nblk(n, 256)), dim3(256), 0, st, rep, n, order, flag, pos,
-                         d->send.as<unsigned long long>(), d->held.as<unsigned long long>());
+                         d->send.as<unsigned long long>(), d->held.as<unsigned int>());
     n_held = pos + n;
   }
   hipLaunchKernelGGL(k_hc_msg, dim3(1), dim3(1), 0, st, n_held, d->attempt, status, d->hc_send.as<long long>());
@@ -934,8 +953,8 @@ __global__ void k_offs(const long long* __restrict__ hc, int world, long long* _
 }
 
 // node arrays in global id order: the gathered buffer (world parts of m record slots) unpacked
-__global__ void k_global_nodes(const unsigned char* __restrict__ recs, long long m, int world,
-                               const long long* __restrict__ off, int rec_bytes, int k, int* __restrict__ node_tokens,
+__global__ void k_global_nodes(const unsigned int* __restrict__ recs, long long m, int world,
+                               const long long* __restrict__ off, int rec_words, int k, int t16, int* __restrict__ node_tokens,
                                unsigned int* __restrict__ node_cov, long long* __restrict__ node_first,
                                unsigned char* __restrict__ node_alive) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -944,15 +963,15 @@ __global__ void k_global_nodes(const unsigned char* __restrict__ recs, long long
   const long long j = i - (long long)r * m;
   if (j >= off[r + 1] - off[r]) return;
   const long long id = off[r] + j;
-  const unsigned char* q = recs + (size_t)i * rec_bytes;
-  node_first[id] = *reinterpret_cast<const long long*>(q);
-  node_cov[id] = *reinterpret_cast<const unsigned int*>(q + 8);
+  const unsigned int* w = recs + (size_t)i * rec_words;
+  node_first[id] = (long long)((unsigned long long)w[0] | ((unsigned long long)w[1] << 32));
+  node_cov[id] = w[2];
   node_alive[id] = 1;
-  const int* tk = reinterpret_cast<const int*>(q + 16);
-  for (int x = 0; x < k; ++x) node_tokens[id * k + x] = tk[x];
+  for (int x = 0; x < k; ++x)
+    node_tokens[id * k + x] = t16 ? (int)((w[3 + (x >> 1)] >> ((x & 1) * 16)) & 0xffffu) : (int)w[3 + x];
 }
 
-__global__ void k_global_pairs(const unsigned long long* __restrict__ recs, long long m, int world,
+__global__ void k_global_pairs(const unsigned int* __restrict__ recs, long long m, int world,
                                const long long* __restrict__ off, unsigned long long* __restrict__ pkey,
                                unsigned long long* __restrict__ pfirst, unsigned int* __restrict__ pcnt) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -961,9 +980,10 @@ __global__ void k_global_pairs(const unsigned long long* __restrict__ recs, long
   const long long j = i - (long long)r * m;
   if (j >= off[r + 1] - off[r]) return;
   const long long id = off[r] + j;
-  pkey[id] = recs[3 * i];
-  pfirst[id] = recs[3 * i + 1];
-  pcnt[id] = (unsigned int)recs[3 * i + 2];
+  const unsigned int* w = recs + 5 * i;
+  pkey[id] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+  pfirst[id] = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+  pcnt[id] = w[4];
 }
 
 // id of the node whose first-seen value is g: the node arrays are in ascending first-seen order
@@ -1034,16 +1054,16 @@ __global__ void k_map_slots(const unsigned long long* __restrict__ replies, long
 static int nodes_global(amg_ctx* c, DistState* d) {
   hipStream_t st = c->stream;
   const long long n = d->n_total, m = d->m_pad;
-  const int rb = (int)held_node_bytes(c->k);
+  const int rb = (int)held_node_bytes(c->k, c->two_v);
   stage_begin(c, "merge_node_global");
   c->packed_nodes = !c->dist_x && (c->two_v <= 65536 && c->k <= AMG_PACK_MAX_K);
   c->n_nodes = n;
   AMGCHK(bs_alloc_nodes(c, n));
   if (m > 0)
     hipLaunchKernelGGL(k_global_nodes, dim3(nblk(m * d->world, 256)), dim3(256), 0, st,
-                       reinterpret_cast<const unsigned char*>(d->gathered_p), m, d->world, d->offs.as<long long>(), rb,
-                       c->k, c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(), c->node_first.as<long long>(),
-                       c->node_alive.as<unsigned char>());
+                       reinterpret_cast<const unsigned int*>(d->gathered_p), m, d->world, d->offs.as<long long>(), rb / 4,
+                       c->k, held_tok16(c->two_v) ? 1 : 0, c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(),
+                       c->node_first.as<long long>(), c->node_alive.as<unsigned char>());
   const long long nl = d->n_send;
   const unsigned long long* rep = static_cast<const unsigned long long*>(d->rep_in_p);
   unsigned long long* status = c->status.as<unsigned long long>();
@@ -1068,7 +1088,7 @@ static int edges_global(amg_ctx* c, DistState* d) {
   AMGCHK(bs_alloc_pairs(c, n));
   if (m > 0)
     hipLaunchKernelGGL(k_global_pairs, dim3(nblk(m * d->world, 256)), dim3(256), 0, st,
-                       reinterpret_cast<const unsigned long long*>(d->gathered_p), m, d->world, d->offs.as<long long>(),
+                       reinterpret_cast<const unsigned int*>(d->gathered_p), m, d->world, d->offs.as<long long>(),
                        c->pair_key.as<unsigned long long>(), c->pair_first.as<unsigned long long>(),
                        c->pair_cnt.as<unsigned int>());
   stage_end(c);
@@ -1268,7 +1288,7 @@ static int advance(amg_ctx* c, amg_xfer* x) {
           return amg_fail(AMG_E_DIST, "%lld local records but %lld destinations", (long long)d->n_send, n_send);
         }
         // every buffer up to the next count exchange is made here: nothing between two exchanges fails for want of memory
-        const int hb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k);
+        const int hb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k, c->two_v);
         AMGCHK(d->send.ensure((size_t)(d->n_send + 1) * REC_BYTES));
         AMGCHK(d->rep_in.ensure((size_t)(d->n_send + 1) * REPLY_WORDS * sizeof(long long)));
         AMGCHK(d->rep_out.ensure((size_t)(d->n_recv + 1) * REPLY_WORDS * sizeof(long long)));
@@ -1369,7 +1389,7 @@ static int advance(amg_ctx* c, amg_xfer* x) {
           d->gathered_p = d->held.p;
           continue;
         }
-        const int hb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k);
+        const int hb = is_edge ? HELD_EDGE_BYTES : (int)held_node_bytes(c->k, c->two_v);
         // equal-size contributions of m record slots; what lies behind a rank's own records is never read
         const void* src = d->held.p;
         if (d->held.cap < (size_t)d->m_pad * hb) {

@@ -199,6 +199,7 @@ struct amg_ctx {
   bool ladj_valid = false;
   bool ladj_stale = false;  // the live lists are those of the graph before some NODES died (ensure_live_adj patches them)
   bool comp_valid = false, adj_valid = false;  // component ids / full edge lists of the built graph are made on demand
+  bool pristine = false;  // nothing has been removed since the build, and its component labels are those of the graph as it is
   // reads
   DevBuf read_fix;  // uint8[n_reads]  read is in _readsToCorrect
 

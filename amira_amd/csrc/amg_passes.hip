@@ -83,6 +83,7 @@ static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
   if (c->ladj_valid && min_edge_cov <= 1 && !getenv("AMG_NO_LADJ_PATCH")) c->ladj_stale = true;  // (A/B + test switch)
   else if (!c->ladj_stale || min_edge_cov > 1) c->ladj_stale = false;
   c->ladj_valid = false;
+  c->pristine = false;
   c->match_valid = false;  // node-id patterns of a cached K6 result may name removed nodes
   if (c->n_edges > 0)
     hipLaunchKernelGGL(k_filter_edges, dim3(nblk(c->n_edges, 256)), dim3(256), 0, st,
@@ -170,8 +171,7 @@ __global__ void k_live_keys(const unsigned char* __restrict__ e_alive, const int
 //   k_lr_fill    every live edge drops its edge id into its row's stretch at its ticket (any order)
 //   k_lr_finish  the ticket-0 edge of a row sorts the row's ids ascending (= list order of the reference: edge ids
 //                follow insertion order) and writes the entries {target, direction} and the row record; rows longer
-//                than LR_SMALL are left to k_lr_long, a workgroup per long row (hub nodes)
-#define LR_SMALL 32
+//                than a wave's 64 lanes are left to k_lr_long, a workgroup per long row (hub nodes)
 __global__ void k_lr_count(const unsigned int* __restrict__ keys, long long n_live, int4* __restrict__ lrows) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_live) atomicAdd(&lrows[keys[i]].y, 1);
@@ -212,37 +212,64 @@ __global__ __launch_bounds__(256) void k_lr_alloc(const unsigned int* __restrict
     }
 }
 
+// (a row with ONE live edge — most rows: a node of a cleaned graph has one forward and one backward neighbour — is
+// finished right here: entry and row record written by the edge that drew its only ticket, which is marked done; the
+// ticket-0 pass that puts rows in order then touches the rows with two edges and more alone.  On the 7.4 M rows of a
+// rebuilt graph of eight read sets that pass took 0.92 ms with every row going through it.)
+#define LR_DONE 0xffffffffu
 __global__ void k_lr_fill(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ edge_of,
-                          const unsigned int* __restrict__ tick, long long n_live, const int4* __restrict__ lrows,
-                          unsigned int* __restrict__ tmp) {
+                          unsigned int* __restrict__ tick, long long n_live, int4* __restrict__ lrows,
+                          const int* __restrict__ e_tgt, const signed char* __restrict__ e_tdir,
+                          unsigned int* __restrict__ tmp, int2* __restrict__ lent) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_live) tmp[lrows[keys[i]].x + tick[i]] = edge_of[i];
-}
-
-__global__ void k_lr_finish(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ tick, long long n_live,
-                            const unsigned int* __restrict__ tmp, const int* __restrict__ e_tgt,
-                            const signed char* __restrict__ e_tdir, int4* __restrict__ lrows, int2* __restrict__ lent,
-                            unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_live || tick[i] != 0u) return;
-  const unsigned int key = keys[i];
-  const int off = lrows[key].x, cnt = lrows[key].y;
-  if (cnt > LR_SMALL) {
-    long_rows[atomicAdd(n_long, 1ull)] = key;
+  if (i >= n_live) return;
+  const unsigned int key = keys[i], e = edge_of[i];
+  const int4 rw = lrows[key];
+  if (rw.y == 1) {
+    const int t = e_tgt[e], d = (int)e_tdir[e];
+    lent[rw.x] = make_int2(t, d);
+    lrows[key] = make_int4(rw.x, 1, t, d);
+    tick[i] = LR_DONE;
     return;
   }
-  unsigned int e[LR_SMALL];
-  for (int j = 0; j < cnt; ++j) {  // insertion sort in registers / scratch: rows hold a handful of edges
-    const unsigned int x = tmp[off + j];
-    int p = j;
-    while (p > 0 && e[p - 1] > x) {
-      e[p] = e[p - 1];
-      --p;
+  tmp[rw.x + tick[i]] = e;
+}
+
+__global__ __launch_bounds__(256) void k_lr_finish(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ tick,
+                                                   long long n_live, const unsigned int* __restrict__ tmp,
+                                                   const int* __restrict__ e_tgt, const signed char* __restrict__ e_tdir,
+                                                   int4* __restrict__ lrows, int2* __restrict__ lent,
+                                                   unsigned int* __restrict__ long_rows, unsigned long long* n_long) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool mine = i < n_live && tick[i] == 0u;  // the ticket-0 edge of a row with two live edges or more
+  unsigned int key = 0;
+  int off = 0, cnt = 0;
+  if (mine) {
+    key = keys[i];
+    off = lrows[key].x;
+    cnt = lrows[key].y;
+    if (cnt > WAVE_ROW_MAX) {
+      long_rows[atomicAdd(n_long, 1ull)] = key;
+      mine = false;
+    } else if (cnt == 2) {  // (most of what is left)
+      unsigned int a = tmp[off], b = tmp[off + 1];
+      if (a > b) {
+        const unsigned int t = a;
+        a = b;
+        b = t;
+      }
+      const int ta = e_tgt[a], da = (int)e_tdir[a];
+      lent[off] = make_int2(ta, da);
+      lent[off + 1] = make_int2(e_tgt[b], (int)e_tdir[b]);
+      lrows[key] = make_int4(off, 2, ta, da);
+      mine = false;
     }
-    e[p] = x;
   }
-  for (int j = 0; j < cnt; ++j) lent[off + j] = make_int2(e_tgt[e[j]], (int)e_tdir[e[j]]);
-  lrows[key] = make_int4(off, cnt, e_tgt[e[0]], (int)e_tdir[e[0]]);
+  wave_rows_in_order(mine, key, (long long)off, cnt, tmp, [&](unsigned int row, long long o, int n, int rank, unsigned int x) {
+    const int t = e_tgt[x], d = (int)e_tdir[x];
+    lent[o + rank] = make_int2(t, d);
+    if (rank == 0) lrows[row] = make_int4((int)o, n, t, d);
+  });
 }
 
 // a workgroup per long row: every element finds its rank among the row's (distinct) edge ids; rows beyond HUGE_ROW are
@@ -355,7 +382,7 @@ static int ensure_live_adj(amg_ctx* c) {
     hipLaunchKernelGGL(k_lr_alloc, dim3(nblk(total, 256 * LR_PER)), dim3(256), 0, st, keys, total, c->ladj_rows.as<int4>(),
                        tick, ctr);
     hipLaunchKernelGGL(k_lr_fill, dim3(nblk(total, 256)), dim3(256), 0, st, keys, edge_of, tick, total,
-                       c->ladj_rows.as<int4>(), tmp);
+                       c->ladj_rows.as<int4>(), c->edge_tgt.as<int>(), c->edge_tdir.as<signed char>(), tmp, c->ladj.as<int2>());
     hipLaunchKernelGGL(k_lr_finish, dim3(nblk(total, 256)), dim3(256), 0, st, keys, tick, total, tmp, c->edge_tgt.as<int>(),
                        c->edge_tdir.as<signed char>(), c->ladj_rows.as<int4>(), c->ladj.as<int2>(), long_rows, ctr + 1);
     const long long hub_words = (E + 31) / 32 + 1;  // (scratch of the hub rows: LR_HUB_BLOCKS bitmaps over the edge ids)
@@ -412,6 +439,7 @@ extern "C" int amg_remove_edges(amg_ctx* c, const int32_t* edge_ids, int64_t n) 
   hipLaunchKernelGGL(k_kill_listed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->s0.as<int>(), (long long)n,
                      c->n_edges, c->edge_alive.as<unsigned char>());
   c->ladj_valid = false;
+  c->pristine = false;
   c->ladj_stale = false;  // (an edge left with both ends alive: the lists are made again)
   c->match_valid = false;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -457,13 +485,30 @@ __global__ void k_clip_mark(GView g, long long n_nodes, int min_length, const un
   for (int j = 0; j < len; ++j) all_high = all_high && ((double)g.n_cov[path[j]] > thr);
   if (all_high) return;
   // a tip that IS its whole component is kept (:710-713)
-  int distinct = 0;
-  for (int j = 0; j < len; ++j) {
-    bool dup = false;
-    for (int q = 0; q < j; ++q) dup = dup || (path[q] == path[j]);
-    distinct += dup ? 0 : 1;
+  if (comp_live) {
+    int distinct = 0;
+    for (int j = 0; j < len; ++j) {
+      bool dup = false;
+      for (int q = 0; q < j; ++q) dup = dup || (path[q] == path[j]);
+      distinct += dup ? 0 : 1;
+    }
+    if ((unsigned int)distinct == comp_live[g.n_comp[n]]) return;
+  } else {
+    // nothing has been removed since the build: the component of the path's nodes is the path exactly when no live
+    // edge leaves it (its nodes have at most two edges each: the walk only enters nodes of degree one or two)
+    bool closed = true;
+    for (int j = 0; j < len && closed; ++j)
+      for (int side = 0; side < 2 && closed; ++side) {
+        const int4 rw = g.lrows[2ll * path[j] + side];
+        for (int q = 0; q < rw.y && closed; ++q) {
+          const int t = q == 0 ? rw.z : g.lent[rw.x + q].x;
+          bool in = false;
+          for (int m = 0; m < len; ++m) in = in || (path[m] == t);
+          closed = in;
+        }
+      }
+    if (closed) return;
   }
-  if ((unsigned int)distinct == comp_live[g.n_comp[n]]) return;
   for (int j = 0; j < len; ++j)
     if (!protect || !protect[path[j]]) kill[path[j]] = 1;
 }
@@ -539,6 +584,34 @@ __global__ void k_comp_hist(const int* __restrict__ comp, const unsigned char* _
   }
 }
 
+// {sum of the live nodes' coverages, number of live nodes} alone (a clip that needs no component labels)
+__global__ __launch_bounds__(256) void k_cov_acc(const unsigned char* __restrict__ alive, const unsigned int* __restrict__ cov,
+                                                 long long n, unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_part[2][4];
+  unsigned long long s_cov = 0, s_n = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (alive[i]) {
+      s_cov += cov[i];
+      s_n += 1;
+    }
+  for (int d = 32; d > 0; d >>= 1) {
+    s_cov += __shfl_xor(s_cov, d, 64);
+    s_n += __shfl_xor(s_n, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_part[0][threadIdx.x >> 6] = s_cov;
+    s_part[1][threadIdx.x >> 6] = s_n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long n_all = s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
+    if (n_all) {
+      atomicAdd(&acc[0], s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3]);
+      atomicAdd(&acc[1], n_all);
+    }
+  }
+}
+
 __global__ void k_scatter_ids(const unsigned char* __restrict__ killed, const long long* __restrict__ pos,
                               long long n, int* __restrict__ out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,22 +654,31 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   if (n_removed) *n_removed = 0;
   if (D == 0) return AMG_OK;
   stages_reset(c);
-  AMGCHK(ensure_components(c));
+  // "a tip that is its whole component is kept" (:710-713) compares the path with the LIVE nodes of its component as
+  // labelled at build time.  While nothing has been removed since the build that is the question whether a live edge
+  // leaves the path, which the walk's own rows answer: no labels are made for the clip of a freshly built graph
+  // (the cleaning sweep's case; AMG_CLIP_COMPONENTS=1: A/B + test switch)
+  const bool by_labels = !c->pristine || getenv("AMG_CLIP_COMPONENTS");
+  if (by_labels) AMGCHK(ensure_components(c));
   stage_begin(c, "clip");
   // live nodes per component, and the mean node coverage's two integers (:868-871), in one pass
   unsigned long long* acc = c->status.as<unsigned long long>() + ST_COV_SUM;  // (the live adjacency below uses ST_COMPACT_*)
   AMGCHK(c->s0.ensure((size_t)D + 8));
-  AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
+  if (by_labels) AMGCHK(c->s4.ensure((size_t)(c->n_components + 2) * sizeof(unsigned int)));
   {
     ClearList cl;
     cl.add(acc, 2 * sizeof(unsigned long long));
     cl.add(c->s0.p, (size_t)D + 8);
-    cl.add(c->s4.p, (size_t)(c->n_components + 2) * sizeof(unsigned int));
+    if (by_labels) cl.add(c->s4.p, (size_t)(c->n_components + 2) * sizeof(unsigned int));
     AMGCHK(clear_many(c, cl));
   }
-  hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
-                     c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
-                     c->s4.as<unsigned int>(), (unsigned int*)nullptr, acc);
+  if (by_labels)
+    hipLaunchKernelGGL(k_comp_hist, dim3(nblk(D, 256) < 256u ? nblk(D, 256) : 256u), dim3(256), 0, st, c->node_comp.as<int>(),
+                       c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, 0u,
+                       c->s4.as<unsigned int>(), (unsigned int*)nullptr, acc);
+  else
+    hipLaunchKernelGGL(k_cov_acc, dim3(nblk(D, 2048) < 256u ? nblk(D, 2048) : 256u), dim3(256), 0, st,
+                       c->node_alive.as<unsigned char>(), c->node_cov.as<unsigned int>(), D, acc);
   unsigned char* d_protect = nullptr;
   if (protect) {
     AMGCHK(c->s5.ensure((size_t)D + 8));
@@ -605,7 +687,8 @@ extern "C" int amg_remove_short_linear_paths(amg_ctx* c, int32_t min_length, con
   }
   AMGCHK(ensure_live_adj(c));
   hipLaunchKernelGGL(k_clip_mark, dim3(nblk(D, 128)), dim3(128), 0, st, make_view(c), D, (int)min_length,
-                     acc, c->s4.as<unsigned int>(), d_protect, c->s0.as<unsigned char>());
+                     acc, by_labels ? c->s4.as<unsigned int>() : (const unsigned int*)nullptr, d_protect,
+                     c->s0.as<unsigned char>());
   int r = finish_kill(c, n_removed, removed_ids);
   stage_end(c);
   c->have_corrected = false;

@@ -218,11 +218,15 @@ class Engine:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         check(_ffi.lib.amg_remove_edges(self._h, ptr(ids), len(ids)))
 
-    def remove_short_linear_paths(self, min_length, protect=None):
-        D = self.graph_sizes()[0]
+    def remove_short_linear_paths(self, min_length, protect=None, want_ids=True):
+        """ids of the removed nodes (ascending); want_ids=False: only their number — nothing but one count leaves the
+        device (callers that go on with the graph on the device and ignore the list, as the reference's drivers do)"""
         n = C.c_int64(0)
-        ids = np.empty(D, np.int32)
         pr = None if protect is None else np.ascontiguousarray(protect, dtype=np.uint8)
+        if not want_ids:
+            check(_ffi.lib.amg_remove_short_linear_paths(self._h, int(min_length), ptr(pr), C.byref(n), None))
+            return n.value
+        ids = np.empty(self.graph_sizes()[0], np.int32)
         check(_ffi.lib.amg_remove_short_linear_paths(self._h, int(min_length), ptr(pr),
                                                      C.byref(n), ptr(ids)))
         return ids[: n.value].copy()

@@ -946,7 +946,7 @@ def main():
         build()
         if record:
             tally()
-        eng.remove_short_linear_paths(k)
+        eng.remove_short_linear_paths(k, want_ids=False)   # (device-resident region: the list of removed ids stays there)
         if record:
             tally()
         n_out = eng.correct_reads()

@@ -238,7 +238,8 @@ def test_position_carry_over_tie_with_shifted_tandem_array(eng):
 
 @pytest.mark.parametrize("env", [{"AMG_X_TIGHT_BITS": "1"}, {"AMG_X_GENERIC_K": "1"}, {"AMG_NODE_BUCKETS": "0"}, {"AMG_PLAIN_SYNC": "1"}, {"AMG_X_HEAD_TILES": "3"}, {"AMG_NO_FAST_GAPPED": "1"}, {"AMG_NO_FAST_NW": "1"},
                                  {"AMG_COUNT_INLINE": "1"}, {"AMG_KEY_MODE": "fp"}, {"AMG_X_RANK_SORT": "1"}, {"AMG_NO_FAST_GAPPED": "1", "AMG_NO_FAST_NW": "1"},
-                                 {"AMG_NO_GAP_MEMO": "1"}, {"AMG_POS_COMPACT_MIN": "-1000000000"}, {"AMG_EDGE_HOME": "0"}, {"AMG_ADJ_SORT": "1"}, {"AMG_NW_NO_SHORTCUT": "1"}, {"AMG_TEST_NODE_BOUND": "300"}])
+                                 {"AMG_NO_GAP_MEMO": "1"}, {"AMG_POS_COMPACT_MIN": "-1000000000"}, {"AMG_EDGE_HOME": "0"}, {"AMG_ADJ_SORT": "1"}, {"AMG_NW_NO_SHORTCUT": "1"}, {"AMG_TEST_NODE_BOUND": "300"},
+                                 {"AMG_CLIP_COMPONENTS": "1"}])
 def test_sweep_general_kernels(eng, monkeypatch, env):
     """the general (any-size) re-threading / alignment kernels, the inline-atomic counting path, the re-threading
     without its path memo, a position pool that is compacted at every amg_adopt_corrected and an edge pass without

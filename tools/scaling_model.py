@@ -57,7 +57,7 @@ e = Engine(0)
 for rep in range(3):
     e.set_reads(toks, offs, vocab.two_v); e.set_positions(gs, ge, rl)
     acc.clear(); torch.cuda.synchronize(); t = time.perf_counter()
-    e.build_filtered(k, 3, 1); e.correct_reads(); e.adopt_corrected(); e.build(k); e.remove_short_linear_paths(k)
+    e.build_filtered(k, 3, 1); e.correct_reads(); e.adopt_corrected(); e.build(k); e.remove_short_linear_paths(k, want_ids=False)
     e.correct_reads(); e.adopt_corrected(); e.build(k); e.finalize(); torch.cuda.synchronize()
     single = (time.perf_counter() - t) * 1e3
 e.close()
@@ -85,7 +85,7 @@ for W in WORLDS:
             en.correct_reads(); en.adopt_corrected()
         D.dist_build_loopback(engines, k)
         for en in engines:
-            en.remove_short_linear_paths(k)
+            en.remove_short_linear_paths(k, want_ids=False)
         for en in engines:
             en.correct_reads(); en.adopt_corrected()
         D.dist_build_loopback(engines, k)
