@@ -24,7 +24,7 @@ class Counts(C.Structure):
         "n_reads", "n_tokens", "n_windows", "n_short_reads", "n_nodes", "n_edges", "n_pairs",
         "n_components", "n_live_nodes", "n_live_edges", "n_reads_to_correct",
         "node_table_slots", "edge_table_slots", "build_retries")] + [("k", C.c_int32), ("two_v", C.c_int32),
-                                                                 ("exact_keys", C.c_int32), ("reserved", C.c_int32)]
+                                                                 ("exact_keys", C.c_int32), ("derived", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -222,7 +222,9 @@ extern "C" int amg_destroy(amg_ctx* c) {
                    &c->edge_alive, &c->adj_off,  &c->adj_edge,   &c->read_fix, &c->ladj_off, &c->ladj, &c->ladj_rows, &c->ladj_pos, &c->ladj_keys, &c->hub_bits, &c->pair_key, &c->pair_first, &c->pair_cnt, &c->dist_a, &c->dist_cnt, &c->dist_first, &c->dist_slot, &c->dist_gtab, &c->dist_lcnt, &c->match_read, &c->match_pos, &c->match_off, &c->match_wave,  &c->c_tokens_buf,
                    &c->c_read_off, &c->c_orig,   &c->c_changed,  &c->c_gstart,  &c->c_gend,
                    &c->c_read_len, &c->status,   &c->sort_tmp, &c->scan_state,   &c->s0, &c->s1, &c->s2, &c->s3,
-                   &c->s4, &c->s5, &c->cnt_state, &c->cnt_list, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->gm_mask, &c->gm_tab, &c->gm_res, &c->gm_list, &c->gm_q, &c->gm_pool, &c->gm_gene, &c->gm_fail, &c->gm_ctr, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->x_ncnt, &c->x_ftag, &c->f_ctrs, &c->x_efinal, &c->x_first_all, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e};
+                   &c->s4, &c->s5, &c->cnt_state, &c->cnt_list, &c->bnd_bits, &c->nw_rec, &c->gap_rec, &c->gm_mask, &c->gm_tab, &c->gm_res, &c->gm_list, &c->gm_q, &c->gm_pool, &c->gm_gene, &c->gm_fail, &c->gm_ctr, &c->nw_big, &c->x_first, &c->x_slot, &c->x_final, &c->x_efirst, &c->x_eslot, &c->x_ecnt, &c->x_ncnt, &c->x_ftag, &c->f_ctrs, &c->x_efinal, &c->x_first_all, &c->pos_off, &c->c_pos_off, &c->pos1_s, &c->pos1_e,
+                   &c->c_src, &c->rd_src, &c->alt_tok_node, &c->alt_tok_dir, &c->alt_ntok, &c->alt_ncov, &c->alt_nfirst,
+                   &c->alt_nalive, &c->alt_pkey, &c->alt_pfirst, &c->alt_pcnt};
   for (DevBuf* b : all) b->release();
   if (c->mail_host) (void)hipHostFree(c->mail_host);
   (void)hipStreamDestroy(c->stream);
@@ -280,6 +282,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
   c->two_v = two_v;
   c->have_pos = c->have_read_len = false;
   c->built = false;
+  c->derive_ready = false;
   c->have_corrected = false;
   c->match_valid = false;
   c->node_hint = 0;
@@ -378,7 +381,7 @@ extern "C" int amg_counts(amg_ctx* c, amg_counts_t* o) {
   o->node_table_slots = c->node_slots;
   o->edge_table_slots = c->edge_slots;
   o->exact_keys = c->exact_keys ? (c->x_fp ? 2 : 1) : 0;  // 2: 16-byte slots keyed by verified 94-bit fingerprints
-  o->reserved = 0;
+  o->derived = c->derived ? 1 : 0;
   o->build_retries = c->retries;
   AMGCHK(count_flags(c, c->node_alive, c->n_nodes, &o->n_live_nodes));
   AMGCHK(count_flags(c, c->edge_alive, c->n_edges, &o->n_live_edges));

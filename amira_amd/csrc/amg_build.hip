@@ -983,6 +983,7 @@ int bs_finish_from_pairs(amg_ctx* c) {
   c->ladj_valid = false;
   c->ladj_stale = false;
   c->pristine = !c->comp_from_claims;  // (a filtered build's labels are those of the graph BEFORE its filter)
+  c->edge_own_deaths = false;
   c->comp_valid = false;
   c->adj_valid = false;
   c->n_components = 0;
@@ -1156,13 +1157,23 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   if (c->two_v <= 0) return amg_fail(AMG_E_STATE, "amg_set_reads first");
   HIPCHK(hipSetDevice(c->device));
   stages_reset(c);
+  // the reads are what the last correction left of the reads of the graph still held, nothing re-threaded: that graph's
+  // live part IS the graph to build (amg_derive.hip; AMG_NO_DERIVE=1: A/B + test switch)
+  const bool derive = c->derive_ready && k == c->k && !c->dist_mode && !getenv("AMG_NO_DERIVE");
+  c->derive_ready = false;
+  c->derived = false;
   c->built = false;
   c->have_corrected = false;
   c->match_valid = false;
-  c->k = k;
   c->retries = 0;
   c->tok_base = 0;
   c->tok_total = c->n_tokens;
+  if (derive) {
+    bool done = false;
+    AMGCHK(derive_from_previous(c, k, &done));
+    if (done) return AMG_OK;  // (amg_build_filtered goes on with amg_filter)
+  }
+  c->k = k;
   c->dist_mode = false;
   c->comp_from_claims = false;
   {
@@ -1400,6 +1411,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_edges_multi(const int* __restr
 static void multi_begin(amg_ctx* c, int k) {
   stages_reset(c);
   c->built = false;
+  c->derive_ready = false;
+  c->derived = false;
   c->have_corrected = false;
   c->match_valid = false;
   c->k = k;

@@ -555,6 +555,8 @@ static int nodes_local(amg_ctx* c, DistState* d) {
   const int k = d->k, world = d->world;
   stages_reset(c);
   c->built = false;
+  c->derive_ready = false;
+  c->derived = false;
   c->have_corrected = false;
   c->match_valid = false;
   c->k = k;

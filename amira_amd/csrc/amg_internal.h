@@ -209,6 +209,15 @@ struct amg_ctx {
   int64_t c_reads = 0, c_tokens = 0;
   DevBuf c_tokens_buf, c_read_off, c_orig, c_changed, c_gstart, c_gend, c_read_len;
 
+  // ---- the rebuild that reuses the previous build (amg_derive.hip)
+  DevBuf c_src, rd_src;          // int64[reads]: token index, in the read set the graph was built from, of every corrected /
+                                 // current read's first gene
+  bool c_derivable = false;      // amg_correct_reads: the corrected set only drops and trims reads of the graph's read set
+  bool derive_ready = false;     // the current reads are such a set of the graph still held (amg_adopt_corrected)
+  bool derived = false;          // the graph at hand was made that way (amg_counts)
+  bool edge_own_deaths = false;  // since the build an edge was removed with both its nodes alive
+  DevBuf alt_tok_node, alt_tok_dir, alt_ntok, alt_ncov, alt_nfirst, alt_nalive, alt_pkey, alt_pfirst, alt_pcnt;
+
   // ---- exact-key build (amg_build_x.hip): arrays indexed by CLAIM id (order of slot creation)
   bool exact_keys = false;   // this build used the exact-key path
   int x_bits = 0;            // bits per token in the packed tuple
@@ -347,6 +356,7 @@ void stage_end(amg_ctx* c);
 void stages_reset(amg_ctx* c);
 
 void dist_release(amg_ctx* c);  // amg_dist.hip
+int derive_from_previous(amg_ctx* c, int k, bool* done);  // amg_derive.hip
 
 // build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
 uint64_t pow2_at_least(uint64_t x);

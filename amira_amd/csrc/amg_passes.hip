@@ -84,6 +84,7 @@ static int apply_removals(amg_ctx* c, unsigned int min_edge_cov) {
   else if (!c->ladj_stale || min_edge_cov > 1) c->ladj_stale = false;
   c->ladj_valid = false;
   c->pristine = false;
+  if (min_edge_cov > 1) c->edge_own_deaths = true;
   c->match_valid = false;  // node-id patterns of a cached K6 result may name removed nodes
   if (c->n_edges > 0)
     hipLaunchKernelGGL(k_filter_edges, dim3(nblk(c->n_edges, 256)), dim3(256), 0, st,
@@ -440,6 +441,7 @@ extern "C" int amg_remove_edges(amg_ctx* c, const int32_t* edge_ids, int64_t n) 
                      c->n_edges, c->edge_alive.as<unsigned char>());
   c->ladj_valid = false;
   c->pristine = false;
+  c->edge_own_deaths = true;
   c->ladj_stale = false;  // (an edge left with both ends alive: the lists are made again)
   c->match_valid = false;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2279,6 +2281,7 @@ struct PackArgs {
   long long* o_off;
   int* o_orig;
   unsigned char* o_changed;
+  long long* o_src;          // per corrected read: token index of its first gene in the current read set (-1: re-threaded)
   const long long* pos_new;  // per read: pool index of a re-threaded read's new positions
   long long* o_posoff;       // per corrected read: pool index of its positions
   long long* o_rl;
@@ -2323,6 +2326,7 @@ __global__ __launch_bounds__(256) void k_corr_pack(PackArgs A) {
     A.o_off[q] = dst;
     A.o_orig[q] = (int)r;
     A.o_changed[q] = (fc == RC_TRIM || fc == RC_GAPPED) ? 1 : 0;
+    A.o_src[q] = fc == RC_GAPPED ? -1ll : src;
     if (a.have_pos) A.o_posoff[q] = poff;
     if (a.read_len) A.o_rl[q] = a.read_len[r];
   }
@@ -2730,6 +2734,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   AMGCHK(c->c_read_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   AMGCHK(c->c_orig.ensure((size_t)(out_reads + 2) * sizeof(int)));
   AMGCHK(c->c_changed.ensure((size_t)(out_reads + 2)));
+  AMGCHK(c->c_src.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   if (c->have_pos) AMGCHK(c->c_pos_off.ensure((size_t)(out_reads + 2) * sizeof(long long)));
   if (c->have_read_len) AMGCHK(c->c_read_len.ensure((size_t)(out_reads + 2) * sizeof(long long)));
 
@@ -2778,6 +2783,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
   Pk.o_off = c->c_read_off.as<long long>();
   Pk.o_orig = c->c_orig.as<int>();
   Pk.o_changed = c->c_changed.as<unsigned char>();
+  Pk.o_src = c->c_src.as<long long>();
   Pk.pos_new = pos_new;
   Pk.o_posoff = c->have_pos ? c->c_pos_off.as<long long>() : nullptr;
   Pk.o_rl = c->have_read_len ? c->c_read_len.as<long long>() : nullptr;
@@ -2799,7 +2805,12 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     unsigned long long v[17];
     AMGCHK(fetch(c, l, v));
     unsigned long long bound = count_alive ? v[16] : (unsigned long long)c->n_nodes;
-    for (int i = 0; i < 16; ++i) bound += v[i];
+    unsigned long long dead_kept = 0;
+    for (int i = 0; i < 16; ++i) dead_kept += v[i];
+    bound += dead_kept;
+    // the graph these reads will make is this graph's live part (amg_derive.hip) when no read was re-threaded or kept
+    // its genes around a dead window, and no edge died on its own: reads were dropped or cut to their live windows
+    c->c_derivable = n_gapped == 0 && dead_kept == 0 && !c->edge_own_deaths && !c->dist_mode;
     c->c_node_bound = (int64_t)bound;
     if (const char* e = getenv("AMG_TEST_NODE_BOUND")) c->c_node_bound = atoll(e);  // test hook: a bound that does not hold
     c->c_node_bound_k = c->k;
@@ -3037,6 +3048,9 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   for (DevBuf* b : {&c->tokens, &c->read_off, &c->read_len}) b->unborrow();
   std::swap(c->tokens, c->c_tokens_buf);
   std::swap(c->read_off, c->c_read_off);
+  std::swap(c->rd_src, c->c_src);
+  c->derive_ready = c->c_derivable;  // (the graph the reads were corrected against is still in place: amg_build may reuse it)
+  c->c_derivable = false;
   if (c->have_pos && compacted) {
     c->pos_identity = true;
     c->pos_n0 = c->c_tokens;
@@ -3106,6 +3120,7 @@ extern "C" int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src) {
   }
   HIPCHK(hipStreamSynchronize(st));
   dst->built = false;
+  dst->derive_ready = false;
   dst->have_corrected = false;
   dst->match_valid = false;
   dst->node_hint = src->c_node_bound > 256 ? src->c_node_bound : 0;  // (amg_adopt_corrected: the same bound)

@@ -82,7 +82,9 @@ typedef struct amg_counts_t {
                           /* fingerprint, every window verified against its key's first    */
                           /* occurrence in the token stream; 0: 32-byte slots, verified    */
                           /* 64-bit fingerprint (>= 2^29 tokens, the merge, AMG_KEY_MODE=fp) */
-  int32_t reserved;
+  int32_t derived;        /* 1: amg_build made this graph from the previous one's live part instead of from the */
+                          /* reads (the reads were that graph's reads with some dropped or cut to their live    */
+                          /* windows by amg_correct_reads, nothing re-threaded: the result is the same graph)   */
 } amg_counts_t;
 
 /* ---- lifetime ------------------------------------------------------------------ */

@@ -40,6 +40,9 @@ def check_corrected(eng, vocab, read_ids, want_genes, want_pos):
     return got_ids, out
 
 
+DERIVED = []   # per run_sweep: was the third graph made from the second one's live part (amg_derive.hip)?
+
+
 def run_sweep(eng, reads, pos, fq, k, min_cov=3):
     from amira_amd import tokenize
     from amira_oracle import GeneMerGraph
@@ -75,6 +78,7 @@ def run_sweep(eng, reads, pos, fq, k, min_cov=3):
     eng.build(k)
     g3 = GeneMerGraph(r3, k, p3)
     compare_engine_to_oracle(eng, oracle_arrays(g3, vocab, ids3, out3["read_offsets"], k))
+    DERIVED.append(eng.counts()["derived"])
     return len(want_removed)
 
 
@@ -114,6 +118,19 @@ def test_low_coverage_components(eng):
         eng.remove_low_coverage_components(m)
         g.remove_low_coverage_components(m)
         compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
+
+
+def test_third_graph_of_a_sweep_is_derived_from_the_second(eng, monkeypatch):
+    """a correction that only drops and trims reads (what follows tip clipping) arms the rebuild that reuses the graph at
+    hand: the sweeps of this module are compared with the oracle either way — here: the shortcut IS taken where it
+    applies, is not with AMG_NO_DERIVE=1, and both give the oracle's graph"""
+    reads, pos, fq = P.synth_inputs(7, 400, 30, 300, 0.03)
+    del DERIVED[:]
+    run_sweep(eng, reads, pos, fq, 5)
+    assert DERIVED == [1]
+    monkeypatch.setenv("AMG_NO_DERIVE", "1")
+    run_sweep(eng, reads, pos, fq, 5)
+    assert DERIVED == [1, 0]
 
 
 @pytest.mark.parametrize("patch", [True, False])
