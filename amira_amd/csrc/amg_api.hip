@@ -282,7 +282,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
   c->two_v = two_v;
   c->have_pos = c->have_read_len = false;
   c->built = false;
-  c->derive_ready = false;
+  c->derive_ready = c->dist_candidate = false;
   c->have_corrected = false;
   c->match_valid = false;
   c->node_hint = 0;

@@ -1160,7 +1160,7 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   // the reads are what the last correction left of the reads of the graph still held, nothing re-threaded: that graph's
   // live part IS the graph to build (amg_derive.hip; AMG_NO_DERIVE=1: A/B + test switch)
   const bool derive = c->derive_ready && k == c->k && !c->dist_mode && !getenv("AMG_NO_DERIVE");
-  c->derive_ready = false;
+  c->derive_ready = c->dist_candidate = false;
   c->derived = false;
   c->built = false;
   c->have_corrected = false;

@@ -43,38 +43,75 @@ __device__ __forceinline__ long long dv_new_token(long long t, const long long* 
   return read_off[i] + q;
 }
 
-// per-window node ids and directions of the new reads: read r is the old tokens src[r] .. of its length
+// per-window node ids and directions of the new reads: read r is the old tokens src[r] .. of its length.
+// One wave takes 64 consecutive reads: lane l owns read l's record (offset, length, source: loaded coalesced), then the
+// 64 lanes walk the reads' windows four reads at a time (records broadcast with v_readlane) — a wave per read was a
+// handful of one-row loads each and bound by their latency (0.36 ms for 0.6 GB)
+#define DV_READS 64
+__device__ __forceinline__ long long dv_bcast(long long v, int lane) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __global__ __launch_bounds__(256) void k_dv_windows(const long long* __restrict__ read_off, const long long* __restrict__ src,
                                                     long long n_reads, int k, const int* __restrict__ old_node,
                                                     const signed char* __restrict__ old_dir,
                                                     const long long* __restrict__ new_id, int* __restrict__ tok_node,
                                                     signed char* __restrict__ tok_dir, unsigned long long* bad) {
-  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_reads) return;
   const int lane = threadIdx.x & 63;
-  const long long o = read_off[r], n = read_off[r + 1] - o, s = src[r];
-  for (long long j = lane; j < n; j += 64) {
-    int v = -1;
-    signed char d = 0;
-    if (j + k <= n) {
-      const int old = old_node[s + j];
-      if (old >= 0) {
-        v = (int)new_id[old];
-        d = old_dir[s + j];
-      } else {
-        *bad = 1ull;  // a kept window that is not a live node: not the case this shortcut is for
+  const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * DV_READS;
+  if (r0 >= n_reads) return;
+  long long o = 0, s = 0;
+  int n = 0;
+  if (r0 + lane < n_reads) {
+    o = read_off[r0 + lane];
+    n = (int)(read_off[r0 + lane + 1] - o);
+    s = src[r0 + lane];
+  }
+  for (int j0 = 0; j0 < DV_READS; j0 += 4) {
+    long long oo[4], ss[4];
+    int nn[4], most = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nn[j] = __builtin_amdgcn_readlane(n, j0 + j);
+      oo[j] = dv_bcast(o, j0 + j);
+      ss[j] = dv_bcast(s, j0 + j);
+      most = nn[j] > most ? nn[j] : most;
+    }
+    for (int q = lane; q < most; q += 64) {
+      int old[4];
+      signed char d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        old[j] = -1;
+        d[j] = 0;
+        if (q + k <= nn[j]) {
+          old[j] = old_node[ss[j] + q];
+          d[j] = old_dir[ss[j] + q];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (q >= nn[j]) continue;
+        int v = -1;
+        if (q + k <= nn[j]) {
+          if (old[j] >= 0) v = (int)new_id[old[j]];
+          else *bad = 1ull;  // a kept window that is not a live node: not the case this shortcut is for
+        }
+        tok_node[oo[j] + q] = v;
+        tok_dir[oo[j] + q] = v >= 0 ? d[j] : (signed char)0;
       }
     }
-    tok_node[o + j] = v;
-    tok_dir[o + j] = d;
   }
 }
 
+// [own_lo, own_hi): the tokens (in the coordinates of first-seen values) of the read set this ctx holds — everything on
+// one GPU; on a rank of a merged build its shard, and first-seen values outside it are left to their rank (0 here)
 __global__ void k_dv_nodes(const unsigned char* __restrict__ alive, const long long* __restrict__ new_id, long long n_old, int k,
                            const int* __restrict__ tok_in, const unsigned int* __restrict__ cov_in,
                            const long long* __restrict__ first_in, const long long* __restrict__ src,
-                           const long long* __restrict__ read_off, long long n_reads, int* __restrict__ tok_out,
-                           unsigned int* __restrict__ cov_out, long long* __restrict__ first_out,
+                           const long long* __restrict__ read_off, long long n_reads, long long own_lo, long long own_hi,
+                           int* __restrict__ tok_out, unsigned int* __restrict__ cov_out, long long* __restrict__ first_out,
                            unsigned char* __restrict__ alive_out, unsigned long long* bad) {
   long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_old || !alive[n]) return;
@@ -82,9 +119,13 @@ __global__ void k_dv_nodes(const unsigned char* __restrict__ alive, const long l
   for (int x = 0; x < k; ++x) tok_out[i * k + x] = tok_in[n * k + x];
   cov_out[i] = cov_in[n];
   alive_out[i] = 1;
-  const long long f = first_in[n];
+  const long long f = first_in[n], tg = f >> 1;
+  if (tg < own_lo || tg >= own_hi) {
+    first_out[i] = 0;
+    return;
+  }
   bool ok = true;
-  const long long t = dv_new_token(f >> 1, src, read_off, n_reads, k, &ok);
+  const long long t = dv_new_token(tg - own_lo, src, read_off, n_reads, k, &ok);
   if (!ok) *bad = 2ull;
   first_out[i] = (t << 1) | (f & 1ll);
 }
@@ -103,6 +144,7 @@ __global__ void k_dv_pairs(const unsigned long long* __restrict__ pkey, const un
                            const unsigned int* __restrict__ pcnt, long long n_pairs, const unsigned int* __restrict__ keep,
                            const long long* __restrict__ pos, const long long* __restrict__ new_id,
                            const long long* __restrict__ src, const long long* __restrict__ read_off, long long n_reads, int k,
+                           long long own_lo, long long own_hi,
                            unsigned long long* __restrict__ okey, unsigned long long* __restrict__ ofirst,
                            unsigned int* __restrict__ ocnt, unsigned long long* bad) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,21 +155,55 @@ __global__ void k_dv_pairs(const unsigned long long* __restrict__ pkey, const un
   const unsigned long long nlo = (unsigned long long)new_id[lo], nhi = (unsigned long long)new_id[hi];
   const long long q = pos[p];
   okey[q] = (key & (1ull << 63)) | (nlo << 32) | (nhi + 1ull);
+  ocnt[q] = pcnt[p];
+  const long long tg = (long long)(f >> 3);
+  if (tg < own_lo || tg >= own_hi) {
+    ofirst[q] = 0ull;
+    return;
+  }
   bool ok = true;
   // first-seen of a class = the token of the adjacency's FIRST window: a kept window next to a kept window
-  const long long t = dv_new_token((long long)(f >> 3), src, read_off, n_reads, k, &ok);
+  const long long t = dv_new_token(tg - own_lo, src, read_off, n_reads, k, &ok);
   if (!ok) *bad = 3ull;
   ofirst[q] = ((unsigned long long)t << 3) | (f & 7ull);
-  ocnt[q] = pcnt[p];
 }
 
-// AMG_OK with *done = true: the graph of the current reads is in place (c->built); *done = false: the ordinary build
-// is to run (nothing it reads has been touched)
-int derive_from_previous(amg_ctx* c, int k, bool* done) {
-  *done = false;
+// merged builds: where, among the squeezed node / class arrays (both in first-seen order), the entries first seen on
+// every rank's shard begin — bounds[r] for nodes, bounds[world + 1 + r] for classes; base[r] = rank r's first token
+__global__ void k_dv_bounds(const long long* __restrict__ base, int world, const long long* __restrict__ node_first,
+                            long long n_nodes, const long long* __restrict__ new_id, const unsigned long long* __restrict__ pfirst,
+                            long long n_pairs, const long long* __restrict__ ppos, long long* __restrict__ bounds) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > world) return;
+  {
+    long long lo = 0, hi = n_nodes;
+    const long long want = r == world ? 0x7fffffffffffffffll : (base[r] << 1);
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (node_first[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    bounds[r] = new_id[lo];
+  }
+  {
+    long long lo = 0, hi = n_pairs;
+    const unsigned long long want = r == world ? ~0ull : ((unsigned long long)base[r] << 3);
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (pfirst[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    bounds[world + 1 + r] = ppos[lo];
+  }
+}
+
+// The graph at hand restricted to its live nodes, in the layout of the current reads, into the alt_* buffers (nothing
+// the ordinary build reads is touched).  own_lo / own_tokens: this ctx's shard in first-seen coordinates (0 and all
+// tokens on one GPU); d_bases != null (merged builds): the ranks' first tokens [world + 1] on the device, and
+// bounds_host receives k_dv_bounds' 2 * (world + 1) values.  *ok = false: not the case this shortcut is for.
+int derive_local(amg_ctx* c, int k, long long own_lo, long long own_tokens, const long long* d_bases, int world,
+                 long long* bounds_host, long long* D2_out, long long* P2_out, bool* ok) {
+  *ok = false;
   hipStream_t st = c->stream;
   const long long D = c->n_nodes, P = c->n_pairs, R = c->n_reads, T = c->n_tokens;
-  if (D <= 0 || R <= 0 || T <= 0) return AMG_OK;
   stage_begin(c, "derive");
   unsigned long long* bad = c->status.as<unsigned long long>() + ST_MISC;
   // ---- new ids of the live nodes, flags of the classes that stay
@@ -151,17 +227,29 @@ int derive_from_previous(amg_ctx* c, int k, bool* done) {
   // ---- per-window ids of the new reads (the largest piece: started before the host needs the counts)
   AMGCHK(c->alt_tok_node.ensure((size_t)(T + 8) * sizeof(int)));
   AMGCHK(c->alt_tok_dir.ensure((size_t)(T + 8)));
-  hipLaunchKernelGGL(k_dv_windows, dim3(nblk(R, 4)), dim3(256), 0, st, c->read_off.as<long long>(), c->rd_src.as<long long>(),
-                     R, k, c->tok_node.as<int>(), c->tok_dir.as<signed char>(), new_id, c->alt_tok_node.as<int>(),
-                     c->alt_tok_dir.as<signed char>(), bad);
-  unsigned long long v[2] = {0, 0};
+  if (R > 0)
+    hipLaunchKernelGGL(k_dv_windows, dim3(nblk(R, 4 * DV_READS)), dim3(256), 0, st, c->read_off.as<long long>(),
+                       c->rd_src.as<long long>(), R, k, c->tok_node.as<int>(), c->tok_dir.as<signed char>(), new_id,
+                       c->alt_tok_node.as<int>(), c->alt_tok_dir.as<signed char>(), bad);
+  long long* d_bounds = nullptr;
+  if (d_bases) {
+    AMGCHK(c->s1.ensure((size_t)(2 * (world + 1)) * sizeof(long long)));
+    d_bounds = c->s1.as<long long>();
+    hipLaunchKernelGGL(k_dv_bounds, dim3(nblk(world + 1, 64)), dim3(64), 0, st, d_bases, world, c->node_first.as<long long>(), D,
+                       new_id, c->pair_first.as<unsigned long long>(), P, ppos, d_bounds);
+  }
+  unsigned long long v[2 + FETCH_MAX - 2];
   {
     FetchList l;
     l.add(new_id + D);
     l.add(ppos + P);
+    if (d_bounds) l.add_words(d_bounds, 2 * (world + 1));
+    if (l.overflow) return amg_fail(AMG_E_ARG, "derive: world too large");
     AMGCHK(fetch(c, l, v));
   }
   const long long D2 = (long long)v[0], P2 = (long long)v[1];
+  if (bounds_host)
+    for (int i = 0; i < 2 * (world + 1); ++i) bounds_host[i] = (long long)v[2 + i];
   // ---- node and edge-class arrays squeezed, first-seen values in the new reads' token coordinates
   AMGCHK(c->alt_ntok.ensure((size_t)(D2 * k + 1) * sizeof(int)));
   AMGCHK(c->alt_ncov.ensure((size_t)(D2 + 1) * sizeof(unsigned int)));
@@ -170,15 +258,18 @@ int derive_from_previous(amg_ctx* c, int k, bool* done) {
   AMGCHK(c->alt_pkey.ensure((size_t)(P2 + 2) * sizeof(unsigned long long)));
   AMGCHK(c->alt_pfirst.ensure((size_t)(P2 + 2) * sizeof(unsigned long long)));
   AMGCHK(c->alt_pcnt.ensure((size_t)(P2 + 2) * sizeof(unsigned int)));
-  hipLaunchKernelGGL(k_dv_nodes, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_alive.as<unsigned char>(), new_id, D, k,
-                     c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(), c->node_first.as<long long>(),
-                     c->rd_src.as<long long>(), c->read_off.as<long long>(), R, c->alt_ntok.as<int>(),
-                     c->alt_ncov.as<unsigned int>(), c->alt_nfirst.as<long long>(), c->alt_nalive.as<unsigned char>(), bad);
+  if (D > 0)
+    hipLaunchKernelGGL(k_dv_nodes, dim3(nblk(D, 256)), dim3(256), 0, st, c->node_alive.as<unsigned char>(), new_id, D, k,
+                       c->node_tokens.as<int>(), c->node_cov.as<unsigned int>(), c->node_first.as<long long>(),
+                       c->rd_src.as<long long>(), c->read_off.as<long long>(), R, own_lo, own_lo + own_tokens,
+                       c->alt_ntok.as<int>(), c->alt_ncov.as<unsigned int>(), c->alt_nfirst.as<long long>(),
+                       c->alt_nalive.as<unsigned char>(), bad);
   if (P > 0)
     hipLaunchKernelGGL(k_dv_pairs, dim3(nblk(P, 256)), dim3(256), 0, st, c->pair_key.as<unsigned long long>(),
                        c->pair_first.as<unsigned long long>(), c->pair_cnt.as<unsigned int>(), P, keep, ppos, new_id,
-                       c->rd_src.as<long long>(), c->read_off.as<long long>(), R, k, c->alt_pkey.as<unsigned long long>(),
-                       c->alt_pfirst.as<unsigned long long>(), c->alt_pcnt.as<unsigned int>(), bad);
+                       c->rd_src.as<long long>(), c->read_off.as<long long>(), R, k, own_lo, own_lo + own_tokens,
+                       c->alt_pkey.as<unsigned long long>(), c->alt_pfirst.as<unsigned long long>(),
+                       c->alt_pcnt.as<unsigned int>(), bad);
   stage_end(c);
   // window / short-read counts of the new reads and their read-end bitmap (whatever builds next from these reads
   // finds what a build leaves); the verdict of the checks rides on its status read-back
@@ -186,6 +277,16 @@ int derive_from_previous(amg_ctx* c, int k, bool* done) {
   unsigned long long hs[ST_WORDS];
   AMGCHK(fetch_status(c, hs));
   if (hs[ST_MISC] || hs[ST_BADINPUT]) return AMG_OK;  // not the case this is for (or malformed reads: the build says so)
+  c->n_windows = (int64_t)hs[ST_N_WINDOWS];
+  c->n_short = (int64_t)hs[ST_N_SHORT];
+  *D2_out = D2;
+  *P2_out = P2;
+  *ok = true;
+  return AMG_OK;
+}
+
+// the alt_* buffers become the graph (derive_local said ok), edges are emitted
+int derive_commit(amg_ctx* c, long long D2, long long P2) {
   std::swap(c->tok_node, c->alt_tok_node);
   std::swap(c->tok_dir, c->alt_tok_dir);
   std::swap(c->node_tokens, c->alt_ntok);
@@ -196,8 +297,6 @@ int derive_from_previous(amg_ctx* c, int k, bool* done) {
   std::swap(c->pair_first, c->alt_pfirst);
   std::swap(c->pair_cnt, c->alt_pcnt);
   AMGCHK(c->node_comp.ensure((size_t)(D2 + 1) * sizeof(int)));
-  c->n_windows = (int64_t)hs[ST_N_WINDOWS];
-  c->n_short = (int64_t)hs[ST_N_SHORT];
   c->n_nodes = c->n_local_nodes = D2;
   c->n_pairs = c->n_local_pairs = P2;
   c->comp_from_claims = false;  // (labels of the graph as it is now, made when somebody asks)
@@ -206,6 +305,19 @@ int derive_from_previous(amg_ctx* c, int k, bool* done) {
   c->built = true;
   c->derived = true;
   c->node_hint = D2 > 256 ? D2 : 256;
+  return AMG_OK;
+}
+
+// AMG_OK with *done = true: the graph of the current reads is in place (c->built); *done = false: the ordinary build
+// is to run (nothing it reads has been touched)
+int derive_from_previous(amg_ctx* c, int k, bool* done) {
+  *done = false;
+  if (c->n_nodes <= 0 || c->n_reads <= 0 || c->n_tokens <= 0) return AMG_OK;
+  long long D2 = 0, P2 = 0;
+  bool ok = false;
+  AMGCHK(derive_local(c, k, 0, 0x3fffffffffffffffll, nullptr, 1, nullptr, &D2, &P2, &ok));
+  if (!ok) return AMG_OK;
+  AMGCHK(derive_commit(c, D2, P2));
   *done = true;
   return AMG_OK;
 }

@@ -79,10 +79,11 @@ __device__ __forceinline__ unsigned int owner_of(unsigned long long key, unsigne
 }
 
 // ------------------------------------------------------------------ state of a ctx's merges
-enum { S_IDLE = 0, S_LOCAL, S_COUNTS, S_REDUCE, S_HOLD, S_HCOUNTS, S_GLOBAL, S_N };
+enum { S_IDLE = 0, S_LOCAL, S_COUNTS, S_REDUCE, S_HOLD, S_HCOUNTS, S_GLOBAL, S_DV_LOCAL, S_DV_ASK, S_DV_FILL, S_N };
 static const char* const kPhaseNames[2 * S_N] = {
     "", "nodes_local", "nodes_counts_pack", "nodes_reduce", "nodes_hold", "nodes_hcounts", "nodes_global",
-    "", "edges_local", "edges_counts_pack", "edges_reduce", "edges_hold", "edges_hcounts", "edges_global"};
+    "derive_local", "derive_ask", "derive_fill",
+    "", "edges_local", "edges_counts_pack", "edges_reduce", "edges_hold", "edges_hcounts", "edges_global", "", "", ""};
 
 struct DistState {
   int rank = 0, world = 1;
@@ -100,6 +101,10 @@ struct DistState {
   bool exchanged = false;
   DevBuf cnt_send, cnt_recv, hc_send, hc_recv, offs;
   DevBuf send, recv, rep_out, rep_in, held, held_pad, gathered;
+  // the rebuild that reuses the previous merged graph (amg_derive.hip; S_DV_*)
+  bool dv_ok = false;
+  long long dv_D2 = 0, dv_P2 = 0, dv_mN = 0, dv_mP = 0;
+  std::vector<long long> dv_bases, dv_bounds;
   const void* gathered_p = nullptr;
   const void* recv_p = nullptr;    // the records this rank owns the keys of (one rank: what it packed)
   void* rep_out_p = nullptr;       // the answers to them
@@ -1104,6 +1109,42 @@ static int edges_global(amg_ctx* c, DistState* d) {
   return AMG_OK;
 }
 
+// ------------------------------------------------------------------ the merged rebuild that reuses the previous one
+// (amg_derive.hip: when NO rank re-threaded a read the graph every rank holds, restricted to its live nodes, is the
+// graph of the corrected reads — every rank squeezes its copy; what only the rank that holds a first occurrence knows,
+// its token index in the NEW reads, travels in one all-gather: two exchanges and one host wait instead of ten and four)
+__global__ void k_dv_msg(long long ok, long long n_tokens, long long attempt, long long n_nodes, long long* __restrict__ msg) {
+  msg[0] = ok;
+  msg[1] = n_tokens;
+  msg[2] = attempt;
+  msg[3] = n_nodes;
+}
+// this rank's part of the all-gather: the first-seen values of the nodes, then of the classes, first seen on its shard
+// (local token indices so far: the shard's new first token is added), each padded to the largest part
+__global__ void k_dv_contrib(const long long* __restrict__ nfirst, long long n_n, long long add_n,
+                             const unsigned long long* __restrict__ pfirst, long long n_p, unsigned long long add_p,
+                             long long m_n, long long m_p, unsigned long long* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_n) out[i] = (unsigned long long)(nfirst[i] + add_n);
+  else if (i >= m_n && i - m_n < n_p) out[i] = pfirst[i - m_n] + add_p;
+}
+__global__ void k_dv_fill(const unsigned long long* __restrict__ all, long long m_n, long long m_p, int world,
+                          const long long* __restrict__ bounds, long long* __restrict__ nfirst,
+                          unsigned long long* __restrict__ pfirst) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long m = m_n + m_p;
+  if (i >= m * world) return;
+  const int r = (int)(i / m);
+  const long long j = i - (long long)r * m;
+  if (j < m_n) {
+    if (j < bounds[r + 1] - bounds[r]) nfirst[bounds[r] + j] = (long long)all[i];
+  } else {
+    const long long* pb = bounds + world + 1;
+    const long long q = j - m_n;
+    if (q < pb[r + 1] - pb[r]) pfirst[pb[r] + q] = all[i];
+  }
+}
+
 // ------------------------------------------------------------------ the driver
 static long long n_local_of(const amg_ctx* c, int kind) { return kind ? c->n_local_pairs : c->n_local_nodes; }
 
@@ -1419,6 +1460,95 @@ static int advance(amg_ctx* c, amg_xfer* x) {
         d->st[5] += d->attempt;
         return 0;
       }
+      case S_DV_LOCAL: {
+        // every rank squeezes its copy of the graph (when ITS correction allows it) and says so; only if all do is the
+        // squeezed graph taken — otherwise the ordinary merged build runs, nothing it reads has been touched
+        d->dv_ok = false;
+        const bool mine = c->derive_ready && (int)d->tokens.size() == W;
+        c->derive_ready = false;
+        c->dist_candidate = false;
+        if (mine) {
+          d->dv_bases.assign(W + 1, 0);
+          for (int p = 0; p < W; ++p) d->dv_bases[p + 1] = d->dv_bases[p] + d->tokens[p];
+          AMGCHK(d->offs.ensure((size_t)(2 * W + 4) * sizeof(long long)));
+          HIPCHK(hipMemcpyAsync(d->offs.p, d->dv_bases.data(), (size_t)(W + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+          d->dv_bounds.assign(2 * (W + 1), 0);
+          AMGCHK(derive_local(c, d->k, d->dv_bases[d->rank], d->tokens[d->rank], d->offs.as<long long>(), W,
+                              d->dv_bounds.data(), &d->dv_D2, &d->dv_P2, &d->dv_ok));
+        }
+        if (!wire) {
+          if (!d->dv_ok) {
+            d->state = S_LOCAL;
+            continue;
+          }
+          d->tokens.assign(1, c->n_tokens);
+          c->tok_base = 0;
+          c->tok_total = c->n_tokens;
+          AMGCHK(derive_commit(c, d->dv_D2, d->dv_P2));
+          ++d->st[7];
+          d->state = S_IDLE;
+          return 0;
+        }
+        AMGCHK(d->cnt_send.ensure((size_t)W * CNT_WORDS * sizeof(long long)));
+        AMGCHK(d->cnt_recv.ensure((size_t)W * CNT_WORDS * sizeof(long long)));
+        hipLaunchKernelGGL(k_dv_msg, dim3(1), dim3(1), 0, st, d->dv_ok ? 1ll : 0ll, (long long)c->n_tokens, (long long)d->attempt,
+                           d->dv_ok ? d->dv_D2 : -1ll, d->cnt_send.as<long long>());
+        xfer_ag(d, x, d->cnt_send.p, d->cnt_recv.p, CNT_WORDS * (int)sizeof(long long), 1, false);
+        d->state = S_DV_ASK;
+        return 1;
+      }
+      case S_DV_ASK: {
+        d->words.assign((size_t)W * CNT_WORDS, 0);
+        const WordRange rr[1] = {{d->cnt_recv.p, W * CNT_WORDS}};
+        AMGCHK(fetch_ranges(c, rr, 1, reinterpret_cast<long long*>(d->words.data())));
+        ++d->st[0];
+        const long long* got = reinterpret_cast<const long long*>(d->words.data());
+        bool all_ok = true;
+        for (int p = 0; p < W; ++p) all_ok = all_ok && got[(size_t)p * CNT_WORDS] == 1 && got[(size_t)p * CNT_WORDS + 3] == d->dv_D2;
+        if (!all_ok) {  // somebody re-threaded a read (or disagrees about the graph): the ordinary merged build
+          d->state = S_LOCAL;
+          continue;
+        }
+        long long base = 0, total = 0;
+        for (int p = 0; p < W; ++p) {
+          d->tokens[p] = got[(size_t)p * CNT_WORDS + 1];
+          if (p < d->rank) base += d->tokens[p];
+          total += d->tokens[p];
+        }
+        c->tok_base = base;
+        c->tok_total = total;
+        const long long* nb = d->dv_bounds.data();
+        const long long* pb = nb + W + 1;
+        d->dv_mN = d->dv_mP = 0;
+        for (int p = 0; p < W; ++p) {
+          if (nb[p + 1] - nb[p] > d->dv_mN) d->dv_mN = nb[p + 1] - nb[p];
+          if (pb[p + 1] - pb[p] > d->dv_mP) d->dv_mP = pb[p + 1] - pb[p];
+        }
+        const long long m = d->dv_mN + d->dv_mP;
+        d->state = S_DV_FILL;
+        if (m == 0) continue;
+        AMGCHK(d->held.ensure((size_t)m * sizeof(unsigned long long)));
+        AMGCHK(d->gathered.ensure((size_t)W * (size_t)m * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(k_dv_contrib, dim3(nblk(m, 256)), dim3(256), 0, st, c->alt_nfirst.as<long long>() + nb[d->rank],
+                           nb[d->rank + 1] - nb[d->rank], (long long)(base << 1),
+                           c->alt_pfirst.as<unsigned long long>() + pb[d->rank], pb[d->rank + 1] - pb[d->rank],
+                           (unsigned long long)base << 3, d->dv_mN, d->dv_mP, d->held.as<unsigned long long>());
+        xfer_ag(d, x, d->held.p, d->gathered.p, (int)sizeof(unsigned long long), m, true);
+        return 1;
+      }
+      case S_DV_FILL: {
+        const long long m = d->dv_mN + d->dv_mP;
+        if (m > 0) {
+          HIPCHK(hipMemcpyAsync(d->offs.p, d->dv_bounds.data(), (size_t)(2 * (W + 1)) * sizeof(long long), hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL(k_dv_fill, dim3(nblk(m * W, 256)), dim3(256), 0, st, d->gathered.as<unsigned long long>(), d->dv_mN,
+                             d->dv_mP, W, d->offs.as<long long>(), c->alt_nfirst.as<long long>(),
+                             c->alt_pfirst.as<unsigned long long>());
+        }
+        AMGCHK(derive_commit(c, d->dv_D2, d->dv_P2));
+        ++d->st[7];
+        d->state = S_IDLE;
+        return 0;
+      }
       default:
         return amg_fail(AMG_E_STATE, "amg_dist_merge_begin first");
     }
@@ -1436,7 +1566,12 @@ extern "C" int amg_dist_merge_begin(amg_ctx* c, int32_t k, uint32_t min_node_cov
   d->attempt = 0;
   d->kind = 0;
   d->fail_ret = 0;
-  d->state = S_LOCAL;
+  // the reads are what a correction left of the reads of the merged graph still held (amg_adopt_corrected), same k, plain
+  // build: the ranks first find out whether that graph's live part will do (S_DV_*; AMG_NO_DERIVE=1: A/B + test switch)
+  const bool candidate = c->dist_candidate && c->dist_mode && c->world == d->world && k == c->k && d->mn == 1 && d->me == 1 &&
+                         !getenv("AMG_NO_DERIVE");
+  if (!candidate) c->dist_candidate = c->derive_ready = false;
+  d->state = candidate ? S_DV_LOCAL : S_LOCAL;
   return AMG_OK;
 }
 
@@ -1564,7 +1699,7 @@ extern "C" int amg_dist_merge_local(amg_ctx* const* ctxs, int32_t world, int32_t
 
 // out[0] host waits on exchanged counts, [1] exchanges, [2] most bytes of records to ONE peer, [3] the same of replies,
 // [4] bytes contributed to the all-gathers of held records, [5] repeated builds (merge-key collisions), [6] bytes of
-// records sent to all peers; since the last reset
+// records sent to all peers, [7] builds made from the previous merged graph's live part; since the last reset
 extern "C" int amg_dist_stats(amg_ctx* c, int64_t* out, int32_t reset) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   DistState* d = dm(c);

@@ -215,6 +215,7 @@ struct amg_ctx {
   bool c_derivable = false;      // amg_correct_reads: the corrected set only drops and trims reads of the graph's read set
   bool derive_ready = false;     // the current reads are such a set of the graph still held (amg_adopt_corrected)
   bool derived = false;          // the graph at hand was made that way (amg_counts)
+  bool dist_candidate = false;   // the same on a rank of a merged build, whatever THIS rank's correction did (every rank asks)
   bool edge_own_deaths = false;  // since the build an edge was removed with both its nodes alive
   DevBuf alt_tok_node, alt_tok_dir, alt_ntok, alt_ncov, alt_nfirst, alt_nalive, alt_pkey, alt_pfirst, alt_pcnt;
 
@@ -356,7 +357,11 @@ void stage_end(amg_ctx* c);
 void stages_reset(amg_ctx* c);
 
 void dist_release(amg_ctx* c);  // amg_dist.hip
-int derive_from_previous(amg_ctx* c, int k, bool* done);  // amg_derive.hip
+// amg_derive.hip
+int derive_from_previous(amg_ctx* c, int k, bool* done);
+int derive_local(amg_ctx* c, int k, long long own_lo, long long own_tokens, const long long* d_bases, int world,
+                 long long* bounds_host, long long* D2_out, long long* P2_out, bool* ok);
+int derive_commit(amg_ctx* c, long long D2, long long P2);
 
 // build stages (amg_build.hip), shared with the multi-GPU path (amg_dist.hip)
 uint64_t pow2_at_least(uint64_t x);

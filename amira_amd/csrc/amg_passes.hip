@@ -2810,7 +2810,7 @@ extern "C" int amg_correct_reads(amg_ctx* c, int64_t* n_out_reads, int64_t* n_ou
     bound += dead_kept;
     // the graph these reads will make is this graph's live part (amg_derive.hip) when no read was re-threaded or kept
     // its genes around a dead window, and no edge died on its own: reads were dropped or cut to their live windows
-    c->c_derivable = n_gapped == 0 && dead_kept == 0 && !c->edge_own_deaths && !c->dist_mode;
+    c->c_derivable = n_gapped == 0 && dead_kept == 0 && !c->edge_own_deaths;
     c->c_node_bound = (int64_t)bound;
     if (const char* e = getenv("AMG_TEST_NODE_BOUND")) c->c_node_bound = atoll(e);  // test hook: a bound that does not hold
     c->c_node_bound_k = c->k;
@@ -3050,6 +3050,7 @@ extern "C" int amg_adopt_corrected(amg_ctx* c) {
   std::swap(c->read_off, c->c_read_off);
   std::swap(c->rd_src, c->c_src);
   c->derive_ready = c->c_derivable;  // (the graph the reads were corrected against is still in place: amg_build may reuse it)
+  c->dist_candidate = c->dist_mode;  // (a rank of a merged build: the ranks decide together, amg_dist.hip S_DV_*)
   c->c_derivable = false;
   if (c->have_pos && compacted) {
     c->pos_identity = true;

@@ -391,13 +391,14 @@ class Engine:
         out = (C.c_int64 * 8)()
         check(_ffi.lib.amg_dist_stats(self._h, out, 1 if reset else 0))
         return {"host_waits": out[0], "exchanges": out[1], "a2a_bytes_per_peer": out[2], "back_bytes_per_peer": out[3],
-                "ag_bytes_contributed": out[4], "repeated_builds": out[5], "a2a_bytes_sent": out[6]}
+                "ag_bytes_contributed": out[4], "repeated_builds": out[5], "a2a_bytes_sent": out[6],
+                "derived_builds": out[7]}
 
     def dist_phase_ms(self, on=True):
         """{phase: synchronised wall ms} of the merge driver since the last call; on: keep measuring"""
-        names = (C.c_char_p * 16)()
-        ms = (C.c_double * 16)()
-        n = _ffi.lib.amg_dist_phase_ms(self._h, 1 if on else 0, names, ms, 16)
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        n = _ffi.lib.amg_dist_phase_ms(self._h, 1 if on else 0, names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
 
 

@@ -312,7 +312,8 @@ int amg_copy_d2h(amg_ctx* ctx, const void* device_ptr, void* host_ptr, int64_t b
 int amg_copy_h2d(amg_ctx* ctx, void* device_ptr, const void* host_ptr, int64_t bytes);
 /* counters of the ctx's merged builds since the last reset: out[0] host waits on exchanged counts, [1] exchanges,
  * [2] most bytes of records sent to ONE peer, [3] the same of replies, [4] bytes contributed to the all-gathers,
- * [5] builds repeated after a merge-key collision, [6] bytes of records sent to all peers */
+ * [5] builds repeated after a merge-key collision, [6] bytes of records sent to all peers, [7] builds made from the
+ * previous merged graph's live part (no rank had re-threaded a read: two exchanges instead of ten) */
 int amg_dist_stats(amg_ctx* ctx, int64_t* out, int32_t reset);
 /* synchronised wall time per phase of the merge driver since the last call (on = 1: keep measuring — every phase is
  * bracketed by stream synchronisations —, 0: stop); names[i] are static strings; returns the number of phases */

@@ -5,20 +5,11 @@ behind the blocks of the ranks below r, whatever the counts (empty blocks includ
 its failure hand-shake, which lives in libamg) is tested on the GPU: tests/test_gpu_dist.py."""
 import ctypes as C
 import os
-import socket
 
 import numpy as np
 import torch.multiprocessing as mp
 
 REC = 24
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 class _HostEngine:
@@ -59,9 +50,10 @@ def _xfer(kind, elem_bytes, send, recv, send_counts=None, recv_counts=None, coun
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (a file as the rendezvous: a TCP port picked by the parent can be taken by the time the store listens on it)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from amira_amd import _ffi
     from amira_amd.dist import perform_host
     eng = _HostEngine()
@@ -97,11 +89,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_exchanges_world2_gloo():
+def test_exchanges_world2_gloo(tmp_path):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = str(tmp_path / "rendezvous")
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -126,11 +126,15 @@ def test_rank_without_reads(thr):
         e.close()
 
 
+@pytest.mark.parametrize("derive", [True, False])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_sweep_equals_unsharded(world):
+def test_sharded_sweep_equals_unsharded(world, derive, monkeypatch):
     """build -> filter -> correct -> build -> clip -> correct -> build with every build merged
     across the emulated ranks; the concatenation of the ranks' corrected reads must equal the
-    single-GPU sweep."""
+    single-GPU sweep.  derive: the third merged build is made from the second one's live part when no rank
+    re-threaded a read after the clip (amg_derive.hip; the ranks ask each other) — or never (AMG_NO_DERIVE=1)."""
+    if not derive:
+        monkeypatch.setenv("AMG_NO_DERIVE", "1")
     from amira_amd import Engine, tokenize
     from amira_amd.dist import dist_build_loopback
     reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
@@ -174,7 +178,11 @@ def test_sharded_sweep_equals_unsharded(world):
     got_outs.append([e.corrected(*e.correct_reads(), True) for e in engines])
     for e in engines:
         e.adopt_corrected()
+    for e in engines:
+        e.dist_stats(reset=True)
     dist_build_loopback(engines, k)
+    taken = [e.dist_stats()["derived_builds"] for e in engines]
+    assert taken == [1 if derive else 0] * world, taken
     for e in engines:
         assert_same_graph(graph_state(e), want_graph)
     for stage in range(2):
@@ -187,7 +195,7 @@ def test_sharded_sweep_equals_unsharded(world):
         e.close()
 
 
-def test_dist_build_over_rccl_world1(monkeypatch):
+def test_dist_build_over_rccl_world1(monkeypatch, tmp_path):
     """amg_dist_init / amg_dist_merge over RCCL itself (libamg's own communicator; its ncclSend / ncclRecv groups and
     all-gathers on the engine's stream), world = 1 with every exchange forced through the transport"""
     import os
@@ -196,11 +204,11 @@ def test_dist_build_over_rccl_world1(monkeypatch):
     import torch.distributed as dist
     from amira_amd import Engine, tokenize
     from amira_amd.dist import dist_build
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     monkeypatch.setenv("AMG_DIST_ALWAYS_EXCHANGE", "1")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    # (a file as the rendezvous: a TCP port picked here can be taken by the time the store listens on it)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rendezvous", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     try:
         reads, _, _ = P.synth_inputs(7, 400, 30, 300, 0.03)
         vocab, toks, offs, _ = tokenize(reads)
@@ -374,14 +382,15 @@ def test_sharded_sweep_with_fused_first_filter():
 def _rccl_worker(rank, world, port, out_dir, empty_rank=None):
     """one rank of a REAL multi-process merged build over RCCL (needs >= world GPUs on the node)"""
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     import numpy as np
     import torch
     import torch.distributed as dist
     try:   # an environment in which two ranks cannot even meet is not a failure of the merge (exit code 77 = skip)
         torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        dist.init_process_group("nccl", init_method=f"file://{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)
         assert float(probe.item()) == world
@@ -426,7 +435,7 @@ def test_dist_build_over_rccl_two_processes(tmp_path, empty_rank):
         pytest.skip("needs two GPUs")
     from amira_amd import Engine, tokenize
     world = 2
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = str(tmp_path / "rendezvous")    # (a file: see test_dist_build_over_rccl_world1)
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, str(tmp_path), empty_rank)) for r in range(world)]
     for p in procs:
@@ -461,13 +470,13 @@ def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep, env=None):
     buffers are staged through the host around the collectives, amira_amd/dist.py) — everything of the N > 1 driver
     except the RCCL transport: count exchanges, padded all-gather, reply trip, the order of the collectives"""
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1")
     os.environ.update(env or {})
     import numpy as np
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from amira_amd import Engine, tokenize
     from amira_amd.dist import dist_build
     reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
@@ -505,9 +514,8 @@ def _gloo_worker(rank, world, port, out_dir, empty_rank, sweep, env=None):
 
 
 def _run_gloo(tmp_path, world, empty_rank, sweep, env=None):
-    import socket
     import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    port = str(tmp_path / "rendezvous")    # (a file: see test_dist_build_over_rccl_world1)
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, str(tmp_path), empty_rank, sweep, env)) for r in range(world)]
     for p in procs:
