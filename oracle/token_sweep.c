@@ -36,6 +36,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 typedef struct tsw {
   int32_t k, two_v;
@@ -506,15 +507,26 @@ static void ob_reserve(outbuf* o, int64_t extra) {
 
 /* correct_reads: the corrected read set stays inside g (tsw_corrected reads it, tsw_adopt makes
  * it the current read set).  Reads without a node (short reads) are not in _readNodes and
- * therefore not in the output; marked reads whose nodes were all removed are dropped (:1150). */
-void tsw_correct(tsw* g, int64_t* n_out_reads, int64_t* n_out_tokens) {
-  free_corr(g);
+ * therefore not in the output; marked reads whose nodes were all removed are dropped (:1150).
+ * Every read is corrected on its own against the graph as it stands (:1123-1134 is a loop over the reads that writes
+ * nothing the next read sees), so the reads [r0, r1) of a chunk can be done apart from the others: correct_chunk is the
+ * reference's loop body over a range of reads with outputs of its own; tsw_correct runs ONE chunk (the sequential
+ * restatement: the CPU baseline), or — tsw_set_threads(n), used by the full-size tests only, where the 8 M-read oracle
+ * run was minutes of the suite — n chunks on n threads and lays their outputs end to end. */
+typedef struct {
+  const tsw* g; int64_t r0, r1;
+  outbuf ob; int64_t* c_off; int32_t* c_orig; uint8_t* c_changed; int64_t nr;
+} corr_chunk;
+
+static void* correct_chunk(void* arg) {
+  corr_chunk* ck = (corr_chunk*)arg;
+  const tsw* g = ck->g;
   const int k = g->k;
   outbuf ob; memset(&ob, 0, sizeof(ob)); ob.pos = g->have_pos;
-  ob_reserve(&ob, g->T + 16);
-  int64_t* c_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(g->n_reads + 1));
-  int32_t* c_orig = (int32_t*)malloc(sizeof(int32_t) * (size_t)(g->n_reads + 1));
-  uint8_t* c_changed = (uint8_t*)malloc((size_t)g->n_reads + 1);
+  ob_reserve(&ob, (g->read_off[ck->r1] - g->read_off[ck->r0]) + 16);
+  int64_t* c_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ck->r1 - ck->r0 + 1));
+  int32_t* c_orig = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ck->r1 - ck->r0 + 1));
+  uint8_t* c_changed = (uint8_t*)malloc((size_t)(ck->r1 - ck->r0) + 1);
   int64_t nr = 0;
   c_off[0] = 0;
   ivec pool = {0, 0, 0}, gaps = {0, 0, 0};
@@ -522,7 +534,7 @@ void tsw_correct(tsw* g, int64_t* n_out_reads, int64_t* n_out_tokens) {
   int32_t* pn = (int32_t*)malloc(sizeof(int32_t) * (size_t)(distance + 4));
   int8_t* pd = (int8_t*)malloc((size_t)(distance + 4));
   int64_t cap_c = 0; int32_t* c_node = NULL; int8_t* c_dir = NULL; int32_t* c_gene = NULL; int32_t* best = NULL;
-  for (int64_t r = 0; r < g->n_reads; ++r) {
+  for (int64_t r = ck->r0; r < ck->r1; ++r) {
     const int64_t t0 = g->read_off[r], L0 = g->read_off[r + 1] - t0, n = L0 - k + 1;
     if (n <= 0) continue;
     const int32_t* W = g->tok_node + t0;
@@ -650,10 +662,62 @@ void tsw_correct(tsw* g, int64_t* n_out_reads, int64_t* n_out_tokens) {
     ob.n += best_ng; c_orig[nr] = (int32_t)r; c_changed[nr] = 1; c_off[++nr] = ob.n;
   }
   free(pool.v); free(gaps.v); free(pn); free(pd); free(c_node); free(c_dir); free(c_gene); free(best);
-  g->c_tok = ob.tok; g->c_gs = ob.gs; g->c_ge = ob.ge; g->c_off = c_off; g->c_orig = c_orig; g->c_changed = c_changed;
-  g->c_reads = nr; g->c_T = ob.n; g->have_corr = 1;
+  ck->ob = ob; ck->c_off = c_off; ck->c_orig = c_orig; ck->c_changed = c_changed; ck->nr = nr;
+  return NULL;
+}
+
+static int g_tsw_threads = 1;
+void tsw_set_threads(int n) { g_tsw_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+
+void tsw_correct(tsw* g, int64_t* n_out_reads, int64_t* n_out_tokens) {
+  free_corr(g);
+  int n_chunks = g_tsw_threads;
+  if ((int64_t)n_chunks > g->n_reads) n_chunks = g->n_reads > 0 ? (int)g->n_reads : 1;
+  corr_chunk* ck = (corr_chunk*)calloc((size_t)n_chunks, sizeof(corr_chunk));
+  for (int c = 0; c < n_chunks; ++c) {
+    ck[c].g = g;
+    ck[c].r0 = g->n_reads * c / n_chunks;
+    ck[c].r1 = g->n_reads * (c + 1) / n_chunks;
+  }
+  if (n_chunks == 1) {
+    correct_chunk(&ck[0]);
+  } else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_chunks);
+    for (int c = 0; c < n_chunks; ++c) pthread_create(&th[c], NULL, correct_chunk, &ck[c]);
+    for (int c = 0; c < n_chunks; ++c) pthread_join(th[c], NULL);
+    free(th);
+  }
+  int64_t nr = 0, nt = 0;
+  for (int c = 0; c < n_chunks; ++c) { nr += ck[c].nr; nt += ck[c].ob.n; }
+  if (n_chunks == 1) {
+    g->c_tok = ck[0].ob.tok; g->c_gs = ck[0].ob.gs; g->c_ge = ck[0].ob.ge;
+    g->c_off = ck[0].c_off; g->c_orig = ck[0].c_orig; g->c_changed = ck[0].c_changed;
+  } else {
+    g->c_tok = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt + 1));
+    g->c_gs = g->have_pos ? (int64_t*)malloc(sizeof(int64_t) * (size_t)(nt + 1)) : NULL;
+    g->c_ge = g->have_pos ? (int64_t*)malloc(sizeof(int64_t) * (size_t)(nt + 1)) : NULL;
+    g->c_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nr + 1));
+    g->c_orig = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+    g->c_changed = (uint8_t*)malloc((size_t)nr + 1);
+    int64_t ro = 0, to = 0;
+    g->c_off[0] = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+      memcpy(g->c_tok + to, ck[c].ob.tok, sizeof(int32_t) * (size_t)ck[c].ob.n);
+      if (g->have_pos) {
+        memcpy(g->c_gs + to, ck[c].ob.gs, sizeof(int64_t) * (size_t)ck[c].ob.n);
+        memcpy(g->c_ge + to, ck[c].ob.ge, sizeof(int64_t) * (size_t)ck[c].ob.n);
+      }
+      for (int64_t i = 0; i < ck[c].nr; ++i) g->c_off[ro + i + 1] = to + ck[c].c_off[i + 1];
+      memcpy(g->c_orig + ro, ck[c].c_orig, sizeof(int32_t) * (size_t)ck[c].nr);
+      memcpy(g->c_changed + ro, ck[c].c_changed, (size_t)ck[c].nr);
+      ro += ck[c].nr; to += ck[c].ob.n;
+      free(ck[c].ob.tok); free(ck[c].ob.gs); free(ck[c].ob.ge); free(ck[c].c_off); free(ck[c].c_orig); free(ck[c].c_changed);
+    }
+  }
+  free(ck);
+  g->c_reads = nr; g->c_T = nt; g->have_corr = 1;
   if (n_out_reads) *n_out_reads = nr;
-  if (n_out_tokens) *n_out_tokens = ob.n;
+  if (n_out_tokens) *n_out_tokens = nt;
 }
 
 /* any pointer may be NULL */

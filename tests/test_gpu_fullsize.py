@@ -164,14 +164,19 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
     from amira_amd import Engine
     from amira_amd.dist import dist_build_loopback
     from helpers import compare_engine_to_sweep, live_arrays
+    import time
+    t_start = time.time()
+    lap = (lambda what: print(f"[cfg5] {time.time() - t_start:7.1f} s  {what}", flush=True)) if os.environ.get("AMG_TEST_TIMES") else (lambda what: None)
     world, N = 8, 1_000_000
     w = bench.WORKLOADS["cfg3-sweep"]          # bench.py: rank r holds reads [r N, (r + 1) N) of this stream
     L, k = w["L"], w["k"]
     vocab, toks, offs = bench.make_tokens(w, 0, world * N)
+    lap("reads made")
     gs = np.tile(np.arange(L, dtype=np.int64) * 1000, world * N)
     ge = gs + 899
     rl = np.full(world * N, L * 1000 + 100, np.int64)
     orc = token_oracle.Sweep(toks, offs, vocab.two_v, gs, ge, rl)
+    lap("oracle loaded")
     engines = []
     try:
         for r in range(world):
@@ -184,7 +189,9 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
 
         # ---- the whole stream through ONE engine's plain build (480 M tokens, 43 M nodes: claim ids from the shard
         # counters, the edge classes of coverage-1 nodes past the edge table, at eight times the benchmark's size)
+        lap("engines loaded")
         orc.build(k)
+        lap("oracle build 1")
         one = Engine(0)
         try:
             one.set_reads(toks, offs, vocab.two_v)
@@ -193,6 +200,7 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
             compare_engine_to_sweep(one, orc, "one engine, 8 M reads")
         finally:
             one.close()
+        lap("one engine compared")
         # ---- build 1, merged, filter_graph(3, 1) fused in == build + filter on the whole stream
         dist_build_loopback(engines, k, 3, 1)
         orc.filter(3, 1)
@@ -214,7 +222,7 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
 
         def correct_all(stage):
             """correct_reads on every rank; the ranks' corrected reads, concatenated, equal the oracle's"""
-            nr, nt = orc.correct_reads()
+            nr, nt = orc.correct_reads(threads=min(32, os.cpu_count() or 1))
             ref = orc.corrected(nr, nt, True)
             outs = [e.corrected(*e.correct_reads(), True) for e in engines]
             for key in ("tokens", "gene_start", "gene_end", "changed"):
@@ -252,14 +260,20 @@ def test_cfg5_emulated_8_ranks_equal_c_oracle():
                 tok_lo += n_tok
             assert tok_lo == len(tn_o)
 
+        lap("merged build 1 compared")
         correct_all("correct 1")
+        lap("correct 1")
         merged_build_equals("build 2")
+        lap("build 2")
         want_removed = np.sort(orc.remove_short_linear_paths(k))
         assert len(want_removed) > 0
         for e in engines:
             assert np.array_equal(np.sort(e.remove_short_linear_paths(k)), want_removed)
+        lap("clip")
         correct_all("correct 2")
+        lap("correct 2")
         merged_build_equals("build 3")
+        lap("build 3")
     finally:
         for e in engines:
             e.close()

@@ -16,8 +16,8 @@ def test_random_sweeps_equal_oracle(seed):
     spec = importlib.util.spec_from_file_location("fuzz_sweep", os.path.join(root, "tools", "fuzz_sweep.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    n_ok, n_pal, n_fail = fz.run(budget=120.0, seed=seed, max_cases=20)
-    assert n_fail == 0 and n_ok + n_pal == 20
+    n_ok, n_pal, n_fail = fz.run(budget=120.0, seed=seed, max_cases=14)
+    assert n_fail == 0 and n_ok + n_pal == 14
 
 
 def test_random_merged_builds_equal_unsharded():
@@ -39,12 +39,12 @@ def test_random_bubble_popping_equals_oracle():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONHASHSEED="0", FUZZ_ONLY="bubbles")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "75", "424242"], env=env,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "35", "424242"], env=env,
                          capture_output=True, text=True, timeout=600)
     last = [l for l in out.stdout.splitlines() if l.startswith("fuzz_api:")]
     assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
     n_ok = int(last[-1].split()[1])
-    assert n_ok >= 3 and " 0 failures" in last[-1]
+    assert n_ok >= 2 and " 0 failures" in last[-1]
 
 
 def test_random_two_word_keys_equal_c_oracle():
@@ -54,8 +54,8 @@ def test_random_two_word_keys_equal_c_oracle():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_twoword.py"), "40", "20261003"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_twoword.py"), "20", "20261003"],
                          capture_output=True, text=True, timeout=600)
     last = [l for l in out.stdout.splitlines() if l.startswith("fuzz_twoword:")]
     assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
-    assert int(last[-1].split()[1]) >= 5 and " 0 failures" in last[-1]
+    assert int(last[-1].split()[1]) >= 3 and " 0 failures" in last[-1]

@@ -78,7 +78,7 @@ def run_sweep(eng, reads, pos, fq, k, min_cov=3):
     eng.build(k)
     g3 = GeneMerGraph(r3, k, p3)
     compare_engine_to_oracle(eng, oracle_arrays(g3, vocab, ids3, out3["read_offsets"], k))
-    DERIVED.append(eng.counts()["derived"])
+    DERIVED.append(eng.counts().get("derived", 0))
     return len(want_removed)
 
 

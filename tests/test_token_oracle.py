@@ -99,3 +99,23 @@ def test_c_sweep_low_coverage_components(ceng):
         ceng.remove_low_coverage_components(m)
         g.remove_low_coverage_components(m)
         compare_engine_to_oracle(ceng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
+
+
+def test_threaded_correct_reads_equals_sequential():
+    """the C sweep oracle corrects every read on its own: the chunks of tsw_set_threads(n) (used by the full-size GPU
+    tests, where the sequential 8 M-read run was minutes) laid end to end are the sequential output"""
+    reads, pos, fq = P.synth_inputs(11, 3000, 40, 400, 0.03)
+    vocab, toks, offs, read_ids = _tokenize(reads)
+    gs = np.fromiter((p[0] for r in read_ids for p in pos[r]), dtype=np.int64)
+    ge = np.fromiter((p[1] for r in read_ids for p in pos[r]), dtype=np.int64)
+    rl = np.asarray([len(fq[r]["sequence"]) for r in read_ids], np.int64)
+    outs = []
+    for threads in (1, 5):
+        o = token_oracle.Sweep(toks, offs, vocab.two_v, gs, ge, rl)
+        o.build(5)
+        o.filter(3, 1)
+        outs.append(o.corrected(*o.correct_reads(threads=threads), True))
+        o.close()
+    assert outs[0]["changed"].any()
+    for key in outs[0]:
+        assert np.array_equal(outs[0][key], outs[1][key]), key

@@ -85,6 +85,7 @@ def _sweep_lib():
     lib.tsw_edges.argtypes = [P] * 7
     lib.tsw_read_nodes.argtypes = [P] * 4
     lib.tsw_adj.argtypes = [P] * 3
+    lib.tsw_set_threads.argtypes = [C.c_int]
     lib._tsw_ready = True
     return lib
 
@@ -166,9 +167,15 @@ class Sweep:
     def remove_low_coverage_components(self, m):
         self.lib.tsw_remove_low_coverage_components(self.h, m)
 
-    def correct_reads(self):
+    def correct_reads(self, threads=1):
+        """threads > 1: the reads in that many chunks side by side (every read is corrected on its own; the outputs are
+        laid end to end) — the full-size tests; 1: the sequential restatement (what bench.py times as cpu_baseline)"""
         a, b = C.c_int64(), C.c_int64()
-        self.lib.tsw_correct(self.h, C.byref(a), C.byref(b))
+        self.lib.tsw_set_threads(int(threads))
+        try:
+            self.lib.tsw_correct(self.h, C.byref(a), C.byref(b))
+        finally:
+            self.lib.tsw_set_threads(1)
         return a.value, b.value
 
     def corrected(self, n_reads, n_tokens, with_pos=False):
