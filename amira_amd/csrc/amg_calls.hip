@@ -873,48 +873,6 @@ extern "C" int amg_calls_load_positions_json(amg_calls* c, const char* path, int
   return AMG_OK;
 }
 
-// text of a stretch of reads as a writer thread makes it: a string whose big allocations are 2 MB-aligned and advised
-// as huge pages (megabytes of fresh heap per thread and call: the page faults, not the formatting, were the time)
-template <class T>
-struct HugeAlloc {
-  typedef T value_type;
-  HugeAlloc() = default;
-  template <class U> HugeAlloc(const HugeAlloc<U>&) {}
-  T* allocate(size_t n) {
-    const size_t bytes = n * sizeof(T);
-    void* p = nullptr;
-    if (bytes >= 2 * kTwoMb) {
-      size_t got = 0;
-      p = big_alloc(bytes, &got);  // (a cached block may be larger than asked for; deallocate returns it at the asked size)
-    } else {
-      p = malloc(bytes ? bytes : 1);
-    }
-    if (!p) throw std::bad_alloc();
-    return static_cast<T*>(p);
-  }
-  void deallocate(T* p, size_t n) {
-    const size_t bytes = n * sizeof(T);
-    if (bytes >= 2 * kTwoMb)
-      big_free(p, (bytes + kTwoMb - 1) & ~(kTwoMb - 1));
-    else
-      free(p);
-  }
-  template <class U> bool operator==(const HugeAlloc<U>&) const { return true; }
-  template <class U> bool operator!=(const HugeAlloc<U>&) const { return false; }
-};
-typedef std::basic_string<char, std::char_traits<char>, HugeAlloc<char>> Text;
-
-static void json_string(Text& out, const char* s, size_t n) {
-  out.push_back('"');
-  for (size_t i = 0; i < n; ++i) {
-    const unsigned char ch = (unsigned char)s[i];
-    if (ch == '"' || ch == '\\') { out.push_back('\\'); out.push_back((char)ch); }
-    else if (ch < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", ch); out += b; }
-    else out.push_back((char)ch);
-  }
-  out.push_back('"');
-}
-
 // output file written in pieces by many threads: the texts of a batch go to their offsets with pwrite, side by side
 // (one thread's write() into the page cache moves 1.5 - 2 GB/s: it was two thirds of a writer's time)
 struct PiecewiseFile {
@@ -940,15 +898,6 @@ struct PiecewiseFile {
     ok = ok && put_at(fd, &ch, 1, pos);
     ++pos;
   }
-  void put_all(const std::vector<Text>& text) {
-    std::vector<off_t> at(text.size() + 1, pos);
-    for (size_t w = 0; w < text.size(); ++w) at[w + 1] = at[w] + (off_t)text[w].size();
-    std::vector<char> good(text.size(), 1);
-    const int f = fd;
-    run_parts(text.size(), [&](size_t w) { good[w] = text[w].empty() || put_at(f, text[w].data(), text[w].size(), at[w]); });
-    for (char g : good) ok = ok && g;
-    pos = at[text.size()];
-  }
   bool finish() {
     ok = ok && fd >= 0 && ftruncate(fd, pos) == 0;
     const bool closed = fd >= 0 && close(fd) == 0;
@@ -957,19 +906,106 @@ struct PiecewiseFile {
   }
 };
 
+// A worker's text: ONE block sized by an upper bound, filled through a bare cursor (appending to a string checked its
+// capacity once per character: the texts were two thirds of a writer's time), a block of the big-buffer cache above.
+struct RawText {
+  char* b = nullptr;
+  size_t got = 0, n = 0;
+  RawText() = default;
+  RawText(const RawText&) = delete;
+  RawText& operator=(const RawText&) = delete;
+  ~RawText() { big_free(b, got); }
+  bool room(size_t want) {
+    n = 0;
+    if (want <= got) return true;
+    big_free(b, got);
+    b = static_cast<char*>(big_alloc(want, &got));
+    if (!b) got = 0;
+    return b != nullptr;
+  }
+};
+
+// the bytes of a JSON string for s[0..n): quotes, backslashes and control characters as json.dumps(ensure_ascii=False)
+// writes them; at most 6 n + 2 bytes
+static char* json_string_raw(char* q, const char* s, size_t n) {
+  *q++ = '"';
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char ch = (unsigned char)s[i];
+    if (ch == '"' || ch == '\\') { *q++ = '\\'; *q++ = (char)ch; }
+    else if (ch < 0x20) { q += snprintf(q, 8, "\\u%04x", ch); }
+    else *q++ = (char)ch;
+  }
+  *q++ = '"';
+  return q;
+}
+
+static const char kDigits2[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+static inline char* put_i64(char* q, long long v) {
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  if (v < 0) *q++ = '-';
+  char buf[24];
+  int n = 0;
+  while (u >= 100) {
+    const unsigned r = (unsigned)(u % 100);
+    u /= 100;
+    buf[n++] = kDigits2[2 * r + 1];
+    buf[n++] = kDigits2[2 * r];
+  }
+  if (u >= 10) {
+    buf[n++] = kDigits2[2 * u + 1];
+    buf[n++] = kDigits2[2 * u];
+  } else {
+    buf[n++] = (char)('0' + u);
+  }
+  while (n) *q++ = buf[--n];
+  return q;
+}
+
+static bool put_raw(PiecewiseFile& f, const std::vector<RawText>& text) {
+  std::vector<off_t> at(text.size() + 1, f.pos);
+  for (size_t w = 0; w < text.size(); ++w) at[w + 1] = at[w] + (off_t)text[w].n;
+  std::vector<char> good(text.size(), 1);
+  const int fd = f.fd;
+  run_parts(text.size(), [&](size_t w) { good[w] = text[w].n == 0 || PiecewiseFile::put_at(fd, text[w].b, text[w].n, at[w]); });
+  for (char g : good) f.ok = f.ok && g;
+  f.pos = at[text.size()];
+  return f.ok;
+}
+
 // write-back: corrected CSR -> {"read": ["+gene", ...]} (json.dumps separators ', ' and ': ',
 // ensure_ascii=False) — result_utils.py:1260-1264.  The text of a stretch of reads is made by one thread each, the
-// stretches are written in order.
+// stretches are written in order.  Every gene's two spellings ("+name" and "-name" as JSON strings) are made once; a
+// read's text is a run of copies.
 extern "C" int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t* read_offsets,
                                     int64_t n_reads, const char* gene_names, int64_t n_genes,
                                     const char* read_ids) {
   if (!path || !read_offsets || !gene_names || !read_ids) return amg_fail(AMG_E_ARG, "null argument");
-  std::vector<const char*> name(n_genes);
-  std::vector<uint32_t> name_len(n_genes);
-  const char* p = gene_names;
-  for (int64_t i = 0; i < n_genes; ++i) { name[i] = p; name_len[i] = (uint32_t)strlen(p); p += name_len[i] + 1; }
+  const bool timing = getenv("AMG_CALLS_TIMING") != nullptr;
+  const auto w_start = std::chrono::steady_clock::now();
+  auto wall = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - w_start).count(); };
+  // spelled[2 g] / spelled[2 g + 1]: the JSON strings of "+name" / "-name" of gene rank g, in one arena
+  std::vector<uint32_t> sp_off((size_t)2 * n_genes + 1, 0);
+  std::string arena;
+  {
+    const char* p = gene_names;
+    std::string tmp;
+    for (int64_t i = 0; i < n_genes; ++i) {
+      const size_t nl = strlen(p);
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        tmp.assign(1, sgn == 0 ? '+' : '-');
+        tmp.append(p, nl);
+        const size_t at = arena.size();
+        arena.resize(at + 6 * tmp.size() + 2);
+        char* e = json_string_raw(&arena[at], tmp.data(), tmp.size());
+        arena.resize((size_t)(e - arena.data()));
+        sp_off[2 * i + sgn + 1] = (uint32_t)arena.size();
+      }
+      p += nl + 1;
+    }
+  }
   std::vector<const char*> rid((size_t)n_reads + 1);
-  p = read_ids;
+  const char* p = read_ids;
   for (int64_t r = 0; r < n_reads; ++r) { rid[r] = p; p += strlen(p) + 1; }
   rid[n_reads] = p;
   PiecewiseFile f(path);
@@ -977,51 +1013,55 @@ extern "C" int amg_calls_write_json(const char* path, const int32_t* tokens, con
   const int64_t V = n_genes ? n_genes : 1;
   const int64_t T = n_reads > 0 ? read_offsets[n_reads] : 0;
   const size_t workers = (size_t)std::max<int64_t>(1, std::min<int64_t>(worker_count((size_t)T * 10 + 1), n_reads));
-  std::vector<Text> text(workers);
+  std::vector<RawText> text(workers);
+  std::vector<char> fine(workers, 1);
   // batches of stretches, so that the text in memory stays bounded for very large files
   const int64_t per_batch = std::max<int64_t>((int64_t)workers * 65536, 1);
   f.put('{');
+  double t_text = 0, t_put = 0;
   for (int64_t lo = 0; lo < n_reads && f.ok; lo += per_batch) {
     const int64_t hi = std::min(n_reads, lo + per_batch);
+    const double t0 = wall();
     run_parts(workers, [&](size_t w) {
-      Text& o = text[w];
-      o.clear();
+      RawText& o = text[w];
       const int64_t a = lo + (hi - lo) * (int64_t)w / (int64_t)workers, b = lo + (hi - lo) * (int64_t)(w + 1) / (int64_t)workers;
-      o.reserve((size_t)(read_offsets[b] - read_offsets[a]) * 12 + (size_t)(b - a) * 24 + 16);
-      for (int64_t r = a; r < b; ++r) {
-        if (r) o += ", ";
-        json_string(o, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
-        o += ": [";
-        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
-          if (t > read_offsets[r]) o += ", ";
-          const int32_t tok = tokens[t];
-          const bool plus = tok >= V;
-          const int64_t g = plus ? tok - V : V - 1 - tok;
-          o.push_back('"');
-          o.push_back(plus ? '+' : '-');
-          // (the name's own quotes / backslashes / control characters are escaped as json.dumps does)
-          const char* nm = name[g];
-          const uint32_t nl = name_len[g];
-          bool plain = true;
-          for (uint32_t i = 0; i < nl; ++i) plain = plain && (unsigned char)nm[i] >= 0x20 && nm[i] != '"' && nm[i] != '\\';
-          if (plain) {
-            o.append(nm, nl);
-            o.push_back('"');
-          } else {
-            o.pop_back();
-            o.pop_back();
-            std::string g2(1, plus ? '+' : '-');
-            g2.append(nm, nl);
-            json_string(o, g2.data(), g2.size());
-          }
-        }
-        o.push_back(']');
+      // exact size of the genes' spellings, a bound for the read ids (escapes)
+      size_t need = 16;
+      for (int64_t t = read_offsets[a]; t < read_offsets[b]; ++t) {
+        const int32_t tok = tokens[t];
+        const int64_t g = tok >= V ? tok - V : V - 1 - tok;
+        const size_t i = (size_t)2 * (size_t)g + (tok >= V ? 0 : 1);
+        need += sp_off[i + 1] - sp_off[i] + 2;
       }
+      need += (size_t)(rid[b] - rid[a]) * 6 + (size_t)(b - a) * 8;
+      if (!o.room(need)) { fine[w] = 0; return; }
+      char* q = o.b;
+      for (int64_t r = a; r < b; ++r) {
+        if (r) { *q++ = ','; *q++ = ' '; }
+        q = json_string_raw(q, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
+        *q++ = ':'; *q++ = ' '; *q++ = '[';
+        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
+          if (t > read_offsets[r]) { *q++ = ','; *q++ = ' '; }
+          const int32_t tok = tokens[t];
+          const int64_t g = tok >= V ? tok - V : V - 1 - tok;
+          const size_t i = (size_t)2 * (size_t)g + (tok >= V ? 0 : 1);
+          const uint32_t len = sp_off[i + 1] - sp_off[i];
+          memcpy(q, arena.data() + sp_off[i], len);
+          q += len;
+        }
+        *q++ = ']';
+      }
+      o.n = (size_t)(q - o.b);
     });
-    f.put_all(text);
+    for (char g : fine) if (!g) return amg_fail(AMG_E_NOMEM, "no memory for the text of %s", path);
+    const double t1 = wall();
+    put_raw(f, text);
+    t_text += t1 - t0;
+    t_put += wall() - t1;
   }
   f.put('}');
   if (!f.finish()) return amg_fail(AMG_E_ARG, "short write to %s", path);
+  if (timing) fprintf(stderr, "write calls: text %.3fs, file %.3fs, total %.3fs wall, %zu workers\n", t_text, t_put, wall(), workers);
   return AMG_OK;
 }
 
@@ -1031,6 +1071,9 @@ extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* g
                                               const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
   if (!path || !read_offsets || !read_ids || ((!gene_start || !gene_end) && n_reads > 0 && read_offsets[n_reads] > 0))
     return amg_fail(AMG_E_ARG, "null argument");
+  const bool timing = getenv("AMG_CALLS_TIMING") != nullptr;
+  const auto w_start = std::chrono::steady_clock::now();
+  auto wall = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - w_start).count(); };
   std::vector<const char*> rid((size_t)n_reads + 1);
   const char* p = read_ids;
   for (int64_t r = 0; r < n_reads; ++r) { rid[r] = p; p += strlen(p) + 1; }
@@ -1039,44 +1082,58 @@ extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* g
   if (f.fd < 0) return amg_fail(AMG_E_ARG, "cannot write %s", path);
   const int64_t T = n_reads > 0 ? read_offsets[n_reads] : 0;
   const size_t workers = (size_t)std::max<int64_t>(1, std::min<int64_t>(worker_count((size_t)T * 16 + 1), n_reads));
-  std::vector<Text> text(workers);
+  std::vector<RawText> text(workers);
+  std::vector<char> fine(workers, 1);
   const int64_t per_batch = std::max<int64_t>((int64_t)workers * 65536, 1);
   f.put('{');
+  double t_text = 0, t_put = 0;
   for (int64_t lo = 0; lo < n_reads && f.ok; lo += per_batch) {
     const int64_t hi = std::min(n_reads, lo + per_batch);
+    const double t0 = wall();
     run_parts(workers, [&](size_t w) {
-      Text& o = text[w];
-      o.clear();
+      RawText& o = text[w];
       const int64_t a = lo + (hi - lo) * (int64_t)w / (int64_t)workers, b = lo + (hi - lo) * (int64_t)(w + 1) / (int64_t)workers;
-      o.reserve((size_t)(read_offsets[b] - read_offsets[a]) * 20 + (size_t)(b - a) * 24 + 16);
-      auto put = [&o](long long v) {  // decimal digits without the detour through a format string
-        char buf[24];
-        int n = 0;
-        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
-        do {
-          buf[n++] = (char)('0' + u % 10);
-          u /= 10;
-        } while (u);
-        if (v < 0) o.push_back('-');
-        while (n) o.push_back(buf[--n]);
-      };
-      for (int64_t r = a; r < b; ++r) {
-        if (r) o += ", ";
-        json_string(o, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
-        o += ": [";
-        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
-          o += t > read_offsets[r] ? ", [" : "[";
-          put((long long)gene_start[t]);
-          o += ", ";
-          put((long long)gene_end[t]);
-          o.push_back(']');
-        }
-        o.push_back(']');
+      // a bound from the longest number of the stretch
+      unsigned long long most = 0;
+      bool neg = false;
+      for (int64_t t = read_offsets[a]; t < read_offsets[b]; ++t) {
+        const long long s0 = gene_start[t], e0 = gene_end[t];
+        neg = neg || s0 < 0 || e0 < 0;
+        const unsigned long long us = s0 < 0 ? 0ull - (unsigned long long)s0 : (unsigned long long)s0;
+        const unsigned long long ue = e0 < 0 ? 0ull - (unsigned long long)e0 : (unsigned long long)e0;
+        most = us > most ? us : most;
+        most = ue > most ? ue : most;
       }
+      int digits = 1;
+      while (most >= 10) { most /= 10; ++digits; }
+      const size_t per_tok = (size_t)(2 * (digits + (neg ? 1 : 0)) + 6);
+      const size_t need = (size_t)(read_offsets[b] - read_offsets[a]) * per_tok + (size_t)(rid[b] - rid[a]) * 6 + (size_t)(b - a) * 8 + 16;
+      if (!o.room(need)) { fine[w] = 0; return; }
+      char* q = o.b;
+      for (int64_t r = a; r < b; ++r) {
+        if (r) { *q++ = ','; *q++ = ' '; }
+        q = json_string_raw(q, rid[r], (size_t)(rid[r + 1] - rid[r] - 1));
+        *q++ = ':'; *q++ = ' '; *q++ = '[';
+        for (int64_t t = read_offsets[r]; t < read_offsets[r + 1]; ++t) {
+          if (t > read_offsets[r]) { *q++ = ','; *q++ = ' '; }
+          *q++ = '[';
+          q = put_i64(q, (long long)gene_start[t]);
+          *q++ = ','; *q++ = ' ';
+          q = put_i64(q, (long long)gene_end[t]);
+          *q++ = ']';
+        }
+        *q++ = ']';
+      }
+      o.n = (size_t)(q - o.b);
     });
-    f.put_all(text);
+    for (char g : fine) if (!g) return amg_fail(AMG_E_NOMEM, "no memory for the text of %s", path);
+    const double t1 = wall();
+    put_raw(f, text);
+    t_text += t1 - t0;
+    t_put += wall() - t1;
   }
   f.put('}');
   if (!f.finish()) return amg_fail(AMG_E_ARG, "short write to %s", path);
+  if (timing) fprintf(stderr, "write positions: text %.3fs, file %.3fs, total %.3fs wall, %zu workers\n", t_text, t_put, wall(), workers);
   return AMG_OK;
 }
