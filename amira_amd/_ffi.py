@@ -87,6 +87,7 @@ def _load():
         "amg_correct_reads": (C.c_int, [P, C.POINTER(I64), C.POINTER(I64)]),
         "amg_get_corrected": (C.c_int, [P, P, P, P, P, P, P]),
         "amg_get_corrected32": (C.c_int, [P, P, P, P, P, P, P, P, C.POINTER(I64)]),
+        "amg_get_corrected_positions32": (C.c_int, [P, P, P]),
         "amg_adopt_corrected": (C.c_int, [P]),
         "amg_set_reads_from_corrected": (C.c_int, [P, P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),
@@ -110,6 +111,7 @@ def _load():
         "amg_calls_load_positions_json": (C.c_int, [P, C.c_char_p, P, P]),
         "amg_calls_write_json": (C.c_int, [C.c_char_p, P, P, I64, P, I64, P]),
         "amg_calls_write_positions_json": (C.c_int, [C.c_char_p, P, P, P, I64, P]),
+        "amg_calls_write_positions_json32": (C.c_int, [C.c_char_p, P, P, P, I64, P]),
         "amg_calls_first_use": (C.c_int, [P, I64, I32, P, I64, P]),
         "amg_calls_has_blanks": (C.c_int, [P, C.POINTER(I32)]),
         "amg_calls_free": (C.c_int, [P]),

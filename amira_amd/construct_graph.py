@@ -1643,7 +1643,16 @@ class GeneMerGraph(BubblePopping):
         return nodes["coverage"][nodes["alive"] != 0].tolist()   # straight from the device arrays
 
     def get_mean_node_coverage(self):
-        return statistics.mean(self.get_all_node_coverages())
+        if self._host_edits:
+            return statistics.mean(self.get_all_node_coverages())
+        # statistics.mean of integers (:868-871) is the exact fraction, an int when it is one and the correctly rounded
+        # float otherwise — which is what Python's own division of the two integers gives; the sum comes off the array
+        nodes = self._v().arrays["nodes"] if self._view is not None else self._engine.nodes()
+        cov = nodes["coverage"][nodes["alive"] != 0]
+        if len(cov) == 0:
+            return statistics.mean([])   # (StatisticsError, as the reference raises)
+        total, n = int(cov.sum(dtype=np.int64)), int(len(cov))
+        return total // n if total % n == 0 else total / n
 
     # ------------------------------------------------------------------ components (:911-958)
     def get_nodes_in_component(self, component):
@@ -2003,7 +2012,7 @@ class GeneMerGraph(BubblePopping):
             which = np.concatenate([np.zeros(len(chosen[0][0]), np.int8), np.ones(len(chosen[1][0]), np.int8)])
             order = np.argsort(rows, kind="stable")   # read order == dict order of _reads
             ro, so, wo = rows[order], starts[order], which[order]
-            rids = [self._read_ids[r] for r in ro.tolist()]
+            rids = self._read_ids_array()[ro].tolist()
             if rids:
                 path_reads.setdefault(named, set()).update(rids)
             pos = self._genePositions

@@ -1067,8 +1067,9 @@ extern "C" int amg_calls_write_json(const char* path, const int32_t* tokens, con
 
 // positions write-back: {"read": [[start, end], ...]} as json.dumps(gene_position_dict) writes it
 // (result_utils.py:1260-1264, second file)
-extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
-                                              const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
+template <class Int>
+static int write_positions_json(const char* path, const Int* gene_start, const Int* gene_end,
+                                const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
   if (!path || !read_offsets || !read_ids || ((!gene_start || !gene_end) && n_reads > 0 && read_offsets[n_reads] > 0))
     return amg_fail(AMG_E_ARG, "null argument");
   const bool timing = getenv("AMG_CALLS_TIMING") != nullptr;
@@ -1136,4 +1137,13 @@ extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* g
   if (!f.finish()) return amg_fail(AMG_E_ARG, "short write to %s", path);
   if (timing) fprintf(stderr, "write positions: text %.3fs, file %.3fs, total %.3fs wall, %zu workers\n", t_text, t_put, wall(), workers);
   return AMG_OK;
+}
+
+extern "C" int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
+                                              const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
+  return write_positions_json<int64_t>(path, gene_start, gene_end, read_offsets, n_reads, read_ids);
+}
+extern "C" int amg_calls_write_positions_json32(const char* path, const int32_t* gene_start, const int32_t* gene_end,
+                                                const int64_t* read_offsets, int64_t n_reads, const char* read_ids) {
+  return write_positions_json<int32_t>(path, gene_start, gene_end, read_offsets, n_reads, read_ids);
 }

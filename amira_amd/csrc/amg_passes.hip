@@ -3012,6 +3012,58 @@ extern "C" int amg_get_corrected32(amg_ctx* c, int32_t* tokens, int64_t* read_of
   return AMG_OK;
 }
 
+// every corrected read's positions laid end to end as 32-bit values (gathered on the device: half the bytes of
+// amg_get_corrected's position arrays over PCIe, and those arrays are four fifths of what a correction hands back)
+__global__ __launch_bounds__(256) void k_gather_positions32(CorrArgs a, const long long* __restrict__ c_off,
+                                                            const long long* __restrict__ c_posoff, long long c_reads,
+                                                            int* __restrict__ o_gs, int* __restrict__ o_ge,
+                                                            unsigned long long* too_wide) {
+  const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= c_reads) return;
+  const int lane = threadIdx.x & 63;
+  const long long a0 = c_off[q], n = c_off[q + 1] - a0;
+  const long long *gs, *ge;
+  pos_base(a, c_posoff[q], gs, ge);
+  bool wide = false;
+  for (long long i = lane; i < n; i += 64) {
+    const long long s = gs[i], e = ge[i];
+    wide = wide || s != (long long)(int)s || e != (long long)(int)e;
+    o_gs[a0 + i] = (int)s;
+    o_ge[a0 + i] = (int)e;
+  }
+  if (wide) *too_wide = 1ull;
+}
+
+extern "C" int amg_get_corrected_positions32(amg_ctx* c, int32_t* gene_start, int32_t* gene_end) {
+  if (!c || !gene_start || !gene_end) return amg_fail(AMG_E_ARG, "null argument");
+  if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");
+  if (!c->have_pos) return amg_fail(AMG_E_STATE, "no gene positions were set");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const long long R = c->c_reads, T = c->c_tokens;
+  if (T == 0) return AMG_OK;
+  AMGCHK(c->c_gstart.ensure((size_t)(T + 64) * sizeof(long long)));
+  AMGCHK(c->c_gend.ensure((size_t)(T + 64) * sizeof(long long)));
+  unsigned long long* flag = c->status.as<unsigned long long>() + ST_MISC;
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned long long), st));
+  CorrArgs a;
+  memset(&a, 0, sizeof(a));
+  fill_pos_args(c, a);
+  hipLaunchKernelGGL(k_gather_positions32, dim3(nblk(R, 4)), dim3(256), 0, st, a, c->c_read_off.as<long long>(),
+                     c->c_pos_off.as<long long>(), R, c->c_gstart.as<int>(), c->c_gend.as<int>(), flag);
+  unsigned long long wide = 0;
+  {
+    FetchList l;
+    l.add(flag);
+    AMGCHK(fetch(c, l, &wide));
+  }
+  if (wide) return amg_fail(AMG_E_ARG, "amg_get_corrected_positions32: a position does not fit 32 bits (amg_get_corrected returns 64-bit positions)");
+  HIPCHK(hipMemcpyAsync(gene_start, c->c_gstart.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(gene_end, c->c_gend.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return AMG_OK;
+}
+
 extern "C" int amg_adopt_corrected(amg_ctx* c) {
   if (!c) return amg_fail(AMG_E_ARG, "null ctx");
   if (!c->have_corrected) return amg_fail(AMG_E_STATE, "amg_correct_reads first");

@@ -239,12 +239,25 @@ class Engine:
         check(_ffi.lib.amg_correct_reads(self._h, C.byref(nr), C.byref(nt)))
         return nr.value, nt.value
 
-    def corrected(self, n_reads, n_tokens, with_positions, buf=None):
+    def corrected(self, n_reads, n_tokens, with_positions, buf=None, pos32=False):
+        """the corrected set on the host.  pos32: the positions as int32 arrays (gathered on the device, half the bytes
+        over PCIe) when every one of them fits — int64 otherwise, as without the flag"""
         out = {"tokens": self._take(buf, "c_tokens", (n_tokens,), np.int32),
                "read_offsets": self._take(buf, "c_read_offsets", (n_reads + 1,), np.int64),
                "orig_read": self._take(buf, "c_orig_read", (n_reads,), np.int32),
                "changed": self._take(buf, "c_changed", (n_reads,), np.uint8)}
         gs = ge = None
+        if with_positions and pos32:
+            gs = self._take(buf, "c_gene_start32", (n_tokens,), np.int32)
+            ge = self._take(buf, "c_gene_end32", (n_tokens,), np.int32)
+            check(_ffi.lib.amg_get_corrected(self._h, ptr(out["tokens"]), ptr(out["read_offsets"]),
+                                             ptr(out["orig_read"]), ptr(out["changed"]), None, None))
+            rc = _ffi.lib.amg_get_corrected_positions32(self._h, ptr(gs), ptr(ge))
+            if rc == 0:
+                out["gene_start"], out["gene_end"] = gs, ge
+                return out
+            if rc != -2:   # (AMG_E_ARG: a position beyond 32 bits — the 64-bit arrays below)
+                check(rc)
         if with_positions:
             gs = self._take(buf, "c_gene_start", (n_tokens,), np.int64)
             ge = self._take(buf, "c_gene_end", (n_tokens,), np.int64)

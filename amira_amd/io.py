@@ -31,7 +31,8 @@ class DeviceCorrected:
 
     def fetch(self):
         if self._arrays is None:
-            out = self._engine.corrected(*self._shape)
+            # (positions as int32 when they fit: gathered on the device, half the bytes over PCIe)
+            out = self._engine.corrected(*self._shape, pos32=True)
             self._arrays = {"tokens": out["tokens"], "gene_start": out["gene_start"], "gene_end": out["gene_end"]}
             self._done()
         return self._arrays
@@ -404,8 +405,10 @@ def write_gene_calls(path, vocab, tokens, read_offsets, read_ids):
 
 def write_gene_positions(path, gene_start, gene_end, read_offsets, read_ids):
     """flat positions -> {"read": [[start, end], ...]} JSON (the second file of result_utils.py:1260-1264)"""
-    gs = np.ascontiguousarray(gene_start, np.int64)
-    ge = np.ascontiguousarray(gene_end, np.int64)
+    narrow = getattr(gene_start, "dtype", None) == np.int32 and getattr(gene_end, "dtype", None) == np.int32
+    gs = np.ascontiguousarray(gene_start, np.int32 if narrow else np.int64)
+    ge = np.ascontiguousarray(gene_end, np.int32 if narrow else np.int64)
     read_offsets = np.ascontiguousarray(read_offsets, np.int64)
     ids = ("\0".join(read_ids) + "\0").encode("utf-8") if len(read_ids) else b""
-    check(_ffi.lib.amg_calls_write_positions_json(str(path).encode(), ptr(gs), ptr(ge), ptr(read_offsets), len(read_ids), ids))
+    fn = _ffi.lib.amg_calls_write_positions_json32 if narrow else _ffi.lib.amg_calls_write_positions_json
+    check(fn(str(path).encode(), ptr(gs), ptr(ge), ptr(read_offsets), len(read_ids), ids))

@@ -427,7 +427,8 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
                         "tok_node": pinned(cap_t, torch.int32), "tok_dir": pinned(cap_t, torch.int8),
                         "c_tokens": pinned(cap_t, torch.int32), "c_read_offsets": pinned(cap_r, torch.int64),
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
-                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)}
+                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64),
+                        "c_gene_start32": pinned(cap_t, torch.int32), "c_gene_end32": pinned(cap_t, torch.int32)}
 
         def step(self):
             eng = self.eng
@@ -450,7 +451,7 @@ def run_e2e_pipelined(w, vocab, toks, offs, k, n_windows, local_rank, counts, st
             eng.build(k)
             eng.remove_short_linear_paths(k)
             n_out = eng.correct_reads()
-            eng.corrected(*n_out, True, buf=self.buf)
+            eng.corrected(*n_out, True, buf=self.buf, pos32=True)
             eng.adopt_corrected()
             eng.build(k)
             eng.nodes(self.buf)
@@ -956,7 +957,7 @@ def main():
             # the corrected calls + positions the reference hands on (graph_utils.py:165) as the drop-in hands them on:
             # contiguous corrected position arrays, every read's (Engine.corrected = what amira_amd.io.DeviceCorrected
             # fetches for GeneMerGraph.correct_reads' mappings)
-            eng.corrected(*n_out, True, buf=readback)
+            eng.corrected(*n_out, True, buf=readback, pos32=True)
         elif readback is not None:
             # the boundary's lighter form: 32-bit positions, and only those the correction PRODUCED — an untouched or
             # trimmed read's positions are a slice of the arrays the caller already has, named by offset
@@ -1060,7 +1061,8 @@ def main():
                         "c_orig_read": pinned(cap_r, torch.int32), "c_changed": pinned(cap_r, torch.uint8),
                         "c_pos_src": pinned(cap_r, torch.int64),
                         "c_new_start": pinned(cap_t, torch.int32), "c_new_end": pinned(cap_t, torch.int32),
-                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64)})
+                        "c_gene_start": pinned(cap_t, torch.int64), "c_gene_end": pinned(cap_t, torch.int64),
+                        "c_gene_start32": pinned(cap_t, torch.int32), "c_gene_end32": pinned(cap_t, torch.int32)})
         side = torch.cuda.Stream(device=dev)
         moved = {}
         ev_reads, ev_pos = torch.cuda.Event(), torch.cuda.Event()
@@ -1100,14 +1102,15 @@ def main():
         h2d = T * 4 + (N + 1) * 8 + (T * 8 + N * 8 if w["sweep"] else 0)
         c_fin = eng.counts()
         d2h_graph = c_fin["n_nodes"] * (4 * k + 4 + 8 + 1 + 4 + 1) + c_fin["n_edges"] * 14 + c_fin["n_tokens"] * 5
-        d2h = d2h_graph + (c_fin["n_tokens"] * (4 + 16) + c_fin["n_reads"] * 13 if w["sweep"] else 0)
+        d2h = d2h_graph + (c_fin["n_tokens"] * (4 + 8) + c_fin["n_reads"] * 13 if w["sweep"] else 0)
         e2e = {"value": n_windows / de, "unit": "gene-mers/s", "ms_per_step": de * 1e3, "steps": n_e2e,
                "timed_region": "SURVEY 8(d): host CSR arrays -> host graph arrays, H2D and D2H inside the clock",
                "h2d_bytes": int(h2d), "d2h_bytes": int(d2h),
                "region": "pinned host CSR (genes, offsets, gene positions as int32, read lengths) -> H2D -> the step -> D2H "
                          "of the final graph (node + edge arrays, node id and direction per window)"
-                         + (" and of the corrected calls with EVERY read's corrected positions as contiguous 64-bit arrays "
-                            "(Engine.corrected: what the drop-in's correct_reads mappings fetch)" if w["sweep"] else "")
+                         + (" and of the corrected calls with EVERY read's corrected positions as contiguous arrays, int32 "
+                            "because they fit (Engine.corrected(pos32=True): what the drop-in's correct_reads mappings "
+                            "fetch, amira_amd.io.DeviceCorrected)" if w["sweep"] else "")
                          + "; position upload overlapped with the first build on a second stream"}
         if w["sweep"]:
             dd, n_dd = timed_e2e(False)

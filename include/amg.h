@@ -227,6 +227,11 @@ int amg_get_corrected(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets,
 int amg_get_corrected32(amg_ctx* ctx, int32_t* tokens, int64_t* read_offsets, int32_t* orig_read,
                         uint8_t* changed, int64_t* pos_src, int32_t* new_start, int32_t* new_end,
                         int64_t* n_new);
+/* The positions of amg_get_corrected — every corrected read's, laid end to end like the genes — as 32-bit values, gathered
+ * on the device: read coordinates fit, and 64-bit position arrays are four fifths of the bytes a correction hands back
+ * (construct_graph.py:1123-1134 returns them per read).  gene_start / gene_end: room for n_out_tokens values each.  A
+ * position beyond 32 bits is an error, AMG_E_ARG (amg_get_corrected returns 64-bit positions). */
+int amg_get_corrected_positions32(amg_ctx* ctx, int32_t* gene_start, int32_t* gene_end);
 /* the corrected read set becomes the current read set (device resident; the next
  * amg_build runs on it) — the rebuild of graph_utils.py:147-150,165 */
 int amg_adopt_corrected(amg_ctx* ctx);
@@ -343,6 +348,9 @@ int amg_calls_write_json(const char* path, const int32_t* tokens, const int64_t*
 /* {"read": [[start, end], ...]} as json.dumps(gene_position_dict) writes it (result_utils.py:1260-1264, second file) */
 int amg_calls_write_positions_json(const char* path, const int64_t* gene_start, const int64_t* gene_end,
                                    const int64_t* read_offsets, int64_t n_reads, const char* read_ids);
+/* the same from 32-bit position arrays (what amg_get_corrected_positions32 hands back) */
+int amg_calls_write_positions_json32(const char* path, const int32_t* gene_start, const int32_t* gene_end,
+                                     const int64_t* read_offsets, int64_t n_reads, const char* read_ids);
 /* pre_processing.py:44-63 (process_pandora_json keeps the genes of interest the reads contain, in the order the reads
  * first show them): first_index[i] = index of the first token whose gene has rank wanted_ranks[i] (either strand),
  * -1 when no token does */

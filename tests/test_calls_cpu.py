@@ -39,6 +39,9 @@ def test_native_loader_equals_python_tokenizer(tmp_path, fixture):
     write_gene_positions(out_p, gs, ge, reads.read_offsets, reads.read_ids)
     # byte for byte what the reference's json.dumps(gene_position_dict) writes (result_utils.py:1260-1264)
     assert open(out_p).read() == json.dumps({r: [list(x) for x in pos[r]] for r in read_ids})
+    # ... and from 32-bit position arrays (what a correction's read-back hands over when the positions fit)
+    write_gene_positions(out_p, gs.astype(np.int32), ge.astype(np.int32), reads.read_offsets, reads.read_ids)
+    assert open(out_p).read() == json.dumps({r: [list(x) for x in pos[r]] for r in read_ids})
 
 
 def test_gene_syntax_and_escapes(tmp_path):

@@ -120,6 +120,25 @@ def test_low_coverage_components(eng):
         compare_engine_to_oracle(eng, oracle_arrays(g, vocab, read_ids, offs, 3), live_only=True)
 
 
+@pytest.mark.parametrize("shift", [0, 1 << 33])
+def test_corrected_positions_as_int32_when_they_fit(eng, shift):
+    """Engine.corrected(pos32=True) — what amira_amd.io.DeviceCorrected fetches — hands the positions over as int32
+    arrays gathered on the device, the same values as the 64-bit read-back; positions beyond 32 bits come as int64"""
+    from amira_amd import tokenize
+    reads, pos, fq = P.synth_inputs(17, 800, 40, 150, 0.05)
+    vocab, toks, offs, read_ids = tokenize(reads)
+    eng.set_reads(toks, offs, vocab.two_v)
+    gs, ge = flat_positions(read_ids, reads, pos)
+    eng.set_positions(gs + shift, ge + shift, np.asarray([len(fq[r]["sequence"]) for r in read_ids], dtype=np.int64) + shift)
+    eng.build(5)
+    eng.filter(3, 1)
+    n = eng.correct_reads()
+    wide, narrow = eng.corrected(*n, True), eng.corrected(*n, True, pos32=True)
+    assert narrow["gene_start"].dtype == (np.int64 if shift else np.int32)
+    for key in wide:
+        assert np.array_equal(wide[key], narrow[key]), key
+
+
 def test_third_graph_of_a_sweep_is_derived_from_the_second(eng, monkeypatch):
     """a correction that only drops and trims reads (what follows tip clipping) arms the rebuild that reuses the graph at
     hand: the sweeps of this module are compared with the oracle either way — here: the shortcut IS taken where it

@@ -100,7 +100,7 @@ def test_engine_leases_and_pool():
             self._leases, self._pool_when_free = weakref.WeakSet(), False
             self.fetched = 0
 
-        def corrected(self, n_reads, n_tokens, have_pos):
+        def corrected(self, n_reads, n_tokens, have_pos, pos32=False):
             self.fetched += 1
             z = np.zeros(n_tokens, np.int64)
             return {"tokens": z.astype(np.int32), "gene_start": z, "gene_end": z}
