@@ -392,9 +392,9 @@ class GeneMerGraph(BubblePopping):
     @classmethod
     def build_many(cls, readDict, kmerSizes, gene_positions=None, device=None):
         """[GeneMerGraph(readDict, k, gene_positions) for k in kmerSizes] — the seven graphs of choose_kmer_size
-        (graph_utils.py:258-296) — with the reads tokenised and uploaded once and the token stream read twice in
-        all instead of twice per k (amg_build_multi).  Graph i owns its own engine; the graphs after the first read
-        the first one's device arrays and keep it alive."""
+        (graph_utils.py:258-296) — with the reads tokenised and uploaded ONCE (amg_build_multi: every graph is built by
+        the ordinary build on an engine of its own; the graphs after the first read the first one's device arrays and
+        keep it alive)."""
         kmerSizes = list(kmerSizes)
         first = cls.__new__(cls)
         first._init_fields(readDict, kmerSizes[0], gene_positions, device)

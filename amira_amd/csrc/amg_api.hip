@@ -91,22 +91,17 @@ __global__ __launch_bounds__(256) void k_clear_many(ClearArgs a) {
 }
 
 // The mailbox: FETCH_MAX + 1 slots of {value, ticket} in pinned host memory; the host waits until every slot it asked
-// for carries the ticket of this read-back.  Default: value, system-scope fence, ticket with release semantics.
-// AMG_FETCH_FENCE=0: value and ticket in ONE 16-byte store and no fence — tried because the ~10 us of idle stream
-// after each of a sweep's 23 read-backs looked like the L2 write-back of that fence; measured, they are not (sweep
-// 7.6 -> 7.55 ms, merged path unchanged): the idle time is the host's round trip.  Kept as an A/B switch.
-__global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long long ticket, int fence) {
+// for carries the ticket of this read-back: value, system-scope fence, ticket with release semantics.  (Value and
+// ticket in ONE 16-byte store without the fence was tried — the ~10 us of idle stream after each read-back looked like
+// the L2 write-back of that fence; measured, they are the host's round trip — and removed.)
+__global__ void k_fetch(FetchList l, unsigned long long* mail, unsigned long long ticket) {
   const int i = threadIdx.x;
   const int n = l.n > 0 ? l.n : 1;  // an empty list still delivers its ticket (stream_wait)
   if (i < n) {
     const unsigned long long v = i < l.n ? *l.p[i] : 0ull;
-    if (fence) {
-      mail[2 * i] = v;
-      __threadfence_system();
-      __hip_atomic_store(mail + 2 * i + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      *reinterpret_cast<ulonglong2*>(mail + 2 * i) = make_ulonglong2(v, ticket);
-    }
+    mail[2 * i] = v;
+    __threadfence_system();
+    __hip_atomic_store(mail + 2 * i + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -126,9 +121,8 @@ int fetch(amg_ctx* c, const FetchList& l, unsigned long long* out, const ClearLi
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->mail_dev), c->mail_host, 0));
     for (int i = 0; i < 2 * (FETCH_MAX + 1); ++i) c->mail_host[i] = 0;
   }
-  static const int fence = getenv("AMG_FETCH_FENCE") ? atoi(getenv("AMG_FETCH_FENCE")) : 1;
   const unsigned long long ticket = ++c->mail_ticket;
-  hipLaunchKernelGGL(k_fetch, dim3(1), dim3(FETCH_MAX <= 64 ? 64 : 128), 0, c->stream, l, c->mail_dev, ticket, fence);
+  hipLaunchKernelGGL(k_fetch, dim3(1), dim3(FETCH_MAX <= 64 ? 64 : 128), 0, c->stream, l, c->mail_dev, ticket);
   if (filler) AMGCHK(clear_many(c, *filler));
   const int n = l.n > 0 ? l.n : 1;
   volatile unsigned long long* m = c->mail_host;
@@ -283,6 +277,7 @@ extern "C" int amg_set_reads(amg_ctx* c, const int32_t* tokens, const int64_t* r
   c->have_pos = c->have_read_len = false;
   c->built = false;
   c->derive_ready = c->dist_candidate = false;
+  c->hint_bound = 0;
   c->have_corrected = false;
   c->match_valid = false;
   c->node_hint = 0;

@@ -644,10 +644,6 @@ int count_ids(amg_ctx* c, int* ids, long long n, const Slot* gather_tab, long lo
   // block at least twice that many ids to count (small inputs: fewer blocks, not a shorter sweep)
   long long want_blocks = (n + 2 * HOT_IDS - 1) / (2 * HOT_IDS);
   unsigned int blocks = (unsigned int)(want_blocks < 1 ? 1 : (want_blocks < COUNT_MAX_BLOCKS ? want_blocks : COUNT_MAX_BLOCKS));
-  if (const char* e = getenv("AMG_COUNT_BLOCKS")) {  // A/B switch
-    const unsigned int b = (unsigned int)atoi(e);
-    if (b >= 1 && b < blocks) blocks = b;
-  }
   for (long long r = 0; r < ranges; ++r) {
     const long long lo = r * HOT_IDS;
     const int last = (r == ranges - 1) ? 1 : 0;
@@ -1176,6 +1172,10 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   c->k = k;
   c->dist_mode = false;
   c->comp_from_claims = false;
+  if (c->hint_bound > 0) {  // reads taken over from another ctx's correction: its bound holds for a graph at ITS gene-mer size
+    if (c->hint_bound_k == k) c->node_hint = c->hint_bound > 256 ? c->hint_bound : 256;
+    c->hint_bound = 0;
+  }
   {
     // test hook: the first AMG_TEST_WEAK_FP attempts use a 12-bit fingerprint, which is
     // certain to collide; the exact verification must catch it and the retry must succeed
@@ -1192,7 +1192,7 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   for (int attempt = 0; attempt < 12; ++attempt) {
     int which = 0;
     int r;
-    if (exact && min_node_cov > 0 && !getenv("AMG_NO_FUSED_FILTER")) {
+    if (exact && min_node_cov > 0) {
       r = bx_nodes_filtered(c, k, min_node_cov, &which);
       if (r == AMG_OK) r = bx_edges(c, &which, min_edge_cov);
       *fused = true;
@@ -1229,205 +1229,14 @@ static int build_impl(amg_ctx* c, int32_t k, uint32_t min_node_cov, uint32_t min
   return amg_fail(AMG_E_OVERFLOW, "build did not converge after 12 attempts");
 }
 
-// ------------------------------------------------------------------ several k in one pass over the tokens
+// ------------------------------------------------------------------ several k over one read set
 // choose_kmer_size (graph_utils.py:258-296) builds the graph of the SAME reads for k = 3, 5, ..., 15.  amg_build_multi
-// makes those graphs with TWO reads of the token stream instead of two per k: a tile of tokens is staged in LDS once
-// and the node pass of every k runs from it (each k into its own table), and likewise the edge pass of every k (whose
-// exact check of the fingerprints needs the tokens again).  Everything per graph — ranking, counting, emission — is
-// the single-graph code on that graph's own ctx.  Fingerprint keys throughout (k up to 16 does not fit the exact slots).
+// puts the reads on the device ONCE — graph i's ctx borrows the first ctx's token arrays — and builds every graph with
+// the ordinary amg_build on its own ctx, one after the other on the first ctx's stream.  (Rounds 2-5 also staged every
+// tile of tokens once for the node passes of all k and once for their edge passes, k_node_upsert_multi / k_edges_multi:
+// measured on cfg 3, `multi_k` in bench.py, the seven graphs took 28.2 ms that way and 28.0 ms as seven builds — the
+// table work of a pass, not the reading of the tokens, is what a build costs — so those kernels are gone.)
 #define MULTI_MAX 8
-struct MultiNodeJob {
-  Slot* tab;
-  unsigned long long mask, seed, fp_mask;
-  int* tok_slot;
-  signed char* tok_dir;
-  unsigned long long* status;
-  int k;
-};
-struct MultiNodeJobs {
-  MultiNodeJob j[MULTI_MAX];
-  int n, kmax;
-};
-
-// tokens t0 .. t0 + TILE + kmax - 1 and the tile's slice of the read-end bitmap into LDS (one read of the stream for
-// all jobs); a token outside [0, two_v) is reported to every job
-template <class Jobs>
-__device__ __forceinline__ void multi_stage(const int* __restrict__ tokens, const unsigned int* __restrict__ bnd_bits,
-                                            long long n_tokens, int kmax, long long t0, int two_v, int* s_tok,
-                                            unsigned int* s_bits, const Jobs& jobs) {
-  bool bad = false;
-  for (int i = threadIdx.x; i < TILE + kmax; i += TILE_THREADS) {
-    const long long t = t0 + i;
-    const int v = t < n_tokens ? __builtin_nontemporal_load(tokens + t) : 0;
-    bad = bad || (unsigned int)v >= (unsigned int)two_v;
-    s_tok[i] = v;
-  }
-  if (bad)
-    for (int q = 0; q < jobs.n; ++q) jobs.j[q].status[ST_BADINPUT] = 2;
-  if (threadIdx.x < TILE_BIT_WORDS) s_bits[threadIdx.x] = bnd_bits[(t0 >> 5) + threadIdx.x];
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(TILE_THREADS) void k_node_upsert_multi(const int* __restrict__ tokens,
-                                                                     const unsigned int* __restrict__ bnd_bits,
-                                                                     long long n_tokens, int two_v, unsigned int probe_limit,
-                                                                     MultiNodeJobs jobs) {
-  __shared__ int s_tok[TILE + AMG_MAX_K];
-  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
-  const long long t0 = (long long)blockIdx.x * TILE;
-  multi_stage(tokens, bnd_bits, n_tokens, jobs.kmax, t0, two_v, s_tok, s_bits, jobs);
-  const int flip = two_v - 1;
-  for (int q = 0; q < jobs.n; ++q) {
-    const MultiNodeJob& J = jobs.j[q];
-    const int k = J.k;
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it) {
-      const int i = threadIdx.x + it * TILE_THREADS;
-      const long long t = t0 + i;
-      if (t >= n_tokens) continue;
-      bool inside, is_last;
-      tile_window(s_bits, i, k, inside, is_last);
-      int out_slot = -1;
-      signed char out_dir = 0;
-      if ((t + k <= n_tokens) && inside) {
-        LdsView w{s_tok + i};
-        const int dir = canon_dir(w, k, flip);
-        if (dir == 0) {
-          J.status[ST_PALINDROME] = 1;  // benign race: every writer stores 1
-        } else {
-          unsigned long long fp = canon_fingerprint(w, k, flip, dir, J.seed) & J.fp_mask;
-          fp = fp ? fp : 1ull;
-          const unsigned long long first = ((unsigned long long)t << 1) | (dir < 0 ? 1ull : 0ull);
-          const long long slot = table_upsert(J.tab, J.mask, fp, fp >> 20, first, probe_limit, false, J.status + ST_OVERFLOW);
-          if (slot < 0) {
-            J.status[ST_OVERFLOW] = 1;
-          } else {
-            out_slot = (int)((unsigned int)slot | (is_last ? AMG_LAST_FLAG : 0u));
-            out_dir = (signed char)dir;
-          }
-        }
-      }
-      J.tok_slot[t] = out_slot;
-      J.tok_dir[t] = out_dir;
-    }
-  }
-}
-
-struct MultiEdgeJob {
-  const Slot* node_tab;
-  const int* node_tokens;
-  const int* tok_slot;
-  const signed char* tok_dir;
-  int* tok_node;
-  Slot* edge_tab;
-  unsigned long long edge_mask;
-  unsigned long long* status;
-  int* tok_pair;
-  int k, packed;
-};
-struct MultiEdgeJobs {
-  MultiEdgeJob j[MULTI_MAX];
-  int n, kmax;
-  unsigned long long* status_of(int q) const { return j[q].status; }
-};
-
-// k_edges for several k from one staged tile of tokens (the exact verification reads the tile in LDS)
-__global__ __launch_bounds__(TILE_THREADS) void k_edges_multi(const int* __restrict__ tokens,
-                                                               const unsigned int* __restrict__ bnd_bits,
-                                                               long long n_tokens, int two_v, unsigned int probe_limit,
-                                                               MultiEdgeJobs jobs) {
-  __shared__ int s_tok[TILE + AMG_MAX_K];
-  __shared__ unsigned int s_bits[TILE_BIT_WORDS];
-  __shared__ int s_id[TILE + 1];
-  __shared__ int s_raw[TILE + 1];
-  __shared__ signed char s_dir[TILE + 1];
-  const long long t0 = (long long)blockIdx.x * TILE;
-  multi_stage(tokens, bnd_bits, n_tokens, jobs.kmax, t0, two_v, s_tok, s_bits, jobs);
-  const int flip = two_v - 1;
-  for (int q = 0; q < jobs.n; ++q) {
-    const MultiEdgeJob& J = jobs.j[q];
-    const int k = J.k;
-    __syncthreads();  // the previous job is done with s_id / s_raw / s_dir
-    for (int i = threadIdx.x; i < TILE + 1; i += TILE_THREADS) {
-      const long long t = t0 + i;
-      int raw = -1;
-      signed char d = 0;
-      if (t < n_tokens) {
-        raw = J.tok_slot[t];
-        d = J.tok_dir[t];
-      }
-      int id = -1;
-      if (raw != -1) {
-        const int* nt = nullptr;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (J.packed) {
-          const uint4* rec = reinterpret_cast<const uint4*>(J.node_tab + ((unsigned int)raw & ~AMG_LAST_FLAG));
-          lo = rec[0];
-          hi = rec[1];
-          id = (int)hi.y;
-        } else {
-          id = J.node_tab[(unsigned int)raw & ~AMG_LAST_FLAG].id;
-          nt = J.node_tokens + (long long)id * k;
-        }
-        if (i < TILE && id >= 0) {  // exact check: the window's canonical tuple must equal the node's
-          bool same = true;
-          for (int x = 0; x < k; ++x) {
-            const int c = d > 0 ? s_tok[i + x] : flip - s_tok[i + k - 1 - x];
-            same = same && (J.packed ? (unsigned int)c == packed_tok(lo, hi, x) : c == nt[x]);
-          }
-          if (!same) J.status[ST_COLLISION] = 1;
-        }
-      }
-      s_id[i] = id;
-      s_raw[i] = raw;
-      s_dir[i] = d;
-      if (i < TILE && t < n_tokens) J.tok_node[t] = id;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < TILE_ITEMS; ++it) {
-      const int i = threadIdx.x + it * TILE_THREADS;
-      if (t0 + i >= n_tokens) continue;
-      const int raw = s_raw[i];
-      int out = -1;
-      if (raw != -1 && !((unsigned int)raw & AMG_LAST_FLAG) && s_id[i] >= 0 && s_id[i + 1] >= 0) {
-        const unsigned int a = (unsigned int)s_id[i], b = (unsigned int)s_id[i + 1];
-        const int dA = s_dir[i], dB = s_dir[i + 1];
-        const unsigned int lo = a < b ? a : b, hi = a < b ? b : a;
-        const unsigned long long sign = (dA * dB < 0) ? 1ull : 0ull;
-        const unsigned long long key = (sign << 63) | ((unsigned long long)lo << 32) | (unsigned long long)(hi + 1u);
-        const unsigned long long orient = (a == lo ? 1ull : 0ull) | (dA > 0 ? 2ull : 0ull) | (dB > 0 ? 4ull : 0ull);
-        const unsigned long long first = ((unsigned long long)(t0 + i) << 3) | orient;
-        const long long slot = table_upsert(J.edge_tab, J.edge_mask, key, mix64(key), first, probe_limit, false);
-        if (slot < 0) J.status[ST_OVERFLOW] = 2;
-        out = (int)slot;
-      }
-      J.tok_pair[t0 + i] = out;
-    }
-  }
-}
-
-// state of a ctx at the start of a build (what build_impl sets)
-static void multi_begin(amg_ctx* c, int k) {
-  stages_reset(c);
-  c->built = false;
-  c->derive_ready = false;
-  c->derived = false;
-  c->have_corrected = false;
-  c->match_valid = false;
-  c->k = k;
-  c->retries = 0;
-  c->tok_base = 0;
-  c->tok_total = c->n_tokens;
-  c->dist_mode = false;
-  c->comp_from_claims = false;
-  c->weak_fp_builds = 0;
-  c->count_inline = false;
-  c->exact_keys = false;
-  c->dist_x = false;
-  bs_size_tables(c);
-}
-
 extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t n) {
   if (!ctxs || !ks || n < 1 || n > MULTI_MAX) return amg_fail(AMG_E_ARG, "amg_build_multi: 1 .. %d graphs", MULTI_MAX);
   amg_ctx* c0 = ctxs[0];
@@ -1458,6 +1267,7 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
     c->have_pos = c->have_read_len = false;
     c->node_hint = 0;
     c->cnt_hint_reset = true;
+    c->derive_ready = c->dist_candidate = false;
     c->stream = c0->stream;
   }
   struct Restore {
@@ -1468,132 +1278,7 @@ extern "C" int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t 
       for (int i = 0; i < n; ++i) ctxs[i]->stream = own[i];
     }
   } restore{ctxs, own, n};
-  hipStream_t st = c0->stream;
-  const long long n_tiles = (T + TILE - 1) / TILE;
-  int kmax = 1;
-  for (int i = 0; i < n; ++i) kmax = ks[i] > kmax ? ks[i] : kmax;
-  std::vector<char> alone(n, 0);  // graphs that have to be built by themselves (a table overflowed, a fingerprint collided)
-  unsigned long long hs[ST_WORDS];
-  // The gene-mer sizes whose tuple fits the exact-key slots (k = 3 always, k = 5 up to 2^18 genes) are built by
-  // themselves with the exact-key kernels: measured on cfg 3 (bench.py `multi_k`), the seven graphs k = 3 .. 15 take
-  // 58 ms through the shared fingerprint passes, 54 ms as seven plain builds and 52 ms this way — the table work of a
-  // pass, not the reading of the tokens, is what a build costs.  AMG_MULTI_ALL=1: everything through the shared passes.
-  {
-    const char* all = getenv("AMG_MULTI_ALL");
-    if (!(all && atoi(all) != 0))
-      for (int i = 0; i < n; ++i) {
-        ctxs[i]->weak_fp_builds = 0;
-        ctxs[i]->dist_mode = false;
-        ctxs[i]->count_inline = false;
-        if (bx_applicable(ctxs[i], ks[i])) alone[i] = 1;
-      }
-  }
-  std::vector<int> shared;  // the graphs of the shared passes
-  for (int i = 0; i < n; ++i)
-    if (!alone[i]) shared.push_back(i);
-
-  // ---- node pass of every k from one staged tile
-  MultiNodeJobs nj;
-  nj.n = (int)shared.size();
-  nj.kmax = kmax;
-  for (int q = 0; q < (int)shared.size(); ++q) {
-    const int i = shared[q];
-    amg_ctx* c = ctxs[i];
-    multi_begin(c, ks[i]);
-    HIPCHK(hipMemsetAsync(c->status.p, 0, ST_WORDS * sizeof(unsigned long long), st));
-    AMGCHK(bs_read_stats(c, ks[i]));
-    AMGCHK(c->tok_slot.ensure((size_t)(T + 1) * sizeof(int)));
-    AMGCHK(c->tok_node.ensure((size_t)(T + 1) * sizeof(int)));
-    AMGCHK(c->tok_dir.ensure((size_t)(T + 1)));
-    AMGCHK(c->node_tab.ensure((size_t)c->node_slots * sizeof(Slot)));
-    HIPCHK(hipMemsetAsync(c->node_tab.p, 0, (size_t)c->node_slots * sizeof(Slot), st));
-    nj.j[q] = MultiNodeJob{c->node_tab.as<Slot>(), (unsigned long long)(c->node_slots - 1), c->seed, ~0ull,
-                           c->tok_slot.as<int>(), c->tok_dir.as<signed char>(), c->status.as<unsigned long long>(), ks[i]};
-  }
-  // (the read-end bitmap the shared passes stage belongs to the first graph OF THE SHARED PASSES)
-  amg_ctx* cs = shared.empty() ? c0 : ctxs[shared[0]];
-  stage_begin(c0, "node_upsert");
-  if (n_tiles > 0 && nj.n > 0)
-    hipLaunchKernelGGL(k_node_upsert_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
-                       cs->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, nj);
-  stage_end(c0);
-  for (int i : shared) {
-    amg_ctx* c = ctxs[i];
-    size_t max_nodes = (size_t)((long long)c->node_slots < T ? c->node_slots : T) + 1;
-    AMGCHK(c->s1.ensure(max_nodes * sizeof(unsigned long long)));
-    AMGCHK(c->s2.ensure(max_nodes * sizeof(unsigned long long)));
-    AMGCHK(c->s3.ensure(max_nodes * sizeof(unsigned int)));
-    AMGCHK(c->s4.ensure(max_nodes * sizeof(unsigned int)));
-    hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->node_slots, 2048)), dim3(256), 0, st, c->node_tab.as<Slot>(),
-                       (unsigned long long)c->node_slots, c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
-                       c->status.as<unsigned long long>() + ST_COMPACT_A);
-    AMGCHK(read_status(c, hs));
-    if (hs[ST_BADINPUT])
-      return amg_fail(AMG_E_ARG, hs[ST_BADINPUT] == 1 ? "read_offsets must start at 0, never decrease and end at the token count"
-                                                      : "a token lies outside [0, two_v)");
-    if (hs[ST_PALINDROME])
-      return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
-    if (hs[ST_OVERFLOW]) {
-      alone[i] = 1;
-      continue;
-    }
-    c->n_windows = (int64_t)hs[ST_N_WINDOWS];
-    c->n_short = (int64_t)hs[ST_N_SHORT];
-    c->n_local_nodes = (int64_t)hs[ST_COMPACT_A];
-    AMGCHK(bs_nodes_rank_local(c));
-  }
-
-  // ---- edge pass of every k from one staged tile
-  MultiEdgeJobs ej;
-  ej.n = 0;
-  ej.kmax = kmax;
-  std::vector<int> in_pass;
-  for (int i : shared) {
-    if (alone[i]) continue;
-    amg_ctx* c = ctxs[i];
-    const long long D = c->n_nodes;
-    if (c->edge_slots < (int64_t)slots_for((uint64_t)D)) c->edge_slots = (int64_t)slots_for((uint64_t)D);
-    AMGCHK(c->tok_pair.ensure((size_t)(T + 4) * sizeof(int)));
-    AMGCHK(c->edge_tab.ensure((size_t)c->edge_slots * sizeof(Slot)));
-    HIPCHK(hipMemsetAsync(c->edge_tab.p, 0, (size_t)c->edge_slots * sizeof(Slot), st));
-    HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_OVERFLOW, 0, sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(c->status.as<unsigned long long>() + ST_COMPACT_B, 0, sizeof(unsigned long long), st));
-    ej.j[ej.n++] = MultiEdgeJob{c->node_tab.as<Slot>(), c->node_tokens.as<int>(), c->tok_slot.as<int>(),
-                                c->tok_dir.as<signed char>(), c->tok_node.as<int>(), c->edge_tab.as<Slot>(),
-                                (unsigned long long)(c->edge_slots - 1), c->status.as<unsigned long long>(),
-                                c->tok_pair.as<int>(), ks[i], c->packed_nodes ? 1 : 0};
-    in_pass.push_back(i);
-  }
-  stage_begin(c0, "edge_upsert");
-  if (n_tiles > 0 && ej.n > 0)
-    hipLaunchKernelGGL(k_edges_multi, dim3((unsigned)n_tiles), dim3(TILE_THREADS), 0, st, c0->tokens.as<int>(),
-                       cs->bnd_bits.as<unsigned int>(), T, c0->two_v, kProbeLimit, ej);
-  stage_end(c0);
-  for (int i : in_pass) {
-    amg_ctx* c = ctxs[i];
-    size_t max_pairs = (size_t)((long long)c->edge_slots < T ? c->edge_slots : T) + 1;
-    AMGCHK(c->s1.ensure(max_pairs * sizeof(unsigned long long)));
-    AMGCHK(c->s2.ensure(max_pairs * sizeof(unsigned long long)));
-    AMGCHK(c->s3.ensure(max_pairs * sizeof(unsigned int)));
-    AMGCHK(c->s4.ensure(max_pairs * sizeof(unsigned int)));
-    hipLaunchKernelGGL(k_compact_slots, dim3(blocks_for(c->edge_slots, 2048)), dim3(256), 0, st, c->edge_tab.as<Slot>(),
-                       (unsigned long long)c->edge_slots, c->s1.as<unsigned long long>(), c->s3.as<unsigned int>(),
-                       c->status.as<unsigned long long>() + ST_COMPACT_B);
-    AMGCHK(read_status(c, hs));
-    if (hs[ST_COLLISION] || hs[ST_OVERFLOW]) {
-      alone[i] = 1;
-      continue;
-    }
-    c->n_local_pairs = (int64_t)hs[ST_COMPACT_B];
-    AMGCHK(count_ids(c, c->tok_node.as<int>(), T, nullptr, c->n_nodes, c->node_cov.as<unsigned int>(), 0));
-    AMGCHK(bs_pairs_from_local(c));
-    AMGCHK(bs_finish_from_pairs(c));
-    c->built = true;
-    c->node_hint = c->n_nodes > 256 ? c->n_nodes : 256;
-  }
-  // ---- the graphs the shared passes could not finish: by themselves, with amg_build's own retries
-  for (int i = 0; i < n; ++i)
-    if (alone[i]) AMGCHK(amg_build(ctxs[i], ks[i]));
-  HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) AMGCHK(amg_build(ctxs[i], ks[i]));
+  HIPCHK(hipStreamSynchronize(c0->stream));
   return AMG_OK;
 }

@@ -1056,6 +1056,10 @@ int bx_nodes_upsert(amg_ctx* c, int k, int* which, bool sharded, bool rank_follo
   if (hs[ST_PALINDROME])
     return amg_fail(AMG_E_PALINDROME, "Gene-mer and reverse complement gene-mer are identical");
   if (hs[ST_MISC]) return amg_fail(AMG_E_HIP, "node pass: a claim id was never published");
+  if (hs[ST_COLLISION]) {  // fingerprint keys: k_x_verify_fp found two gene-mers under one key — nothing is built on this table
+    *which = 3;
+    return AMG_E_OVERFLOW;
+  }
   if (hs[ST_OVERFLOW]) {
     *which = 1;
     return AMG_E_OVERFLOW;
@@ -1205,9 +1209,6 @@ int bx_edges_upsert(amg_ctx* c, int* which, bool lone, bool sharded, bool rank_f
   // need one — sized for a quarter of the nodes; an input that needs more overflows once and is rebuilt 4x larger
   const int64_t want_slots = (int64_t)slots_for((uint64_t)(home_n ? D / 4 + 1 : D));
   if (c->edge_slots < want_slots) c->edge_slots = want_slots;
-  if (const char* e = getenv("AMG_EDGE_SLOTS_LOG2")) {  // A/B switch (first builds only: D large)
-    if (D > (1 << 20)) c->edge_slots = 1ll << atoi(e);
-  }
   const size_t tab_slots = (size_t)c->edge_slots + (size_t)home_n;
   if (!home_n) lone = false;
   // claims: at most one per table slot, plus (lone) two classes per single node, never more than the windows

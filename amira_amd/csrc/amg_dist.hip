@@ -498,7 +498,7 @@ static int nodes_local_x(amg_ctx* c, int k, int world, unsigned long long key_ma
   hipStream_t st = c->stream;
   for (int attempt = 0;; ++attempt) {
     int which = 0;
-    int r = bx_nodes_upsert(c, k, &which, !getenv("AMG_DIST_ONE_COUNTER"), false);  // claims from the shard counters (A/B switch)
+    int r = bx_nodes_upsert(c, k, &which, true, false);  // (claims from the shard counters)
     if (r == AMG_OK) break;
     if (r != AMG_E_OVERFLOW || which != 1 || attempt >= 8) return r;
     ++c->retries;
@@ -530,7 +530,7 @@ static int edges_local_x(amg_ctx* c, int world) {
   hipStream_t st = c->stream;
   for (int attempt = 0;; ++attempt) {
     int which = 0;
-    int r = bx_edges_upsert(c, &which, false, !getenv("AMG_DIST_ONE_COUNTER"), false);
+    int r = bx_edges_upsert(c, &which, false, true, false);
     if (r == AMG_OK) break;
     if (r == AMG_E_OVERFLOW && which == 3)
       return amg_fail(AMG_E_COLLISION, "two gene-mers share a merge key: the merged build is repeated with the next seed");

@@ -158,6 +158,8 @@ struct amg_ctx {
   int64_t node_hint = 0;  // distinct-node estimate carried between builds
   int64_t c_node_bound = 0;  // amg_correct_reads: upper bound for the nodes of the graph the corrected reads make (at gene-mer size c_node_bound_k)
   int c_node_bound_k = 0;
+  int64_t hint_bound = 0;    // amg_set_reads_from_corrected: the source's bound for THESE reads, applied by a build at hint_bound_k
+  int hint_bound_k = 0;
   bool filtered_build = false;  // bx_nodes_upsert is running for amg_build_filtered (head launch: see there)
   int64_t n_local_nodes = 0, n_local_pairs = 0;  // before a multi-GPU merge
   int64_t tok_base = 0;   // global index of this shard's first token (0 on a single GPU)

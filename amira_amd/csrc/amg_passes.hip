@@ -3176,7 +3176,10 @@ extern "C" int amg_set_reads_from_corrected(amg_ctx* dst, amg_ctx* src) {
   dst->derive_ready = false;
   dst->have_corrected = false;
   dst->match_valid = false;
-  dst->node_hint = src->c_node_bound > 256 ? src->c_node_bound : 0;  // (amg_adopt_corrected: the same bound)
+  // (amg_adopt_corrected: the same bound — for a build at the gene-mer size it was made for; dst has no graph of its own)
+  dst->node_hint = 0;
+  dst->hint_bound = src->c_node_bound;
+  dst->hint_bound_k = src->c_node_bound_k;
   dst->cnt_hint_reset = true;
   return AMG_OK;
 }

@@ -78,8 +78,8 @@ class Engine:
 
     @staticmethod
     def build_multi(engines, ks):
-        """the graphs of engines[0]'s reads for every k of ks, graph i on engines[i], with two passes over the tokens in
-        all (amg_build_multi); the other engines borrow engines[0]'s read arrays: keep it alive and unchanged"""
+        """the graphs of engines[0]'s reads for every k of ks, graph i on engines[i] (amg_build_multi: the reads are on
+        the device once); the other engines borrow engines[0]'s read arrays: keep it alive and unchanged"""
         n = len(engines)
         assert n == len(ks) and n >= 1
         handles = (C.c_void_p * n)(*[e._h for e in engines])

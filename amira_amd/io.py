@@ -337,7 +337,9 @@ class _ArrayPool:
     fresh heap on every call, and a gigabyte of fresh heap is a quarter of a million page faults.  An array the pool
     handed out is given out again once nobody else refers to it any more (its reference count is back to the pool's
     own: every view, slice or mapping built on it holds a reference to it, so an array somebody can still see is never
-    reused); otherwise a new one is made.  `clear()` drops the pool's arrays."""
+    reused); otherwise a new one is made.  The test is CPython's reference count: a consumer that keeps only a raw
+    POINTER into an array (ptr(a), a.ctypes.data) beyond the call it made it for must keep the array itself referenced
+    too — everything in this package does.  `clear()` drops the pool's arrays (pre_processing.trim_buffers calls it)."""
 
     def __init__(self, keep=6):
         self._held, self._keep = [], keep

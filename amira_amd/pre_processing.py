@@ -65,7 +65,10 @@ def process_pandora_json(pandoraJSON, genesOfInterest, gene_positions):
 
 
 def trim_buffers():
-    """give the loader's and the writers' cached work buffers back to the system (amg_calls_trim)"""
+    """give the loader's and the writers' cached work buffers back to the system (amg_calls_trim), and the arrays the
+    Python-side loader keeps for its next call (amira_amd.io: up to six token / position arrays of the last loads)"""
+    from . import io
+    io._pool.clear()
     n = C.c_int64(0)
     check(_ffi.lib.amg_calls_trim(C.byref(n)))
     return n.value

@@ -738,9 +738,9 @@ def run_bubbles(local_rank, with_cpu=True):
 
 def run_multi_k(w, vocab, toks, offs, local_rank):
     """SURVEY 8 row f3 (graph_utils.py:258-296 choose_kmer_size): the seven graphs k = 3, 5, ..., 15 of the workload's
-    reads as ONE amg_build_multi call (two passes over the tokens for all seven, fingerprint keys) against seven
-    amg_build calls (two passes each; exact keys where the tuple fits 94 bits), and the hybrid — plain builds for the
-    k that take exact keys, one multi call for the rest."""
+    reads — ONE amg_build_multi call (the reads on the device once, every graph by the ordinary build on an engine of
+    its own) against seven amg_build calls on engines that each hold a copy of the reads; which key scheme each k took.
+    (The shared passes of rounds 2-5, one staged tile for the node passes of all k, bought nothing and are gone.)"""
     from amira_amd import Engine
     ks = list(range(3, 16, 2))
     engines = [Engine(local_rank) for _ in ks]
@@ -764,25 +764,17 @@ def run_multi_k(w, vocab, toks, offs, local_rank):
 
         many = timed(lambda: Engine.build_multi(engines, ks))
         nodes_multi = [e.counts()["n_nodes"] for e in engines]
+        for e in engines:   # (build_multi left the others borrowing the first one's reads)
+            e.set_reads(toks, offs, vocab.two_v)
         singles = [timed(lambda i=i: engines[i].build(ks[i])) for i in range(len(ks))]
         nodes_single = [e.counts()["n_nodes"] for e in engines]
-        exact = [i for i in range(len(ks)) if engines[i].counts()["exact_keys"]]
-        rest = [i for i in range(len(ks)) if i not in exact]
-
-        def hybrid():
-            for i in exact:
-                engines[i].build(ks[i])
-            if rest:
-                Engine.build_multi([engines[i] for i in rest], [ks[i] for i in rest])
-
-        hyb = timed(hybrid)
-        T = len(toks)
+        schemes = [engines[i].counts()["exact_keys"] for i in range(len(ks))]
         return {"ks": ks, "build_many_ms": round(many, 3), "seven_builds_ms": round(sum(singles), 3),
-                "single_build_ms": [round(x, 3) for x in singles], "hybrid_ms": round(hyb, 3),
-                "exact_key_ks": [ks[i] for i in exact], "nodes": nodes_single,
-                "same_graph_sizes": nodes_single == nodes_multi,
-                "token_bytes_read": {"build_many": 2 * 4 * T, "seven_builds": 14 * 4 * T,
-                                     "hybrid": (2 * len(exact) + (2 if rest else 0)) * 4 * T}}
+                "single_build_ms": [round(x, 3) for x in singles],
+                "key_scheme": {"exact tuple": [k_ for k_, s_ in zip(ks, schemes) if s_ == 1],
+                               "94-bit fingerprint, verified": [k_ for k_, s_ in zip(ks, schemes) if s_ == 2],
+                               "32-byte slots": [k_ for k_, s_ in zip(ks, schemes) if s_ == 0]},
+                "nodes": nodes_single, "same_graph_sizes": nodes_single == nodes_multi}
     finally:
         for e in engines:
             e.close()

@@ -143,11 +143,10 @@ int amg_build(amg_ctx* ctx, int32_t k);
  * with alive = 0). */
 int amg_build_filtered(amg_ctx* ctx, int32_t k, uint32_t min_node_cov, uint32_t min_edge_cov);
 /* amg_build of the SAME reads for n (<= 8) gene-mer sizes, graph i on ctxs[i] with k = ks[i] — choose_kmer_size's
- * builds for k = 3, 5, ..., 15 (graph_utils.py:258-296) — with two reads of the token stream in all (one staged tile
- * serves the node pass of every k, another the edge pass of every k) instead of two per k.  The reads are those of
- * ctxs[0] (amg_set_reads there first); the other ctxs BORROW its device arrays: they stay valid until ctxs[0]'s reads
- * change or it is destroyed.  Positions are not shared (set them per ctx if a correction is to follow).  One device;
- * the call is synchronous.  Each graph is exactly what amg_build(ctxs[i], ks[i]) builds. */
+ * builds for k = 3, 5, ..., 15 (graph_utils.py:258-296).  The reads are those of ctxs[0] (amg_set_reads there first) and
+ * are on the device once: the other ctxs BORROW its device arrays, which stay valid until ctxs[0]'s reads change or it
+ * is destroyed.  Positions are not shared (set them per ctx if a correction is to follow).  One device; the call is
+ * synchronous.  Each graph is exactly what amg_build(ctxs[i], ks[i]) builds — and is built by it. */
 int amg_build_multi(amg_ctx* const* ctxs, const int32_t* ks, int32_t n);
 int amg_counts(amg_ctx* ctx, amg_counts_t* out);
 /* amg_build leaves component ids (assign_component_ids, construct_graph.py:920-927) and the per-node
