@@ -62,8 +62,19 @@ def build_filtered_graph(read_dict, kmer_size, gene_positions, min_node_coverage
     return GeneMerGraph(read_dict, kmer_size, gene_positions, _filter=(min_node_coverage, min_edge_coverage))
 
 
+_CORES_NOTE = []
+
+
 def build_multiprocessed_graph(annotatedReads, geneMer_size, cores, gene_positions=None):
-    """single-graph result (what cores=1 gives in the reference), built on the GPU."""
+    """graph_utils.py:105-124.  The reference shards the reads over `cores` host processes and merges their sub-graphs;
+    its own pipeline always passes cores = 1 (CHANGELOG: multi-process builds were slower), and that single-graph result
+    is what comes back here, built on ONE GPU whatever `cores` says — said once on stderr when cores > 1.  The read-
+    sharded build across GPUs is a collective of its own, one process per GPU with the shard's reads as token arrays:
+    amira_amd.dist.dist_build / amg_dist_merge."""
+    if cores is not None and int(cores) > 1 and not _CORES_NOTE:
+        _CORES_NOTE.append(True)
+        sys.stderr.write(f"\nAmira (amira_amd): build_multiprocessed_graph builds on one GPU; cores={cores} is not used "
+                         "(read-sharded builds over several GPUs: amira_amd.dist.dist_build)\n")
     return build_graph(_own(annotatedReads), geneMer_size, _own(gene_positions))
 
 

@@ -917,13 +917,14 @@ def main():
     torch.cuda.synchronize()
     eng = Engine(local_rank)
     n_windows = N * (L - k + 1)
-    stage_ms, info = {}, {}
+    stage_ms, stage_each, info = {}, {}, {}
 
     def tally():
         for name, ms in eng.timings():  # HIP events recorded on the engine's own stream
             stage_ms.setdefault(name, [0.0, 0])
             stage_ms[name][0] += ms
             stage_ms[name][1] += 1
+            stage_each.setdefault(name, []).append(ms)
 
     def sweep_after_first_build(record, readback=None, moved=None, full=True):
         if not (merge or args.fused_filter):
@@ -1233,6 +1234,11 @@ def main():
                          "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": cands[dom],
                          "avg_launch_ms": stage_avg[dom], "launches_per_step": stage_ms[dom][1],
+                         # every launch of the step on its own (a cleaning sweep: the first build's pass over uncorrected
+                         # reads creates 5.4 M keys, the rebuild's finds nearly all of its keys; the third graph of the
+                         # sweep is made from the second one's live part and has no table pass at all)
+                         "launch_ms": [round(x, 4) for x in stage_each.get(dom, [])],
+                         "launch_frac": [round(cands[dom] / (x * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) for x in stage_each.get(dom, []) if x > 0],
                          "largest_stages": per_kernel,
                          "table_passes": table_passes,
                          "whole_sweep": whole_sweep,
