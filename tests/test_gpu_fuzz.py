@@ -31,6 +31,17 @@ def test_random_merged_builds_equal_unsharded():
     assert n_fail == 0 and n_ok > 100
 
 
+def test_random_merged_sweeps_equal_single_gpu_sweep():
+    """tools/fuzz_dist_sweep.py: the whole cleaning sweep with every build merged across 2 - 8 emulated ranks (the third
+    one made from the second graph's live part whenever no rank re-threaded a read) against the single-GPU sweep"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_dist_sweep", os.path.join(root, "tools", "fuzz_dist_sweep.py"))
+    fd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fd)
+    n_ok, n_skip, n_fail = fd.run(budget=60.0, seed=8151, max_cases=120)
+    assert n_fail == 0 and n_ok > 60
+
+
 def test_random_bubble_popping_equals_oracle():
     """tools/fuzz_api.py restricted to bubble popping (f1): correct_low_coverage_paths on random reads, the device
     MinHash against the oracle's pure-Python sketch.  In a child interpreter with PYTHONHASHSEED=0 (the reference's
