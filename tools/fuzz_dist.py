@@ -30,21 +30,28 @@ def run(budget, seed, max_cases=None):
         ref = Engine(0); engines = []
         try:
             ref.set_reads(toks, offs, vocab.two_v)
+            palindrome = False
             try:
                 ref.build(k)
             except Exception as e:  # noqa: BLE001
-                if getattr(e, "code", None) == -4:
-                    n_skip += 1     # palindromic gene-mer (even k): nothing to merge
-                    continue
-                raise
-            if thr:
+                if getattr(e, "code", None) != -4:
+                    raise
+                palindrome = True   # a palindromic gene-mer (even k): every rank of the merged build must say so too
+            if thr and not palindrome:
                 ref.filter(*thr)
             for r in range(world):
                 lo, hi = bounds[r], bounds[r + 1]
                 e = Engine(0)
                 e.set_reads(toks[offs[lo]:offs[hi]], offs[lo:hi + 1] - offs[lo], vocab.two_v)
                 engines.append(e)
-            dist_build_loopback(engines, k, *(thr or (1, 1)))
+            try:
+                dist_build_loopback(engines, k, *(thr or (1, 1)))
+                assert not palindrome, "the unsharded build found a palindromic gene-mer, the merged one did not"
+            except Exception as e:  # noqa: BLE001
+                if getattr(e, "code", None) != -4 or not palindrome:
+                    raise
+                n_skip += 1
+                continue
             if thr:
                 want = td.live_state(ref)
                 for r, e in enumerate(engines):
@@ -68,7 +75,7 @@ def run(budget, seed, max_cases=None):
                 e.close()
         if n_fail >= 5:
             break
-    print(f"fuzz_dist: {n_ok} merged builds equal to the unsharded one, {n_skip} palindromic inputs skipped, {n_fail} failures (seed {seed})")
+    print(f"fuzz_dist: {n_ok} merged builds equal to the unsharded one, {n_skip} palindromic inputs refused by both, {n_fail} failures (seed {seed})")
     return n_ok, n_skip, n_fail
 
 
