@@ -92,6 +92,11 @@ def _load():
         "amg_set_reads_from_corrected": (C.c_int, [P, P]),
         "amg_match_patterns": (C.c_int, [P, C.c_int, P, P, I64, P, P, P]),
         "amg_minhash": (C.c_int, [P, P, P, P, I64, I32, C.c_uint64, P, P, I64, C.POINTER(I64)]),
+        "amg_junction_paths": (C.c_int, [P, I32, C.POINTER(I64)]),
+        "amg_get_junction_paths": (C.c_int, [P, P, P, P, P, P, P]),
+        "amg_seqs_create": (C.c_int, [I32, P, P, I64, C.POINTER(P)]),
+        "amg_seqs_destroy": (C.c_int, [P]),
+        "amg_path_sketch_overlaps": (C.c_int, [P, P, P, I32, C.c_uint64, I64, P, P, I64, P, P, P, P]),
         "amg_dist_unique_id": (C.c_int, [P, I32]),
         "amg_dist_init": (C.c_int, [P, P, I32, I32]),
         "amg_dist_merge": (C.c_int, [P, I32, U32, U32]),

@@ -3,17 +3,63 @@ amira/construct_graph.py (reference v0.11.0): correct_low_coverage_paths :2196-2
 callees (:1482-1485, :1515-1667, :1693-1955, :1977-2014, :2066-2194, :2252-2265), plus
 get_unitigs_in_graph :2961-2975 (row f4).
 
-The graph work here is host-side orchestration over a handful of junctions, as in the reference;
-what scales with the data — hashing every k-mer of every read segment under a bubble — runs on the
-device: `amg_minhash` (amira_amd/csrc/amg_minhash.hip) computes sourmash's scaled MinHash
-(MurmurHash3_x64_128 of canonical k-mers, seed 42) for all segments of all nodes in one launch.
-`MinHash` below offers the three calls the reference makes on sourmash.MinHash on top of it.
+What grows with the data runs on the device, on the device's own node ids (amira_amd/csrc/amg_bubbles.hip):
+  * the search for the paths between junctions — ONE search per start junction that notes every junction it arrives at,
+    where the reference searches once per (start, stop) pair (`Engine.junction_paths`);
+  * the sketches: the reads' bases are uploaded once per cleaning run (`Sequences`), a node's sketch is hashed straight
+    from them under every window that sits on the node, the paths' sketches are united and compared on the device
+    (`Engine.path_sketch_overlaps`) — the host sees sketch sizes and overlaps, never a hash.
+What decides with those numbers — which path of a bubble is the better one, which reads are rewritten and how — is
+host-side orchestration over a handful of paths, as in the reference.  A graph edited on the host (add_node, ...) and
+the cases the device path leaves alone (a gene-mer size beyond 16: 4 k > 64 levels of search; two nodes joined by
+several edges at the end of a path, where the reference fails; AMG_BUBBLES_BY_OBJECTS=1, the A/B and test switch) go
+through the reference-shaped methods below, object by object, with `MinHash` (sourmash's three calls over amg_minhash).
 """
+import os
 import statistics
 import sys
 from collections import Counter, defaultdict
 
+import numpy as np
+
+from . import _ffi
 from .path_finding_utils import Tree
+
+_SEQS = {}   # (id(fastq_data), device) -> (fastq_data, Sequences, {read id: row}, number of reads)
+
+
+def _sequences_for(fastq_data, device):
+    """the bases of fastq_data's reads on the device: uploaded when a cleaning run first asks, kept until another
+    fastq_data comes along (release_sequences() lets go at once).  fastq_data is taken as read-only, as the reference
+    treats it."""
+    from .engine import Sequences
+    key = (id(fastq_data), int(device))
+    got = _SEQS.get(key)
+    if got is None or got[0] is not fastq_data or got[3] != len(fastq_data):
+        release_sequences()
+        ids = list(fastq_data)
+        got = _SEQS[key] = (fastq_data, Sequences([fastq_data[r]["sequence"] for r in ids], device),
+                            {r: i for i, r in enumerate(ids)}, len(ids))
+    return got
+
+
+def release_sequences():
+    for entry in _SEQS.values():
+        entry[1].close()
+    _SEQS.clear()
+
+
+class _PathOverlaps:
+    """stands in for path_minimizers ({path: [node sketches]}) where the device has united and compared the sketches:
+    sizes of the paths' sketches and, for every pair of paths between the same terminals, the hashes they share"""
+
+    def __init__(self, index_of, size, common_of):
+        self._index_of, self._size, self._common_of = index_of, size, common_of
+
+    def compare(self, high_nodes, low_nodes):
+        """(len(high sketch), len(low sketch), len(high sketch & low sketch))"""
+        i, j = self._index_of[tuple(high_nodes)], self._index_of[tuple(low_nodes)]
+        return self._size[i], self._size[j], self._common_of[(i, j)]
 
 
 class MinHash:
@@ -311,14 +357,18 @@ class BubblePopping:
             high_nodes = [n[0] for n in high_entry]
             if tuple(high_nodes) in corrected_paths or any(n in seen_nodes for n in high_nodes):
                 continue
-            high_sketch = self.get_minimizers_from_minhashes(high_nodes, path_minimizers)
+            on_device = isinstance(path_minimizers, _PathOverlaps)
+            high_sketch = None if on_device else self.get_minimizers_from_minhashes(high_nodes, path_minimizers)
             for low_entry, low_coverage in paths[i + 1:]:
                 low_nodes = [n[0] for n in low_entry]
                 if tuple(low_nodes) in corrected_paths or any(n in seen_nodes for n in low_nodes):
                     continue
-                low_sketch = self.get_minimizers_from_minhashes(low_nodes, path_minimizers)
-                common = len(high_sketch & low_sketch)
-                if max(common / len(low_sketch), common / len(high_sketch)) > threshold:
+                if on_device:
+                    n_high, n_low, common = path_minimizers.compare(high_nodes, low_nodes)
+                else:
+                    low_sketch = self.get_minimizers_from_minhashes(low_nodes, path_minimizers)
+                    n_high, n_low, common = len(high_sketch), len(low_sketch), len(high_sketch & low_sketch)
+                if max(common / n_low, common / n_high) > threshold:
                     operation = (tuple(low_nodes), tuple(high_nodes), low_coverage, high_coverage)
                     correction_operations.add(operation)
                     corrected_paths.add(tuple(low_nodes))
@@ -373,26 +423,102 @@ class BubblePopping:
                 self.correct_gene_positions_on_read(first_shared, last_shared, subset, read_id, fastq_data)
         return path_coverages
 
+    # ------------------------------------------------------------------ the device's share
+    def _junction_paths_on_device(self):
+        """{component: [path, ...]} with every path get_all_paths_between_junctions_in_component would add to its set,
+        in the order it would add them, as lists of (node hash, direction) — and the components in order; None when the
+        device path does not apply (module docstring)"""
+        max_distance = self.get_kmerSize() * 4
+        if self._host_edits or max_distance > 64 or max_distance < 2 or os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
+            return None
+        found = self._engine.junction_paths(max_distance)
+        if found["flags"]:
+            return None
+        v = self._v()
+        nodes = v.arrays["nodes"]
+        component_of = nodes["component"]
+        components = sorted(set(component_of[nodes["alive"] != 0].tolist()))
+        start_component = component_of[found["junction_node"]]
+        by_component = {int(c): [] for c in np.unique(start_component).tolist()}
+        off, ids, dirs = found["path_off"].tolist(), found["path_node"], found["path_dir"].tolist()
+        v.ensure_hashes(np.unique(ids).tolist())
+        hashes = [v.node_hash[i] for i in ids.tolist()]
+        path_component = start_component[found["path_start"]].tolist()
+        for p, c in enumerate(path_component):
+            by_component[c].append(list(zip(hashes[off[p]:off[p + 1]], dirs[off[p]:off[p + 1]])))
+        return components, by_component
+
+    def _path_overlaps_on_device(self, bubbles, fastq_data):
+        """what define_correction_operations asks of the sketches, for every pair of paths it can ask about: the paths
+        between the same terminals, the one of higher coverage first (the order correct_bubble_paths sorts them in)"""
+        if self._host_edits or os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
+            return None
+        index_of, path_ids, pair_a, pair_b = {}, [], [], []
+        node_id = self._v().node_of_hash
+        for entries in bubbles.values():
+            if len(entries) < 2:
+                continue
+            group = []
+            for entry, _coverage in sorted(list(entries), key=lambda e: e[1], reverse=True):
+                key = tuple(n[0] for n in entry)
+                if key not in index_of:
+                    index_of[key] = len(path_ids)
+                    path_ids.append([node_id[h] for h in key])
+                group.append(index_of[key])
+            for a in range(len(group)):
+                for b in range(a + 1, len(group)):
+                    pair_a.append(group[a])
+                    pair_b.append(group[b])
+        if not pair_a:
+            return _PathOverlaps({}, [], {})
+        try:
+            _, seqs, row_of, _ = _sequences_for(fastq_data, self._engine.device)
+            rows = np.fromiter((row_of.get(r, -1) for r in self._read_ids), np.int32, len(self._read_ids))
+            identity = len(rows) <= seqs.n and bool((rows == np.arange(len(rows), dtype=np.int32)).all())
+            path_off = np.zeros(len(path_ids) + 1, np.int64)
+            np.cumsum([len(p) for p in path_ids], out=path_off[1:])
+            flat = np.fromiter((x for p in path_ids for x in p), np.int32, int(path_off[-1]))
+            size, common = self._engine.path_sketch_overlaps(seqs, None if identity else rows, 11, 10, path_off, flat,
+                                                             pair_a, pair_b)
+        except (_ffi.AmgError, KeyError, TypeError):
+            return None   # (a read without a sequence, a position below zero, ...: the objects' way says what the reference says)
+        return _PathOverlaps(index_of, size.tolist(), dict(zip(zip(pair_a, pair_b), common.tolist())))
+
     def correct_low_coverage_paths(self, fastq_data, genesOfInterest, cores, min_path_coverage,
                                    components_to_skip, use_minimizers=False):
         """pop bubbles: between every pair of junctions, reads on the lower-coverage way through are
         re-written to the higher-coverage one when their sequences' MinHash containment exceeds 0.8"""
         assert self.get_gene_positions()
-        starts = self.identify_potential_bubble_starts()
         max_distance = self.get_kmerSize() * 4
+        on_device = self._junction_paths_on_device()
+        if on_device is not None:
+            components, paths_of = on_device
+        else:
+            starts = self.identify_potential_bubble_starts()
+            components = self.components()
         path_coverages = []
-        components = self.components()
         for component in components:
             sys.stderr.write(f"\n\tAmira: popping bubbles using 1 CPU for component {component} / {len(components)}\n")
-            if component in components_to_skip or component not in starts:
-                continue
-            unique_paths = self.get_all_paths_between_junctions_in_component(starts[component], max_distance, cores)
+            if on_device is not None:
+                if component in components_to_skip or component not in paths_of:
+                    continue
+                unique_paths = set()
+                for p in paths_of[component]:
+                    unique_paths.add(tuple(sorted([p, [(h, -d) for h, d in reversed(p)]])[0]))
+                unique_paths = list(unique_paths)
+            else:
+                if component in components_to_skip or component not in starts:
+                    continue
+                unique_paths = self.get_all_paths_between_junctions_in_component(starts[component], max_distance, cores)
             shortest_first = sorted(self.filter_paths_between_bubble_starts(unique_paths), key=lambda e: len(e[0]))
-            path_minimizers = (self.get_minhashes_for_paths(shortest_first, fastq_data, cores)
-                               if use_minimizers else None)
-            path_coverages += self.correct_bubble_paths(
-                self.separate_paths_by_terminal_nodes(shortest_first), fastq_data, path_minimizers,
-                genesOfInterest, min_path_coverage)
+            bubbles = self.separate_paths_by_terminal_nodes(shortest_first)
+            path_minimizers = None
+            if use_minimizers:
+                path_minimizers = self._path_overlaps_on_device(bubbles, fastq_data)
+                if path_minimizers is None:
+                    path_minimizers = self.get_minhashes_for_paths(shortest_first, fastq_data, cores)
+            path_coverages += self.correct_bubble_paths(bubbles, fastq_data, path_minimizers, genesOfInterest,
+                                                        min_path_coverage)
         return self.get_reads(), self.get_gene_positions(), path_coverages, min_path_coverage
 
     # ------------------------------------------------------------------ unitigs (row f4)

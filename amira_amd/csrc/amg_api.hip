@@ -209,6 +209,7 @@ extern "C" int amg_destroy(amg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   stages_reset(c);
   dist_release(c);
+  bubbles_release(c);
   DevBuf* all[] = {&c->tokens,    &c->read_off,  &c->gene_start, &c->gene_end,  &c->read_len,
                    &c->node_tab,  &c->edge_tab,  &c->tok_slot,   &c->tok_node,  &c->tok_dir, &c->tok_pair,
                    &c->node_tokens, &c->node_cov, &c->node_first, &c->node_comp, &c->node_alive,

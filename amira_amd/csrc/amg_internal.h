@@ -126,6 +126,7 @@ struct StageTime {
 static const uint64_t kAmgSeed0 = 0x9E3779B97F4A7C15ull;  // initial fingerprint seed (amg_build re-seeds on a collision)
 
 struct DistState;  // amg_dist.hip: communicator, buffers and progress of the ctx's merged builds
+struct BubbleState;  // amg_bubbles.hip: what amg_junction_paths found, until the caller has fetched it
 
 struct amg_ctx {
   int device = 0;
@@ -248,6 +249,7 @@ struct amg_ctx {
   bool dist_sorted = false;  // the local records leave in sorted order (send_order)
   DevBuf dist_a, dist_cnt, dist_first, dist_slot, dist_gtab, dist_lcnt;
   DistState* dist = nullptr;
+  BubbleState* bub = nullptr;  // amg_bubbles.hip
 
   // ---- K6 result cache (two-call protocol of amg_match_patterns)
   bool match_valid = false;
@@ -357,6 +359,24 @@ int stream_wait(amg_ctx* c);  // hipStreamSynchronize at the latency of fetch()
 void stage_begin(amg_ctx* c, const char* name);
 void stage_end(amg_ctx* c);
 void stages_reset(amg_ctx* c);
+
+// ------------------------------------------------------------------ walkers' view of the live graph (amg_passes.hip)
+struct GView {
+  // live adjacency: row 2n = forward list of node n, row 2n+1 = backward list, only ALIVE
+  // edges, in list order, with the target inline (.x = target node, .y = target direction)
+  const int2* lent;
+  const int4* lrows;  // per row {offset, live count, first target, first direction}: one 16-B load
+                      // tells a walker everything about a row with <= 1 live edge (most rows)
+  const unsigned char* n_alive;
+  const unsigned int* n_cov;
+  const int* n_tok;
+  const long long* n_first;
+  const int* n_comp;
+  int k, flip;
+};
+int ensure_live_adj(amg_ctx* c);  // the live lists below exist and are up to date
+GView make_view(amg_ctx* c);
+void bubbles_release(amg_ctx* c);
 
 void dist_release(amg_ctx* c);  // amg_dist.hip
 // amg_derive.hip

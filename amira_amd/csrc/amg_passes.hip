@@ -137,19 +137,7 @@ extern "C" int amg_remove_nodes(amg_ctx* c, const int32_t* node_ids, int64_t n) 
 
 
 // ------------------------------------------------------------------ graph view for walkers
-struct GView {
-  // live adjacency: row 2n = forward list of node n, row 2n+1 = backward list, only ALIVE
-  // edges, in list order, with the target inline (.x = target node, .y = target direction)
-  const int2* lent;
-  const int4* lrows;  // per row {offset, live count, first target, first direction}: one 16-B load
-                      // tells a walker everything about a row with <= 1 live edge (most rows)
-  const unsigned char* n_alive;
-  const unsigned int* n_cov;
-  const int* n_tok;
-  const long long* n_first;
-  const int* n_comp;
-  int k, flip;
-};
+// (GView: amg_internal.h)
 
 // Live adjacency straight from the live edges: flag + scan squeezes the removed edges out in edge
 // order, a stable sort by row (2 * source + side) groups them, so a row lists its live edges in
@@ -341,7 +329,7 @@ __global__ void k_lr_patch(int4* __restrict__ lrows, int2* __restrict__ lent, lo
   if (w != rw.y) lrows[r] = make_int4(rw.x, w, first.x, first.y);
 }
 
-static int ensure_live_adj(amg_ctx* c) {
+int ensure_live_adj(amg_ctx* c) {
   if (c->ladj_valid) return AMG_OK;
   hipStream_t st = c->stream;
   if (c->ladj_stale) {
@@ -396,7 +384,7 @@ static int ensure_live_adj(amg_ctx* c) {
   return AMG_OK;
 }
 
-static GView make_view(amg_ctx* c) {
+GView make_view(amg_ctx* c) {
   GView g;
   g.lent = c->ladj.as<int2>();
   g.lrows = c->ladj_rows.as<int4>();

@@ -351,6 +351,36 @@ class Engine:
             out[int(ids[0])] = set(np.unique(hs).tolist())
         return out
 
+    # ---- bubble popping on device ids (include/amg.h: amg_junction_paths, amg_path_sketch_overlaps)
+    def junction_paths(self, max_distance):
+        """the junctions of the live graph and every path between two of them that has a rival, in the order the
+        reference's double loop over the junctions meets them (amg_junction_paths).  Returns a dict of arrays:
+        junction_node, junction_dir, path_start (index of the start junction), path_off, path_node, path_dir, and
+        `flags` (non-zero: do not use the paths — see include/amg.h)"""
+        sizes = (C.c_int64 * 4)()
+        check(_ffi.lib.amg_junction_paths(self._h, int(max_distance), sizes))
+        J, P, N, flags = (int(x) for x in sizes)
+        out = {"junction_node": np.empty(J, np.int32), "junction_dir": np.empty(J, np.int8),
+               "path_start": np.empty(P, np.int32), "path_off": np.zeros(P + 1, np.int64),
+               "path_node": np.empty(N, np.int32), "path_dir": np.empty(N, np.int8), "flags": flags}
+        check(_ffi.lib.amg_get_junction_paths(self._h, ptr(out["junction_node"]), ptr(out["junction_dir"]),
+                                              ptr(out["path_start"]), ptr(out["path_off"]), ptr(out["path_node"]),
+                                              ptr(out["path_dir"])))
+        return out
+
+    def path_sketch_overlaps(self, seqs, row_to_seq, ksize, scaled, path_off, path_node, pair_a, pair_b):
+        """sizes of the paths' sketches and the number of hashes each listed pair of paths shares
+        (amg_path_sketch_overlaps); seqs: a Sequences on this engine's device"""
+        path_off = np.ascontiguousarray(path_off, np.int64)
+        path_node = np.ascontiguousarray(path_node, np.int32)
+        pair_a, pair_b = np.ascontiguousarray(pair_a, np.int32), np.ascontiguousarray(pair_b, np.int32)
+        rts = None if row_to_seq is None else np.ascontiguousarray(row_to_seq, np.int32)
+        n_paths, n_pairs = len(path_off) - 1, len(pair_a)
+        size, common = np.zeros(max(n_paths, 1), np.int64), np.zeros(max(n_pairs, 1), np.int64)
+        check(_ffi.lib.amg_path_sketch_overlaps(self._h, seqs._h, ptr(rts), int(ksize), int(scaled), n_paths, ptr(path_off),
+                                                ptr(path_node), n_pairs, ptr(pair_a), ptr(pair_b), ptr(size), ptr(common)))
+        return size[:n_paths], common[:n_pairs]
+
     # ---- multi-GPU: read shards + key-owner table merge (include/amg.h; drivers in amira_amd/dist.py)
     @staticmethod
     def dist_unique_id():
@@ -446,3 +476,41 @@ def lease_done(engine, lease):
     engine._leases.discard(lease)
     if engine._pool_when_free and len(engine._leases) == 0:
         release_engine(engine)
+
+
+class Sequences:
+    """the reads' nucleotide sequences resident on a device (amg_seqs_create): one upload serves every graph of a
+    cleaning run.  `sequences`: list of str (ASCII) or bytes, kept alive by the caller during the call only."""
+
+    def __init__(self, sequences, device=0):
+        n = len(sequences)
+        ptrs = (C.c_void_p * max(n, 1))()
+        lens = np.zeros(max(n, 1), np.int64)
+        as_utf8 = C.pythonapi.PyUnicode_AsUTF8AndSize
+        as_utf8.restype, as_utf8.argtypes = C.c_void_p, [C.py_object, C.POINTER(C.c_ssize_t)]
+        size = C.c_ssize_t(0)
+        keep = []
+        for i, s in enumerate(sequences):
+            if isinstance(s, str):
+                ptrs[i] = as_utf8(s, C.byref(size))   # (the string's own bytes for ASCII text: nothing is copied)
+                lens[i] = size.value
+            else:
+                b = bytes(s)
+                keep.append(b)
+                ptrs[i] = C.cast(C.c_char_p(b), C.c_void_p).value
+                lens[i] = len(b)
+        self._h = C.c_void_p()
+        self.device, self.n = int(device), n
+        check(_ffi.lib.amg_seqs_create(int(device), ptrs, ptr(lens), n, C.byref(self._h)))
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib.amg_seqs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -265,6 +265,40 @@ int amg_minhash(amg_ctx* ctx, const uint8_t* bases, const int64_t* seg_off, cons
                 int64_t n_seg, int32_t ksize, uint64_t scaled, int32_t* out_set, uint64_t* out_hash,
                 int64_t cap, int64_t* n_out);
 
+/* ---- bubble popping on device ids (row f1, correct_low_coverage_paths construct_graph.py:2196-2250).
+ *      amg_junction_paths: the junctions of the live graph (identify_potential_bubble_starts :2252-2265: a live node
+ *      with more than one live edge in its forward list is junction (node, +1), in its backward list (node, -1); in
+ *      node order, forward before backward) and every path get_all_paths_between_junctions_in_component (:2066-2098)
+ *      would put into its set BEFORE it picks the smaller of the path and its mirror image: for every start junction,
+ *      for every stop junction in list order, the paths new_find_paths_between_nodes(start, stop, max_distance) (:2292-
+ *      2342) returns that arrive at the stop through its junction side, in the order it returns them, when there are
+ *      at least two.  (One search per start instead of one per pair: amira_amd/csrc/amg_bubbles.hip.)  Paths never
+ *      leave a component, so the caller splits the list by the component of the start.
+ *      sizes[0] = junctions, [1] = paths, [2] = nodes over all paths, [3] = flags: bit 0 — a path ends at a junction
+ *      over two nodes with more than one edge between them, where the reference fails (:1515-1523 on a list); bit 1 —
+ *      a search was abandoned after 2^24 steps.  With a flag set the paths are not to be used.
+ *      amg_get_junction_paths copies out: junction_node / junction_dir [junctions], path_start [paths] (index of the
+ *      start junction), path_off [paths + 1], path_node / path_dir [sizes[2]]; any pointer may be NULL. ---------- */
+int amg_junction_paths(amg_ctx* ctx, int32_t max_distance, int64_t* sizes /*[4]*/);
+int amg_get_junction_paths(amg_ctx* ctx, int32_t* junction_node, int8_t* junction_dir, int32_t* path_start,
+                           int64_t* path_off, int32_t* path_node, int8_t* path_dir);
+/* the reads' nucleotide sequences (fastq_data[read]["sequence"]) resident on a device: seq[i] points at len[i] bytes
+ * (HOST memory, copied during the call).  One handle serves every graph of a cleaning run. */
+typedef struct amg_seqs amg_seqs;
+int amg_seqs_create(int32_t device, const char* const* seq, const int64_t* len, int64_t n, amg_seqs** out);
+int amg_seqs_destroy(amg_seqs* seqs);
+/* The sketches bubble popping compares (:2148-2194, :1747-1786): a node's sketch is the scaled MinHash (ksize, scaled;
+ * amg_minhash's definition) of sequence[start of the window's first gene : end of its last gene + 1] over every window
+ * of the ctx's reads that sits on the node, a path's sketch the union over its nodes.  Paths are lists of node ids
+ * (path_off [n_paths + 1], path_node); read row r of the ctx has sequence row_to_seq[r] of `seqs` (NULL: r).
+ * Out: sketch_size[p] = hashes in path p's sketch; common[q] = hashes the sketches of paths pair_a[q] and pair_b[q]
+ * share.  Needs the gene positions of the ctx's reads (amg_set_positions*) as handed over, i.e. a ctx whose reads
+ * were set, not adopted from its own correction. */
+int amg_path_sketch_overlaps(amg_ctx* ctx, const amg_seqs* seqs, const int32_t* row_to_seq, int32_t ksize,
+                             uint64_t scaled, int64_t n_paths, const int64_t* path_off, const int32_t* path_node,
+                             int64_t n_pairs, const int32_t* pair_a, const int32_t* pair_b, int64_t* sketch_size,
+                             int64_t* common);
+
 /* ---- multi-GPU: read-sharded build with a key-owner table merge — the single-graph result of
  *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
  *      One process per GPU; every rank holds a contiguous shard of the reads in its ctx (amg_set_reads), rank r the
