@@ -97,6 +97,7 @@ def _load():
         "amg_seqs_create": (C.c_int, [I32, P, P, I64, C.POINTER(P)]),
         "amg_seqs_destroy": (C.c_int, [P]),
         "amg_path_sketch_overlaps": (C.c_int, [P, P, P, I32, C.c_uint64, I64, P, P, I64, P, P, P, P]),
+        "amg_nw_align": (C.c_int, [P, I32, P, I32, P, C.POINTER(I32)]),
         "amg_dist_unique_id": (C.c_int, [P, I32]),
         "amg_dist_init": (C.c_int, [P, P, I32, I32]),
         "amg_dist_merge": (C.c_int, [P, I32, U32, U32]),

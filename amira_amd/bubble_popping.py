@@ -106,6 +106,10 @@ class BubblePopping:
 
     # ------------------------------------------------------------------ alignment / path helpers
     def calculate_path_coverage(self, path):
+        if not self._host_edits:   # (the coverages as the device holds them: no Node objects)
+            v = self._v()
+            coverage, id_of = v.arrays["nodes"]["coverage"], v.node_of_hash
+            return statistics.mean([int(coverage[id_of[n[0]]]) for n in path[1:-1]])
         return statistics.mean([self.get_node_by_hash(n[0]).get_node_coverage() for n in path[1:-1]])
 
     def get_direction_between_two_nodes(self, source_node_hash, target_node_hash):

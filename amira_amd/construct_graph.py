@@ -22,6 +22,7 @@ raises.  Host-side methods below only do what the reference also does in Python 
 built graph (unitig gene strings, linear-path walks, anchor / block logic of the read-path
 clustering).
 """
+import ctypes as C
 import os
 import statistics
 import sys
@@ -354,6 +355,8 @@ class GeneMerGraph(BubblePopping):
         """_filter = (minNodeCoverage, minEdgeCoverage): the graph comes out as GeneMerGraph(...).filter_graph(...)
         would leave it, with the filter applied during the build (amg_build_filtered; graph_utils.build_filtered_graph)"""
         self._init_fields(readDict, kmerSize, gene_positions, device)
+        if isinstance(readDict, TokenizedReads):
+            readDict = readDict.settled()   # (reads replaced by hand — bubble popping — are spelled into the arrays)
         on_device = readDict.device_source() if isinstance(readDict, TokenizedReads) else None
         if on_device is not None and on_device.engine().device == self._engine.device:
             # the output of a correct_reads that never left the GPU: taken over device to device, positions included
@@ -467,7 +470,7 @@ class GeneMerGraph(BubblePopping):
 
     def _positions_from_mapping(self):
         if self._gs_val is None and isinstance(self._genePositions, TokenizedPositions) \
-                and self._genePositions._moved is None and self._genePositions._gs is not None:
+                and self._genePositions.as_made() and self._genePositions._gs is not None:
             keep32 = self._genePositions.gene_start.dtype == np.int32 and self._genePositions.gene_end.dtype == np.int32
             self._gs_val = np.ascontiguousarray(self._genePositions.gene_start, np.int32 if keep32 else np.int64)
             self._ge_val = np.ascontiguousarray(self._genePositions.gene_end, np.int32 if keep32 else np.int64)
@@ -485,7 +488,8 @@ class GeneMerGraph(BubblePopping):
     def _host_positions(self, gene_positions):
         """flat int64 (start, end) per gene, aligned with the tokens"""
         offs = self._read_off
-        if isinstance(gene_positions, TokenizedPositions) and gene_positions._moved is None:  # as it was made
+        if isinstance(gene_positions, TokenizedPositions):
+            gene_positions = gene_positions.settled()   # (redirected / hand-set reads gathered into arrays of their own)
             # (int32 arrays stay int32: they cross PCIe as they are, amg_set_positions32)
             keep32 = gene_positions.gene_start.dtype == np.int32 and gene_positions.gene_end.dtype == np.int32
             self._gs_val = np.ascontiguousarray(gene_positions.gene_start, np.int32 if keep32 else np.int64)
@@ -650,7 +654,7 @@ class GeneMerGraph(BubblePopping):
         # the per-window node ids (240 MB per million reads), the window directions (60 MB) and the node -> reads lists
         # (computed on the device for ALL nodes, 4 bytes per window) are fetched when somebody asks for them: read-path
         # clustering asks the device for the windows of the reads it looks at instead (Engine.read_node_ids_of)
-        arrays = v.arrays = _LazyArrays({"nodes": nodes, "edges": edges})
+        arrays = v.arrays = _LazyArrays({"nodes": nodes, "edges": edges, "adj_off": adj_off, "adj_edge": adj_edge})
         arrays.makers["tok_node"] = lambda: {"tok_node": eng.read_node_ids()}
         arrays.makers["tok_dir"] = lambda: {"tok_dir": eng.read_dirs()}
         arrays.makers["node_reads_off"] = arrays.makers["node_reads"] = \
@@ -1442,6 +1446,29 @@ class GeneMerGraph(BubblePopping):
         """host twin of k_corr_nw: match 1 / mismatch 0 / gap -1, borders -index, ties broken
         by max over (score, pointer) tuples => UP > LEFT > DIAG (:1433-1480)."""
         N, M = len(x), len(y)
+        if N * M > 16 and not os.environ.get("AMG_NW_PYTHON"):
+            # beyond a handful of cells: the same recurrence and tie order on interned genes in libamg (amg_nw_align)
+            code = {}
+            try:
+                xs = np.fromiter((code.setdefault(g, len(code)) for g in x), np.int32, N)
+                ys = np.fromiter((code.setdefault(g, len(code)) for g in y), np.int32, M)
+            except TypeError:
+                xs = None   # (unhashable items: the table below compares them as they are)
+            if xs is not None:
+                ops, n_ops = np.empty(N + M, np.int8), C.c_int32(0)
+                _ffi.check(_ffi.lib.amg_nw_align(_ffi.ptr(xs), N, _ffi.ptr(ys), M, _ffi.ptr(ops), C.byref(n_ops)))
+                alignment, i, j = [], 0, 0
+                for op in ops[:n_ops.value].tolist():
+                    if op == 0:
+                        alignment.append((x[i], y[j]))
+                        i, j = i + 1, j + 1
+                    elif op == 1:
+                        alignment.append((x[i], "*"))
+                        i += 1
+                    else:
+                        alignment.append(("*", y[j]))
+                        j += 1
+                return alignment
         DIAG, LEFT, UP = (-1, -1), (-1, 0), (0, -1)
         F, Ptr = {(-1, -1): 0}, {}
         for i in range(N):
@@ -1503,6 +1530,10 @@ class GeneMerGraph(BubblePopping):
         fails at any step redo the whole path extending to the left."""
         if len(listOfNodes) == 1:
             return self.get_gene_mer_genes(self.get_node_by_hash(listOfNodes[0]))
+        if not self._host_edits:
+            genes = self._genes_in_unitig_from_arrays(listOfNodes)
+            if genes is not None:
+                return genes
         k1 = self._kmerSize - 1
 
         def first_orientation():
@@ -1540,6 +1571,44 @@ class GeneMerGraph(BubblePopping):
 
         genes = walk(False)
         return genes if genes is not None else walk(True)
+
+    def _genes_in_unitig_from_arrays(self, listOfNodes):
+        """get_genes_in_unitig on the device's arrays (node tokens, live edge lists) instead of Node / Edge objects;
+        None wherever the objects' way would not simply return (nodes that are not adjacent, several edges between
+        two nodes, a path that spells nothing): it then runs and says what the reference says"""
+        v = self._v()
+        a = v.arrays
+        n_tok, e_alive, e_tgt, e_sdir = a["nodes"]["tokens"], a["edges"]["alive"], a["edges"]["tgt"], a["edges"]["sdir"]
+        adj_off, adj_edge = a["adj_off"], a["adj_edge"]
+        id_of = v.node_of_hash
+        ids = [id_of.get(h) for h in listOfNodes]
+        if None in ids:
+            return None
+        flip = self._vocab.two_v - 1
+
+        def edges_to(src, tgt):   # live edges src -> tgt, forward list first: what get_edge_hashes_between_nodes collects
+            lo, hi = int(adj_off[2 * src]), int(adj_off[2 * src + 2])
+            return [e for e in adj_edge[lo:hi].tolist() if e_alive[e] and e_tgt[e] == tgt]
+
+        genes = None
+        k1 = self._kmerSize - 1
+        for n in range(len(ids) - 1):
+            there, back = edges_to(ids[n], ids[n + 1]), edges_to(ids[n + 1], ids[n])
+            if len(there) != 1 or len(back) != 1:
+                return None
+            if n == 0:
+                first = n_tok[ids[0]].tolist()
+                genes = first if int(e_sdir[there[0]]) == 1 else [flip - t for t in reversed(first)]
+            fw = n_tok[ids[n + 1]].tolist()
+            tail = genes[-k1:] if k1 else genes[0:]
+            if fw[:-1] == tail:
+                genes.append(fw[-1])
+            else:
+                bw = [flip - t for t in reversed(fw)]
+                if bw[:-1] != tail:
+                    return None   # (the objects' way starts over, extending to the left)
+                genes.append(bw[-1])
+        return self._vocab.decode(genes)
 
     # ------------------------------------------------------------------ GML output (:542-586, :873-909)
     def write_node_entry(self, node_id, node_string, node_coverage, reads, component_ID, nodeColor):

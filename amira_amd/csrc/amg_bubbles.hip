@@ -844,3 +844,43 @@ extern "C" int amg_bubbles_debug_copy(amg_ctx* c, int32_t which, void* out, int6
   HIPCHK(hipMemcpy(out, src[which]->p, (size_t)bytes, hipMemcpyDeviceToHost));
   return AMG_OK;
 }
+
+// ------------------------------------------------------------------ the alignment of two short gene lists (host)
+// needleman_wunsch (construct_graph.py:1433-1480) on interned genes: match 1, mismatch 0, gap -1, borders -index, the
+// best of (score, pointer) with the pointers ordered DIAG < LEFT < UP — a tie goes UP, then LEFT.  ops, in alignment
+// order: 0 = (x, y), 1 = (x, *), 2 = (*, y); at most n + m of them.  The two paths of a bubble are a few dozen genes:
+// this is the host's share of compare_paths (:1566), called once per correction operation.
+extern "C" int amg_nw_align(const int32_t* x, int32_t n, const int32_t* y, int32_t m, int8_t* ops, int32_t* n_ops) {
+  if (n < 0 || m < 0 || !n_ops || ((n || m) && !ops) || (n && !x) || (m && !y)) return amg_fail(AMG_E_ARG, "bad argument");
+  const int W = m + 1;
+  std::vector<int> F((size_t)(n + 1) * W);
+  std::vector<signed char> P((size_t)(n + 1) * W, 0);
+  // F[i + 1][j + 1] = the reference's F[i, j]; its borders are F[i, -1] = -i, F[-1, j] = -j (so F[0, -1] = 0 too)
+  F[0] = 0;
+  for (int i = 0; i < n; ++i) F[(size_t)(i + 1) * W] = -i;
+  for (int j = 0; j < m; ++j) F[(size_t)j + 1] = -j;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const int diag = F[(size_t)i * W + j] + (x[i] == y[j] ? 1 : 0);
+      const int left = F[(size_t)i * W + j + 1] - 1;   // F[i - 1, j] - 1: a gene of x against a gap
+      const int up = F[(size_t)(i + 1) * W + j] - 1;   // F[i, j - 1] - 1: a gene of y against a gap
+      int best = diag;
+      signed char ptr = 0;
+      if (left >= best) { best = left; ptr = 1; }
+      if (up >= best) { best = up; ptr = 2; }
+      F[(size_t)(i + 1) * W + j + 1] = best;
+      P[(size_t)(i + 1) * W + j + 1] = ptr;
+    }
+  std::vector<signed char> rev;
+  int i = n - 1, j = m - 1;
+  while (i >= 0 && j >= 0) {
+    const signed char p = P[(size_t)(i + 1) * W + j + 1];
+    rev.push_back(p);
+    if (p == 0) { --i; --j; } else if (p == 1) { --i; } else { --j; }
+  }
+  while (i >= 0) { rev.push_back(1); --i; }
+  while (j >= 0) { rev.push_back(2); --j; }
+  *n_ops = (int32_t)rev.size();
+  for (size_t t = 0; t < rev.size(); ++t) ops[t] = rev[rev.size() - 1 - t];
+  return AMG_OK;
+}

@@ -10,6 +10,7 @@ The reference's only parallelism is host processes over read shards whose merge 
 on the device and `cores` is accepted for signature compatibility only.
 """
 import statistics
+import os
 import sys
 
 import numpy as np
@@ -26,11 +27,13 @@ def _tokenized(reads, gene_positions):
     from .io import TokenizedPositions, TokenizedReads
     from .tokens import tokenize
     if isinstance(reads, TokenizedReads):
-        reads_t = reads
+        reads_t = reads.settled()
     else:
         reads_t = TokenizedReads(*tokenize(reads))
-    if gene_positions is None or (isinstance(gene_positions, TokenizedPositions) and gene_positions._moved is None):
+    if gene_positions is None:
         return reads_t, gene_positions
+    if isinstance(gene_positions, TokenizedPositions):
+        return reads_t, gene_positions.settled()
     offs, n = reads_t.read_offsets, int(reads_t.read_offsets[-1])
     gs, ge = np.empty(n, np.int64), np.empty(n, np.int64)
     for r, rid in enumerate(reads_t.read_ids):
@@ -133,6 +136,18 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
     iteration and the filter_graph that follows it run as one device pass (build_filtered_graph)."""
     prev_nodes = 0
     components_to_skip = set()
+    # dicts in, dicts out — and arrays in between: the reads and their positions are tokenised ONCE, every build of
+    # every iteration takes them over as arrays (device to device after a correction), the reads bubble popping
+    # rewrites are spelled into them (TokenizedReads / TokenizedPositions .settled()).  Callers that hand the array-
+    # backed mappings over (amira_amd.pre_processing.process_pandora_json) get them back.
+    from .io import TokenizedReads
+    as_dicts = not isinstance(new_annotatedReads, TokenizedReads)
+    if as_dicts and new_gene_position_dict and len(new_gene_position_dict) >= len(new_annotatedReads) \
+            and not os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
+        try:
+            new_annotatedReads, new_gene_position_dict = _tokenized(new_annotatedReads, new_gene_position_dict)
+        except (KeyError, TypeError, ValueError, IndexError, AssertionError):
+            pass   # (positions that do not cover the reads, ...: the dicts go through as they are)
     for this_iteration in range(cleaning_iterations):
         sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
         graph = build_filtered_graph(_own(new_annotatedReads), geneMer_size, _own(new_gene_position_dict),
@@ -154,6 +169,9 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
         new_annotatedReads, new_gene_position_dict, path_coverages, min_path_coverage = (
             graph.correct_low_coverage_paths(fastq_content, sample_genesOfInterest, cores,
                                              min_path_coverage, components_to_skip, True))
+    if as_dicts and isinstance(new_annotatedReads, TokenizedReads):
+        new_annotatedReads = {r: new_annotatedReads[r] for r in new_annotatedReads}
+        new_gene_position_dict = {r: new_gene_position_dict[r] for r in new_gene_position_dict}
     return new_annotatedReads, new_gene_position_dict
 
 

@@ -145,6 +145,35 @@ class TokenizedReads(Mapping):
             raise IndexError(i)
         return self.vocab.gene(int(self.tokens[a + i]))
 
+    def __setitem__(self, read_id, genes):   # bubble popping rewrites a read's genes (construct_graph.py:1534-1545)
+        if read_id not in self._idx():
+            raise KeyError(f"{read_id}: only the reads this mapping was made with can be replaced")
+        self._cache[read_id] = genes
+        self.__dict__.setdefault("_edited", set()).add(read_id)
+
+    def edited(self):
+        return bool(self.__dict__.get("_edited"))
+
+    def settled(self):
+        """this mapping as arrays: itself while no read has been replaced, otherwise a new TokenizedReads with the
+        replaced reads spelled into the arrays (the untouched ones are copied in one piece)"""
+        edited = self.__dict__.get("_edited")
+        if not edited:
+            return self
+        idx = self._idx()
+        rows = np.fromiter((idx[r] for r in edited), np.int64, len(edited))
+        order = np.argsort(rows)
+        rows = rows[order]
+        token_of = self.vocab.token
+        try:
+            new_rows = [np.fromiter((token_of(g) for g in self._cache[self.read_ids[i]]), np.int32) for i in rows.tolist()]
+        except (KeyError, ValueError, AssertionError):   # a gene the vocabulary has never seen: start over from the strings
+            from .tokens import tokenize
+            return TokenizedReads(*tokenize({r: self[r] for r in self.read_ids}))
+        tokens, offs = _replace_rows(self.read_offsets, rows, new_rows, (self.tokens,))
+        return TokenizedReads(self.vocab, tokens[0], offs, self.read_ids, source_rows=self.source_rows,
+                              source_ids=self.source_ids)
+
     def __iter__(self):
         return iter(self.read_ids)
 
@@ -153,6 +182,31 @@ class TokenizedReads(Mapping):
 
     def __contains__(self, read_id):
         return read_id in self._idx()
+
+
+def _replace_rows(offsets, rows, new_rows, columns, new_columns=None):
+    """CSR arrays `columns` (all over `offsets`) with the rows `rows` (ascending) replaced: new_rows[i] is row rows[i]
+    of the first column (new_columns[c][i] of column c when there are several).  Returns (new columns, new offsets);
+    the untouched rows move in one gather."""
+    n = len(offsets) - 1
+    lens = np.diff(offsets)
+    lens[rows] = [len(x) for x in new_rows]
+    new_off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=new_off[1:])
+    keep = np.ones(n, bool)
+    keep[rows] = False
+    kept = np.flatnonzero(keep)
+    src, _ = _gather_rows(offsets, kept)
+    dst, _ = _gather_rows(new_off, kept)
+    out = []
+    for c, col in enumerate(columns):
+        fresh = np.empty(int(new_off[-1]), col.dtype)
+        fresh[dst] = col[src]
+        values = new_rows if c == 0 else new_columns[c]
+        for i, r in enumerate(rows.tolist()):
+            fresh[new_off[r]:new_off[r + 1]] = values[i]
+        out.append(fresh)
+    return out, new_off
 
 
 class TokenizedPositions(Mapping):
@@ -222,6 +276,8 @@ class TokenizedPositions(Mapping):
         c = TokenizedPositions(self.read_ids, self.read_offsets, self._gs, self._ge)
         c._index = self._index
         c._cache = dict(self._cache)
+        if self.__dict__.get("_edited"):
+            c._edited = set(self._edited)
         if self._moved is not None:
             c._moved = (self._moved[0].copy(), self._moved[1])
         return c
@@ -231,14 +287,19 @@ class TokenizedPositions(Mapping):
         TokenizedPositions `other` — what GeneMerGraph.correct_reads does to the caller's gene positions for every
         read it changed (construct_graph.py:1282-1284, :1328), for a million reads at once"""
         if self._moved is not None and self._moved[1] is not other:   # a second correction on the same mapping
+            pinned = self.__dict__.setdefault("_edited", set())
             for i in np.flatnonzero(self._moved[0] >= 0).tolist():
                 self[self.read_ids[i]]       # pin what the first one left (rare: the drivers rebuild in between)
+                pinned.add(self.read_ids[i])
             self._moved = None
         if self._moved is None:
             self._moved = (np.full(len(self.read_ids), -1, np.int64), other)
         self._moved[0][rows] = other_rows
+        edited = self.__dict__.get("_edited")
         for i in np.asarray(rows).tolist() if len(self._cache) else ():
             self._cache.pop(self.read_ids[i], None)
+            if edited:
+                edited.discard(self.read_ids[i])
 
     def pos_at(self, read_id, i):
         """self[read_id][i] without building the read's list of pairs"""
@@ -256,8 +317,42 @@ class TokenizedPositions(Mapping):
         return int(self.gene_start[a + i]), int(self.gene_end[a + i])
 
     def __setitem__(self, read_id, value):   # correct_reads / bubble popping replace a read's positions
-        self._idx()
+        if read_id not in self._idx():
+            raise KeyError(f"{read_id}: only the reads this mapping was made with can be replaced")
         self._cache[read_id] = value
+        self.__dict__.setdefault("_edited", set()).add(read_id)
+
+    def edited(self):
+        return bool(self.__dict__.get("_edited"))
+
+    def as_made(self):
+        """nothing has been redirected (replace_rows) or replaced by hand since the arrays were made"""
+        return self._moved is None and not self.__dict__.get("_edited")
+
+    def settled(self):
+        """this mapping as arrays: itself while nothing has been redirected or replaced, otherwise a new
+        TokenizedPositions — the redirected reads gathered from the mapping they point at, the hand-set ones spelled in
+        from their lists, everything else copied in one piece"""
+        if self.as_made():
+            return self
+        gs, ge, offs = self.gene_start, self.gene_end, self.read_offsets
+        if self._moved is not None:
+            to, other = self._moved
+            moved = np.flatnonzero(to >= 0)
+            if len(moved):
+                o_idx, o_off = _gather_rows(other.read_offsets, to[moved])
+                starts, ends = other.gene_start[o_idx], other.gene_end[o_idx]
+                cuts = o_off[1:-1]
+                (gs, ge), offs = _replace_rows(offs, moved, np.split(starts, cuts), (gs, ge),
+                                               {1: np.split(ends, cuts)})
+        edited = self.__dict__.get("_edited")
+        if edited:
+            idx = self._idx()
+            rows = np.sort(np.fromiter((idx[r] for r in edited), np.int64, len(edited)))
+            lists = [self._cache[self.read_ids[i]] for i in rows.tolist()]
+            (gs, ge), offs = _replace_rows(offs, rows, [[p[0] for p in l] for l in lists], (gs, ge),
+                                           {1: [[p[1] for p in l] for l in lists]})
+        return TokenizedPositions(self.read_ids, offs, gs, ge)
 
     def __iter__(self):
         return iter(self.read_ids)

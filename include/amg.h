@@ -299,6 +299,11 @@ int amg_path_sketch_overlaps(amg_ctx* ctx, const amg_seqs* seqs, const int32_t* 
                              int64_t n_pairs, const int32_t* pair_a, const int32_t* pair_b, int64_t* sketch_size,
                              int64_t* common);
 
+/* needleman_wunsch (construct_graph.py:1433-1480) of two short lists of interned genes on the host: match 1, mismatch 0,
+ * gap -1, ties UP > LEFT > DIAG as the reference's max over (score, pointer) gives them.  ops (room for n + m), in
+ * alignment order: 0 = (x gene, y gene), 1 = (x gene, "*"), 2 = ("*", y gene). */
+int amg_nw_align(const int32_t* x, int32_t n, const int32_t* y, int32_t m, int8_t* ops, int32_t* n_ops);
+
 /* ---- multi-GPU: read-sharded build with a key-owner table merge — the single-graph result of
  *      build_multiprocessed_graph + merge_graphs (graph_utils.py:94-124) at cores = 1.
  *      One process per GPU; every rank holds a contiguous shard of the reads in its ctx (amg_set_reads), rank r the
