@@ -23,7 +23,6 @@ from collections import Counter, defaultdict
 import numpy as np
 
 from . import _ffi
-from .path_finding_utils import Tree
 
 _SEQS = {}   # (id(fastq_data), device) -> (fastq_data, Sequences, {read id: row}, number of reads)
 
@@ -340,16 +339,26 @@ class BubblePopping:
         return dict(ranked)
 
     def filter_paths_between_bubble_starts(self, unique_paths):
+        """the paths that hold no other path (read either way along) as a run of their own nodes, shortest first, with
+        their mean inner coverage (:2125-2146).  The reference asks a suffix tree over all paths for the paths that hold
+        path i; here every (node, direction) item lists where it occurs, and a path is looked for where its first item
+        occurs: the same hits, in time proportional to the occurrences instead of to all paths per question."""
         unique_paths = sorted(list(unique_paths), key=len)
-        tree = Tree({i: p for i, p in enumerate(unique_paths)})
+        keys = [tuple(q) for q in unique_paths]
+        occurrences = {}
+        for j, q in enumerate(keys):
+            for at, item in enumerate(q):
+                occurrences.setdefault(item, []).append((j, at))
         filtered_paths, contained = [], set()
         for i, p in enumerate(unique_paths):
             if i in contained:
                 continue
-            forward = list(p)
-            hits = [pid for pid, _ in tree.find_all(forward)] + [pid for pid, _ in tree.find_all(forward[::-1])]
-            contained.update(j for j in hits if j != i)
-            if len(p) > 2:
+            m = len(p)
+            for query in (keys[i], keys[i][::-1]):
+                for j, at in occurrences.get(query[0], ()) if m else ():
+                    if j != i and keys[j][at:at + m] == query:
+                        contained.add(j)
+            if m > 2:
                 filtered_paths.append((p, self.calculate_path_coverage(p)))
         return filtered_paths
 
@@ -382,6 +391,14 @@ class BubblePopping:
         return path_coverages
 
     def get_path_reads_to_correct(self, reads_to_correct, seen_nodes):
+        if not self._host_edits and seen_nodes:   # the nodes' reads straight from the device's node -> reads lists
+            v = self._v()
+            off, rows, ids, id_of = v.arrays["node_reads_off"], v.arrays["node_reads"], self._read_ids, v.node_of_hash
+            for node_hash, operation in seen_nodes.items():
+                i = id_of[node_hash]
+                for r in rows[off[i]:off[i + 1]].tolist():
+                    reads_to_correct.setdefault(ids[r], operation)
+            return
         for node_hash, operation in seen_nodes.items():
             for read in self.get_node_by_hash(node_hash).get_reads():
                 reads_to_correct.setdefault(read, operation)

@@ -1586,20 +1586,36 @@ class GeneMerGraph(BubblePopping):
             return None
         flip = self._vocab.two_v - 1
 
-        def edges_to(src, tgt):   # live edges src -> tgt, forward list first: what get_edge_hashes_between_nodes collects
-            lo, hi = int(adj_off[2 * src]), int(adj_off[2 * src + 2])
-            return [e for e in adj_edge[lo:hi].tolist() if e_alive[e] and e_tgt[e] == tgt]
+        # per node, the first time a path runs over it: its live edges as (target, source direction), forward list
+        # first — what get_edge_hashes_between_nodes collects from — and its tokens
+        out_edges, tokens_of = a.setdefault("_out_edges", {}), a.setdefault("_tokens_of", {})
+
+        def node_edges(i):
+            got = out_edges.get(i)
+            if got is None:
+                lo, hi = int(adj_off[2 * i]), int(adj_off[2 * i + 2])
+                es = adj_edge[lo:hi]
+                es = es[e_alive[es] != 0]
+                got = out_edges[i] = list(zip(e_tgt[es].tolist(), e_sdir[es].tolist()))
+            return got
+
+        def node_tokens(i):
+            got = tokens_of.get(i)
+            if got is None:
+                got = tokens_of[i] = n_tok[i].tolist()
+            return got
 
         genes = None
         k1 = self._kmerSize - 1
         for n in range(len(ids) - 1):
-            there, back = edges_to(ids[n], ids[n + 1]), edges_to(ids[n + 1], ids[n])
-            if len(there) != 1 or len(back) != 1:
+            src, tgt = ids[n], ids[n + 1]
+            there = [sd for t, sd in node_edges(src) if t == tgt]
+            if len(there) != 1 or sum(1 for t, _ in node_edges(tgt) if t == src) != 1:
                 return None
             if n == 0:
-                first = n_tok[ids[0]].tolist()
-                genes = first if int(e_sdir[there[0]]) == 1 else [flip - t for t in reversed(first)]
-            fw = n_tok[ids[n + 1]].tolist()
+                first = node_tokens(src)
+                genes = list(first) if there[0] == 1 else [flip - t for t in reversed(first)]
+            fw = node_tokens(tgt)
             tail = genes[-k1:] if k1 else genes[0:]
             if fw[:-1] == tail:
                 genes.append(fw[-1])

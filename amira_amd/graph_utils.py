@@ -148,27 +148,37 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
             new_annotatedReads, new_gene_position_dict = _tokenized(new_annotatedReads, new_gene_position_dict)
         except (KeyError, TypeError, ValueError, IndexError, AssertionError):
             pass   # (positions that do not cover the reads, ...: the dicts go through as they are)
-    for this_iteration in range(cleaning_iterations):
-        sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
-        graph = build_filtered_graph(_own(new_annotatedReads), geneMer_size, _own(new_gene_position_dict),
-                                     node_min_coverage, 1)
-        new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
-        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
-        if graph.get_total_number_of_nodes() == prev_nodes:
-            sys.stderr.write(f"\n\tAmira: terminating cleaning at iteration {this_iteration+1}\n")
-            break
-        prev_nodes = graph.get_total_number_of_nodes()
-        sys.stderr.write("\n\tAmira: removing dead ends\n")
-        short_reads.update(graph.get_short_read_annotations())
-        short_read_gene_positions.update(graph.get_short_read_gene_positions())
-        graph.remove_short_linear_paths(geneMer_size, _lazy_hashes=True)
-        new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
-        graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
-        short_reads.update(graph.get_short_read_annotations())
-        short_read_gene_positions.update(graph.get_short_read_gene_positions())
-        new_annotatedReads, new_gene_position_dict, path_coverages, min_path_coverage = (
-            graph.correct_low_coverage_paths(fastq_content, sample_genesOfInterest, cores,
-                                             min_path_coverage, components_to_skip, True))
+    # (the cyclic collector is paused for the run: the steps below make and drop millions of small containers — gene
+    # lists, position pairs, path tuples — none of them in cycles, and every pass of the collector over a heap that
+    # holds the reads of a whole sample costs more than the step that triggered it)
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        for this_iteration in range(cleaning_iterations):
+            sys.stderr.write(f"\nAmira: running graph cleaning iteration {this_iteration+1}\n")
+            graph = build_filtered_graph(_own(new_annotatedReads), geneMer_size, _own(new_gene_position_dict),
+                                         node_min_coverage, 1)
+            new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
+            graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+            if graph.get_total_number_of_nodes() == prev_nodes:
+                sys.stderr.write(f"\n\tAmira: terminating cleaning at iteration {this_iteration+1}\n")
+                break
+            prev_nodes = graph.get_total_number_of_nodes()
+            sys.stderr.write("\n\tAmira: removing dead ends\n")
+            short_reads.update(graph.get_short_read_annotations())
+            short_read_gene_positions.update(graph.get_short_read_gene_positions())
+            graph.remove_short_linear_paths(geneMer_size, _lazy_hashes=True)
+            new_annotatedReads, new_gene_position_dict = graph.correct_reads(fastq_content)
+            graph = build_multiprocessed_graph(new_annotatedReads, geneMer_size, 1, new_gene_position_dict)
+            short_reads.update(graph.get_short_read_annotations())
+            short_read_gene_positions.update(graph.get_short_read_gene_positions())
+            new_annotatedReads, new_gene_position_dict, path_coverages, min_path_coverage = (
+                graph.correct_low_coverage_paths(fastq_content, sample_genesOfInterest, cores,
+                                                 min_path_coverage, components_to_skip, True))
+    finally:
+        if gc_was_on:
+            gc.enable()
     if as_dicts and isinstance(new_annotatedReads, TokenizedReads):
         new_annotatedReads = {r: new_annotatedReads[r] for r in new_annotatedReads}
         new_gene_position_dict = {r: new_gene_position_dict[r] for r in new_gene_position_dict}

@@ -14,14 +14,23 @@ print(f"inputs: {time.perf_counter() - t:.2f} s", flush=True)
 n_windows = sum(max(0, len(v) - K + 1) for v in calls.values())
 
 
+ARRAYS = os.environ.get("PROBE_ARRAYS") == "1"
+if ARRAYS:
+    reads_t, pos_t = gu._tokenized(calls, pos)
+
+
 def drive():
     short, short_pos = {}, {}
     with tempfile.TemporaryDirectory() as tmp:
+        if ARRAYS:
+            a, b = reads_t, pos_t
+        else:
+            a, b = {r: list(v) for r, v in calls.items()}, {r: list(v) for r, v in pos.items()}
         t = time.perf_counter()
-        reads, positions = gu.iterative_bubble_popping({r: list(v) for r, v in calls.items()},
-                                                        {r: list(v) for r, v in pos.items()}, 3, K, 1, short, short_pos,
-                                                        fq, tmp, 3, set(), 2)
-        return time.perf_counter() - t, sum(len(v) for v in reads.values())
+        reads, positions = gu.iterative_bubble_popping(a, b, 3, K, 1, short, short_pos, fq, tmp, 3, set(), 2)
+        dt = time.perf_counter() - t
+        n = int(reads.settled().read_offsets[-1]) if ARRAYS else sum(len(v) for v in reads.values())
+        return dt, n
 
 
 with contextlib.redirect_stderr(io.StringIO()):
@@ -30,7 +39,7 @@ with contextlib.redirect_stderr(io.StringIO()):
     pr.enable()
     t1, genes = drive()
     pr.disable()
-print(f"N={N} L={L} V={V} k={K}: first call {t0:.2f} s, second {t1:.2f} s under cProfile, {n_windows / t1 / 1e6:.3f} M gene-mers/s, genes out {genes}")
+print(f"arrays={ARRAYS} N={N} L={L} V={V} k={K}: first call {t0:.2f} s, second {t1:.2f} s under cProfile, {n_windows / t1 / 1e6:.3f} M gene-mers/s, genes out {genes}")
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])
