@@ -66,9 +66,11 @@ def process_pandora_json(pandoraJSON, genesOfInterest, gene_positions):
 
 def trim_buffers():
     """give the loader's and the writers' cached work buffers back to the system (amg_calls_trim), and the arrays the
-    Python-side loader keeps for its next call (amira_amd.io: up to six token / position arrays of the last loads)"""
-    from . import io
+    Python-side loader keeps for its next call (amira_amd.io: up to six token / position arrays of the last loads), and
+    the reads' nucleotide sequences the last cleaning run left on the device (amira_amd.bubble_popping)"""
+    from . import bubble_popping, io
     io._pool.clear()
+    bubble_popping.release_sequences()   # (the reads' bases a cleaning run left on the device)
     n = C.c_int64(0)
     check(_ffi.lib.amg_calls_trim(C.byref(n)))
     return n.value
