@@ -133,3 +133,34 @@ def test_raw_calls_on_a_graph_without_junctions():
         assert found["path_off"].tolist() == [0]
     finally:
         e.close()
+
+
+def _cleaning_inputs(seed, N, L, V, err):
+    from amira_amd import synth
+    ids, sts = synth.loop_reads(seed, N, L, V, err, 0)
+    calls = synth.to_read_dict(ids, sts, synth.gene_names(V, 0))
+    pos = {r: [(80 * i, 80 * i + 59) for i in range(len(g))] for r, g in calls.items()}
+    return calls, pos, P.synth_fastq(calls, pos, flank=40)
+
+
+@pytest.mark.parametrize("case", [(81, 400, 30, 150, 3, 0.04), (82, 600, 40, 300, 5, 0.03)])
+def test_cleaning_run_from_arrays_from_dicts_and_by_objects(case, monkeypatch, tmp_path):
+    """iterative_bubble_popping (graph_utils.py:127-181): array-backed mappings in and out, dicts in and out (tokenised
+    once inside), and the reference-shaped way object by object give the same reads and positions"""
+    from amira_amd import graph_utils as gu
+    seed, N, L, V, k, err = case
+    calls, pos, fq = _cleaning_inputs(seed, N, L, V, err)
+
+    def run(reads, positions):
+        short, short_pos = {}, {}
+        r, p = gu.iterative_bubble_popping(reads, positions, 3, k, 1, short, short_pos, fq, str(tmp_path), 3, set(), 2)
+        return {x: list(r[x]) for x in r}, {x: [tuple(q) for q in p[x]] for x in p}, sorted(short)
+
+    copy = lambda: ({r: list(v) for r, v in calls.items()}, {r: list(v) for r, v in pos.items()})  # noqa: E731
+    from_dicts = run(*copy())
+    from_arrays = run(*gu._tokenized(*copy()))
+    monkeypatch.setenv("AMG_BUBBLES_BY_OBJECTS", "1")
+    by_objects = run(*copy())
+    assert from_arrays == from_dicts
+    assert by_objects == from_dicts
+    assert sum(len(v) for v in from_dicts[0].values()) > 0
