@@ -50,7 +50,7 @@ def test_random_bubble_popping_equals_oracle():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONHASHSEED="0", FUZZ_ONLY="bubbles")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "35", "424242"], env=env,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "20", "424242"], env=env,
                          capture_output=True, text=True, timeout=600)
     last = [l for l in out.stdout.splitlines() if l.startswith("fuzz_api:")]
     assert out.returncode == 0 and last, out.stdout[-2000:] + out.stderr[-2000:]
