@@ -415,9 +415,17 @@ class BubblePopping:
         self.get_path_reads_to_correct(reads_to_correct, seen_nodes)
         k = self.get_kmerSize()
         plans = {}   # operation -> (alignment, mirrored alignment, gene-mer counter, mirrored counter)
+        spelled = {}   # (a better path is the better path of several worse ones)
+
+        def genes_of(path):
+            got = spelled.get(path)
+            if got is None:
+                got = spelled[path] = self.get_genes_in_unitig(list(path))
+            return list(got)
+
         for operation in correction_operations:
-            better = self.get_genes_in_unitig(list(operation[1]))
-            worse = self.get_genes_in_unitig(list(operation[0]))
+            better = genes_of(operation[1])
+            worse = genes_of(operation[0])
             fw_alignment, rv_alignment, _, _ = self.compare_paths(worse, better)
             if any(low[1:] in genesOfInterest and high[1:] not in genesOfInterest for high, low in fw_alignment):
                 continue   # the correction would delete a gene of interest

@@ -1607,10 +1607,11 @@ class GeneMerGraph(BubblePopping):
 
         genes = None
         k1 = self._kmerSize - 1
+        edges = [node_edges(i) for i in ids]
         for n in range(len(ids) - 1):
             src, tgt = ids[n], ids[n + 1]
-            there = [sd for t, sd in node_edges(src) if t == tgt]
-            if len(there) != 1 or sum(1 for t, _ in node_edges(tgt) if t == src) != 1:
+            there = [sd for t, sd in edges[n] if t == tgt]
+            if len(there) != 1 or sum(1 for t, _ in edges[n + 1] if t == src) != 1:
                 return None
             if n == 0:
                 first = node_tokens(src)

@@ -180,8 +180,9 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
         if gc_was_on:
             gc.enable()
     if as_dicts and isinstance(new_annotatedReads, TokenizedReads):
-        new_annotatedReads = {r: new_annotatedReads[r] for r in new_annotatedReads}
-        new_gene_position_dict = {r: new_gene_position_dict[r] for r in new_gene_position_dict}
+        new_annotatedReads = new_annotatedReads.to_dict()
+        new_gene_position_dict = (new_gene_position_dict.to_dict() if hasattr(new_gene_position_dict, "to_dict")
+                                  else {r: new_gene_position_dict[r] for r in new_gene_position_dict})
     return new_annotatedReads, new_gene_position_dict
 
 

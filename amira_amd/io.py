@@ -174,6 +174,13 @@ class TokenizedReads(Mapping):
         return TokenizedReads(self.vocab, tokens[0], offs, self.read_ids, source_rows=self.source_rows,
                               source_ids=self.source_ids)
 
+    def to_dict(self):
+        """{read id: [genes]} as a plain dict: every gene spelled in ONE pass over the tokens, the reads cut out of that
+        list (a lookup per read decodes its own slice: a million small numpy slices)"""
+        s = self.settled()
+        genes, offs = s.vocab.decode(s.tokens), s.read_offsets.tolist()
+        return {r: genes[offs[i]:offs[i + 1]] for i, r in enumerate(s.read_ids)}
+
     def __iter__(self):
         return iter(self.read_ids)
 
@@ -281,6 +288,12 @@ class TokenizedPositions(Mapping):
         if self._moved is not None:
             c._moved = (self._moved[0].copy(), self._moved[1])
         return c
+
+    def to_dict(self):
+        """{read id: [(start, end), ...]} as a plain dict, the pairs made in one pass"""
+        s = self.settled()
+        pairs, offs = list(zip(s.gene_start.tolist(), s.gene_end.tolist())), s.read_offsets.tolist()
+        return {r: pairs[offs[i]:offs[i + 1]] for i, r in enumerate(s.read_ids)}
 
     def replace_rows(self, rows, other, other_rows):
         """the positions of reads `rows` (indices into read_ids) are from now on rows `other_rows` of the

@@ -737,13 +737,18 @@ def run_bubbles(local_rank, with_cpu=True):
                    "_path_overlaps_on_device": gu.GeneMerGraph._path_overlaps_on_device,
                    "filter_paths_between_bubble_starts": gu.GeneMerGraph.filter_paths_between_bubble_starts,
                    "correct_bubble_paths": gu.GeneMerGraph.correct_bubble_paths}
+        seq_fn = bp._sequences_for
         try:
             for name, fn in patched.items():
                 setattr(gu.GeneMerGraph, name, timed(name, fn))
+            bp._sequences_for = timed("_sequences_for", seq_fn)
+            bp.release_sequences()   # (a cleaning run uploads its reads' bases once: inside the clock)
             t_arr, out_arr = drive(gu, reads_t, pos_t, fq, k)
         finally:
+            bp._sequences_for = seq_fn
             for name, fn in patched.items():
                 setattr(gu.GeneMerGraph, name, fn)
+        bp.release_sequences()
         t_dict, out_dict = drive(gu, {r: list(v) for r, v in calls.items()}, {r: list(v) for r, v in pos.items()}, fq, k)
     genes_arr = int(out_arr.settled().read_offsets[-1])
     out["iterative_bubble_popping"] = {
@@ -755,6 +760,7 @@ def run_bubbles(local_rank, with_cpu=True):
                               "  paths between junctions (device search + hashing the nodes' names)": round(lap.get("_junction_paths_on_device", 0.0), 3),
                               "  path filter": round(lap.get("filter_paths_between_bubble_starts", 0.0), 3),
                               "  sketches and overlaps (device)": round(lap.get("_path_overlaps_on_device", 0.0), 3),
+                              "    of which the reads' bases to the device, once (PCIe)": round(lap.get("_sequences_for", 0.0), 3),
                               "  operations + rewriting the reads": round(lap.get("correct_bubble_paths", 0.0), 3),
                               "cleaning sweeps (9 builds, 6 corrections, 3 clips) and the rest": round(t_arr - lap.get("correct_low_coverage_paths", 0.0), 3)},
         "from_dicts": {"s_per_call": round(t_dict, 3), "gene_mers_per_s": n_windows / t_dict,

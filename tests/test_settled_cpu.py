@@ -115,3 +115,17 @@ def test_native_alignment_equals_the_python_table(seed, monkeypatch):
         got.append((x[i], y[j]) if op == 0 else (x[i], "*") if op == 1 else ("*", y[j]))
         i, j = i + (op != 2), j + (op != 1)
     assert got == want
+
+
+def test_plain_dicts_of_settled_mappings():
+    rng = np.random.default_rng(5)
+    reads = _reads(rng)
+    ids = list(reads)
+    pos = _positions(reads)
+    t = TokenizedReads(*tokenize(reads))
+    p = TokenizedPositions(ids, t.read_offsets, *_flat(pos, ids))
+    t["r2"] = ["+g1", "-g2", "+g3"]
+    p["r2"] = [(1, 2), (3, 4), (5, 6)]
+    reads["r2"], pos["r2"] = ["+g1", "-g2", "+g3"], [(1, 2), (3, 4), (5, 6)]
+    assert t.to_dict() == reads and list(t.to_dict()) == ids
+    assert p.to_dict() == {r: list(v) for r, v in pos.items()}
