@@ -841,18 +841,6 @@ extern "C" int amg_path_sketch_overlaps(amg_ctx* c, const amg_seqs* seqs, const 
   return finish();
 }
 
-// test hook (not part of include/amg.h): the intermediate arrays of the last amg_path_sketch_overlaps call
-extern "C" int amg_bubbles_debug_copy(amg_ctx* c, int32_t which, void* out, int64_t bytes) {
-  if (!c || !c->bub || !out) return amg_fail(AMG_E_ARG, "nothing to copy");
-  BubbleState* b = c->bub;
-  DevBuf* src[] = {&b->segs, &b->out_h, &b->srt_h, &b->out_p, &b->srt_i, &b->h2, &b->srt_p, &b->noff, &b->nlist, &b->pstart};
-  if (which < 0 || which >= (int)(sizeof(src) / sizeof(src[0]))) return amg_fail(AMG_E_ARG, "which");
-  if ((size_t)bytes > src[which]->cap) return amg_fail(AMG_E_ARG, "more than the buffer holds");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpy(out, src[which]->p, (size_t)bytes, hipMemcpyDeviceToHost));
-  return AMG_OK;
-}
-
 // ------------------------------------------------------------------ the alignment of two short gene lists (host)
 // needleman_wunsch (construct_graph.py:1433-1480) on interned genes: match 1, mismatch 0, gap -1, borders -index, the
 // best of (score, pointer) with the pointers ordered DIAG < LEFT < UP — a tie goes UP, then LEFT.  ops, in alignment
