@@ -16,6 +16,7 @@ class AmgError(RuntimeError):
 
 
 E_PALINDROME = -4
+E_NOMEM = -6
 MAX_K = 16
 
 

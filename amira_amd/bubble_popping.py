@@ -482,7 +482,7 @@ class BubblePopping:
         between the same terminals, the one of higher coverage first (the order correct_bubble_paths sorts them in)"""
         if self._host_edits or os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
             return None
-        index_of, path_ids, pair_a, pair_b = {}, [], [], []
+        index_of, path_ids, groups = {}, [], []
         node_id = self._v().node_of_hash
         for entries in bubbles.values():
             if len(entries) < 2:
@@ -494,24 +494,47 @@ class BubblePopping:
                     index_of[key] = len(path_ids)
                     path_ids.append([node_id[h] for h in key])
                 group.append(index_of[key])
-            for a in range(len(group)):
-                for b in range(a + 1, len(group)):
-                    pair_a.append(group[a])
-                    pair_b.append(group[b])
-        if not pair_a:
+            groups.append(group)
+        if not groups:
             return _PathOverlaps({}, [], {})
+        size, common_of = [0] * len(path_ids), {}
         try:
             _, seqs, row_of, _ = _sequences_for(fastq_data, self._engine.device)
             rows = np.fromiter((row_of.get(r, -1) for r in self._read_ids), np.int32, len(self._read_ids))
             identity = len(rows) <= seqs.n and bool((rows == np.arange(len(rows), dtype=np.int32)).all())
-            path_off = np.zeros(len(path_ids) + 1, np.int64)
-            np.cumsum([len(p) for p in path_ids], out=path_off[1:])
-            flat = np.fromiter((x for p in path_ids for x in p), np.int32, int(path_off[-1]))
-            size, common = self._engine.path_sketch_overlaps(seqs, None if identity else rows, 11, 10, path_off, flat,
-                                                             pair_a, pair_b)
+
+            def compare(some):
+                """the paths of these groups in one call; a call too big for the device's buffers is cut in two"""
+                local, pair_a, pair_b = {}, [], []
+                for group in some:
+                    for p in group:
+                        local.setdefault(p, len(local))
+                    for a in range(len(group)):
+                        for b in range(a + 1, len(group)):
+                            pair_a.append(local[group[a]])
+                            pair_b.append(local[group[b]])
+                order = list(local)
+                path_off = np.zeros(len(order) + 1, np.int64)
+                np.cumsum([len(path_ids[p]) for p in order], out=path_off[1:])
+                flat = np.fromiter((x for p in order for x in path_ids[p]), np.int32, int(path_off[-1]))
+                try:
+                    got_size, got_common = self._engine.path_sketch_overlaps(
+                        seqs, None if identity else rows, 11, 10, path_off, flat, pair_a, pair_b)
+                except _ffi.AmgError as err:
+                    if err.code != _ffi.E_NOMEM or len(some) < 2:
+                        raise
+                    compare(some[:len(some) // 2])
+                    compare(some[len(some) // 2:])
+                    return
+                for p, n in zip(order, got_size.tolist()):
+                    size[p] = n
+                for a, b, n in zip(pair_a, pair_b, got_common.tolist()):
+                    common_of[(order[a], order[b])] = n
+
+            compare(groups)
         except (_ffi.AmgError, KeyError, TypeError):
             return None   # (a read without a sequence, a position below zero, ...: the objects' way says what the reference says)
-        return _PathOverlaps(index_of, size.tolist(), dict(zip(zip(pair_a, pair_b), common.tolist())))
+        return _PathOverlaps(index_of, size, common_of)
 
     def correct_low_coverage_paths(self, fastq_data, genesOfInterest, cores, min_path_coverage,
                                    components_to_skip, use_minimizers=False):

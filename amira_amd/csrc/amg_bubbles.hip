@@ -808,7 +808,9 @@ extern "C" int amg_path_sketch_overlaps(amg_ctx* c, const amg_seqs* seqs, const 
   }
   const long long M = (long long)got[0];
   if (M == 0) return finish();
-  if (M >= (1ll << 32)) {
+  long long max_pairs = 1ll << 30;  // (40 bytes of buffers per pair; the sorts index pairs with 32 bits)
+  if (const char* e = getenv("AMG_TEST_SKETCH_PAIRS")) max_pairs = atoll(e);  // test hook: callers split their paths
+  if (M >= max_pairs) {
     stage_end(c);
     return amg_fail(AMG_E_NOMEM, "%lld (path, hash) pairs in one call: split the paths", M);
   }

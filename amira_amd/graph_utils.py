@@ -179,6 +179,8 @@ def iterative_bubble_popping(new_annotatedReads, new_gene_position_dict, cleanin
     finally:
         if gc_was_on:
             gc.enable()
+        from .bubble_popping import release_sequences
+        release_sequences()   # (the reads' bases went to the device once for this run: not kept beyond it)
     if as_dicts and isinstance(new_annotatedReads, TokenizedReads):
         new_annotatedReads = new_annotatedReads.to_dict()
         new_gene_position_dict = (new_gene_position_dict.to_dict() if hasattr(new_gene_position_dict, "to_dict")

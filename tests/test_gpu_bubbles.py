@@ -164,3 +164,39 @@ def test_cleaning_run_from_arrays_from_dicts_and_by_objects(case, monkeypatch, t
     assert from_arrays == from_dicts
     assert by_objects == from_dicts
     assert sum(len(v) for v in from_dicts[0].values()) > 0
+
+
+def test_sketch_calls_too_big_for_one_go_are_split(monkeypatch):
+    """amg_path_sketch_overlaps refuses more (path, hash) pairs than its buffers are meant for (AMG_E_NOMEM); the
+    caller then compares the groups of paths in halves — same sizes, same overlaps"""
+    g, fq = _graph(*CASES[4])
+    if g is None:
+        pytest.skip("palindromic gene-mer")
+    calls = []
+    inner = g._engine.path_sketch_overlaps
+    monkeypatch.setattr(g._engine, "path_sketch_overlaps", lambda *a, **k: (calls.append(1), inner(*a, **k))[1])
+    starts = g.identify_potential_bubble_starts()
+    split = 0
+    for component, junctions in starts.items():
+        unique = g.get_all_paths_between_junctions_in_component(junctions, g.get_kmerSize() * 4, 1)
+        shortest_first = sorted(g.filter_paths_between_bubble_starts(unique), key=lambda e: len(e[0]))
+        bubbles = g.separate_paths_by_terminal_nodes(shortest_first)
+        monkeypatch.delenv("AMG_TEST_SKETCH_PAIRS", raising=False)
+        whole = g._path_overlaps_on_device(bubbles, fq)
+        assert whole is not None
+        if sum(1 for e in bubbles.values() if len(e) > 1) < 2:
+            continue
+        cap = 64 * sum(whole._size) + 64
+        while cap > 16:    # ever smaller buffers, until the one call no longer fits and halves of it do
+            monkeypatch.setenv("AMG_TEST_SKETCH_PAIRS", str(cap))
+            del calls[:]
+            halves = g._path_overlaps_on_device(bubbles, fq)
+            if halves is None:
+                break      # (one group alone is beyond this cap)
+            assert halves._size == whole._size and halves._common_of == whole._common_of
+            if len(calls) > 1:
+                split += 1
+                break
+            cap //= 2
+    monkeypatch.delenv("AMG_TEST_SKETCH_PAIRS", raising=False)
+    assert split > 0 or not starts
