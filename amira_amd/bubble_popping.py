@@ -466,7 +466,7 @@ class BubblePopping:
         v = self._v()
         nodes = v.arrays["nodes"]
         component_of = nodes["component"]
-        components = sorted(set(component_of[nodes["alive"] != 0].tolist()))
+        components = np.unique(component_of[nodes["alive"] != 0]).tolist()   # (= sorted({n.get_component() for live n}))
         start_component = component_of[found["junction_node"]]
         by_component = {int(c): [] for c in np.unique(start_component).tolist()}
         off, ids, dirs = found["path_off"].tolist(), found["path_node"], found["path_dir"].tolist()
