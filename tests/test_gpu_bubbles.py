@@ -99,7 +99,7 @@ def test_sequences_in_another_order_than_the_reads():
         assert one._size == two._size and one._common_of == two._common_of
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + [(91, 2000, 60, 800, 5, 0.02)])   # (the last one: hundreds of junctions)
 def test_whole_step_equals_the_objects_way(case, monkeypatch):
     def run(by_objects):
         if by_objects:
