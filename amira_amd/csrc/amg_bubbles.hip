@@ -16,7 +16,7 @@
 //
 // What decides with these numbers (which path of a pair is the better one, which reads are rewritten) stays host-side
 // orchestration over a handful of paths, as in the reference (amira_amd/bubble_popping.py).
-#include "amg_device.h"
+#include "amg_kmer.h"
 
 #include <algorithm>
 
@@ -493,49 +493,8 @@ __global__ __launch_bounds__(256) void k_bs_segs(const int* __restrict__ tok_nod
   segs[base + (unsigned long long)__popcll(vote & ((1ull << lane) - 1ull))] = s;
 }
 
-// MurmurHash3_x64_128's first word over a canonical k-mer (amg_minhash.hip holds the definition and its source)
-__device__ __forceinline__ unsigned long long bs_rotl(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
-__device__ __forceinline__ unsigned long long bs_fmix(unsigned long long k) {
-  k ^= k >> 33;
-  k *= 0xFF51AFD7ED558CCDull;
-  k ^= k >> 33;
-  k *= 0xC4CEB9FE1A85EC53ull;
-  k ^= k >> 33;
-  return k;
-}
-__device__ __forceinline__ unsigned long long bs_murmur_h1(const unsigned char* d, int len, unsigned long long seed) {
-  const unsigned long long c1 = 0x87C37B91114253D5ull, c2 = 0x4CF5AD432745937Full;
-  unsigned long long h1 = seed, h2 = seed;
-  int off = 0;
-  for (; off + 16 <= len; off += 16) {
-    unsigned long long k1 = 0, k2 = 0;
-    for (int b = 0; b < 8; ++b) {
-      k1 |= (unsigned long long)d[off + b] << (8 * b);
-      k2 |= (unsigned long long)d[off + 8 + b] << (8 * b);
-    }
-    k1 *= c1; k1 = bs_rotl(k1, 31); k1 *= c2; h1 ^= k1;
-    h1 = bs_rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52DCE729ull;
-    k2 *= c2; k2 = bs_rotl(k2, 33); k2 *= c1; h2 ^= k2;
-    h2 = bs_rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495AB5ull;
-  }
-  const int t = len - off;
-  unsigned long long k1 = 0, k2 = 0;
-  for (int b = 8; b < t; ++b) k2 |= (unsigned long long)d[off + b] << (8 * (b - 8));
-  for (int b = 0; b < t && b < 8; ++b) k1 |= (unsigned long long)d[off + b] << (8 * b);
-  if (t > 8) { k2 *= c2; k2 = bs_rotl(k2, 33); k2 *= c1; h2 ^= k2; }
-  if (t > 0) { k1 *= c1; k1 = bs_rotl(k1, 31); k1 *= c2; h1 ^= k1; }
-  h1 ^= (unsigned long long)len;
-  h2 ^= (unsigned long long)len;
-  h1 += h2; h2 += h1;
-  h1 = bs_fmix(h1); h2 = bs_fmix(h2);
-  h1 += h2;
-  return h1;
-}
-__device__ __forceinline__ unsigned char bs_upper(unsigned char c) { return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c; }
-__device__ __forceinline__ unsigned char bs_comp(unsigned char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
-
 #define BS_CHUNK 1024
-#define BS_MAX_K 32
+#define BS_MAX_K KM_MAX_K
 #define BS_WPB 4
 
 // One WAVE per segment: the segment goes through the wave's slab of LDS a chunk at a time (k - 1 bases of overlap), lane
@@ -543,7 +502,7 @@ __device__ __forceinline__ unsigned char bs_comp(unsigned char c) { return c == 
 // path that lists the segment's node.  EMIT = false counts the pairs of every segment (seg_cnt), EMIT = true writes them
 // behind the segment's own offset (seg_base = the prefix sums of the counts): no counter is shared between waves — one
 // returning atomic per wave and round on a single word was five sixths of this kernel's time.
-template <bool EMIT>
+template <bool EMIT, int NW>  // NW: words of a k-mer, (ksize + 7) / 8 (amg_kmer.h)
 __global__ __launch_bounds__(64 * BS_WPB) void k_bs_hash(const BsSeg* __restrict__ segs, long long n_segs,
                                                          const unsigned char* __restrict__ bases, int ksize,
                                                          unsigned long long max_hash, const long long* __restrict__ noff,
@@ -551,7 +510,7 @@ __global__ __launch_bounds__(64 * BS_WPB) void k_bs_hash(const BsSeg* __restrict
                                                          const long long* __restrict__ seg_base,
                                                          long long cap, unsigned int* __restrict__ out_p,
                                                          unsigned long long* __restrict__ out_h) {
-  __shared__ unsigned char s_b[BS_WPB][BS_CHUNK + BS_MAX_K];
+  __shared__ __attribute__((aligned(8))) unsigned char s_b[BS_WPB][BS_CHUNK + BS_MAX_K + 24];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long si = (long long)blockIdx.x * BS_WPB + wv;
   if (si >= n_segs) return;
@@ -562,7 +521,7 @@ __global__ __launch_bounds__(64 * BS_WPB) void k_bs_hash(const BsSeg* __restrict
   unsigned char* sb = s_b[wv];
   for (int c0 = 0; c0 + ksize <= sg.len; c0 += BS_CHUNK) {
     const int have = min(sg.len - c0, BS_CHUNK + ksize - 1);
-    for (int i = lane; i < have; i += 64) sb[i] = bs_upper(bases[sg.src + c0 + i]);
+    for (int i = lane; i < have + 24; i += 64) sb[i] = i < have ? km_stage(bases[sg.src + c0 + i]) : (unsigned char)0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int starts = have - ksize + 1;
@@ -570,24 +529,7 @@ __global__ __launch_bounds__(64 * BS_WPB) void k_bs_hash(const BsSeg* __restrict
       const int i = i0 + lane;
       bool keep = false;
       unsigned long long hv = 0;
-      if (i < starts) {
-        unsigned char fw[BS_MAX_K], rc[BS_MAX_K];
-        bool valid = true;
-        for (int j = 0; j < ksize; ++j) {
-          const unsigned char ch = sb[i + j];
-          valid = valid && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
-          fw[j] = ch;
-        }
-        if (valid) {
-          int cmp = 0;
-          for (int j = 0; j < ksize; ++j) {
-            rc[j] = bs_comp(fw[ksize - 1 - j]);
-            if (cmp == 0 && fw[j] != rc[j]) cmp = fw[j] < rc[j] ? -1 : 1;
-          }
-          hv = bs_murmur_h1(cmp <= 0 ? fw : rc, ksize, 42ull);
-          keep = hv <= max_hash;
-        }
-      }
+      if (i < starts) keep = km_canonical_hash<NW>(sb, i, ksize, &hv) && hv <= max_hash;
       const unsigned long long vote = __ballot(keep);
       if (vote == 0ull) continue;
       const unsigned long long n_keep = (unsigned long long)__popcll(vote);
@@ -781,7 +723,10 @@ extern "C" int amg_path_sketch_overlaps(amg_ctx* c, const amg_seqs* seqs, const 
     cl.add(b->seg_cnt.as<long long>() + n_segs, sizeof(long long));
     AMGCHK(clear_many(c, cl));
   }
-  hipLaunchKernelGGL(k_bs_hash<false>, dim3(nblk((long long)n_segs, BS_WPB)), dim3(64 * BS_WPB), 0, st, b->segs.as<BsSeg>(),
+  const int nw = ((int)ksize + 7) / 8;
+  auto count_kernel = nw == 1 ? k_bs_hash<false, 1> : nw == 2 ? k_bs_hash<false, 2> : nw == 3 ? k_bs_hash<false, 3> : k_bs_hash<false, 4>;
+  auto emit_kernel = nw == 1 ? k_bs_hash<true, 1> : nw == 2 ? k_bs_hash<true, 2> : nw == 3 ? k_bs_hash<true, 3> : k_bs_hash<true, 4>;
+  hipLaunchKernelGGL(count_kernel, dim3(nblk((long long)n_segs, BS_WPB)), dim3(64 * BS_WPB), 0, st, b->segs.as<BsSeg>(),
                      (long long)n_segs, seqs->bases.as<unsigned char>(), (int)ksize, max_hash, b->noff.as<long long>(),
                      b->nlist.as<int>(), b->seg_cnt.as<long long>(), (const long long*)nullptr, 0ll, (unsigned int*)nullptr,
                      (unsigned long long*)nullptr);
@@ -821,7 +766,7 @@ extern "C" int amg_path_sketch_overlaps(amg_ctx* c, const amg_seqs* seqs, const 
   AMGCHK(b->srt_i.ensure((size_t)(M + 1) * sizeof(unsigned int)));
   AMGCHK(b->iota.ensure((size_t)(M + 1) * sizeof(unsigned int)));
   AMGCHK(b->h2.ensure((size_t)(M + 1) * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(k_bs_hash<true>, dim3(nblk((long long)n_segs, BS_WPB)), dim3(64 * BS_WPB), 0, st, b->segs.as<BsSeg>(),
+  hipLaunchKernelGGL(emit_kernel, dim3(nblk((long long)n_segs, BS_WPB)), dim3(64 * BS_WPB), 0, st, b->segs.as<BsSeg>(),
                      (long long)n_segs, seqs->bases.as<unsigned char>(), (int)ksize, max_hash, b->noff.as<long long>(),
                      b->nlist.as<int>(), (long long*)nullptr, b->seg_base.as<long long>(), M, b->out_p.as<unsigned int>(),
                      b->out_h.as<unsigned long long>());

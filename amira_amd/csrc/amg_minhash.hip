@@ -9,73 +9,45 @@
 // kept when hash <= max_hash (2^64 - 1 for scaled = 1, round(2^64 / scaled) otherwise).
 //
 // One thread per k-mer start.  A block stages its 1024 + ksize - 1 bases in LDS (one coalesced
-// read of the byte stream), every thread cuts its window from LDS, hashes it and the survivors
-// are compacted with a block scan + one atomicAdd per block.  Segments are told apart by a
+// read of the byte stream; upper case, 0 for anything outside ACGT), every thread takes its k-mer
+// out of LDS as 64-bit words, reverse-complements, compares and hashes it a word at a time
+// (amg_kmer.h) and the survivors are compacted with a block scan + one atomicAdd per block.  Segments are told apart by a
 // per-base segment id found by binary search over the (few) segment offsets of the tile.
 // Algorithmic traffic: 1 byte read per base, 12 bytes written per kept hash (1/scaled of them):
 // an HBM stream, integer work only.
-#include "amg_device.h"
+#include "amg_kmer.h"
 
 #define MH_TILE 1024
-#define MH_MAX_K 32
+#define MH_MAX_K KM_MAX_K
 
-__device__ __forceinline__ unsigned long long mh_rotl(unsigned long long x, int r) { return (x << r) | (x >> (64 - r)); }
-__device__ __forceinline__ unsigned long long mh_fmix(unsigned long long k) {
-  k ^= k >> 33;
-  k *= 0xFF51AFD7ED558CCDull;
-  k ^= k >> 33;
-  k *= 0xC4CEB9FE1A85EC53ull;
-  k ^= k >> 33;
-  return k;
-}
-
-// first half of MurmurHash3_x64_128 (Austin Appleby, public domain) of len <= 32 bytes
-__device__ __forceinline__ unsigned long long mh_murmur_h1(const unsigned char* d, int len, unsigned long long seed) {
-  const unsigned long long c1 = 0x87C37B91114253D5ull, c2 = 0x4CF5AD432745937Full;
-  unsigned long long h1 = seed, h2 = seed;
-  int off = 0;
-  for (; off + 16 <= len; off += 16) {
-    unsigned long long k1 = 0, k2 = 0;
-    for (int b = 0; b < 8; ++b) {
-      k1 |= (unsigned long long)d[off + b] << (8 * b);
-      k2 |= (unsigned long long)d[off + 8 + b] << (8 * b);
-    }
-    k1 *= c1; k1 = mh_rotl(k1, 31); k1 *= c2; h1 ^= k1;
-    h1 = mh_rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52DCE729ull;
-    k2 *= c2; k2 = mh_rotl(k2, 33); k2 *= c1; h2 ^= k2;
-    h2 = mh_rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495AB5ull;
-  }
-  const int t = len - off;
-  unsigned long long k1 = 0, k2 = 0;
-  for (int b = 8; b < t; ++b) k2 |= (unsigned long long)d[off + b] << (8 * (b - 8));
-  for (int b = 0; b < t && b < 8; ++b) k1 |= (unsigned long long)d[off + b] << (8 * b);
-  if (t > 8) { k2 *= c2; k2 = mh_rotl(k2, 33); k2 *= c1; h2 ^= k2; }
-  if (t > 0) { k1 *= c1; k1 = mh_rotl(k1, 31); k1 *= c2; h1 ^= k1; }
-  h1 ^= (unsigned long long)len;
-  h2 ^= (unsigned long long)len;
-  h1 += h2; h2 += h1;
-  h1 = mh_fmix(h1); h2 = mh_fmix(h2);
-  h1 += h2;
-  return h1;
-}
-
-__device__ __forceinline__ unsigned char mh_upper(unsigned char c) { return (c >= 'a' && c <= 'z') ? (unsigned char)(c - 32) : c; }
-__device__ __forceinline__ unsigned char mh_comp(unsigned char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
-
+template <int NW>  // words of a k-mer: (ksize + 7) / 8
 __global__ __launch_bounds__(256) void k_minhash(const unsigned char* __restrict__ bases, long long n_bases,
                                                  const long long* __restrict__ seg_off, const int* __restrict__ seg_set,
                                                  long long n_seg, int ksize, unsigned long long max_hash,
                                                  unsigned long long* counter, long long cap,
                                                  int* __restrict__ out_set, unsigned long long* __restrict__ out_hash) {
-  __shared__ unsigned char s_b[MH_TILE + MH_MAX_K];
+  __shared__ __attribute__((aligned(8))) unsigned char s_b[MH_TILE + MH_MAX_K + 24];
   __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
   const long long t0 = (long long)blockIdx.x * MH_TILE;
-  for (int i = threadIdx.x; i < MH_TILE + ksize - 1; i += 256) {
+  for (int i = threadIdx.x; i < MH_TILE + MH_MAX_K + 24; i += 256) {
     const long long t = t0 + i;
-    s_b[i] = t < n_bases ? mh_upper(bases[t]) : (unsigned char)'N';
+    s_b[i] = (i < MH_TILE + ksize - 1 && t < n_bases) ? km_stage(bases[t]) : (unsigned char)0;
+  }
+  // the segments this tile's bases lie in: two searches over all offsets per block, then every thread looks among
+  // those few (a search over all of them per k-mer start was half of this kernel's time)
+  __shared__ long long s_seg[2];
+  if (threadIdx.x < 2) {
+    const long long t = threadIdx.x == 0 ? t0 : (t0 + MH_TILE - 1 < n_bases ? t0 + MH_TILE - 1 : n_bases - 1);
+    long long lo = 0, hi = n_seg;  // seg_off[lo] <= t < seg_off[hi]
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (seg_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    s_seg[threadIdx.x] = lo;
   }
   __syncthreads();
+  const long long seg_lo = s_seg[0], seg_hi = s_seg[1] + 1;
   unsigned long long h[4];
   int set[4];
   unsigned int keep = 0;
@@ -85,26 +57,14 @@ __global__ __launch_bounds__(256) void k_minhash(const unsigned char* __restrict
     const long long t = t0 + i;
     if (t + ksize > n_bases) continue;
     // the segment this base belongs to: last offset <= t
-    long long lo = 0, hi = n_seg;  // seg_off[lo] <= t < seg_off[hi]
+    long long lo = seg_lo, hi = seg_hi;  // seg_off[lo] <= t < seg_off[hi]
     while (hi - lo > 1) {
       const long long mid = (lo + hi) >> 1;
       if (seg_off[mid] <= t) lo = mid; else hi = mid;
     }
     if (t + ksize > seg_off[lo + 1]) continue;  // the window runs over the end of its segment
-    unsigned char fw[MH_MAX_K], rc[MH_MAX_K];
-    bool valid = true;
-    for (int j = 0; j < ksize; ++j) {
-      const unsigned char c = s_b[i + j];
-      valid = valid && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
-      fw[j] = c;
-    }
-    if (!valid) continue;  // force=True: windows with other characters are skipped
-    int cmp = 0;
-    for (int j = 0; j < ksize; ++j) {
-      rc[j] = mh_comp(fw[ksize - 1 - j]);
-      if (cmp == 0 && fw[j] != rc[j]) cmp = fw[j] < rc[j] ? -1 : 1;
-    }
-    const unsigned long long hv = mh_murmur_h1(cmp <= 0 ? fw : rc, ksize, 42ull);
+    unsigned long long hv;
+    if (!km_canonical_hash<NW>(s_b, i, ksize, &hv)) continue;  // force=True: windows with other characters are skipped
     if (hv <= max_hash) {
       h[it] = hv;
       set[it] = seg_set[lo];
@@ -171,7 +131,8 @@ extern "C" int amg_minhash(amg_ctx* c, const uint8_t* bases, const int64_t* seg_
   stages_reset(c);
   stage_begin(c, "minhash");
   const unsigned int blocks = (unsigned int)((n_bases + MH_TILE - 1) / MH_TILE);
-  hipLaunchKernelGGL(k_minhash, dim3(blocks), dim3(256), 0, st, d_b.as<unsigned char>(), (long long)n_bases,
+  auto kern = ksize <= 8 ? k_minhash<1> : ksize <= 16 ? k_minhash<2> : ksize <= 24 ? k_minhash<3> : k_minhash<4>;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, d_b.as<unsigned char>(), (long long)n_bases,
                      d_off.as<long long>(), d_set.as<int>(), (long long)n_seg, (int)ksize, max_hash, ctr,
                      (long long)want, d_os.as<int>(), d_oh.as<unsigned long long>());
   stage_end(c);

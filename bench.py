@@ -696,9 +696,10 @@ def run_bubbles(local_rank, with_cpu=True):
                          "achieved": alg / (best_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bases_per_s": len(bases) / (best_ms * 1e-3),
-                         "note": "one thread hashes one k-mer start (MurmurHash3_x64_128 over the canonical 11-mer: ~150 "
-                                 "integer instructions per byte read): the kernel is bound by instruction issue, not by "
-                                 "bytes — the fraction says how far from the HBM line it sits, not that bytes are wasted"}}
+                         "note": "one thread hashes one k-mer start (MurmurHash3_x64_128 over the canonical 11-mer, the k-mer "
+                                 "taken, reverse-complemented and compared as 64-bit words: ~ten 64-bit multiplies per "
+                                 "byte read): the kernel is bound by instruction issue, not by bytes — the fraction says "
+                                 "how far from the HBM line it sits, not that bytes are wasted"}}
     finally:
         eng.close()
     # ---- the driver on reads with nucleotide sequences: three cleaning iterations with bubble popping, at a real size
