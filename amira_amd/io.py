@@ -125,6 +125,8 @@ class TokenizedReads(Mapping):
 
     def subset(self, rows):
         """the reads at `rows` (indices into read_ids), in that order, as a TokenizedReads of their own"""
+        if self.edited():
+            return self.settled().subset(rows)
         rows = np.asarray(rows, dtype=np.int64)
         idx, new_off = _gather_rows(self.read_offsets, rows)
         ids = np.asarray(self.read_ids, dtype=object)[rows].tolist()

@@ -15,22 +15,18 @@ import numpy as np
 from .io import TokenizedPositions, TokenizedReads, write_gene_calls, write_gene_positions
 
 
-def _plain_positions(p):
-    """a TokenizedPositions whose rows can be written straight from its arrays (no redirected or hand-set rows)"""
-    return isinstance(p, TokenizedPositions) and p._moved is None and not p._cache
-
-
 def write_pandora_gene_calls(output_dir, gene_position_dict, annotatedReads, outfile_1, outfile_2):
     """result_utils.py:1260-1264: json.dumps(annotatedReads) -> outfile_1, json.dumps(gene_position_dict) -> outfile_2
     (output_dir is not used there either)."""
     jobs = []
+    # (reads bubble popping rewrote and positions a correction redirected are spelled into the arrays first: .settled())
     if isinstance(annotatedReads, TokenizedReads):
-        r = annotatedReads
+        r = annotatedReads.settled()
         jobs.append(lambda: write_gene_calls(outfile_1, r.vocab, r.tokens, r.read_offsets, r.read_ids))
     else:
         jobs.append(lambda: _dump(outfile_1, annotatedReads))
-    if _plain_positions(gene_position_dict):
-        p = gene_position_dict
+    if isinstance(gene_position_dict, TokenizedPositions):
+        p = gene_position_dict.settled()
         jobs.append(lambda: write_gene_positions(outfile_2, p.gene_start, p.gene_end, p.read_offsets, p.read_ids))
     else:
         jobs.append(lambda: _dump(outfile_2, gene_position_dict))

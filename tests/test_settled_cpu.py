@@ -129,3 +129,22 @@ def test_plain_dicts_of_settled_mappings():
     reads["r2"], pos["r2"] = ["+g1", "-g2", "+g3"], [(1, 2), (3, 4), (5, 6)]
     assert t.to_dict() == reads and list(t.to_dict()) == ids
     assert p.to_dict() == {r: list(v) for r, v in pos.items()}
+
+
+def test_writers_see_the_reads_and_positions_replaced_by_hand(tmp_path):
+    """write_pandora_gene_calls (result_utils.py:1260-1264) on array-backed mappings after bubble popping rewrote reads"""
+    import json
+    from amira_amd.result_utils import write_pandora_gene_calls
+    rng = np.random.default_rng(9)
+    reads = _reads(rng)
+    ids = list(reads)
+    pos = _positions(reads)
+    t = TokenizedReads(*tokenize(reads))
+    p = TokenizedPositions(ids, t.read_offsets, *_flat(pos, ids))
+    t["r5"], p["r5"] = ["-g3", "+g1"], [(7, 9), (11, 15)]
+    reads["r5"], pos["r5"] = ["-g3", "+g1"], [(7, 9), (11, 15)]
+    p["r1"]   # (a lookup alone leaves a list in the cache: not an edit)
+    a, b = str(tmp_path / "calls.json"), str(tmp_path / "positions.json")
+    write_pandora_gene_calls(str(tmp_path), p, t, a, b)
+    assert open(a).read() == json.dumps(reads)
+    assert open(b).read() == json.dumps({r: [list(x) for x in v] for r, v in pos.items()})
