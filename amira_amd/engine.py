@@ -494,6 +494,8 @@ class Sequences:
             if isinstance(s, str):
                 ptrs[i] = as_utf8(s, C.byref(size))   # (the string's own bytes for ASCII text: nothing is copied)
                 lens[i] = size.value
+                if size.value != len(s):   # (positions index characters: a byte per character or nothing)
+                    raise TypeError("a read's sequence holds characters outside ASCII")
             else:
                 b = bytes(s)
                 keep.append(b)
