@@ -2396,8 +2396,14 @@ class GeneMerGraph(BubblePopping):
         native = (not self._host_edits and hasattr(Tree, "from_flat") and not os.environ.get("AMG_CLUSTER_PYTHON")
                   and _clustering.emulation_ok() and not self._any_read_name_ends_with("_reverse"))
         if native:
-            self._cluster_genes_native(list(listOfGenes), mean_node_coverage, cores, allele_counts, clustered_reads,
-                                       path_reads)
+            # a bounded number of genes at a time: what _cluster_genes_native holds per gene (its reads' node lists, the
+            # block plans, a flag per read) is then bounded too; the genes' results are entered in the caller's order
+            # either way (AMG_CLUSTER_GENES_PER_CALL: test switch)
+            genes = list(listOfGenes)
+            step = max(int(os.environ.get("AMG_CLUSTER_GENES_PER_CALL", "64")), 1)
+            for at in range(0, len(genes), step):
+                self._cluster_genes_native(genes[at:at + step], mean_node_coverage, cores, allele_counts,
+                                           clustered_reads, path_reads)
             listOfGenes = ()
         for geneOfInterest in listOfGenes:
             hashes = [n.__hash__() for n in self.get_nodes_containing(geneOfInterest)]

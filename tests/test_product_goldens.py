@@ -37,6 +37,13 @@ def test_product_matches_reference(name):
     assert got == GOLD[name]
 
 
+@pytest.mark.parametrize("name", ["planted_small", "planted_dense_k5"])
+def test_clustering_one_gene_per_native_call(name, monkeypatch):
+    """read-path clustering takes the genes of interest a bounded number at a time (64): one at a time gives the same"""
+    monkeypatch.setenv("AMG_CLUSTER_GENES_PER_CALL", "1")
+    assert run_case_seed0("product", name) == GOLD[name]
+
+
 def test_reference_api_surface():
     """spot checks in the style of the reference's own unit tests (tests/test_gene_mer_graph.py)."""
     import amira_amd
