@@ -1296,6 +1296,14 @@ class GeneMerGraph(BubblePopping):
             self._read_ids_arr = np.asarray(self._read_ids, dtype=object)
         return self._read_ids_arr
 
+    def _names_of_rows(self, rows):
+        """read names of a few rows (an int array), in that order: straight out of the list while the rows are few —
+        an object array of a million names costs more to make than a few thousand lookups"""
+        if getattr(self, "_read_ids_arr", None) is None and 8 * len(rows) < len(self._read_ids):
+            ids = self._read_ids
+            return [ids[i] for i in rows.tolist()]
+        return self._read_ids_array()[rows].tolist()
+
     def correct_single_read(self, read_id, readNodes, fastq_data):
         """host twin of one read of the device correction (:1136-1151), for callers that correct a
         single read by hand; correct_reads runs all of them on the device"""
@@ -2098,7 +2106,7 @@ class GeneMerGraph(BubblePopping):
             which = np.concatenate([np.zeros(len(chosen[0][0]), np.int8), np.ones(len(chosen[1][0]), np.int8)])
             order = np.argsort(rows, kind="stable")   # read order == dict order of _reads
             ro, so, wo = rows[order], starts[order], which[order]
-            rids = self._read_ids_array()[ro].tolist()
+            rids = self._names_of_rows(ro)
             if rids:
                 path_reads.setdefault(named, set()).update(rids)
             pos = self._genePositions
@@ -2253,7 +2261,6 @@ class GeneMerGraph(BubblePopping):
         the reference's set — and the rows come out of the node -> reads lists themselves, not out of a name -> row
         table of the whole read set"""
         v = self._v()
-        names_of = self._read_ids_array()
         node_ids = [i for i in node_ids if v.alive[i]]
         # the reads of these few nodes by one batched device search over the per-window node ids (k_match with
         # one-node patterns: hits ordered by node, read, position) — not the node -> reads lists of every node
@@ -2277,7 +2284,7 @@ class GeneMerGraph(BubblePopping):
         first_at = np.empty(int(seq.max()) + 1, np.int64)
         first_at[seq[::-1]] = at[::-1]                  # (written back to front: the first occurrence is what stays)
         order = seq[first_at[seq] == at]                # distinct rows in the order they first appear
-        names = names_of[order].tolist()
+        names = self._names_of_rows(order)
         reads.update(names)
         row_of = dict(zip(names, order.tolist()))
         self._known_rows.update(row_of)
