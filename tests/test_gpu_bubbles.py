@@ -200,3 +200,45 @@ def test_sketch_calls_too_big_for_one_go_are_split(monkeypatch):
             cap //= 2
     monkeypatch.delenv("AMG_TEST_SKETCH_PAIRS", raising=False)
     assert split > 0 or not starts
+
+
+def test_long_sequences_cross_the_upload_buffers():
+    """amg_seqs_create sends the bases through two 32 MB pinned buffers that take turns: segments that straddle the
+    seams of the stream (and lie far into it) sketch as the same bases do on the host"""
+    from amira_amd import Engine, tokenize
+    from amira_amd.engine import Sequences
+    rng = np.random.default_rng(7)
+    seam = 32 << 20
+    lengths = [seam + 4000, seam - 2500, 2 * seam + 77]            # seams fall inside read 0, read 1 | 2 and read 2
+    seqs = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)].tobytes().decode() for n in lengths]
+    genes = ["+g%d" % j for j in range(8)]
+    reads = {"r%d" % i: list(genes) for i in range(3)}
+    vocab, toks, offs, ids = tokenize(reads)
+    k = 3
+    # where the genes sit on each read: right across the seams of the concatenated stream
+    stream_start = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    around = [seam - 300, 2 * seam - 300 - int(stream_start[1]), 3 * seam - 300 - int(stream_start[2])]
+    gs = np.concatenate([np.arange(8, dtype=np.int64) * 80 + a for a in around])
+    ge = gs + 59
+    e = Engine(0)
+    s = Sequences(seqs, 0)
+    try:
+        e.set_reads(toks, offs, vocab.two_v)
+        e.set_positions(gs, ge, np.asarray(lengths, np.int64))
+        e.build(k)
+        D = e.graph_sizes()[0]
+        tok_node = e.read_node_ids()
+        size, common = e.path_sketch_overlaps(s, None, 11, 1, np.arange(D + 1, dtype=np.int64), np.arange(D, dtype=np.int32),
+                                              [0], [D - 1])
+        want = []
+        for node in range(D):
+            segs = []
+            for w in np.flatnonzero(tok_node == node).tolist():
+                r = int(np.searchsorted(offs, w, side="right") - 1)
+                segs.append(seqs[r][int(gs[w]):int(ge[w + k - 1]) + 1])
+            want.append(e.minhash(segs, [0] * len(segs), 11, 1)[0])
+        assert size.tolist() == [len(x) for x in want] and min(size.tolist()) > 100
+        assert common.tolist() == [len(want[0] & want[D - 1])]
+    finally:
+        s.close()
+        e.close()
