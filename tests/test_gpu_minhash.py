@@ -18,7 +18,8 @@ def _random_segments(rng, n, lo, hi):
     return segs
 
 
-@pytest.mark.parametrize("ksize,scaled", [(11, 10), (9, 1), (21, 3), (4, 1), (32, 2)])
+@pytest.mark.parametrize("ksize,scaled", [(11, 10), (9, 1), (21, 3), (4, 1), (32, 2),
+                                          (1, 1), (8, 1), (16, 1), (17, 1), (24, 2), (25, 1), (31, 1)])   # (word boundaries of amg_kmer.h)
 def test_device_sketch_equals_oracle(ksize, scaled):
     from amira_amd import Engine
     from amira_oracle.minhash import MinHash
