@@ -105,7 +105,7 @@ class BubblePopping:
 
     # ------------------------------------------------------------------ alignment / path helpers
     def calculate_path_coverage(self, path):
-        if not self._host_edits:   # (the coverages as the device holds them: no Node objects)
+        if not self._host_edits and not os.environ.get("AMG_BUBBLES_BY_OBJECTS"):   # (the coverages as the device holds them)
             v = self._v()
             coverage, id_of = v.arrays["nodes"]["coverage"], v.node_of_hash
             return statistics.mean([int(coverage[id_of[n[0]]]) for n in path[1:-1]])
@@ -391,7 +391,8 @@ class BubblePopping:
         return path_coverages
 
     def get_path_reads_to_correct(self, reads_to_correct, seen_nodes):
-        if not self._host_edits and seen_nodes:   # the nodes' reads straight from the device's node -> reads lists
+        if not self._host_edits and seen_nodes and not os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
+            # the nodes' reads straight from the device's node -> reads lists
             v = self._v()
             off, rows, ids, id_of = v.arrays["node_reads_off"], v.arrays["node_reads"], self._read_ids, v.node_of_hash
             for node_hash, operation in seen_nodes.items():

@@ -1538,7 +1538,7 @@ class GeneMerGraph(BubblePopping):
         fails at any step redo the whole path extending to the left."""
         if len(listOfNodes) == 1:
             return self.get_gene_mer_genes(self.get_node_by_hash(listOfNodes[0]))
-        if not self._host_edits:
+        if not self._host_edits and not os.environ.get("AMG_BUBBLES_BY_OBJECTS"):
             genes = self._genes_in_unitig_from_arrays(listOfNodes)
             if genes is not None:
                 return genes
