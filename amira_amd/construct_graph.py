@@ -1594,45 +1594,42 @@ class GeneMerGraph(BubblePopping):
             return None
         flip = self._vocab.two_v - 1
 
-        # per node, the first time a path runs over it: its live edges as (target, source direction), forward list
-        # first — what get_edge_hashes_between_nodes collects from — and its tokens
-        out_edges, tokens_of = a.setdefault("_out_edges", {}), a.setdefault("_tokens_of", {})
+        # per node, the first time a path runs over it: {target: (live edges to it, source direction of the first)} over
+        # its forward list, then its backward list — what get_edge_hashes_between_nodes collects from — and its tokens
+        # both ways
+        node_info = a.setdefault("_unitig_nodes", {})
 
-        def node_edges(i):
-            got = out_edges.get(i)
+        def info(i):
+            got = node_info.get(i)
             if got is None:
                 lo, hi = int(adj_off[2 * i]), int(adj_off[2 * i + 2])
                 es = adj_edge[lo:hi]
                 es = es[e_alive[es] != 0]
-                got = out_edges[i] = list(zip(e_tgt[es].tolist(), e_sdir[es].tolist()))
+                to = {}
+                for t, sd in zip(e_tgt[es].tolist(), e_sdir[es].tolist()):
+                    seen = to.get(t)
+                    to[t] = (1, sd) if seen is None else (seen[0] + 1, seen[1])
+                fw = n_tok[i].tolist()
+                got = node_info[i] = (to, fw, [flip - t for t in reversed(fw)])
             return got
 
-        def node_tokens(i):
-            got = tokens_of.get(i)
-            if got is None:
-                got = tokens_of[i] = n_tok[i].tolist()
-            return got
-
-        genes = None
+        infos = [info(i) for i in ids]
         k1 = self._kmerSize - 1
-        edges = [node_edges(i) for i in ids]
+        genes = None
         for n in range(len(ids) - 1):
-            src, tgt = ids[n], ids[n + 1]
-            there = [sd for t, sd in edges[n] if t == tgt]
-            if len(there) != 1 or sum(1 for t, _ in edges[n + 1] if t == src) != 1:
+            there, back = infos[n][0].get(ids[n + 1]), infos[n + 1][0].get(ids[n])
+            if there is None or back is None or there[0] != 1 or back[0] != 1:
                 return None
             if n == 0:
-                first = node_tokens(src)
-                genes = list(first) if there[0] == 1 else [flip - t for t in reversed(first)]
-            fw = node_tokens(tgt)
+                genes = list(infos[0][1] if there[1] == 1 else infos[0][2])
+            _, fw, bw = infos[n + 1]
             tail = genes[-k1:] if k1 else genes[0:]
             if fw[:-1] == tail:
                 genes.append(fw[-1])
-            else:
-                bw = [flip - t for t in reversed(fw)]
-                if bw[:-1] != tail:
-                    return None   # (the objects' way starts over, extending to the left)
+            elif bw[:-1] == tail:
                 genes.append(bw[-1])
+            else:
+                return None   # (the objects' way starts over, extending to the left)
         return self._vocab.decode(genes)
 
     # ------------------------------------------------------------------ GML output (:542-586, :873-909)
